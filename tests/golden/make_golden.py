@@ -1,0 +1,316 @@
+"""Generates tests/golden/*.npz by running the UNMODIFIED reference source.
+
+Build-container only: needs /root/reference.  Two kinds of vectors:
+
+  * `xcorr_np_*`: the reference's genuine pure-NumPy path
+    `flow_field.masked_xcorr(use_jax=False)` -- needs only import stubs;
+  * everything else: reference functions executed over the NumPy stand-in for
+    jax in `_refshim/refshim.py` ("reference over a stand-in", NOT XLA).
+
+Every file stores inputs AND expected outputs, so the tests never need the
+reference.  Run:  python tests/golden/make_golden.py
+"""
+import dataclasses
+import os
+import sys
+
+import numpy as np
+from scipy import ndimage
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '_refshim'))
+import refshim  # noqa: E402
+
+refshim.install()
+from sofima import flow_field as rff  # noqa: E402
+from sofima import mesh as rmesh  # noqa: E402
+from sofima import map_utils as rmap  # noqa: E402
+
+
+def save(name, **arrs):
+  path = os.path.join(HERE, name + '.npz')
+  np.savez_compressed(path, **arrs)
+  print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def em_like(rng, shape, sigma=2.0):
+  img = ndimage.gaussian_filter(rng.standard_normal(shape), sigma)
+  img = (img - img.min()) / (img.max() - img.min()) * 255
+  return img.astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
+def gen_xcorr_np():
+  rng = np.random.default_rng(11)
+  a = rng.standard_normal((3, 24, 24)).astype(np.float32) * 30
+  b = rng.standard_normal((3, 20, 20)).astype(np.float32) * 30
+  am = rng.random(a.shape) < 0.15
+  bm = rng.random(b.shape) < 0.15
+  a3 = rng.standard_normal((2, 8, 10, 12)).astype(np.float32) * 10
+  b3 = rng.standard_normal((2, 6, 10, 12)).astype(np.float32) * 10
+  am3 = rng.random(a3.shape) < 0.1
+  bm3 = rng.random(b3.shape) < 0.1
+  save(
+      'xcorr_np',
+      a=a, b=b, am=am, bm=bm, a3=a3, b3=b3, am3=am3, bm3=bm3,
+      unmasked=rff.masked_xcorr(a, b, use_jax=False),
+      masked=rff.masked_xcorr(a.copy(), b.copy(), am, bm, use_jax=False),
+      masked_prev_only=rff.masked_xcorr(a.copy(), b.copy(), am, None,
+                                        use_jax=False),
+      unmasked3=rff.masked_xcorr(a3, b3, use_jax=False, dim=3),
+      masked3=rff.masked_xcorr(a3.copy(), b3.copy(), am3, bm3, use_jax=False,
+                               dim=3),
+  )
+
+
+def gen_peaks():
+  rng = np.random.default_rng(12)
+  s = 31
+  imgs = np.zeros((8, s, s), np.float32)
+  # 0: two peaks 10 @ (10,10), 8 @ (20,20)
+  imgs[0, 10, 10] = 10
+  imgs[0, 20, 20] = 8
+  # 1: single peak exactly where image 0 has its 2nd peak (batch coupling)
+  imgs[1, 20, 20] = 5
+  # 2: single corner peak on a floor (window shift + zero padding)
+  imgs[2] = 0.1
+  imgs[2, 0, 0] = 3.1
+  # 3: all zero -> NaNs
+  # 4: negative-only surface
+  imgs[4] = -1.0
+  imgs[4, 15, 15] = -0.5
+  # 5..7: smooth random surfaces
+  for i in (5, 6, 7):
+    imgs[i] = ndimage.gaussian_filter(
+        rng.standard_normal((s, s)), 1.5).astype(np.float32)
+  out_all = np.array(rff._batched_peaks(imgs, (15, 15), 2, 0.5, 5))
+  out_0 = np.array(rff._batched_peaks(imgs[:1], (15, 15), 2, 0.5, 5))
+  out_r = np.array(rff._batched_peaks(imgs[5:], (15, 15), 2, 0.5, (2, 3)))
+  vol = ndimage.gaussian_filter(
+      rng.standard_normal((3, 9, 11, 13)), 1.0).astype(np.float32)
+  out_3d = np.array(rff._batched_peaks(vol, (4, 5, 6), 1, 0.5, (1, 2, 2)))
+  save('peaks', imgs=imgs, out_all=out_all, out_0=out_0, out_r=out_r,
+       vol=vol, out_3d=out_3d)
+
+
+def gen_flow():
+  rng = np.random.default_rng(13)
+  h, w, m = 192, 160, 12
+  base = em_like(rng, (h + 2 * m, w + 2 * m))
+  dy, dx = 3, -5
+  pre = base[m:m + h, m:m + w].copy()
+  post = base[m + dy:m + dy + h, m + dx:m + dx + w].copy()
+  calc = rff.JAXMaskedXCorrWithStatsCalculator()
+  out = {'pre': pre, 'post': post}
+  out['plain'] = calc.flow_field(pre, post, 48, 24, batch_size=8)
+
+  pre_mask = np.zeros((h, w), bool)
+  pre_mask[:70, :60] = True
+  pre_mask[100:130, 90:150] = rng.random((30, 60)) < 0.3
+  post_mask = np.zeros((h + 8, w + 8), bool)   # larger than the image
+  post_mask[150:, 100:] = True
+  post_mask[20:60, 80:120] = rng.random((40, 40)) < 0.2
+  out['pre_mask'] = pre_mask
+  out['post_mask'] = post_mask
+  out['masked'] = calc.flow_field(pre, post, 48, 24, pre_mask=pre_mask,
+                                  post_mask=post_mask, batch_size=8)
+  out['masksel'] = calc.flow_field(
+      pre, post, 48, 24, pre_mask=pre_mask, post_mask=post_mask,
+      mask_only_for_patch_selection=True, max_masked=0.5, batch_size=16)
+
+  out['postpatch'] = calc.flow_field(pre, post, 48, 24, batch_size=8,
+                                     post_patch_size=32)
+
+  sel = rng.random((7, 5)) < 0.6
+  out['sel'] = sel
+  out['selected'] = calc.flow_field(pre, post, (48, 32), (24, 16),
+                                    selection_mask=np.pad(sel, ((0, 0), (0, 4))),
+                                    batch_size=5)
+
+  # Targeting: a coarse field shifts where patches are taken from.
+  tg_pre = np.zeros((2, 4, 4), np.float32)
+  tg_pre[0] = 6.0
+  tg_pre[1] = -4.0
+  tg_pre[0, 0, 0] = np.nan
+  tg_post = np.full((2, 3, 3), 0.0, np.float32)
+  tg_post[0] = -3.0
+  tg_post[1] = 5.0
+  out['tg_pre'] = tg_pre
+  out['tg_post'] = tg_post
+  out['targeted'] = calc.flow_field(
+      pre, post, 48, 24, batch_size=8, pre_targeting_field=tg_pre,
+      pre_targeting_step=48, post_targeting_field=tg_post,
+      post_targeting_step=64)
+
+  calc_m = rff.JAXMaskedXCorrWithStatsCalculator(mean=120.0,
+                                                 peak_min_distance=3,
+                                                 peak_radius=(3, 4))
+  pre_f = pre.astype(np.float32) + rng.standard_normal(pre.shape).astype(
+      np.float32)
+  post_f = post.astype(np.float32)
+  out['pre_f'] = pre_f
+  out['post_f'] = post_f
+  out['float_mean'] = calc_m.flow_field(pre_f, post_f, 40, 20, batch_size=64)
+  save('flow2d', **out)
+
+  # 3-D
+  vol = em_like(rng, (24 + 6, 40 + 6, 40 + 6), sigma=1.5)
+  pre3 = vol[3:27, 3:43, 3:43].copy()
+  post3 = vol[2:26, 5:45, 2:42].copy()
+  f3 = calc.flow_field(pre3, post3, (16, 24, 24), 8, batch_size=4)
+  save('flow3d', pre=pre3, post=post3, plain=f3)
+
+
+# ---------------------------------------------------------------------------
+def cfg_dict(cfg):
+  return {k: (list(v) if isinstance(v, tuple) else v)
+          for k, v in dataclasses.asdict(cfg).items()}
+
+
+def gen_mesh():
+  import json
+  rng = np.random.default_rng(14)
+  out = {}
+  x2 = (rng.standard_normal((2, 2, 12, 14)) * 3).astype(np.float32)
+  out['x2'] = x2
+  for poo in (False, True):
+    out[f'f2_{int(poo)}'] = np.array(
+        rmesh.inplane_force(x2, 0.1, (40.0, 30.0), poo))
+  x3 = (rng.standard_normal((3, 6, 7, 8)) * 2).astype(np.float32)
+  x3b = (rng.standard_normal((3, 2, 5, 6, 7)) * 2).astype(np.float32)
+  out['x3'] = x3
+  out['x3b'] = x3b
+  for poo in (False, True):
+    out[f'f3_{int(poo)}'] = np.array(
+        rmesh.elastic_mesh_3d(x3, 0.1, (20.0, 25.0, 14.0), poo))
+    out[f'f3b_{int(poo)}'] = np.array(
+        rmesh.elastic_mesh_3d(x3b, 0.05, 16.0, poo))
+  planar = ((1, 0, 0), (0, 1, 0), (1, 1, 0), (-1, 1, 0))
+  out['f3_planar'] = np.array(
+      rmesh.elastic_mesh_3d(x3, 0.1, (20.0, 25.0, 14.0), False, links=planar))
+  # A fold: neighbouring nodes swapped, exercises sign factors and nan_to_num.
+  xf = np.zeros((2, 1, 6, 6), np.float32)
+  xf[0, 0, 2, 2] = 45.0
+  xf[1, 0, 3, 3] = -41.0
+  xf[0, 0, 4, 1] = -40.0   # coincides with left neighbour -> zero length
+  out['xf'] = xf
+  for poo in (False, True):
+    out[f'ff_{int(poo)}'] = np.array(
+        rmesh.inplane_force(xf, 0.1, (40.0, 40.0), poo))
+  save('mesh_force', **out)
+
+  out = {}
+  cfgs = {}
+  x0 = (rng.standard_normal((2, 2, 20, 24)) * 2).astype(np.float32)
+  prev = (rng.standard_normal((2, 2, 20, 24)) * 4).astype(np.float32)
+  prev[:, 0, 3:6, 4:9] = np.nan
+  v0 = np.zeros_like(x0)
+  out['x0'] = x0
+  out['prev'] = prev
+
+  def run_vv(tag, cfg, cap, prev_=prev, x_=x0, force=rmesh.inplane_force,
+             **kw):
+    st = rmesh.velocity_verlet(x_.copy(), np.zeros_like(x_), prev_, cfg,
+                               force_cap=cap, mesh_force=force, **kw)
+    cfgs[tag] = cfg_dict(cfg)
+    cfgs[tag]['_force_cap'] = cap
+    for i, name in enumerate(('x', 'v', 'a')):
+      out[f'{tag}_{name}'] = np.array(st[i], np.float32)
+    if len(st) > 3:
+      out[f'{tag}_scal'] = np.array([float(s) for s in st[3:]], np.float64)
+
+  base = dict(dt=0.01, gamma=0.0, k0=0.05, k=0.1, stride=(20.0, 20.0),
+              max_iters=1000, stop_v_max=0.001)
+  for n in (1, 10, 100):
+    run_vv(f'fire{n}', rmesh.IntegrationConfig(num_iters=n, **base), 1e6)
+  run_vv('fire_cap', rmesh.IntegrationConfig(
+      num_iters=60, start_cap=0.02, final_cap=1.0, cap_upscale_every=7,
+      prefer_orig_order=True, dt_max=30.0, **base), 0.02)
+  run_vv('fire_drift', rmesh.IntegrationConfig(
+      num_iters=25, remove_drift=True, **base), 1e6)
+  dbase = dict(base)
+  dbase['gamma'] = 0.5
+  run_vv('damped10', rmesh.IntegrationConfig(num_iters=10, fire=False, **dbase),
+         1e6)
+  run_vv('noprev10', rmesh.IntegrationConfig(num_iters=10, **base), 1e6,
+         prev_=None)
+
+  x30 = (rng.standard_normal((3, 5, 8, 9)) * 1.5).astype(np.float32)
+  prev3 = (rng.standard_normal((3, 5, 8, 9)) * 2).astype(np.float32)
+  out['x30'] = x30
+  out['prev3'] = prev3
+  b3 = dict(base)
+  b3['stride'] = (20.0, 20.0, 12.0)
+  run_vv('fire3d_20', rmesh.IntegrationConfig(num_iters=20, **b3), 1e6,
+         prev_=prev3, x_=x30, force=rmesh.elastic_mesh_3d)
+  out['cfgs'] = np.array(json.dumps(cfgs))
+  save('mesh_vv', **out)
+
+  # relax_mesh end-to-end
+  out = {}
+  cfgs = {}
+  xr = np.zeros((2, 1, 30, 30))
+  xr[0, 0, 10:20, 6] = 3
+  xr[0, 0, 10:20, 24] = -4
+  xr[1, 0, 20, 6:12] = 2
+  out['xr'] = xr
+  cfg = rmesh.IntegrationConfig(dt=0.01, gamma=0.0, k0=0.1, k=0.1,
+                                stride=(10, 10), num_iters=100,
+                                max_iters=10000, stop_v_max=0.001, fire=True)
+  xs, ek, t = rmesh.relax_mesh(xr.copy(), np.zeros_like(xr), cfg)
+  cfgs['fire'] = cfg_dict(cfg)
+  out['fire_x'] = np.array(xs, np.float32)
+  out['fire_ekin'] = np.array(ek)
+  out['fire_t'] = np.array(t)
+
+  cfg = rmesh.IntegrationConfig(
+      dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(40, 40), num_iters=50,
+      max_iters=400, stop_v_max=0.005, dt_max=1000, start_cap=0.01,
+      final_cap=10, prefer_orig_order=True)
+  xe = np.zeros((2, 2, 20, 24), np.float32)
+  pe = (rng.standard_normal((2, 2, 20, 24)) * 5).astype(np.float32)
+  pe = ndimage.gaussian_filter(pe, (0, 0, 2, 2)).astype(np.float32) * 4
+  pe[:, 1, :4, :5] = np.nan
+  out['xe'] = xe
+  out['pe'] = pe
+  xs, ek, t = rmesh.relax_mesh(xe.copy(), pe, cfg)
+  cfgs['em2d'] = cfg_dict(cfg)
+  out['em2d_x'] = np.array(xs, np.float32)
+  out['em2d_ekin'] = np.array(ek)
+  out['em2d_t'] = np.array(t)
+  out['cfgs'] = np.array(json.dumps(cfgs))
+  save('mesh_relax', **out)
+
+
+def gen_maps():
+  rng = np.random.default_rng(15)
+  m1 = (rng.standard_normal((2, 2, 9, 11)) * 6).astype(np.float32)
+  m2 = (rng.standard_normal((2, 2, 12, 10)) * 6).astype(np.float32)
+  m1[:, 0, 2, 3] = np.nan
+  m2[:, 1, 5:7, 4] = np.nan
+  out = dict(m1=m1, m2=m2)
+  for mode in ('nearest', 'constant'):
+    out[f'c2_{mode}'] = np.array(rmap.compose_maps_fast(
+        m1, (0, 10, 20), (16, 16), m2, (0, -5, 8), (20, 20), mode=mode))
+  n1 = (rng.standard_normal((3, 4, 5, 6)) * 3).astype(np.float32)
+  n2 = (rng.standard_normal((3, 5, 6, 7)) * 3).astype(np.float32)
+  out['n1'] = n1
+  out['n2'] = n2
+  for mode in ('nearest', 'constant'):
+    out[f'c3_{mode}'] = np.array(rmap.compose_maps_fast(
+        n1, (1, 2, 3), (8, 10, 10), n2, (0, 1, 2), (8, 10, 10), mode=mode))
+  save('compose_maps', **out)
+
+
+if __name__ == '__main__':
+  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps']
+  if 'xcorr' in which:
+    gen_xcorr_np()
+  if 'peaks' in which:
+    gen_peaks()
+  if 'flow' in which:
+    gen_flow()
+  if 'mesh' in which:
+    gen_mesh()
+  if 'maps' in which:
+    gen_maps()
