@@ -1,0 +1,188 @@
+/* sofima_amd.h -- C ABI of libsofima_amd.so (MI355X / gfx950).
+ *
+ * The library is the drop-in device back end for the two compute cores of
+ * SOFIMA.  The reference has no FFI: its "operator API" is the Python
+ * signatures of flow_field.py / mesh.py.  Each entry point below names the
+ * reference function (file:line under /root/reference) whose device work it
+ * replaces; sofima_amd/flow_field.py and sofima_amd/mesh.py bind them through
+ * ctypes with exactly the reference's Python signatures.
+ *
+ * Conventions
+ *   - plain C types only; every buffer is CALLER-OWNED device memory (HIP
+ *     pointers, e.g. torch.Tensor.data_ptr()); the library never allocates or
+ *     frees device memory -- scratch space is passed in as `workspace`;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream).  Entry points do not synchronise unless stated;
+ *   - return 0 on success, a negative SFM_ERR_* otherwise; the message is in
+ *     sfm_last_error() (thread-local).  No C++ exception crosses the boundary;
+ *   - image / mask / surface arrays are row-major [z,]y,x; mesh arrays are
+ *     [C, batch, z, y, x] with C = 2|3 vector components in x,y[,z] order;
+ *   - shapes, sizes and starts are given in [z]yx order padded to 3 entries:
+ *     for 2-D data entry 0 is 1 (sizes) or 0 (starts).
+ */
+#ifndef SOFIMA_AMD_H_
+#define SOFIMA_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_ABI_VERSION 1
+
+#define SFM_OK 0
+#define SFM_ERR_INVALID (-1)     /* bad argument / unsupported combination */
+#define SFM_ERR_HIP (-2)         /* a HIP runtime call failed              */
+#define SFM_ERR_WORKSPACE (-3)   /* workspace missing or too small         */
+#define SFM_ERR_NO_DEVICE (-4)   /* no gfx950 device visible               */
+
+#define SFM_DTYPE_U8 0
+#define SFM_DTYPE_F32 1
+
+/* Which correlation kernel family to use. AUTO picks MFMA_I8 whenever the
+ * inputs qualify (uint8 images, 2-D, no masks in the correlation) and DIRECT
+ * otherwise. */
+#define SFM_XCORR_AUTO 0
+#define SFM_XCORR_DIRECT 1    /* f32 shift-by-shift kernel, any dtype/dim/mask */
+#define SFM_XCORR_MFMA_I8 2   /* int8 MFMA Toeplitz kernel                   */
+
+int sfm_version(void);
+const char* sfm_last_error(void);
+/* Number of visible HIP devices (0 and SFM_OK when none). */
+int sfm_device_count(int* count);
+
+/* ------------------------------------------------------------------------
+ * Patch cross-correlation + peak statistics for ONE batch.
+ * Replaces flow_field.batched_xcorr_peaks (flow_field.py:374-441) =
+ * _batched_xcorr (:278-371) + masked_xcorr(use_jax=True) (:36-156) +
+ * _batched_peaks (:205-275) + _peak_stats (:178-202).
+ * ---------------------------------------------------------------------- */
+typedef struct SfmXcorrDesc {
+  int32_t ndim;                 /* 2 or 3                                    */
+  int32_t dtype;                /* SFM_DTYPE_* of pre/post image             */
+  const void* pre_image;        /* device, [z,]y,x                           */
+  const void* post_image;
+  const uint8_t* pre_mask;      /* device bool bytes (1 = invalid) or NULL   */
+  const uint8_t* post_mask;
+  int32_t pre_shape[3];         /* [z]yx, entry 0 = 1 for 2-D                */
+  int32_t post_shape[3];
+  int32_t pre_mask_shape[3];    /* masks may differ in shape from the images */
+  int32_t post_mask_shape[3];
+  int32_t patch[3];             /* pre patch size  P                         */
+  int32_t post_patch[3];        /* post patch size Q (<= P)                  */
+  const int32_t* pre_starts;    /* device [batch, ndim] [z]yx, row-major     */
+  const int32_t* post_starts;   /* device [batch, ndim]                      */
+  int32_t batch;                /* rows in the starts arrays (incl. padding) */
+  int32_t use_mean;             /* 0: subtract per-patch mean; 1: use `mean` */
+  float mean;
+  int32_t min_distance;         /* max-filter half width (reference: 2)      */
+  float threshold_rel;          /* reference: 0.5                            */
+  int32_t peak_radius[3];       /* [z]yx sharpness window radius             */
+  int32_t method;               /* SFM_XCORR_*                               */
+  void* workspace;              /* device scratch                            */
+  size_t workspace_bytes;
+  void* stream;
+} SfmXcorrDesc;
+
+/* Scratch bytes sfm_xcorr_peaks / sfm_xcorr_surface need for this desc. */
+size_t sfm_xcorr_workspace_bytes(const SfmXcorrDesc* desc);
+
+/* peaks: device float [batch, ndim + 2] = x, y[, z], sharpness, ratio.
+ * The batch-coupled behaviours of the reference (second-peak suppression set,
+ * batch-global masked-NCC tolerances) are computed over all `batch` rows. */
+int sfm_xcorr_peaks(const SfmXcorrDesc* desc, float* peaks);
+
+/* surface: device float [batch, *(P + Q - 1)]; the array masked_xcorr returns
+ * for the mean-subtracted patches (flow_field.py:361-371). */
+int sfm_xcorr_surface(const SfmXcorrDesc* desc, float* surface);
+
+/* Stand-alone peak statistics, replaces _batched_peaks (flow_field.py:205-275)
+ * for a caller-provided batch of surfaces. */
+typedef struct SfmPeaksDesc {
+  int32_t ndim;
+  int32_t batch;
+  int32_t shape[3];             /* surface [z]yx                             */
+  float center_offset[3];       /* [z]yx                                     */
+  int32_t min_distance;
+  float threshold_rel;
+  int32_t peak_radius[3];
+  const float* surface;         /* device [batch, *shape]                    */
+  void* workspace;
+  size_t workspace_bytes;
+  void* stream;
+} SfmPeaksDesc;
+
+size_t sfm_peaks_workspace_bytes(const SfmPeaksDesc* desc);
+int sfm_peaks(const SfmPeaksDesc* desc, float* peaks);
+
+/* ------------------------------------------------------------------------
+ * Spring mesh.
+ * ---------------------------------------------------------------------- */
+#define SFM_MESH_MAX_LINKS 13
+
+typedef struct SfmMeshDesc {
+  int32_t ncomp;                /* 2: inplane_force (mesh.py:42-169)
+                                   3: elastic_mesh_3d (mesh.py:192-279)      */
+  int32_t shape[4];             /* batch, z, y, x  (ncomp 2: batch = 1 and z
+                                   slices are independent)                   */
+  /* Configuration scalars are doubles so that host-side constant folding
+     matches the reference's Python-float arithmetic before rounding to f32. */
+  double stride[3];             /* x, y[, z] node spacing                    */
+  double k;                     /* intra-mesh spring constant                */
+  double k0;                    /* spring constant to `prev`                 */
+  int32_t prefer_orig_order;
+  int32_t n_links;              /* ncomp 3 only; 0 = the 13 default links    */
+  int32_t links[SFM_MESH_MAX_LINKS][3];  /* xyz directions, |v| <= 1         */
+  /* integrator (mesh.IntegrationConfig, mesh.py:282-338) */
+  double dt;
+  double gamma;
+  int32_t num_iters;
+  int32_t fire;
+  double f_alpha, f_inc, f_dec, alpha0;  /* alpha0 = config.alpha            */
+  int32_t n_min;
+  double dt_max;                /* in units of dt, like the reference        */
+  double final_cap;
+  double cap_scale;
+  int32_t cap_upscale_every;
+  int32_t remove_drift;
+  /* state, device float [ncomp, batch, z, y, x] */
+  float* x;
+  float* v;
+  float* a;
+  const float* prev;            /* or NULL                                   */
+  void* workspace;
+  size_t workspace_bytes;
+  void* stream;
+} SfmMeshDesc;
+
+/* FIRE scalars carried between chunks (mesh.py:449, :513, :589). */
+typedef struct SfmFireState {
+  float dt;
+  float alpha;
+  int32_t n_pos;
+  float cap;
+} SfmFireState;
+
+typedef struct SfmChunkStats {
+  float e_kin;                  /* sum |v|^2   (mesh.py:584-585)             */
+  float v_max;                  /* max |v|     (mesh.py:586)                 */
+} SfmChunkStats;
+
+size_t sfm_mesh_workspace_bytes(const SfmMeshDesc* desc);
+
+/* out = mesh_force(x): device float, same shape as x.  Uses desc->x only. */
+int sfm_mesh_force(const SfmMeshDesc* desc, float* out);
+
+/* One call of mesh.velocity_verlet (mesh.py:371-521): a = F(x); num_iters
+ * damped-Verlet or FIRE steps on x, v, a in place; `fire` is in/out (n_pos
+ * restarts at 0 like the reference); stats are copied back to the host, which
+ * synchronises the stream. */
+int sfm_mesh_relax_chunk(const SfmMeshDesc* desc, SfmFireState* fire,
+                         SfmChunkStats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* SOFIMA_AMD_H_ */

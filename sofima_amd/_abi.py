@@ -1,0 +1,181 @@
+"""ctypes binding of libsofima_amd.so (include/sofima_amd.h).
+
+PyTorch-ROCm tensors are used only as the owner of device memory and streams;
+every kernel is reached through the C ABI.  There is no CPU fallback: if the
+library is missing or no GPU is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import _build
+
+_lib = None
+_lock = threading.Lock()
+
+SFM_OK = 0
+DTYPE_U8 = 0
+DTYPE_F32 = 1
+XCORR_AUTO = 0
+XCORR_DIRECT = 1
+XCORR_MFMA_I8 = 2
+MAX_LINKS = 13
+
+i32 = C.c_int32
+
+
+class SfmXcorrDesc(C.Structure):
+  _fields_ = [
+      ('ndim', i32),
+      ('dtype', i32),
+      ('pre_image', C.c_void_p),
+      ('post_image', C.c_void_p),
+      ('pre_mask', C.c_void_p),
+      ('post_mask', C.c_void_p),
+      ('pre_shape', i32 * 3),
+      ('post_shape', i32 * 3),
+      ('pre_mask_shape', i32 * 3),
+      ('post_mask_shape', i32 * 3),
+      ('patch', i32 * 3),
+      ('post_patch', i32 * 3),
+      ('pre_starts', C.c_void_p),
+      ('post_starts', C.c_void_p),
+      ('batch', i32),
+      ('use_mean', i32),
+      ('mean', C.c_float),
+      ('min_distance', i32),
+      ('threshold_rel', C.c_float),
+      ('peak_radius', i32 * 3),
+      ('method', i32),
+      ('workspace', C.c_void_p),
+      ('workspace_bytes', C.c_size_t),
+      ('stream', C.c_void_p),
+  ]
+
+
+class SfmPeaksDesc(C.Structure):
+  _fields_ = [
+      ('ndim', i32),
+      ('batch', i32),
+      ('shape', i32 * 3),
+      ('center_offset', C.c_float * 3),
+      ('min_distance', i32),
+      ('threshold_rel', C.c_float),
+      ('peak_radius', i32 * 3),
+      ('surface', C.c_void_p),
+      ('workspace', C.c_void_p),
+      ('workspace_bytes', C.c_size_t),
+      ('stream', C.c_void_p),
+  ]
+
+
+class SfmMeshDesc(C.Structure):
+  _fields_ = [
+      ('ncomp', i32),
+      ('shape', i32 * 4),
+      ('stride', C.c_double * 3),
+      ('k', C.c_double),
+      ('k0', C.c_double),
+      ('prefer_orig_order', i32),
+      ('n_links', i32),
+      ('links', (i32 * 3) * MAX_LINKS),
+      ('dt', C.c_double),
+      ('gamma', C.c_double),
+      ('num_iters', i32),
+      ('fire', i32),
+      ('f_alpha', C.c_double),
+      ('f_inc', C.c_double),
+      ('f_dec', C.c_double),
+      ('alpha0', C.c_double),
+      ('n_min', i32),
+      ('dt_max', C.c_double),
+      ('final_cap', C.c_double),
+      ('cap_scale', C.c_double),
+      ('cap_upscale_every', i32),
+      ('remove_drift', i32),
+      ('x', C.c_void_p),
+      ('v', C.c_void_p),
+      ('a', C.c_void_p),
+      ('prev', C.c_void_p),
+      ('workspace', C.c_void_p),
+      ('workspace_bytes', C.c_size_t),
+      ('stream', C.c_void_p),
+  ]
+
+
+class SfmFireState(C.Structure):
+  _fields_ = [('dt', C.c_float), ('alpha', C.c_float), ('n_pos', i32),
+              ('cap', C.c_float)]
+
+
+class SfmChunkStats(C.Structure):
+  _fields_ = [('e_kin', C.c_float), ('v_max', C.c_float)]
+
+
+# name -> (restype, argtypes); mirrors include/sofima_amd.h one to one.
+SIGNATURES = {
+    'sfm_version': (C.c_int, []),
+    'sfm_last_error': (C.c_char_p, []),
+    'sfm_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'sfm_xcorr_workspace_bytes': (C.c_size_t, [C.POINTER(SfmXcorrDesc)]),
+    'sfm_xcorr_peaks': (C.c_int, [C.POINTER(SfmXcorrDesc), C.c_void_p]),
+    'sfm_xcorr_surface': (C.c_int, [C.POINTER(SfmXcorrDesc), C.c_void_p]),
+    'sfm_peaks_workspace_bytes': (C.c_size_t, [C.POINTER(SfmPeaksDesc)]),
+    'sfm_peaks': (C.c_int, [C.POINTER(SfmPeaksDesc), C.c_void_p]),
+    'sfm_mesh_workspace_bytes': (C.c_size_t, [C.POINTER(SfmMeshDesc)]),
+    'sfm_mesh_force': (C.c_int, [C.POINTER(SfmMeshDesc), C.c_void_p]),
+    'sfm_mesh_relax_chunk': (C.c_int, [C.POINTER(SfmMeshDesc),
+                                       C.POINTER(SfmFireState),
+                                       C.POINTER(SfmChunkStats)]),
+}
+
+
+class SofimaAmdError(RuntimeError):
+  """A C-ABI call returned an error code."""
+
+
+def lib_path() -> str:
+  return os.environ.get('SOFIMA_AMD_LIB', _build.LIB_PATH)
+
+
+def load():
+  """Loads libsofima_amd.so; raises if it has not been built."""
+  global _lib
+  with _lock:
+    if _lib is not None:
+      return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+      raise SofimaAmdError(
+          f'{path} not found: build it with `python -m sofima_amd._build` '
+          '(or __graft_entry__.build()). There is no CPU fallback.')
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(lib, name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = lib
+    return _lib
+
+
+def check(rc: int):
+  if rc != SFM_OK:
+    msg = load().sfm_last_error().decode('utf-8', 'replace')
+    raise SofimaAmdError(f'libsofima_amd error {rc}: {msg}')
+
+
+def device_count() -> int:
+  n = C.c_int(0)
+  check(load().sfm_device_count(C.byref(n)))
+  return n.value
+
+
+def require_gpu():
+  """Fails loudly when the HIP path cannot run (no silent fallback)."""
+  import torch
+  if not torch.cuda.is_available() or device_count() < 1:
+    raise SofimaAmdError(
+        'sofima_amd needs an MI355X (gfx950) GPU: no HIP device is visible and '
+        'there is no CPU fallback.')

@@ -1,0 +1,70 @@
+"""Builds libsofima_amd.so (HIP, gfx950) and the C oracle helpers in-tree."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, 'csrc')
+LIB_DIR = os.path.join(PKG_DIR, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libsofima_amd.so')
+OBJ_DIR = os.path.join(PKG_DIR, 'build')
+
+# Translation units and their extra flags.  The mesh kernels follow the
+# reference's f32 operation order, so FMA contraction is disabled there.
+SOURCES = {
+    'sfm_core.hip': [],
+    'sfm_mesh.hip': ['-ffp-contract=off'],
+    'sfm_xcorr.hip': [],
+    'sfm_xcorr_mfma.hip': [],
+}
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+          '-Wno-unused-result']
+
+
+def _hipcc() -> str:
+  exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+  if not os.path.exists(exe):
+    raise RuntimeError('hipcc not found; cannot build libsofima_amd.so')
+  return exe
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+  if not os.path.exists(target):
+    return True
+  t = os.path.getmtime(target)
+  return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+  """Compiles every HIP translation unit for gfx950 and links the library."""
+  os.makedirs(LIB_DIR, exist_ok=True)
+  os.makedirs(OBJ_DIR, exist_ok=True)
+  headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+             if f.endswith('.h')]
+  headers.append(os.path.join(PKG_DIR, '..', 'include', 'sofima_amd.h'))
+  hipcc = _hipcc()
+  objs = []
+  relink = force
+  for src, extra in SOURCES.items():
+    src_path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ_DIR, src + '.o')
+    objs.append(obj)
+    if force or _stale(obj, [src_path] + headers):
+      cmd = [hipcc] + COMMON + extra + ['-c', src_path, '-o', obj]
+      if verbose:
+        print(' '.join(cmd))
+      subprocess.run(cmd, check=True)
+      relink = True
+  if relink or _stale(LIB_PATH, objs):
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH
+           ] + objs
+    if verbose:
+      print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+  return LIB_PATH
+
+
+if __name__ == '__main__':
+  print(build(force=False, verbose=True))

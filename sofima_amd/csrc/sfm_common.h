@@ -1,0 +1,47 @@
+// Shared host-side helpers for libsofima_amd.so (gfx950 only).
+#ifndef SFM_COMMON_H_
+#define SFM_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/sofima_amd.h"
+
+namespace sfm {
+
+// Thread-local error text behind sfm_last_error().
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+#define SFM_HIP_CHECK(expr)                                                  \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess)                                                    \
+      return ::sfm::fail(SFM_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
+                         hipGetErrorString(e_), __FILE__, __LINE__);         \
+  } while (0)
+
+#define SFM_LAUNCH_CHECK() SFM_HIP_CHECK(hipGetLastError())
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Carves aligned sub-buffers out of the caller's workspace.
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+  size_t total() const { return align_up(off, 256); }
+};
+
+}  // namespace sfm
+
+#endif  // SFM_COMMON_H_

@@ -1,0 +1,651 @@
+// Elastic spring-mesh relaxer for gfx950.
+//
+// Device replacement for mesh.py of the reference:
+//   inplane_force     (mesh.py:42-169)   -> link stencil, 4 in-plane families
+//   elastic_mesh_3d   (mesh.py:192-279)  -> link stencil, up to 13 families
+//   velocity_verlet   (mesh.py:371-521)  -> one "advance" + one "integrate"
+//                                           kernel per step, FIRE scalars kept
+//                                           on the device
+//
+// Data layout: state arrays x, v, a, prev are float [C, B, Z, Y, X] (C = 2|3
+// vector components, x fastest).  One thread owns one node (all C components)
+// and gathers its neighbours; every spring is evaluated by both of its end
+// nodes, so there are no atomics and results are run-to-run deterministic.
+// This translation unit is compiled with -ffp-contract=off so that the f32
+// arithmetic follows the reference's operation order without FMA fusion.
+//
+// Step structure (FIRE; the damped-Verlet path skips the scalar logic):
+//   advance(k):   [k > 0] every block reduces the per-block partials of step
+//                 k-1 in a fixed order -> power, drift sums -> updates
+//                 (dt, alpha, n_pos, cap), gates v, removes drift;
+//                 then x += dt v + dt^2/2 a
+//   integrate(k): a' = F(x) + clip(-k0 (x - prev)); v = VV(v, a, a');
+//                 partial power = sum a'.v; FIRE velocity mixing;
+//                 per-block partials -> global
+//   finish:       the pending gate / drift / scalar update of the last step,
+//                 then e_kin and v_max.
+#include "sfm_common.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 1024;
+constexpr int kNP = 8;  // partials per block: power, sx[3], sv[3], pad
+
+struct MeshParams {
+  int ncomp;
+  int B, Z, Y, X;
+  long long N;  // nodes = B*Z*Y*X
+  int n_links;
+  int order2d;  // reference summation order of inplane_force
+  int dir[SFM_MESH_MAX_LINKS][3];     // xyz
+  float rest[SFM_MESH_MAX_LINKS][3];  // xyz rest vector
+  float neg_k[SFM_MESH_MAX_LINKS];    // -k_eff
+  int prefer;
+  float neg_k0;
+  int has_prev;
+  // integrator
+  int fire;
+  int remove_drift;
+  float gamma;
+  float vv_dt;  // damped Verlet: fixed dt
+  float f_alpha, f_inc, f_dec, alpha0;
+  int n_min;
+  float dt_cap;
+  float final_cap, cap_scale;
+  int cap_every;
+  float n_f;  // N as the f32 mean divisor (mean = sum / N)
+};
+
+struct Scalars {
+  float dt, alpha;
+  int n_pos;
+  float cap;
+  float gate;
+  float mx[3];
+  float mv[3];
+};
+
+__device__ __forceinline__ float vec_len(const float* d, int c) {
+  float s = d[0] * d[0] + d[1] * d[1];
+  if (c == 3) s = s + d[2] * d[2];
+  return sqrtf(s);
+}
+
+// Force of one spring given d = x_far - x_near + rest (mesh.py:107-117,
+// 252-270).  Non-finite components become 0 like nan_to_num(posinf=0,
+// neginf=0).
+template <int C>
+__device__ __forceinline__ void spring(const float* d, const float* rest,
+                                       const int* dir, float neg_k, int prefer,
+                                       float* f) {
+  const float l = vec_len(d, C);
+  const float l0 = vec_len(rest, C);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float num = l0;
+    if (prefer && dir[c] != 0) {
+      const float sg = d[c] > 0.f ? 1.f : (d[c] < 0.f ? -1.f : 0.f);
+      num = l0 * (static_cast<float>(dir[c]) * sg);
+    }
+    const float t = num / l;
+    const float u = 1.0f - t;
+    float v = (neg_k * u) * d[c];
+    if (!isfinite(v)) v = 0.f;
+    f[c] = v;
+  }
+}
+
+template <int C>
+__device__ void node_force(const float* __restrict__ x, const MeshParams& p,
+                           long long n, float* out) {
+  const int xi = static_cast<int>(n % p.X);
+  long long r = n / p.X;
+  const int yi = static_cast<int>(r % p.Y);
+  r /= p.Y;
+  const int zi = static_cast<int>(r % p.Z);
+  float self[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) self[c] = x[c * p.N + n];
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+
+  auto far_side = [&](int L, float* f) -> bool {
+    // This node is the far end; the near end is node - dir.
+    const int nx = xi - p.dir[L][0], ny = yi - p.dir[L][1],
+              nz = zi - p.dir[L][2];
+    if (nx < 0 || nx >= p.X || ny < 0 || ny >= p.Y || nz < 0 || nz >= p.Z)
+      return false;
+    const long long m =
+        n - p.dir[L][0] - (long long)p.dir[L][1] * p.X -
+        (long long)p.dir[L][2] * p.X * p.Y;
+    float d[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) d[c] = self[c] - x[c * p.N + m] + p.rest[L][c];
+    spring<C>(d, p.rest[L], p.dir[L], p.neg_k[L], p.prefer, f);
+    return true;
+  };
+  auto near_side = [&](int L, float* f) -> bool {
+    const int nx = xi + p.dir[L][0], ny = yi + p.dir[L][1],
+              nz = zi + p.dir[L][2];
+    if (nx < 0 || nx >= p.X || ny < 0 || ny >= p.Y || nz < 0 || nz >= p.Z)
+      return false;
+    const long long m =
+        n + p.dir[L][0] + (long long)p.dir[L][1] * p.X +
+        (long long)p.dir[L][2] * p.X * p.Y;
+    float d[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) d[c] = x[c * p.N + m] - self[c] + p.rest[L][c];
+    spring<C>(d, p.rest[L], p.dir[L], p.neg_k[L], p.prefer, f);
+    return true;
+  };
+
+  float f[C];
+  if (p.order2d) {
+    // f1p + f2p + f3p + f4p - f1n - f2n - f3n - f4n   (mesh.py:169)
+    for (int L = 0; L < p.n_links; ++L)
+      if (far_side(L, f)) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = acc[c] + f[c];
+      }
+    for (int L = 0; L < p.n_links; ++L)
+      if (near_side(L, f)) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = acc[c] - f[c];
+      }
+  } else {
+    // per link: += fp; -= fn   (mesh.py:271-277)
+    for (int L = 0; L < p.n_links; ++L) {
+      if (far_side(L, f)) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = acc[c] + f[c];
+      }
+      if (near_side(L, f)) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = acc[c] - f[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) out[c] = acc[c];
+}
+
+// clip(-k0 * nan_to_num(x - prev), -cap, cap)   (mesh.py:432-433)
+__device__ __forceinline__ float prev_pull(float x, float prev, float neg_k0,
+                                           float cap) {
+  float d = x - prev;
+  if (isnan(d)) d = 0.f;
+  if (isinf(d)) d = d > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  const float pl = neg_k0 * d;
+  return fminf(fmaxf(pl, -cap), cap);
+}
+
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+force_kernel(const float* __restrict__ x, const float* __restrict__ prev,
+             float* __restrict__ out, MeshParams p, float cap, int add_prev) {
+  for (long long n = blockIdx.x * (long long)kBlock + threadIdx.x; n < p.N;
+       n += (long long)gridDim.x * kBlock) {
+    float f[C];
+    node_force<C>(x, p, n, f);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float v = f[c];
+      if (add_prev)
+        v = v + prev_pull(x[c * p.N + n], prev[c * p.N + n], p.neg_k0, cap);
+      out[c * p.N + n] = v;
+    }
+  }
+}
+
+// Fixed-order block reduction of `nv` values per thread (nv <= kNP).
+__device__ void block_sum(float* vals, int nv, float* lds) {
+  for (int i = 0; i < nv; ++i) lds[i * kBlock + threadIdx.x] = vals[i];
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+      for (int i = 0; i < nv; ++i)
+        lds[i * kBlock + threadIdx.x] =
+            lds[i * kBlock + threadIdx.x] + lds[i * kBlock + threadIdx.x + s];
+    __syncthreads();
+  }
+  for (int i = 0; i < nv; ++i) vals[i] = lds[i * kBlock];
+  __syncthreads();
+}
+
+// Reduces the partials of the previous step and advances the FIRE scalars
+// (mesh.py:455-497).  Every block computes the identical result.
+__device__ void update_scalars(const Scalars& in, const float* partials,
+                               int n_part_rows, const MeshParams& p,
+                               float* lds, Scalars* out) {
+  float acc[kNP];
+  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
+  for (int r = threadIdx.x; r < n_part_rows; r += kBlock)
+    for (int i = 0; i < 7; ++i) acc[i] = acc[i] + partials[r * kNP + i];
+  block_sum(acc, 7, lds);
+  const float power = acc[0];
+  Scalars s = in;
+  const bool downhill = power >= 0.f;
+  s.n_pos = downhill ? in.n_pos + 1 : 0;
+  if (downhill) {
+    if (s.n_pos > p.n_min) {
+      s.dt = fminf(in.dt * p.f_inc, p.dt_cap);
+      s.alpha = in.alpha * p.f_alpha;
+    }
+    if (s.n_pos > 0 && (s.n_pos % p.cap_every) == 0) s.cap = p.cap_scale * in.cap;
+  } else {
+    s.dt = in.dt * p.f_dec;
+    s.alpha = p.alpha0;
+  }
+  s.cap = fminf(s.cap, p.final_cap);
+  s.gate = downhill ? 1.f : 0.f;
+  for (int c = 0; c < 3; ++c) {
+    s.mx[c] = p.remove_drift ? acc[1 + c] / p.n_f : 0.f;
+    s.mv[c] = p.remove_drift ? (acc[4 + c] / p.n_f) * s.gate : 0.f;
+  }
+  *out = s;
+}
+
+// x += dt v + dt^2/2 a, after applying the pending gate / drift of the
+// previous step (mesh.py:439, 492-497).
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+advance_kernel(float* __restrict__ x, float* __restrict__ v,
+               const float* __restrict__ a, MeshParams p,
+               const Scalars* __restrict__ scal_in, Scalars* __restrict__ scal_out,
+               const float* __restrict__ partials, int n_part_rows,
+               int pending) {
+  __shared__ float lds[kNP * kBlock];
+  Scalars s;
+  if (p.fire) {
+    if (pending) {
+      update_scalars(*scal_in, partials, n_part_rows, p, lds, &s);
+    } else {
+      s = *scal_in;
+      s.gate = 1.f;
+      for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scal_out = s;
+  } else {
+    s.dt = p.vv_dt;
+    s.gate = 1.f;
+    for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+  }
+  const float dt = s.dt;
+  const float c2 = 0.5f * (dt * dt);
+  for (long long n = blockIdx.x * (long long)kBlock + threadIdx.x; n < p.N;
+       n += (long long)gridDim.x * kBlock) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float xv = x[c * p.N + n];
+      float vv = v[c * p.N + n];
+      if (p.fire && pending) {
+        vv = vv * s.gate;
+        if (p.remove_drift) {
+          xv = xv - s.mx[c];
+          vv = vv - s.mv[c];
+        }
+        v[c * p.N + n] = vv;
+      }
+      x[c * p.N + n] = xv + (dt * vv + c2 * a[c * p.N + n]);
+    }
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
+                 float* __restrict__ a, const float* __restrict__ prev,
+                 MeshParams p, const Scalars* __restrict__ scal,
+                 float fixed_cap, float* __restrict__ partials) {
+  __shared__ float lds[kNP * kBlock];
+  float dt, alpha, cap;
+  if (p.fire) {
+    dt = scal->dt;
+    alpha = scal->alpha;
+    cap = scal->cap;
+  } else {
+    dt = p.vv_dt;
+    alpha = 0.f;
+    cap = fixed_cap;
+  }
+  const float hdtg = (0.5f * dt) * p.gamma;
+  const float fact0 = 1.0f / (1.0f + hdtg);
+  const float fact1 = 1.0f - hdtg;
+  const float hdt = 0.5f * dt;
+  float part[kNP];
+  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+  for (long long n = blockIdx.x * (long long)kBlock + threadIdx.x; n < p.N;
+       n += (long long)gridDim.x * kBlock) {
+    float f[C], vn[C];
+    node_force<C>(x, p, n, f);
+    float a2 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float xv = x[c * p.N + n];
+      if (p.has_prev) f[c] = f[c] + prev_pull(xv, prev[c * p.N + n], p.neg_k0, cap);
+      const float a_old = a[c * p.N + n];
+      vn[c] = fact0 * (v[c * p.N + n] * fact1 + hdt * (a_old + f[c]));
+      a[c * p.N + n] = f[c];
+      a2 = a2 + f[c] * f[c];
+      v2 = v2 + vn[c] * vn[c];
+      if (p.fire) {
+        part[0] = part[0] + f[c] * vn[c];
+        part[1 + c] = part[1 + c] + xv;
+      }
+    }
+    if (p.fire) {
+      const float a_norm = sqrtf(a2) + 1e-6f;
+      const float v_norm = sqrtf(v2);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
+        part[4 + c] = part[4 + c] + vn[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c * p.N + n] = vn[c];
+  }
+  if (p.fire) {
+    block_sum(part, 7, lds);
+    if (threadIdx.x == 0)
+      for (int i = 0; i < kNP; ++i) partials[blockIdx.x * kNP + i] = part[i];
+  }
+}
+
+// Applies the pending gate / drift of the last step and emits the per-block
+// kinetic-energy partials (mesh.py:492-497, 584-586).
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+finish_kernel(float* __restrict__ x, float* __restrict__ v, MeshParams p,
+              const Scalars* __restrict__ scal_in, Scalars* __restrict__ scal_out,
+              const float* __restrict__ partials, int n_part_rows, int pending,
+              float* __restrict__ stat_partials) {
+  __shared__ float lds[kNP * kBlock];
+  Scalars s;
+  s.gate = 1.f;
+  for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+  if (p.fire) {
+    if (pending) {
+      update_scalars(*scal_in, partials, n_part_rows, p, lds, &s);
+    } else {
+      s = *scal_in;
+      s.gate = 1.f;
+      for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scal_out = s;
+  }
+  float ek = 0.f, vmax2 = 0.f;
+  for (long long n = blockIdx.x * (long long)kBlock + threadIdx.x; n < p.N;
+       n += (long long)gridDim.x * kBlock) {
+    float v2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float vv = v[c * p.N + n];
+      if (p.fire && pending) {
+        vv = vv * s.gate;
+        if (p.remove_drift) {
+          x[c * p.N + n] = x[c * p.N + n] - s.mx[c];
+          vv = vv - s.mv[c];
+        }
+        v[c * p.N + n] = vv;
+      }
+      v2 = v2 + vv * vv;
+    }
+    ek = ek + v2;
+    vmax2 = fmaxf(vmax2, v2);
+  }
+  lds[threadIdx.x] = ek;
+  lds[kBlock + threadIdx.x] = vmax2;
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      lds[threadIdx.x] = lds[threadIdx.x] + lds[threadIdx.x + st];
+      lds[kBlock + threadIdx.x] =
+          fmaxf(lds[kBlock + threadIdx.x], lds[kBlock + threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    stat_partials[blockIdx.x * 2] = lds[0];
+    stat_partials[blockIdx.x * 2 + 1] = lds[kBlock];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+stats_kernel(const float* __restrict__ stat_partials, int rows,
+             float* __restrict__ out) {
+  __shared__ float lds[2 * kBlock];
+  float ek = 0.f, vm = 0.f;
+  for (int r = threadIdx.x; r < rows; r += kBlock) {
+    ek = ek + stat_partials[r * 2];
+    vm = fmaxf(vm, stat_partials[r * 2 + 1]);
+  }
+  lds[threadIdx.x] = ek;
+  lds[kBlock + threadIdx.x] = vm;
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      lds[threadIdx.x] = lds[threadIdx.x] + lds[threadIdx.x + st];
+      lds[kBlock + threadIdx.x] =
+          fmaxf(lds[kBlock + threadIdx.x], lds[kBlock + threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = lds[0];
+    out[1] = sqrtf(lds[kBlock]);
+  }
+}
+
+const int kDefaultLinks[13][3] = {
+    {1, 0, 0}, {0, 1, 0},  {0, 0, 1},  {1, 1, 0},  {-1, 1, 0},
+    {1, 0, 1}, {-1, 0, 1}, {0, 1, 1},  {0, -1, 1}, {1, 1, 1},
+    {1, 1, -1}, {1, -1, 1}, {-1, 1, 1}};
+
+int build_params(const SfmMeshDesc* d, MeshParams* p) {
+  if (!d) return sfm::fail(SFM_ERR_INVALID, "desc is NULL");
+  if (d->ncomp != 2 && d->ncomp != 3)
+    return sfm::fail(SFM_ERR_INVALID, "ncomp must be 2 or 3, got %d", d->ncomp);
+  for (int i = 0; i < 4; ++i)
+    if (d->shape[i] < 1)
+      return sfm::fail(SFM_ERR_INVALID, "shape[%d] = %d", i, d->shape[i]);
+  std::memset(p, 0, sizeof(*p));
+  p->ncomp = d->ncomp;
+  p->B = d->shape[0];
+  p->Z = d->shape[1];
+  p->Y = d->shape[2];
+  p->X = d->shape[3];
+  p->N = (long long)p->B * p->Z * p->Y * p->X;
+  p->prefer = d->prefer_orig_order;
+  p->neg_k0 = static_cast<float>(-d->k0);
+  p->has_prev = d->prev != nullptr;
+  if (d->ncomp == 2) {
+    // Batch and z are both independent slices for the in-plane force; fold
+    // them so the stencil never crosses a slice (Z extent of the stencil = 1).
+    p->Z = 1;
+    p->B = d->shape[0] * d->shape[1];
+    const int dirs[4][3] = {{1, 0, 0}, {0, 1, 0}, {1, 1, 0}, {-1, 1, 0}};
+    p->n_links = 4;
+    p->order2d = 1;
+    const float kf = static_cast<float>(d->k);
+    const float k2 = kf / sqrtf(2.0f);  // k / jnp.sqrt(2.0)  (mesh.py:137)
+    for (int L = 0; L < 4; ++L) {
+      for (int c = 0; c < 3; ++c) p->dir[L][c] = dirs[L][c];
+      p->rest[L][0] = static_cast<float>(dirs[L][0] * d->stride[0]);
+      p->rest[L][1] = static_cast<float>(dirs[L][1] * d->stride[1]);
+      p->rest[L][2] = 0.f;
+      p->neg_k[L] = L < 2 ? static_cast<float>(-d->k) : -k2;
+    }
+  } else {
+    p->n_links = d->n_links > 0 ? d->n_links : 13;
+    if (p->n_links > SFM_MESH_MAX_LINKS)
+      return sfm::fail(SFM_ERR_INVALID, "too many links: %d", p->n_links);
+    for (int L = 0; L < p->n_links; ++L) {
+      float r2 = 0.f;
+      for (int c = 0; c < 3; ++c) {
+        const int v = d->n_links > 0 ? d->links[L][c] : kDefaultLinks[L][c];
+        if (v < -1 || v > 1)
+          return sfm::fail(SFM_ERR_INVALID,
+                           "Only |v| <= 1 values supported within links.");
+        p->dir[L][c] = v;
+        p->rest[L][c] = static_cast<float>(d->stride[c] * v);
+      }
+      r2 = p->rest[L][0] * p->rest[L][0] + p->rest[L][1] * p->rest[L][1];
+      r2 = r2 + p->rest[L][2] * p->rest[L][2];
+      const float l0 = sqrtf(r2);
+      // k_eff = k * stride_x / |l0|   (mesh.py:259)
+      p->neg_k[L] = static_cast<float>(-(d->k * d->stride[0] / (double)l0));
+    }
+  }
+  p->fire = d->fire;
+  p->remove_drift = d->remove_drift;
+  p->gamma = static_cast<float>(d->gamma);
+  p->vv_dt = static_cast<float>(d->dt);
+  p->f_alpha = static_cast<float>(d->f_alpha);
+  p->f_inc = static_cast<float>(d->f_inc);
+  p->f_dec = static_cast<float>(d->f_dec);
+  p->alpha0 = static_cast<float>(d->alpha0);
+  p->n_min = d->n_min;
+  p->dt_cap = static_cast<float>(d->dt_max * d->dt);
+  p->final_cap = static_cast<float>(d->final_cap);
+  p->cap_scale = static_cast<float>(d->cap_scale);
+  p->cap_every = d->cap_upscale_every > 0 ? d->cap_upscale_every : 1;
+  p->n_f = static_cast<float>(p->N);
+  return SFM_OK;
+}
+
+int grid_for(long long n) {
+  long long g = (n + kBlock - 1) / kBlock;
+  if (g > kMaxBlocks) g = kMaxBlocks;
+  if (g < 1) g = 1;
+  return static_cast<int>(g);
+}
+
+struct MeshWorkspace {
+  Scalars* scal;       // [2]
+  float* partials;     // [kMaxBlocks * kNP]
+  float* stat_part;    // [kMaxBlocks * 2]
+  float* stats;        // [2]
+  size_t bytes;
+};
+
+MeshWorkspace carve(void* ws) {
+  sfm::Carver c(ws);
+  MeshWorkspace w;
+  w.scal = c.take<Scalars>(2);
+  w.partials = c.take<float>(kMaxBlocks * kNP);
+  w.stat_part = c.take<float>(kMaxBlocks * 2);
+  w.stats = c.take<float>(2);
+  w.bytes = c.total();
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sfm_mesh_workspace_bytes(const SfmMeshDesc* /*desc*/) {
+  return carve(nullptr).bytes;
+}
+
+int sfm_mesh_force(const SfmMeshDesc* d, float* out) {
+  MeshParams p;
+  if (int rc = build_params(d, &p)) return rc;
+  if (!d->x || !out) return sfm::fail(SFM_ERR_INVALID, "x/out is NULL");
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  const int grid = grid_for(p.N);
+  if (p.ncomp == 2)
+    hipLaunchKernelGGL(force_kernel<2>, dim3(grid), dim3(kBlock), 0, st, d->x,
+                       nullptr, out, p, 0.f, 0);
+  else
+    hipLaunchKernelGGL(force_kernel<3>, dim3(grid), dim3(kBlock), 0, st, d->x,
+                       nullptr, out, p, 0.f, 0);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
+                         SfmChunkStats* stats) {
+  MeshParams p;
+  if (int rc = build_params(d, &p)) return rc;
+  if (!d->x || !d->v || !d->a)
+    return sfm::fail(SFM_ERR_INVALID, "x/v/a must be device pointers");
+  if (!fire || !stats) return sfm::fail(SFM_ERR_INVALID, "fire/stats is NULL");
+  if (d->num_iters < 0) return sfm::fail(SFM_ERR_INVALID, "num_iters < 0");
+  if (d->remove_drift && d->ncomp == 3 && d->shape[0] > 1)
+    return sfm::fail(SFM_ERR_INVALID,
+                     "remove_drift on 5-D arrays (per-column means of the "
+                     "reference) is not implemented");
+  MeshWorkspace w = carve(d->workspace);
+  if (!d->workspace || d->workspace_bytes < w.bytes)
+    return sfm::fail(SFM_ERR_WORKSPACE, "mesh workspace needs %zu bytes, got %zu",
+                     w.bytes, d->workspace_bytes);
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  const int grid = grid_for(p.N);
+
+  Scalars s0;
+  std::memset(&s0, 0, sizeof(s0));
+  s0.dt = fire->dt;
+  s0.alpha = fire->alpha;
+  s0.n_pos = 0;  // restarts every call (mesh.py:513)
+  s0.cap = fire->cap;
+  s0.gate = 1.f;
+  SFM_HIP_CHECK(hipMemcpyAsync(&w.scal[0], &s0, sizeof(s0),
+                               hipMemcpyHostToDevice, st));
+
+  const float cap0 = fire->cap;
+#define SFM_MESH_DISPATCH(KERNEL, ...)                                       \
+  do {                                                                       \
+    if (p.ncomp == 2)                                                        \
+      hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(kBlock), 0, st,         \
+                         __VA_ARGS__);                                       \
+    else                                                                     \
+      hipLaunchKernelGGL(KERNEL<3>, dim3(grid), dim3(kBlock), 0, st,         \
+                         __VA_ARGS__);                                       \
+    SFM_LAUNCH_CHECK();                                                      \
+  } while (0)
+
+  // a = F(x) + pull(prev, cap)   (mesh.py:501)
+  SFM_MESH_DISPATCH(force_kernel, d->x, d->prev, d->a, p, cap0, p.has_prev);
+
+  int cur = 0;
+  for (int it = 0; it < d->num_iters; ++it) {
+    const int pending = it > 0;
+    SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
+                      &w.scal[cur ^ 1], w.partials, grid, pending);
+    cur ^= 1;
+    SFM_MESH_DISPATCH(integrate_kernel, d->x, d->v, d->a, d->prev, p,
+                      &w.scal[cur], cap0, w.partials);
+  }
+  const int pending = d->num_iters > 0;
+  SFM_MESH_DISPATCH(finish_kernel, d->x, d->v, p, &w.scal[cur],
+                    &w.scal[cur ^ 1], w.partials, grid, pending, w.stat_part);
+  cur ^= 1;
+#undef SFM_MESH_DISPATCH
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(kBlock), 0, st, w.stat_part,
+                     grid, w.stats);
+  SFM_LAUNCH_CHECK();
+
+  Scalars s1;
+  float hs[2];
+  SFM_HIP_CHECK(hipMemcpyAsync(&s1, &w.scal[cur], sizeof(s1),
+                               hipMemcpyDeviceToHost, st));
+  SFM_HIP_CHECK(hipMemcpyAsync(hs, w.stats, sizeof(hs), hipMemcpyDeviceToHost, st));
+  SFM_HIP_CHECK(hipStreamSynchronize(st));
+  if (p.fire) {
+    fire->dt = s1.dt;
+    fire->alpha = s1.alpha;
+    fire->n_pos = s1.n_pos;
+    fire->cap = s1.cap;
+  }
+  stats->e_kin = hs[0];
+  stats->v_max = hs[1];
+  return SFM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,711 @@
+// Patch cross-correlation + peak statistics for gfx950: batch driver, patch
+// gather, the general shift-by-shift correlation kernel and the peak kernels.
+//
+// Device replacement for flow_field.py of the reference:
+//   _batched_xcorr   (flow_field.py:278-371)  -> gather_kernel (clamped patch
+//                     gather, per-patch (masked) mean, validity planes)
+//   masked_xcorr     (flow_field.py:36-156)   -> corr_direct_kernel (+ the
+//                     Padfield assembly and masked_finalize_kernel), or the
+//                     int8 MFMA kernel in sfm_xcorr_mfma.hip for uint8 data
+//   _batched_peaks / _peak_stats (flow_field.py:178-275)
+//                                             -> peaks_first_kernel,
+//                                                peaks_second_kernel
+//
+// The reference evaluates the full linear correlation with zero-padded FFTs;
+// here every output shift is summed directly:
+//     out[k] = sum_i A[i + k - (Q-1)] * B[i]      (zero shift at k = Q-1)
+// which is the same quantity (oracle/flow_oracle.py checks both forms against
+// the reference's own output).  The masked (Padfield) surface is assembled
+// from six such sums exactly as SURVEY.md section 8a derives.
+#include "sfm_common.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace sfm {
+// Implemented in sfm_xcorr_mfma.hip.
+bool mfma_i8_eligible(const SfmXcorrDesc* d);
+size_t mfma_i8_workspace_bytes(const SfmXcorrDesc* d);
+int mfma_i8_surface(const SfmXcorrDesc* d, void* ws, float* surface);
+}  // namespace sfm
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kCandCap = 2048;  // per-patch candidate list capacity
+constexpr float kEps = 1.1920928955078125e-07f;  // float32 eps
+
+struct Geo {
+  int nd;
+  int P[3], Q[3], S[3];  // [z]yx; S = P + Q - 1
+  long long Pn, Qn, Sn;
+};
+
+int make_geo(const SfmXcorrDesc* d, Geo* g) {
+  if (d->ndim != 2 && d->ndim != 3)
+    return sfm::fail(SFM_ERR_INVALID, "ndim must be 2 or 3, got %d", d->ndim);
+  g->nd = d->ndim;
+  g->Pn = g->Qn = g->Sn = 1;
+  for (int i = 0; i < 3; ++i) {
+    g->P[i] = d->patch[i];
+    g->Q[i] = d->post_patch[i];
+    if (g->P[i] < 1 || g->Q[i] < 1)
+      return sfm::fail(SFM_ERR_INVALID, "patch sizes must be >= 1");
+    if (d->ndim == 2 && i == 0 && (g->P[0] != 1 || g->Q[0] != 1))
+      return sfm::fail(SFM_ERR_INVALID, "2-D descriptors need patch[0] == 1");
+    if (g->P[i] > d->pre_shape[i] || g->Q[i] > d->post_shape[i])
+      return sfm::fail(SFM_ERR_INVALID, "patch larger than image on axis %d", i);
+    g->S[i] = g->P[i] + g->Q[i] - 1;
+    g->Pn *= g->P[i];
+    g->Qn *= g->Q[i];
+    g->Sn *= g->S[i];
+  }
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// gather: clamped patch extraction, mean subtraction, mask zeroing
+// ---------------------------------------------------------------------------
+struct GatherArgs {
+  const void* img;
+  const unsigned char* mask;
+  int ishape[3], mshape[3], psz[3];
+  const int* starts;
+  int nd;
+  int use_mean;
+  float mean;
+  float* out;    // [B, psz]
+  float* valid;  // [B, psz] or null
+  long long pn;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) gather_kernel(GatherArgs g0, GatherArgs g1) {
+  const GatherArgs& g = blockIdx.y == 0 ? g0 : g1;
+  const int b = blockIdx.x;
+  __shared__ double s_sum[kBlock];
+  __shared__ double s_cnt[kBlock];
+  int st[3] = {0, 0, 0}, ms[3] = {0, 0, 0};
+  for (int i = 0; i < g.nd; ++i) {
+    const int v = g.starts[b * g.nd + i];
+    const int ax = 3 - g.nd + i;
+    // lax.dynamic_slice clamps the start so the slice stays in bounds; image
+    // and mask are clamped against their own shapes.
+    st[ax] = min(max(v, 0), g.ishape[ax] - g.psz[ax]);
+    ms[ax] = min(max(v, 0), g.mshape[ax] - g.psz[ax]);
+  }
+  const T* img = static_cast<const T*>(g.img);
+  const long long py = g.psz[1], px = g.psz[2];
+  auto pix = [&](long long i, float* val, bool* masked) {
+    const int x = static_cast<int>(i % px);
+    const long long r = i / px;
+    const int y = static_cast<int>(r % py);
+    const int z = static_cast<int>(r / py);
+    const long long off =
+        ((long long)(st[0] + z) * g.ishape[1] + (st[1] + y)) * g.ishape[2] +
+        (st[2] + x);
+    *val = static_cast<float>(img[off]);
+    *masked = false;
+    if (g.mask) {
+      const long long mo =
+          ((long long)(ms[0] + z) * g.mshape[1] + (ms[1] + y)) * g.mshape[2] +
+          (ms[2] + x);
+      *masked = g.mask[mo] != 0;
+    }
+  };
+  float mu = g.mean;
+  if (!g.use_mean) {
+    double s = 0.0, c = 0.0;
+    for (long long i = threadIdx.x; i < g.pn; i += kBlock) {
+      float v;
+      bool m;
+      pix(i, &v, &m);
+      if (!m) {
+        s += v;
+        c += 1.0;
+      }
+    }
+    s_sum[threadIdx.x] = s;
+    s_cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int k = kBlock / 2; k > 0; k >>= 1) {
+      if (threadIdx.x < k) {
+        s_sum[threadIdx.x] += s_sum[threadIdx.x + k];
+        s_cnt[threadIdx.x] += s_cnt[threadIdx.x + k];
+      }
+      __syncthreads();
+    }
+    mu = static_cast<float>(s_sum[0] / s_cnt[0]);  // NaN when all masked
+  }
+  for (long long i = threadIdx.x; i < g.pn; i += kBlock) {
+    float v;
+    bool m;
+    pix(i, &v, &m);
+    g.out[b * g.pn + i] = m ? 0.f : v - mu;
+    if (g.valid) g.valid[b * g.pn + i] = m ? 0.f : 1.f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// general direct correlation (any dim / dtype / masks)
+// ---------------------------------------------------------------------------
+struct CorrArgs {
+  const float* a;   // [B, P] centred, masked pixels zeroed
+  const float* b;   // [B, Q]
+  const float* va;  // validity planes or null
+  const float* vb;
+  Geo g;
+  float* out;       // unmasked: surface; masked: numerator
+  float* den;       // masked only
+  float* ov;        // masked only
+  unsigned int* maxima;  // masked only: bits of max |den|, max overlap
+};
+
+template <bool MASKED>
+__global__ void __launch_bounds__(kBlock) corr_direct_kernel(CorrArgs c) {
+  const Geo& g = c.g;
+  const int kx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ky = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int kz = blockIdx.z % g.S[0];
+  const int bi = blockIdx.z / g.S[0];
+  const bool live = kx < g.S[2] && ky < g.S[1];
+  float xc = 0.f, sa = 0.f, sb = 0.f, nov = 0.f, qa = 0.f, qb = 0.f;
+  if (live) {
+    const int dz = kz - (g.Q[0] - 1), dy = ky - (g.Q[1] - 1),
+              dx = kx - (g.Q[2] - 1);
+    const int z0 = max(0, -dz), z1 = min(g.Q[0], g.P[0] - dz);
+    const int y0 = max(0, -dy), y1 = min(g.Q[1], g.P[1] - dy);
+    const int x0 = max(0, -dx), x1 = min(g.Q[2], g.P[2] - dx);
+    const float* A = c.a + bi * g.Pn;
+    const float* Bp = c.b + bi * g.Qn;
+    const float* VA = MASKED ? c.va + bi * g.Pn : nullptr;
+    const float* VB = MASKED ? c.vb + bi * g.Qn : nullptr;
+    for (int z = z0; z < z1; ++z)
+      for (int y = y0; y < y1; ++y) {
+        const long long ao =
+            ((long long)(z + dz) * g.P[1] + (y + dy)) * g.P[2] + dx;
+        const long long bo = ((long long)z * g.Q[1] + y) * g.Q[2];
+        for (int x = x0; x < x1; ++x) {
+          const float av = A[ao + x];
+          const float bv = Bp[bo + x];
+          xc = fmaf(av, bv, xc);
+          if (MASKED) {
+            const float wa = VA[ao + x];
+            const float wb = VB[bo + x];
+            sa = fmaf(av, wb, sa);
+            sb = fmaf(wa, bv, sb);
+            nov = fmaf(wa, wb, nov);
+            qa = fmaf(av * av, wb, qa);
+            qb = fmaf(wa, bv * bv, qb);
+          }
+        }
+      }
+  }
+  if (!live) return;
+  const long long o =
+      bi * g.Sn + ((long long)kz * g.S[1] + ky) * g.S[2] + kx;
+  if (!MASKED) {
+    c.out[o] = xc;
+    return;
+  }
+  // Padfield assembly (flow_field.py:113-131).
+  float ovv = fmaxf(rintf(nov), kEps);
+  const float inv = 1.0f / ovv;
+  const float num = xc - sa * sb * inv;
+  const float pd = fmaxf(qa - sa * sa * inv, 0.f);
+  const float cd = fmaxf(qb - sb * sb * inv, 0.f);
+  const float den = sqrtf(pd * cd);
+  c.out[o] = num;
+  c.den[o] = den;
+  c.ov[o] = ovv;
+  // Batch-global maxima (flow_field.py:137, 151); values are >= 0 so the
+  // integer order of the bit patterns is the float order.
+  atomicMax(&c.maxima[0], __float_as_uint(fabsf(den)));
+  atomicMax(&c.maxima[1], __float_as_uint(ovv));
+}
+
+__global__ void __launch_bounds__(kBlock)
+masked_finalize_kernel(float* __restrict__ out, const float* __restrict__ den,
+                       const float* __restrict__ ov,
+                       const unsigned int* __restrict__ maxima, long long n) {
+  const float tol = 1e3f * kEps * __uint_as_float(maxima[0]);
+  const float px_thr = 0.3f * __uint_as_float(maxima[1]);
+  for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n;
+       i += (long long)gridDim.x * kBlock) {
+    const float dn = den[i];
+    float v = dn > tol ? out[i] / dn : 0.f;
+    v = fminf(fmaxf(v, -1.f), 1.f);
+    if (ov[i] < px_thr) v = 0.f;
+    out[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// peaks
+// ---------------------------------------------------------------------------
+struct PeakArgs {
+  const float* surf;  // [B, S]
+  int nd;
+  int S[3];
+  long long Sn;
+  int batch;
+  float center[3];  // [z]yx
+  int min_distance;
+  float threshold_rel;
+  int radius[3];
+  // workspace
+  int* idx1;               // [B]
+  float* v1;               // [B]
+  int* zero_is_peak;       // [B]
+  int* cand_count;         // [B]
+  float* cand_val;         // [B, kCandCap]
+  int* cand_idx;           // [B, kCandCap]
+  unsigned int* bitmap;    // [ceil(Sn / 32)]
+  float* out;              // [B, nd + 2]
+};
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
+  return v > bv || (v == bv && i < bi);
+}
+
+// (value, index) arg-max with first-index tie break across the block.
+__device__ void block_argmax(float* v, int* i, float* lv, int* li) {
+  lv[threadIdx.x] = *v;
+  li[threadIdx.x] = *i;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s &&
+        better(lv[threadIdx.x + s], li[threadIdx.x + s], lv[threadIdx.x],
+               li[threadIdx.x])) {
+      lv[threadIdx.x] = lv[threadIdx.x + s];
+      li[threadIdx.x] = li[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  *v = lv[0];
+  *i = li[0];
+  __syncthreads();
+}
+
+// img == maxfilter(img) (zero 'same' padding) && img > thr
+// (flow_field.py:238-254).
+__device__ bool is_peak_at(const float* s, const PeakArgs& p, long long pos,
+                           float thr, float* val) {
+  const int x = static_cast<int>(pos % p.S[2]);
+  const long long r = pos / p.S[2];
+  const int y = static_cast<int>(r % p.S[1]);
+  const int z = static_cast<int>(r / p.S[1]);
+  const float v = s[pos];
+  *val = v;
+  if (!(v > thr)) return false;
+  const int m = p.min_distance;
+  const int mz = p.nd == 3 ? m : 0;
+  float wm = -INFINITY;
+  bool outside = false;
+  for (int dz = -mz; dz <= mz; ++dz)
+    for (int dy = -m; dy <= m; ++dy)
+      for (int dx = -m; dx <= m; ++dx) {
+        const int zz = z + dz, yy = y + dy, xx = x + dx;
+        if (zz < 0 || zz >= p.S[0] || yy < 0 || yy >= p.S[1] || xx < 0 ||
+            xx >= p.S[2]) {
+          outside = true;
+          continue;
+        }
+        wm = fmaxf(wm, s[((long long)zz * p.S[1] + yy) * p.S[2] + xx]);
+      }
+  if (outside) wm = fmaxf(wm, 0.f);
+  return v == wm;
+}
+
+__global__ void __launch_bounds__(kBlock) peaks_first_kernel(PeakArgs p) {
+  __shared__ float lv[kBlock];
+  __shared__ int li[kBlock];
+  const int b = blockIdx.x;
+  const float* s = p.surf + b * p.Sn;
+  float mx = -INFINITY;
+  for (long long i = threadIdx.x; i < p.Sn; i += kBlock) mx = fmaxf(mx, s[i]);
+  int dummy = 0;
+  block_argmax(&mx, &dummy, lv, li);
+  const float thr = p.threshold_rel * mx;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (long long i = threadIdx.x; i < p.Sn; i += kBlock) {
+    float v;
+    if (is_peak_at(s, p, i, thr, &v)) {
+      if (better(v, static_cast<int>(i), bv, bi)) {
+        bv = v;
+        bi = static_cast<int>(i);
+      }
+      const int slot = atomicAdd(&p.cand_count[b], 1);
+      if (slot < kCandCap) {
+        p.cand_val[(long long)b * kCandCap + slot] = v;
+        p.cand_idx[(long long)b * kCandCap + slot] = static_cast<int>(i);
+      }
+      if (i == 0) p.zero_is_peak[b] = 1;
+    }
+  }
+  block_argmax(&bv, &bi, lv, li);
+  if (threadIdx.x == 0) {
+    const int i1 = bv == -INFINITY ? 0 : bi;  // argmax of an all -inf row is 0
+    p.idx1[b] = i1;
+    p.v1[b] = bv;
+    atomicOr(&p.bitmap[i1 >> 5], 1u << (i1 & 31));
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
+  __shared__ float lv[kBlock];
+  __shared__ int li[kBlock];
+  const int b = blockIdx.x;
+  const float* s = p.surf + b * p.Sn;
+  const float v1 = p.v1[b];
+  const int i1 = p.idx1[b];
+  const int w = p.nd + 2;
+  if (v1 == -INFINITY) {
+    if (threadIdx.x < w) p.out[b * w + threadIdx.x] = NAN;
+    return;
+  }
+  // Second peak: best candidate whose flat index is not a first-peak index of
+  // ANY surface in the batch (flow_field.py:263-265).
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  const int cnt = p.cand_count[b];
+  if (cnt <= kCandCap) {
+    for (int k = threadIdx.x; k < cnt; k += kBlock) {
+      const float v = p.cand_val[(long long)b * kCandCap + k];
+      const int i = p.cand_idx[(long long)b * kCandCap + k];
+      if ((p.bitmap[i >> 5] >> (i & 31)) & 1u) continue;
+      if (better(v, i, bv, bi)) {
+        bv = v;
+        bi = i;
+      }
+    }
+  } else {
+    // Candidate list overflowed (plateaus): rescan the surface.
+    float mx = -INFINITY;
+    for (long long i = threadIdx.x; i < p.Sn; i += kBlock) mx = fmaxf(mx, s[i]);
+    int dummy = 0;
+    block_argmax(&mx, &dummy, lv, li);
+    const float thr = p.threshold_rel * mx;
+    for (long long i = threadIdx.x; i < p.Sn; i += kBlock) {
+      if ((p.bitmap[i >> 5] >> (i & 31)) & 1u) continue;
+      float v;
+      if (is_peak_at(s, p, i, thr, &v) &&
+          better(v, static_cast<int>(i), bv, bi)) {
+        bv = v;
+        bi = static_cast<int>(i);
+      }
+    }
+  }
+  block_argmax(&bv, &bi, lv, li);
+  // The value is read from the UN-suppressed array (flow_field.py:266-268):
+  // with nothing left the arg-max is index 0, whose value is the surface value
+  // there if index 0 is itself a peak.
+  float v2 = bv;
+  if (bv == -INFINITY && p.zero_is_peak[b]) v2 = s[0];
+
+  // Sharpness: peak / min over a clamped window (flow_field.py:186-192).
+  int pos[3], start[3], size[3];
+  {
+    long long r = i1;
+    pos[2] = static_cast<int>(r % p.S[2]);
+    r /= p.S[2];
+    pos[1] = static_cast<int>(r % p.S[1]);
+    pos[0] = static_cast<int>(r / p.S[1]);
+  }
+  long long wn = 1;
+  for (int a = 0; a < 3; ++a) {
+    size[a] = (a == 0 && p.nd == 2) ? 1 : 2 * p.radius[a] + 1;
+    size[a] = min(size[a], p.S[a]);
+    start[a] = min(max(pos[a] - size[a] / 2, 0), p.S[a] - size[a]);
+    wn *= size[a];
+  }
+  float mn = INFINITY;
+  for (long long k = threadIdx.x; k < wn; k += kBlock) {
+    const int x = static_cast<int>(k % size[2]);
+    const long long r = k / size[2];
+    const int y = static_cast<int>(r % size[1]);
+    const int z = static_cast<int>(r / size[1]);
+    mn = fminf(mn, s[((long long)(start[0] + z) * p.S[1] + (start[1] + y)) *
+                         p.S[2] +
+                     (start[2] + x)]);
+  }
+  lv[threadIdx.x] = mn;
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st)
+      lv[threadIdx.x] = fminf(lv[threadIdx.x], lv[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* o = p.out + b * w;
+    // x, y[, z] = reversed axis order
+    for (int a = 0; a < p.nd; ++a) {
+      const int ax = 2 - a;
+      o[a] = static_cast<float>(pos[ax]) - p.center[ax];
+    }
+    o[p.nd] = s[i1] / lv[0];
+    o[p.nd + 1] = v2 == -INFINITY ? 0.f : v1 / v2;
+  }
+}
+
+struct PeakWs {
+  int* idx1;
+  float* v1;
+  int* zero_is_peak;
+  int* cand_count;
+  float* cand_val;
+  int* cand_idx;
+  unsigned int* bitmap;
+  size_t zero_from, zero_bytes;  // region that must be cleared per batch
+  size_t bytes;
+};
+
+PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn) {
+  PeakWs w;
+  w.idx1 = c.take<int>(batch);
+  w.v1 = c.take<float>(batch);
+  w.cand_val = c.take<float>((size_t)batch * kCandCap);
+  w.cand_idx = c.take<int>((size_t)batch * kCandCap);
+  const size_t z0 = sfm::align_up(c.off, 256);
+  w.zero_is_peak = c.take<int>(batch);
+  w.cand_count = c.take<int>(batch);
+  w.bitmap = c.take<unsigned int>((size_t)((sn + 31) / 32));
+  w.zero_from = z0;
+  w.zero_bytes = c.total() - z0;
+  w.bytes = c.total();
+  return w;
+}
+
+int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int nd,
+              const int* S, long long sn, int batch, const float* center,
+              int min_distance, float threshold_rel, const int* radius,
+              float* out, hipStream_t st) {
+  PeakArgs p;
+  p.surf = surf;
+  p.nd = nd;
+  for (int i = 0; i < 3; ++i) {
+    p.S[i] = S[i];
+    p.center[i] = center[i];
+    p.radius[i] = radius[i];
+  }
+  p.Sn = sn;
+  p.batch = batch;
+  p.min_distance = min_distance;
+  p.threshold_rel = threshold_rel;
+  p.idx1 = w.idx1;
+  p.v1 = w.v1;
+  p.zero_is_peak = w.zero_is_peak;
+  p.cand_count = w.cand_count;
+  p.cand_val = w.cand_val;
+  p.cand_idx = w.cand_idx;
+  p.bitmap = w.bitmap;
+  p.out = out;
+  SFM_HIP_CHECK(hipMemsetAsync(ws_base + w.zero_from, 0, w.zero_bytes, st));
+  hipLaunchKernelGGL(peaks_first_kernel, dim3(batch), dim3(kBlock), 0, st, p);
+  SFM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(peaks_second_kernel, dim3(batch), dim3(kBlock), 0, st, p);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// batch driver
+// ---------------------------------------------------------------------------
+struct XcorrWs {
+  float *a0, *b0, *va, *vb, *surface, *den, *ov;
+  unsigned int* maxima;
+  void* mfma;
+  PeakWs peaks;
+  size_t bytes;
+};
+
+bool is_masked(const SfmXcorrDesc* d) { return d->pre_mask || d->post_mask; }
+
+bool use_mfma(const SfmXcorrDesc* d) {
+  if (d->method == SFM_XCORR_DIRECT) return false;
+  return sfm::mfma_i8_eligible(d);
+}
+
+XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
+                    bool with_peaks) {
+  sfm::Carver c(d->workspace);
+  XcorrWs w;
+  std::memset(&w, 0, sizeof(w));
+  const size_t B = d->batch;
+  const bool masked = is_masked(d);
+  if (use_mfma(d)) {
+    const size_t n = sfm::mfma_i8_workspace_bytes(d);
+    w.mfma = c.take<char>(n);
+  } else {
+    w.a0 = c.take<float>(B * g.Pn);
+    w.b0 = c.take<float>(B * g.Qn);
+    if (masked) {
+      w.va = c.take<float>(B * g.Pn);
+      w.vb = c.take<float>(B * g.Qn);
+      w.den = c.take<float>(B * g.Sn);
+      w.ov = c.take<float>(B * g.Sn);
+      w.maxima = c.take<unsigned int>(2);
+    }
+  }
+  if (with_surface) w.surface = c.take<float>(B * g.Sn);
+  if (with_peaks) w.peaks = carve_peaks(c, d->batch, g.Sn);
+  w.bytes = c.total();
+  return w;
+}
+
+int check_desc(const SfmXcorrDesc* d) {
+  if (!d) return sfm::fail(SFM_ERR_INVALID, "desc is NULL");
+  if (d->batch < 1) return sfm::fail(SFM_ERR_INVALID, "batch must be >= 1");
+  if (!d->pre_image || !d->post_image || !d->pre_starts || !d->post_starts)
+    return sfm::fail(SFM_ERR_INVALID, "image / starts pointers must be set");
+  if (d->dtype != SFM_DTYPE_U8 && d->dtype != SFM_DTYPE_F32)
+    return sfm::fail(SFM_ERR_INVALID, "unsupported dtype tag %d", d->dtype);
+  if (d->method == SFM_XCORR_MFMA_I8 && !sfm::mfma_i8_eligible(d))
+    return sfm::fail(SFM_ERR_INVALID,
+                     "MFMA_I8 needs uint8 2-D images without correlation masks");
+  return SFM_OK;
+}
+
+int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
+                    float* surface) {
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  if (use_mfma(d)) return sfm::mfma_i8_surface(d, w.mfma, surface);
+  const bool masked = is_masked(d);
+  GatherArgs ga[2];
+  for (int k = 0; k < 2; ++k) {
+    GatherArgs& a = ga[k];
+    a.img = k == 0 ? d->pre_image : d->post_image;
+    a.mask = k == 0 ? d->pre_mask : d->post_mask;
+    for (int i = 0; i < 3; ++i) {
+      a.ishape[i] = k == 0 ? d->pre_shape[i] : d->post_shape[i];
+      a.mshape[i] = k == 0 ? d->pre_mask_shape[i] : d->post_mask_shape[i];
+      a.psz[i] = k == 0 ? g.P[i] : g.Q[i];
+      if (a.mask && a.mshape[i] < a.psz[i])
+        return sfm::fail(SFM_ERR_INVALID, "mask smaller than patch on axis %d", i);
+    }
+    a.starts = k == 0 ? d->pre_starts : d->post_starts;
+    a.nd = d->ndim;
+    a.use_mean = d->use_mean;
+    a.mean = d->mean;
+    a.out = k == 0 ? w.a0 : w.b0;
+    a.valid = masked ? (k == 0 ? w.va : w.vb) : nullptr;
+    a.pn = k == 0 ? g.Pn : g.Qn;
+  }
+  if (d->dtype == SFM_DTYPE_U8)
+    hipLaunchKernelGGL(gather_kernel<unsigned char>, dim3(d->batch, 2),
+                       dim3(kBlock), 0, st, ga[0], ga[1]);
+  else
+    hipLaunchKernelGGL(gather_kernel<float>, dim3(d->batch, 2), dim3(kBlock), 0,
+                       st, ga[0], ga[1]);
+  SFM_LAUNCH_CHECK();
+
+  CorrArgs c;
+  c.a = w.a0;
+  c.b = w.b0;
+  c.va = w.va;
+  c.vb = w.vb;
+  c.g = g;
+  c.out = surface;
+  c.den = w.den;
+  c.ov = w.ov;
+  c.maxima = w.maxima;
+  const long long gz = (long long)d->batch * g.S[0];
+  if (gz > 65535LL * 32768)
+    return sfm::fail(SFM_ERR_INVALID, "batch * S_z too large");
+  dim3 grid((g.S[2] + 63) / 64, (g.S[1] + 3) / 4, (unsigned)gz);
+  if (masked) {
+    SFM_HIP_CHECK(hipMemsetAsync(w.maxima, 0, 2 * sizeof(unsigned int), st));
+    hipLaunchKernelGGL(corr_direct_kernel<true>, grid, dim3(kBlock), 0, st, c);
+    SFM_LAUNCH_CHECK();
+    const long long n = (long long)d->batch * g.Sn;
+    const int fg = (int)((n + kBlock - 1) / kBlock > 4096 ? 4096
+                                                           : (n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(masked_finalize_kernel, dim3(fg), dim3(kBlock), 0, st,
+                       surface, w.den, w.ov, w.maxima, n);
+    SFM_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(corr_direct_kernel<false>, grid, dim3(kBlock), 0, st, c);
+    SFM_LAUNCH_CHECK();
+  }
+  return SFM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sfm_xcorr_workspace_bytes(const SfmXcorrDesc* d) {
+  if (check_desc(d) != SFM_OK) return 0;
+  Geo g;
+  if (make_geo(d, &g) != SFM_OK) return 0;
+  SfmXcorrDesc tmp = *d;
+  tmp.workspace = nullptr;
+  return carve_xcorr(&tmp, g, true, true).bytes;
+}
+
+int sfm_xcorr_surface(const SfmXcorrDesc* d, float* surface) {
+  if (int rc = check_desc(d)) return rc;
+  if (!surface) return sfm::fail(SFM_ERR_INVALID, "surface is NULL");
+  Geo g;
+  if (int rc = make_geo(d, &g)) return rc;
+  XcorrWs w = carve_xcorr(d, g, false, false);
+  if (!d->workspace || d->workspace_bytes < w.bytes)
+    return sfm::fail(SFM_ERR_WORKSPACE, "xcorr workspace needs %zu bytes, got %zu",
+                     w.bytes, d->workspace_bytes);
+  return compute_surface(d, g, w, surface);
+}
+
+int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
+  if (int rc = check_desc(d)) return rc;
+  if (!peaks) return sfm::fail(SFM_ERR_INVALID, "peaks is NULL");
+  Geo g;
+  if (int rc = make_geo(d, &g)) return rc;
+  XcorrWs w = carve_xcorr(d, g, true, true);
+  if (!d->workspace || d->workspace_bytes < w.bytes)
+    return sfm::fail(SFM_ERR_WORKSPACE, "xcorr workspace needs %zu bytes, got %zu",
+                     w.bytes, d->workspace_bytes);
+  if (int rc = compute_surface(d, g, w, w.surface)) return rc;
+  float center[3];
+  for (int i = 0; i < 3; ++i)
+    center[i] = static_cast<float>((g.P[i] + g.Q[i]) / 2 - 1);
+  return run_peaks(w.peaks, static_cast<char*>(d->workspace), w.surface, d->ndim,
+                   g.S, g.Sn, d->batch, center, d->min_distance,
+                   d->threshold_rel, d->peak_radius, peaks,
+                   static_cast<hipStream_t>(d->stream));
+}
+
+size_t sfm_peaks_workspace_bytes(const SfmPeaksDesc* d) {
+  if (!d || d->batch < 1) return 0;
+  long long sn = 1;
+  for (int i = 0; i < 3; ++i) sn *= d->shape[i];
+  sfm::Carver c(nullptr);
+  return carve_peaks(c, d->batch, sn).bytes;
+}
+
+int sfm_peaks(const SfmPeaksDesc* d, float* peaks) {
+  if (!d || !peaks || !d->surface)
+    return sfm::fail(SFM_ERR_INVALID, "desc / surface / peaks is NULL");
+  if (d->ndim != 2 && d->ndim != 3)
+    return sfm::fail(SFM_ERR_INVALID, "ndim must be 2 or 3");
+  if (d->batch < 1) return sfm::fail(SFM_ERR_INVALID, "batch must be >= 1");
+  long long sn = 1;
+  for (int i = 0; i < 3; ++i) {
+    if (d->shape[i] < 1) return sfm::fail(SFM_ERR_INVALID, "bad surface shape");
+    sn *= d->shape[i];
+  }
+  if (sn > 0x7fffffffLL)
+    return sfm::fail(SFM_ERR_INVALID, "surface too large for int32 indices");
+  sfm::Carver c(d->workspace);
+  PeakWs w = carve_peaks(c, d->batch, sn);
+  if (!d->workspace || d->workspace_bytes < w.bytes)
+    return sfm::fail(SFM_ERR_WORKSPACE, "peaks workspace needs %zu bytes, got %zu",
+                     w.bytes, d->workspace_bytes);
+  return run_peaks(w, static_cast<char*>(d->workspace), d->surface, d->ndim,
+                   d->shape, sn, d->batch, d->center_offset, d->min_distance,
+                   d->threshold_rel, d->peak_radius, peaks,
+                   static_cast<hipStream_t>(d->stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,456 @@
+"""Flow-field estimation by patch cross-correlation on MI355X.
+
+Drop-in for the reference's `sofima/flow_field.py`: the same public names,
+signatures, argument meaning and result layout, with the device work done by
+hand-written HIP kernels behind the C ABI of libsofima_amd.so
+(include/sofima_amd.h).  There is no JAX and no CPU fallback.
+
+  JAXMaskedXCorrWithStatsCalculator  <-> flow_field.py:449-712
+  masked_xcorr                       <-> flow_field.py:36-156
+  _batched_peaks                     <-> flow_field.py:205-275
+  batched_xcorr_peaks                <-> flow_field.py:374-441
+
+Flow fields are [dim + 2, *grid] float32 with channels x, y[, z], peak
+sharpness, peak ratio (vector components in the REVERSE of the image axis
+order); NaN marks entries that were not or could not be estimated.
+
+Host-side differences from the reference that do not change results: the start
+coordinates of ALL batches are computed up front and uploaded once, the
+batches are enqueued back to back on the current HIP stream and read back with
+a single copy (the reference blocks on a device->host copy per batch and
+scatters results patch by patch in Python).  Batch membership -- which the
+reference's results depend on -- is unchanged.
+"""
+from __future__ import annotations
+
+import collections.abc
+import ctypes as C
+import itertools
+from typing import Callable, Iterator, Sequence, TypeVar
+
+import numpy as np
+import torch
+
+from . import _abi
+from . import _dev
+
+T = TypeVar('T')
+Array = np.ndarray
+
+
+def _silent_fn(x: list[T]) -> Iterator[T]:
+  for item in x:
+    yield item
+
+
+def _pad3(vals, fill):
+  vals = [int(v) for v in vals]
+  return [fill] * (3 - len(vals)) + vals
+
+
+def _i3(vals):
+  return (C.c_int32 * 3)(*vals)
+
+
+# ---------------------------------------------------------------------------
+# patch selection helpers (integral image over the mask)
+# ---------------------------------------------------------------------------
+def _integral_image(mask):
+  """Summed-volume table with a zero plane in front of every axis.
+
+  Replaces flow_field._integral_image (flow_field.py:159-175) + the
+  `connectomics` integral_image helper.  The table is tiny compared with the
+  correlation work and is consumed by host index arithmetic, so it is built
+  with NumPy in int64 (the reference switches to int64 for large masks too).
+  """
+  if mask is None:
+    return None
+  ii = np.asarray(mask).astype(np.int64)
+  for axis in range(ii.ndim):
+    ii = np.cumsum(ii, axis=axis)
+  return np.pad(ii, [(1, 0)] * ii.ndim)
+
+
+def _query_integral_image(svt, diam, stride):
+  nd = svt.ndim
+  hi = [np.s_[diam[i]::stride[i]] for i in range(nd)]
+  lo = [np.s_[:-diam[i]:stride[i]] for i in range(nd)]
+  total = 0
+  for bits in itertools.product((0, 1), repeat=nd):
+    sel = tuple(hi[i] if b else lo[i] for i, b in enumerate(bits))
+    total = total + (-1) ** (nd - sum(bits)) * svt[sel]
+  return total
+
+
+# ---------------------------------------------------------------------------
+# C-ABI call helpers
+# ---------------------------------------------------------------------------
+class _Resident:
+  """Images / masks of one flow_field() call, resident in HBM."""
+
+  def __init__(self, pre_image, post_image, pre_mask, post_mask, dev):
+    self.dev = dev
+    self.pre, self.dtype = _dev.as_device_image(pre_image, dev)
+    self.post, dt2 = _dev.as_device_image(post_image, dev)
+    if dt2 != self.dtype:
+      # Mixed inputs: correlate in float32.
+      self.pre = self.pre.to(torch.float32)
+      self.post = self.post.to(torch.float32)
+      self.dtype = _abi.DTYPE_F32
+    self.pre_mask = _dev.as_device_mask(pre_mask, dev)
+    self.post_mask = _dev.as_device_mask(post_mask, dev)
+    self.ndim = self.pre.ndim
+
+
+def _make_desc(res: _Resident, patch_size, post_patch_size, mean, min_distance,
+               threshold_rel, peak_radius, method) -> _abi.SfmXcorrDesc:
+  nd = res.ndim
+  d = _abi.SfmXcorrDesc()
+  d.ndim = nd
+  d.dtype = res.dtype
+  d.pre_image = res.pre.data_ptr()
+  d.post_image = res.post.data_ptr()
+  d.pre_shape = _i3(_pad3(res.pre.shape, 1))
+  d.post_shape = _i3(_pad3(res.post.shape, 1))
+  if res.pre_mask is not None:
+    d.pre_mask = res.pre_mask.data_ptr()
+    d.pre_mask_shape = _i3(_pad3(res.pre_mask.shape, 1))
+  if res.post_mask is not None:
+    d.post_mask = res.post_mask.data_ptr()
+    d.post_mask_shape = _i3(_pad3(res.post_mask.shape, 1))
+  d.patch = _i3(_pad3(patch_size, 1))
+  d.post_patch = _i3(_pad3(post_patch_size, 1))
+  d.use_mean = 0 if mean is None else 1
+  d.mean = 0.0 if mean is None else float(mean)
+  if isinstance(min_distance, collections.abc.Sequence):
+    # The reference leaves `size` undefined for sequences (flow_field.py:232).
+    raise NotImplementedError('min_distance must be a scalar')
+  d.min_distance = int(min_distance)
+  d.threshold_rel = float(threshold_rel)
+  if not isinstance(peak_radius, collections.abc.Sequence):
+    peak_radius = (peak_radius,) * nd
+  d.peak_radius = _i3(_pad3([int(r) for r in peak_radius], 0))
+  d.method = method
+  d.stream = _dev.stream_ptr()
+  return d
+
+
+def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray,
+                 post_starts: np.ndarray, batch_size: int,
+                 progress_fn=None) -> np.ndarray:
+  """Enqueues every batch, returns peaks [n_batches * batch_size, dim + 2]."""
+  lib = _abi.load()
+  nd = res.ndim
+  n = pre_starts.shape[0]
+  assert n % batch_size == 0
+  n_batches = n // batch_size
+  starts = torch.from_numpy(
+      np.ascontiguousarray(
+          np.stack([pre_starts, post_starts]).astype(np.int32))).to(res.dev)
+  peaks = torch.empty((n, nd + 2), dtype=torch.float32, device=res.dev)
+  desc.batch = batch_size
+  desc.pre_starts = starts.data_ptr()
+  desc.post_starts = starts.data_ptr()
+  need = lib.sfm_xcorr_workspace_bytes(C.byref(desc))
+  if need == 0:
+    _abi.check(-1)
+  ws = _dev.workspace(need, res.dev)
+  desc.workspace = ws.data_ptr()
+  desc.workspace_bytes = ws.numel()
+  row_bytes = batch_size * nd * 4
+  it = range(n_batches) if progress_fn is None else progress_fn
+  for bi, _ in enumerate(it):
+    desc.pre_starts = starts.data_ptr() + bi * row_bytes
+    desc.post_starts = starts.data_ptr() + (n_batches + bi) * row_bytes
+    out_ptr = peaks.data_ptr() + bi * batch_size * (nd + 2) * 4
+    _abi.check(lib.sfm_xcorr_peaks(C.byref(desc), out_ptr))
+  return peaks.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------
+# public: functions taking pre-extracted patches / surfaces
+# ---------------------------------------------------------------------------
+def masked_xcorr(prev: Array, curr: Array, prev_mask: Array | None = None,
+                 curr_mask: Array | None = None, use_jax: bool = False,
+                 dim: int = 2, method: int = _abi.XCORR_AUTO) -> np.ndarray:
+  """Cross-correlation between two (masked) image batches.
+
+  Same contract as flow_field.masked_xcorr (flow_field.py:36-156): full linear
+  correlation over the last `dim` axes (leading axes are batch); RAW values
+  without masks, Padfield-normalised values in [-1, 1] with masks; the
+  normalisation tolerances use maxima over the whole batch.  `use_jax` is
+  accepted for signature compatibility; the computation always runs on the
+  GPU in float32.
+  """
+  del use_jax
+  dev = _dev.device()
+  prev = np.asarray(prev)
+  curr = np.asarray(curr)
+  if dim not in (2, 3):
+    raise NotImplementedError('dim must be 2 or 3')
+  lead = prev.shape[:-dim]
+  if curr.shape[:-dim] != lead:
+    raise ValueError('prev and curr need identical batch dimensions')
+  b = int(np.prod(lead)) if lead else 1
+  p = prev.shape[-dim:]
+  q = curr.shape[-dim:]
+
+  def stack(a, sz):
+    if a is None:
+      return None
+    a = np.asarray(a).reshape((b * sz[0],) + tuple(sz[1:]))
+    return a
+
+  if prev_mask is not None:
+    prev_mask = np.broadcast_to(np.asarray(prev_mask), prev.shape)
+  if curr_mask is not None:
+    curr_mask = np.broadcast_to(np.asarray(curr_mask), curr.shape)
+  res = _Resident(stack(prev.astype(np.float32, copy=False), p),
+                  stack(curr.astype(np.float32, copy=False), q),
+                  stack(prev_mask, p), stack(curr_mask, q), dev)
+  desc = _make_desc(res, p, q, 0.0, 2, 0.5, 5, method)
+  st_pre = np.zeros((b, dim), np.int32)
+  st_post = np.zeros((b, dim), np.int32)
+  st_pre[:, 0] = np.arange(b) * p[0]
+  st_post[:, 0] = np.arange(b) * q[0]
+  starts = torch.from_numpy(np.stack([st_pre, st_post])).to(dev)
+  desc.batch = b
+  desc.pre_starts = starts.data_ptr()
+  desc.post_starts = starts.data_ptr() + b * dim * 4
+  lib = _abi.load()
+  need = lib.sfm_xcorr_workspace_bytes(C.byref(desc))
+  ws = _dev.workspace(need, dev)
+  desc.workspace = ws.data_ptr()
+  desc.workspace_bytes = ws.numel()
+  s = tuple(int(a + c - 1) for a, c in zip(p, q))
+  out = torch.empty((b,) + s, dtype=torch.float32, device=dev)
+  _abi.check(lib.sfm_xcorr_surface(C.byref(desc), out.data_ptr()))
+  return out.cpu().numpy().reshape(tuple(lead) + s)
+
+
+def _batched_peaks(img, center_offset, min_distance: int, threshold_rel: float,
+                   peak_radius: int | Sequence[int] = 5) -> np.ndarray:
+  """Peak statistics for a batch of correlation surfaces -> [b, dim + 2].
+
+  Same contract as flow_field._batched_peaks (flow_field.py:205-275),
+  including its batch-coupled second-peak suppression.
+  """
+  dev = _dev.device()
+  surf = _dev.as_device_f32(img, dev, copy=False)
+  dim = surf.ndim - 1
+  if dim not in (2, 3):
+    raise NotImplementedError('surfaces must be 2-D or 3-D')
+  if isinstance(min_distance, collections.abc.Sequence):
+    raise NotImplementedError('min_distance must be a scalar')
+  if not isinstance(peak_radius, collections.abc.Sequence):
+    peak_radius = (peak_radius,) * dim
+  d = _abi.SfmPeaksDesc()
+  d.ndim = dim
+  d.batch = surf.shape[0]
+  d.shape = _i3(_pad3(surf.shape[1:], 1))
+  d.center_offset = (C.c_float * 3)(
+      *([0.0] * (3 - dim) + [float(c) for c in center_offset]))
+  d.min_distance = int(min_distance)
+  d.threshold_rel = float(threshold_rel)
+  d.peak_radius = _i3(_pad3([int(r) for r in peak_radius], 0))
+  d.surface = surf.data_ptr()
+  d.stream = _dev.stream_ptr()
+  lib = _abi.load()
+  ws = _dev.workspace(lib.sfm_peaks_workspace_bytes(C.byref(d)), dev)
+  d.workspace = ws.data_ptr()
+  d.workspace_bytes = ws.numel()
+  out = torch.empty((surf.shape[0], dim + 2), dtype=torch.float32, device=dev)
+  _abi.check(lib.sfm_peaks(C.byref(d), out.data_ptr()))
+  return out.cpu().numpy()
+
+
+def batched_xcorr_peaks(pre_image, post_image, pre_mask, post_mask,
+                        patch_size: Sequence[int], starts, mean: float | None,
+                        min_distance: int = 2, threshold_rel: float = 0.5,
+                        peak_radius: int | Sequence[int] = 5,
+                        post_patch_size: Sequence[int] | None = None,
+                        post_starts=None,
+                        method: int = _abi.XCORR_AUTO) -> np.ndarray:
+  """One batch of patch correlations + peak statistics -> [b, dim + 2].
+
+  Same contract as flow_field.batched_xcorr_peaks (flow_field.py:374-441).
+  """
+  dev = _dev.device()
+  res = _Resident(pre_image, post_image, pre_mask, post_mask, dev)
+  patch_size = tuple(int(p) for p in patch_size)
+  post_patch_size = patch_size if post_patch_size is None else tuple(
+      int(p) for p in post_patch_size)
+  starts = np.asarray(starts).astype(np.int32)
+  post_starts = starts if post_starts is None else np.asarray(
+      post_starts).astype(np.int32)
+  desc = _make_desc(res, patch_size, post_patch_size, mean, min_distance,
+                    threshold_rel, peak_radius, method)
+  return _run_batches(res, desc, starts, post_starts, starts.shape[0])
+
+
+# ---------------------------------------------------------------------------
+# public: the calculator
+# ---------------------------------------------------------------------------
+class JAXMaskedXCorrWithStatsCalculator:
+  """Estimates optical flow using masked cross-correlation (GPU, HIP).
+
+  Name, constructor and `flow_field` signature follow the reference class
+  (flow_field.py:449-492) so existing drivers run unchanged.
+  """
+
+  non_spatial_flow_channels = 2  # peak sharpness, peak ratio
+
+  def __init__(self, mean: float | None = None, peak_min_distance: float = 2,
+               peak_radius: float = 5, method: int = _abi.XCORR_AUTO):
+    self._mean = mean
+    self._min_distance = peak_min_distance
+    self._peak_radius = peak_radius
+    self._method = method
+
+  # -- host planning -------------------------------------------------------
+  @staticmethod
+  def _targeting(field, tstep, starts, psize, img_shape):
+    """Integer [z]yx patch shifts from a targeting field, kept in bounds
+    (flow_field.py:626-649 / :652-677)."""
+    centre = (np.array(psize) // 2).reshape((1, -1))
+    tstep = np.array(tstep).reshape((1, -1))
+    query = np.round((starts + centre) / tstep).astype(int)
+    q = [np.clip(query[:, i], 0, field.shape[i + 1] - 1)
+         for i in range(query.shape[-1])]
+    off = np.nan_to_num(field[(slice(None),) + tuple(q)].T).astype(int)[:, ::-1]
+    new_starts = starts + off
+    off = off - np.minimum(new_starts, 0)
+    shape = np.array(img_shape)[None, ...]
+    overshoot = np.maximum(new_starts + np.array(psize)[None, ...], shape) - shape
+    return off - overshoot
+
+  def plan(self, pre_shape, post_shape, patch_size, step, pre_mask=None,
+           post_mask=None, selection_mask=None, max_masked=0.75,
+           batch_size=4096, post_patch_size=None, pre_targeting_field=None,
+           pre_targeting_step=None, post_targeting_field=None,
+           post_targeting_step=None):
+    """Everything flow_field() decides on the host before touching the GPU.
+
+    Returns a dict with the output shape, the row-major grid positions, the
+    per-batch (edge-padded) pre/post start coordinates and targeting offsets.
+    """
+    nd = len(pre_shape)
+    out_shape = (np.array(post_shape) - (np.array(post_patch_size) - step)) // step
+    out_sel = tuple(slice(0, int(s)) for s in out_shape)
+    if selection_mask is None:
+      selection_mask = np.ones(out_shape, dtype=bool)
+    else:
+      selection_mask = np.array(selection_mask[out_sel], dtype=bool)
+    for mask, psz in ((pre_mask, patch_size), (post_mask, post_patch_size)):
+      if mask is None:
+        continue
+      s = _query_integral_image(_integral_image(mask), psz, step)
+      m = (s / np.prod(psz) >= max_masked)[out_sel]
+      selection_mask[m] = False
+
+    patch_offset = ((np.array(patch_size) - post_patch_size) // 2)[None, ...]
+    oyx = np.array(np.where(selection_mask)).T.reshape(-1, nd)
+    n = oyx.shape[0]
+    n_batches = (n + batch_size - 1) // batch_size
+    pad = n_batches * batch_size - n
+    # Every batch is padded to `batch_size` by repeating its LAST position
+    # (flow_field.py:614-618) so that batch-coupled results do not change.
+    pos_all = oyx
+    if pad:
+      pos_all = np.concatenate([oyx, np.repeat(oyx[-1:], pad, axis=0)])
+    post_starts = pos_all * np.array(step).reshape((1, -1))
+    pre_starts = np.clip(post_starts - patch_offset, 0, np.inf).astype(int)
+    tg_offsets = post_offsets = None
+    if pre_targeting_field is not None and pre_targeting_step is not None:
+      tg_offsets = self._targeting(pre_targeting_field, pre_targeting_step,
+                                   pre_starts, patch_size, pre_shape)
+      pre_starts = pre_starts + tg_offsets
+    if post_targeting_field is not None and post_targeting_step is not None:
+      post_offsets = self._targeting(post_targeting_field, post_targeting_step,
+                                     post_starts, post_patch_size, post_shape)
+      post_starts = post_starts + post_offsets
+    pre_starts = np.clip(pre_starts, 0, np.inf).astype(int)
+    post_starts = np.clip(post_starts, 0, np.inf).astype(int)
+    return dict(out_shape=out_shape, positions=oyx, n_batches=n_batches,
+                pre_starts=pre_starts, post_starts=post_starts,
+                tg_offsets=tg_offsets, post_offsets=post_offsets)
+
+  # -- the reference entry point ----------------------------------------------
+  def flow_field(
+      self,
+      pre_image: np.ndarray,
+      post_image: np.ndarray,
+      patch_size: int | Sequence[int],
+      step: int | Sequence[int],
+      pre_mask=None,
+      post_mask=None,
+      mask_only_for_patch_selection=False,
+      selection_mask=None,
+      max_masked=0.75,
+      batch_size=4096,
+      post_patch_size: int | Sequence[int] | None = None,
+      pre_targeting_field: np.ndarray | None = None,
+      pre_targeting_step: int | Sequence[int] | None = None,
+      post_targeting_field: np.ndarray | None = None,
+      post_targeting_step: int | Sequence[int] | None = None,
+      progress_fn: Callable[[list[T]], Iterator[T]] = _silent_fn,
+  ):
+    """Computes the flow field from post to pre (flow_field.py:474-712).
+
+    Arguments and result are those of the reference method.  Images may also
+    be torch CUDA tensors (uint8 or float32) that are already resident in HBM.
+    """
+    assert pre_image.ndim == post_image.ndim
+    nd = pre_image.ndim
+    if not isinstance(patch_size, collections.abc.Sequence):
+      patch_size = (patch_size,) * nd
+    if post_patch_size is not None:
+      if not isinstance(post_patch_size, collections.abc.Sequence):
+        post_patch_size = (post_patch_size,) * nd
+    else:
+      post_patch_size = patch_size
+    if not isinstance(step, collections.abc.Sequence):
+      step = (step,) * nd
+    if pre_targeting_step is not None and not isinstance(
+        pre_targeting_step, collections.abc.Sequence):
+      pre_targeting_step = (pre_targeting_step,) * nd
+    if post_targeting_step is not None and not isinstance(
+        post_targeting_step, collections.abc.Sequence):
+      post_targeting_step = (post_targeting_step,) * nd
+    assert len(patch_size) == nd
+    assert len(post_patch_size) == nd
+    assert len(step) == nd
+    patch_size = tuple(int(p) for p in patch_size)
+    post_patch_size = tuple(int(p) for p in post_patch_size)
+    step = tuple(int(s) for s in step)
+
+    plan = self.plan(tuple(pre_image.shape), tuple(post_image.shape),
+                     patch_size, step, pre_mask, post_mask, selection_mask,
+                     max_masked, batch_size, post_patch_size,
+                     pre_targeting_field, pre_targeting_step,
+                     post_targeting_field, post_targeting_step)
+    out_shape = plan['out_shape']
+    output = np.full([self.non_spatial_flow_channels + nd] + out_shape.tolist(),
+                     np.nan, dtype=np.float32)
+    pos = plan['positions']
+    n = pos.shape[0]
+    if n == 0:
+      return output
+
+    if mask_only_for_patch_selection:
+      pre_mask = post_mask = None
+    dev = _dev.device()
+    res = _Resident(pre_image, post_image, pre_mask, post_mask, dev)
+    desc = _make_desc(res, patch_size, post_patch_size, self._mean,
+                      self._min_distance, 0.5, self._peak_radius, self._method)
+    # progress_fn receives the list of per-batch grid positions like the
+    # reference's (flow_field.py:610) and is only iterated for its side effects.
+    batches = [pos[i:i + batch_size] for i in range(0, n, batch_size)]
+    peaks = _run_batches(res, desc, plan['pre_starts'], plan['post_starts'],
+                         batch_size, progress_fn(batches))[:n]
+    if plan['tg_offsets'] is not None:
+      peaks[:, :nd] += plan['tg_offsets'][:n, ::-1]  # xy[z]
+    if plan['post_offsets'] is not None:
+      peaks[:, :nd] -= plan['post_offsets'][:n, ::-1]
+    output[(slice(None),) + tuple(pos.T)] = peaks.T
+    return output

@@ -1,0 +1,222 @@
+"""HIP flow-field path vs golden vectors, reference KATs and the oracle (-m gpu)."""
+import numpy as np
+import pytest
+
+from oracle import flow_oracle
+from tests.util import check_flow
+
+pytestmark = pytest.mark.gpu
+
+METHODS = [1, 0]  # SFM_XCORR_DIRECT, SFM_XCORR_AUTO (MFMA where eligible)
+
+
+# -- the reference's own known-answer tests (tests/flow_field_test.py) -------
+@pytest.mark.parametrize('method', METHODS)
+def test_kat_delta_images(gpu, method):
+  from sofima_amd import flow_field
+  pre_image = np.zeros((120, 120), dtype=np.uint8)
+  post_image = np.zeros((120, 120), dtype=np.uint8)
+  pre_image[60, 60] = 255
+  post_image[70, 53] = 255
+  calculator = flow_field.JAXMaskedXCorrWithStatsCalculator(method=method)
+  field = calculator.flow_field(pre_image, post_image, patch_size=80, step=40,
+                                batch_size=4)
+  np.testing.assert_array_equal([4, 2, 2], field.shape)
+  np.testing.assert_array_equal(7 * np.ones((2, 2)), field[0, ...])
+  np.testing.assert_array_equal(-10 * np.ones((2, 2)), field[1, ...])
+  np.testing.assert_array_equal(np.zeros((2, 2)), field[3, ...])
+
+  post_image[54, 68] = 255
+  post_image_mask = np.zeros((128, 128), dtype=bool)
+  post_image_mask[:55, :70] = 1
+  field = calculator.flow_field(pre_image, post_image, patch_size=80, step=40,
+                                post_mask=post_image_mask, batch_size=4)
+  np.testing.assert_array_equal([4, 2, 2], field.shape)
+  np.testing.assert_array_equal(7 * np.ones((2, 2)), field[0, ...])
+  np.testing.assert_array_equal(-10 * np.ones((2, 2)), field[1, ...])
+  np.testing.assert_array_equal(np.zeros((2, 2)), field[3, ...])
+
+
+def test_kat_3d(gpu):
+  from sofima_amd import flow_field
+  pre_image = np.zeros((50, 100, 100), dtype=np.uint8)
+  post_image = np.zeros((50, 100, 100), dtype=np.uint8)
+  pre_image[25, 50, 50] = 255
+  post_image[22, 45, 54] = 255
+  calculator = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  flow = calculator.flow_field(pre_image, post_image, patch_size=(40, 80, 80),
+                               step=10, batch_size=1)
+  np.testing.assert_array_equal([5, 2, 3, 3], flow.shape)
+  np.testing.assert_array_equal(np.full([2, 3, 3], -4), flow[0, ...])
+  np.testing.assert_array_equal(np.full([2, 3, 3], 5), flow[1, ...])
+  np.testing.assert_array_equal(np.full([2, 3, 3], 3), flow[2, ...])
+
+
+def test_kat_peak(gpu):
+  from sofima_amd import flow_field
+  hy, hx = np.mgrid[:50, :50]
+  cy, cx = 20, 28
+  hy = cy - hy
+  hx = cx - hx
+  r = np.sqrt(2 * hx**2 + hy**2)
+  peak_max = 10
+  xcorr = peak_max * np.exp(-r / 4)
+  peaks = flow_field._batched_peaks(xcorr[np.newaxis, ...], (25, 25),
+                                    min_distance=2, threshold_rel=0.5,
+                                    peak_radius=(2, 3))
+  np.testing.assert_array_equal([1, 4], peaks.shape)
+  x32 = xcorr.astype(np.float32)
+  peak_support = np.min(x32[cy - 2:cy + 3, cx - 3:cx + 4])
+  assert peaks[0, 0] == 3
+  assert peaks[0, 1] == -5
+  assert peaks[0, 2] == np.float32(peak_max) / peak_support
+  assert peaks[0, 3] == 0
+
+
+@pytest.mark.parametrize('method', METHODS)
+def test_kat_post_targeting(gpu, method):
+  from sofima_amd import flow_field
+  pre_image = np.zeros((120, 120), dtype=np.uint8)
+  post_image = np.zeros((120, 120), dtype=np.uint8)
+  pre_image[50, 55] = 255
+  post_image[100, 100] = 255
+  calculator = flow_field.JAXMaskedXCorrWithStatsCalculator(method=method)
+  field = calculator.flow_field(pre_image, post_image, patch_size=80, step=40,
+                                batch_size=4)
+  np.testing.assert_array_equal(np.isnan(field[:, 0, 0]), True)
+  post_targeting_field = np.full((2, 2, 2), 40.0, dtype=np.float32)
+  field = calculator.flow_field(pre_image, post_image, patch_size=80, step=40,
+                                batch_size=4,
+                                post_targeting_field=post_targeting_field,
+                                post_targeting_step=40)
+  np.testing.assert_array_equal([4, 2, 2], field.shape)
+  np.testing.assert_array_equal(-45 * np.ones((2, 2)), field[0, ...])
+  np.testing.assert_array_equal(-50 * np.ones((2, 2)), field[1, ...])
+
+
+# -- golden vectors ------------------------------------------------------------
+def test_masked_xcorr_golden(gpu, golden):
+  from sofima_amd import flow_field
+  g = golden('xcorr_np')
+  got = flow_field.masked_xcorr(g['a'], g['b'])
+  scale = np.abs(g['unmasked']).max()
+  np.testing.assert_allclose(got, g['unmasked'], atol=1e-5 * scale)
+  got = flow_field.masked_xcorr(g['a'], g['b'], g['am'], g['bm'])
+  np.testing.assert_allclose(got, g['masked'], atol=2e-5)
+  got = flow_field.masked_xcorr(g['a3'], g['b3'], dim=3)
+  scale = np.abs(g['unmasked3']).max()
+  np.testing.assert_allclose(got, g['unmasked3'], atol=1e-5 * scale)
+  got = flow_field.masked_xcorr(g['a3'], g['b3'], g['am3'], g['bm3'], dim=3)
+  np.testing.assert_allclose(got, g['masked3'], atol=2e-5)
+  # one-sided mask: float32 semantics (see oracle docstring on the 0.3 tie)
+  got = flow_field.masked_xcorr(g['a'], g['b'], g['am'], None)
+  want = flow_oracle.xcorr_surface(g['a'], g['b'], g['am'], None)
+  np.testing.assert_allclose(got, want, atol=2e-5)
+
+
+def test_batched_peaks_golden(gpu, golden):
+  from sofima_amd import flow_field
+  g = golden('peaks')
+  got = flow_field._batched_peaks(g['imgs'], (15, 15), 2, 0.5, 5)
+  np.testing.assert_array_equal(got, g['out_all'])
+  got = flow_field._batched_peaks(g['imgs'][:1], (15, 15), 2, 0.5, 5)
+  np.testing.assert_array_equal(got, g['out_0'])
+  got = flow_field._batched_peaks(g['imgs'][5:], (15, 15), 2, 0.5, (2, 3))
+  np.testing.assert_array_equal(got, g['out_r'])
+  got = flow_field._batched_peaks(g['vol'], (4, 5, 6), 1, 0.5, (1, 2, 2))
+  np.testing.assert_array_equal(got, g['out_3d'])
+
+
+def test_peaks_plateau_overflow(gpu):
+  """More equal-valued peaks than the candidate list holds -> rescan path."""
+  from sofima_amd import flow_field
+  img = np.full((2, 80, 80), 2.0, np.float32)
+  img[1, 40, 41] = 3.0
+  got = flow_field._batched_peaks(img, (40, 40), 2, 0.5, 5)
+  want = flow_oracle.batched_peaks(img, (40, 40), 2, 0.5, 5)
+  np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize('method', METHODS)
+def test_flow_golden_2d(gpu, golden, method):
+  from sofima_amd import flow_field
+  g = golden('flow2d')
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator(method=method)
+  pre, post = g['pre'], g['post']
+  check_flow(calc.flow_field(pre, post, 48, 24, batch_size=8), g['plain'])
+  check_flow(
+      calc.flow_field(pre, post, 48, 24, pre_mask=g['pre_mask'],
+                      post_mask=g['post_mask'], batch_size=8), g['masked'])
+  check_flow(
+      calc.flow_field(pre, post, 48, 24, pre_mask=g['pre_mask'],
+                      post_mask=g['post_mask'],
+                      mask_only_for_patch_selection=True, max_masked=0.5,
+                      batch_size=16), g['masksel'])
+  check_flow(
+      calc.flow_field(pre, post, 48, 24, batch_size=8, post_patch_size=32),
+      g['postpatch'])
+  check_flow(
+      calc.flow_field(pre, post, (48, 32), (24, 16),
+                      selection_mask=np.pad(g['sel'], ((0, 0), (0, 4))),
+                      batch_size=5), g['selected'])
+  check_flow(
+      calc.flow_field(pre, post, 48, 24, batch_size=8,
+                      pre_targeting_field=g['tg_pre'], pre_targeting_step=48,
+                      post_targeting_field=g['tg_post'],
+                      post_targeting_step=64), g['targeted'])
+  calc_m = flow_field.JAXMaskedXCorrWithStatsCalculator(
+      mean=120.0, peak_min_distance=3, peak_radius=(3, 4), method=method)
+  check_flow(calc_m.flow_field(g['pre_f'], g['post_f'], 40, 20, batch_size=64),
+             g['float_mean'])
+
+
+def test_flow_golden_3d(gpu, golden):
+  from sofima_amd import flow_field
+  g = golden('flow3d')
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  check_flow(calc.flow_field(g['pre'], g['post'], (16, 24, 24), 8,
+                             batch_size=4), g['plain'])
+
+
+# -- against the oracle at production patch geometry -----------------------------
+def _em_pair(seed, h, w, shift=(3, -5), warp=0.0):
+  from scipy import ndimage
+  rng = np.random.default_rng(seed)
+  m = 16
+  base = ndimage.gaussian_filter(rng.standard_normal((h + 2 * m, w + 2 * m)), 2.0)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  dy, dx = shift
+  pre = base[m:m + h, m:m + w].copy()
+  post = base[m + dy:m + dy + h, m + dx:m + dx + w].copy()
+  if warp:
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    d = warp * np.sin(2 * np.pi * xx / 512) * np.cos(2 * np.pi * yy / 512)
+    post = ndimage.map_coordinates(post.astype(np.float32), [yy + d, xx - d],
+                                   order=1, mode='nearest')
+    post = np.clip(np.round(post), 0, 255).astype(np.uint8)
+  return pre, post
+
+
+@pytest.mark.parametrize('method', METHODS)
+def test_flow_production_geometry_vs_oracle(gpu, method):
+  """patch 160 / step 40 (em_2d defaults), unmasked raw path, warped pair."""
+  from sofima_amd import flow_field
+  pre, post = _em_pair(5, 640, 720, warp=3.0)
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator(method=method)
+  got = calc.flow_field(pre, post, 160, 40, batch_size=64)
+  want = flow_oracle.flow_field(pre, post, 160, 40, batch_size=64, workers=4)
+  check_flow(got, want, sharp_rtol=2e-3)
+
+
+def test_surface_u8_exact_vs_direct_oracle(gpu):
+  """uint8 patches: the surface equals the exact integer correlation of the
+  mean-subtracted patches to float32 rounding."""
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(9)
+  a = rng.integers(0, 256, (3, 96, 96)).astype(np.float32)
+  b = rng.integers(0, 256, (3, 96, 96)).astype(np.float32)
+  a0 = a - a.mean(axis=(1, 2), keepdims=True, dtype=np.float32)
+  b0 = b - b.mean(axis=(1, 2), keepdims=True, dtype=np.float32)
+  want = flow_oracle.xcorr_surface_direct(a0, b0)
+  got = flow_field.masked_xcorr(a0, b0)
+  np.testing.assert_allclose(got, want, atol=1e-5 * np.abs(want).max())
