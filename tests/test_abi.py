@@ -1,0 +1,89 @@
+"""The C-ABI library loads on a CPU-only box and exports what the header says."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from sofima_amd import _abi, _build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'sofima_amd.h')
+
+
+@pytest.fixture(scope='module')
+def lib():
+  if not os.path.exists(_abi.lib_path()):
+    _build.build()
+  return _abi.load()
+
+
+def _declared_functions():
+  text = open(HEADER).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(sfm_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree(lib):
+  declared = _declared_functions()
+  assert declared, 'no functions parsed from the header'
+  assert sorted(_abi.SIGNATURES) == declared
+  for name in declared:
+    assert hasattr(lib, name), f'{name} is declared but not exported'
+
+
+def test_version_and_error_channel(lib):
+  assert lib.sfm_version() == 1
+  # A NULL descriptor is rejected with a message, not a crash.
+  rc = lib.sfm_mesh_force(None, None)
+  assert rc == -1
+  assert b'NULL' in lib.sfm_last_error()
+  rc = lib.sfm_xcorr_peaks(None, None)
+  assert rc == -1
+  n = ctypes.c_int(-5)
+  assert lib.sfm_device_count(ctypes.byref(n)) == 0
+  assert n.value >= 0
+
+
+def test_struct_layouts_match_header():
+  """Field order of the ctypes structs == field order in the header."""
+  text = open(HEADER).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  for cname, cls in (('SfmXcorrDesc', _abi.SfmXcorrDesc),
+                     ('SfmPeaksDesc', _abi.SfmPeaksDesc),
+                     ('SfmMeshDesc', _abi.SfmMeshDesc),
+                     ('SfmFireState', _abi.SfmFireState),
+                     ('SfmChunkStats', _abi.SfmChunkStats)):
+    body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,
+                     re.S).group(1)
+    names = []
+    for decl in body.split(';'):
+      decl = decl.strip()
+      if not decl:
+        continue
+      for part in decl.split(','):
+        m = re.search(r'([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])*\s*$', part.strip())
+        names.append(m.group(1))
+    assert names == [f[0] for f in cls._fields_], cname
+
+
+def test_no_gpu_means_loud_failure():
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  import numpy as np
+  from sofima_amd import flow_field, mesh
+  with pytest.raises(_abi.SofimaAmdError):
+    mesh.inplane_force(np.zeros((2, 1, 4, 4)), 0.1, (10, 10))
+  with pytest.raises(_abi.SofimaAmdError):
+    flow_field.JAXMaskedXCorrWithStatsCalculator().flow_field(
+        np.zeros((64, 64), np.uint8), np.zeros((64, 64), np.uint8), 32, 16)
+
+
+def test_product_code_never_imports_the_oracle():
+  pkg = os.path.join(ROOT, 'sofima_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(('.py', '.hip', '.h', '.cpp')):
+        src = open(os.path.join(dirpath, f)).read()
+        assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f

@@ -1,0 +1,142 @@
+"""Pins the CPU oracle against the golden vectors made from the reference.
+
+xcorr_np.npz comes from the reference's genuine NumPy path
+(masked_xcorr(use_jax=False)); the other files from the reference source
+executed over the NumPy stand-in for jax (tests/golden/make_golden.py).
+"""
+import numpy as np
+import pytest
+
+from oracle import flow_oracle as fo
+from oracle import mesh_oracle as mo
+from tests.util import cfg_from, check_flow, load_cfgs
+
+
+def test_xcorr_surface_vs_reference_numpy_path(golden):
+  g = golden('xcorr_np')
+  for fn in (fo.xcorr_surface, fo.xcorr_surface_direct):
+    s = np.abs(g['unmasked']).max()
+    np.testing.assert_allclose(fn(g['a'], g['b']), g['unmasked'], atol=2e-6 * s)
+    np.testing.assert_allclose(fn(g['a'], g['b'], g['am'], g['bm']),
+                               g['masked'], atol=1e-6)
+    s = np.abs(g['unmasked3']).max()
+    np.testing.assert_allclose(fn(g['a3'], g['b3'], dim=3), g['unmasked3'],
+                               atol=2e-6 * s)
+    np.testing.assert_allclose(fn(g['a3'], g['b3'], g['am3'], g['bm3'], dim=3),
+                               g['masked3'], atol=1e-6)
+  # One-sided mask; the reference's NumPy path runs in float64 there.
+  np.testing.assert_allclose(
+      fo.xcorr_surface(g['a'], g['b'], g['am'], None, dtype=np.float64),
+      g['masked_prev_only'], atol=1e-6)
+  np.testing.assert_allclose(
+      fo.xcorr_surface_direct(g['a'], g['b'], g['am'], None),
+      g['masked_prev_only'], atol=1e-6)
+
+
+def test_batched_peaks_vs_golden(golden):
+  g = golden('peaks')
+  np.testing.assert_array_equal(
+      fo.batched_peaks(g['imgs'], (15, 15), 2, 0.5, 5), g['out_all'])
+  np.testing.assert_array_equal(
+      fo.batched_peaks(g['imgs'][:1], (15, 15), 2, 0.5, 5), g['out_0'])
+  np.testing.assert_array_equal(
+      fo.batched_peaks(g['imgs'][5:], (15, 15), 2, 0.5, (2, 3)), g['out_r'])
+  np.testing.assert_array_equal(
+      fo.batched_peaks(g['vol'], (4, 5, 6), 1, 0.5, (1, 2, 2)), g['out_3d'])
+  # The batch-coupled quirks are in the vectors: image 0 alone has ratio 1.25,
+  # batched with image 1 its second peak is suppressed.
+  assert g['out_0'][0, 3] == np.float32(1.25)
+  assert g['out_all'][0, 3] == 0
+  assert g['out_all'][2, 3] == 1.0          # single peak at flat index 0
+  assert np.isnan(g['out_all'][3]).all()    # all-zero surface
+
+
+def test_flow_field_vs_golden(golden):
+  g = golden('flow2d')
+  pre, post = g['pre'], g['post']
+  check_flow(fo.flow_field(pre, post, 48, 24, batch_size=8), g['plain'])
+  check_flow(fo.flow_field(pre, post, 48, 24, pre_mask=g['pre_mask'],
+                           post_mask=g['post_mask'], batch_size=8), g['masked'])
+  check_flow(fo.flow_field(pre, post, 48, 24, pre_mask=g['pre_mask'],
+                           post_mask=g['post_mask'],
+                           mask_only_for_patch_selection=True, max_masked=0.5,
+                           batch_size=16), g['masksel'])
+  check_flow(fo.flow_field(pre, post, 48, 24, batch_size=8, post_patch_size=32),
+             g['postpatch'])
+  check_flow(fo.flow_field(pre, post, (48, 32), (24, 16),
+                           selection_mask=np.pad(g['sel'], ((0, 0), (0, 4))),
+                           batch_size=5), g['selected'])
+  check_flow(fo.flow_field(pre, post, 48, 24, batch_size=8,
+                           pre_targeting_field=g['tg_pre'],
+                           pre_targeting_step=48,
+                           post_targeting_field=g['tg_post'],
+                           post_targeting_step=64), g['targeted'])
+  check_flow(fo.flow_field(g['pre_f'], g['post_f'], 40, 20, batch_size=64,
+                           mean=120.0, min_distance=3, peak_radius=(3, 4)),
+             g['float_mean'])
+  # the vectors exercise what they claim to
+  assert np.isnan(g['masksel'][0]).sum() > np.isnan(g['plain'][0]).sum()
+  assert (g['plain'][0] == -5).all() and (g['plain'][1] == 3).all()
+
+
+def test_flow_field_3d_vs_golden(golden):
+  g = golden('flow3d')
+  check_flow(fo.flow_field(g['pre'], g['post'], (16, 24, 24), 8, batch_size=4),
+             g['plain'])
+
+
+def test_forces_vs_golden(golden):
+  g = golden('mesh_force')
+  tol = dict(rtol=1e-5, atol=2e-6)
+  for poo in (0, 1):
+    np.testing.assert_allclose(
+        mo.inplane_force(g['x2'], 0.1, (40.0, 30.0), bool(poo)),
+        g[f'f2_{poo}'], **tol)
+    np.testing.assert_allclose(
+        mo.elastic_mesh_3d(g['x3'], 0.1, (20.0, 25.0, 14.0), bool(poo)),
+        g[f'f3_{poo}'], **tol)
+    np.testing.assert_allclose(
+        mo.elastic_mesh_3d(g['x3b'], 0.05, 16.0, bool(poo)), g[f'f3b_{poo}'],
+        **tol)
+    np.testing.assert_allclose(
+        mo.inplane_force(g['xf'], 0.1, (40.0, 40.0), bool(poo)),
+        g[f'ff_{poo}'], **tol)
+  planar = ((1, 0, 0), (0, 1, 0), (1, 1, 0), (-1, 1, 0))
+  np.testing.assert_allclose(
+      mo.elastic_mesh_3d(g['x3'], 0.1, (20.0, 25.0, 14.0), False, links=planar),
+      g['f3_planar'], **tol)
+
+
+@pytest.mark.parametrize('tag', ['fire1', 'fire10', 'fire100', 'fire_cap',
+                                 'fire_drift', 'damped10', 'noprev10',
+                                 'fire3d_20'])
+def test_velocity_verlet_vs_golden(golden, tag):
+  g = golden('mesh_vv')
+  c = load_cfgs(g)[tag]
+  cap = c['_force_cap']
+  cfg = cfg_from(c)
+  is3d = '3d' in tag
+  x0 = g['x30'] if is3d else g['x0']
+  prev = None if 'noprev' in tag else (g['prev3'] if is3d else g['prev'])
+  force = mo.elastic_mesh_3d if is3d else mo.inplane_force
+  st = mo.velocity_verlet(x0, np.zeros_like(x0), prev, cfg, cap,
+                          mesh_force=force)
+  for i, name in enumerate('xva'):
+    np.testing.assert_allclose(st[i], g[f'{tag}_{name}'], rtol=1e-4, atol=5e-5)
+  if cfg.fire:
+    np.testing.assert_allclose([float(s) for s in st[3:]], g[f'{tag}_scal'],
+                               rtol=1e-6)
+
+
+def test_relax_vs_golden(golden):
+  g = golden('mesh_relax')
+  cfgs = load_cfgs(g)
+  xs, ek, t = mo.relax_mesh(g['xr'], np.zeros_like(g['xr']),
+                            cfg_from(cfgs['fire']))
+  assert t == int(g['fire_t'])
+  np.testing.assert_allclose(xs, g['fire_x'], atol=1e-3)
+  np.testing.assert_allclose(ek, g['fire_ekin'], rtol=1e-2, atol=1e-9)
+  xs, ek, t = mo.relax_mesh(g['xe'], g['pe'], cfg_from(cfgs['em2d']))
+  assert t == int(g['em2d_t'])
+  np.testing.assert_allclose(xs, g['em2d_x'], atol=5e-3)
+  np.testing.assert_allclose(ek, g['em2d_ekin'], rtol=5e-2, atol=1e-6)

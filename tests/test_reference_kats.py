@@ -1,0 +1,125 @@
+"""The reference's own known-answer tests, re-typed against the CPU oracle.
+
+Sources: /root/reference/tests/flow_field_test.py:24-125 and
+tests/mesh_test.py:25-144.  The same cases run against the HIP path in
+tests/test_gpu_flow.py / tests/test_gpu_mesh.py.
+"""
+import types
+
+import numpy as np
+
+from oracle import flow_oracle as fo
+from oracle import mesh_oracle as mo
+
+
+def test_delta_images_and_mask():
+  pre = np.zeros((120, 120), np.uint8)
+  post = np.zeros((120, 120), np.uint8)
+  pre[60, 60] = 255
+  post[70, 53] = 255
+  f = fo.flow_field(pre, post, 80, 40, batch_size=4)
+  assert f.shape == (4, 2, 2)
+  np.testing.assert_array_equal(f[0], 7)
+  np.testing.assert_array_equal(f[1], -10)
+  np.testing.assert_array_equal(f[3], 0)
+  post[54, 68] = 255
+  mask = np.zeros((128, 128), bool)
+  mask[:55, :70] = 1
+  f = fo.flow_field(pre, post, 80, 40, post_mask=mask, batch_size=4)
+  np.testing.assert_array_equal(f[0], 7)
+  np.testing.assert_array_equal(f[1], -10)
+  np.testing.assert_array_equal(f[3], 0)
+
+
+def test_3d():
+  pre = np.zeros((50, 100, 100), np.uint8)
+  post = np.zeros((50, 100, 100), np.uint8)
+  pre[25, 50, 50] = 255
+  post[22, 45, 54] = 255
+  f = fo.flow_field(pre, post, (40, 80, 80), 10, batch_size=1)
+  assert f.shape == (5, 2, 3, 3)
+  np.testing.assert_array_equal(f[0], -4)
+  np.testing.assert_array_equal(f[1], 5)
+  np.testing.assert_array_equal(f[2], 3)
+
+
+def test_peak():
+  hy, hx = np.mgrid[:50, :50]
+  cy, cx = 20, 28
+  r = np.sqrt(2 * (cx - hx)**2 + (cy - hy)**2)
+  xcorr = (10 * np.exp(-r / 4)).astype(np.float32)
+  p = fo.batched_peaks(xcorr[None], (25, 25), 2, 0.5, (2, 3))
+  assert p.shape == (1, 4)
+  assert p[0, 0] == 3 and p[0, 1] == -5 and p[0, 3] == 0
+  assert p[0, 2] == xcorr[cy, cx] / xcorr[cy - 2:cy + 3, cx - 3:cx + 4].min()
+
+
+def test_post_targeting():
+  pre = np.zeros((120, 120), np.uint8)
+  post = np.zeros((120, 120), np.uint8)
+  pre[50, 55] = 255
+  post[100, 100] = 255
+  f = fo.flow_field(pre, post, 80, 40, batch_size=4)
+  assert np.isnan(f[:, 0, 0]).all()
+  tg = np.full((2, 2, 2), 40.0, np.float32)
+  f = fo.flow_field(pre, post, 80, 40, batch_size=4, post_targeting_field=tg,
+                    post_targeting_step=40)
+  np.testing.assert_array_equal(f[0], -45)
+  np.testing.assert_array_equal(f[1], -50)
+
+
+def _cfg(**kw):
+  base = dict(f_alpha=0.99, f_inc=1.1, f_dec=0.5, alpha=0.1, n_min=5,
+              dt_max=10.0, start_cap=1e6, final_cap=1e6, cap_scale=1.1,
+              cap_upscale_every=100, prefer_orig_order=False,
+              remove_drift=False, fire=True)
+  base.update(kw)
+  return types.SimpleNamespace(**base)
+
+
+def test_relaxation_fire_and_damped():
+  for fire, gamma in ((True, 0.0), (False, 0.9 * np.sqrt(4 * 0.1))):
+    x = np.zeros((2, 1, 50, 50))
+    x[0, 0, 20:30, 10] = 3
+    x[0, 0, 20:30, 40] = -4
+    x[1, 0, 30, 10:20] = 2
+    cfg = _cfg(dt=0.01, gamma=gamma, k0=0.1, k=0.1, stride=(10, 10),
+               num_iters=100, max_iters=10000, stop_v_max=0.001, fire=fire)
+    new_x, _, _ = mo.relax_mesh(x, np.zeros_like(x), cfg)
+    np.testing.assert_array_almost_equal(new_x, np.zeros_like(x), decimal=3)
+
+
+def test_equilibrium():
+  x = np.zeros((2, 1, 10, 10))
+  np.testing.assert_array_equal(x, mo.inplane_force(x, 1.0, (40.0, 40.0)))
+  x = np.zeros((3, 10, 10, 10))
+  np.testing.assert_array_equal(x, mo.elastic_mesh_3d(x, 1.0, 40.0))
+  x = np.zeros((3, 5, 10, 10, 10))
+  np.testing.assert_array_equal(x, mo.elastic_mesh_3d(x, 1.0, 40.0))
+
+
+def test_force_and_consistency():
+  x = np.zeros((2, 1, 10, 10))
+  dx, dy = 4, -3
+  x[0, 0, 5, 5] = dx
+  x[1, 0, 5, 5] = dy
+  k, l0 = 0.1, 10.0
+  f = mo.inplane_force(x, k, (l0, 10))
+  l = np.sqrt((l0 + dx)**2 + dy**2)
+  np.testing.assert_allclose(
+      [k * (l - l0) * (l0 + dx) / l, k * (l - l0) * dy / l], f[:, 0, 5, 4],
+      rtol=1e-6)
+  l = np.sqrt((l0 - dx)**2 + (l0 - dy)**2)
+  l2, k2 = l0 * np.sqrt(2.0), k / np.sqrt(2.0)
+  np.testing.assert_allclose(
+      [-k2 * (l - l2) * (l0 - dx) / l, -k2 * (l - l2) * (l0 - dy) / l],
+      f[:, 0, 6, 6], rtol=1e-5)
+  planar = ((1, 0, 0), (0, 1, 0), (1, 1, 0), (-1, 1, 0))
+  rng = np.random.default_rng(42)
+  x = rng.random((3, 1, 50, 50))
+  x[2] = 0
+  for poo in (False, True):
+    np.testing.assert_allclose(
+        mo.inplane_force(x[:2], 0.01, (40.0, 40.0), poo)[:2],
+        mo.elastic_mesh_3d(x, 0.01, (40.0, 40.0, 14.0), poo, links=planar)[:2],
+        atol=1e-5)
