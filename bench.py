@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Headline benchmark: patch-xcorr Mpix/s + mesh node-updates/s on 8192^2 tiles.
+
+One "step" = one pass of the hot path over one synthetic 8192x8192 EM tile
+pair (BASELINE.json configs[1]):
+  1. flow_field(pre, post, patch 160, step 40, batch 1024)  -> [4, 201, 201]
+  2. relax_mesh([2, 1, 205, 205], prev from that flow, em_2d FIRE config,
+     1000 iterations)
+with the images already resident in HBM.  With --gpus N every rank processes
+its own independent tile pair (weak scaling, no data-path collective); the time
+is the max over ranks.
+
+Prints ONE JSON line (rank 0).  `value` is patch-xcorr Mpix/s = post-image
+pixels / wall time of flow_field(); the mesh figure is in the
+`mesh` object.  `roofline` describes the dominant kernel (the patch-correlation
+kernel), timed with HIP events inside the timed region through the library's
+sfm_profile_* hooks.  `cpu_baseline` times the CPU oracle (a NumPy/SciPy port
+of the reference algorithm) on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATCH, STEP, BATCH = 160, 40, 1024
+MESH_ITERS = 1000
+# MI355X peaks (MI355X_MICROARCH.md): dense int8 MFMA ~= 2x bf16 = 5.0 POP/s,
+# f32 vector/MFMA 157.3 TFLOP/s, HBM 8 TB/s.
+PEAK_I8_TOPS = 5000.0
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_pair(size, seed, shift=(3, -5)):
+  """EM-like texture pair: low-pass noise, integer content shift + fresh
+  noise in the second image."""
+  from scipy import ndimage
+  rng = np.random.default_rng(seed)
+  m = 16
+  base = ndimage.gaussian_filter(
+      rng.standard_normal((size + 2 * m, size + 2 * m), dtype=np.float32), 2.0)
+  base = (base - base.min()) / (base.max() - base.min()) * 255
+  dy, dx = shift
+  pre = base[m:m + size, m:m + size]
+  post = base[m + dy:m + dy + size, m + dx:m + dx + size]
+  post = post + rng.standard_normal(post.shape, dtype=np.float32) * 4
+  return (np.clip(pre, 0, 255).astype(np.uint8),
+          np.clip(post, 0, 255).astype(np.uint8))
+
+
+def mesh_inputs(flow, pad):
+  """prev = flow padded with NaN by patch//2//step nodes (em_alignment nb)."""
+  f = np.pad(flow[:2], ((0, 0), (pad, pad), (pad, pad)),
+             constant_values=np.nan)
+  return f[:, None].astype(np.float32)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=3)
+  ap.add_argument('--warmup', type=int, default=1)
+  ap.add_argument('--size', type=int, default=8192)
+  ap.add_argument('--method', type=int, default=0,
+                  help='0 auto, 1 direct f32, 2 int8 MFMA')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--mesh-iters', type=int, default=MESH_ITERS)
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  from sofima_amd import _abi, flow_field, mesh
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', local_rank))
+  assert world == args.gpus or world == 1, (world, args.gpus)
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  lib = _abi.load()
+
+  size = args.size
+  pre, post = synth_pair(size, 1002 + rank)
+  pre_t = torch.from_numpy(pre).to(dev)
+  post_t = torch.from_numpy(post).to(dev)
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator(method=args.method)
+  cfg = mesh.IntegrationConfig(
+      dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(STEP, STEP),
+      num_iters=args.mesh_iters, max_iters=args.mesh_iters, stop_v_max=0.005,
+      dt_max=1000, start_cap=0.01, final_cap=10, prefer_orig_order=True)
+  pad = PATCH // 2 // STEP
+
+  def flow_step():
+    return calc.flow_field(pre_t, post_t, PATCH, STEP, batch_size=BATCH)
+
+  def mesh_step(prev):
+    x0 = torch.zeros(prev.shape, dtype=torch.float32, device=dev)
+    return mesh.relax_mesh(x0, prev, cfg)
+
+  def barrier():
+    torch.cuda.synchronize(dev)
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize(dev)
+
+  flow = None
+  for _ in range(args.warmup):
+    flow = flow_step()
+    prev_t = torch.from_numpy(mesh_inputs(flow, pad)).to(dev)
+    mesh_step(prev_t)
+  if flow is None:
+    flow = flow_step()
+    prev_t = torch.from_numpy(mesh_inputs(flow, pad)).to(dev)
+
+  prof = _abi.SfmProfile()
+  lib.sfm_profile_read(C.byref(prof))  # reset
+  lib.sfm_profile_enable(1)
+  barrier()
+  t_flow = t_mesh = 0.0
+  t0 = time.perf_counter()
+  mesh_steps_done = 0
+  for _ in range(args.steps):
+    a = time.perf_counter()
+    flow = flow_step()
+    torch.cuda.synchronize(dev)
+    b = time.perf_counter()
+    _, _, t_iters = mesh_step(prev_t)
+    torch.cuda.synchronize(dev)
+    c = time.perf_counter()
+    t_flow += b - a
+    t_mesh += c - b
+    mesh_steps_done += t_iters
+  barrier()
+  elapsed = time.perf_counter() - t0
+  lib.sfm_profile_enable(0)
+  _abi.check(lib.sfm_profile_read(C.byref(prof)))
+
+  times = torch.tensor([elapsed, t_flow, t_mesh], dtype=torch.float64,
+                       device=dev)
+  if world > 1:
+    dist.all_reduce(times, op=dist.ReduceOp.MAX)
+  elapsed, t_flow, t_mesh = [float(v) for v in times.cpu()]
+
+  n_grid = (size - (PATCH - STEP)) // STEP
+  n_patches = n_grid * n_grid
+  mesh_nodes = (n_grid + 2 * pad) ** 2
+  pix = float(size) * size
+  mpix_s = world * pix * args.steps / t_flow / 1e6
+  node_updates_s = world * mesh_nodes * mesh_steps_done / t_mesh
+
+  # Roofline of the dominant kernel: algorithmic work per launch = 2 P^4 flop
+  # per patch (every pixel pair contributes to exactly one shift) x patches
+  # per launch.
+  flop_per_patch = 2.0 * PATCH ** 4
+  xc_ms, xc_n = prof.kernel_ms[0], prof.launches[0]
+  ms_ms, ms_n = prof.kernel_ms[1], prof.launches[1]
+  uses_mfma = args.method != 1 and bool(
+      getattr(flow_field, 'MFMA_I8_AVAILABLE', False))
+  roof = None
+  if xc_n:
+    avg_ms = xc_ms / xc_n
+    patches_per_launch = n_patches * args.steps / xc_n
+    achieved = flop_per_patch * patches_per_launch / (avg_ms * 1e-3) / 1e12
+    peak = PEAK_I8_TOPS if uses_mfma else PEAK_F32_TFLOPS
+    roof = {
+        'kernel': 'xcorr_mfma_i8' if uses_mfma else 'corr_direct_kernel<f32>',
+        'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
+        'unit': 'TOP/s' if uses_mfma else 'TFLOP/s',
+        'frac': round(achieved / peak, 4),
+        'avg_launch_ms': round(avg_ms, 4), 'launches': int(xc_n),
+        'patches_per_launch': round(patches_per_launch, 1),
+        'flop_per_patch': flop_per_patch, 'traffic': None,
+    }
+  mesh_obj = {
+      'value': node_updates_s, 'unit': 'node-updates/s',
+      'nodes': mesh_nodes, 'iterations_per_step': mesh_steps_done // max(args.steps, 1),
+      'ms_per_step': t_mesh / args.steps * 1e3,
+  }
+  if ms_n:
+    avg_us = ms_ms / ms_n * 1e3
+    gbs = mesh_nodes * 56.0 / (avg_us * 1e-6) / 1e9
+    mesh_obj['roofline'] = {
+        'kernel': 'integrate_kernel<2>', 'bound': 'hbm',
+        'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+        'frac': round(gbs / PEAK_HBM_GBS, 5),
+        'avg_launch_us': round(avg_us, 3), 'launches': int(ms_n),
+        'bytes_per_node_update': 56, 'traffic': None,
+        'note': 'state (1.3 MB) is cache resident; the step is launch/sync '
+                'bound, see steps_per_s',
+    }
+    mesh_obj['steps_per_s'] = mesh_steps_done / t_mesh
+
+  out = {
+      'metric': 'patch-xcorr Mpix/s (+ mesh node-updates/s) on 8192^2 tiles',
+      'value': mpix_s, 'unit': 'Mpix/s', 'n_gpus': world,
+      'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': elapsed / args.steps * 1e3,
+      'flow_ms_per_step': t_flow / args.steps * 1e3,
+      'mesh_ms_per_step': t_mesh / args.steps * 1e3,
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'u8' if uses_mfma else 'f32', 'data': 'synthetic',
+      'config': {
+          'workload': f'single {size}x{size} EM tile pair per GPU, patch=160 '
+                      f'step=40 batch=1024 flow + {args.mesh_iters}-iter FIRE '
+                      'mesh relax [2,1,205,205] (BASELINE configs[1])',
+          'patches_per_pair': n_patches, 'xcorr_method':
+              'int8 MFMA' if uses_mfma else 'direct f32',
+      },
+      'patches_per_s': world * n_patches * args.steps / t_flow,
+      'mesh': mesh_obj, 'roofline': roof,
+  }
+
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    out['cpu_baseline'] = cpu_baseline(pre, post, cfg)
+  if rank == 0:
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def cpu_baseline(pre, post, cfg):
+  """Times the CPU oracle on a bounded sample of the same workload."""
+  from oracle import flow_oracle, mesh_oracle
+  cores = os.cpu_count() or 1
+  sample_batches, sample_batch = 2, 256
+  t0 = time.perf_counter()
+  flow_oracle.flow_field(pre, post, PATCH, STEP, batch_size=sample_batch,
+                         workers=cores, max_batches=sample_batches)
+  t = time.perf_counter() - t0
+  n = sample_batches * sample_batch
+  mpix = n * STEP * STEP / 1e6 / t
+  rng = np.random.default_rng(0)
+  prev = rng.standard_normal((2, 1, 205, 205)).astype(np.float32)
+  import types
+  c = types.SimpleNamespace(**{**cfg.to_dict(), 'num_iters': 40,
+                               'max_iters': 40})
+  c.stride = tuple(c.stride)
+  t1 = time.perf_counter()
+  mesh_oracle.relax_mesh(np.zeros_like(prev), prev, c)
+  tm = time.perf_counter() - t1
+  return {
+      'value': mpix, 'unit': 'Mpix/s', 'cores': cores, 'kind': 'port',
+      'sample': f'{n} patches ({sample_batches} batches of {sample_batch}) of '
+                f'the same 8192^2 pair, FFT form, scipy.fft workers={cores}; '
+                f'{t:.1f} s',
+      'patches_per_s': n / t,
+      'mesh': {'value': 205 * 205 * 40 / tm, 'unit': 'node-updates/s',
+               'cores': 1, 'sample': f'40 FIRE steps on [2,1,205,205]; {tm:.1f} s'},
+  }
+
+
+if __name__ == '__main__':
+  main()

@@ -53,6 +53,19 @@ const char* sfm_last_error(void);
 /* Number of visible HIP devices (0 and SFM_OK when none). */
 int sfm_device_count(int* count);
 
+/* Kernel timing hooks (used by bench.py for the roofline figures; no
+ * reference counterpart).  While enabled, hipEvents on the launch stream
+ * bracket every launch of the dominant kernels: the patch-correlation kernel
+ * (kind 0) and the mesh integrate kernel (kind 1).  sfm_profile_read waits for
+ * the recorded events, returns the accumulated kernel time and launch count
+ * per kind since the last read, and resets the counters. */
+typedef struct SfmProfile {
+  double kernel_ms[2];
+  int64_t launches[2];
+} SfmProfile;
+int sfm_profile_enable(int on);
+int sfm_profile_read(SfmProfile* out);
+
 /* ------------------------------------------------------------------------
  * Patch cross-correlation + peak statistics for ONE batch.
  * Replaces flow_field.batched_xcorr_peaks (flow_field.py:374-441) =

@@ -110,6 +110,10 @@ class SfmFireState(C.Structure):
               ('cap', C.c_float)]
 
 
+class SfmProfile(C.Structure):
+  _fields_ = [('kernel_ms', C.c_double * 2), ('launches', C.c_int64 * 2)]
+
+
 class SfmChunkStats(C.Structure):
   _fields_ = [('e_kin', C.c_float), ('v_max', C.c_float)]
 
@@ -119,6 +123,8 @@ SIGNATURES = {
     'sfm_version': (C.c_int, []),
     'sfm_last_error': (C.c_char_p, []),
     'sfm_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'sfm_profile_enable': (C.c_int, [C.c_int]),
+    'sfm_profile_read': (C.c_int, [C.POINTER(SfmProfile)]),
     'sfm_xcorr_workspace_bytes': (C.c_size_t, [C.POINTER(SfmXcorrDesc)]),
     'sfm_xcorr_peaks': (C.c_int, [C.POINTER(SfmXcorrDesc), C.c_void_p]),
     'sfm_xcorr_surface': (C.c_int, [C.POINTER(SfmXcorrDesc), C.c_void_p]),

@@ -25,6 +25,13 @@ int fail(int code, const char* fmt, ...);
 
 #define SFM_LAUNCH_CHECK() SFM_HIP_CHECK(hipGetLastError())
 
+// bench.py timing hooks (sfm_profile_*): no-ops unless enabled.
+constexpr int kProfXcorr = 0;
+constexpr int kProfMesh = 1;
+bool profiling();
+void prof_begin(int kind, hipStream_t st);
+void prof_end(int kind, hipStream_t st);
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Carves aligned sub-buffers out of the caller's workspace.

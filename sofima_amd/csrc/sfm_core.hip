@@ -1,7 +1,10 @@
 // Version / error plumbing of the C ABI.
 #include "sfm_common.h"
 
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace sfm {
 
@@ -18,9 +21,68 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+namespace {
+std::mutex g_prof_mu;
+std::atomic<bool> g_prof_on{false};
+struct Span {
+  hipEvent_t a, b;
+};
+std::vector<Span> g_spans[2];
+std::vector<Span> g_free;
+Span g_open[2];
+}  // namespace
+
+bool profiling() { return g_prof_on.load(std::memory_order_relaxed); }
+
+void prof_begin(int kind, hipStream_t st) {
+  if (!profiling()) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  Span s;
+  if (!g_free.empty()) {
+    s = g_free.back();
+    g_free.pop_back();
+  } else {
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess)
+      return;
+  }
+  (void)hipEventRecord(s.a, st);
+  g_open[kind] = s;
+}
+
+void prof_end(int kind, hipStream_t st) {
+  if (!profiling()) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(g_open[kind].b, st);
+  g_spans[kind].push_back(g_open[kind]);
+}
+
 }  // namespace sfm
 
 extern "C" {
+
+int sfm_profile_enable(int on) {
+  sfm::g_prof_on.store(on != 0);
+  return SFM_OK;
+}
+
+int sfm_profile_read(SfmProfile* out) {
+  if (!out) return sfm::fail(SFM_ERR_INVALID, "out is NULL");
+  std::lock_guard<std::mutex> lk(sfm::g_prof_mu);
+  for (int k = 0; k < 2; ++k) {
+    double ms = 0.0;
+    for (auto& s : sfm::g_spans[k]) {
+      SFM_HIP_CHECK(hipEventSynchronize(s.b));
+      float t = 0.f;
+      SFM_HIP_CHECK(hipEventElapsedTime(&t, s.a, s.b));
+      ms += t;
+      sfm::g_free.push_back(s);
+    }
+    out->kernel_ms[k] = ms;
+    out->launches[k] = static_cast<int64_t>(sfm::g_spans[k].size());
+    sfm::g_spans[k].clear();
+  }
+  return SFM_OK;
+}
 
 int sfm_version(void) { return SFM_ABI_VERSION; }
 

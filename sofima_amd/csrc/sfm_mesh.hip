@@ -619,8 +619,10 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
                       &w.scal[cur ^ 1], w.partials, grid, pending);
     cur ^= 1;
+    sfm::prof_begin(sfm::kProfMesh, st);
     SFM_MESH_DISPATCH(integrate_kernel, d->x, d->v, d->a, d->prev, p,
                       &w.scal[cur], cap0, w.partials);
+    sfm::prof_end(sfm::kProfMesh, st);
   }
   const int pending = d->num_iters > 0;
   SFM_MESH_DISPATCH(finish_kernel, d->x, d->v, p, &w.scal[cur],

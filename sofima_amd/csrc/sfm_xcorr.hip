@@ -626,7 +626,9 @@ int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
                        surface, w.den, w.ov, w.maxima, n);
     SFM_LAUNCH_CHECK();
   } else {
+    sfm::prof_begin(sfm::kProfXcorr, st);
     hipLaunchKernelGGL(corr_direct_kernel<false>, grid, dim3(kBlock), 0, st, c);
+    sfm::prof_end(sfm::kProfXcorr, st);
     SFM_LAUNCH_CHECK();
   }
   return SFM_OK;

@@ -53,7 +53,8 @@ def test_struct_layouts_match_header():
                      ('SfmPeaksDesc', _abi.SfmPeaksDesc),
                      ('SfmMeshDesc', _abi.SfmMeshDesc),
                      ('SfmFireState', _abi.SfmFireState),
-                     ('SfmChunkStats', _abi.SfmChunkStats)):
+                     ('SfmChunkStats', _abi.SfmChunkStats),
+                     ('SfmProfile', _abi.SfmProfile)):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,
                      re.S).group(1)
     names = []
