@@ -1,10 +1,528 @@
-// int8 MFMA Toeplitz correlation (placeholder until the kernel lands).
+// Patch cross-correlation on the int8 matrix cores of gfx950 (CDNA4).
+//
+// Device replacement for masked_xcorr(use_jax=True) of the reference
+// (flow_field.py:36-89, unmasked branch) + the mean subtraction of
+// _batched_xcorr (flow_field.py:340-353) for uint8 2-D patches: the reference
+// evaluates  out[dy, dx] = sum_{y,x} (A[y+dy, x+dx] - mA) (B[y, x] - mB)
+// with zero-padded FFTs; here the sum is evaluated exactly.
+//
+// 1. Integer core.  With per-patch integer centres cA, cB (chosen so that
+//    a' = a - cA and b' = b - cB fit int8) the product sum S = sum a' b' is an
+//    exact int32 and
+//        out = S - mA' SB - mB' SA + mA' mB' N
+//    where mA' = mA - cA (|mA'| <= 0.5 unless clamped), SA / SB are the sums
+//    of a' / b' over the overlap rectangle of the shift (box sums from a
+//    per-patch integral image) and N the overlap area.
+//
+// 2. The product sum as a GEMM on v_mfma_i32_16x16x64_i8.  For an output tile
+//    of 16 dy values (M) x 16 dx values (N) the contraction index is
+//    k = (yb, xa): A-operand[dy, k] = a'[yb + dy, xa] and
+//    B-operand[k, dx] = b'[yb, xa - dx].  One MFMA consumes four k-slots
+//    (lane group g = lane >> 4 <-> patch row yb0 + g) of 16 consecutive xa
+//    each (one "chunk" ca):
+//      - the A fragment of lane (m, g) is an aligned 16-byte row segment
+//        a'[yb0 + g + dy0 + m, 16 ca ..] read with ds_read_b128 from an LDS
+//        copy of the pre patch that is zero padded above and below, so
+//        shifts that run off the patch contribute zeros;
+//      - the B fragment of lane (n, g) is b'[yb0 + g, 16 (ca - q) + t - n + ..]:
+//        a byte-shifted window of row yb0 + g that depends on ca and the
+//        output tile q only through c = ca - q.  Each lane reads the 4 NCE + 1
+//        aligned dwords covering its windows once per row group and funnel
+//        shifts them (v_alignbyte_b32) into NCE fragments, which are then
+//        used against every A chunk: NCA x NCE MFMAs per row group into
+//        NCA + NCE - 1 accumulator tiles, all from 14 LDS loads + NCE*4 VALU ops.
+//    A wave owns one 16-row dy tile at a time and all dx tiles of it; tiles
+//    only visit the patch rows that overlap (zero skipping), so the MFMA work
+//    is ~1.24x the algorithmic 2 P^4 flop for P = Q = 160.
+//
+// 3. Epilogue: box sums from the integral images (global, L2 resident), the
+//    float32 correction above, coalesced stores of the surface tile.
+//
+// LDS per workgroup (P = Q = 160): pre patch (Py + 34) x 176 B + post patch
+// (Qy + 3) x 208 B = 68 KB -> two workgroups (8 waves) per CU.  Row pitches
+// 176 / 208 keep the b128 / b32 fragment reads bank-conflict free.
 #include "sfm_common.h"
 
-namespace sfm {
-bool mfma_i8_eligible(const SfmXcorrDesc*) { return false; }
-size_t mfma_i8_workspace_bytes(const SfmXcorrDesc*) { return 0; }
-int mfma_i8_surface(const SfmXcorrDesc*, void*, float*) {
-  return fail(SFM_ERR_INVALID, "MFMA_I8 path not available");
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kPadTop = 16;     // zero rows above the pre patch in LDS
+constexpr int kPadBottom = 18;  // zero rows below
+constexpr int kMaxTilesPerWave = 24;
+
+struct PatchParams {  // written by the prep kernel, one per patch
+  int y0[2], x0[2];   // clamped patch origin in the image (pre, post)
+  int c[2];           // integer centres
+  float mu[2];        // mean - centre
+};
+
+struct MfmaArgs {
+  const unsigned char* img[2];
+  int ishape[2][2];   // [side][y, x]
+  const int* starts[2];
+  int P[2], Q[2];     // pre / post patch [y, x]
+  int S[2];           // surface [y, x]
+  int batch;
+  int use_mean;
+  float mean;
+  PatchParams* pp;
+  int* integ[2];      // [B, (py+1) * (px+1)] per side
+  long long integ_stride[2];
+  float* surface;     // [B, Sy, Sx]
+  // LDS geometry
+  int pa, pb;         // row pitches (bytes)
+  int ml;             // left margin of the post patch rows (bytes)
+  int a_bytes, b_bytes;
+  // static tile schedule: tiles (dy tile indices) per wave
+  unsigned char tiles[kWaves][kMaxTilesPerWave];
+  int n_tiles[kWaves];
+};
+
+__device__ __forceinline__ unsigned load_u32_guarded(const unsigned* base,
+                                                     long long idx,
+                                                     long long n_words) {
+  return (idx >= 0 && idx < n_words) ? base[idx] : 0u;
 }
+
+// ---------------------------------------------------------------------------
+// prep: patch statistics, integer centre, integral image
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int red[3][kThreads];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int py = s == 0 ? a.P[0] : a.Q[0];
+  const int px = s == 0 ? a.P[1] : a.Q[1];
+  const int H = a.ishape[s][0], W = a.ishape[s][1];
+  // lax.dynamic_slice start clamping (flow_field.py:320-325).
+  const int y0 = min(max(a.starts[s][b * 2 + 0], 0), H - py);
+  const int x0 = min(max(a.starts[s][b * 2 + 1], 0), W - px);
+  const unsigned char* img = a.img[s];
+  int mn = 255, mx = 0, sum = 0;
+  for (int i = threadIdx.x; i < py * px; i += kThreads) {
+    const int y = i / px, x = i - y * px;
+    const int v = img[(long long)(y0 + y) * W + x0 + x];
+    smem[i] = static_cast<unsigned char>(v);
+    mn = min(mn, v);
+    mx = max(mx, v);
+    sum += v;
+  }
+  red[0][threadIdx.x] = mn;
+  red[1][threadIdx.x] = mx;
+  red[2][threadIdx.x] = sum;
+  __syncthreads();
+  for (int k = kThreads / 2; k > 0; k >>= 1) {
+    if (threadIdx.x < k) {
+      red[0][threadIdx.x] = min(red[0][threadIdx.x], red[0][threadIdx.x + k]);
+      red[1][threadIdx.x] = max(red[1][threadIdx.x], red[1][threadIdx.x + k]);
+      red[2][threadIdx.x] += red[2][threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  mn = red[0][0];
+  mx = red[1][0];
+  sum = red[2][0];
+  const float n_f = static_cast<float>(py * px);
+  const float mean = a.use_mean ? a.mean : static_cast<float>(sum) / n_f;
+  // Centre: nearest integer to the mean that keeps every pixel in int8.
+  int c = static_cast<int>(rintf(fminf(fmaxf(mean, 0.f), 255.f)));
+  c = min(max(c, mx - 127), mn + 128);
+  if (threadIdx.x == 0) {
+    PatchParams* p = &a.pp[b];
+    p->y0[s] = y0;
+    p->x0[s] = x0;
+    p->c[s] = c;
+    p->mu[s] = a.use_mean
+                   ? a.mean - static_cast<float>(c)
+                   : static_cast<float>(
+                         (static_cast<double>(sum) - static_cast<double>(c) * py * px) /
+                         (static_cast<double>(py) * px));
+  }
+  int* I = a.integ[s] + b * a.integ_stride[s];
+  const int ip = px + 1;
+  // Column running sums -> I[y + 1][x + 1]; zero first row / column.
+  for (int x = threadIdx.x; x <= px; x += kThreads) I[x] = 0;
+  for (int y = threadIdx.x; y <= py; y += kThreads) I[y * ip] = 0;
+  for (int x = threadIdx.x; x < px; x += kThreads) {
+    int run = 0;
+    for (int y = 0; y < py; ++y) {
+      run += static_cast<int>(smem[y * px + x]) - c;
+      I[(y + 1) * ip + x + 1] = run;
+    }
+  }
+  __syncthreads();
+  // Row-wise inclusive scan (wave scan with carry).
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int y = 1 + wave; y <= py; y += kWaves) {
+    int carry = 0;
+    for (int x0c = 0; x0c < px; x0c += 64) {
+      const int x = x0c + lane;
+      int v = x < px ? I[y * ip + x + 1] : 0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+      }
+      v += carry;
+      if (x < px) I[y * ip + x + 1] = v;
+      carry = __shfl(v, 63, 64);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// main kernel
+// ---------------------------------------------------------------------------
+// Loads one patch into LDS as int8 (pixel - centre), 16 bytes per work item,
+// from arbitrarily aligned global rows.
+__device__ __forceinline__ void stage_patch(
+    const unsigned char* __restrict__ img, long long img_bytes, int W, int y0,
+    int x0, int py, int px, int centre, unsigned char* __restrict__ dst,
+    int pitch, int row_off, int col_off, int n_chunks) {
+  const unsigned* words = reinterpret_cast<const unsigned*>(img);
+  const long long n_words = (img_bytes + 3) >> 2;
+  const unsigned cc = static_cast<unsigned>(centre) * 0x01010101u;
+  for (int item = threadIdx.x; item < py * n_chunks; item += kThreads) {
+    const int y = item / n_chunks, ch = item - y * n_chunks;
+    const long long off = (long long)(y0 + y) * W + x0 + ch * 16;
+    const long long w0 = off >> 2;
+    const unsigned sh = static_cast<unsigned>(off & 3);
+    unsigned w[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) w[k] = load_u32_guarded(words, w0 + k, n_words);
+    v4i out;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned v = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
+      // bytewise v - centre (mod 256) == int8 value of pixel - centre
+      const unsigned H = 0x80808080u;
+      v = ((v | H) - (cc & ~H)) ^ ((v ^ ~cc) & H);
+      // zero bytes beyond the patch width
+      const int xb = ch * 16 + k * 4;
+      if (xb + 4 > px) {
+        const int keep = px - xb;  // < 4
+        v = keep <= 0 ? 0u : (v & (0xffffffffu >> (8 * (4 - keep))));
+      }
+      out[k] = static_cast<int>(v);
+    }
+    *reinterpret_cast<v4i*>(dst + (row_off + y) * pitch + col_off + ch * 16) = out;
+  }
+}
+
+__device__ __forceinline__ int box_sum(const int* __restrict__ I, int ip, int y0,
+                                       int y1, int x0, int x1) {
+  // I has a zero first row and column.
+  int s = I[y1 * ip + x1];
+  if (y0 > 0) s -= I[y0 * ip + x1];
+  if (x0 > 0) s -= I[y1 * ip + x0];
+  if (y0 > 0 && x0 > 0) s += I[y0 * ip + x0];
+  return s;
+}
+
+template <int NCA, int NCE>
+__global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
+  constexpr int NQ = NCA + NCE - 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* A_lds = smem;
+  unsigned char* B_lds = smem + a.a_bytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int Py = a.P[0], Px = a.P[1], Qy = a.Q[0], Qx = a.Q[1];
+  const int Sy = a.S[0], Sx = a.S[1];
+  const long long Sn = (long long)Sy * Sx;
+
+  // Zero the whole LDS image once: pad rows / margins stay zero afterwards.
+  for (int i = threadIdx.x * 16; i < a.a_bytes + a.b_bytes; i += kThreads * 16)
+    *reinterpret_cast<v4i*>(smem + i) = v4i{0, 0, 0, 0};
+
+  const long long bytes0 = (long long)a.ishape[0][0] * a.ishape[0][1];
+  const long long bytes1 = (long long)a.ishape[1][0] * a.ishape[1][1];
+  const int cq0 = NCE - 1;
+  // Per-lane start of the B windows inside a padded post-patch row.
+  const int pos0 = a.ml + Qx - 1 - n - 16 * cq0;
+  const int sh = pos0 & 3;
+
+  for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
+    __syncthreads();  // previous patch fully consumed / zero fill done
+    const PatchParams pp = a.pp[b];
+    stage_patch(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], Py, Px,
+                pp.c[0], A_lds, a.pa, kPadTop, 0, NCA);
+    stage_patch(a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
+                pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16);
+    __syncthreads();
+
+    const int* IA = a.integ[0] + b * a.integ_stride[0];
+    const int* IB = a.integ[1] + b * a.integ_stride[1];
+    const float mua = pp.mu[0], mub = pp.mu[1];
+    const float muab = mua * mub;
+    float* surf = a.surface + b * Sn;
+
+    for (int ti = 0; ti < a.n_tiles[wave]; ++ti) {
+      const int p = a.tiles[wave][ti];
+      const int dy0 = 16 * p - (Qy - 1);
+      const int ylo = max(0, -dy0 - 15);
+      const int yhi = min(Qy, Py - dy0);
+      v4i acc[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] = v4i{0, 0, 0, 0};
+
+      const unsigned char* ap =
+          A_lds + (kPadTop + ylo + g + dy0 + n) * a.pa;
+      const unsigned char* bp = B_lds + (ylo + g) * a.pb + (pos0 & ~3);
+      for (int yb0 = ylo; yb0 < yhi; yb0 += 4) {
+        unsigned d[4 * NCE + 1];
+#pragma unroll
+        for (int j = 0; j < 4 * NCE + 1; ++j)
+          d[j] = *reinterpret_cast<const unsigned*>(bp + 4 * j);
+        v4i af[NCA];
+#pragma unroll
+        for (int ca = 0; ca < NCA; ++ca)
+          af[ca] = *reinterpret_cast<const v4i*>(ap + 16 * ca);
+#pragma unroll
+        for (int c = 0; c < NCE; ++c) {
+          v4i bf;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            bf[k] = static_cast<int>(
+                __builtin_amdgcn_alignbyte(d[4 * c + k + 1], d[4 * c + k], sh));
+#pragma unroll
+          for (int ca = 0; ca < NCA; ++ca) {
+            const int q = ca - c + cq0;
+            acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ca], bf, acc[q], 0,
+                                                           0, 0);
+          }
+        }
+        ap += 4 * a.pa;
+        bp += 4 * a.pb;
+      }
+
+      // Epilogue: lane holds rows ky = 16 p + 4 g + r, columns kx = 16 q + n.
+      const int ipa = Px + 1, ipb = Qx + 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ky = 16 * p + 4 * g + r;
+        if (ky >= Sy) continue;
+        const int dy = ky - (Qy - 1);
+        const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
+        const int yb0 = ya0 - dy, yb1 = ya1 - dy;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int kx = 16 * q + n;
+          if (kx >= Sx) continue;
+          const int dx = kx - (Qx - 1);
+          const int xa0 = max(0, dx), xa1 = min(Px, Qx + dx);
+          const int xb0 = xa0 - dx, xb1 = xa1 - dx;
+          const int sa = box_sum(IA, ipa, ya0, ya1, xa0, xa1);
+          const int sb = box_sum(IB, ipb, yb0, yb1, xb0, xb1);
+          const int nov = (ya1 - ya0) * (xa1 - xa0);
+          float v = static_cast<float>(acc[q][r]);
+          v = v - mua * static_cast<float>(sb);
+          v = v - mub * static_cast<float>(sa);
+          v = v + muab * static_cast<float>(nov);
+          surf[(long long)ky * Sx + kx] = v;
+        }
+      }
+    }
+  }
+}
+
+struct Variant {
+  int nca, nce;
+};
+// Instantiated chunk geometries: NCA >= ceil(Px / 16), NCE >= floor((Qx + 14) / 16) + 1.
+constexpr Variant kVariants[] = {{3, 4}, {4, 5}, {5, 6}, {6, 7}, {8, 9}, {10, 11}};
+
+int pick_variant(int px, int qx) {
+  const int nca = (px + 15) / 16, nce = (qx + 14) / 16 + 1;
+  for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
+    if (kVariants[i].nca >= nca && kVariants[i].nce >= nce) return static_cast<int>(i);
+  return -1;
+}
+
+struct Layout {
+  int nca, nce, pa, pb, ml, a_bytes, b_bytes;
+};
+
+Layout make_layout(const SfmXcorrDesc* d, const Variant& v) {
+  Layout l;
+  l.nca = v.nca;
+  l.nce = v.nce;
+  const int py = d->patch[1], qy = d->post_patch[1], qx = d->post_patch[2];
+  // Pre patch rows: 16 * NCA data bytes, pitch = odd multiple of 16 bytes so
+  // that 16 consecutive rows hit 16 different 16-byte LDS slots.
+  int pa16 = v.nca;
+  if ((pa16 & 1) == 0) pa16 += 1;
+  l.pa = pa16 * 16;
+  l.a_bytes = (py + kPadTop + kPadBottom) * l.pa;
+  // Post patch rows: left margin so that every lane window starts >= 0.
+  const int cq0 = v.nce - 1;
+  int ml = 16 * cq0 + 16 - qx;
+  if (ml < 0) ml = 0;
+  ml = (ml + 15) / 16 * 16;
+  l.ml = ml;
+  // Furthest byte touched: window start (n = 0) + 16 * NCE + 4 bytes read-ahead.
+  int need = ml + qx - 1 - 16 * cq0 + 16 * v.nce + 4;
+  need = std::max(need, ml + (qx + 15) / 16 * 16);
+  int pb16 = (need + 15) / 16;
+  // pitch / 4 mod 32 in {20, 12, ...}: keep 4 consecutive rows on distinct
+  // banks for the dword reads: use pitch = 16 * odd with (pitch / 4) % 8 == 4.
+  while (((pb16 * 4) % 8) != 4) ++pb16;
+  l.pb = pb16 * 16;
+  l.b_bytes = (qy + 3) * l.pb;
+  l.a_bytes = (l.a_bytes + 15) / 16 * 16;
+  l.b_bytes = (l.b_bytes + 15) / 16 * 16;
+  return l;
+}
+
+struct Ws {
+  PatchParams* pp;
+  int* integ[2];
+  long long stride[2];
+  size_t bytes;
+};
+
+Ws carve_ws(const SfmXcorrDesc* d, void* base) {
+  sfm::Carver c(base);
+  Ws w;
+  const size_t B = d->batch;
+  w.pp = c.take<PatchParams>(B);
+  w.stride[0] = (long long)(d->patch[1] + 1) * (d->patch[2] + 1);
+  w.stride[1] = (long long)(d->post_patch[1] + 1) * (d->post_patch[2] + 1);
+  w.integ[0] = c.take<int>(B * w.stride[0]);
+  w.integ[1] = c.take<int>(B * w.stride[1]);
+  w.bytes = c.total();
+  return w;
+}
+
+template <int NCA, int NCE>
+int launch_variant(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SFM_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  sfm::prof_begin(sfm::kProfXcorr, st);
+  hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE>), dim3(grid), dim3(kThreads),
+                     lds, st, a);
+  sfm::prof_end(sfm::kProfXcorr, st);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+}  // namespace
+
+namespace sfm {
+
+bool mfma_i8_eligible(const SfmXcorrDesc* d) {
+  if (!d || d->ndim != 2 || d->dtype != SFM_DTYPE_U8) return false;
+  if (d->pre_mask || d->post_mask) return false;
+  if (d->patch[0] != 1 || d->post_patch[0] != 1) return false;
+  const int py = d->patch[1], px = d->patch[2];
+  const int qy = d->post_patch[1], qx = d->post_patch[2];
+  if (pick_variant(px, qx) < 0) return false;
+  if (py < 1 || qy < 1 || qy > py || qx > px) return false;
+  if ((long long)py * px > 32768) return false;        // prep kernel LDS copy
+  if ((long long)qy * qx * 16384 > 0x7fffffffLL) return false;  // int32 sums
+  if ((py + qy - 1 + 15) / 16 > kWaves * kMaxTilesPerWave) return false;
+  if ((reinterpret_cast<uintptr_t>(d->pre_image) & 3) ||
+      (reinterpret_cast<uintptr_t>(d->post_image) & 3))
+    return false;
+  return true;
+}
+
+size_t mfma_i8_workspace_bytes(const SfmXcorrDesc* d) {
+  return carve_ws(d, nullptr).bytes;
+}
+
+int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface) {
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  const int vi = pick_variant(d->patch[2], d->post_patch[2]);
+  if (vi < 0) return fail(SFM_ERR_INVALID, "patch too wide for the MFMA path");
+  const Layout l = make_layout(d, kVariants[vi]);
+  Ws w = carve_ws(d, ws_base);
+  MfmaArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.img[0] = static_cast<const unsigned char*>(d->pre_image);
+  a.img[1] = static_cast<const unsigned char*>(d->post_image);
+  for (int k = 0; k < 2; ++k) {
+    a.ishape[0][k] = d->pre_shape[1 + k];
+    a.ishape[1][k] = d->post_shape[1 + k];
+    a.P[k] = d->patch[1 + k];
+    a.Q[k] = d->post_patch[1 + k];
+    a.S[k] = a.P[k] + a.Q[k] - 1;
+  }
+  a.starts[0] = d->pre_starts;
+  a.starts[1] = d->post_starts;
+  a.batch = d->batch;
+  a.use_mean = d->use_mean;
+  a.mean = d->mean;
+  a.pp = w.pp;
+  a.integ[0] = w.integ[0];
+  a.integ[1] = w.integ[1];
+  a.integ_stride[0] = w.stride[0];
+  a.integ_stride[1] = w.stride[1];
+  a.surface = surface;
+  a.pa = l.pa;
+  a.pb = l.pb;
+  a.ml = l.ml;
+  a.a_bytes = l.a_bytes;
+  a.b_bytes = l.b_bytes;
+
+  // Static schedule: dy tiles sorted by the number of patch rows they visit,
+  // dealt to the 4 waves longest-first.
+  const int np = (a.S[0] + 15) / 16;
+  std::vector<std::pair<int, int>> work;
+  for (int p = 0; p < np; ++p) {
+    const int dy0 = 16 * p - (a.Q[0] - 1);
+    const int ylo = std::max(0, -dy0 - 15), yhi = std::min(a.Q[0], a.P[0] - dy0);
+    work.push_back({std::max(0, (yhi - ylo + 3) / 4), p});
+  }
+  std::sort(work.begin(), work.end(),
+            [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
+              return x.first > y.first || (x.first == y.first && x.second < y.second);
+            });
+  int load[kWaves] = {0, 0, 0, 0};
+  for (auto& t : work) {
+    int best = 0;
+    for (int k = 1; k < kWaves; ++k)
+      if (load[k] < load[best]) best = k;
+    if (a.n_tiles[best] >= kMaxTilesPerWave)
+      return fail(SFM_ERR_INVALID, "too many dy tiles");
+    a.tiles[best][a.n_tiles[best]++] = static_cast<unsigned char>(t.second);
+    load[best] += t.first + 1;  // + epilogue
+  }
+
+  const size_t prep_lds = (size_t)a.P[0] * a.P[1];
+  hipLaunchKernelGGL(mfma_prep_kernel, dim3(d->batch, 2), dim3(kThreads),
+                     prep_lds, st, a);
+  SFM_LAUNCH_CHECK();
+
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  }
+  const size_t lds = (size_t)l.a_bytes + l.b_bytes;
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int grid = std::min(d->batch, cus * per_cu);
+  switch (vi) {
+    case 0: return launch_variant<3, 4>(a, grid, lds, st);
+    case 1: return launch_variant<4, 5>(a, grid, lds, st);
+    case 2: return launch_variant<5, 6>(a, grid, lds, st);
+    case 3: return launch_variant<6, 7>(a, grid, lds, st);
+    case 4: return launch_variant<8, 9>(a, grid, lds, st);
+    case 5: return launch_variant<10, 11>(a, grid, lds, st);
+  }
+  return fail(SFM_ERR_INVALID, "no MFMA variant");
+}
+
 }  // namespace sfm

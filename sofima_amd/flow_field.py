@@ -34,7 +34,9 @@ import torch
 from . import _abi
 from . import _dev
 
-T = TypeVar('T')
+T = TypeVar("T")
+# The uint8 2-D unmasked path runs on the int8 matrix cores (sfm_xcorr_mfma.hip).
+MFMA_I8_AVAILABLE = True
 Array = np.ndarray
 
 
