@@ -27,7 +27,9 @@ namespace sfm {
 // Implemented in sfm_xcorr_mfma.hip.
 bool mfma_i8_eligible(const SfmXcorrDesc* d);
 size_t mfma_i8_workspace_bytes(const SfmXcorrDesc* d);
+// Writes a surface padded to whole 16 x 16 tiles: [B, rows, pitch].
 int mfma_i8_surface(const SfmXcorrDesc* d, void* ws, float* surface);
+void mfma_i8_padded_dims(const SfmXcorrDesc* d, int* rows, int* pitch);
 }  // namespace sfm
 
 namespace {
@@ -245,10 +247,12 @@ masked_finalize_kernel(float* __restrict__ out, const float* __restrict__ den,
 // peaks
 // ---------------------------------------------------------------------------
 struct PeakArgs {
-  const float* surf;  // [B, S]
+  const float* surf;  // [B, S] with row pitch / per-surface stride below
   int nd;
   int S[3];
-  long long Sn;
+  long long Sn;           // logical elements per surface
+  int pitch;              // floats between consecutive x-rows (>= S[2])
+  long long bstride;      // floats between consecutive surfaces
   int batch;
   float center[3];  // [z]yx
   int min_distance;
@@ -288,17 +292,16 @@ __device__ void block_argmax(float* v, int* i, float* lv, int* li) {
   __syncthreads();
 }
 
-// img == maxfilter(img) (zero 'same' padding) && img > thr
-// (flow_field.py:238-254).
-__device__ bool is_peak_at(const float* s, const PeakArgs& p, long long pos,
-                           float thr, float* val) {
-  const int x = static_cast<int>(pos % p.S[2]);
-  const long long r = pos / p.S[2];
-  const int y = static_cast<int>(r % p.S[1]);
-  const int z = static_cast<int>(r / p.S[1]);
-  const float v = s[pos];
-  *val = v;
-  if (!(v > thr)) return false;
+// Element (z, y, x) of a surface with row pitch.
+__device__ __forceinline__ float surf_at(const float* s, const PeakArgs& p, int z,
+                                         int y, int x) {
+  return s[((long long)z * p.S[1] + y) * p.pitch + x];
+}
+
+// img == maxfilter(img) (zero 'same' padding) for an element already known to
+// exceed the threshold (flow_field.py:238-254).
+__device__ bool is_window_max(const float* s, const PeakArgs& p, int z, int y,
+                              int x, float v) {
   const int m = p.min_distance;
   const int mz = p.nd == 3 ? m : 0;
   float wm = -INFINITY;
@@ -312,39 +315,63 @@ __device__ bool is_peak_at(const float* s, const PeakArgs& p, long long pos,
           outside = true;
           continue;
         }
-        wm = fmaxf(wm, s[((long long)zz * p.S[1] + yy) * p.S[2] + xx]);
+        wm = fmaxf(wm, surf_at(s, p, zz, yy, xx));
       }
   if (outside) wm = fmaxf(wm, 0.f);
   return v == wm;
+}
+
+__device__ float surface_max(const float* s, const PeakArgs& p, float* lv,
+                             int* li) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = p.S[0] * p.S[1];
+  float mx = -INFINITY;
+  for (int r = wave; r < rows; r += kBlock / 64) {
+    const float* row = s + (long long)r * p.pitch;
+    for (int x = lane; x < p.S[2]; x += 64) mx = fmaxf(mx, row[x]);
+  }
+  int dummy = 0;
+  block_argmax(&mx, &dummy, lv, li);
+  return mx;
+}
+
+// Calls fn(flat_index, value) for every peak of the surface.
+template <typename F>
+__device__ void for_each_peak(const float* s, const PeakArgs& p, float thr, F fn) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = p.S[0] * p.S[1];
+  for (int r = wave; r < rows; r += kBlock / 64) {
+    const int z = r / p.S[1], y = r - z * p.S[1];
+    const float* row = s + (long long)r * p.pitch;
+    for (int x = lane; x < p.S[2]; x += 64) {
+      const float v = row[x];
+      if (v > thr && is_window_max(s, p, z, y, x, v))
+        fn(r * p.S[2] + x, v);
+    }
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) peaks_first_kernel(PeakArgs p) {
   __shared__ float lv[kBlock];
   __shared__ int li[kBlock];
   const int b = blockIdx.x;
-  const float* s = p.surf + b * p.Sn;
-  float mx = -INFINITY;
-  for (long long i = threadIdx.x; i < p.Sn; i += kBlock) mx = fmaxf(mx, s[i]);
-  int dummy = 0;
-  block_argmax(&mx, &dummy, lv, li);
+  const float* s = p.surf + b * p.bstride;
+  const float mx = surface_max(s, p, lv, li);
   const float thr = p.threshold_rel * mx;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (long long i = threadIdx.x; i < p.Sn; i += kBlock) {
-    float v;
-    if (is_peak_at(s, p, i, thr, &v)) {
-      if (better(v, static_cast<int>(i), bv, bi)) {
-        bv = v;
-        bi = static_cast<int>(i);
-      }
-      const int slot = atomicAdd(&p.cand_count[b], 1);
-      if (slot < kCandCap) {
-        p.cand_val[(long long)b * kCandCap + slot] = v;
-        p.cand_idx[(long long)b * kCandCap + slot] = static_cast<int>(i);
-      }
-      if (i == 0) p.zero_is_peak[b] = 1;
+  for_each_peak(s, p, thr, [&](int i, float v) {
+    if (better(v, i, bv, bi)) {
+      bv = v;
+      bi = i;
     }
-  }
+    const int slot = atomicAdd(&p.cand_count[b], 1);
+    if (slot < kCandCap) {
+      p.cand_val[(long long)b * kCandCap + slot] = v;
+      p.cand_idx[(long long)b * kCandCap + slot] = i;
+    }
+    if (i == 0) p.zero_is_peak[b] = 1;
+  });
   block_argmax(&bv, &bi, lv, li);
   if (threadIdx.x == 0) {
     const int i1 = bv == -INFINITY ? 0 : bi;  // argmax of an all -inf row is 0
@@ -358,7 +385,7 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
   __shared__ float lv[kBlock];
   __shared__ int li[kBlock];
   const int b = blockIdx.x;
-  const float* s = p.surf + b * p.Sn;
+  const float* s = p.surf + b * p.bstride;
   const float v1 = p.v1[b];
   const int i1 = p.idx1[b];
   const int w = p.nd + 2;
@@ -383,20 +410,13 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
     }
   } else {
     // Candidate list overflowed (plateaus): rescan the surface.
-    float mx = -INFINITY;
-    for (long long i = threadIdx.x; i < p.Sn; i += kBlock) mx = fmaxf(mx, s[i]);
-    int dummy = 0;
-    block_argmax(&mx, &dummy, lv, li);
-    const float thr = p.threshold_rel * mx;
-    for (long long i = threadIdx.x; i < p.Sn; i += kBlock) {
-      if ((p.bitmap[i >> 5] >> (i & 31)) & 1u) continue;
-      float v;
-      if (is_peak_at(s, p, i, thr, &v) &&
-          better(v, static_cast<int>(i), bv, bi)) {
+    const float mx = surface_max(s, p, lv, li);
+    for_each_peak(s, p, p.threshold_rel * mx, [&](int i, float v) {
+      if (((p.bitmap[i >> 5] >> (i & 31)) & 1u) == 0 && better(v, i, bv, bi)) {
         bv = v;
-        bi = static_cast<int>(i);
+        bi = i;
       }
-    }
+    });
   }
   block_argmax(&bv, &bi, lv, li);
   // The value is read from the UN-suppressed array (flow_field.py:266-268):
@@ -427,9 +447,7 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
     const long long r = k / size[2];
     const int y = static_cast<int>(r % size[1]);
     const int z = static_cast<int>(r / size[1]);
-    mn = fminf(mn, s[((long long)(start[0] + z) * p.S[1] + (start[1] + y)) *
-                         p.S[2] +
-                     (start[2] + x)]);
+    mn = fminf(mn, surf_at(s, p, start[0] + z, start[1] + y, start[2] + x));
   }
   lv[threadIdx.x] = mn;
   __syncthreads();
@@ -445,8 +463,20 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
       const int ax = 2 - a;
       o[a] = static_cast<float>(pos[ax]) - p.center[ax];
     }
-    o[p.nd] = s[i1] / lv[0];
+    o[p.nd] = surf_at(s, p, pos[0], pos[1], pos[2]) / lv[0];
     o[p.nd + 1] = v2 == -INFINITY ? 0.f : v1 / v2;
+  }
+}
+
+// Copies a tile-padded surface [B, rows, pitch] into the compact [B, Sy, Sx].
+__global__ void __launch_bounds__(kBlock)
+compact_surface_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                       int sy, int sx, int rows, int pitch) {
+  const int b = blockIdx.y;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < sy * sx;
+       i += gridDim.x * kBlock) {
+    const int y = i / sx, x = i - y * sx;
+    dst[(long long)b * sy * sx + i] = src[((long long)b * rows + y) * pitch + x];
   }
 }
 
@@ -478,8 +508,9 @@ PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn) {
   return w;
 }
 
-int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int nd,
-              const int* S, long long sn, int batch, const float* center,
+int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
+              long long bstride, int nd, const int* S, long long sn, int batch,
+              const float* center,
               int min_distance, float threshold_rel, const int* radius,
               float* out, hipStream_t st) {
   PeakArgs p;
@@ -491,6 +522,8 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int nd,
     p.radius[i] = radius[i];
   }
   p.Sn = sn;
+  p.pitch = pitch;
+  p.bstride = bstride;
   p.batch = batch;
   p.min_distance = min_distance;
   p.threshold_rel = threshold_rel;
@@ -518,6 +551,7 @@ struct XcorrWs {
   unsigned int* maxima;
   void* mfma;
   PeakWs peaks;
+  int srows, spitch;  // layout of `surface`: [B, srows, spitch]
   size_t bytes;
 };
 
@@ -549,7 +583,14 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
       w.maxima = c.take<unsigned int>(2);
     }
   }
-  if (with_surface) w.surface = c.take<float>(B * g.Sn);
+  w.srows = g.S[0] * g.S[1];
+  w.spitch = g.S[2];
+  if (use_mfma(d)) {
+    // The MFMA kernel stores whole 16 x 16 tiles: padded work surface.
+    sfm::mfma_i8_padded_dims(d, &w.srows, &w.spitch);
+    with_surface = true;
+  }
+  if (with_surface) w.surface = c.take<float>(B * (size_t)w.srows * w.spitch);
   if (with_peaks) w.peaks = carve_peaks(c, d->batch, g.Sn);
   w.bytes = c.total();
   return w;
@@ -656,6 +697,14 @@ int sfm_xcorr_surface(const SfmXcorrDesc* d, float* surface) {
   if (!d->workspace || d->workspace_bytes < w.bytes)
     return sfm::fail(SFM_ERR_WORKSPACE, "xcorr workspace needs %zu bytes, got %zu",
                      w.bytes, d->workspace_bytes);
+  if (use_mfma(d)) {
+    if (int rc = compute_surface(d, g, w, w.surface)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(d->stream);
+    hipLaunchKernelGGL(compact_surface_kernel, dim3(64, d->batch), dim3(kBlock), 0,
+                       st, w.surface, surface, g.S[1], g.S[2], w.srows, w.spitch);
+    SFM_LAUNCH_CHECK();
+    return SFM_OK;
+  }
   return compute_surface(d, g, w, surface);
 }
 
@@ -672,8 +721,9 @@ int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
   float center[3];
   for (int i = 0; i < 3; ++i)
     center[i] = static_cast<float>((g.P[i] + g.Q[i]) / 2 - 1);
-  return run_peaks(w.peaks, static_cast<char*>(d->workspace), w.surface, d->ndim,
-                   g.S, g.Sn, d->batch, center, d->min_distance,
+  return run_peaks(w.peaks, static_cast<char*>(d->workspace), w.surface,
+                   w.spitch, (long long)w.srows * w.spitch, d->ndim, g.S, g.Sn,
+                   d->batch, center, d->min_distance,
                    d->threshold_rel, d->peak_radius, peaks,
                    static_cast<hipStream_t>(d->stream));
 }
@@ -704,8 +754,9 @@ int sfm_peaks(const SfmPeaksDesc* d, float* peaks) {
   if (!d->workspace || d->workspace_bytes < w.bytes)
     return sfm::fail(SFM_ERR_WORKSPACE, "peaks workspace needs %zu bytes, got %zu",
                      w.bytes, d->workspace_bytes);
-  return run_peaks(w, static_cast<char*>(d->workspace), d->surface, d->ndim,
-                   d->shape, sn, d->batch, d->center_offset, d->min_distance,
+  return run_peaks(w, static_cast<char*>(d->workspace), d->surface, d->shape[2],
+                   sn, d->ndim, d->shape, sn, d->batch, d->center_offset,
+                   d->min_distance,
                    d->threshold_rel, d->peak_radius, peaks,
                    static_cast<hipStream_t>(d->stream));
 }

@@ -35,8 +35,16 @@
 //    only visit the patch rows that overlap (zero skipping), so the MFMA work
 //    is ~1.24x the algorithmic 2 P^4 flop for P = Q = 160.
 //
-// 3. Epilogue: box sums from the integral images (global, L2 resident), the
-//    float32 correction above, coalesced stores of the surface tile.
+// 3. Epilogue.  For P == Q (the production case) every overlap rectangle is
+//    anchored at a patch corner, and with yv = dy mod Py, xv = dx mod Px,
+//    ey = -sign(dy), ex = -sign(dx) the whole correction collapses to
+//        ey ex G[yv][xv] + ey Rrow[dx>=0][yv] + ex Rcol[dy>=0][xv] + const
+//                        + mA' mB' ny nx
+//    with ONE combined float table per patch,
+//        G[yv][xv] = -mB' IA[yv][xv] - mA' IB[Py - yv][Px - xv]
+//    (IA / IB = integral images of a' / b'), and four 1-D arrays, all written
+//    by the prep kernel: one coalesced gather per output instead of eight.
+//    For P != Q (post_patch_size) the general 8-lookup box-sum form is used.
 //
 // LDS per workgroup (P = Q = 160): pre patch (Py + 34) x 176 B + post patch
 // (Qy + 3) x 208 B = 68 KB -> two workgroups (8 waves) per CU.  Row pitches
@@ -44,6 +52,7 @@
 #include "sfm_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -73,9 +82,12 @@ struct MfmaArgs {
   int use_mean;
   float mean;
   PatchParams* pp;
-  int* integ[2];      // [B, (py+1) * (px+1)] per side
+  int* integ[2];      // general path: [B, (py+1) * (px+1)] per side
   long long integ_stride[2];
-  float* surface;     // [B, Sy, Sx]
+  float* gtab;        // same-size path: [B, Py * Px] combined table G
+  float* aux;         // same-size path: [B, 4 * aux_n + 4] 1-D arrays + consts
+  int aux_n;          // max(Py, Px) + 1
+  float* surface;     // [B, 16 NP, 16 NQ] (padded to whole tiles)
   // LDS geometry
   int pa, pb;         // row pitches (bytes)
   int ml;             // left margin of the post patch rows (bytes)
@@ -83,6 +95,8 @@ struct MfmaArgs {
   // static tile schedule: tiles (dy tile indices) per wave
   unsigned char tiles[kWaves][kMaxTilesPerWave];
   int n_tiles[kWaves];
+  int sx_pitch;       // padded surface: row pitch (floats) = 16 * NQ
+  long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
 };
 
 __device__ __forceinline__ unsigned load_u32_guarded(const unsigned* base,
@@ -178,6 +192,152 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// prep for P == Q: centres, means, combined correction table G and the 1-D
+// row / column arrays.  One block per patch.  LDS: raw column running sums of
+// both patches as uint16 ((Py + 1) x Px each), per-wave row scratch.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int red[2][3][kThreads];
+  __shared__ int s_c[2];
+  __shared__ float s_mu[2];
+  const int b = blockIdx.x;
+  const int py = a.P[0], px = a.P[1];
+  unsigned short* colsum[2];
+  colsum[0] = reinterpret_cast<unsigned short*>(smem);
+  colsum[1] = colsum[0] + (py + 1) * px;
+  int* scratch = reinterpret_cast<int*>(colsum[1] + (py + 1) * px);  // [4][2][px + 2]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  int y0[2], x0[2];
+  for (int s = 0; s < 2; ++s) {
+    const int H = a.ishape[s][0], W = a.ishape[s][1];
+    y0[s] = min(max(a.starts[s][b * 2 + 0], 0), H - py);
+    x0[s] = min(max(a.starts[s][b * 2 + 1], 0), W - px);
+  }
+  // Column pass: thread x walks down its column of both patches.
+  for (int s = 0; s < 2; ++s) {
+    int mn = 255, mx = 0, sum = 0;
+    const int W = a.ishape[s][1];
+    for (int x = threadIdx.x; x < px; x += kThreads) {
+      const unsigned char* col = a.img[s] + (long long)y0[s] * W + x0[s] + x;
+      int run = 0;
+      colsum[s][x] = 0;
+      for (int y = 0; y < py; ++y) {
+        const int v = col[(long long)y * W];
+        mn = min(mn, v);
+        mx = max(mx, v);
+        run += v;
+        colsum[s][(y + 1) * px + x] = static_cast<unsigned short>(run);
+      }
+      sum += run;
+    }
+    red[s][0][threadIdx.x] = mn;
+    red[s][1][threadIdx.x] = mx;
+    red[s][2][threadIdx.x] = sum;
+  }
+  __syncthreads();
+  for (int k = kThreads / 2; k > 0; k >>= 1) {
+    if (threadIdx.x < k)
+      for (int s = 0; s < 2; ++s) {
+        red[s][0][threadIdx.x] = min(red[s][0][threadIdx.x], red[s][0][threadIdx.x + k]);
+        red[s][1][threadIdx.x] = max(red[s][1][threadIdx.x], red[s][1][threadIdx.x + k]);
+        red[s][2][threadIdx.x] += red[s][2][threadIdx.x + k];
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) {
+    const int s = threadIdx.x;
+    const int mn = red[s][0][0], mx = red[s][1][0], sum = red[s][2][0];
+    const float mean =
+        a.use_mean ? a.mean : static_cast<float>(sum) / static_cast<float>(py * px);
+    int c = static_cast<int>(rintf(fminf(fmaxf(mean, 0.f), 255.f)));
+    c = min(max(c, mx - 127), mn + 128);
+    s_c[s] = c;
+    s_mu[s] = a.use_mean
+                  ? a.mean - static_cast<float>(c)
+                  : static_cast<float>((static_cast<double>(sum) -
+                                        static_cast<double>(c) * py * px) /
+                                       (static_cast<double>(py) * px));
+    PatchParams* p = &a.pp[b];
+    p->y0[s] = y0[s];
+    p->x0[s] = x0[s];
+    p->c[s] = c;
+    p->mu[s] = s_mu[s];
+  }
+  __syncthreads();
+  const int ca = s_c[0], cb = s_c[1];
+  const float mua = s_mu[0], mub = s_mu[1];
+  float* G = a.gtab + (long long)b * py * px;
+  float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
+  float* rrowA = aux;
+  float* rrowB = aux + a.aux_n;
+  float* rcolA = aux + 2 * a.aux_n;
+  float* rcolB = aux + 3 * a.aux_n;
+  int* rowA = scratch + wave * 2 * (px + 2);  // IA[yv][0..px]
+  int* rowB = rowA + (px + 2);                // IB[py - yv][0..px]
+  // Each wave owns rows yv = wave, wave + 4, ... (yv == py: A totals only).
+  for (int yv = wave; yv <= py; yv += kWaves) {
+    const int yw = py - yv;
+    int carryA = 0, carryB = 0;
+    if (lane == 0) {
+      rowA[0] = 0;
+      rowB[0] = 0;
+    }
+    for (int xc = 0; xc < px; xc += 64) {
+      const int x = xc + lane;
+      int va = 0, vb = 0;
+      if (x < px) {
+        va = static_cast<int>(colsum[0][yv * px + x]) - ca * yv;
+        vb = static_cast<int>(colsum[1][yw * px + x]) - cb * yw;
+      }
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int ta = __shfl_up(va, d, 64);
+        const int tb = __shfl_up(vb, d, 64);
+        if (lane >= d) {
+          va += ta;
+          vb += tb;
+        }
+      }
+      va += carryA;
+      vb += carryB;
+      if (x < px) {
+        rowA[x + 1] = va;
+        rowB[x + 1] = vb;
+      }
+      carryA = __shfl(va, 63, 64);
+      carryB = __shfl(vb, 63, 64);
+    }
+    // The same wave wrote the scratch rows; keep the compiler from moving the
+    // reads above the writes (LDS operations of one wave execute in order).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (yv < py) {
+      for (int xv = lane; xv < px; xv += 64)
+        G[yv * px + xv] = -mub * static_cast<float>(rowA[xv]) -
+                          mua * static_cast<float>(rowB[px - xv]);
+      if (lane == 0) {
+        rrowA[yv] = -mub * static_cast<float>(rowA[px]);
+        rrowB[yv] = mua * static_cast<float>(rowB[px]);
+      }
+    }
+    if (yv == 0)
+      for (int xv = lane; xv < px; xv += 64)
+        rcolB[xv] = mua * static_cast<float>(rowB[px - xv]);
+    if (yv == py) {
+      for (int xv = lane; xv < px; xv += 64)
+        rcolA[xv] = -mub * static_cast<float>(rowA[xv]);
+      if (lane == 0) aux[4 * a.aux_n + 0] = -mub * static_cast<float>(rowA[px]);
+    }
+    if (yv == 0 && lane == 0)
+      aux[4 * a.aux_n + 1] = -mua * static_cast<float>(rowB[px]);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------
 // Loads one patch into LDS as int8 (pixel - centre), 16 bytes per work item,
@@ -226,17 +386,18 @@ __device__ __forceinline__ int box_sum(const int* __restrict__ I, int ip, int y0
   return s;
 }
 
-template <int NCA, int NCE>
+template <int NCA, int NCE, bool SAME>
 __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   constexpr int NQ = NCA + NCE - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* A_lds = smem;
   unsigned char* B_lds = smem + a.a_bytes;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* R_lds = reinterpret_cast<float*>(smem + a.a_bytes + a.b_bytes);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int Py = a.P[0], Px = a.P[1], Qy = a.Q[0], Qx = a.Q[1];
   const int Sy = a.S[0], Sx = a.S[1];
-  const long long Sn = (long long)Sy * Sx;
 
   // Zero the whole LDS image once: pad rows / margins stay zero afterwards.
   for (int i = threadIdx.x * 16; i < a.a_bytes + a.b_bytes; i += kThreads * 16)
@@ -256,16 +417,25 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                 pp.c[0], A_lds, a.pa, kPadTop, 0, NCA);
     stage_patch(a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
                 pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16);
+    float const_a = 0.f, const_b = 0.f;
+    if (SAME) {
+      const float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
+      for (int i = threadIdx.x; i < 4 * a.aux_n; i += kThreads) R_lds[i] = aux[i];
+      const_a = aux[4 * a.aux_n + 0];
+      const_b = aux[4 * a.aux_n + 1];
+    }
     __syncthreads();
 
-    const int* IA = a.integ[0] + b * a.integ_stride[0];
-    const int* IB = a.integ[1] + b * a.integ_stride[1];
+    const int* IA = SAME ? nullptr : a.integ[0] + b * a.integ_stride[0];
+    const int* IB = SAME ? nullptr : a.integ[1] + b * a.integ_stride[1];
+    const float* G = SAME ? a.gtab + (long long)b * Py * Px : nullptr;
     const float mua = pp.mu[0], mub = pp.mu[1];
     const float muab = mua * mub;
-    float* surf = a.surface + b * Sn;
+    float* surf = a.surface + b * a.s_stride;
 
-    for (int ti = 0; ti < a.n_tiles[wave]; ++ti) {
-      const int p = a.tiles[wave][ti];
+    const int n_my_tiles = __builtin_amdgcn_readfirstlane(a.n_tiles[wave]);
+    for (int ti = 0; ti < n_my_tiles; ++ti) {
+      const int p = __builtin_amdgcn_readfirstlane(a.tiles[wave][ti]);
       const int dy0 = 16 * p - (Qy - 1);
       const int ylo = max(0, -dy0 - 15);
       const int yhi = min(Qy, Py - dy0);
@@ -304,29 +474,94 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       }
 
       // Epilogue: lane holds rows ky = 16 p + 4 g + r, columns kx = 16 q + n.
-      const int ipa = Px + 1, ipb = Qx + 1;
+      // Branch-free: indices are clamped so every table load is in bounds;
+      // only the store is predicated.
+      // The surface buffer is padded to whole tiles (pitch 16 NQ, 16 NP rows),
+      // so every lane stores unconditionally.
+      int srow[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ky = 16 * p + 4 * g + r;
-        if (ky >= Sy) continue;
-        const int dy = ky - (Qy - 1);
-        const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
-        const int yb0 = ya0 - dy, yb1 = ya1 - dy;
+      for (int r = 0; r < 4; ++r) srow[r] = (16 * p + 4 * g + r) * a.sx_pitch + n;
+      if (SAME) {
+        // corr = ey ex G[yv][xv] + ey Rrow[sx][yv] + ex Rcol[sy][xv] + const
+        //        + mua mub ny nx        (header comment, item 3)
+        const float* rrowA = R_lds;
+        const float* rrowB = R_lds + a.aux_n;
+        const float* rcolA = R_lds + 2 * a.aux_n;
+        const float* rcolB = R_lds + 3 * a.aux_n;
+        int grow[4];
+        float ey[4], rra[4], rrb[4], fny[4];
+        bool sy[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ky = min(16 * p + 4 * g + r, Sy - 1);
+          const int dy = ky - (Py - 1);
+          sy[r] = dy >= 0;
+          const int yv = sy[r] ? dy : dy + Py;
+          ey[r] = sy[r] ? -1.f : 1.f;
+          grow[r] = yv * Px;
+          rra[r] = rrowA[yv];
+          rrb[r] = rrowB[yv];
+          fny[r] = muab * static_cast<float>(Py - abs(dy));
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          // Keep the scheduler from hoisting all 4 NQ gathers at once (that
+          // spills the accumulators): one q column (4 gathers) at a time.
+          __builtin_amdgcn_sched_barrier(0);
+          const int kx = 16 * q + n;
+          const int dx = min(kx, Sx - 1) - (Px - 1);
+          const bool sx = dx >= 0;
+          const int xv = sx ? dx : dx + Px;
+          const float ex = sx ? -1.f : 1.f;
+          const float rca = rcolA[xv], rcb = rcolB[xv];
+          const float fnx = static_cast<float>(Px - abs(dx));
+          float gv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gv[r] = G[grow[r] + xv];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float corr = (ey[r] * ex) * gv[r];
+            corr += ey[r] * (sx ? rra[r] : rrb[r]);
+            corr += ex * (sy[r] ? rca : rcb);
+            corr += (sy[r] && sx) ? const_a : 0.f;
+            corr += (!sy[r] && !sx) ? const_b : 0.f;
+            corr += fny[r] * fnx;
+            surf[srow[r] + 16 * q] = static_cast<float>(acc[q][r]) + corr;
+          }
+        }
+      } else {
+        const int ipa = Px + 1, ipb = Qx + 1;
+        int oa0[4], oa1[4], ob0[4], ob1[4], ny[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ky = min(16 * p + 4 * g + r, Sy - 1);
+          const int dy = ky - (Qy - 1);
+          const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
+          oa0[r] = ya0 * ipa;
+          oa1[r] = ya1 * ipa;
+          ob0[r] = (ya0 - dy) * ipb;
+          ob1[r] = (ya1 - dy) * ipb;
+          ny[r] = ya1 - ya0;
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int kx = 16 * q + n;
-          if (kx >= Sx) continue;
-          const int dx = kx - (Qx - 1);
+          const int dx = min(kx, Sx - 1) - (Qx - 1);
           const int xa0 = max(0, dx), xa1 = min(Px, Qx + dx);
           const int xb0 = xa0 - dx, xb1 = xa1 - dx;
-          const int sa = box_sum(IA, ipa, ya0, ya1, xa0, xa1);
-          const int sb = box_sum(IB, ipb, yb0, yb1, xb0, xb1);
-          const int nov = (ya1 - ya0) * (xa1 - xa0);
-          float v = static_cast<float>(acc[q][r]);
-          v = v - mua * static_cast<float>(sb);
-          v = v - mub * static_cast<float>(sa);
-          v = v + muab * static_cast<float>(nov);
-          surf[(long long)ky * Sx + kx] = v;
+          const float fnx = static_cast<float>(xa1 - xa0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int sa = IA[oa1[r] + xa1] - IA[oa0[r] + xa1] -
+                           IA[oa1[r] + xa0] + IA[oa0[r] + xa0];
+            const int sb = IB[ob1[r] + xb1] - IB[ob0[r] + xb1] -
+                           IB[ob1[r] + xb0] + IB[ob0[r] + xb0];
+            float v = static_cast<float>(acc[q][r]);
+            v = v - mua * static_cast<float>(sb);
+            v = v - mub * static_cast<float>(sa);
+            v = v + muab * (static_cast<float>(ny[r]) * fnx);
+            surf[srow[r] + 16 * q] = v;
+          }
         }
       }
     }
@@ -381,41 +616,63 @@ Layout make_layout(const SfmXcorrDesc* d, const Variant& v) {
   return l;
 }
 
+bool same_size(const SfmXcorrDesc* d) {
+  return d->patch[1] == d->post_patch[1] && d->patch[2] == d->post_patch[2] &&
+         d->patch[1] <= 256;  // uint16 raw column sums in the prep kernel
+}
+
 struct Ws {
   PatchParams* pp;
   int* integ[2];
   long long stride[2];
+  float* gtab;
+  float* aux;
+  int aux_n;
   size_t bytes;
 };
 
 Ws carve_ws(const SfmXcorrDesc* d, void* base) {
   sfm::Carver c(base);
   Ws w;
+  std::memset(&w, 0, sizeof(w));
   const size_t B = d->batch;
   w.pp = c.take<PatchParams>(B);
-  w.stride[0] = (long long)(d->patch[1] + 1) * (d->patch[2] + 1);
-  w.stride[1] = (long long)(d->post_patch[1] + 1) * (d->post_patch[2] + 1);
-  w.integ[0] = c.take<int>(B * w.stride[0]);
-  w.integ[1] = c.take<int>(B * w.stride[1]);
+  if (same_size(d)) {
+    w.aux_n = std::max(d->patch[1], d->patch[2]) + 1;
+    w.gtab = c.take<float>(B * d->patch[1] * d->patch[2]);
+    w.aux = c.take<float>(B * (4 * w.aux_n + 4));
+  } else {
+    w.stride[0] = (long long)(d->patch[1] + 1) * (d->patch[2] + 1);
+    w.stride[1] = (long long)(d->post_patch[1] + 1) * (d->post_patch[2] + 1);
+    w.integ[0] = c.take<int>(B * w.stride[0]);
+    w.integ[1] = c.take<int>(B * w.stride[1]);
+  }
   w.bytes = c.total();
   return w;
 }
 
-template <int NCA, int NCE>
-int launch_variant(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+template <int NCA, int NCE, bool SAME>
+int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
+  static size_t attr_set = 0;
+  if (lds > attr_set) {
     SFM_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+        reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE, SAME>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    attr_set = lds;
   }
   sfm::prof_begin(sfm::kProfXcorr, st);
-  hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE>), dim3(grid), dim3(kThreads),
-                     lds, st, a);
+  hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, SAME>), dim3(grid),
+                     dim3(kThreads), lds, st, a);
   sfm::prof_end(sfm::kProfXcorr, st);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
+}
+
+template <int NCA, int NCE>
+int launch_variant(const MfmaArgs& a, bool same, int grid, size_t lds,
+                   hipStream_t st) {
+  return same ? launch_one<NCA, NCE, true>(a, grid, lds, st)
+              : launch_one<NCA, NCE, false>(a, grid, lds, st);
 }
 
 }  // namespace
@@ -443,6 +700,13 @@ size_t mfma_i8_workspace_bytes(const SfmXcorrDesc* d) {
   return carve_ws(d, nullptr).bytes;
 }
 
+void mfma_i8_padded_dims(const SfmXcorrDesc* d, int* rows, int* pitch) {
+  const int vi = pick_variant(d->patch[2], d->post_patch[2]);
+  const int sy = d->patch[1] + d->post_patch[1] - 1;
+  *rows = (sy + 15) / 16 * 16;
+  *pitch = vi < 0 ? 0 : 16 * (kVariants[vi].nca + kVariants[vi].nce - 1);
+}
+
 int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const int vi = pick_variant(d->patch[2], d->post_patch[2]);
@@ -466,11 +730,21 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface) {
   a.use_mean = d->use_mean;
   a.mean = d->mean;
   a.pp = w.pp;
+  const bool same = same_size(d);
   a.integ[0] = w.integ[0];
   a.integ[1] = w.integ[1];
   a.integ_stride[0] = w.stride[0];
   a.integ_stride[1] = w.stride[1];
+  a.gtab = w.gtab;
+  a.aux = w.aux;
+  a.aux_n = w.aux_n;
   a.surface = surface;
+  {
+    int rows = 0, pitch = 0;
+    mfma_i8_padded_dims(d, &rows, &pitch);
+    a.sx_pitch = pitch;
+    a.s_stride = (long long)rows * pitch;
+  }
   a.pa = l.pa;
   a.pb = l.pb;
   a.ml = l.ml;
@@ -501,9 +775,23 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface) {
     load[best] += t.first + 1;  // + epilogue
   }
 
-  const size_t prep_lds = (size_t)a.P[0] * a.P[1];
-  hipLaunchKernelGGL(mfma_prep_kernel, dim3(d->batch, 2), dim3(kThreads),
-                     prep_lds, st, a);
+  if (same) {
+    const size_t prep_lds = (size_t)2 * (a.P[0] + 1) * a.P[1] * 2 +
+                            (size_t)kWaves * 2 * (a.P[1] + 2) * 4 + 16;
+    static size_t prep_attr = 0;
+    if (prep_lds > prep_attr) {
+      SFM_HIP_CHECK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&mfma_prep_same_kernel),
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(prep_lds)));
+      prep_attr = prep_lds;
+    }
+    hipLaunchKernelGGL(mfma_prep_same_kernel, dim3(d->batch), dim3(kThreads),
+                       prep_lds, st, a);
+  } else {
+    const size_t prep_lds = (size_t)a.P[0] * a.P[1];
+    hipLaunchKernelGGL(mfma_prep_kernel, dim3(d->batch, 2), dim3(kThreads),
+                       prep_lds, st, a);
+  }
   SFM_LAUNCH_CHECK();
 
   int dev = 0, cus = 256;
@@ -511,16 +799,17 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   }
-  const size_t lds = (size_t)l.a_bytes + l.b_bytes;
+  const size_t lds =
+      (size_t)l.a_bytes + l.b_bytes + (same ? (size_t)4 * w.aux_n * 4 : 0);
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   const int grid = std::min(d->batch, cus * per_cu);
   switch (vi) {
-    case 0: return launch_variant<3, 4>(a, grid, lds, st);
-    case 1: return launch_variant<4, 5>(a, grid, lds, st);
-    case 2: return launch_variant<5, 6>(a, grid, lds, st);
-    case 3: return launch_variant<6, 7>(a, grid, lds, st);
-    case 4: return launch_variant<8, 9>(a, grid, lds, st);
-    case 5: return launch_variant<10, 11>(a, grid, lds, st);
+    case 0: return launch_variant<3, 4>(a, same, grid, lds, st);
+    case 1: return launch_variant<4, 5>(a, same, grid, lds, st);
+    case 2: return launch_variant<5, 6>(a, same, grid, lds, st);
+    case 3: return launch_variant<6, 7>(a, same, grid, lds, st);
+    case 4: return launch_variant<8, 9>(a, same, grid, lds, st);
+    case 5: return launch_variant<10, 11>(a, same, grid, lds, st);
   }
   return fail(SFM_ERR_INVALID, "no MFMA variant");
 }
