@@ -193,45 +193,71 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
 
 // ---------------------------------------------------------------------------
 // prep for P == Q: centres, means, combined correction table G and the 1-D
-// row / column arrays.  One block per patch.  LDS: raw column running sums of
-// both patches as uint16 ((Py + 1) x Px each), per-wave row scratch.
+// row / column arrays.  One 256-thread block per patch; LDS holds the two raw
+// uint8 patches (2 Py Px bytes), so several blocks share a CU.
+//
+// Wave w sweeps the rows yv = [w R, (w + 1) R) of the table (R = ceil(Py / 4))
+// keeping, per lane, the running column sums of the pre patch above row yv and
+// of the post patch above row Py - yv; a wave scan over x turns them into the
+// integral-image rows IA[yv][.] and IB[Py - yv][.]; raw pixel sums are used and
+// the centre is folded in afterwards (I'[y][x] = Iraw[y][x] - c y x).
 // ---------------------------------------------------------------------------
+constexpr int kPrepCols = 3;  // columns per lane: Px <= 192
+
 __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int red[2][3][kThreads];
   __shared__ int s_c[2];
   __shared__ float s_mu[2];
+  __shared__ int band_tot[2][kWaves][64 * kPrepCols];
+  __shared__ int row_scr[kWaves][2][64 * kPrepCols + 2];
   const int b = blockIdx.x;
   const int py = a.P[0], px = a.P[1];
-  unsigned short* colsum[2];
-  colsum[0] = reinterpret_cast<unsigned short*>(smem);
-  colsum[1] = colsum[0] + (py + 1) * px;
-  int* scratch = reinterpret_cast<int*>(colsum[1] + (py + 1) * px);  // [4][2][px + 2]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* pix[2] = {smem, smem + ((py * px + 15) & ~15)};
 
+  // Phase 1: coalesced copy of both patches into LDS (16 bytes per item).
   int y0[2], x0[2];
   for (int s = 0; s < 2; ++s) {
     const int H = a.ishape[s][0], W = a.ishape[s][1];
     y0[s] = min(max(a.starts[s][b * 2 + 0], 0), H - py);
     x0[s] = min(max(a.starts[s][b * 2 + 1], 0), W - px);
+    const unsigned* words = reinterpret_cast<const unsigned*>(a.img[s]);
+    const long long n_words = ((long long)H * W + 3) >> 2;
+    const int n_chunks = (px + 15) / 16;
+    for (int item = threadIdx.x; item < py * n_chunks; item += kThreads) {
+      const int y = item / n_chunks, ch = item - y * n_chunks;
+      const long long off = (long long)(y0[s] + y) * W + x0[s] + ch * 16;
+      const long long w0 = off >> 2;
+      const unsigned sh = static_cast<unsigned>(off & 3);
+      unsigned w[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) w[k] = load_u32_guarded(words, w0 + k, n_words);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned v = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
+        const int xb = ch * 16 + k * 4;
+        unsigned char* dst = pix[s] + y * px + xb;
+        if (xb + 4 <= px && ((y * px + xb) & 3) == 0) {
+          *reinterpret_cast<unsigned*>(dst) = v;
+        } else {
+          for (int t = 0; t < 4; ++t)
+            if (xb + t < px) dst[t] = static_cast<unsigned char>(v >> (8 * t));
+        }
+      }
+    }
   }
-  // Column pass: thread x walks down its column of both patches.
+  __syncthreads();
+
+  // Phase 2: min / max / sum per patch -> integer centre and residual mean.
   for (int s = 0; s < 2; ++s) {
     int mn = 255, mx = 0, sum = 0;
-    const int W = a.ishape[s][1];
-    for (int x = threadIdx.x; x < px; x += kThreads) {
-      const unsigned char* col = a.img[s] + (long long)y0[s] * W + x0[s] + x;
-      int run = 0;
-      colsum[s][x] = 0;
-      for (int y = 0; y < py; ++y) {
-        const int v = col[(long long)y * W];
-        mn = min(mn, v);
-        mx = max(mx, v);
-        run += v;
-        colsum[s][(y + 1) * px + x] = static_cast<unsigned short>(run);
-      }
-      sum += run;
+    for (int i = threadIdx.x; i < py * px; i += kThreads) {
+      const int v = pix[s][i];
+      mn = min(mn, v);
+      mx = max(mx, v);
+      sum += v;
     }
     red[s][0][threadIdx.x] = mn;
     red[s][1][threadIdx.x] = mx;
@@ -266,6 +292,22 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
     p->c[s] = c;
     p->mu[s] = s_mu[s];
   }
+
+  // Phase 3a: per-band column totals (band w = rows [w R, (w + 1) R)).
+  const int R = (py + kWaves - 1) / kWaves;
+  const int ra0 = min(wave * R, py), ra1 = min(ra0 + R, py);
+#pragma unroll
+  for (int k = 0; k < kPrepCols; ++k) {
+    const int x = lane + 64 * k;
+    int ta = 0, tb = 0;
+    if (x < px)
+      for (int y = ra0; y < ra1; ++y) {
+        ta += pix[0][y * px + x];
+        tb += pix[1][y * px + x];
+      }
+    band_tot[0][wave][lane + 64 * k] = ta;
+    band_tot[1][wave][lane + 64 * k] = tb;
+  }
   __syncthreads();
   const int ca = s_c[0], cb = s_c[1];
   const float mua = s_mu[0], mub = s_mu[1];
@@ -275,23 +317,44 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
   float* rrowB = aux + a.aux_n;
   float* rcolA = aux + 2 * a.aux_n;
   float* rcolB = aux + 3 * a.aux_n;
-  int* rowA = scratch + wave * 2 * (px + 2);  // IA[yv][0..px]
-  int* rowB = rowA + (px + 2);                // IB[py - yv][0..px]
-  // Each wave owns rows yv = wave, wave + 4, ... (yv == py: A totals only).
-  for (int yv = wave; yv <= py; yv += kWaves) {
+  int* rowA = row_scr[wave][0];  // IrawA[yv][0..px]
+  int* rowB = row_scr[wave][1];  // IrawB[py - yv][0..px]
+
+  // Phase 3b: running column sums at the first row of the band.
+  //   colA = sum of pre rows  [0, yv)      at yv = ra0
+  //   colB = sum of post rows [0, py - yv) at yv = ra0
+  int colA[kPrepCols], colB[kPrepCols];
+#pragma unroll
+  for (int k = 0; k < kPrepCols; ++k) {
+    colA[k] = 0;
+    colB[k] = 0;
+    for (int w2 = 0; w2 < kWaves; ++w2) {
+      const int lo = min(w2 * R, py), hi = min(lo + R, py);
+      if (hi <= ra0) colA[k] += band_tot[0][w2][lane + 64 * k];
+      if (hi <= py - ra0) {
+        colB[k] += band_tot[1][w2][lane + 64 * k];
+      } else if (lo < py - ra0) {
+        // partial band: rows [lo, py - ra0)
+        const int x = lane + 64 * k;
+        if (x < px)
+          for (int y = lo; y < py - ra0; ++y) colB[k] += pix[1][y * px + x];
+      }
+    }
+  }
+  // Sweep.  Wave 3 also emits the yv == py row (pre-patch totals).
+  const int y_end = wave == kWaves - 1 ? py + 1 : ra1;
+  for (int yv = ra0; yv < y_end; ++yv) {
     const int yw = py - yv;
     int carryA = 0, carryB = 0;
     if (lane == 0) {
       rowA[0] = 0;
       rowB[0] = 0;
     }
-    for (int xc = 0; xc < px; xc += 64) {
-      const int x = xc + lane;
-      int va = 0, vb = 0;
-      if (x < px) {
-        va = static_cast<int>(colsum[0][yv * px + x]) - ca * yv;
-        vb = static_cast<int>(colsum[1][yw * px + x]) - cb * yw;
-      }
+#pragma unroll
+    for (int k = 0; k < kPrepCols; ++k) {
+      const int x = lane + 64 * k;
+      int va = x < px ? colA[k] : 0;
+      int vb = x < px ? colB[k] : 0;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
         const int ta = __shfl_up(va, d, 64);
@@ -310,30 +373,41 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
       carryA = __shfl(va, 63, 64);
       carryB = __shfl(vb, 63, 64);
     }
-    // The same wave wrote the scratch rows; keep the compiler from moving the
-    // reads above the writes (LDS operations of one wave execute in order).
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // centred integral images: I'[y][x] = Iraw[y][x] - c y x
+    auto ia = [&](int x) { return static_cast<float>(rowA[x] - ca * yv * x); };
+    auto ib = [&](int x) { return static_cast<float>(rowB[x] - cb * yw * x); };
     if (yv < py) {
       for (int xv = lane; xv < px; xv += 64)
-        G[yv * px + xv] = -mub * static_cast<float>(rowA[xv]) -
-                          mua * static_cast<float>(rowB[px - xv]);
+        G[yv * px + xv] = -mub * ia(xv) - mua * ib(px - xv);
       if (lane == 0) {
-        rrowA[yv] = -mub * static_cast<float>(rowA[px]);
-        rrowB[yv] = mua * static_cast<float>(rowB[px]);
+        rrowA[yv] = -mub * ia(px);
+        rrowB[yv] = mua * ib(px);
       }
     }
-    if (yv == 0)
-      for (int xv = lane; xv < px; xv += 64)
-        rcolB[xv] = mua * static_cast<float>(rowB[px - xv]);
-    if (yv == py) {
-      for (int xv = lane; xv < px; xv += 64)
-        rcolA[xv] = -mub * static_cast<float>(rowA[xv]);
-      if (lane == 0) aux[4 * a.aux_n + 0] = -mub * static_cast<float>(rowA[px]);
+    if (yv == 0) {
+      for (int xv = lane; xv < px; xv += 64) rcolB[xv] = mua * ib(px - xv);
+      if (lane == 0) aux[4 * a.aux_n + 1] = -mua * ib(px);
     }
-    if (yv == 0 && lane == 0)
-      aux[4 * a.aux_n + 1] = -mua * static_cast<float>(rowB[px]);
+    if (yv == py) {
+      for (int xv = lane; xv < px; xv += 64) rcolA[xv] = -mub * ia(xv);
+      if (lane == 0) aux[4 * a.aux_n + 0] = -mub * ia(px);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // advance to row yv + 1
+    if (yv < py) {
+#pragma unroll
+      for (int k = 0; k < kPrepCols; ++k) {
+        const int x = lane + 64 * k;
+        if (x < px) {
+          colA[k] += pix[0][yv * px + x];
+          colB[k] -= pix[1][(yw - 1) * px + x];
+        }
+      }
+    }
   }
 }
 
@@ -618,7 +692,7 @@ Layout make_layout(const SfmXcorrDesc* d, const Variant& v) {
 
 bool same_size(const SfmXcorrDesc* d) {
   return d->patch[1] == d->post_patch[1] && d->patch[2] == d->post_patch[2] &&
-         d->patch[1] <= 256;  // uint16 raw column sums in the prep kernel
+         d->patch[2] <= 64 * kPrepCols;  // columns per lane in the prep kernel
 }
 
 struct Ws {
@@ -776,8 +850,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface) {
   }
 
   if (same) {
-    const size_t prep_lds = (size_t)2 * (a.P[0] + 1) * a.P[1] * 2 +
-                            (size_t)kWaves * 2 * (a.P[1] + 2) * 4 + 16;
+    const size_t prep_lds = 2 * (((size_t)a.P[0] * a.P[1] + 15) & ~(size_t)15);
     static size_t prep_attr = 0;
     if (prep_lds > prep_attr) {
       SFM_HIP_CHECK(hipFuncSetAttribute(
