@@ -32,6 +32,23 @@ bool profiling();
 void prof_begin(int kind, hipStream_t st);
 void prof_end(int kind, hipStream_t st);
 
+// Buffers of the peak search that the MFMA kernel fills itself when the first
+// pass is fused into it (sfm_xcorr_mfma.hip: fused_first_peak).
+struct FusedPeaks {
+  int cand_cap;
+  int* idx1;
+  float* v1;
+  int* zero_is_peak;
+  int* cand_count;
+  float* cand_val;
+  int* cand_idx;
+  unsigned* bitmap;
+  int hot_cap;     // per-surface capacity of the hot list
+  int* hot_count;  // zeroed with the rest of the per-batch state
+  float* hot_val;
+  int* hot_idx;
+};
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Carves aligned sub-buffers out of the caller's workspace.

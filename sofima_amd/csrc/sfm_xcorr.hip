@@ -28,7 +28,8 @@ namespace sfm {
 bool mfma_i8_eligible(const SfmXcorrDesc* d);
 size_t mfma_i8_workspace_bytes(const SfmXcorrDesc* d);
 // Writes a surface padded to whole 16 x 16 tiles: [B, rows, pitch].
-int mfma_i8_surface(const SfmXcorrDesc* d, void* ws, float* surface);
+int mfma_i8_surface(const SfmXcorrDesc* d, void* ws, float* surface,
+                    const FusedPeaks* fused);
 void mfma_i8_padded_dims(const SfmXcorrDesc* d, int* rows, int* pitch);
 }  // namespace sfm
 
@@ -36,6 +37,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kCandCap = 2048;  // per-patch candidate list capacity
+constexpr int kHotCap = 4096;   // per-patch hot list of the fused MFMA path
 constexpr float kEps = 1.1920928955078125e-07f;  // float32 eps
 
 struct Geo {
@@ -488,19 +490,25 @@ struct PeakWs {
   float* cand_val;
   int* cand_idx;
   unsigned int* bitmap;
+  int* hot_count;      // fused MFMA path only
+  float* hot_val;
+  int* hot_idx;
   size_t zero_from, zero_bytes;  // region that must be cleared per batch
   size_t bytes;
 };
 
-PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn) {
+PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn, bool hot = false) {
   PeakWs w;
   w.idx1 = c.take<int>(batch);
   w.v1 = c.take<float>(batch);
+  w.hot_val = hot ? c.take<float>((size_t)batch * kHotCap) : nullptr;
+  w.hot_idx = hot ? c.take<int>((size_t)batch * kHotCap) : nullptr;
   w.cand_val = c.take<float>((size_t)batch * kCandCap);
   w.cand_idx = c.take<int>((size_t)batch * kCandCap);
   const size_t z0 = sfm::align_up(c.off, 256);
   w.zero_is_peak = c.take<int>(batch);
   w.cand_count = c.take<int>(batch);
+  w.hot_count = c.take<int>(batch);
   w.bitmap = c.take<unsigned int>((size_t)((sn + 31) / 32));
   w.zero_from = z0;
   w.zero_bytes = c.total() - z0;
@@ -512,7 +520,7 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
               long long bstride, int nd, const int* S, long long sn, int batch,
               const float* center,
               int min_distance, float threshold_rel, const int* radius,
-              float* out, hipStream_t st) {
+              float* out, hipStream_t st, bool first_pass_done = false) {
   PeakArgs p;
   p.surf = surf;
   p.nd = nd;
@@ -535,9 +543,11 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
   p.cand_idx = w.cand_idx;
   p.bitmap = w.bitmap;
   p.out = out;
-  SFM_HIP_CHECK(hipMemsetAsync(ws_base + w.zero_from, 0, w.zero_bytes, st));
-  hipLaunchKernelGGL(peaks_first_kernel, dim3(batch), dim3(kBlock), 0, st, p);
-  SFM_LAUNCH_CHECK();
+  if (!first_pass_done) {
+    SFM_HIP_CHECK(hipMemsetAsync(ws_base + w.zero_from, 0, w.zero_bytes, st));
+    hipLaunchKernelGGL(peaks_first_kernel, dim3(batch), dim3(kBlock), 0, st, p);
+    SFM_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(peaks_second_kernel, dim3(batch), dim3(kBlock), 0, st, p);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
@@ -591,7 +601,7 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
     with_surface = true;
   }
   if (with_surface) w.surface = c.take<float>(B * (size_t)w.srows * w.spitch);
-  if (with_peaks) w.peaks = carve_peaks(c, d->batch, g.Sn);
+  if (with_peaks) w.peaks = carve_peaks(c, d->batch, g.Sn, use_mfma(d));
   w.bytes = c.total();
   return w;
 }
@@ -610,9 +620,9 @@ int check_desc(const SfmXcorrDesc* d) {
 }
 
 int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
-                    float* surface) {
+                    float* surface, const sfm::FusedPeaks* fused = nullptr) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
-  if (use_mfma(d)) return sfm::mfma_i8_surface(d, w.mfma, surface);
+  if (use_mfma(d)) return sfm::mfma_i8_surface(d, w.mfma, surface, fused);
   const bool masked = is_masked(d);
   GatherArgs ga[2];
   for (int k = 0; k < 2; ++k) {
@@ -717,7 +727,28 @@ int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
   if (!d->workspace || d->workspace_bytes < w.bytes)
     return sfm::fail(SFM_ERR_WORKSPACE, "xcorr workspace needs %zu bytes, got %zu",
                      w.bytes, d->workspace_bytes);
-  if (int rc = compute_surface(d, g, w, w.surface)) return rc;
+  // With the MFMA kernel the first peak pass runs inside it, per finished
+  // surface; its per-batch state has to be cleared before the launch.
+  const bool fuse = use_mfma(d);
+  sfm::FusedPeaks fp;
+  if (fuse) {
+    SFM_HIP_CHECK(hipMemsetAsync(static_cast<char*>(d->workspace) + w.peaks.zero_from,
+                                 0, w.peaks.zero_bytes,
+                                 static_cast<hipStream_t>(d->stream)));
+    fp.cand_cap = kCandCap;
+    fp.idx1 = w.peaks.idx1;
+    fp.v1 = w.peaks.v1;
+    fp.zero_is_peak = w.peaks.zero_is_peak;
+    fp.cand_count = w.peaks.cand_count;
+    fp.cand_val = w.peaks.cand_val;
+    fp.cand_idx = w.peaks.cand_idx;
+    fp.bitmap = w.peaks.bitmap;
+    fp.hot_cap = kHotCap;
+    fp.hot_count = w.peaks.hot_count;
+    fp.hot_val = w.peaks.hot_val;
+    fp.hot_idx = w.peaks.hot_idx;
+  }
+  if (int rc = compute_surface(d, g, w, w.surface, fuse ? &fp : nullptr)) return rc;
   float center[3];
   for (int i = 0; i < 3; ++i)
     center[i] = static_cast<float>((g.P[i] + g.Q[i]) / 2 - 1);
@@ -725,7 +756,7 @@ int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
                    w.spitch, (long long)w.srows * w.spitch, d->ndim, g.S, g.Sn,
                    d->batch, center, d->min_distance,
                    d->threshold_rel, d->peak_radius, peaks,
-                   static_cast<hipStream_t>(d->stream));
+                   static_cast<hipStream_t>(d->stream), fuse);
 }
 
 size_t sfm_peaks_workspace_bytes(const SfmPeaksDesc* d) {

@@ -92,9 +92,26 @@ struct MfmaArgs {
   int pa, pb;         // row pitches (bytes)
   int ml;             // left margin of the post patch rows (bytes)
   int a_bytes, b_bytes;
+  int r_bytes;        // aux arrays / reduction scratch behind the patches
   // static tile schedule: tiles (dy tile indices) per wave
   unsigned char tiles[kWaves][kMaxTilesPerWave];
   int n_tiles[kWaves];
+  // fused first-peak search (flow_field.py:238-262); see FusedPeaks
+  int do_peaks;
+  float threshold_rel;
+  int min_distance;
+  int cand_cap;
+  int* idx1;
+  float* v1;
+  int* zero_is_peak;
+  int* cand_count;
+  float* cand_val;
+  int* cand_idx;
+  unsigned* bitmap;
+  int hot_cap;        // per-surface capacity of the hot list
+  int* hot_count;     // [B]
+  float* hot_val;     // [B, hot_cap]
+  int* hot_idx;       // [B, hot_cap] flat index ky * Sx + kx
   int sx_pitch;       // padded surface: row pitch (floats) = 16 * NQ
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
 };
@@ -460,6 +477,104 @@ __device__ __forceinline__ int box_sum(const int* __restrict__ I, int ip, int y0
   return s;
 }
 
+// First-peak search of one finished surface, run by the workgroup that just
+// produced it (the surface is L2 hot; nothing is re-read from HBM later).
+// Same result as peaks_first_kernel in sfm_xcorr.hip: peak = element that
+// equals its (2 m + 1)^2 zero-padded window maximum and exceeds
+// threshold_rel * max(surface) (flow_field.py:238-262).
+__device__ __forceinline__ bool peak_better(float v, int i, float bv, int bi) {
+  return v > bv || (v == bv && i < bi);
+}
+
+__device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
+                                 int Sy, int Sx, const int* pmax_lds,
+                                 float* scratch) {
+  __syncthreads();  // all tiles stored, running maximum final
+  const float mx = __int_as_float(*pmax_lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pitch = a.sx_pitch;
+  const int m = a.min_distance;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  // Tests one element that exceeds the threshold and records it if it is a
+  // window maximum.
+  auto consider = [&](int y, int x, float v) {
+    float wm = -INFINITY;
+    bool outside = false;
+    for (int dy = -m; dy <= m; ++dy)
+      for (int dx = -m; dx <= m; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy < 0 || yy >= Sy || xx < 0 || xx >= Sx) {
+          outside = true;
+          continue;
+        }
+        wm = fmaxf(wm, surf[(long long)yy * pitch + xx]);
+      }
+    if (outside) wm = fmaxf(wm, 0.f);
+    if (v != wm) return;
+    const int i = y * Sx + x;
+    if (peak_better(v, i, bv, bi)) {
+      bv = v;
+      bi = i;
+    }
+    const int slot = atomicAdd(&a.cand_count[b], 1);
+    if (slot < a.cand_cap) {
+      a.cand_val[(long long)b * a.cand_cap + slot] = v;
+      a.cand_idx[(long long)b * a.cand_cap + slot] = i;
+    }
+    if (i == 0) a.zero_is_peak[b] = 1;
+  };
+  if (mx > 0.f) {
+    const float thr = a.threshold_rel * mx;
+    const int n_hot = a.hot_count[b];
+    if (n_hot <= a.hot_cap) {
+      const float* hv = a.hot_val + (long long)b * a.hot_cap;
+      const int* hi = a.hot_idx + (long long)b * a.hot_cap;
+      for (int e = threadIdx.x; e < n_hot; e += kThreads) {
+        const float v = hv[e];
+        if (!(v > thr)) continue;
+        const int i = hi[e];
+        const int y = i / Sx;
+        consider(y, i - y * Sx, v);
+      }
+    } else {
+      // Hot list overflowed (flat surfaces): sweep the stored surface.
+      const int n4 = (Sx + 3) >> 2;
+      for (int y = wave; y < Sy; y += kWaves) {
+        const float* row = surf + (long long)y * pitch;
+        for (int c4 = lane; c4 < n4; c4 += 64) {
+          const float4 q4 = *reinterpret_cast<const float4*>(row + 4 * c4);
+          const float vals[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (vals[t] > thr && 4 * c4 + t < Sx) consider(y, 4 * c4 + t, vals[t]);
+        }
+      }
+    }
+  }
+  // (value, index) arg-max across the block, first index wins ties.
+  float* lv = scratch;
+  int* li = reinterpret_cast<int*>(scratch + kThreads);
+  lv[threadIdx.x] = bv;
+  li[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s && peak_better(lv[threadIdx.x + s], li[threadIdx.x + s],
+                                       lv[threadIdx.x], li[threadIdx.x])) {
+      lv[threadIdx.x] = lv[threadIdx.x + s];
+      li[threadIdx.x] = li[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v1 = lv[0];
+    const int i1 = v1 == -INFINITY ? 0 : li[0];  // argmax of an all -inf row is 0
+    a.idx1[b] = i1;
+    a.v1[b] = v1;
+    atomicOr(&a.bitmap[i1 >> 5], 1u << (i1 & 31));
+  }
+}
+
 template <int NCA, int NCE, bool SAME>
 __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   constexpr int NQ = NCA + NCE - 1;
@@ -467,6 +582,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   unsigned char* A_lds = smem;
   unsigned char* B_lds = smem + a.a_bytes;
   float* R_lds = reinterpret_cast<float*>(smem + a.a_bytes + a.b_bytes);
+  // 16 bytes behind the aux arrays: running maximum of the current surface.
+  int* pmax_lds = reinterpret_cast<int*>(smem + a.a_bytes + a.b_bytes + a.r_bytes);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -491,6 +608,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                 pp.c[0], A_lds, a.pa, kPadTop, 0, NCA);
     stage_patch(a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
                 pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16);
+    if (threadIdx.x == 0) *pmax_lds = 0;  // float bits of max(surface, 0)
     float const_a = 0.f, const_b = 0.f;
     if (SAME) {
       const float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
@@ -553,8 +671,13 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       // The surface buffer is padded to whole tiles (pitch 16 NQ, 16 NP rows),
       // so every lane stores unconditionally.
       int srow[4];
+      bool rowok[4];
+      float tmax = 0.f;  // max(tile, 0): only positive maxima matter
 #pragma unroll
-      for (int r = 0; r < 4; ++r) srow[r] = (16 * p + 4 * g + r) * a.sx_pitch + n;
+      for (int r = 0; r < 4; ++r) {
+        srow[r] = (16 * p + 4 * g + r) * a.sx_pitch + n;
+        rowok[r] = 16 * p + 4 * g + r < Sy;
+      }
       if (SAME) {
         // corr = ey ex G[yv][xv] + ey Rrow[sx][yv] + ex Rcol[sy][xv] + const
         //        + mua mub ny nx        (header comment, item 3)
@@ -600,7 +723,11 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             corr += (sy[r] && sx) ? const_a : 0.f;
             corr += (!sy[r] && !sx) ? const_b : 0.f;
             corr += fny[r] * fnx;
-            surf[srow[r] + 16 * q] = static_cast<float>(acc[q][r]) + corr;
+            const float v = static_cast<float>(acc[q][r]) + corr;
+            surf[srow[r] + 16 * q] = v;
+            const bool ok = rowok[r] && (q < NQ - 1 || kx < Sx);
+            tmax = fmaxf(tmax, ok ? v : 0.f);
+            acc[q][r] = __float_as_int(ok ? v : -INFINITY);
           }
         }
       } else {
@@ -635,10 +762,47 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             v = v - mub * static_cast<float>(sa);
             v = v + muab * (static_cast<float>(ny[r]) * fnx);
             surf[srow[r] + 16 * q] = v;
+            const bool ok = rowok[r] && (q < NQ - 1 || kx < Sx);
+            tmax = fmaxf(tmax, ok ? v : 0.f);
+            acc[q][r] = __float_as_int(ok ? v : -INFINITY);
+          }
+        }
+      }
+      if (a.do_peaks) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, d, 64));
+        // non-negative floats order like their bit patterns
+        if (lane == 0 && tmax > 0.f) atomicMax(pmax_lds, __float_as_int(tmax));
+        // Hot list: every element above threshold_rel * (running maximum) can
+        // still turn out to be a peak; the final filter runs when the surface
+        // is complete.  The running maximum never exceeds the final one, so
+        // nothing that matters is dropped.
+        const float mrun = fmaxf(tmax, __int_as_float(*pmax_lds));
+        const float thr_t = a.threshold_rel * mrun;
+        float* hv = a.hot_val + (long long)b * a.hot_cap;
+        int* hi = a.hot_idx + (long long)b * a.hot_cap;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float v0 = __int_as_float(acc[q][0]), v1 = __int_as_float(acc[q][1]);
+          const float v2 = __int_as_float(acc[q][2]), v3 = __int_as_float(acc[q][3]);
+          const float vm = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+          if (__any(vm > thr_t)) {  // wave-uniform, rarely taken
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = __int_as_float(acc[q][r]);
+              if (v > thr_t) {
+                const int slot = atomicAdd(&a.hot_count[b], 1);
+                if (slot < a.hot_cap) {
+                  hv[slot] = v;
+                  hi[slot] = (16 * p + 4 * g + r) * Sx + 16 * q + n;
+                }
+              }
+            }
           }
         }
       }
     }
+    if (a.do_peaks) fused_first_peak(a, b, surf, Sy, Sx, pmax_lds, R_lds);
   }
 }
 
@@ -781,7 +945,8 @@ void mfma_i8_padded_dims(const SfmXcorrDesc* d, int* rows, int* pitch) {
   *pitch = vi < 0 ? 0 : 16 * (kVariants[vi].nca + kVariants[vi].nce - 1);
 }
 
-int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface) {
+int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
+                    const FusedPeaks* fp) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const int vi = pick_variant(d->patch[2], d->post_patch[2]);
   if (vi < 0) return fail(SFM_ERR_INVALID, "patch too wide for the MFMA path");
@@ -813,6 +978,23 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface) {
   a.aux = w.aux;
   a.aux_n = w.aux_n;
   a.surface = surface;
+  if (fp) {
+    a.do_peaks = 1;
+    a.threshold_rel = d->threshold_rel;
+    a.min_distance = d->min_distance;
+    a.cand_cap = fp->cand_cap;
+    a.idx1 = fp->idx1;
+    a.v1 = fp->v1;
+    a.zero_is_peak = fp->zero_is_peak;
+    a.cand_count = fp->cand_count;
+    a.cand_val = fp->cand_val;
+    a.cand_idx = fp->cand_idx;
+    a.bitmap = fp->bitmap;
+    a.hot_cap = fp->hot_cap;
+    a.hot_count = fp->hot_count;
+    a.hot_val = fp->hot_val;
+    a.hot_idx = fp->hot_idx;
+  }
   {
     int rows = 0, pitch = 0;
     mfma_i8_padded_dims(d, &rows, &pitch);
@@ -872,8 +1054,13 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   }
-  const size_t lds =
-      (size_t)l.a_bytes + l.b_bytes + (same ? (size_t)4 * w.aux_n * 4 : 0);
+  // Region behind the patches: the four 1-D correction arrays, reused as the
+  // arg-max scratch of the fused peak search, then the running-max word.
+  size_t r_bytes = same ? (size_t)4 * w.aux_n * 4 : 0;
+  r_bytes = std::max(r_bytes, (size_t)kThreads * 8);
+  r_bytes = (r_bytes + 15) / 16 * 16;
+  a.r_bytes = static_cast<int>(r_bytes);
+  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   const int grid = std::min(d->batch, cus * per_cu);
   switch (vi) {
