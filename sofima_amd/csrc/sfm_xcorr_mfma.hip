@@ -221,6 +221,18 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
 // ---------------------------------------------------------------------------
 constexpr int kPrepCols = 3;  // columns per lane: Px <= 192
 
+// Wave-wide inclusive add scan on the DPP network (row shifts inside each
+// 16-lane row, then row broadcasts), ~12 VALU ops instead of 6 LDS permutes.
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return v;
+}
+
 __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int red[2][3][kThreads];
@@ -311,19 +323,22 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
   }
 
   // Phase 3a: per-band column totals (band w = rows [w R, (w + 1) R)).
+  // Lane l owns the kPrepCols consecutive columns kPrepCols * l + k, so one
+  // wave scan over the per-lane totals gives the prefix along x.
   const int R = (py + kWaves - 1) / kWaves;
   const int ra0 = min(wave * R, py), ra1 = min(ra0 + R, py);
+  const int xl = kPrepCols * lane;
 #pragma unroll
   for (int k = 0; k < kPrepCols; ++k) {
-    const int x = lane + 64 * k;
+    const int x = xl + k;
     int ta = 0, tb = 0;
     if (x < px)
       for (int y = ra0; y < ra1; ++y) {
         ta += pix[0][y * px + x];
         tb += pix[1][y * px + x];
       }
-    band_tot[0][wave][lane + 64 * k] = ta;
-    band_tot[1][wave][lane + 64 * k] = tb;
+    band_tot[0][wave][xl + k] = ta;
+    band_tot[1][wave][xl + k] = tb;
   }
   __syncthreads();
   const int ca = s_c[0], cb = s_c[1];
@@ -347,49 +362,42 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
     colB[k] = 0;
     for (int w2 = 0; w2 < kWaves; ++w2) {
       const int lo = min(w2 * R, py), hi = min(lo + R, py);
-      if (hi <= ra0) colA[k] += band_tot[0][w2][lane + 64 * k];
+      if (hi <= ra0) colA[k] += band_tot[0][w2][xl + k];
       if (hi <= py - ra0) {
-        colB[k] += band_tot[1][w2][lane + 64 * k];
+        colB[k] += band_tot[1][w2][xl + k];
       } else if (lo < py - ra0) {
-        // partial band: rows [lo, py - ra0)
-        const int x = lane + 64 * k;
+        const int x = xl + k;  // partial band: rows [lo, py - ra0)
         if (x < px)
           for (int y = lo; y < py - ra0; ++y) colB[k] += pix[1][y * px + x];
       }
     }
   }
-  // Sweep.  Wave 3 also emits the yv == py row (pre-patch totals).
+  // Sweep.  The last wave also emits the yv == py row (pre-patch totals).
   const int y_end = wave == kWaves - 1 ? py + 1 : ra1;
   for (int yv = ra0; yv < y_end; ++yv) {
     const int yw = py - yv;
-    int carryA = 0, carryB = 0;
+    // Inclusive prefix over the lane's own columns, then across lanes.
+    int pa[kPrepCols], pb[kPrepCols];
+    int sa = 0, sb = 0;
+#pragma unroll
+    for (int k = 0; k < kPrepCols; ++k) {
+      sa += xl + k < px ? colA[k] : 0;
+      sb += xl + k < px ? colB[k] : 0;
+      pa[k] = sa;
+      pb[k] = sb;
+    }
+    const int ea = wave_scan_incl(sa) - sa;  // exclusive prefix of lane totals
+    const int eb = wave_scan_incl(sb) - sb;
     if (lane == 0) {
       rowA[0] = 0;
       rowB[0] = 0;
     }
 #pragma unroll
-    for (int k = 0; k < kPrepCols; ++k) {
-      const int x = lane + 64 * k;
-      int va = x < px ? colA[k] : 0;
-      int vb = x < px ? colB[k] : 0;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int ta = __shfl_up(va, d, 64);
-        const int tb = __shfl_up(vb, d, 64);
-        if (lane >= d) {
-          va += ta;
-          vb += tb;
-        }
+    for (int k = 0; k < kPrepCols; ++k)
+      if (xl + k < px) {
+        rowA[xl + k + 1] = ea + pa[k];
+        rowB[xl + k + 1] = eb + pb[k];
       }
-      va += carryA;
-      vb += carryB;
-      if (x < px) {
-        rowA[x + 1] = va;
-        rowB[x + 1] = vb;
-      }
-      carryA = __shfl(va, 63, 64);
-      carryB = __shfl(vb, 63, 64);
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -418,7 +426,7 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
     if (yv < py) {
 #pragma unroll
       for (int k = 0; k < kPrepCols; ++k) {
-        const int x = lane + 64 * k;
+        const int x = xl + k;
         if (x < px) {
           colA[k] += pix[0][yv * px + x];
           colB[k] -= pix[1][(yw - 1) * px + x];
