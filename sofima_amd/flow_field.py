@@ -431,25 +431,54 @@ class JAXMaskedXCorrWithStatsCalculator:
                      max_masked, batch_size, post_patch_size,
                      pre_targeting_field, pre_targeting_step,
                      post_targeting_field, post_targeting_step)
+    pos = plan['positions']
+    n = pos.shape[0]
+    if n == 0:
+      return self.assemble(plan, nd, np.zeros((0, nd + 2), np.float32))
+
+    if mask_only_for_patch_selection:
+      pre_mask = post_mask = None
+    # progress_fn receives the list of per-batch grid positions like the
+    # reference's (flow_field.py:610) and is only iterated for its side effects.
+    batches = [pos[i:i + batch_size] for i in range(0, n, batch_size)]
+    peaks = self.compute_batches(pre_image, post_image, pre_mask, post_mask,
+                                 patch_size, post_patch_size, plan, batch_size,
+                                 None, progress_fn(batches))
+    return self.assemble(plan, nd, peaks)
+
+  # -- pieces shared with sofima_amd.dist ---------------------------------------
+  def compute_batches(self, pre_image, post_image, pre_mask, post_mask,
+                      patch_size, post_patch_size, plan, batch_size,
+                      batch_ids=None, progress=None) -> np.ndarray:
+    """Peaks [len(batch_ids) * batch_size, dim + 2] of the selected batches
+    (all batches when `batch_ids` is None), computed on the current GPU."""
+    dev = _dev.device()
+    res = _Resident(pre_image, post_image, pre_mask, post_mask, dev)
+    desc = _make_desc(res, patch_size, post_patch_size, self._mean,
+                      self._min_distance, 0.5, self._peak_radius, self._method)
+    pre_st, post_st = plan['pre_starts'], plan['post_starts']
+    if batch_ids is not None:
+      sel = np.concatenate([
+          np.arange(b * batch_size, (b + 1) * batch_size) for b in batch_ids
+      ]) if len(batch_ids) else np.zeros((0,), int)
+      pre_st, post_st = pre_st[sel], post_st[sel]
+      if len(sel) == 0:
+        return np.zeros((0, res.ndim + 2), np.float32)
+    return _run_batches(res, desc, pre_st, post_st, batch_size, progress)
+
+  @classmethod
+  def assemble(cls, plan, nd, peaks) -> np.ndarray:
+    """Scatters per-patch peaks (padding rows allowed at the end) into the
+    [dim + 2, *grid] flow array, undoing the targeting offsets
+    (flow_field.py:701-709)."""
     out_shape = plan['out_shape']
-    output = np.full([self.non_spatial_flow_channels + nd] + out_shape.tolist(),
+    output = np.full([cls.non_spatial_flow_channels + nd] + out_shape.tolist(),
                      np.nan, dtype=np.float32)
     pos = plan['positions']
     n = pos.shape[0]
     if n == 0:
       return output
-
-    if mask_only_for_patch_selection:
-      pre_mask = post_mask = None
-    dev = _dev.device()
-    res = _Resident(pre_image, post_image, pre_mask, post_mask, dev)
-    desc = _make_desc(res, patch_size, post_patch_size, self._mean,
-                      self._min_distance, 0.5, self._peak_radius, self._method)
-    # progress_fn receives the list of per-batch grid positions like the
-    # reference's (flow_field.py:610) and is only iterated for its side effects.
-    batches = [pos[i:i + batch_size] for i in range(0, n, batch_size)]
-    peaks = _run_batches(res, desc, plan['pre_starts'], plan['post_starts'],
-                         batch_size, progress_fn(batches))[:n]
+    peaks = np.array(peaks[:n], dtype=np.float32)
     if plan['tg_offsets'] is not None:
       peaks[:, :nd] += plan['tg_offsets'][:n, ::-1]  # xy[z]
     if plan['post_offsets'] is not None:
