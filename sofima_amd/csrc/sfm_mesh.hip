@@ -27,6 +27,7 @@
 #include "sfm_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -442,6 +443,486 @@ stats_kernel(const float* __restrict__ stat_partials, int rows,
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Persistent single-launch integrator for in-plane meshes that fit the chip
+// (one 32 x 32 node tile per workgroup, one workgroup per CU, one node per
+// thread, node state in registers).
+//
+// The multi-launch path above pays two kernel boundaries per step (~20 us per
+// step for the 205 x 205 mesh of an 8192^2 section).  Here the whole chunk of
+// num_iters steps is one launch; per step every workgroup publishes
+//   - (x, v, a) of its 124 perimeter nodes, and
+//   - its partial sums (power, drift sums)
+// as 8-byte {epoch, value} granules written with write-through agent-scope
+// stores, and polls the granules of its 8 neighbour tiles and the partials of
+// all workgroups with relaxed agent-scope loads: the data is its own flag, no
+// cache fence and no grid barrier is needed (MI355X hand-off recipe R2).
+// Because a neighbour's (x, v, a) is known, a tile advances its halo nodes
+// itself, so there is ONE exchange per step.  Every workgroup reduces the
+// partials of all workgroups in the same fixed order, so the FIRE scalars
+// (dt, alpha, n_pos, cap, gate) are computed redundantly and identically.
+// Granule slots are double buffered by epoch parity: a workgroup can be at
+// most one step ahead of the slowest one because it needs everyone's partials.
+// Spins are bounded; on a timeout the kernel raises an abort flag, writes
+// nothing back, and the host re-runs the chunk on the multi-launch path.
+// ---------------------------------------------------------------------------
+constexpr int kNodeGran = 6;   // x0 x1 v0 v1 a0 a1
+constexpr int kPartGran = 8;   // power, sum x[3], sum v[3], pad
+constexpr int kMaxWg = 256;
+constexpr int kSpinLimit = 1 << 21;
+
+typedef unsigned long long u64;
+
+template <int T>
+struct Tile {
+  static constexpr int kThreads = T * T;
+  static constexpr int kWavesT = kThreads / 64;
+  static constexpr int kPerim = 4 * T - 4;
+  static constexpr int kHalo = 4 * T + 4;
+  static constexpr int kSlot = kPerim * kNodeGran + kPartGran;  // granules
+  static constexpr int kHaloPolls = (kHalo * kNodeGran + kThreads - 1) / kThreads;
+  static constexpr int kPartPolls = (kMaxWg * 7 + kThreads - 1) / kThreads;
+  static constexpr int kPolls = kHaloPolls + kPartPolls;
+};
+
+struct PersistArgs {
+  u64* comm;            // [nWG][2][slot] granules, zeroed before launch
+  int* abort;           // set on timeout
+  const Scalars* scal_in;
+  Scalars* scal_out;
+  float* stat_partials; // [nWG][2]
+  int num_iters;
+  float cap0;
+  int nty, ntx, n_wg;
+};
+
+__device__ __forceinline__ void put_granule(u64* g, unsigned epoch, float v) {
+  __hip_atomic_store(g, (static_cast<u64>(epoch) << 32) | __float_as_uint(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Polls N granules concurrently: all loads of a round are in flight together,
+// so a collect costs one round trip, not one per granule.
+template <int N>
+__device__ __forceinline__ bool poll_granules(const u64* const* g, float* const* d,
+                                              unsigned epoch, int* abort) {
+  unsigned need = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (g[i]) need |= 1u << i;
+  for (int spin = 0; need && spin < kSpinLimit; ++spin) {
+    u64 x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      x[i] = (need >> i) & 1u
+                 ? __hip_atomic_load(g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                 : 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (((need >> i) & 1u) && static_cast<unsigned>(x[i] >> 32) == epoch) {
+        *d[i] = __uint_as_float(static_cast<unsigned>(x[i]));
+        need &= ~(1u << i);
+      }
+    if (!need) break;
+    if ((spin & 1023) == 1023 &&
+        __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (need) {
+    __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
+  return true;
+}
+
+// Fixed-order wave sum on the DPP network + row broadcasts (result valid in
+// lane 63).
+#define SFM_DPP_F32(x, ctrl, rmask, bc)                                         \
+  __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, \
+                                             0xf, bc))
+__device__ __forceinline__ float wave_sum63(float v) {
+  v = v + SFM_DPP_F32(v, 0x111, 0xf, true);   // row_shr:1
+  v = v + SFM_DPP_F32(v, 0x112, 0xf, true);   // row_shr:2
+  v = v + SFM_DPP_F32(v, 0x114, 0xf, true);   // row_shr:4
+  v = v + SFM_DPP_F32(v, 0x118, 0xf, true);   // row_shr:8
+  v = v + SFM_DPP_F32(v, 0x142, 0xa, false);  // row_bcast:15
+  v = v + SFM_DPP_F32(v, 0x143, 0xc, false);  // row_bcast:31
+  return v;
+}
+
+// Spring force with a precomputed rest length (same arithmetic as spring<2>).
+__device__ __forceinline__ void spring2(float d0, float d1, float l0, const int* dir,
+                                        float neg_k, int prefer, float* f) {
+  const float l = sqrtf(d0 * d0 + d1 * d1);
+  const float d[2] = {d0, d1};
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float num = l0;
+    if (prefer && dir[c] != 0) {
+      const float sg = d[c] > 0.f ? 1.f : (d[c] < 0.f ? -1.f : 0.f);
+      num = l0 * (static_cast<float>(dir[c]) * sg);
+    }
+    const float t = num / l;
+    const float u = 1.0f - t;
+    float v = (neg_k * u) * d[c];
+    if (!isfinite(v)) v = 0.f;
+    f[c] = v;
+  }
+}
+
+template <int T>
+__device__ __forceinline__ int perim_index(int ly, int lx) {
+  if (ly == 0) return lx;
+  if (ly == T - 1) return T + lx;
+  if (lx == 0) return 2 * T + (ly - 1);
+  if (lx == T - 1) return 2 * T + (T - 2) + (ly - 1);
+  return -1;
+}
+
+template <int T>
+__device__ __forceinline__ void halo_coord(int h, int* hy, int* hx) {
+  if (h < T + 2) { *hy = 0; *hx = h; }
+  else if (h < 2 * (T + 2)) { *hy = T + 1; *hx = h - (T + 2); }
+  else if (h < 2 * (T + 2) + T) { *hx = 0; *hy = h - 2 * (T + 2) + 1; }
+  else { *hx = T + 1; *hy = h - 2 * (T + 2) - T + 1; }
+}
+
+template <int T>
+__global__ void __launch_bounds__(T * T)
+mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ vg,
+                      float* __restrict__ ag, const float* __restrict__ prevg,
+                      PersistArgs q) {
+  using TL = Tile<T>;
+  constexpr int NT = TL::kThreads;
+  __shared__ float xt[2][T + 2][T + 3];
+  __shared__ float hval[TL::kHalo][kNodeGran];
+  __shared__ float part_all[kMaxWg][kPartGran];
+  __shared__ float wred[TL::kWavesT][kPartGran];
+  __shared__ float sums[kPartGran];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ly = tid / T, lx = tid % T;
+  const int wg = blockIdx.x;
+  const int tx_i = wg % q.ntx;
+  const int ty_i = (wg / q.ntx) % q.nty;
+  const int slice = wg / (q.ntx * q.nty);
+  const int yi = ty_i * T + ly, xi = tx_i * T + lx;
+  const bool active = yi < p.Y && xi < p.X;
+  const long long plane = (long long)p.Y * p.X;
+  const long long n = slice * plane + (long long)yi * p.X + xi;
+  const int pidx = perim_index<T>(ly, lx);
+  const int nred = p.remove_drift ? 7 : 1;  // values exchanged per workgroup
+
+  // Halo slot owned by this thread (threads < kHalo): position + source node.
+  int hy = 0, hx = 0;
+  long long h_n = -1;
+  if (tid < TL::kHalo) {
+    halo_coord<T>(tid, &hy, &hx);
+    const int gy = ty_i * T + hy - 1, gx = tx_i * T + hx - 1;
+    if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X)
+      h_n = slice * plane + (long long)gy * p.X + gx;
+  }
+  // Granules this thread fetches in a collect: halo (slot relative offsets).
+  long long h_off[TL::kHaloPolls];
+  float* h_dst[TL::kHaloPolls];
+#pragma unroll
+  for (int u = 0; u < TL::kHaloPolls; ++u) {
+    h_off[u] = -1;
+    h_dst[u] = nullptr;
+    const int t = tid + u * NT;
+    if (t < TL::kHalo * kNodeGran) {
+      const int h = t / kNodeGran, j = t - h * kNodeGran;
+      int qy, qx;
+      halo_coord<T>(h, &qy, &qx);
+      const int gy = ty_i * T + qy - 1, gx = tx_i * T + qx - 1;
+      if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X) {
+        const int oty = gy / T, otx = gx / T;
+        const int owg = (slice * q.nty + oty) * q.ntx + otx;
+        h_off[u] = (long long)owg * 2 * TL::kSlot +
+                   perim_index<T>(gy - oty * T, gx - otx * T) * kNodeGran + j;
+        h_dst[u] = &hval[h][j];
+      }
+    }
+  }
+
+  float x0 = 0.f, x1 = 0.f, v0 = 0.f, v1 = 0.f, a0 = 0.f, a1 = 0.f;
+  float pr0 = 0.f, pr1 = 0.f;
+  if (active) {
+    x0 = xg[n];
+    x1 = xg[p.N + n];
+    v0 = vg[n];
+    v1 = vg[p.N + n];
+    if (p.has_prev) {
+      pr0 = prevg[n];
+      pr1 = prevg[p.N + n];
+    }
+  }
+  Scalars s = *q.scal_in;
+  s.gate = 1.f;
+  for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+  if (!p.fire) s.dt = p.vv_dt;
+  const float fixed_cap = q.cap0;
+  float l0[4];
+#pragma unroll
+  for (int L = 0; L < 4; ++L) l0[L] = vec_len(p.rest[L], 2);
+
+  auto tile_force = [&](float* out) {
+    // identical operation order to node_force<2> with order2d
+    const float s0 = xt[0][ly + 1][lx + 1], s1 = xt[1][ly + 1][lx + 1];
+    float acc0 = 0.f, acc1 = 0.f, f[2];
+#pragma unroll
+    for (int L = 0; L < 4; ++L) {  // this node is the far end
+      const int nx = xi - p.dir[L][0], ny = yi - p.dir[L][1];
+      if (nx < 0 || nx >= p.X || ny < 0 || ny >= p.Y) continue;
+      const int ty = ly + 1 - p.dir[L][1], tx = lx + 1 - p.dir[L][0];
+      spring2(s0 - xt[0][ty][tx] + p.rest[L][0], s1 - xt[1][ty][tx] + p.rest[L][1],
+              l0[L], p.dir[L], p.neg_k[L], p.prefer, f);
+      acc0 = acc0 + f[0];
+      acc1 = acc1 + f[1];
+    }
+#pragma unroll
+    for (int L = 0; L < 4; ++L) {  // this node is the near end
+      const int nx = xi + p.dir[L][0], ny = yi + p.dir[L][1];
+      if (nx < 0 || nx >= p.X || ny < 0 || ny >= p.Y) continue;
+      const int ty = ly + 1 + p.dir[L][1], tx = lx + 1 + p.dir[L][0];
+      spring2(xt[0][ty][tx] - s0 + p.rest[L][0], xt[1][ty][tx] - s1 + p.rest[L][1],
+              l0[L], p.dir[L], p.neg_k[L], p.prefer, f);
+      acc0 = acc0 - f[0];
+      acc1 = acc1 - f[1];
+    }
+    out[0] = acc0;
+    out[1] = acc1;
+  };
+
+  // ---- a = F(x) + pull at the initial positions ------------------------------
+  xt[0][ly + 1][lx + 1] = x0;
+  xt[1][ly + 1][lx + 1] = x1;
+  if (h_n >= 0) {
+    xt[0][hy][hx] = xg[h_n];
+    xt[1][hy][hx] = xg[p.N + h_n];
+  }
+  __syncthreads();
+  if (active) {
+    float f[2];
+    tile_force(f);
+    if (p.has_prev) {
+      f[0] = f[0] + prev_pull(x0, pr0, p.neg_k0, p.fire ? s.cap : fixed_cap);
+      f[1] = f[1] + prev_pull(x1, pr1, p.neg_k0, p.fire ? s.cap : fixed_cap);
+    }
+    a0 = f[0];
+    a1 = f[1];
+  }
+  float my_part = 0.f;  // threads < nred: this workgroup's partial sum #tid
+
+  bool ok = true;
+  for (int k = 1; k <= q.num_iters + 1; ++k) {
+    const unsigned epoch = static_cast<unsigned>(k);
+    const bool last = k == q.num_iters + 1;
+    const long long slot_off = (long long)(k & 1) * TL::kSlot;
+    u64* my_slot = q.comm + (long long)wg * 2 * TL::kSlot + slot_off;
+    // ---- publish the state after k - 1 steps ----------------------------------
+    if (!last && active && pidx >= 0) {
+      u64* g = my_slot + pidx * kNodeGran;
+      put_granule(g + 0, epoch, x0);
+      put_granule(g + 1, epoch, x1);
+      put_granule(g + 2, epoch, v0);
+      put_granule(g + 3, epoch, v1);
+      put_granule(g + 4, epoch, a0);
+      put_granule(g + 5, epoch, a1);
+    }
+    const bool reduce_now = p.fire && k > 1;
+    if (reduce_now && tid < nred)
+      put_granule(my_slot + TL::kPerim * kNodeGran + tid, epoch, my_part);
+    // ---- collect ------------------------------------------------------------------
+    const u64* g[TL::kPolls];
+    float* d[TL::kPolls];
+#pragma unroll
+    for (int u = 0; u < TL::kHaloPolls; ++u) {
+      const bool want = !last && h_off[u] >= 0;
+      g[u] = want ? q.comm + h_off[u] + slot_off : nullptr;
+      d[u] = h_dst[u];
+    }
+#pragma unroll
+    for (int u = 0; u < TL::kPartPolls; ++u) {
+      const int t = tid + u * NT;
+      const int w2 = t / nred, j = t - w2 * nred;
+      const bool want = reduce_now && w2 < q.n_wg && w2 != wg;
+      g[TL::kHaloPolls + u] =
+          want ? q.comm + (long long)w2 * 2 * TL::kSlot + slot_off +
+                     TL::kPerim * kNodeGran + j
+               : nullptr;
+      d[TL::kHaloPolls + u] = want ? &part_all[w2][j] : nullptr;
+    }
+    if (reduce_now && tid < nred) part_all[wg][tid] = my_part;  // own: no round trip
+    const bool mine_ok = poll_granules<TL::kPolls>(g, d, epoch, q.abort);
+    if (!__syncthreads_and(mine_ok ? 1 : 0)) {
+      ok = false;
+      break;
+    }
+    // ---- FIRE scalars from the partials of step k - 1 -------------------------------
+    if (reduce_now) {
+      // value i is summed over workgroups by wave i mod #waves (fixed order:
+      // strided per lane, then the DPP tree): identical in every workgroup.
+      for (int i = wave; i < nred; i += TL::kWavesT) {
+        float t = 0.f;
+        for (int w2 = lane; w2 < q.n_wg; w2 += 64) t = t + part_all[w2][i];
+        t = wave_sum63(t);
+        if (lane == 63) sums[i] = t;
+      }
+      __syncthreads();
+      const float power = sums[0];
+      Scalars t = s;
+      const bool downhill = power >= 0.f;
+      t.n_pos = downhill ? s.n_pos + 1 : 0;
+      if (downhill) {
+        if (t.n_pos > p.n_min) {
+          t.dt = fminf(s.dt * p.f_inc, p.dt_cap);
+          t.alpha = s.alpha * p.f_alpha;
+        }
+        if (t.n_pos > 0 && (t.n_pos % p.cap_every) == 0) t.cap = p.cap_scale * s.cap;
+      } else {
+        t.dt = s.dt * p.f_dec;
+        t.alpha = p.alpha0;
+      }
+      t.cap = fminf(t.cap, p.final_cap);
+      t.gate = downhill ? 1.f : 0.f;
+      for (int c = 0; c < 3; ++c) {
+        t.mx[c] = p.remove_drift ? sums[1 + c] / p.n_f : 0.f;
+        t.mv[c] = p.remove_drift ? (sums[4 + c] / p.n_f) * t.gate : 0.f;
+      }
+      s = t;
+      // pending gate / drift of step k - 1 on the node's own state
+      v0 = v0 * s.gate;
+      v1 = v1 * s.gate;
+      if (p.remove_drift) {
+        x0 = x0 - s.mx[0];
+        x1 = x1 - s.mx[1];
+        v0 = v0 - s.mv[0];
+        v1 = v1 - s.mv[1];
+      }
+    }
+    if (last) break;
+
+    // ---- advance: x += dt v + dt^2/2 a for own and halo nodes --------------------
+    const float dt = s.dt;
+    const float c2 = 0.5f * (dt * dt);
+    x0 = x0 + (dt * v0 + c2 * a0);
+    x1 = x1 + (dt * v1 + c2 * a1);
+    xt[0][ly + 1][lx + 1] = x0;
+    xt[1][ly + 1][lx + 1] = x1;
+    if (h_n >= 0) {
+      float hx0 = hval[tid][0], hx1 = hval[tid][1];
+      float hv0 = hval[tid][2], hv1 = hval[tid][3];
+      if (reduce_now) {
+        hv0 = hv0 * s.gate;
+        hv1 = hv1 * s.gate;
+        if (p.remove_drift) {
+          hx0 = hx0 - s.mx[0];
+          hx1 = hx1 - s.mx[1];
+          hv0 = hv0 - s.mv[0];
+          hv1 = hv1 - s.mv[1];
+        }
+      }
+      xt[0][hy][hx] = hx0 + (dt * hv0 + c2 * hval[tid][4]);
+      xt[1][hy][hx] = hx1 + (dt * hv1 + c2 * hval[tid][5]);
+    }
+    __syncthreads();
+
+    // ---- integrate ------------------------------------------------------------------
+    float part[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      const float cap = p.fire ? s.cap : fixed_cap;
+      const float hdtg = (0.5f * dt) * p.gamma;
+      const float fact0 = 1.0f / (1.0f + hdtg);
+      const float fact1 = 1.0f - hdtg;
+      const float hdt = 0.5f * dt;
+      float f[2];
+      tile_force(f);
+      if (p.has_prev) {
+        f[0] = f[0] + prev_pull(x0, pr0, p.neg_k0, cap);
+        f[1] = f[1] + prev_pull(x1, pr1, p.neg_k0, cap);
+      }
+      float n0 = fact0 * (v0 * fact1 + hdt * (a0 + f[0]));
+      float n1 = fact0 * (v1 * fact1 + hdt * (a1 + f[1]));
+      a0 = f[0];
+      a1 = f[1];
+      if (p.fire) {
+        float a2 = 0.f, v2 = 0.f, pw = 0.f;
+        a2 = a2 + f[0] * f[0];
+        v2 = v2 + n0 * n0;
+        pw = pw + f[0] * n0;
+        a2 = a2 + f[1] * f[1];
+        v2 = v2 + n1 * n1;
+        pw = pw + f[1] * n1;
+        part[0] = pw;
+        part[1] = x0;
+        part[2] = x1;
+        const float a_norm = sqrtf(a2) + 1e-6f;
+        const float v_norm = sqrtf(v2);
+        n0 = n0 + s.alpha * (f[0] / a_norm * v_norm - n0);
+        n1 = n1 + s.alpha * (f[1] / a_norm * v_norm - n1);
+        part[4] = n0;
+        part[5] = n1;
+      }
+      v0 = n0;
+      v1 = n1;
+    }
+    if (p.fire) {
+      // block sums in a fixed order: DPP tree per wave, then waves in order
+      for (int i = 0; i < nred; ++i) {
+        const float t = wave_sum63(part[i]);
+        if (lane == 63) wred[wave][i] = t;
+      }
+      __syncthreads();  // also: everyone is done with xt / hval / part_all
+      if (tid < nred) {
+        float t = 0.f;
+        for (int w2 = 0; w2 < TL::kWavesT; ++w2) t = t + wred[w2][tid];
+        my_part = t;
+      }
+    } else {
+      __syncthreads();
+    }
+  }
+
+  if (!ok) return;  // timed out: leave the global state untouched
+  // ---- write back, chunk statistics ------------------------------------------------
+  float ek = 0.f, vm2 = 0.f;
+  if (active) {
+    xg[n] = x0;
+    xg[p.N + n] = x1;
+    vg[n] = v0;
+    vg[p.N + n] = v1;
+    ag[n] = a0;
+    ag[p.N + n] = a1;
+    ek = v0 * v0 + v1 * v1;
+    vm2 = ek;
+  }
+#pragma unroll
+  for (int dd = 32; dd > 0; dd >>= 1) {
+    ek = ek + __shfl_xor(ek, dd, 64);
+    vm2 = fmaxf(vm2, __shfl_xor(vm2, dd, 64));
+  }
+  __syncthreads();
+  if (lane == 0) {
+    wred[wave][0] = ek;
+    wred[wave][1] = vm2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float e = 0.f, m = 0.f;
+    for (int w2 = 0; w2 < TL::kWavesT; ++w2) {
+      e = e + wred[w2][0];
+      m = fmaxf(m, wred[w2][1]);
+    }
+    q.stat_partials[wg * 2] = e;
+    q.stat_partials[wg * 2 + 1] = m;
+    if (wg == 0) *q.scal_out = s;
+  }
+}
+
 const int kDefaultLinks[13][3] = {
     {1, 0, 0}, {0, 1, 0},  {0, 0, 1},  {1, 1, 0},  {-1, 1, 0},
     {1, 0, 1}, {-1, 0, 1}, {0, 1, 1},  {0, -1, 1}, {1, 1, 1},
@@ -519,6 +1000,11 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
   return SFM_OK;
 }
 
+bool persistent_enabled() {
+  const char* e = getenv("SFM_MESH_PERSISTENT");
+  return !(e && e[0] == '0');
+}
+
 int grid_for(long long n) {
   long long g = (n + kBlock - 1) / kBlock;
   if (g > kMaxBlocks) g = kMaxBlocks;
@@ -531,6 +1017,9 @@ struct MeshWorkspace {
   float* partials;     // [kMaxBlocks * kNP]
   float* stat_part;    // [kMaxBlocks * 2]
   float* stats;        // [2]
+  u64* comm;           // persistent path: [256][2][slot] granules
+  int* abort;          // persistent path: timeout flag
+  size_t comm_bytes;
   size_t bytes;
 };
 
@@ -541,6 +1030,10 @@ MeshWorkspace carve(void* ws) {
   w.partials = c.take<float>(kMaxBlocks * kNP);
   w.stat_part = c.take<float>(kMaxBlocks * 2);
   w.stats = c.take<float>(2);
+  const size_t slot_max = Tile<32>::kSlot;
+  w.comm = c.take<u64>((size_t)kMaxWg * 2 * slot_max + 8);
+  w.abort = reinterpret_cast<int*>(w.comm + (size_t)kMaxWg * 2 * slot_max);
+  w.comm_bytes = ((size_t)kMaxWg * 2 * slot_max + 8) * sizeof(u64);
   w.bytes = c.total();
   return w;
 }
@@ -599,6 +1092,78 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
                                hipMemcpyHostToDevice, st));
 
   const float cap0 = fire->cap;
+
+  // Persistent single-launch path for in-plane meshes that fit the chip.
+  if (persistent_enabled() && p.ncomp == 2 && d->num_iters >= 1) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    }
+    // Small tiles spread the (latency bound) step over more CUs; fall back to
+    // 32 x 32 tiles when there would be more workgroups than CUs.
+    int tile = 0;
+    for (int t : {16, 32}) {
+      const long long nw = (long long)p.B * ((p.Y + t - 1) / t) * ((p.X + t - 1) / t);
+      if (nw <= kMaxWg && nw <= cus) {
+        tile = t;
+        break;
+      }
+    }
+    if (tile) {
+      const int nty = (p.Y + tile - 1) / tile, ntx = (p.X + tile - 1) / tile;
+      const long long n_wg = (long long)p.B * nty * ntx;
+      PersistArgs q;
+      q.comm = w.comm;
+      q.abort = w.abort;
+      q.scal_in = &w.scal[0];
+      q.scal_out = &w.scal[1];
+      q.stat_partials = w.stat_part;
+      q.num_iters = d->num_iters;
+      q.cap0 = cap0;
+      q.nty = nty;
+      q.ntx = ntx;
+      q.n_wg = static_cast<int>(n_wg);
+      SFM_HIP_CHECK(hipMemsetAsync(w.comm, 0, w.comm_bytes, st));
+      sfm::prof_begin(sfm::kProfMesh, st);
+      if (tile == 16)
+        hipLaunchKernelGGL(mesh_persist2d_kernel<16>, dim3(q.n_wg), dim3(256), 0, st,
+                           p, d->x, d->v, d->a, d->prev, q);
+      else
+        hipLaunchKernelGGL(mesh_persist2d_kernel<32>, dim3(q.n_wg), dim3(1024), 0, st,
+                           p, d->x, d->v, d->a, d->prev, q);
+      sfm::prof_end(sfm::kProfMesh, st);
+      SFM_LAUNCH_CHECK();
+      hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(kBlock), 0, st, w.stat_part,
+                         q.n_wg, w.stats);
+      SFM_LAUNCH_CHECK();
+      Scalars s1;
+      float hs[2];
+      int aborted = 0;
+      SFM_HIP_CHECK(hipMemcpyAsync(&s1, &w.scal[1], sizeof(s1),
+                                   hipMemcpyDeviceToHost, st));
+      SFM_HIP_CHECK(hipMemcpyAsync(hs, w.stats, sizeof(hs), hipMemcpyDeviceToHost, st));
+      SFM_HIP_CHECK(hipMemcpyAsync(&aborted, w.abort, sizeof(int),
+                                   hipMemcpyDeviceToHost, st));
+      SFM_HIP_CHECK(hipStreamSynchronize(st));
+      if (!aborted) {
+        if (p.fire) {
+          fire->dt = s1.dt;
+          fire->alpha = s1.alpha;
+          fire->n_pos = s1.n_pos;
+          fire->cap = s1.cap;
+        }
+        stats->e_kin = hs[0];
+        stats->v_max = hs[1];
+        return SFM_OK;
+      }
+      // Timed out (workgroups not co-resident?): the state is untouched, fall
+      // through to the multi-launch path.
+      SFM_HIP_CHECK(hipMemcpyAsync(&w.scal[0], &s0, sizeof(s0),
+                                   hipMemcpyHostToDevice, st));
+    }
+  }
 #define SFM_MESH_DISPATCH(KERNEL, ...)                                       \
   do {                                                                       \
     if (p.ncomp == 2)                                                        \
