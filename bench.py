@@ -196,18 +196,40 @@ def main():
       'ms_per_step': t_mesh / args.steps * 1e3,
   }
   if ms_n:
-    avg_us = ms_ms / ms_n * 1e3
-    gbs = mesh_nodes * 56.0 / (avg_us * 1e-6) / 1e9
+    # Timed launches are either one persistent kernel per chunk (num_iters
+    # steps each) or one integrate kernel per step.
+    steps_per_launch = mesh_steps_done / ms_n
+    us_per_step = ms_ms * 1e3 / mesh_steps_done
+    gbs = mesh_nodes * 56.0 / (us_per_step * 1e-6) / 1e9
+    persistent = steps_per_launch > 1.5
     mesh_obj['roofline'] = {
-        'kernel': 'integrate_kernel<2>', 'bound': 'hbm',
-        'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-        'frac': round(gbs / PEAK_HBM_GBS, 5),
-        'avg_launch_us': round(avg_us, 3), 'launches': int(ms_n),
+        'kernel': 'mesh_persist2d_kernel<16>' if persistent else 'integrate_kernel<2>',
+        'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS,
+        'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
+        'kernel_us_per_step': round(us_per_step, 3), 'launches': int(ms_n),
+        'steps_per_launch': round(steps_per_launch, 1),
         'bytes_per_node_update': 56, 'traffic': None,
-        'note': 'state (1.3 MB) is cache resident; the step is launch/sync '
-                'bound, see steps_per_s',
+        'note': 'the 1.3 MB state never leaves the chip (registers + LDS in the '
+                'persistent kernel); the step is bound by the per-step '
+                'inter-workgroup exchange latency, not by HBM: see steps_per_s',
     }
     mesh_obj['steps_per_s'] = mesh_steps_done / t_mesh
+
+  # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes
+  # (profiles/r01_pmc_traffic.json, written by tools/pmc_summary.py); null when
+  # no measurement of this build's kernel is on file.
+  if roof and uses_mfma:
+    try:
+      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+      for name, v in pmc.items():
+        if 'xcorr_mfma_kernel<10, 11, true>' in name and size == 8192:
+          roof['traffic'] = v['hbm_bytes_per_launch']
+          roof['traffic_note'] = (
+              'bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, '
+              'separate --pmc passes; algorithmic HBM bytes per launch = patches '
+              '52 MB + G tables 103 MB + surface 414 MB = 570 MB')
+    except (OSError, ValueError):
+      pass
 
   out = {
       'metric': 'patch-xcorr Mpix/s (+ mesh node-updates/s) on 8192^2 tiles',
@@ -258,7 +280,7 @@ def cpu_baseline(pre, post, cfg):
   mpix = n * STEP * STEP / 1e6 / t
   rng = np.random.default_rng(0)
   prev = rng.standard_normal((2, 1, 205, 205)).astype(np.float32)
-  iters = 300
+  iters = 3000
   c = types.SimpleNamespace(**{**cfg.to_dict(), 'num_iters': iters,
                                'max_iters': iters})
   c.stride = tuple(c.stride)
