@@ -131,6 +131,58 @@ size_t sfm_peaks_workspace_bytes(const SfmPeaksDesc* desc);
 int sfm_peaks(const SfmPeaksDesc* desc, float* peaks);
 
 /* ------------------------------------------------------------------------
+ * Coordinate-map composition.
+ * Replaces map_utils.compose_maps_fast (map_utils.py:616-734): bilinear /
+ * trilinear resampling of map2 (absolute) at the targets of map1, result in
+ * map1's relative format.  Maps are float [C, z, y, x], C = 2 (every z
+ * section independently in-plane) or 3 (volumetric).
+ * ---------------------------------------------------------------------- */
+#define SFM_INTERP_NEAREST 0   /* out-of-range corner indices are clamped      */
+#define SFM_INTERP_CONSTANT 1  /* out-of-range corners read as NaN             */
+
+typedef struct SfmComposeDesc {
+  int32_t ncomp;                /* 2 or 3                                    */
+  int32_t mode;                 /* SFM_INTERP_*                              */
+  int32_t shape1[3];            /* z, y, x of map1 (and of the output)       */
+  int32_t shape2[3];            /* z, y, x of map2                           */
+  float start1[3];              /* zyx origin of map1 (z ignored for C = 2)  */
+  float start2[3];
+  float stride1[3];             /* zyx node spacing of map1                  */
+  float stride2[3];
+  const float* map1;            /* device [C, *shape1]                       */
+  const float* map2;            /* device [C, *shape2]                       */
+  void* stream;
+} SfmComposeDesc;
+
+int sfm_compose_maps(const SfmComposeDesc* desc, float* out);
+
+/* ------------------------------------------------------------------------
+ * Target mesh of an elastic tile montage.
+ * Replaces stitch_elastic.compute_target_mesh (stitch_elastic.py:624-676,
+ * with _update_mesh :573-620 and _apply_flow :456-570) vmapped over all
+ * tiles: out[:, t] = positions in the meshes of tile t's neighbours that the
+ * flow fields say its nodes correspond to; NaN where no neighbour overlaps.
+ * ---------------------------------------------------------------------- */
+typedef struct SfmTargetMeshDesc {
+  int32_t ncomp;                /* 2 (in-plane montage)                      */
+  int32_t n_tiles;
+  int32_t mesh_shape[3];        /* z, y, x of one tile mesh (z = 1)          */
+  int32_t fx_shape[3];          /* z, y, x of one flow array in fx           */
+  int32_t fy_shape[3];
+  int32_t n_fx;                 /* flow arrays in fx (its dimension 1)       */
+  int32_t n_fy;
+  int32_t nbor_fields;          /* 8 (NeighborInfo, stitch_elastic.py:43-72) */
+  float stride[3];              /* zyx stride of flow and mesh               */
+  const int32_t* nbors;         /* device [n_tiles, 4, nbor_fields]          */
+  const float* fx;              /* device [ncomp, n_fx, *fx_shape]           */
+  const float* fy;              /* device [ncomp, n_fy, *fy_shape]           */
+} SfmTargetMeshDesc;
+
+/* x, out: device float [ncomp, n_tiles, *mesh_shape]. */
+int sfm_target_mesh(const SfmTargetMeshDesc* desc, const float* x, float* out,
+                    void* stream);
+
+/* ------------------------------------------------------------------------
  * Spring mesh.
  * ---------------------------------------------------------------------- */
 #define SFM_MESH_MAX_LINKS 13
@@ -168,6 +220,9 @@ typedef struct SfmMeshDesc {
   void* workspace;
   size_t workspace_bytes;
   void* stream;
+  /* Optional native prev_fn (mesh.py:429-430): when set, `prev` must be NULL
+     and prev = target_mesh(x) is re-evaluated inside every force evaluation. */
+  const SfmTargetMeshDesc* target;
 } SfmMeshDesc;
 
 /* FIRE scalars carried between chunks (mesh.py:449, :513, :589). */

@@ -71,6 +71,39 @@ class SfmPeaksDesc(C.Structure):
   ]
 
 
+class SfmComposeDesc(C.Structure):
+  _fields_ = [
+      ('ncomp', i32),
+      ('mode', i32),
+      ('shape1', i32 * 3),
+      ('shape2', i32 * 3),
+      ('start1', C.c_float * 3),
+      ('start2', C.c_float * 3),
+      ('stride1', C.c_float * 3),
+      ('stride2', C.c_float * 3),
+      ('map1', C.c_void_p),
+      ('map2', C.c_void_p),
+      ('stream', C.c_void_p),
+  ]
+
+
+class SfmTargetMeshDesc(C.Structure):
+  _fields_ = [
+      ('ncomp', i32),
+      ('n_tiles', i32),
+      ('mesh_shape', i32 * 3),
+      ('fx_shape', i32 * 3),
+      ('fy_shape', i32 * 3),
+      ('n_fx', i32),
+      ('n_fy', i32),
+      ('nbor_fields', i32),
+      ('stride', C.c_float * 3),
+      ('nbors', C.c_void_p),
+      ('fx', C.c_void_p),
+      ('fy', C.c_void_p),
+  ]
+
+
 class SfmMeshDesc(C.Structure):
   _fields_ = [
       ('ncomp', i32),
@@ -102,6 +135,7 @@ class SfmMeshDesc(C.Structure):
       ('workspace', C.c_void_p),
       ('workspace_bytes', C.c_size_t),
       ('stream', C.c_void_p),
+      ('target', C.POINTER(SfmTargetMeshDesc)),
   ]
 
 
@@ -130,6 +164,9 @@ SIGNATURES = {
     'sfm_xcorr_surface': (C.c_int, [C.POINTER(SfmXcorrDesc), C.c_void_p]),
     'sfm_peaks_workspace_bytes': (C.c_size_t, [C.POINTER(SfmPeaksDesc)]),
     'sfm_peaks': (C.c_int, [C.POINTER(SfmPeaksDesc), C.c_void_p]),
+    'sfm_compose_maps': (C.c_int, [C.POINTER(SfmComposeDesc), C.c_void_p]),
+    'sfm_target_mesh': (C.c_int, [C.POINTER(SfmTargetMeshDesc), C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     'sfm_mesh_workspace_bytes': (C.c_size_t, [C.POINTER(SfmMeshDesc)]),
     'sfm_mesh_force': (C.c_int, [C.POINTER(SfmMeshDesc), C.c_void_p]),
     'sfm_mesh_relax_chunk': (C.c_int, [C.POINTER(SfmMeshDesc),

@@ -18,6 +18,7 @@ SOURCES = {
     'sfm_mesh.hip': ['-ffp-contract=off'],
     'sfm_xcorr.hip': [],
     'sfm_xcorr_mfma.hip': [],
+    'sfm_maps.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
           '-Wno-unused-result']

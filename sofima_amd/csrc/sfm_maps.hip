@@ -1,0 +1,288 @@
+// Coordinate-map composition and the montage target mesh for gfx950.
+//
+//   compose_kernel      <-> map_utils.compose_maps_fast (map_utils.py:616-734),
+//                           i.e. jax.scipy.ndimage.map_coordinates(order=1)
+//   target_mesh_kernel  <-> stitch_elastic.compute_target_mesh
+//                           (stitch_elastic.py:456-676) for all tiles
+//
+// Both are gathers with a handful of flops per output: HBM/latency bound, one
+// thread per output node, coalesced along x.
+#include "sfm_common.h"
+
+#include <cmath>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// order-1 map_coordinates of JAX: per axis lower = floor(q), weights
+// (1 - t, t); corners visited lower-before-upper with the first axis
+// outermost; products of weights times the corner value summed left to right;
+// mode constant: a corner with any index out of range contributes cval = NaN.
+struct Axis {
+  int lo;
+  float w_lo, w_hi;
+};
+
+__device__ __forceinline__ Axis make_axis(float q) {
+  Axis a;
+  const float f = floorf(q);
+  a.w_hi = q - f;
+  a.w_lo = 1.0f - a.w_hi;
+  a.lo = static_cast<int>(f);
+  return a;
+}
+
+// Bilinear sample of plane `m` [ny, nx] + ref (ref = offset + index * step
+// along `ref_axis`) at (qy, qx).
+__device__ float sample2(const float* __restrict__ m, int ny, int nx, float qy,
+                         float qx, bool constant, int ref_axis, float ref_off,
+                         float ref_step) {
+  if (isnan(qy) || isnan(qx)) return NAN;
+  const Axis ay = make_axis(qy), ax = make_axis(qx);
+  float sum = 0.f;
+  bool first = true;
+#pragma unroll
+  for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx) {
+      int iy = ay.lo + cy, ix = ax.lo + cx;
+      const float w = (cy ? ay.w_hi : ay.w_lo) * (cx ? ax.w_hi : ax.w_lo);
+      bool valid = iy >= 0 && iy < ny && ix >= 0 && ix < nx;
+      iy = min(max(iy, 0), ny - 1);
+      ix = min(max(ix, 0), nx - 1);
+      float v = m[(long long)iy * nx + ix] +
+                (ref_off + static_cast<float>(ref_axis == 0 ? iy : ix)) * ref_step;
+      if (constant && !valid) v = NAN;
+      const float t = w * v;
+      sum = first ? t : sum + t;
+      first = false;
+    }
+  return sum;
+}
+
+__device__ float sample3(const float* __restrict__ m, int nz, int ny, int nx,
+                         float qz, float qy, float qx, bool constant, int ref_axis,
+                         float ref_off, float ref_step) {
+  if (isnan(qz) || isnan(qy) || isnan(qx)) return NAN;
+  const Axis az = make_axis(qz), ay = make_axis(qy), ax = make_axis(qx);
+  float sum = 0.f;
+  bool first = true;
+#pragma unroll
+  for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) {
+        int iz = az.lo + cz, iy = ay.lo + cy, ix = ax.lo + cx;
+        const float w = ((cz ? az.w_hi : az.w_lo) * (cy ? ay.w_hi : ay.w_lo)) *
+                        (cx ? ax.w_hi : ax.w_lo);
+        bool valid = iz >= 0 && iz < nz && iy >= 0 && iy < ny && ix >= 0 && ix < nx;
+        iz = min(max(iz, 0), nz - 1);
+        iy = min(max(iy, 0), ny - 1);
+        ix = min(max(ix, 0), nx - 1);
+        const int ri = ref_axis == 0 ? iz : (ref_axis == 1 ? iy : ix);
+        float v = m[((long long)iz * ny + iy) * nx + ix] +
+                  (ref_off + static_cast<float>(ri)) * ref_step;
+        if (constant && !valid) v = NAN;
+        const float t = w * v;
+        sum = first ? t : sum + t;
+        first = false;
+      }
+  return sum;
+}
+
+struct ComposeArgs {
+  int ncomp, constant;
+  int s1[3], s2[3];
+  float off1[3], off2[3];  // start - origin, zyx
+  float st1[3], st2[3];
+  const float* m1;
+  const float* m2;
+  float* out;
+};
+
+__global__ void __launch_bounds__(kBlock) compose_kernel(ComposeArgs a) {
+  const long long n1 = (long long)a.s1[0] * a.s1[1] * a.s1[2];
+  const long long n2 = (long long)a.s2[0] * a.s2[1] * a.s2[2];
+  const long long plane2 = (long long)a.s2[1] * a.s2[2];
+  for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n1;
+       i += (long long)gridDim.x * kBlock) {
+    const int x = static_cast<int>(i % a.s1[2]);
+    const long long r = i / a.s1[2];
+    const int y = static_cast<int>(r % a.s1[1]);
+    const int z = static_cast<int>(r / a.s1[1]);
+    const float ref1x = (static_cast<float>(x) + a.off1[2]) * a.st1[2];
+    const float ref1y = (static_cast<float>(y) + a.off1[1]) * a.st1[1];
+    const float qx = (ref1x + a.m1[i]) / a.st2[2];
+    const float qy = (ref1y + a.m1[n1 + i]) / a.st2[1];
+    if (a.ncomp == 2) {
+      // every z section on its own (map_utils.py:666-695); a section missing
+      // in map2 cannot occur: the reference indexes map2[:, z] directly.
+      const float* p0 = a.m2 + (long long)z * plane2;
+      const float* p1 = a.m2 + n2 + (long long)z * plane2;
+      a.out[i] = sample2(p0, a.s2[1], a.s2[2], qy, qx, a.constant, 1, a.off2[2],
+                         a.st2[2]) - ref1x;
+      a.out[n1 + i] = sample2(p1, a.s2[1], a.s2[2], qy, qx, a.constant, 0,
+                              a.off2[1], a.st2[1]) - ref1y;
+    } else {
+      const float ref1z = (static_cast<float>(z) + a.off1[0]) * a.st1[0];
+      const float qz = (ref1z + a.m1[2 * n1 + i]) / a.st2[0];
+      a.out[i] = sample3(a.m2, a.s2[0], a.s2[1], a.s2[2], qz, qy, qx, a.constant,
+                         2, a.off2[2], a.st2[2]) - ref1x;
+      a.out[n1 + i] = sample3(a.m2 + n2, a.s2[0], a.s2[1], a.s2[2], qz, qy, qx,
+                              a.constant, 1, a.off2[1], a.st2[1]) - ref1y;
+      a.out[2 * n1 + i] = sample3(a.m2 + 2 * n2, a.s2[0], a.s2[1], a.s2[2], qz, qy,
+                                  qx, a.constant, 0, a.off2[0], a.st2[0]) - ref1z;
+    }
+  }
+}
+
+// NeighborInfo field indices (stitch_elastic.py:43-72).
+enum { kNbor = 0, kFlow = 1, kOffOrtho = 2, kSizeOrtho = 3, kSizeOverlap = 4,
+       kFineX = 5, kFineY = 6, kDim = 7 };
+
+struct TargetArgs {
+  SfmTargetMeshDesc d;
+  const float* x;
+  float* out;
+};
+
+// One thread per (tile, node).  The reference pastes the four neighbour
+// updates in order into a NaN canvas, keeping the previous value where the
+// update is NaN (per component); the last non-NaN update wins.
+__global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
+  const SfmTargetMeshDesc& d = a.d;
+  const int my = d.mesh_shape[1], mx = d.mesh_shape[2];
+  const long long mn = (long long)my * mx;
+  const long long total = (long long)d.n_tiles * mn;
+  const float sy = d.stride[1], sx = d.stride[2];
+  for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kBlock) {
+    const int tile = static_cast<int>(i / mn);
+    const int node = static_cast<int>(i - tile * mn);
+    const int ty = node / mx, tx = node - ty * mx;
+    float rx = NAN, ry = NAN;
+    for (int j = 0; j < 4; ++j) {
+      const int* nb = d.nbors + ((long long)tile * 4 + j) * d.nbor_fields;
+      const int nbor = nb[kNbor];
+      if (nbor == -1) continue;
+      const int flow_idx = nb[kFlow];
+      const int dim = nb[kDim] == 0 ? 0 : 1;
+      const int mult = nbor == flow_idx ? 1 : -1;
+      const int off_ortho = nb[kOffOrtho];
+      const int f_ortho = nb[kSizeOrtho], f_overlap = nb[kSizeOverlap];
+      const int* fshape = dim == 0 ? d.fx_shape : d.fy_shape;
+      const int n_f = dim == 0 ? d.n_fx : d.n_fy;
+      const float* farr = dim == 0 ? d.fx : d.fy;
+      const int fy_n = fshape[1], fx_n = fshape[2];
+      // size of the neighbour mesh along / across the overlap direction
+      const int par_n = dim == 0 ? mx : my;
+      const int ortho_n = dim == 0 ? my : mx;
+      const int start_par = mult == 1 ? par_n - f_overlap : 0;
+      const bool s_hi = (mult == 1 && off_ortho > 0) || (mult == -1 && off_ortho < 0);
+      const int start_ortho = s_hi ? ortho_n - f_ortho : 0;
+      const int st_y = dim == 0 ? start_ortho : start_par;
+      const int st_x = dim == 0 ? start_par : start_ortho;
+      const int tg_par = mult == 1 ? 0 : par_n - f_overlap;
+      const bool t_hi = (mult == 1 && off_ortho < 0) || (mult == -1 && off_ortho > 0);
+      const int tg_ortho = t_hi ? ortho_n - f_ortho : 0;
+      const int tg_y = dim == 0 ? tg_ortho : tg_par;
+      const int tg_x = dim == 0 ? tg_par : tg_ortho;
+      const int uy = ty - tg_y, ux = tx - tg_x;
+      if (uy < 0 || uy >= fy_n || ux < 0 || ux >= fx_n) continue;
+      // jax clamps the dynamic index; valid data never needs it
+      const int fi = min(max(flow_idx, 0), n_f - 1);
+      const long long fplane = (long long)fy_n * fx_n;
+      const long long fo = (long long)fi * fplane + (long long)uy * fx_n + ux;
+      const float m1x = static_cast<float>(mult) * farr[fo];
+      const float m1y = static_cast<float>(mult) * farr[(long long)n_f * fplane + fo];
+      // compose_maps_fast(flow @ start, neighbour mesh @ 0, mode constant)
+      const float ref1x = (static_cast<float>(ux) + static_cast<float>(st_x)) * sx;
+      const float ref1y = (static_cast<float>(uy) + static_cast<float>(st_y)) * sy;
+      const float qx = (ref1x + m1x) / sx;
+      const float qy = (ref1y + m1y) / sy;
+      const int nb_i = min(max(nbor, 0), d.n_tiles - 1);
+      const float* nx0 = a.x + (long long)nb_i * mn;
+      const float* nx1 = a.x + ((long long)d.n_tiles + nb_i) * mn;
+      float ux_v = sample2(nx0, my, mx, qy, qx, true, 1, 0.f, sx) - ref1x;
+      float uy_v = sample2(nx1, my, mx, qy, qx, true, 0, 0.f, sy) - ref1y;
+      ux_v = ux_v + static_cast<float>(mult * nb[kFineX]);
+      uy_v = uy_v + static_cast<float>(mult * nb[kFineY]);
+      if (!isnan(ux_v)) rx = ux_v;
+      if (!isnan(uy_v)) ry = uy_v;
+    }
+    a.out[(long long)tile * mn + node] = rx;
+    a.out[((long long)d.n_tiles + tile) * mn + node] = ry;
+  }
+}
+
+int grid_for(long long n) {
+  long long g = (n + kBlock - 1) / kBlock;
+  return static_cast<int>(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+namespace sfm {
+
+int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
+                       hipStream_t st) {
+  if (!d || !x || !out) return fail(SFM_ERR_INVALID, "target mesh: NULL argument");
+  if (d->ncomp != 2 || d->mesh_shape[0] != 1)
+    return fail(SFM_ERR_INVALID, "target mesh: only in-plane montages (ncomp 2)");
+  if (d->nbor_fields < 8 || !d->nbors || !d->fx || !d->fy || d->n_tiles < 1)
+    return fail(SFM_ERR_INVALID, "target mesh: bad neighbour / flow arrays");
+  TargetArgs a;
+  a.d = *d;
+  a.x = x;
+  a.out = out;
+  const long long total =
+      (long long)d->n_tiles * d->mesh_shape[1] * d->mesh_shape[2];
+  hipLaunchKernelGGL(target_mesh_kernel, dim3(grid_for(total)), dim3(kBlock), 0, st,
+                     a);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+}  // namespace sfm
+
+extern "C" {
+
+int sfm_compose_maps(const SfmComposeDesc* d, float* out) {
+  if (!d || !out || !d->map1 || !d->map2)
+    return sfm::fail(SFM_ERR_INVALID, "compose: NULL argument");
+  if (d->ncomp != 2 && d->ncomp != 3)
+    return sfm::fail(SFM_ERR_INVALID, "compose: ncomp must be 2 or 3");
+  ComposeArgs a;
+  a.ncomp = d->ncomp;
+  a.constant = d->mode == SFM_INTERP_CONSTANT;
+  for (int i = 0; i < 3; ++i) {
+    if (d->shape1[i] < 1 || d->shape2[i] < 1)
+      return sfm::fail(SFM_ERR_INVALID, "compose: bad shape");
+    a.s1[i] = d->shape1[i];
+    a.s2[i] = d->shape2[i];
+    const float origin = fminf(d->start1[i], d->start2[i]);
+    a.off1[i] = d->start1[i] - origin;
+    a.off2[i] = d->start2[i] - origin;
+    a.st1[i] = d->stride1[i];
+    a.st2[i] = d->stride2[i];
+  }
+  if (d->ncomp == 2 && d->shape1[0] > d->shape2[0])
+    return sfm::fail(SFM_ERR_INVALID, "compose: map2 has fewer sections than map1");
+  a.m1 = d->map1;
+  a.m2 = d->map2;
+  a.out = out;
+  const long long n1 = (long long)a.s1[0] * a.s1[1] * a.s1[2];
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  hipLaunchKernelGGL(compose_kernel, dim3(grid_for(n1)), dim3(kBlock), 0, st, a);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+int sfm_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
+                    void* stream) {
+  return sfm::launch_target_mesh(d, x, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -30,6 +30,12 @@
 #include <cstdlib>
 #include <cstring>
 
+namespace sfm {
+// sfm_maps.hip
+int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
+                       hipStream_t st);
+}  // namespace sfm
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -944,7 +950,7 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
   p->N = (long long)p->B * p->Z * p->Y * p->X;
   p->prefer = d->prefer_orig_order;
   p->neg_k0 = static_cast<float>(-d->k0);
-  p->has_prev = d->prev != nullptr;
+  p->has_prev = d->prev != nullptr || d->target != nullptr;
   if (d->ncomp == 2) {
     // Batch and z are both independent slices for the in-plane force; fold
     // them so the stencil never crosses a slice (Z extent of the stencil = 1).
@@ -1020,12 +1026,14 @@ struct MeshWorkspace {
   u64* comm;           // persistent path: [256][2][slot] granules
   int* abort;          // persistent path: timeout flag
   size_t comm_bytes;
+  float* prev_buf;     // native prev_fn: prev = target_mesh(x), [ncomp * N]
   size_t bytes;
 };
 
-MeshWorkspace carve(void* ws) {
+MeshWorkspace carve(void* ws, size_t prev_floats = 0) {
   sfm::Carver c(ws);
   MeshWorkspace w;
+  w.prev_buf = prev_floats ? c.take<float>(prev_floats) : nullptr;
   w.scal = c.take<Scalars>(2);
   w.partials = c.take<float>(kMaxBlocks * kNP);
   w.stat_part = c.take<float>(kMaxBlocks * 2);
@@ -1042,8 +1050,12 @@ MeshWorkspace carve(void* ws) {
 
 extern "C" {
 
-size_t sfm_mesh_workspace_bytes(const SfmMeshDesc* /*desc*/) {
-  return carve(nullptr).bytes;
+size_t sfm_mesh_workspace_bytes(const SfmMeshDesc* d) {
+  size_t prev_floats = 0;
+  if (d && d->target)
+    prev_floats = (size_t)d->ncomp * d->shape[0] * d->shape[1] * d->shape[2] *
+                  d->shape[3];
+  return carve(nullptr, prev_floats).bytes;
 }
 
 int sfm_mesh_force(const SfmMeshDesc* d, float* out) {
@@ -1074,12 +1086,16 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     return sfm::fail(SFM_ERR_INVALID,
                      "remove_drift on 5-D arrays (per-column means of the "
                      "reference) is not implemented");
-  MeshWorkspace w = carve(d->workspace);
+  if (d->target && d->prev)
+    return sfm::fail(SFM_ERR_INVALID,
+                     "Only one of: \"prev\" and \"prev_fn\" can be specified.");
+  MeshWorkspace w = carve(d->workspace, d->target ? (size_t)p.ncomp * p.N : 0);
   if (!d->workspace || d->workspace_bytes < w.bytes)
     return sfm::fail(SFM_ERR_WORKSPACE, "mesh workspace needs %zu bytes, got %zu",
                      w.bytes, d->workspace_bytes);
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const int grid = grid_for(p.N);
+  const float* prev_ptr = d->target ? w.prev_buf : d->prev;
 
   Scalars s0;
   std::memset(&s0, 0, sizeof(s0));
@@ -1094,7 +1110,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   const float cap0 = fire->cap;
 
   // Persistent single-launch path for in-plane meshes that fit the chip.
-  if (persistent_enabled() && p.ncomp == 2 && d->num_iters >= 1) {
+  if (persistent_enabled() && p.ncomp == 2 && d->num_iters >= 1 && !d->target) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess) {
       hipDeviceProp_t prop;
@@ -1175,8 +1191,10 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     SFM_LAUNCH_CHECK();                                                      \
   } while (0)
 
-  // a = F(x) + pull(prev, cap)   (mesh.py:501)
-  SFM_MESH_DISPATCH(force_kernel, d->x, d->prev, d->a, p, cap0, p.has_prev);
+  // a = F(x) + pull(prev, cap)   (mesh.py:501); prev = prev_fn(x) if native
+  if (d->target)
+    if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
+  SFM_MESH_DISPATCH(force_kernel, d->x, prev_ptr, d->a, p, cap0, p.has_prev);
 
   int cur = 0;
   for (int it = 0; it < d->num_iters; ++it) {
@@ -1184,8 +1202,10 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
                       &w.scal[cur ^ 1], w.partials, grid, pending);
     cur ^= 1;
+    if (d->target)
+      if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
     sfm::prof_begin(sfm::kProfMesh, st);
-    SFM_MESH_DISPATCH(integrate_kernel, d->x, d->v, d->a, d->prev, p,
+    SFM_MESH_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
                       &w.scal[cur], cap0, w.partials);
     sfm::prof_end(sfm::kProfMesh, st);
   }

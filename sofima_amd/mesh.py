@@ -219,6 +219,16 @@ def _resolve_force(mesh_force):
       'callables cannot be fused into the HIP integrator (see DESIGN.md).')
 
 
+def _native_prev_fn(prev_fn):
+  """Returns the TargetMeshFn behind `prev_fn`, or raises for JAX closures."""
+  from . import stitch_elastic
+  if isinstance(prev_fn, stitch_elastic.TargetMeshFn):
+    return prev_fn
+  raise NotImplementedError(
+      'prev_fn must be a sofima_amd.stitch_elastic.TargetMeshFn; arbitrary '
+      'Python callables cannot be fused into the HIP integrator (DESIGN.md)')
+
+
 def _chunk_desc(x_t, v_t, a_t, prev_t, config: IntegrationConfig, ncomp, links,
                 ws) -> _abi.SfmMeshDesc:
   d = _base_desc(x_t, ncomp, config.k, config.stride, config.prefer_orig_order,
@@ -249,14 +259,21 @@ def _chunk_desc(x_t, v_t, a_t, prev_t, config: IntegrationConfig, ncomp, links,
 
 
 def _run_chunk(x_t, v_t, prev_t, config, force_cap, fire_dt, fire_alpha, ncomp,
-               links):
+               links, target=None):
   """One velocity_verlet call on device tensors (x_t, v_t updated in place)."""
   lib = _abi.load()
   a_t = torch.empty_like(x_t)
-  probe = _abi.SfmMeshDesc()
+  probe = _base_desc(x_t, ncomp, config.k, config.stride,
+                     config.prefer_orig_order, links)
+  tdesc = None
+  if target is not None:
+    tdesc = target.bind(x_t)
+    probe.target = C.pointer(tdesc)
   ws = _dev.workspace(lib.sfm_mesh_workspace_bytes(C.byref(probe)),
                       x_t.device)
   d = _chunk_desc(x_t, v_t, a_t, prev_t, config, ncomp, links, ws)
+  if tdesc is not None:
+    d.target = C.pointer(tdesc)
   fire = _abi.SfmFireState()
   fire.dt = np.float32(config.dt if fire_dt is None else fire_dt)
   fire.alpha = np.float32(config.alpha if fire_alpha is None else fire_alpha)
@@ -278,17 +295,16 @@ def velocity_verlet(x, v, prev, config: IntegrationConfig, force_cap: float,
   (x, v, a) or, with FIRE, (x, v, a, dt, alpha, n_pos, cap).  The inputs are
   not modified.
   """
-  if prev_fn is not None:
-    raise NotImplementedError(
-        'prev_fn callables are not supported by the HIP integrator yet '
-        '(DESIGN.md, "next")')
+  target = None if prev_fn is None else _native_prev_fn(prev_fn)
+  if target is not None and prev is not None:
+    raise ValueError('Only one of: "prev" and "prev_fn" can be specified.')
   ncomp, links = _resolve_force(mesh_force)
   dev = _dev.device()
   x_t = _dev.as_device_f32(x, dev, copy=True)
   v_t = _dev.as_device_f32(v, dev, copy=True)
   prev_t = None if prev is None else _dev.as_device_f32(prev, dev, copy=False)
   a_t, fire, _ = _run_chunk(x_t, v_t, prev_t, config, force_cap, fire_dt,
-                            fire_alpha, ncomp, links)
+                            fire_alpha, ncomp, links, target)
   out = (DeviceArray(x_t), DeviceArray(v_t), DeviceArray(a_t))
   if config.fire:
     out += (np.float32(fire.dt), np.float32(fire.alpha), int(fire.n_pos),
@@ -319,10 +335,7 @@ def relax_mesh(x, prev, config: IntegrationConfig, mesh_force=inplane_force,
 
   if prev is not None and prev_fn is not None:
     raise ValueError('Only one of: "prev" and "prev_fn" can be specified.')
-  if prev_fn is not None:
-    raise NotImplementedError(
-        'prev_fn callables are not supported by the HIP integrator yet '
-        '(DESIGN.md, "next")')
+  target = None if prev_fn is None else _native_prev_fn(prev_fn)
 
   ncomp, links = _resolve_force(mesh_force)
   dev = _dev.device()
@@ -332,7 +345,7 @@ def relax_mesh(x, prev, config: IntegrationConfig, mesh_force=inplane_force,
 
   while t < config.max_iters:
     _, fire, stats = _run_chunk(x_t, v_t, prev_t, config, cap, dt, alpha,
-                                ncomp, links)
+                                ncomp, links, target)
     t += config.num_iters
     e_kin.append(float(stats.e_kin))
     v_max = float(stats.v_max)

@@ -1,0 +1,101 @@
+"""Target mesh of an elastic tile montage on MI355X.
+
+Drop-in for the device part of the reference's `stitch_elastic.py`:
+`compute_target_mesh` (stitch_elastic.py:624-676, with `_update_mesh` :573-620
+and `_apply_flow` :456-570) -- the `prev_fn` that `mesh.relax_mesh` evaluates
+inside every force evaluation when a montage is relaxed.  The host-side
+drivers of that file (`compute_flow_map`, `aggregate_arrays`) are out of scope;
+their outputs (`fx`, `fy`, `x`, `nbors`) are the inputs here.
+
+The notebooks build the prev_fn as
+    jit(lambda x: transpose(vmap(partial(compute_target_mesh, x=x, fx=fx, fy=fy,
+                                         stride=stride))(nbors), [1, 0, 2, 3]))
+`TargetMeshFn(nbors, fx, fy, stride)` is that function as one HIP kernel;
+`mesh.relax_mesh(x, None, cfg, prev_fn=TargetMeshFn(...))` runs it natively.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+
+import numpy as np
+import torch
+
+from . import _abi
+from . import _dev
+from ._dev import DeviceArray
+
+
+class NeighborInfo(enum.IntEnum):
+  """Indices in a neighbour-info row (stitch_elastic.py:43-72)."""
+  nbor_idx = 0
+  flow_idx = 1
+  coarse_offset_ortho = 2
+  flow_size_ortho = 3
+  flow_size_overlap = 4
+  fine_off_x = 5
+  fine_off_y = 6
+  dim = 7
+  coarse_offset_z = 8
+  flow_size_z = 9
+  fine_off_z = 10
+
+
+class TargetMeshFn:
+  """prev_fn(x) for all tiles of a 2-D montage: [2, N, y, x] -> [2, N, y, x]."""
+
+  def __init__(self, nbors, fx, fy, stride=(20, 20)):
+    dev = _dev.device()
+    nb = np.ascontiguousarray(np.asarray(nbors), dtype=np.int32)
+    if nb.ndim != 3 or nb.shape[1] != 4 or nb.shape[2] < 8:
+      raise ValueError('nbors must be [n_tiles, 4, 8 or 11]')
+    self.fx = _dev.as_device_f32(fx, dev, copy=False)
+    self.fy = _dev.as_device_f32(fy, dev, copy=False)
+    if self.fx.ndim != 4 or self.fx.shape[0] != 2:
+      raise NotImplementedError('only in-plane montages ([2, n, y, x] flows)')
+    self.nbors = torch.from_numpy(nb).to(dev)
+    self.stride = tuple(float(s) for s in stride)
+    d = _abi.SfmTargetMeshDesc()
+    d.ncomp = 2
+    d.n_tiles = nb.shape[0]
+    d.fx_shape = (C.c_int32 * 3)(1, *self.fx.shape[2:])
+    d.fy_shape = (C.c_int32 * 3)(1, *self.fy.shape[2:])
+    d.n_fx = self.fx.shape[1]
+    d.n_fy = self.fy.shape[1]
+    d.nbor_fields = nb.shape[2]
+    d.stride = (C.c_float * 3)(1.0, *self.stride)
+    d.nbors = self.nbors.data_ptr()
+    d.fx = self.fx.data_ptr()
+    d.fy = self.fy.data_ptr()
+    self.desc = d
+
+  def bind(self, x_t: torch.Tensor) -> _abi.SfmTargetMeshDesc:
+    if x_t.ndim != 4 or x_t.shape[0] != 2 or x_t.shape[1] != self.desc.n_tiles:
+      raise ValueError('x must be [2, n_tiles, y, x]')
+    self.desc.mesh_shape = (C.c_int32 * 3)(1, *x_t.shape[2:])
+    return self.desc
+
+  def __call__(self, x) -> DeviceArray:
+    dev = _dev.device()
+    x_t = _dev.as_device_f32(x, dev, copy=False)
+    d = self.bind(x_t)
+    out = torch.empty_like(x_t)
+    _abi.check(_abi.load().sfm_target_mesh(C.byref(d), x_t.data_ptr(),
+                                           out.data_ptr(), _dev.stream_ptr()))
+    return DeviceArray(out)
+
+
+def compute_target_mesh(nbor_data, x, fx, fy, stride=(20, 20)) -> np.ndarray:
+  """Target positions for ONE tile mesh (stitch_elastic.py:624-676).
+
+  nbor_data: [4, 8] neighbour info of the tile; x, fx, fy as in the reference.
+  Evaluates the whole montage and returns the entry of the tile whose
+  neighbour rows were given (the tile is identified by position 0 of a
+  one-tile batch).
+  """
+  nb = np.asarray(nbor_data)[None]
+  x = np.asarray(x)
+  fn = TargetMeshFn(np.repeat(nb, x.shape[1], axis=0), fx, fy, stride)
+  # every "tile" of the batch uses the same neighbour rows; entry 0 is the
+  # result the reference returns for this nbor_data
+  return np.asarray(fn(x))[:, 0]

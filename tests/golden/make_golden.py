@@ -302,8 +302,73 @@ def gen_maps():
   save('compose_maps', **out)
 
 
+def gen_montage():
+  """2 x 2 montage of 512^2 tiles through the reference's stitch_rigid /
+  stitch_elastic chain: the inputs and outputs of
+  compute_target_mesh (the prev_fn of the montage relaxation) and the relaxed
+  mesh."""
+  import functools as ft
+  import json
+  from sofima import stitch_rigid, stitch_elastic, flow_utils
+  jax = sys.modules['jax']
+  jnp = sys.modules['jax.numpy']
+  rng = np.random.default_rng(1001)
+  t, ov = 512, 64
+  canvas = ndimage.gaussian_filter(rng.standard_normal((2 * t, 2 * t)), 2.0)
+  canvas = ((canvas - canvas.min()) / (canvas.max() - canvas.min()) * 255
+            ).astype(np.uint8)
+  jit = {(0, 0): (0, 0), (1, 0): (3, -2), (0, 1): (-4, 5), (1, 1): (2, 1)}
+  tile_map = {}
+  for (tx, ty), (dy, dx) in jit.items():
+    y0 = 20 + ty * (t - ov) + dy
+    x0 = 20 + tx * (t - ov) + dx
+    tile_map[(tx, ty)] = canvas[y0:y0 + t, x0:x0 + t]
+  cx, cy = stitch_rigid.compute_coarse_offsets(
+      (2, 2), tile_map, overlaps_xy=((96, 128), (96, 128)), min_overlap=32)
+  coarse = stitch_rigid.optimize_coarse_mesh(cx, cy)
+  stride = (32, 32)
+  cx2, cy2 = cx[:, 0], cy[:, 0]
+  fx_, offx = stitch_elastic.compute_flow_map(
+      tile_map, cx2, 0, patch_size=(64, 64), stride=stride, batch_size=64)
+  fy_, offy = stitch_elastic.compute_flow_map(
+      tile_map, cy2, 1, patch_size=(64, 64), stride=stride, batch_size=64)
+  kw = dict(min_peak_ratio=1.4, min_peak_sharpness=1.4, max_deviation=5,
+            max_magnitude=0)
+  fine_x = {k: flow_utils.clean_flow(v[:, None], **kw)[:, 0]
+            for k, v in fx_.items()}
+  fine_y = {k: flow_utils.clean_flow(v[:, None], **kw)[:, 0]
+            for k, v in fy_.items()}
+  fx, fy, x, nbors, key_to_idx = stitch_elastic.aggregate_arrays(
+      (cx2, fine_x, offx), (cy2, fine_y, offy), list(tile_map.keys()),
+      coarse[:, 0], stride=stride, tile_shape=(t, t))
+  fx = np.asarray(fx, np.float32)
+  fy = np.asarray(fy, np.float32)
+  x = np.asarray(x, np.float32)
+  # a non-trivial mesh state so the bilinear part is exercised
+  xs = x + (rng.standard_normal(x.shape) * 1.5).astype(np.float32)
+
+  def prev_fn(xx):
+    tf = ft.partial(stitch_elastic.compute_target_mesh, x=xx, fx=fx, fy=fy,
+                    stride=stride)
+    r = jax.vmap(tf)(nbors)
+    return jnp.transpose(r, [1, 0, 2, 3])
+
+  tg0 = np.asarray(prev_fn(jnp.asarray(x)))
+  tg1 = np.asarray(prev_fn(jnp.asarray(xs)))
+  cfg = rmesh.IntegrationConfig(
+      dt=0.001, gamma=0., k0=0.01, k=0.1, stride=stride, num_iters=100,
+      max_iters=200, stop_v_max=0.001, dt_max=100, prefer_orig_order=True,
+      start_cap=0.1, final_cap=10., remove_drift=True)
+  xr, ek, tt = rmesh.relax_mesh(x.copy(), None, cfg, prev_fn=prev_fn)
+  save('montage', fx=fx, fy=fy, x=x, xs=xs, nbors=np.asarray(nbors, np.int32),
+       tg0=tg0, tg1=tg1, relaxed=np.asarray(xr, np.float32),
+       ekin=np.asarray(ek), t=np.asarray(tt),
+       cfg=np.array(json.dumps(cfg_dict(cfg))), stride=np.asarray(stride))
+  print('target finite fraction', np.isfinite(tg0[0]).mean(axis=(1, 2)))
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps']
+  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'montage']
   if 'xcorr' in which:
     gen_xcorr_np()
   if 'peaks' in which:
@@ -314,3 +379,5 @@ if __name__ == '__main__':
     gen_mesh()
   if 'maps' in which:
     gen_maps()
+  if 'montage' in which:
+    gen_montage()

@@ -54,7 +54,9 @@ def test_struct_layouts_match_header():
                      ('SfmMeshDesc', _abi.SfmMeshDesc),
                      ('SfmFireState', _abi.SfmFireState),
                      ('SfmChunkStats', _abi.SfmChunkStats),
-                     ('SfmProfile', _abi.SfmProfile)):
+                     ('SfmProfile', _abi.SfmProfile),
+                     ('SfmComposeDesc', _abi.SfmComposeDesc),
+                     ('SfmTargetMeshDesc', _abi.SfmTargetMeshDesc)):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,
                      re.S).group(1)
     names = []

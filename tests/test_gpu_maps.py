@@ -1,0 +1,86 @@
+"""compose_maps_fast and the montage target mesh on the GPU (-m gpu)."""
+import json
+
+import numpy as np
+import pytest
+
+from tests.util import cfg_from
+
+pytestmark = pytest.mark.gpu
+
+
+def test_compose_maps_fast_kat(gpu):
+  """tests/map_utils_test.py:266-301 of the reference (exact piecewise case)."""
+  from sofima_amd import map_utils
+  coord_map = np.zeros([2, 1, 60, 60])
+  flow = np.zeros([2, 1, 50, 50])
+  flow[0, 0, :, 10:25] = -5
+  flow[0, 0, :, 25:40] = 65
+  flow[:, 0, :, 4] = np.nan
+  stride = 40
+  start1, start2 = (64, 58, 42), (64, 50, 40)   # zyx = box.start[::-1]
+  updated = np.array(map_utils.compose_maps_fast(flow, start1, stride, coord_map,
+                                                 start2, stride))
+  np.testing.assert_array_equal(updated, flow)
+  coord_map[0, :, :, 7:] = -10
+  updated = np.array(map_utils.compose_maps_fast(flow, start1, stride, coord_map,
+                                                 start2, stride))
+  flow[0, 0, :, 5:10] = -10
+  flow[0, 0, :, 10:25] = -15
+  flow[0, 0, :, 25:40] = 55
+  flow[0, 0, :, 40:] = -10
+  np.testing.assert_array_equal(updated, flow)
+
+
+def test_compose_maps_fast_golden(gpu, golden):
+  from sofima_amd import map_utils
+  g = golden('compose_maps')
+  for mode in ('nearest', 'constant'):
+    got = np.array(map_utils.compose_maps_fast(
+        g['m1'], (0, 10, 20), (16, 16), g['m2'], (0, -5, 8), (20, 20), mode=mode))
+    want = g[f'c2_{mode}']
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-5)
+    got = np.array(map_utils.compose_maps_fast(
+        g['n1'], (1, 2, 3), (8, 10, 10), g['n2'], (0, 1, 2), (8, 10, 10),
+        mode=mode))
+    want = g[f'c3_{mode}']
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-5)
+
+
+def test_target_mesh_golden(gpu, golden):
+  """compute_target_mesh of a 2 x 2 montage (reference chain over the jax
+  stand-in: stitch_rigid -> stitch_elastic -> aggregate_arrays)."""
+  from sofima_amd import stitch_elastic
+  g = golden('montage')
+  fn = stitch_elastic.TargetMeshFn(g['nbors'], g['fx'], g['fy'],
+                                   tuple(g['stride']))
+  for xin, want in ((g['x'], g['tg0']), (g['xs'], g['tg1'])):
+    got = np.array(fn(xin))
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-4)
+  # something was actually pasted for every tile
+  assert (np.isfinite(g['tg0'][0]).mean(axis=(1, 2)) > 0.05).all()
+  # single-tile form of the reference
+  one = stitch_elastic.compute_target_mesh(g['nbors'][1], g['xs'], g['fx'],
+                                           g['fy'], tuple(g['stride']))
+  np.testing.assert_allclose(one, g['tg1'][:, 1], rtol=1e-5, atol=1e-4)
+
+
+def test_montage_relaxation_golden(gpu, golden):
+  """relax_mesh(x, None, cfg, prev_fn=target mesh) with remove_drift."""
+  from sofima_amd import mesh, stitch_elastic
+  g = golden('montage')
+  cfg = cfg_from(json.loads(str(g['cfg'])), mesh.IntegrationConfig)
+  fn = stitch_elastic.TargetMeshFn(g['nbors'], g['fx'], g['fy'],
+                                   tuple(g['stride']))
+  xs, ek, t = mesh.relax_mesh(g['x'], None, cfg, prev_fn=fn)
+  assert t == int(g['t'])
+  np.testing.assert_allclose(np.array(xs), g['relaxed'], atol=2e-3)
+  np.testing.assert_allclose(ek, g['ekin'], rtol=2e-2)
+  with pytest.raises(ValueError):
+    mesh.relax_mesh(g['x'], g['x'], cfg, prev_fn=fn)
+  with pytest.raises(NotImplementedError):
+    mesh.relax_mesh(g['x'], None, cfg, prev_fn=lambda a: a)
