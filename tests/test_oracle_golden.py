@@ -140,3 +140,47 @@ def test_relax_vs_golden(golden):
   assert t == int(g['em2d_t'])
   np.testing.assert_allclose(xs, g['em2d_x'], atol=5e-3)
   np.testing.assert_allclose(ek, g['em2d_ekin'], rtol=5e-2, atol=1e-6)
+
+
+def test_compose_maps_vs_golden(golden):
+  from oracle import maps_oracle as mpo
+  g = golden('compose_maps')
+  for mode in ('nearest', 'constant'):
+    got = mpo.compose_maps_fast(g['m1'], (0, 10, 20), (16, 16), g['m2'],
+                                (0, -5, 8), (20, 20), mode=mode)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(g[f'c2_{mode}']))
+    np.testing.assert_allclose(got, g[f'c2_{mode}'], rtol=1e-5, atol=2e-5)
+    got = mpo.compose_maps_fast(g['n1'], (1, 2, 3), (8, 10, 10), g['n2'],
+                                (0, 1, 2), (8, 10, 10), mode=mode)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(g[f'c3_{mode}']))
+    np.testing.assert_allclose(got, g[f'c3_{mode}'], rtol=1e-5, atol=2e-5)
+  # reference KAT (tests/map_utils_test.py:266-301)
+  coord_map = np.zeros([2, 1, 60, 60])
+  flow = np.zeros([2, 1, 50, 50])
+  flow[0, 0, :, 10:25] = -5
+  flow[0, 0, :, 25:40] = 65
+  flow[:, 0, :, 4] = np.nan
+  coord_map[0, :, :, 7:] = -10
+  upd = mpo.compose_maps_fast(flow, (64, 58, 42), 40, coord_map, (64, 50, 40), 40)
+  flow[0, 0, :, 5:10] = -10
+  flow[0, 0, :, 10:25] = -15
+  flow[0, 0, :, 25:40] = 55
+  flow[0, 0, :, 40:] = -10
+  np.testing.assert_array_equal(upd, flow)
+
+
+def test_target_mesh_and_montage_relax_vs_golden(golden):
+  import json
+  from oracle import maps_oracle as mpo
+  g = golden('montage')
+  stride = tuple(g['stride'])
+  for xin, want in ((g['x'], g['tg0']), (g['xs'], g['tg1'])):
+    got = mpo.target_mesh_all(g['nbors'], xin, g['fx'], g['fy'], stride)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-4)
+  cfg = cfg_from(json.loads(str(g['cfg'])))
+  prev_fn = lambda xx: mpo.target_mesh_all(g['nbors'], xx, g['fx'], g['fy'], stride)
+  xs, ek, t = mo.relax_mesh(g['x'], None, cfg, prev_fn=prev_fn)
+  assert t == int(g['t'])
+  np.testing.assert_allclose(xs, g['relaxed'], atol=2e-3)
+  np.testing.assert_allclose(ek, g['ekin'], rtol=2e-2)
