@@ -220,3 +220,70 @@ def test_surface_u8_exact_vs_direct_oracle(gpu):
   want = flow_oracle.xcorr_surface_direct(a0, b0)
   got = flow_field.masked_xcorr(a0, b0)
   np.testing.assert_allclose(got, want, atol=1e-5 * np.abs(want).max())
+
+
+# -- int8 MFMA kernel against the general direct kernel over patch geometries ----
+@pytest.mark.parametrize('py,px,qy,qx', [
+    (17, 17, 17, 17), (33, 40, 33, 40), (48, 48, 32, 32), (50, 70, 50, 70),
+    (64, 64, 64, 64), (100, 96, 60, 80), (127, 129, 127, 129),
+    (160, 160, 160, 160), (160, 160, 96, 112), (200, 150, 200, 150),
+])
+def test_mfma_matches_direct_kernel(gpu, py, px, qy, qx):
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(py * 1000 + px)
+  from scipy import ndimage
+  h, w = 420, 460
+  base = ndimage.gaussian_filter(rng.standard_normal((h + 8, w + 8)), 1.5)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  pre = base[4:4 + h, 4:4 + w].copy()
+  post = base[6:6 + h, 1:1 + w].copy()
+  post[::7, ::5] += 3                      # not an exact copy
+  b = 13
+  # starts include negative / overshooting values: clamped like dynamic_slice
+  starts = np.stack([rng.integers(-20, h - py + 30, b),
+                     rng.integers(-20, w - px + 30, b)], axis=1)
+  post_starts = starts + np.array([(py - qy) // 2, (px - qx) // 2])
+  kw = dict(min_distance=2, threshold_rel=0.5, peak_radius=5,
+            post_patch_size=(qy, qx), post_starts=post_starts)
+  for mean in (None, 117.5):
+    ref = flow_field.batched_xcorr_peaks(pre, post, None, None, (py, px), starts,
+                                         mean, method=1, **kw)
+    got = flow_field.batched_xcorr_peaks(pre, post, None, None, (py, px), starts,
+                                         mean, method=2, **kw)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(got[:, :2], ref[:, :2])
+    ok = np.isfinite(ref[:, 2])
+    np.testing.assert_allclose(got[ok, 2], ref[ok, 2], rtol=5e-3)
+    np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=1e-3, atol=1e-6)
+
+
+def test_mfma_extreme_contrast_and_flat_patches(gpu):
+  """Full 0..255 range (centre clamped to 128) and constant patches."""
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(5)
+  pre = rng.integers(0, 256, (256, 256)).astype(np.uint8)
+  post = np.roll(pre, (2, -3), axis=(0, 1)).copy()
+  pre[:64, :64] = 0            # flat patches -> all-zero surface -> NaN
+  post[:64, :64] = 255
+  calc2 = flow_field.JAXMaskedXCorrWithStatsCalculator(method=2)
+  calc1 = flow_field.JAXMaskedXCorrWithStatsCalculator(method=1)
+  a = calc2.flow_field(pre, post, 64, 32, batch_size=16)
+  b = calc1.flow_field(pre, post, 64, 32, batch_size=16)
+  assert np.isnan(a[:, 0, 0]).all()
+  np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+  np.testing.assert_array_equal(a[:2], b[:2])
+  m = np.isfinite(b[0])
+  assert (a[0][m] == 3).mean() > 0.9 and (a[1][m] == -2).mean() > 0.9
+
+
+def test_flow_field_empty_selection_and_single_patch(gpu):
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(6)
+  img = rng.integers(0, 256, (96, 96)).astype(np.uint8)
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  sel = np.zeros((2, 2), bool)
+  f = calc.flow_field(img, img, 64, 32, selection_mask=sel, batch_size=4)
+  assert f.shape == (4, 2, 2) and np.isnan(f).all()
+  f = calc.flow_field(img, img, 96, 96, batch_size=1)       # patch == image
+  assert f.shape == (4, 1, 1)
+  np.testing.assert_array_equal(f[:2, 0, 0], [0, 0])
