@@ -448,30 +448,44 @@ __device__ __forceinline__ void stage_patch(
   const unsigned* words = reinterpret_cast<const unsigned*>(img);
   const long long n_words = (img_bytes + 3) >> 2;
   const unsigned cc = static_cast<unsigned>(centre) * 0x01010101u;
-  for (int item = threadIdx.x; item < py * n_chunks; item += kThreads) {
-    const int y = item / n_chunks, ch = item - y * n_chunks;
-    const long long off = (long long)(y0 + y) * W + x0 + ch * 16;
-    const long long w0 = off >> 2;
-    const unsigned sh = static_cast<unsigned>(off & 3);
-    unsigned w[5];
+  constexpr int kBatch = 4;  // items whose loads are in flight together
+  const int n_items = py * n_chunks;
+  for (int item0 = threadIdx.x; item0 < n_items; item0 += kThreads * kBatch) {
+    unsigned w[kBatch][5];
+    unsigned shv[kBatch];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) w[k] = load_u32_guarded(words, w0 + k, n_words);
-    v4i out;
+    for (int u = 0; u < kBatch; ++u) {
+      const int item = item0 + u * kThreads;
+      const int y = item / n_chunks, ch = item - y * n_chunks;
+      const long long off = (long long)(y0 + y) * W + x0 + ch * 16;
+      const long long w0 = off >> 2;
+      shv[u] = static_cast<unsigned>(off & 3);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      unsigned v = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
-      // bytewise v - centre (mod 256) == int8 value of pixel - centre
-      const unsigned H = 0x80808080u;
-      v = ((v | H) - (cc & ~H)) ^ ((v ^ ~cc) & H);
-      // zero bytes beyond the patch width
-      const int xb = ch * 16 + k * 4;
-      if (xb + 4 > px) {
-        const int keep = px - xb;  // < 4
-        v = keep <= 0 ? 0u : (v & (0xffffffffu >> (8 * (4 - keep))));
-      }
-      out[k] = static_cast<int>(v);
+      for (int k = 0; k < 5; ++k)
+        w[u][k] = item < n_items ? load_u32_guarded(words, w0 + k, n_words) : 0u;
     }
-    *reinterpret_cast<v4i*>(dst + (row_off + y) * pitch + col_off + ch * 16) = out;
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int item = item0 + u * kThreads;
+      if (item >= n_items) break;
+      const int y = item / n_chunks, ch = item - y * n_chunks;
+      v4i out;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        unsigned v = __builtin_amdgcn_alignbyte(w[u][k + 1], w[u][k], shv[u]);
+        // bytewise v - centre (mod 256) == int8 value of pixel - centre
+        const unsigned H = 0x80808080u;
+        v = ((v | H) - (cc & ~H)) ^ ((v ^ ~cc) & H);
+        // zero bytes beyond the patch width
+        const int xb = ch * 16 + k * 4;
+        if (xb + 4 > px) {
+          const int keep = px - xb;  // < 4
+          v = keep <= 0 ? 0u : (v & (0xffffffffu >> (8 * (4 - keep))));
+        }
+        out[k] = static_cast<int>(v);
+      }
+      *reinterpret_cast<v4i*>(dst + (row_off + y) * pitch + col_off + ch * 16) = out;
+    }
   }
 }
 
@@ -496,7 +510,7 @@ __device__ __forceinline__ bool peak_better(float v, int i, float bv, int bi) {
 
 __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
                                  int Sy, int Sx, const int* pmax_lds,
-                                 float* scratch) {
+                                 const int* hot_lds, float* scratch) {
   __syncthreads();  // all tiles stored, running maximum final
   const float mx = __int_as_float(*pmax_lds);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -534,7 +548,7 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
   };
   if (mx > 0.f) {
     const float thr = a.threshold_rel * mx;
-    const int n_hot = a.hot_count[b];
+    const int n_hot = *hot_lds;
     if (n_hot <= a.hot_cap) {
       const float* hv = a.hot_val + (long long)b * a.hot_cap;
       const int* hi = a.hot_idx + (long long)b * a.hot_cap;
@@ -592,6 +606,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   float* R_lds = reinterpret_cast<float*>(smem + a.a_bytes + a.b_bytes);
   // 16 bytes behind the aux arrays: running maximum of the current surface.
   int* pmax_lds = reinterpret_cast<int*>(smem + a.a_bytes + a.b_bytes + a.r_bytes);
+  int* hot_lds = pmax_lds + 1;  // hot-list fill count of the current patch
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -616,7 +631,10 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                 pp.c[0], A_lds, a.pa, kPadTop, 0, NCA);
     stage_patch(a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
                 pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16);
-    if (threadIdx.x == 0) *pmax_lds = 0;  // float bits of max(surface, 0)
+    if (threadIdx.x == 0) {
+      *pmax_lds = 0;  // float bits of max(surface, 0)
+      *hot_lds = 0;
+    }
     float const_a = 0.f, const_b = 0.f;
     if (SAME) {
       const float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
@@ -673,6 +691,12 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         bp += 4 * a.pb;
       }
 
+      // The epilogue's table addresses do not depend on the MFMA loop; without
+      // this opaque zero the compiler hoists its ~100 gathers above the loop
+      // and spills the accumulators.  After the loop there are >140 free VGPRs,
+      // so all gathers of a tile can be in flight together.
+      int opaque_zero;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero) : : "memory");
       // Epilogue: lane holds rows ky = 16 p + 4 g + r, columns kx = 16 q + n.
       // Branch-free: indices are clamped so every table load is in bounds;
       // only the store is predicated.
@@ -703,39 +727,65 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           sy[r] = dy >= 0;
           const int yv = sy[r] ? dy : dy + Py;
           ey[r] = sy[r] ? -1.f : 1.f;
-          grow[r] = yv * Px;
+          grow[r] = yv * Px + opaque_zero;
           rra[r] = rrowA[yv];
           rrb[r] = rrowB[yv];
           fny[r] = muab * static_cast<float>(Py - abs(dy));
         }
+        // Software pipeline over groups of kQG output columns: the G gathers
+        // of group i + 1 are issued before group i is combined and stored, so
+        // ~2 kQG * 4 loads are in flight without letting the compiler hoist
+        // all 4 NQ of them (which spills the accumulators).
+        constexpr int kQG = 4;
+        constexpr int kGroups = (NQ + kQG - 1) / kQG;
+        auto xv_of = [&](int q) {
+          const int dx = min(16 * q + n, Sx - 1) - (Px - 1);
+          return dx >= 0 ? dx : dx + Px;
+        };
+        float gbuf[2][kQG][4];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          // Keep the scheduler from hoisting all 4 NQ gathers at once (that
-          // spills the accumulators): one q column (4 gathers) at a time.
+        for (int u = 0; u < kQG; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            gbuf[0][u][r] = u < NQ ? G[grow[r] + xv_of(u)] : 0.f;
+#pragma unroll
+        for (int grp = 0; grp < kGroups; ++grp) {
           __builtin_amdgcn_sched_barrier(0);
-          const int kx = 16 * q + n;
-          const int dx = min(kx, Sx - 1) - (Px - 1);
-          const bool sx = dx >= 0;
-          const int xv = sx ? dx : dx + Px;
-          const float ex = sx ? -1.f : 1.f;
-          const float rca = rcolA[xv], rcb = rcolB[xv];
-          const float fnx = static_cast<float>(Px - abs(dx));
-          float gv[4];
+          if (grp + 1 < kGroups) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gv[r] = G[grow[r] + xv];
+            for (int u = 0; u < kQG; ++u)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float corr = (ey[r] * ex) * gv[r];
-            corr += ey[r] * (sx ? rra[r] : rrb[r]);
-            corr += ex * (sy[r] ? rca : rcb);
-            corr += (sy[r] && sx) ? const_a : 0.f;
-            corr += (!sy[r] && !sx) ? const_b : 0.f;
-            corr += fny[r] * fnx;
-            const float v = static_cast<float>(acc[q][r]) + corr;
-            surf[srow[r] + 16 * q] = v;
-            const bool ok = rowok[r] && (q < NQ - 1 || kx < Sx);
-            tmax = fmaxf(tmax, ok ? v : 0.f);
-            acc[q][r] = __float_as_int(ok ? v : -INFINITY);
+              for (int r = 0; r < 4; ++r) {
+                const int q = (grp + 1) * kQG + u;
+                gbuf[(grp + 1) & 1][u][r] = q < NQ ? G[grow[r] + xv_of(q)] : 0.f;
+              }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < kQG; ++u) {
+            const int q = grp * kQG + u;
+            if (q >= NQ) break;
+            const int kx = 16 * q + n;
+            const int dx = min(kx, Sx - 1) - (Px - 1);
+            const bool sx = dx >= 0;
+            const int xv = sx ? dx : dx + Px;
+            const float ex = sx ? -1.f : 1.f;
+            const float rca = rcolA[xv], rcb = rcolB[xv];
+            const float fnx = static_cast<float>(Px - abs(dx));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float corr = (ey[r] * ex) * gbuf[grp & 1][u][r];
+              corr += ey[r] * (sx ? rra[r] : rrb[r]);
+              corr += ex * (sy[r] ? rca : rcb);
+              corr += (sy[r] && sx) ? const_a : 0.f;
+              corr += (!sy[r] && !sx) ? const_b : 0.f;
+              corr += fny[r] * fnx;
+              const float v = static_cast<float>(acc[q][r]) + corr;
+              surf[srow[r] + 16 * q] = v;
+              const bool ok = rowok[r] && (q < NQ - 1 || kx < Sx);
+              tmax = fmaxf(tmax, ok ? v : 0.f);
+              acc[q][r] = __float_as_int(ok ? v : -INFINITY);
+            }
           }
         }
       } else {
@@ -746,9 +796,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           const int ky = min(16 * p + 4 * g + r, Sy - 1);
           const int dy = ky - (Qy - 1);
           const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
-          oa0[r] = ya0 * ipa;
+          oa0[r] = ya0 * ipa + opaque_zero;
           oa1[r] = ya1 * ipa;
-          ob0[r] = (ya0 - dy) * ipb;
+          ob0[r] = (ya0 - dy) * ipb + opaque_zero;
           ob1[r] = (ya1 - dy) * ipb;
           ny[r] = ya1 - ya0;
         }
@@ -799,7 +849,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             for (int r = 0; r < 4; ++r) {
               const float v = __int_as_float(acc[q][r]);
               if (v > thr_t) {
-                const int slot = atomicAdd(&a.hot_count[b], 1);
+                const int slot = atomicAdd(hot_lds, 1);
                 if (slot < a.hot_cap) {
                   hv[slot] = v;
                   hi[slot] = (16 * p + 4 * g + r) * Sx + 16 * q + n;
@@ -810,7 +860,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         }
       }
     }
-    if (a.do_peaks) fused_first_peak(a, b, surf, Sy, Sx, pmax_lds, R_lds);
+    if (a.do_peaks) fused_first_peak(a, b, surf, Sy, Sx, pmax_lds, hot_lds, R_lds);
   }
 }
 
