@@ -17,7 +17,8 @@ SOURCES = {
     'sfm_core.hip': [],
     'sfm_mesh.hip': ['-ffp-contract=off'],
     'sfm_xcorr.hip': [],
-    'sfm_xcorr_mfma.hip': [],
+    'sfm_xcorr_mfma.hip': (['-DSFM_MFMA_TIMING']
+                           if os.environ.get('SFM_MFMA_TIMING') else []),
     'sfm_maps.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',

@@ -113,6 +113,7 @@ struct MfmaArgs {
   float* hot_val;     // [B, hot_cap]
   int* hot_idx;       // [B, hot_cap] flat index ky * Sx + kx
   int sx_pitch;       // padded surface: row pitch (floats) = 16 * NQ
+  int debug;          // SFM_MFMA_TIMING builds only: ablation switches
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
 };
 
@@ -624,8 +625,19 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   const int pos0 = a.ml + Qx - 1 - n - 16 * cq0;
   const int sh = pos0 & 3;
 
+#ifdef SFM_MFMA_TIMING
+  long long tph[8] = {0,0,0,0,0,0,0,0}; long long tc = clock64(); int npat = 0;
+#define TICK(i) { long long tn = clock64(); tph[i] += tn - tc; tc = tn; }
+#else
+#define TICK(i)
+#endif
   for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
+#ifdef SFM_MFMA_TIMING
+    ++npat;
+#endif
+    TICK(7)
     __syncthreads();  // previous patch fully consumed / zero fill done
+    TICK(0)
     const PatchParams pp = a.pp[b];
     stage_patch(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], Py, Px,
                 pp.c[0], A_lds, a.pa, kPadTop, 0, NCA);
@@ -641,9 +653,17 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       for (int i = threadIdx.x; i < 4 * a.aux_n; i += kThreads) R_lds[i] = aux[i];
       const_a = aux[4 * a.aux_n + 0];
       const_b = aux[4 * a.aux_n + 1];
+      // Pull this patch's correction table (written by the prep kernel, by now
+      // in HBM / Infinity Cache) into the XCD's L2: one touch per 64-byte line.
+      // The epilogue gathers then hit L2 instead of paying ~2 us each.
+      const float* gt = a.gtab + (long long)b * Py * Px;
+      float touch = 0.f;
+      for (int i = threadIdx.x * 16; i < Py * Px; i += kThreads * 16) touch += gt[i];
+      if (touch == 1.2345e-30f) R_lds[0] = touch;  // keeps the loads alive
     }
     __syncthreads();
 
+    TICK(1)
     const int* IA = SAME ? nullptr : a.integ[0] + b * a.integ_stride[0];
     const int* IB = SAME ? nullptr : a.integ[1] + b * a.integ_stride[1];
     const float* G = SAME ? a.gtab + (long long)b * Py * Px : nullptr;
@@ -691,6 +711,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         bp += 4 * a.pb;
       }
 
+      TICK(2)
       // The epilogue's table addresses do not depend on the MFMA loop; without
       // this opaque zero the compiler hoists its ~100 gathers above the loop
       // and spills the accumulators.  After the loop there are >140 free VGPRs,
@@ -732,60 +753,79 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           rrb[r] = rrowB[yv];
           fny[r] = muab * static_cast<float>(Py - abs(dy));
         }
-        // Software pipeline over groups of kQG output columns: the G gathers
-        // of group i + 1 are issued before group i is combined and stored, so
-        // ~2 kQG * 4 loads are in flight without letting the compiler hoist
-        // all 4 NQ of them (which spills the accumulators).
-        constexpr int kQG = 4;
-        constexpr int kGroups = (NQ + kQG - 1) / kQG;
+        // Output columns q and q + NCA map to the same table column when
+        // Px == 16 NCA (xv = dx mod Px), so one gather serves both.  Software
+        // pipeline over groups of kQG column pairs: the gathers of group i + 1
+        // are issued before group i is combined and stored.
+        // Column index through the opaque zero: per-column quantities (table
+        // columns, LDS addresses, signs) are tile-invariant and would otherwise
+        // be hoisted out of the tile loop, kept live across the MFMA loop
+        // (40+ VGPRs) and spilled.
+        const int nn = n + opaque_zero;
+        const bool paired = Px == 16 * NCA;
+        constexpr int kQG = 2;
+        constexpr int kGroups = (NCA + kQG - 1) / kQG;
         auto xv_of = [&](int q) {
-          const int dx = min(16 * q + n, Sx - 1) - (Px - 1);
+          const int dx = min(16 * q + nn, Sx - 1) - (Px - 1);
           return dx >= 0 ? dx : dx + Px;
         };
-        float gbuf[2][kQG][4];
+        auto emit = [&](int q, const float* gv) {
+          const int kx = 16 * q + nn;
+          const int dx = min(kx, Sx - 1) - (Px - 1);
+          const bool sx = dx >= 0;
+          const int xv = sx ? dx : dx + Px;
+          const float ex = sx ? -1.f : 1.f;
+          const float rc_a = (a.debug & 4) ? 0.f : rcolA[xv], rc_b = (a.debug & 4) ? 0.f : rcolB[xv];
+          const float fnx = static_cast<float>(Px - abs(dx));
 #pragma unroll
-        for (int u = 0; u < kQG; ++u)
+          for (int r = 0; r < 4; ++r) {
+            float corr = (ey[r] * ex) * gv[r];
+            corr += ey[r] * (sx ? rra[r] : rrb[r]);
+            corr += ex * (sy[r] ? rc_a : rc_b);
+            corr += (sy[r] && sx) ? const_a : 0.f;
+            corr += (!sy[r] && !sx) ? const_b : 0.f;
+            corr += fny[r] * fnx;
+            const float v = static_cast<float>(acc[q][r]) + corr;
+            if (!(a.debug & 2)) __builtin_nontemporal_store(v, &surf[srow[r] + 16 * q]);
+            const bool ok = rowok[r] && (q < NQ - 1 || kx < Sx);
+            tmax = fmaxf(tmax, ok ? v : 0.f);
+            acc[q][r] = __float_as_int(ok ? v : -INFINITY);
+          }
+        };
+        // gbuf[slot][u][0] = G for column q, [1] = G for column q + NCA
+        float gbuf[2][kQG][2][4];
+        auto fetch = [&](int grp, int slot) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            gbuf[0][u][r] = u < NQ ? G[grow[r] + xv_of(u)] : 0.f;
+          for (int u = 0; u < kQG; ++u) {
+            const int q = grp * kQG + u;
+            if (q >= NCA) break;
+            const int x0 = xv_of(q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gbuf[slot][u][0][r] = (a.debug & 1) ? 0.f : G[grow[r] + x0];
+            if (q + NCA < NQ) {
+              if (paired) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gbuf[slot][u][1][r] = gbuf[slot][u][0][r];
+              } else {
+                const int x1 = xv_of(q + NCA);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gbuf[slot][u][1][r] = G[grow[r] + x1];
+              }
+            }
+          }
+        };
+        fetch(0, 0);
 #pragma unroll
         for (int grp = 0; grp < kGroups; ++grp) {
           __builtin_amdgcn_sched_barrier(0);
-          if (grp + 1 < kGroups) {
-#pragma unroll
-            for (int u = 0; u < kQG; ++u)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int q = (grp + 1) * kQG + u;
-                gbuf[(grp + 1) & 1][u][r] = q < NQ ? G[grow[r] + xv_of(q)] : 0.f;
-              }
-          }
+          if (grp + 1 < kGroups) fetch(grp + 1, (grp + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < kQG; ++u) {
             const int q = grp * kQG + u;
-            if (q >= NQ) break;
-            const int kx = 16 * q + n;
-            const int dx = min(kx, Sx - 1) - (Px - 1);
-            const bool sx = dx >= 0;
-            const int xv = sx ? dx : dx + Px;
-            const float ex = sx ? -1.f : 1.f;
-            const float rca = rcolA[xv], rcb = rcolB[xv];
-            const float fnx = static_cast<float>(Px - abs(dx));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float corr = (ey[r] * ex) * gbuf[grp & 1][u][r];
-              corr += ey[r] * (sx ? rra[r] : rrb[r]);
-              corr += ex * (sy[r] ? rca : rcb);
-              corr += (sy[r] && sx) ? const_a : 0.f;
-              corr += (!sy[r] && !sx) ? const_b : 0.f;
-              corr += fny[r] * fnx;
-              const float v = static_cast<float>(acc[q][r]) + corr;
-              surf[srow[r] + 16 * q] = v;
-              const bool ok = rowok[r] && (q < NQ - 1 || kx < Sx);
-              tmax = fmaxf(tmax, ok ? v : 0.f);
-              acc[q][r] = __float_as_int(ok ? v : -INFINITY);
-            }
+            if (q >= NCA) break;
+            emit(q, gbuf[grp & 1][u][0]);
+            if (q + NCA < NQ) emit(q + NCA, gbuf[grp & 1][u][1]);
           }
         }
       } else {
@@ -826,6 +866,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           }
         }
       }
+      TICK(3)
       if (a.do_peaks) {
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, d, 64));
@@ -859,9 +900,18 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           }
         }
       }
+      TICK(4)
     }
+    TICK(5)
     if (a.do_peaks) fused_first_peak(a, b, surf, Sy, Sx, pmax_lds, hot_lds, R_lds);
+    TICK(6)
   }
+#ifdef SFM_MFMA_TIMING
+  if (blockIdx.x == 7 && lane == 0)
+    printf("wave %d patches %d: sync %lld stage %lld mfma %lld epi %lld hot %lld tail %lld peaks %lld\n",
+           wave, npat, tph[0] / npat, tph[1] / npat, tph[2] / npat, tph[3] / npat,
+           tph[4] / npat, tph[5] / npat, tph[6] / npat);
+#endif
 }
 
 struct Variant {
@@ -1064,6 +1114,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   a.ml = l.ml;
   a.a_bytes = l.a_bytes;
   a.b_bytes = l.b_bytes;
+  if (const char* e = getenv("SFM_MFMA_DEBUG")) a.debug = atoi(e);
 
   // Static schedule: dy tiles sorted by the number of patch rows they visit,
   // dealt to the 4 waves longest-first.
