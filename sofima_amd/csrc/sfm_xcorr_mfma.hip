@@ -113,7 +113,6 @@ struct MfmaArgs {
   float* hot_val;     // [B, hot_cap]
   int* hot_idx;       // [B, hot_cap] flat index ky * Sx + kx
   int sx_pitch;       // padded surface: row pitch (floats) = 16 * NQ
-  int debug;          // SFM_MFMA_TIMING builds only: ablation switches
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
 };
 
@@ -626,6 +625,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   const int sh = pos0 & 3;
 
 #ifdef SFM_MFMA_TIMING
+  const long long wstart = wall_clock64();
   long long tph[8] = {0,0,0,0,0,0,0,0}; long long tc = clock64(); int npat = 0;
 #define TICK(i) { long long tn = clock64(); tph[i] += tn - tc; tc = tn; }
 #else
@@ -674,6 +674,15 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     const int n_my_tiles = __builtin_amdgcn_readfirstlane(a.n_tiles[wave]);
     for (int ti = 0; ti < n_my_tiles; ++ti) {
       const int p = __builtin_amdgcn_readfirstlane(a.tiles[wave][ti]);
+      // The two workgroups of a CU share each SIMD's MFMA pipe, and the issue
+      // arbiter always favours the older wave: the younger workgroup would
+      // run ~25 % slower and finish long after its partner.  Alternating the
+      // priority per tile (opposite phase for the second dispatch wave of
+      // workgroups) evens the two out.
+      if ((ti & 1) ^ (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0))
+        __builtin_amdgcn_s_setprio(1);
+      else
+        __builtin_amdgcn_s_setprio(0);
       const int dy0 = 16 * p - (Qy - 1);
       const int ylo = max(0, -dy0 - 15);
       const int yhi = min(Qy, Py - dy0);
@@ -734,34 +743,33 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       if (SAME) {
         // corr = ey ex G[yv][xv] + ey Rrow[sx][yv] + ex Rcol[sy][xv] + const
         //        + mua mub ny nx        (header comment, item 3)
+        // arranged as  (ey ex) g + A[r][sx] + B[q][sy] + fny[r] fnx[q]  with the
+        // constants folded into A.  Rows / columns of the tile padding get
+        // NaN through fny / fnx: NaN never wins fmaxf and never passes "> thr".
         const float* rrowA = R_lds;
         const float* rrowB = R_lds + a.aux_n;
         const float* rcolA = R_lds + 2 * a.aux_n;
         const float* rcolB = R_lds + 3 * a.aux_n;
+        const int nn = n + opaque_zero;
         int grow[4];
-        float ey[4], rra[4], rrb[4], fny[4];
+        float ey[4], a_neg[4], a_pos[4], fny[4];
         bool sy[4];
+        float* rowp[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ky = min(16 * p + 4 * g + r, Sy - 1);
+          const int ky_raw = 16 * p + 4 * g + r;
+          const int ky = min(ky_raw, Sy - 1);
           const int dy = ky - (Py - 1);
           sy[r] = dy >= 0;
           const int yv = sy[r] ? dy : dy + Py;
           ey[r] = sy[r] ? -1.f : 1.f;
           grow[r] = yv * Px + opaque_zero;
-          rra[r] = rrowA[yv];
-          rrb[r] = rrowB[yv];
-          fny[r] = muab * static_cast<float>(Py - abs(dy));
+          // A[r][sx]: sx = 0 (dx < 0) and sx = 1 (dx >= 0)
+          a_neg[r] = ey[r] * rrowB[yv] + (sy[r] ? 0.f : const_b);
+          a_pos[r] = ey[r] * rrowA[yv] + (sy[r] ? const_a : 0.f);
+          fny[r] = ky_raw < Sy ? muab * static_cast<float>(Py - abs(dy)) : NAN;
+          rowp[r] = surf + ky_raw * a.sx_pitch + nn;
         }
-        // Output columns q and q + NCA map to the same table column when
-        // Px == 16 NCA (xv = dx mod Px), so one gather serves both.  Software
-        // pipeline over groups of kQG column pairs: the gathers of group i + 1
-        // are issued before group i is combined and stored.
-        // Column index through the opaque zero: per-column quantities (table
-        // columns, LDS addresses, signs) are tile-invariant and would otherwise
-        // be hoisted out of the tile loop, kept live across the MFMA loop
-        // (40+ VGPRs) and spilled.
-        const int nn = n + opaque_zero;
         const bool paired = Px == 16 * NCA;
         constexpr int kQG = 2;
         constexpr int kGroups = (NCA + kQG - 1) / kQG;
@@ -775,21 +783,19 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           const bool sx = dx >= 0;
           const int xv = sx ? dx : dx + Px;
           const float ex = sx ? -1.f : 1.f;
-          const float rc_a = (a.debug & 4) ? 0.f : rcolA[xv], rc_b = (a.debug & 4) ? 0.f : rcolB[xv];
-          const float fnx = static_cast<float>(Px - abs(dx));
+          const float b_pos = ex * rcolA[xv];  // sy = 1
+          const float b_neg = ex * rcolB[xv];  // sy = 0
+          const float fnx = (q < NQ - 1 || kx < Sx)
+                                ? static_cast<float>(Px - abs(dx)) : NAN;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float corr = (ey[r] * ex) * gv[r];
-            corr += ey[r] * (sx ? rra[r] : rrb[r]);
-            corr += ex * (sy[r] ? rc_a : rc_b);
-            corr += (sy[r] && sx) ? const_a : 0.f;
-            corr += (!sy[r] && !sx) ? const_b : 0.f;
-            corr += fny[r] * fnx;
+            float corr = fmaf(ey[r] * ex, gv[r], sx ? a_pos[r] : a_neg[r]);
+            corr += sy[r] ? b_pos : b_neg;
+            corr = fmaf(fny[r], fnx, corr);
             const float v = static_cast<float>(acc[q][r]) + corr;
-            if (!(a.debug & 2)) __builtin_nontemporal_store(v, &surf[srow[r] + 16 * q]);
-            const bool ok = rowok[r] && (q < NQ - 1 || kx < Sx);
-            tmax = fmaxf(tmax, ok ? v : 0.f);
-            acc[q][r] = __float_as_int(ok ? v : -INFINITY);
+            __builtin_nontemporal_store(v, rowp[r] + 16 * q);
+            tmax = fmaxf(tmax, v);
+            acc[q][r] = __float_as_int(v);
           }
         };
         // gbuf[slot][u][0] = G for column q, [1] = G for column q + NCA
@@ -801,7 +807,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             if (q >= NCA) break;
             const int x0 = xv_of(q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gbuf[slot][u][0][r] = (a.debug & 1) ? 0.f : G[grow[r] + x0];
+            for (int r = 0; r < 4; ++r) gbuf[slot][u][0][r] = G[grow[r] + x0];
             if (q + NCA < NQ) {
               if (paired) {
 #pragma unroll
@@ -880,6 +886,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         const float thr_t = a.threshold_rel * mrun;
         float* hv = a.hot_val + (long long)b * a.hot_cap;
         int* hi = a.hot_idx + (long long)b * a.hot_cap;
+        // tmax is the wave-wide tile maximum: nothing to do unless it clears
+        // the running threshold (the common case away from the peak).
+        if (tmax > thr_t)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const float v0 = __int_as_float(acc[q][0]), v1 = __int_as_float(acc[q][1]);
@@ -907,6 +916,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     TICK(6)
   }
 #ifdef SFM_MFMA_TIMING
+  if ((blockIdx.x == 7 || blockIdx.x == 300) && lane == 0 && wave == 0)
+    printf("wg %d wall %lld (100MHz ticks) start %lld\n", blockIdx.x, (long long)(wall_clock64() - wstart), wstart % 100000000);
   if (blockIdx.x == 7 && lane == 0)
     printf("wave %d patches %d: sync %lld stage %lld mfma %lld epi %lld hot %lld tail %lld peaks %lld\n",
            wave, npat, tph[0] / npat, tph[1] / npat, tph[2] / npat, tph[3] / npat,
@@ -1006,6 +1017,14 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     attr_set = lds;
   }
+#ifdef SFM_MFMA_TIMING
+  {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xcorr_mfma_kernel<NCA, NCE, SAME>, kThreads, lds);
+    static bool once = false;
+    if (!once) { printf("occupancy: %d blocks/CU, lds %zu, grid %d\n", nb, lds, grid); once = true; }
+  }
+#endif
   sfm::prof_begin(sfm::kProfXcorr, st);
   hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, SAME>), dim3(grid),
                      dim3(kThreads), lds, st, a);
@@ -1114,7 +1133,6 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   a.ml = l.ml;
   a.a_bytes = l.a_bytes;
   a.b_bytes = l.b_bytes;
-  if (const char* e = getenv("SFM_MFMA_DEBUG")) a.debug = atoi(e);
 
   // Static schedule: dy tiles sorted by the number of patch rows they visit,
   // dealt to the 4 waves longest-first.
