@@ -220,6 +220,8 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
 // the centre is folded in afterwards (I'[y][x] = Iraw[y][x] - c y x).
 // ---------------------------------------------------------------------------
 constexpr int kPrepCols = 3;  // columns per lane: Px <= 192
+constexpr int kPrepWaves = 8;  // bands of rows swept concurrently
+constexpr int kPrepThreads = 64 * kPrepWaves;
 
 // Wave-wide inclusive add scan on the DPP network (row shifts inside each
 // 16-lane row, then row broadcasts), ~12 VALU ops instead of 6 LDS permutes.
@@ -233,13 +235,15 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
   return v;
 }
 
-__global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
+__global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int red[2][3][kThreads];
   __shared__ int s_c[2];
   __shared__ float s_mu[2];
-  __shared__ int band_tot[2][kWaves][64 * kPrepCols];
-  __shared__ int row_scr[kWaves][2][64 * kPrepCols + 2];
+  __shared__ int band_tot[2][kPrepWaves][64 * kPrepCols];
+  __shared__ int row_scr[kPrepWaves][2][64 * kPrepCols + 2];
+  // reduction scratch of phase 2, aliased onto band_tot (separated by a barrier)
+  static_assert(sizeof(band_tot) >= sizeof(int) * 2 * 3 * kPrepThreads, "alias");
+  int (*red)[3][kPrepThreads] = reinterpret_cast<int (*)[3][kPrepThreads]>(&band_tot[0][0][0]);
   const int b = blockIdx.x;
   const int py = a.P[0], px = a.P[1];
   const int lane = threadIdx.x & 63;
@@ -255,24 +259,38 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
     const unsigned* words = reinterpret_cast<const unsigned*>(a.img[s]);
     const long long n_words = ((long long)H * W + 3) >> 2;
     const int n_chunks = (px + 15) / 16;
-    for (int item = threadIdx.x; item < py * n_chunks; item += kThreads) {
-      const int y = item / n_chunks, ch = item - y * n_chunks;
-      const long long off = (long long)(y0[s] + y) * W + x0[s] + ch * 16;
-      const long long w0 = off >> 2;
-      const unsigned sh = static_cast<unsigned>(off & 3);
-      unsigned w[5];
+    const int n_items = py * n_chunks;
+    constexpr int kBatch = 4;  // items whose loads are in flight together
+    for (int item0 = threadIdx.x; item0 < n_items; item0 += kPrepThreads * kBatch) {
+      unsigned w[kBatch][5];
+      unsigned shv[kBatch];
 #pragma unroll
-      for (int k = 0; k < 5; ++k) w[k] = load_u32_guarded(words, w0 + k, n_words);
+      for (int u = 0; u < kBatch; ++u) {
+        const int item = item0 + u * kPrepThreads;
+        const int y = item / n_chunks, ch = item - y * n_chunks;
+        const long long off = (long long)(y0[s] + y) * W + x0[s] + ch * 16;
+        const long long w0 = off >> 2;
+        shv[u] = static_cast<unsigned>(off & 3);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned v = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
-        const int xb = ch * 16 + k * 4;
-        unsigned char* dst = pix[s] + y * px + xb;
-        if (xb + 4 <= px && ((y * px + xb) & 3) == 0) {
-          *reinterpret_cast<unsigned*>(dst) = v;
-        } else {
-          for (int t = 0; t < 4; ++t)
-            if (xb + t < px) dst[t] = static_cast<unsigned char>(v >> (8 * t));
+        for (int k = 0; k < 5; ++k)
+          w[u][k] = item < n_items ? load_u32_guarded(words, w0 + k, n_words) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int item = item0 + u * kPrepThreads;
+        if (item >= n_items) break;
+        const int y = item / n_chunks, ch = item - y * n_chunks;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned v = __builtin_amdgcn_alignbyte(w[u][k + 1], w[u][k], shv[u]);
+          const int xb = ch * 16 + k * 4;
+          unsigned char* dst = pix[s] + y * px + xb;
+          if (xb + 4 <= px && ((y * px + xb) & 3) == 0) {
+            *reinterpret_cast<unsigned*>(dst) = v;
+          } else {
+            for (int t = 0; t < 4; ++t)
+              if (xb + t < px) dst[t] = static_cast<unsigned char>(v >> (8 * t));
+          }
         }
       }
     }
@@ -282,7 +300,7 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
   // Phase 2: min / max / sum per patch -> integer centre and residual mean.
   for (int s = 0; s < 2; ++s) {
     int mn = 255, mx = 0, sum = 0;
-    for (int i = threadIdx.x; i < py * px; i += kThreads) {
+    for (int i = threadIdx.x; i < py * px; i += kPrepThreads) {
       const int v = pix[s][i];
       mn = min(mn, v);
       mx = max(mx, v);
@@ -293,7 +311,7 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
     red[s][2][threadIdx.x] = sum;
   }
   __syncthreads();
-  for (int k = kThreads / 2; k > 0; k >>= 1) {
+  for (int k = kPrepThreads / 2; k > 0; k >>= 1) {
     if (threadIdx.x < k)
       for (int s = 0; s < 2; ++s) {
         red[s][0][threadIdx.x] = min(red[s][0][threadIdx.x], red[s][0][threadIdx.x + k]);
@@ -321,11 +339,12 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
     p->c[s] = c;
     p->mu[s] = s_mu[s];
   }
+  __syncthreads();  // `red` (aliased with band_tot) fully consumed
 
   // Phase 3a: per-band column totals (band w = rows [w R, (w + 1) R)).
   // Lane l owns the kPrepCols consecutive columns kPrepCols * l + k, so one
   // wave scan over the per-lane totals gives the prefix along x.
-  const int R = (py + kWaves - 1) / kWaves;
+  const int R = (py + kPrepWaves - 1) / kPrepWaves;
   const int ra0 = min(wave * R, py), ra1 = min(ra0 + R, py);
   const int xl = kPrepCols * lane;
 #pragma unroll
@@ -360,7 +379,7 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
   for (int k = 0; k < kPrepCols; ++k) {
     colA[k] = 0;
     colB[k] = 0;
-    for (int w2 = 0; w2 < kWaves; ++w2) {
+    for (int w2 = 0; w2 < kPrepWaves; ++w2) {
       const int lo = min(w2 * R, py), hi = min(lo + R, py);
       if (hi <= ra0) colA[k] += band_tot[0][w2][xl + k];
       if (hi <= py - ra0) {
@@ -373,7 +392,7 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_same_kernel(MfmaArgs a) {
     }
   }
   // Sweep.  The last wave also emits the yv == py row (pre-patch totals).
-  const int y_end = wave == kWaves - 1 ? py + 1 : ra1;
+  const int y_end = wave == kPrepWaves - 1 ? py + 1 : ra1;
   for (int yv = ra0; yv < y_end; ++yv) {
     const int yw = py - yv;
     // Inclusive prefix over the lane's own columns, then across lanes.
@@ -1167,7 +1186,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(prep_lds)));
       prep_attr = prep_lds;
     }
-    hipLaunchKernelGGL(mfma_prep_same_kernel, dim3(d->batch), dim3(kThreads),
+    hipLaunchKernelGGL(mfma_prep_same_kernel, dim3(d->batch), dim3(kPrepThreads),
                        prep_lds, st, a);
   } else {
     const size_t prep_lds = (size_t)a.P[0] * a.P[1];
