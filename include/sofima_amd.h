@@ -111,6 +111,23 @@ int sfm_xcorr_peaks(const SfmXcorrDesc* desc, float* peaks);
  * for the mean-subtracted patches (flow_field.py:361-371). */
 int sfm_xcorr_surface(const SfmXcorrDesc* desc, float* surface);
 
+/* Masked-pixel count of every patch of the sampling grid.  Replaces
+ * flow_field._integral_image (flow_field.py:159-175) + the box query of the
+ * summed-area table (flow_field.py:575-589) used for patch selection:
+ * counts[o] = number of non-zero mask bytes in the patch of size `patch` at
+ * o * step, for o in [0, (shape - patch) / step] per axis. */
+typedef struct SfmMaskCountDesc {
+  int32_t ndim;
+  int32_t shape[3];             /* mask [z]yx                                */
+  int32_t patch[3];
+  int32_t step[3];
+  const uint8_t* mask;          /* device bool bytes                         */
+  void* stream;
+} SfmMaskCountDesc;
+
+/* counts: device int32 [prod((shape - patch) / step + 1)], row-major. */
+int sfm_mask_patch_counts(const SfmMaskCountDesc* desc, int32_t* counts);
+
 /* Stand-alone peak statistics, replaces _batched_peaks (flow_field.py:205-275)
  * for a caller-provided batch of surfaces. */
 typedef struct SfmPeaksDesc {

@@ -55,6 +55,17 @@ class SfmXcorrDesc(C.Structure):
   ]
 
 
+class SfmMaskCountDesc(C.Structure):
+  _fields_ = [
+      ('ndim', i32),
+      ('shape', i32 * 3),
+      ('patch', i32 * 3),
+      ('step', i32 * 3),
+      ('mask', C.c_void_p),
+      ('stream', C.c_void_p),
+  ]
+
+
 class SfmPeaksDesc(C.Structure):
   _fields_ = [
       ('ndim', i32),
@@ -162,6 +173,7 @@ SIGNATURES = {
     'sfm_xcorr_workspace_bytes': (C.c_size_t, [C.POINTER(SfmXcorrDesc)]),
     'sfm_xcorr_peaks': (C.c_int, [C.POINTER(SfmXcorrDesc), C.c_void_p]),
     'sfm_xcorr_surface': (C.c_int, [C.POINTER(SfmXcorrDesc), C.c_void_p]),
+    'sfm_mask_patch_counts': (C.c_int, [C.POINTER(SfmMaskCountDesc), C.c_void_p]),
     'sfm_peaks_workspace_bytes': (C.c_size_t, [C.POINTER(SfmPeaksDesc)]),
     'sfm_peaks': (C.c_int, [C.POINTER(SfmPeaksDesc), C.c_void_p]),
     'sfm_compose_maps': (C.c_int, [C.POINTER(SfmComposeDesc), C.c_void_p]),

@@ -31,6 +31,9 @@ size_t mfma_i8_workspace_bytes(const SfmXcorrDesc* d);
 int mfma_i8_surface(const SfmXcorrDesc* d, void* ws, float* surface,
                     const FusedPeaks* fused);
 void mfma_i8_padded_dims(const SfmXcorrDesc* d, int* rows, int* pitch);
+// Masked correlation: padded numerator / denominator / overlap + batch maxima.
+int mfma_i8_masked(const SfmXcorrDesc* d, void* ws, float* num, float* den,
+                   float* ov, unsigned int* maxima);
 }  // namespace sfm
 
 namespace {
@@ -243,6 +246,42 @@ masked_finalize_kernel(float* __restrict__ out, const float* __restrict__ den,
     if (ov[i] < px_thr) v = 0.f;
     out[i] = v;
   }
+}
+
+// ---------------------------------------------------------------------------
+// patch selection: masked-pixel count per grid patch
+// ---------------------------------------------------------------------------
+struct MaskCountArgs {
+  const unsigned char* mask;
+  int S[3], P[3], T[3], O[3];  // mask shape, patch, step, output grid
+  int* out;
+};
+
+__global__ void __launch_bounds__(kBlock) mask_count_kernel(MaskCountArgs a) {
+  __shared__ int red[kBlock];
+  const long long o = blockIdx.x;
+  const int ox = static_cast<int>(o % a.O[2]);
+  const int oy = static_cast<int>((o / a.O[2]) % a.O[1]);
+  const int oz = static_cast<int>(o / ((long long)a.O[2] * a.O[1]));
+  const long long base =
+      ((long long)oz * a.T[0] * a.S[1] + (long long)oy * a.T[1]) * a.S[2] +
+      (long long)ox * a.T[2];
+  const long long rows = (long long)a.P[0] * a.P[1];
+  int cnt = 0;
+  for (long long i = threadIdx.x; i < rows * a.P[2]; i += kBlock) {
+    const int x = static_cast<int>(i % a.P[2]);
+    const long long r = i / a.P[2];
+    const int y = static_cast<int>(r % a.P[1]);
+    const int z = static_cast<int>(r / a.P[1]);
+    cnt += a.mask[base + ((long long)z * a.S[1] + y) * a.S[2] + x] != 0;
+  }
+  red[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int k = kBlock / 2; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.out[o] = red[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -582,6 +621,13 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
   if (use_mfma(d)) {
     const size_t n = sfm::mfma_i8_workspace_bytes(d);
     w.mfma = c.take<char>(n);
+    if (masked) {
+      int rows = 0, pitch = 0;
+      sfm::mfma_i8_padded_dims(d, &rows, &pitch);
+      w.den = c.take<float>(B * (size_t)rows * pitch);
+      w.ov = c.take<float>(B * (size_t)rows * pitch);
+      w.maxima = c.take<unsigned int>(2);
+    }
   } else {
     w.a0 = c.take<float>(B * g.Pn);
     w.b0 = c.take<float>(B * g.Qn);
@@ -601,7 +647,7 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
     with_surface = true;
   }
   if (with_surface) w.surface = c.take<float>(B * (size_t)w.srows * w.spitch);
-  if (with_peaks) w.peaks = carve_peaks(c, d->batch, g.Sn, use_mfma(d));
+  if (with_peaks) w.peaks = carve_peaks(c, d->batch, g.Sn, use_mfma(d) && !masked);
   w.bytes = c.total();
   return w;
 }
@@ -615,15 +661,28 @@ int check_desc(const SfmXcorrDesc* d) {
     return sfm::fail(SFM_ERR_INVALID, "unsupported dtype tag %d", d->dtype);
   if (d->method == SFM_XCORR_MFMA_I8 && !sfm::mfma_i8_eligible(d))
     return sfm::fail(SFM_ERR_INVALID,
-                     "MFMA_I8 needs uint8 2-D images without correlation masks");
+                     "MFMA_I8 needs uint8 2-D images and patches up to 160 wide");
   return SFM_OK;
 }
 
 int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
                     float* surface, const sfm::FusedPeaks* fused = nullptr) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
-  if (use_mfma(d)) return sfm::mfma_i8_surface(d, w.mfma, surface, fused);
   const bool masked = is_masked(d);
+  if (use_mfma(d) && masked) {
+    // eight exact integer correlations on the matrix cores + Padfield assembly,
+    // then the same batch-global finalize step as the direct path
+    if (int rc = sfm::mfma_i8_masked(d, w.mfma, surface, w.den, w.ov, w.maxima))
+      return rc;
+    const long long n = (long long)d->batch * w.srows * w.spitch;
+    const int fg = (int)((n + kBlock - 1) / kBlock > 4096 ? 4096
+                                                           : (n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(masked_finalize_kernel, dim3(fg), dim3(kBlock), 0, st,
+                       surface, w.den, w.ov, w.maxima, n);
+    SFM_LAUNCH_CHECK();
+    return SFM_OK;
+  }
+  if (use_mfma(d)) return sfm::mfma_i8_surface(d, w.mfma, surface, fused);
   GatherArgs ga[2];
   for (int k = 0; k < 2; ++k) {
     GatherArgs& a = ga[k];
@@ -729,7 +788,7 @@ int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
                      w.bytes, d->workspace_bytes);
   // With the MFMA kernel the first peak pass runs inside it, per finished
   // surface; its per-batch state has to be cleared before the launch.
-  const bool fuse = use_mfma(d);
+  const bool fuse = use_mfma(d) && !is_masked(d);
   sfm::FusedPeaks fp;
   if (fuse) {
     SFM_HIP_CHECK(hipMemsetAsync(static_cast<char*>(d->workspace) + w.peaks.zero_from,
@@ -757,6 +816,31 @@ int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
                    d->batch, center, d->min_distance,
                    d->threshold_rel, d->peak_radius, peaks,
                    static_cast<hipStream_t>(d->stream), fuse);
+}
+
+int sfm_mask_patch_counts(const SfmMaskCountDesc* d, int32_t* counts) {
+  if (!d || !d->mask || !counts)
+    return sfm::fail(SFM_ERR_INVALID, "mask counts: NULL argument");
+  if (d->ndim != 2 && d->ndim != 3)
+    return sfm::fail(SFM_ERR_INVALID, "mask counts: ndim must be 2 or 3");
+  MaskCountArgs a;
+  a.mask = d->mask;
+  a.out = counts;
+  long long n = 1;
+  for (int i = 0; i < 3; ++i) {
+    a.S[i] = d->shape[i];
+    a.P[i] = d->patch[i];
+    a.T[i] = d->step[i];
+    if (a.P[i] < 1 || a.T[i] < 1 || a.S[i] < a.P[i])
+      return sfm::fail(SFM_ERR_INVALID, "mask counts: bad geometry on axis %d", i);
+    a.O[i] = (a.S[i] - a.P[i]) / a.T[i] + 1;
+    n *= a.O[i];
+  }
+  if (n > 0x7fffffffLL) return sfm::fail(SFM_ERR_INVALID, "mask counts: grid too large");
+  hipLaunchKernelGGL(mask_count_kernel, dim3(static_cast<unsigned>(n)), dim3(kBlock),
+                     0, static_cast<hipStream_t>(d->stream), a);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
 }
 
 size_t sfm_peaks_workspace_bytes(const SfmPeaksDesc* d) {

@@ -56,6 +56,10 @@
 #include <cstring>
 #include <vector>
 
+namespace sfm {
+void mfma_i8_padded_dims(const SfmXcorrDesc* d, int* rows, int* pitch);
+}  // namespace sfm
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -70,7 +74,14 @@ struct PatchParams {  // written by the prep kernel, one per patch
   int y0[2], x0[2];   // clamped patch origin in the image (pre, post)
   int c[2];           // integer centres
   float mu[2];        // mean - centre
+  int my0[2], mx0[2]; // masked path: clamped patch origin in the mask arrays
 };
+
+// Operand planes of the masked (Padfield) path, all int8:
+//   VAL    (pixel - centre) on valid pixels, 0 on masked ones
+//   VALID  1 on valid pixels
+//   SQHI / SQLO  with s = VAL^2:  s = 128 (SQHI + 64) + SQLO on valid pixels
+enum Plane { kPlaneVal = 0, kPlaneValid = 1, kPlaneSqHi = 2, kPlaneSqLo = 3 };
 
 struct MfmaArgs {
   const unsigned char* img[2];
@@ -113,6 +124,11 @@ struct MfmaArgs {
   float* hot_val;     // [B, hot_cap]
   int* hot_idx;       // [B, hot_cap] flat index ky * Sx + kx
   int sx_pitch;       // padded surface: row pitch (floats) = 16 * NQ
+  // raw-product mode (masked path)
+  const unsigned char* mask[2];
+  int mshape[2][2];
+  int plane[2];       // Plane of the pre / post operand
+  int* raw_out;       // [batch, rows, sx_pitch] int32 products
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
 };
 
@@ -508,6 +524,193 @@ __device__ __forceinline__ void stage_patch(
   }
 }
 
+// Masked path: stages one operand plane of a patch, 16 pixels per work item,
+// from arbitrarily aligned image / mask rows (aligned dword loads + funnel
+// shift, several items in flight).
+__device__ void stage_plane(const unsigned char* __restrict__ img, long long img_bytes,
+                            int W, int y0, int x0,
+                            const unsigned char* __restrict__ mask,
+                            long long mask_bytes, int MW, int my0, int mx0, int py,
+                            int px, int centre, int plane,
+                            unsigned char* __restrict__ dst, int pitch, int row_off,
+                            int col_off, int n_chunks) {
+  const unsigned* iw = reinterpret_cast<const unsigned*>(img);
+  const long long n_iw = (img_bytes + 3) >> 2;
+  // the mask base pointer may be byte aligned: split into aligned base + shift
+  const unsigned long long mbase = reinterpret_cast<unsigned long long>(mask);
+  const unsigned* mw = reinterpret_cast<const unsigned*>(mbase & ~3ull);
+  const long long m_lead = static_cast<long long>(mbase & 3ull);
+  const long long n_mw = (mask_bytes + m_lead + 3) >> 2;
+  constexpr int kBatch = 2;
+  const int n_items = py * n_chunks;
+  for (int item0 = threadIdx.x; item0 < n_items; item0 += kThreads * kBatch) {
+    unsigned wi[kBatch][5], wm[kBatch][5], shi[kBatch], shm[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int item = item0 + u * kThreads;
+      const int y = item / n_chunks, ch = item - y * n_chunks;
+      const long long off = (long long)(y0 + y) * W + x0 + ch * 16;
+      const long long moff = (long long)(my0 + y) * MW + mx0 + ch * 16 + m_lead;
+      shi[u] = static_cast<unsigned>(off & 3);
+      shm[u] = static_cast<unsigned>(moff & 3);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        wi[u][k] = item < n_items ? load_u32_guarded(iw, (off >> 2) + k, n_iw) : 0u;
+        wm[u][k] = (mask && item < n_items) ? load_u32_guarded(mw, (moff >> 2) + k, n_mw)
+                                            : 0u;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int item = item0 + u * kThreads;
+      if (item >= n_items) break;
+      const int y = item / n_chunks, ch = item - y * n_chunks;
+      v4i out;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned pv = __builtin_amdgcn_alignbyte(wi[u][k + 1], wi[u][k], shi[u]);
+        const unsigned mv = __builtin_amdgcn_alignbyte(wm[u][k + 1], wm[u][k], shm[u]);
+        unsigned o = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int x = ch * 16 + k * 4 + t;
+          const int ap = static_cast<int>((pv >> (8 * t)) & 0xffu) - centre;
+          const bool valid = ((mv >> (8 * t)) & 0xffu) == 0 && x < px;
+          const int sq = ap * ap;
+          int val = plane == kPlaneVal ? ap
+                    : plane == kPlaneValid ? 1
+                    : plane == kPlaneSqHi ? (sq >> 7) - 64
+                                          : (sq & 127);
+          if (!valid) val = 0;
+          o |= static_cast<unsigned>(val & 0xff) << (8 * t);
+        }
+        out[k] = static_cast<int>(o);
+      }
+      *reinterpret_cast<v4i*>(dst + (row_off + y) * pitch + col_off + ch * 16) = out;
+    }
+  }
+}
+
+// Masked path prep: clamped origins in image and mask, masked mean, centre.
+__global__ void __launch_bounds__(kThreads) mfma_prep_masked_kernel(MfmaArgs a) {
+  __shared__ int red[4][kThreads];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int py = s == 0 ? a.P[0] : a.Q[0];
+  const int px = s == 0 ? a.P[1] : a.Q[1];
+  const int H = a.ishape[s][0], W = a.ishape[s][1];
+  const int sy = a.starts[s][b * 2 + 0], sx = a.starts[s][b * 2 + 1];
+  const int y0 = min(max(sy, 0), H - py), x0 = min(max(sx, 0), W - px);
+  const unsigned char* mask = a.mask[s];
+  const int MH = a.mshape[s][0], MW = a.mshape[s][1];
+  const int my0 = mask ? min(max(sy, 0), MH - py) : 0;
+  const int mx0 = mask ? min(max(sx, 0), MW - px) : 0;
+  int mn = 255, mx = 0, sum = 0, cnt = 0;
+  for (int i = threadIdx.x; i < py * px; i += kThreads) {
+    const int y = i / px, x = i - y * px;
+    if (mask && mask[(long long)(my0 + y) * MW + mx0 + x]) continue;
+    const int v = a.img[s][(long long)(y0 + y) * W + x0 + x];
+    mn = min(mn, v);
+    mx = max(mx, v);
+    sum += v;
+    ++cnt;
+  }
+  red[0][threadIdx.x] = mn;
+  red[1][threadIdx.x] = mx;
+  red[2][threadIdx.x] = sum;
+  red[3][threadIdx.x] = cnt;
+  __syncthreads();
+  for (int k = kThreads / 2; k > 0; k >>= 1) {
+    if (threadIdx.x < k) {
+      red[0][threadIdx.x] = min(red[0][threadIdx.x], red[0][threadIdx.x + k]);
+      red[1][threadIdx.x] = max(red[1][threadIdx.x], red[1][threadIdx.x + k]);
+      red[2][threadIdx.x] += red[2][threadIdx.x + k];
+      red[3][threadIdx.x] += red[3][threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    mn = red[0][0];
+    mx = red[1][0];
+    sum = red[2][0];
+    cnt = red[3][0];
+    PatchParams* p = &a.pp[b];
+    p->y0[s] = y0;
+    p->x0[s] = x0;
+    p->my0[s] = my0;
+    p->mx0[s] = mx0;
+    int c = 128;
+    float mu = 0.f;
+    if (cnt > 0) {
+      // nanmean over the unmasked pixels (flow_field.py:340-347)
+      const float mean =
+          a.use_mean ? a.mean : static_cast<float>(sum) / static_cast<float>(cnt);
+      c = static_cast<int>(rintf(fminf(fmaxf(mean, 0.f), 255.f)));
+      c = min(max(c, mx - 127), mn + 128);
+      mu = a.use_mean ? a.mean - static_cast<float>(c)
+                      : static_cast<float>((static_cast<double>(sum) -
+                                            static_cast<double>(c) * cnt) /
+                                           static_cast<double>(cnt));
+    }
+    p->c[s] = c;
+    p->mu[s] = mu;
+  }
+}
+
+// Masked path: Padfield assembly (flow_field.py:113-131) from the eight exact
+// integer product surfaces, in double precision.
+//   raw: [8][n_patches][elems] in the order of kMaskedPasses below.
+struct AssembleArgs {
+  const int* raw;
+  long long plane_stride;  // ints between consecutive product surfaces
+  const PatchParams* pp;
+  long long elems;         // padded elements per patch
+  int n_patches;
+  float* num;              // out: numerator   [n_patches, elems]
+  float* den;              // out: denominator
+  float* ov;               // out: overlap
+  unsigned int* maxima;    // batch-global max |den|, max overlap (float bits)
+};
+
+__global__ void __launch_bounds__(kThreads) mfma_assemble_masked_kernel(AssembleArgs g) {
+  const long long total = g.elems * g.n_patches;
+  float mden = 0.f, mov = 0.f;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kThreads) {
+    const int b = static_cast<int>(i / g.elems);
+    const double mua = g.pp[b].mu[0], mub = g.pp[b].mu[1];
+    double P[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P[k] = static_cast<double>(g.raw[k * g.plane_stride + i]);
+    const double n_ov = P[3];
+    const double ov = fmax(n_ov, 1.1920928955078125e-07);
+    const double mc_p = P[1] - mua * n_ov;   // sum of a0 over curr-valid overlap
+    const double mc_c = P[2] - mub * n_ov;
+    const double xc = P[0] - mub * P[1] - mua * P[2] + mua * mub * n_ov;
+    const double num = xc - mc_p * mc_c / ov;
+    const double sa2 = 128.0 * P[4] + P[5] + 8192.0 * n_ov - 2.0 * mua * P[1] +
+                       mua * mua * n_ov;
+    const double sb2 = 128.0 * P[6] + P[7] + 8192.0 * n_ov - 2.0 * mub * P[2] +
+                       mub * mub * n_ov;
+    const double pd = fmax(sa2 - mc_p * mc_p / ov, 0.0);
+    const double cd = fmax(sb2 - mc_c * mc_c / ov, 0.0);
+    const float den = static_cast<float>(sqrt(pd * cd));
+    g.num[i] = static_cast<float>(num);
+    g.den[i] = den;
+    g.ov[i] = static_cast<float>(ov);
+    mden = fmaxf(mden, fabsf(den));
+    mov = fmaxf(mov, static_cast<float>(ov));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    mden = fmaxf(mden, __shfl_xor(mden, d, 64));
+    mov = fmaxf(mov, __shfl_xor(mov, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&g.maxima[0], __float_as_uint(mden));
+    atomicMax(&g.maxima[1], __float_as_uint(mov));
+  }
+}
+
 __device__ __forceinline__ int box_sum(const int* __restrict__ I, int ip, int y0,
                                        int y1, int x0, int x1) {
   // I has a zero first row and column.
@@ -616,8 +819,12 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
   }
 }
 
-template <int NCA, int NCE, bool SAME>
+constexpr int kModeGeneral = 0, kModeSame = 1, kModeRaw = 2;
+
+template <int NCA, int NCE, int MODE>
 __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
+  constexpr bool SAME = MODE == kModeSame;
+  constexpr bool RAW = MODE == kModeRaw;
   constexpr int NQ = NCA + NCE - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* A_lds = smem;
@@ -658,10 +865,21 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     __syncthreads();  // previous patch fully consumed / zero fill done
     TICK(0)
     const PatchParams pp = a.pp[b];
-    stage_patch(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], Py, Px,
-                pp.c[0], A_lds, a.pa, kPadTop, 0, NCA);
-    stage_patch(a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
-                pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16);
+    if (RAW) {
+      stage_plane(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], a.mask[0],
+                  (long long)a.mshape[0][0] * a.mshape[0][1], a.mshape[0][1],
+                  pp.my0[0], pp.mx0[0], Py, Px, pp.c[0], a.plane[0], A_lds, a.pa,
+                  kPadTop, 0, NCA);
+      stage_plane(a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], a.mask[1],
+                  (long long)a.mshape[1][0] * a.mshape[1][1], a.mshape[1][1],
+                  pp.my0[1], pp.mx0[1], Qy, Qx, pp.c[1], a.plane[1], B_lds, a.pb, 0,
+                  a.ml, (Qx + 15) / 16);
+    } else {
+      stage_patch(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], Py, Px,
+                  pp.c[0], A_lds, a.pa, kPadTop, 0, NCA);
+      stage_patch(a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
+                  pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16);
+    }
     if (threadIdx.x == 0) {
       *pmax_lds = 0;  // float bits of max(surface, 0)
       *hot_lds = 0;
@@ -683,8 +901,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     __syncthreads();
 
     TICK(1)
-    const int* IA = SAME ? nullptr : a.integ[0] + b * a.integ_stride[0];
-    const int* IB = SAME ? nullptr : a.integ[1] + b * a.integ_stride[1];
+    const int* IA = (SAME || RAW) ? nullptr : a.integ[0] + b * a.integ_stride[0];
+    const int* IB = (SAME || RAW) ? nullptr : a.integ[1] + b * a.integ_stride[1];
     const float* G = SAME ? a.gtab + (long long)b * Py * Px : nullptr;
     const float mua = pp.mu[0], mub = pp.mu[1];
     const float muab = mua * mub;
@@ -758,6 +976,15 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       for (int r = 0; r < 4; ++r) {
         srow[r] = (16 * p + 4 * g + r) * a.sx_pitch + n;
         rowok[r] = 16 * p + 4 * g + r < Sy;
+      }
+      if (RAW) {
+        // exact integer products; the Padfield assembly happens afterwards
+        int* raw = a.raw_out + b * a.s_stride;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) raw[srow[r] + 16 * q] = acc[q][r];
+        continue;
       }
       if (SAME) {
         // corr = ey ex G[yv][xv] + ey Rrow[sx][yv] + ex Rcol[sy][xv] + const
@@ -1027,25 +1254,17 @@ Ws carve_ws(const SfmXcorrDesc* d, void* base) {
   return w;
 }
 
-template <int NCA, int NCE, bool SAME>
+template <int NCA, int NCE, int MODE>
 int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   static size_t attr_set = 0;
   if (lds > attr_set) {
     SFM_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE, SAME>),
+        reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE, MODE>),
         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     attr_set = lds;
   }
-#ifdef SFM_MFMA_TIMING
-  {
-    int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, xcorr_mfma_kernel<NCA, NCE, SAME>, kThreads, lds);
-    static bool once = false;
-    if (!once) { printf("occupancy: %d blocks/CU, lds %zu, grid %d\n", nb, lds, grid); once = true; }
-  }
-#endif
   sfm::prof_begin(sfm::kProfXcorr, st);
-  hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, SAME>), dim3(grid),
+  hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, MODE>), dim3(grid),
                      dim3(kThreads), lds, st, a);
   sfm::prof_end(sfm::kProfXcorr, st);
   SFM_LAUNCH_CHECK();
@@ -1053,10 +1272,120 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
 }
 
 template <int NCA, int NCE>
-int launch_variant(const MfmaArgs& a, bool same, int grid, size_t lds,
+int launch_variant(const MfmaArgs& a, int mode, int grid, size_t lds,
                    hipStream_t st) {
-  return same ? launch_one<NCA, NCE, true>(a, grid, lds, st)
-              : launch_one<NCA, NCE, false>(a, grid, lds, st);
+  switch (mode) {
+    case kModeSame: return launch_one<NCA, NCE, kModeSame>(a, grid, lds, st);
+    case kModeRaw: return launch_one<NCA, NCE, kModeRaw>(a, grid, lds, st);
+    default: return launch_one<NCA, NCE, kModeGeneral>(a, grid, lds, st);
+  }
+}
+
+int launch_mode(int vi, const MfmaArgs& a, int mode, int grid, size_t lds,
+                hipStream_t st) {
+  switch (vi) {
+    case 0: return launch_variant<3, 4>(a, mode, grid, lds, st);
+    case 1: return launch_variant<4, 5>(a, mode, grid, lds, st);
+    case 2: return launch_variant<5, 6>(a, mode, grid, lds, st);
+    case 3: return launch_variant<6, 7>(a, mode, grid, lds, st);
+    case 4: return launch_variant<8, 9>(a, mode, grid, lds, st);
+    case 5: return launch_variant<10, 11>(a, mode, grid, lds, st);
+  }
+  return sfm::fail(SFM_ERR_INVALID, "no MFMA variant");
+}
+
+int device_cus() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
+// Geometry, image pointers, LDS layout and the static tile schedule shared by
+// every mode.
+int fill_common(const SfmXcorrDesc* d, const Layout& l, MfmaArgs* ap) {
+  MfmaArgs& a = *ap;
+  std::memset(&a, 0, sizeof(a));
+  a.img[0] = static_cast<const unsigned char*>(d->pre_image);
+  a.img[1] = static_cast<const unsigned char*>(d->post_image);
+  a.mask[0] = d->pre_mask;
+  a.mask[1] = d->post_mask;
+  for (int k = 0; k < 2; ++k) {
+    a.ishape[0][k] = d->pre_shape[1 + k];
+    a.ishape[1][k] = d->post_shape[1 + k];
+    a.mshape[0][k] = d->pre_mask_shape[1 + k];
+    a.mshape[1][k] = d->post_mask_shape[1 + k];
+    a.P[k] = d->patch[1 + k];
+    a.Q[k] = d->post_patch[1 + k];
+    a.S[k] = a.P[k] + a.Q[k] - 1;
+  }
+  a.starts[0] = d->pre_starts;
+  a.starts[1] = d->post_starts;
+  a.batch = d->batch;
+  a.use_mean = d->use_mean;
+  a.mean = d->mean;
+  {
+    int rows = 0, pitch = 0;
+    sfm::mfma_i8_padded_dims(d, &rows, &pitch);
+    a.sx_pitch = pitch;
+    a.s_stride = (long long)rows * pitch;
+  }
+  a.pa = l.pa;
+  a.pb = l.pb;
+  a.ml = l.ml;
+  a.a_bytes = l.a_bytes;
+  a.b_bytes = l.b_bytes;
+  // Static schedule: dy tiles sorted by the number of patch rows they visit,
+  // dealt to the 4 waves longest-first.
+  const int np = (a.S[0] + 15) / 16;
+  std::vector<std::pair<int, int>> work;
+  for (int p = 0; p < np; ++p) {
+    const int dy0 = 16 * p - (a.Q[0] - 1);
+    const int ylo = std::max(0, -dy0 - 15), yhi = std::min(a.Q[0], a.P[0] - dy0);
+    work.push_back({std::max(0, (yhi - ylo + 3) / 4), p});
+  }
+  std::sort(work.begin(), work.end(),
+            [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
+              return x.first > y.first || (x.first == y.first && x.second < y.second);
+            });
+  int load[kWaves] = {0, 0, 0, 0};
+  for (auto& t : work) {
+    int best = 0;
+    for (int k = 1; k < kWaves; ++k)
+      if (load[k] < load[best]) best = k;
+    if (a.n_tiles[best] >= kMaxTilesPerWave)
+      return sfm::fail(SFM_ERR_INVALID, "too many dy tiles");
+    a.tiles[best][a.n_tiles[best]++] = static_cast<unsigned char>(t.second);
+    load[best] += t.first + 1;  // + epilogue
+  }
+  return SFM_OK;
+}
+
+// Masked path: eight raw-product passes over sub-batches, then the assembly.
+constexpr int kMaskedChunk = 512;
+const int kMaskedPasses[8][2] = {
+    {kPlaneVal, kPlaneVal},     {kPlaneVal, kPlaneValid},  {kPlaneValid, kPlaneVal},
+    {kPlaneValid, kPlaneValid}, {kPlaneSqHi, kPlaneValid}, {kPlaneSqLo, kPlaneValid},
+    {kPlaneValid, kPlaneSqHi},  {kPlaneValid, kPlaneSqLo}};
+
+struct MaskedWs {
+  PatchParams* pp;
+  int* raw;  // [8][kMaskedChunk][rows * pitch]
+  size_t bytes;
+};
+
+MaskedWs carve_masked(const SfmXcorrDesc* d, void* base) {
+  sfm::Carver c(base);
+  MaskedWs w;
+  int rows = 0, pitch = 0;
+  sfm::mfma_i8_padded_dims(d, &rows, &pitch);
+  const size_t chunk = std::min<size_t>(d->batch, kMaskedChunk);
+  w.pp = c.take<PatchParams>(d->batch);
+  w.raw = c.take<int>((size_t)8 * chunk * rows * pitch);
+  w.bytes = c.total();
+  return w;
 }
 
 }  // namespace
@@ -1065,7 +1394,6 @@ namespace sfm {
 
 bool mfma_i8_eligible(const SfmXcorrDesc* d) {
   if (!d || d->ndim != 2 || d->dtype != SFM_DTYPE_U8) return false;
-  if (d->pre_mask || d->post_mask) return false;
   if (d->patch[0] != 1 || d->post_patch[0] != 1) return false;
   const int py = d->patch[1], px = d->patch[2];
   const int qy = d->post_patch[1], qx = d->post_patch[2];
@@ -1081,6 +1409,7 @@ bool mfma_i8_eligible(const SfmXcorrDesc* d) {
 }
 
 size_t mfma_i8_workspace_bytes(const SfmXcorrDesc* d) {
+  if (d->pre_mask || d->post_mask) return carve_masked(d, nullptr).bytes;
   return carve_ws(d, nullptr).bytes;
 }
 
@@ -1099,21 +1428,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   const Layout l = make_layout(d, kVariants[vi]);
   Ws w = carve_ws(d, ws_base);
   MfmaArgs a;
-  std::memset(&a, 0, sizeof(a));
-  a.img[0] = static_cast<const unsigned char*>(d->pre_image);
-  a.img[1] = static_cast<const unsigned char*>(d->post_image);
-  for (int k = 0; k < 2; ++k) {
-    a.ishape[0][k] = d->pre_shape[1 + k];
-    a.ishape[1][k] = d->post_shape[1 + k];
-    a.P[k] = d->patch[1 + k];
-    a.Q[k] = d->post_patch[1 + k];
-    a.S[k] = a.P[k] + a.Q[k] - 1;
-  }
-  a.starts[0] = d->pre_starts;
-  a.starts[1] = d->post_starts;
-  a.batch = d->batch;
-  a.use_mean = d->use_mean;
-  a.mean = d->mean;
+  if (int rc = fill_common(d, l, &a)) return rc;
   a.pp = w.pp;
   const bool same = same_size(d);
   a.integ[0] = w.integ[0];
@@ -1141,42 +1456,6 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     a.hot_val = fp->hot_val;
     a.hot_idx = fp->hot_idx;
   }
-  {
-    int rows = 0, pitch = 0;
-    mfma_i8_padded_dims(d, &rows, &pitch);
-    a.sx_pitch = pitch;
-    a.s_stride = (long long)rows * pitch;
-  }
-  a.pa = l.pa;
-  a.pb = l.pb;
-  a.ml = l.ml;
-  a.a_bytes = l.a_bytes;
-  a.b_bytes = l.b_bytes;
-
-  // Static schedule: dy tiles sorted by the number of patch rows they visit,
-  // dealt to the 4 waves longest-first.
-  const int np = (a.S[0] + 15) / 16;
-  std::vector<std::pair<int, int>> work;
-  for (int p = 0; p < np; ++p) {
-    const int dy0 = 16 * p - (a.Q[0] - 1);
-    const int ylo = std::max(0, -dy0 - 15), yhi = std::min(a.Q[0], a.P[0] - dy0);
-    work.push_back({std::max(0, (yhi - ylo + 3) / 4), p});
-  }
-  std::sort(work.begin(), work.end(),
-            [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
-              return x.first > y.first || (x.first == y.first && x.second < y.second);
-            });
-  int load[kWaves] = {0, 0, 0, 0};
-  for (auto& t : work) {
-    int best = 0;
-    for (int k = 1; k < kWaves; ++k)
-      if (load[k] < load[best]) best = k;
-    if (a.n_tiles[best] >= kMaxTilesPerWave)
-      return fail(SFM_ERR_INVALID, "too many dy tiles");
-    a.tiles[best][a.n_tiles[best]++] = static_cast<unsigned char>(t.second);
-    load[best] += t.first + 1;  // + epilogue
-  }
-
   if (same) {
     const size_t prep_lds = 2 * (((size_t)a.P[0] * a.P[1] + 15) & ~(size_t)15);
     static size_t prep_attr = 0;
@@ -1195,11 +1474,6 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   }
   SFM_LAUNCH_CHECK();
 
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-  }
   // Region behind the patches: the four 1-D correction arrays, reused as the
   // arg-max scratch of the fused peak search, then the running-max word.
   size_t r_bytes = same ? (size_t)4 * w.aux_n * 4 : 0;
@@ -1208,16 +1482,66 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   a.r_bytes = static_cast<int>(r_bytes);
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
-  const int grid = std::min(d->batch, cus * per_cu);
-  switch (vi) {
-    case 0: return launch_variant<3, 4>(a, same, grid, lds, st);
-    case 1: return launch_variant<4, 5>(a, same, grid, lds, st);
-    case 2: return launch_variant<5, 6>(a, same, grid, lds, st);
-    case 3: return launch_variant<6, 7>(a, same, grid, lds, st);
-    case 4: return launch_variant<8, 9>(a, same, grid, lds, st);
-    case 5: return launch_variant<10, 11>(a, same, grid, lds, st);
+  const int grid = std::min(d->batch, device_cus() * per_cu);
+  return launch_mode(vi, a, same ? kModeSame : kModeGeneral, grid, lds, st);
+}
+
+// Masked (Padfield) correlation on the matrix cores.  Outputs, all padded to
+// whole tiles [batch, rows, pitch]: num (numerator), den, ov, and the
+// batch-global maxima the finalize step needs (flow_field.py:137, 151).
+int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* num, float* den,
+                   float* ov, unsigned int* maxima) {
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  const int vi = pick_variant(d->patch[2], d->post_patch[2]);
+  if (vi < 0) return fail(SFM_ERR_INVALID, "patch too wide for the MFMA path");
+  const Layout l = make_layout(d, kVariants[vi]);
+  MaskedWs w = carve_masked(d, ws_base);
+  MfmaArgs a;
+  if (int rc = fill_common(d, l, &a)) return rc;
+  for (int k = 0; k < 2; ++k)
+    if (a.mask[k] && (a.mshape[k][0] < (k ? a.Q[0] : a.P[0]) ||
+                      a.mshape[k][1] < (k ? a.Q[1] : a.P[1])))
+      return fail(SFM_ERR_INVALID, "mask smaller than patch");
+  a.pp = w.pp;
+  hipLaunchKernelGGL(mfma_prep_masked_kernel, dim3(d->batch, 2), dim3(kThreads), 0,
+                     st, a);
+  SFM_LAUNCH_CHECK();
+  SFM_HIP_CHECK(hipMemsetAsync(maxima, 0, 2 * sizeof(unsigned int), st));
+  size_t r_bytes = (size_t)kThreads * 8;
+  a.r_bytes = static_cast<int>(r_bytes);
+  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int cus = device_cus();
+  const long long elems = a.s_stride;
+  for (int lo = 0; lo < d->batch; lo += kMaskedChunk) {
+    const int nb = std::min(kMaskedChunk, d->batch - lo);
+    const long long plane_stride = (long long)nb * elems;
+    MfmaArgs c = a;
+    c.batch = nb;
+    c.pp = w.pp + lo;
+    const int grid = std::min(nb, cus * per_cu);
+    for (int pass = 0; pass < 8; ++pass) {
+      c.plane[0] = kMaskedPasses[pass][0];
+      c.plane[1] = kMaskedPasses[pass][1];
+      c.raw_out = w.raw + pass * plane_stride;
+      if (int rc = launch_mode(vi, c, kModeRaw, grid, lds, st)) return rc;
+    }
+    AssembleArgs g;
+    g.raw = w.raw;
+    g.plane_stride = plane_stride;
+    g.pp = w.pp + lo;
+    g.elems = elems;
+    g.n_patches = nb;
+    g.num = num + (long long)lo * elems;
+    g.den = den + (long long)lo * elems;
+    g.ov = ov + (long long)lo * elems;
+    g.maxima = maxima;
+    const long long total = plane_stride;
+    const int ag = static_cast<int>(std::min<long long>((total + kThreads - 1) / kThreads, 4096));
+    hipLaunchKernelGGL(mfma_assemble_masked_kernel, dim3(ag), dim3(kThreads), 0, st, g);
+    SFM_LAUNCH_CHECK();
   }
-  return fail(SFM_ERR_INVALID, "no MFMA variant");
+  return SFM_OK;
 }
 
 }  // namespace sfm

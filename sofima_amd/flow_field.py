@@ -84,6 +84,33 @@ def _query_integral_image(svt, diam, stride):
   return total
 
 
+def _masked_counts(mask, patch_size, step):
+  """Number of masked pixels in every grid patch, [*(shape - patch)//step + 1].
+
+  Device replacement for `_integral_image` + the summed-area-table query of
+  the reference (flow_field.py:575-589): `sfm_mask_patch_counts`.  Falls back
+  to the host summed-area table only when no GPU is visible (planning-only
+  use, e.g. the CPU unit tests of `plan()`).
+  """
+  if not torch.cuda.is_available():
+    return _query_integral_image(_integral_image(mask), patch_size, step)
+  dev = _dev.device()
+  m = _dev.as_device_mask(mask, dev)
+  nd = m.ndim
+  d = _abi.SfmMaskCountDesc()
+  d.ndim = nd
+  d.shape = _i3(_pad3(m.shape, 1))
+  d.patch = _i3(_pad3(patch_size, 1))
+  d.step = _i3(_pad3(step, 1))
+  d.mask = m.data_ptr()
+  d.stream = _dev.stream_ptr()
+  grid = [(int(s) - int(p)) // int(t) + 1
+          for s, p, t in zip(m.shape, patch_size, step)]
+  out = torch.empty(grid, dtype=torch.int32, device=dev)
+  _abi.check(_abi.load().sfm_mask_patch_counts(C.byref(d), out.data_ptr()))
+  return out.cpu().numpy()
+
+
 # ---------------------------------------------------------------------------
 # C-ABI call helpers
 # ---------------------------------------------------------------------------
@@ -346,7 +373,7 @@ class JAXMaskedXCorrWithStatsCalculator:
     for mask, psz in ((pre_mask, patch_size), (post_mask, post_patch_size)):
       if mask is None:
         continue
-      s = _query_integral_image(_integral_image(mask), psz, step)
+      s = _masked_counts(mask, psz, step)
       m = (s / np.prod(psz) >= max_masked)[out_sel]
       selection_mask[m] = False
 

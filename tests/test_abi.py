@@ -55,6 +55,7 @@ def test_struct_layouts_match_header():
                      ('SfmFireState', _abi.SfmFireState),
                      ('SfmChunkStats', _abi.SfmChunkStats),
                      ('SfmProfile', _abi.SfmProfile),
+                     ('SfmMaskCountDesc', _abi.SfmMaskCountDesc),
                      ('SfmComposeDesc', _abi.SfmComposeDesc),
                      ('SfmTargetMeshDesc', _abi.SfmTargetMeshDesc)):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,

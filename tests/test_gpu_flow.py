@@ -287,3 +287,73 @@ def test_flow_field_empty_selection_and_single_patch(gpu):
   f = calc.flow_field(img, img, 96, 96, batch_size=1)       # patch == image
   assert f.shape == (4, 1, 1)
   np.testing.assert_array_equal(f[:2, 0, 0], [0, 0])
+
+
+@pytest.mark.parametrize('py,px,qy,qx', [(48, 48, 48, 48), (64, 80, 40, 64),
+                                         (160, 160, 160, 160)])
+def test_masked_mfma_matches_direct_kernel(gpu, py, px, qy, qx):
+  """Padfield NCC from eight int8 MFMA correlations vs the f32 direct kernel,
+  including full-range pixels (a - centre = -128 exercises the square split)."""
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(py + 7 * qx)
+  from scipy import ndimage
+  h, w = 400, 420
+  base = ndimage.gaussian_filter(rng.standard_normal((h + 8, w + 8)), 1.5)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  pre = base[4:4 + h, 4:4 + w].copy()
+  post = base[6:6 + h, 1:1 + w].copy()
+  pre[10:14, 10:300] = 0
+  pre[14:18, 10:300] = 255
+  pre_mask = rng.random((h, w)) < 0.1
+  pre_mask[200:260, 100:220] = True
+  post_mask = np.zeros((h + 6, w + 3), bool)      # larger than the image
+  post_mask[50:120, 300:] = True
+  post_mask[rng.random(post_mask.shape) < 0.05] = True
+  b = 9
+  starts = np.stack([rng.integers(0, h - py, b), rng.integers(0, w - px, b)], 1)
+  post_starts = starts + np.array([(py - qy) // 2, (px - qx) // 2])
+  kw = dict(min_distance=2, threshold_rel=0.5, peak_radius=5,
+            post_patch_size=(qy, qx), post_starts=post_starts)
+  for masks in ((pre_mask, post_mask), (None, post_mask), (pre_mask, None)):
+    ref = flow_field.batched_xcorr_peaks(pre, post, masks[0], masks[1], (py, px),
+                                         starts, None, method=1, **kw)
+    got = flow_field.batched_xcorr_peaks(pre, post, masks[0], masks[1], (py, px),
+                                         starts, None, method=2, **kw)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(got[:, :2], ref[:, :2])
+    ok = np.isfinite(ref[:, 2])
+    np.testing.assert_allclose(got[ok, 2], ref[ok, 2], rtol=2e-2)
+    np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=2e-3, atol=1e-6)
+
+
+def test_masked_flow_production_geometry_vs_oracle(gpu):
+  from sofima_amd import flow_field
+  pre, post = _em_pair(11, 520, 560, warp=2.0)
+  rng = np.random.default_rng(2)
+  pre_mask = np.zeros(pre.shape, bool)
+  pre_mask[100:180, 200:330] = True
+  post_mask = rng.random(post.shape) < 0.03
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  got = calc.flow_field(pre, post, 160, 40, pre_mask=pre_mask,
+                        post_mask=post_mask, batch_size=32)
+  want = flow_oracle.flow_field(pre, post, 160, 40, pre_mask=pre_mask,
+                                post_mask=post_mask, batch_size=32, workers=4)
+  check_flow(got, want, sharp_rtol=5e-3, ratio_rtol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,patch,step', [
+    ((300, 517), (160, 160), (40, 40)),
+    ((97, 64), (17, 32), (5, 8)),
+    ((9, 40, 50), (4, 16, 16), (2, 8, 8)),
+    ((33, 33), (33, 33), (7, 7)),
+])
+def test_mask_patch_counts_match_summed_area_table(gpu, shape, patch, step):
+  """sfm_mask_patch_counts == flow_field.py:575-589 box query, exactly."""
+  from sofima_amd import flow_field as ff
+  rng = np.random.default_rng(7)
+  mask = rng.random(shape) < 0.3
+  want = ff._query_integral_image(ff._integral_image(mask), patch, step)
+  got = ff._masked_counts(mask, patch, step)
+  assert got.shape == want.shape
+  np.testing.assert_array_equal(got.astype(np.int64), want.astype(np.int64))
