@@ -222,7 +222,7 @@ def main():
     try:
       pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
       for name, v in pmc.items():
-        if 'xcorr_mfma_kernel<10, 11, true>' in name and size == 8192:
+        if 'xcorr_mfma_kernel<10, 11,' in name and size == 8192:
           roof['traffic'] = v['hbm_bytes_per_launch']
           roof['traffic_note'] = (
               'bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, '
