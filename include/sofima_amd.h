@@ -88,6 +88,7 @@ typedef struct SfmXcorrDesc {
   const int32_t* pre_starts;    /* device [batch, ndim] [z]yx, row-major     */
   const int32_t* post_starts;   /* device [batch, ndim]                      */
   int32_t batch;                /* rows in the starts arrays (incl. padding) */
+  int32_t group;                /* rows per reference batch, see below; 0 = batch */
   int32_t use_mean;             /* 0: subtract per-patch mean; 1: use `mean` */
   float mean;
   int32_t min_distance;         /* max-filter half width (reference: 2)      */
@@ -104,7 +105,10 @@ size_t sfm_xcorr_workspace_bytes(const SfmXcorrDesc* desc);
 
 /* peaks: device float [batch, ndim + 2] = x, y[, z], sharpness, ratio.
  * The batch-coupled behaviours of the reference (second-peak suppression set,
- * batch-global masked-NCC tolerances) are computed over all `batch` rows. */
+ * batch-global masked-NCC tolerances) are computed over every run of `group`
+ * consecutive rows separately (the last run may be shorter): one call can
+ * carry many reference batches (flow_field.py:610-699) in one launch and
+ * still returns what the reference returns batch by batch. */
 int sfm_xcorr_peaks(const SfmXcorrDesc* desc, float* peaks);
 
 /* surface: device float [batch, *(P + Q - 1)]; the array masked_xcorr returns

@@ -43,6 +43,7 @@ class SfmXcorrDesc(C.Structure):
       ('pre_starts', C.c_void_p),
       ('post_starts', C.c_void_p),
       ('batch', i32),
+      ('group', i32),
       ('use_mean', i32),
       ('mean', C.c_float),
       ('min_distance', i32),

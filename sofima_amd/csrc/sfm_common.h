@@ -42,7 +42,9 @@ struct FusedPeaks {
   int* cand_count;
   float* cand_val;
   int* cand_idx;
-  unsigned* bitmap;
+  unsigned* bitmap;   // [n_groups, bitmap_words]
+  int group;          // rows per coupling group
+  int bitmap_words;
   int hot_cap;     // per-surface capacity of the hot list
   int* hot_count;  // zeroed with the rest of the per-batch state
   float* hot_val;

@@ -306,7 +306,9 @@ struct PeakArgs {
   int* cand_count;         // [B]
   float* cand_val;         // [B, kCandCap]
   int* cand_idx;           // [B, kCandCap]
-  unsigned int* bitmap;    // [ceil(Sn / 32)]
+  unsigned int* bitmap;    // [n_groups, bitmap_words]
+  int group;               // rows per coupling group
+  int bitmap_words;
   float* out;              // [B, nd + 2]
 };
 
@@ -418,7 +420,8 @@ __global__ void __launch_bounds__(kBlock) peaks_first_kernel(PeakArgs p) {
     const int i1 = bv == -INFINITY ? 0 : bi;  // argmax of an all -inf row is 0
     p.idx1[b] = i1;
     p.v1[b] = bv;
-    atomicOr(&p.bitmap[i1 >> 5], 1u << (i1 & 31));
+    atomicOr(&p.bitmap[(long long)(b / p.group) * p.bitmap_words + (i1 >> 5)],
+             1u << (i1 & 31));
   }
 }
 
@@ -430,6 +433,7 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
   const float v1 = p.v1[b];
   const int i1 = p.idx1[b];
   const int w = p.nd + 2;
+  const unsigned int* bitmap = p.bitmap + (long long)(b / p.group) * p.bitmap_words;
   if (v1 == -INFINITY) {
     if (threadIdx.x < w) p.out[b * w + threadIdx.x] = NAN;
     return;
@@ -443,7 +447,7 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
     for (int k = threadIdx.x; k < cnt; k += kBlock) {
       const float v = p.cand_val[(long long)b * kCandCap + k];
       const int i = p.cand_idx[(long long)b * kCandCap + k];
-      if ((p.bitmap[i >> 5] >> (i & 31)) & 1u) continue;
+      if ((bitmap[i >> 5] >> (i & 31)) & 1u) continue;
       if (better(v, i, bv, bi)) {
         bv = v;
         bi = i;
@@ -453,7 +457,7 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
     // Candidate list overflowed (plateaus): rescan the surface.
     const float mx = surface_max(s, p, lv, li);
     for_each_peak(s, p, p.threshold_rel * mx, [&](int i, float v) {
-      if (((p.bitmap[i >> 5] >> (i & 31)) & 1u) == 0 && better(v, i, bv, bi)) {
+      if (((bitmap[i >> 5] >> (i & 31)) & 1u) == 0 && better(v, i, bv, bi)) {
         bv = v;
         bi = i;
       }
@@ -529,6 +533,7 @@ struct PeakWs {
   float* cand_val;
   int* cand_idx;
   unsigned int* bitmap;
+  int group, bitmap_words;
   int* hot_count;      // fused MFMA path only
   float* hot_val;
   int* hot_idx;
@@ -536,8 +541,11 @@ struct PeakWs {
   size_t bytes;
 };
 
-PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn, bool hot = false) {
+PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn, bool hot = false,
+                   int group = 0) {
   PeakWs w;
+  w.group = group > 0 && group < batch ? group : batch;
+  w.bitmap_words = static_cast<int>((sn + 31) / 32);
   w.idx1 = c.take<int>(batch);
   w.v1 = c.take<float>(batch);
   w.hot_val = hot ? c.take<float>((size_t)batch * kHotCap) : nullptr;
@@ -548,7 +556,8 @@ PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn, bool hot = false) {
   w.zero_is_peak = c.take<int>(batch);
   w.cand_count = c.take<int>(batch);
   w.hot_count = c.take<int>(batch);
-  w.bitmap = c.take<unsigned int>((size_t)((sn + 31) / 32));
+  w.bitmap = c.take<unsigned int>(
+      (size_t)((batch + w.group - 1) / w.group) * w.bitmap_words);
   w.zero_from = z0;
   w.zero_bytes = c.total() - z0;
   w.bytes = c.total();
@@ -581,6 +590,8 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
   p.cand_val = w.cand_val;
   p.cand_idx = w.cand_idx;
   p.bitmap = w.bitmap;
+  p.group = w.group;
+  p.bitmap_words = w.bitmap_words;
   p.out = out;
   if (!first_pass_done) {
     SFM_HIP_CHECK(hipMemsetAsync(ws_base + w.zero_from, 0, w.zero_bytes, st));
@@ -647,7 +658,8 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
     with_surface = true;
   }
   if (with_surface) w.surface = c.take<float>(B * (size_t)w.srows * w.spitch);
-  if (with_peaks) w.peaks = carve_peaks(c, d->batch, g.Sn, use_mfma(d) && !masked);
+  if (with_peaks)
+    w.peaks = carve_peaks(c, d->batch, g.Sn, use_mfma(d) && !masked, d->group);
   w.bytes = c.total();
   return w;
 }
@@ -655,6 +667,7 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
 int check_desc(const SfmXcorrDesc* d) {
   if (!d) return sfm::fail(SFM_ERR_INVALID, "desc is NULL");
   if (d->batch < 1) return sfm::fail(SFM_ERR_INVALID, "batch must be >= 1");
+  if (d->group < 0) return sfm::fail(SFM_ERR_INVALID, "group must be >= 0");
   if (!d->pre_image || !d->post_image || !d->pre_starts || !d->post_starts)
     return sfm::fail(SFM_ERR_INVALID, "image / starts pointers must be set");
   if (d->dtype != SFM_DTYPE_U8 && d->dtype != SFM_DTYPE_F32)
@@ -744,24 +757,28 @@ int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
   return SFM_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-size_t sfm_xcorr_workspace_bytes(const SfmXcorrDesc* d) {
-  if (check_desc(d) != SFM_OK) return 0;
-  Geo g;
-  if (make_geo(d, &g) != SFM_OK) return 0;
-  SfmXcorrDesc tmp = *d;
-  tmp.workspace = nullptr;
-  return carve_xcorr(&tmp, g, true, true).bytes;
+// Rows that share the reference's batch-coupled behaviours.
+int group_rows(const SfmXcorrDesc* d) {
+  return d->group > 0 && d->group < d->batch ? d->group : d->batch;
 }
 
-int sfm_xcorr_surface(const SfmXcorrDesc* d, float* surface) {
-  if (int rc = check_desc(d)) return rc;
-  if (!surface) return sfm::fail(SFM_ERR_INVALID, "surface is NULL");
-  Geo g;
-  if (int rc = make_geo(d, &g)) return rc;
+// The fused MFMA path keeps the coupled state per group and takes any number
+// of groups in one launch; every other path runs group by group.
+bool one_launch(const SfmXcorrDesc* d) {
+  return group_rows(d) == d->batch || (use_mfma(d) && !is_masked(d));
+}
+
+SfmXcorrDesc sub_desc(const SfmXcorrDesc* d, int off) {
+  SfmXcorrDesc sub = *d;
+  const int rows = group_rows(d);
+  sub.batch = d->batch - off < rows ? d->batch - off : rows;
+  sub.group = 0;
+  sub.pre_starts = d->pre_starts + (long long)off * d->ndim;
+  sub.post_starts = d->post_starts + (long long)off * d->ndim;
+  return sub;
+}
+
+int surface_one(const SfmXcorrDesc* d, const Geo& g, float* surface) {
   XcorrWs w = carve_xcorr(d, g, false, false);
   if (!d->workspace || d->workspace_bytes < w.bytes)
     return sfm::fail(SFM_ERR_WORKSPACE, "xcorr workspace needs %zu bytes, got %zu",
@@ -777,11 +794,7 @@ int sfm_xcorr_surface(const SfmXcorrDesc* d, float* surface) {
   return compute_surface(d, g, w, surface);
 }
 
-int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
-  if (int rc = check_desc(d)) return rc;
-  if (!peaks) return sfm::fail(SFM_ERR_INVALID, "peaks is NULL");
-  Geo g;
-  if (int rc = make_geo(d, &g)) return rc;
+int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
   XcorrWs w = carve_xcorr(d, g, true, true);
   if (!d->workspace || d->workspace_bytes < w.bytes)
     return sfm::fail(SFM_ERR_WORKSPACE, "xcorr workspace needs %zu bytes, got %zu",
@@ -802,6 +815,8 @@ int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
     fp.cand_val = w.peaks.cand_val;
     fp.cand_idx = w.peaks.cand_idx;
     fp.bitmap = w.peaks.bitmap;
+    fp.group = w.peaks.group;
+    fp.bitmap_words = w.peaks.bitmap_words;
     fp.hot_cap = kHotCap;
     fp.hot_count = w.peaks.hot_count;
     fp.hot_val = w.peaks.hot_val;
@@ -816,6 +831,50 @@ int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
                    d->batch, center, d->min_distance,
                    d->threshold_rel, d->peak_radius, peaks,
                    static_cast<hipStream_t>(d->stream), fuse);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sfm_xcorr_workspace_bytes(const SfmXcorrDesc* d) {
+  if (check_desc(d) != SFM_OK) return 0;
+  Geo g;
+  if (make_geo(d, &g) != SFM_OK) return 0;
+  SfmXcorrDesc tmp = *d;
+  tmp.workspace = nullptr;
+  if (!one_launch(d)) {  // run group by group: scratch for one group
+    tmp.batch = group_rows(d);
+    tmp.group = 0;
+  }
+  return carve_xcorr(&tmp, g, true, true).bytes;
+}
+
+int sfm_xcorr_surface(const SfmXcorrDesc* d, float* surface) {
+  if (int rc = check_desc(d)) return rc;
+  if (!surface) return sfm::fail(SFM_ERR_INVALID, "surface is NULL");
+  Geo g;
+  if (int rc = make_geo(d, &g)) return rc;
+  if (!is_masked(d) || group_rows(d) == d->batch) return surface_one(d, g, surface);
+  // masked surfaces are normalised with maxima over their reference batch
+  for (int off = 0; off < d->batch; off += group_rows(d)) {
+    const SfmXcorrDesc sub = sub_desc(d, off);
+    if (int rc = surface_one(&sub, g, surface + (long long)off * g.Sn)) return rc;
+  }
+  return SFM_OK;
+}
+
+int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
+  if (int rc = check_desc(d)) return rc;
+  if (!peaks) return sfm::fail(SFM_ERR_INVALID, "peaks is NULL");
+  Geo g;
+  if (int rc = make_geo(d, &g)) return rc;
+  if (one_launch(d)) return peaks_one(d, g, peaks);
+  for (int off = 0; off < d->batch; off += group_rows(d)) {
+    const SfmXcorrDesc sub = sub_desc(d, off);
+    if (int rc = peaks_one(&sub, g, peaks + (long long)off * (d->ndim + 2))) return rc;
+  }
+  return SFM_OK;
 }
 
 int sfm_mask_patch_counts(const SfmMaskCountDesc* d, int32_t* counts) {

@@ -119,6 +119,7 @@ struct MfmaArgs {
   float* cand_val;
   int* cand_idx;
   unsigned* bitmap;
+  int group, bitmap_words;
   int hot_cap;        // per-surface capacity of the hot list
   int* hot_count;     // [B]
   float* hot_val;     // [B, hot_cap]
@@ -130,6 +131,9 @@ struct MfmaArgs {
   int plane[2];       // Plane of the pre / post operand
   int* raw_out;       // [batch, rows, sx_pitch] int32 products
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
+  // dynamic patch queue (NULL: static striding over the workgroups)
+  int* work_counter;
+  int prio_mode;      // experiment knob: 0 natural, 1 alternate per tile, 2 static
 };
 
 __device__ __forceinline__ unsigned load_u32_guarded(const unsigned* base,
@@ -142,6 +146,8 @@ __device__ __forceinline__ unsigned load_u32_guarded(const unsigned* base,
 // prep: patch statistics, integer centre, integral image
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
+  if (a.work_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    *a.work_counter = 0;  // the correlation kernel's patch queue
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int red[3][kThreads];
   const int b = blockIdx.x, s = blockIdx.y;
@@ -252,6 +258,8 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 }
 
 __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a) {
+  if (a.work_counter && blockIdx.x == 0 && threadIdx.x == 0)
+    *a.work_counter = 0;  // the correlation kernel's patch queue
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_c[2];
   __shared__ float s_mu[2];
@@ -721,8 +729,9 @@ __device__ __forceinline__ int box_sum(const int* __restrict__ I, int ip, int y0
   return s;
 }
 
-// First-peak search of one finished surface, run by the workgroup that just
-// produced it (the surface is L2 hot; nothing is re-read from HBM later).
+// First-peak search of one finished surface from what the correlation kernel
+// left behind: the surface maximum and the hot list (every element that
+// exceeded threshold_rel * running maximum when its tile was produced).
 // Same result as peaks_first_kernel in sfm_xcorr.hip: peak = element that
 // equals its (2 m + 1)^2 zero-padded window maximum and exceeds
 // threshold_rel * max(surface) (flow_field.py:238-262).
@@ -815,11 +824,34 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
     const int i1 = v1 == -INFINITY ? 0 : li[0];  // argmax of an all -inf row is 0
     a.idx1[b] = i1;
     a.v1[b] = v1;
-    atomicOr(&a.bitmap[i1 >> 5], 1u << (i1 & 31));
+    atomicOr(&a.bitmap[(long long)(b / a.group) * a.bitmap_words + (i1 >> 5)],
+             1u << (i1 & 31));
   }
 }
 
 constexpr int kModeGeneral = 0, kModeSame = 1, kModeRaw = 2;
+
+// One workgroup per surface; v1[b] holds the surface maximum on entry.
+__global__ void __launch_bounds__(kThreads) mfma_first_peak_kernel(MfmaArgs a) {
+  __shared__ float scratch[2 * kThreads];
+  __shared__ int s_pmax, s_hot;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    s_pmax = __float_as_int(a.v1[b]);
+    s_hot = a.hot_count[b];
+  }
+  fused_first_peak(a, b, a.surface + b * a.s_stride, a.S[0], a.S[1], &s_pmax, &s_hot,
+                   scratch);
+}
+
+// Next patch of this workgroup; called by all threads at the end of a patch.
+__device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_lds) {
+  if (!a.work_counter) return b + gridDim.x;
+  __syncthreads();
+  if (threadIdx.x == 0) *next_lds = gridDim.x + atomicAdd(a.work_counter, 1);
+  __syncthreads();
+  return *next_lds;
+}
 
 template <int NCA, int NCE, int MODE>
 __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
@@ -857,7 +889,19 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #else
 #define TICK(i)
 #endif
-  for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
+  // Patches are handed out dynamically: the two workgroups of a CU do not run
+  // at the same speed (see the priority note below) and finish whole patches
+  // at different times.
+  int* next_lds = hot_lds + 1;
+  if (a.prio_mode == 3) {
+    // HW_REG_LDS_ALLOC[7:0] = LDS_BASE: 0 for the first workgroup of the CU.
+    const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6) & 0xff;
+    if (lds_base != 0)
+      __builtin_amdgcn_s_setprio(3);
+    else
+      __builtin_amdgcn_s_setprio(0);
+  }
+  for (int b = blockIdx.x; b < a.batch; b = next_patch(a, b, next_lds)) {
 #ifdef SFM_MFMA_TIMING
     ++npat;
 #endif
@@ -916,10 +960,17 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       // run ~25 % slower and finish long after its partner.  Alternating the
       // priority per tile (opposite phase for the second dispatch wave of
       // workgroups) evens the two out.
-      if ((ti & 1) ^ (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0))
-        __builtin_amdgcn_s_setprio(1);
-      else
-        __builtin_amdgcn_s_setprio(0);
+      if (a.prio_mode == 1) {
+        if ((ti & 1) ^ (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0))
+          __builtin_amdgcn_s_setprio(1);
+        else
+          __builtin_amdgcn_s_setprio(0);
+      } else if (a.prio_mode == 2) {
+        if (blockIdx.x >= (gridDim.x >> 1))
+          __builtin_amdgcn_s_setprio(1);
+        else
+          __builtin_amdgcn_s_setprio(0);
+      }
       const int dy0 = 16 * p - (Qy - 1);
       const int ylo = max(0, -dy0 - 15);
       const int yhi = min(Qy, Py - dy0);
@@ -1054,15 +1105,12 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             const int x0 = xv_of(q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) gbuf[slot][u][0][r] = G[grow[r] + x0];
-            if (q + NCA < NQ) {
-              if (paired) {
+            // Px == 16 NCA: column q + NCA reads the same table entries (the
+            // copy is taken at use time; copying here would wait for the loads)
+            if (q + NCA < NQ && !paired) {
+              const int x1 = xv_of(q + NCA);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gbuf[slot][u][1][r] = gbuf[slot][u][0][r];
-              } else {
-                const int x1 = xv_of(q + NCA);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gbuf[slot][u][1][r] = G[grow[r] + x1];
-              }
+              for (int r = 0; r < 4; ++r) gbuf[slot][u][1][r] = G[grow[r] + x1];
             }
           }
         };
@@ -1077,7 +1125,13 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             const int q = grp * kQG + u;
             if (q >= NCA) break;
             emit(q, gbuf[grp & 1][u][0]);
-            if (q + NCA < NQ) emit(q + NCA, gbuf[grp & 1][u][1]);
+            if (q + NCA < NQ) {
+              float g1[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                g1[r] = paired ? gbuf[grp & 1][u][0][r] : gbuf[grp & 1][u][1][r];
+              emit(q + NCA, g1);
+            }
           }
         }
       } else {
@@ -1158,7 +1212,16 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       TICK(4)
     }
     TICK(5)
-    if (a.do_peaks) fused_first_peak(a, b, surf, Sy, Sx, pmax_lds, hot_lds, R_lds);
+    if (a.do_peaks) {
+      // Publish the running maximum and the hot-list fill; the first-peak
+      // search over them is mfma_first_peak_kernel (every patch in parallel,
+      // off the matrix pipeline's critical path).
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        a.v1[b] = __int_as_float(*pmax_lds);
+        a.hot_count[b] = *hot_lds;
+      }
+    }
     TICK(6)
   }
 #ifdef SFM_MFMA_TIMING
@@ -1231,6 +1294,7 @@ struct Ws {
   float* gtab;
   float* aux;
   int aux_n;
+  int* counter;
   size_t bytes;
 };
 
@@ -1240,6 +1304,7 @@ Ws carve_ws(const SfmXcorrDesc* d, void* base) {
   std::memset(&w, 0, sizeof(w));
   const size_t B = d->batch;
   w.pp = c.take<PatchParams>(B);
+  w.counter = c.take<int>(64);
   if (same_size(d)) {
     w.aux_n = std::max(d->patch[1], d->patch[2]) + 1;
     w.gtab = c.take<float>(B * d->patch[1] * d->patch[2]);
@@ -1439,6 +1504,12 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   a.aux = w.aux;
   a.aux_n = w.aux_n;
   a.surface = surface;
+  {
+    const char* e = std::getenv("SFM_MFMA_QUEUE");
+    a.work_counter = (e && e[0] == '0') ? nullptr : w.counter;
+    const char* p = std::getenv("SFM_MFMA_PRIO");
+    a.prio_mode = p ? std::atoi(p) : 0;
+  }
   if (fp) {
     a.do_peaks = 1;
     a.threshold_rel = d->threshold_rel;
@@ -1451,6 +1522,8 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     a.cand_val = fp->cand_val;
     a.cand_idx = fp->cand_idx;
     a.bitmap = fp->bitmap;
+    a.group = fp->group;
+    a.bitmap_words = fp->bitmap_words;
     a.hot_cap = fp->hot_cap;
     a.hot_count = fp->hot_count;
     a.hot_val = fp->hot_val;
@@ -1483,7 +1556,13 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   const int grid = std::min(d->batch, device_cus() * per_cu);
-  return launch_mode(vi, a, same ? kModeSame : kModeGeneral, grid, lds, st);
+  if (int rc = launch_mode(vi, a, same ? kModeSame : kModeGeneral, grid, lds, st))
+    return rc;
+  if (fp) {
+    hipLaunchKernelGGL(mfma_first_peak_kernel, dim3(d->batch), dim3(kThreads), 0, st, a);
+    SFM_LAUNCH_CHECK();
+  }
+  return SFM_OK;
 }
 
 // Masked (Padfield) correlation on the matrix cores.  Outputs, all padded to
@@ -1503,6 +1582,7 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* num, float* den,
                       a.mshape[k][1] < (k ? a.Q[1] : a.P[1])))
       return fail(SFM_ERR_INVALID, "mask smaller than patch");
   a.pp = w.pp;
+  a.prio_mode = 1;
   hipLaunchKernelGGL(mfma_prep_masked_kernel, dim3(d->batch, 2), dim3(kThreads), 0,
                      st, a);
   SFM_LAUNCH_CHECK();

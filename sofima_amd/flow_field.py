@@ -164,6 +164,10 @@ def _make_desc(res: _Resident, patch_size, post_patch_size, mean, min_distance,
   return d
 
 
+# Patches per C call (a multiple of the reference batch is used).
+LAUNCH_PATCHES = 4096
+
+
 def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray,
                  post_starts: np.ndarray, batch_size: int,
                  progress_fn=None) -> np.ndarray:
@@ -177,7 +181,12 @@ def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray
       np.ascontiguousarray(
           np.stack([pre_starts, post_starts]).astype(np.int32))).to(res.dev)
   peaks = torch.empty((n, nd + 2), dtype=torch.float32, device=res.dev)
-  desc.batch = batch_size
+  # One C call carries several reference batches (`group` rows each keep the
+  # batch-coupled behaviours): fewer, larger launches fill the chip even when
+  # the reference batch is small.
+  per_call = max(1, LAUNCH_PATCHES // batch_size)
+  desc.batch = min(per_call, n_batches) * batch_size
+  desc.group = batch_size
   desc.pre_starts = starts.data_ptr()
   desc.post_starts = starts.data_ptr()
   need = lib.sfm_xcorr_workspace_bytes(C.byref(desc))
@@ -187,12 +196,16 @@ def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray
   desc.workspace = ws.data_ptr()
   desc.workspace_bytes = ws.numel()
   row_bytes = batch_size * nd * 4
-  it = range(n_batches) if progress_fn is None else progress_fn
-  for bi, _ in enumerate(it):
+  it = iter(range(n_batches) if progress_fn is None else progress_fn)
+  for bi in range(0, n_batches, per_call):
+    nb = min(per_call, n_batches - bi)
+    desc.batch = nb * batch_size
     desc.pre_starts = starts.data_ptr() + bi * row_bytes
     desc.post_starts = starts.data_ptr() + (n_batches + bi) * row_bytes
     out_ptr = peaks.data_ptr() + bi * batch_size * (nd + 2) * 4
     _abi.check(lib.sfm_xcorr_peaks(C.byref(desc), out_ptr))
+    for _ in range(nb):
+      next(it, None)
   return peaks.cpu().numpy()
 
 

@@ -357,3 +357,40 @@ def test_mask_patch_counts_match_summed_area_table(gpu, shape, patch, step):
   got = ff._masked_counts(mask, patch, step)
   assert got.shape == want.shape
   np.testing.assert_array_equal(got.astype(np.int64), want.astype(np.int64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('method,masked,dtype', [
+    (0, False, np.uint8), (1, False, np.uint8), (0, True, np.uint8),
+    (0, False, np.float32),
+])
+def test_many_batches_per_call_equal_batch_by_batch(gpu, monkeypatch, method,
+                                                    masked, dtype):
+  """`group` keeps the reference's per-batch coupling inside one launch.
+
+  Calls that carry several reference batches (SfmXcorrDesc.group) must give
+  bit-identical fields to one call per batch, including the batch-coupled
+  second-peak suppression (Q1) and masked tolerances (Q2).
+  """
+  from sofima_amd import flow_field as ff
+  rng = np.random.default_rng(11)
+  base = rng.integers(0, 256, (260, 300)).astype(np.float32)
+  from scipy import ndimage
+  base = ndimage.gaussian_filter(base, 1.5)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255)
+  pre = base[4:244, 6:286].astype(dtype)
+  post = base[1:241, 9:289].astype(dtype)
+  kw = {}
+  if masked:
+    kw = dict(pre_mask=rng.random(pre.shape) < 0.05,
+              post_mask=rng.random(post.shape) < 0.05)
+  calc = ff.JAXMaskedXCorrWithStatsCalculator(method=method)
+  monkeypatch.setattr(ff, 'LAUNCH_PATCHES', 1)
+  one = calc.flow_field(pre, post, 48, 8, batch_size=37, **kw)
+  monkeypatch.setattr(ff, 'LAUNCH_PATCHES', 37 * 5)
+  five = calc.flow_field(pre, post, 48, 8, batch_size=37, **kw)
+  monkeypatch.setattr(ff, 'LAUNCH_PATCHES', 1 << 20)
+  every = calc.flow_field(pre, post, 48, 8, batch_size=37, **kw)
+  assert one.shape[1] * one.shape[2] > 37 * 6
+  np.testing.assert_array_equal(one, five)
+  np.testing.assert_array_equal(one, every)
