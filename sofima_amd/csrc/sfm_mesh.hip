@@ -38,6 +38,7 @@ int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
 
 namespace {
 
+typedef unsigned long long u64;
 constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 1024;
 constexpr int kNP = 8;  // partials per block: power, sx[3], sv[3], pad
@@ -85,20 +86,24 @@ __device__ __forceinline__ float vec_len(const float* d, int c) {
 // Force of one spring given d = x_far - x_near + rest (mesh.py:107-117,
 // 252-270).  Non-finite components become 0 like nan_to_num(posinf=0,
 // neginf=0).
+// One IEEE division per spring: (l0 * m) / l == (l0 / l) * m bit for bit when
+// m is -1, 0 or 1 (sign flips and zeros commute with rounding; the NaN / inf
+// cases give NaN both ways and end up 0), so the per-component quotients of
+// the reference (mesh.py:109-116) share r = l0 / l.
 template <int C>
 __device__ __forceinline__ void spring(const float* d, const float* rest,
                                        const int* dir, float neg_k, int prefer,
                                        float* f) {
   const float l = vec_len(d, C);
   const float l0 = vec_len(rest, C);
+  const float r = l0 / l;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    float num = l0;
+    float t = r;
     if (prefer && dir[c] != 0) {
       const float sg = d[c] > 0.f ? 1.f : (d[c] < 0.f ? -1.f : 0.f);
-      num = l0 * (static_cast<float>(dir[c]) * sg);
+      t = r * (static_cast<float>(dir[c]) * sg);
     }
-    const float t = num / l;
     const float u = 1.0f - t;
     float v = (neg_k * u) * d[c];
     if (!isfinite(v)) v = 0.f;
@@ -106,17 +111,70 @@ __device__ __forceinline__ void spring(const float* d, const float* rest,
   }
 }
 
-template <int C>
-__device__ void node_force(const float* __restrict__ x, const MeshParams& p,
-                           long long n, float* out) {
-  const int xi = static_cast<int>(n % p.X);
-  long long r = n / p.X;
-  const int yi = static_cast<int>(r % p.Y);
-  r /= p.Y;
-  const int zi = static_cast<int>(r % p.Z);
-  float self[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) self[c] = x[c * p.N + n];
+// In-plane spring with compile-time link direction (DX, DY).
+template <int DX, int DY>
+__device__ __forceinline__ void spring_xy(float d0, float d1, float l0, float neg_k,
+                                          int prefer, float* f) {
+  const float l = sqrtf(d0 * d0 + d1 * d1);
+  const float r = l0 / l;
+  float t0 = r, t1 = r;
+  if (prefer) {
+    if (DX != 0) {
+      const float sg = d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f);
+      t0 = r * (static_cast<float>(DX) * sg);
+    }
+    if (DY != 0) {
+      const float sg = d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f);
+      t1 = r * (static_cast<float>(DY) * sg);
+    }
+  }
+  float v0 = (neg_k * (1.0f - t0)) * d0;
+  float v1 = (neg_k * (1.0f - t1)) * d1;
+  if (!isfinite(v0)) v0 = 0.f;
+  if (!isfinite(v1)) v1 = 0.f;
+  f[0] = v0;
+  f[1] = v1;
+}
+
+// inplane_force at one node from an LDS tile: the four link families of
+// build_params (ncomp 2) unrolled, same operation order as node_force_at with
+// order2d.  `ctr` indexes the node inside a tile of row pitch TW.
+template <int TW>
+__device__ __forceinline__ void node_force_tile2d(const float* xt0, const float* xt1,
+                                                  int ctr, const MeshParams& p, int xi,
+                                                  int yi, float s0, float s1,
+                                                  const float* l0, float* out) {
+  float acc0 = 0.f, acc1 = 0.f, f[2];
+#define SFM_FAR(L, DX, DY)                                                         \
+  if (xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 && yi - (DY) < p.Y) {    \
+    const int m = ctr - (DY) * TW - (DX);                                          \
+    spring_xy<DX, DY>(s0 - xt0[m] + p.rest[L][0], s1 - xt1[m] + p.rest[L][1],      \
+                      l0[L], p.neg_k[L], p.prefer, f);                             \
+    acc0 = acc0 + f[0];                                                            \
+    acc1 = acc1 + f[1];                                                            \
+  }
+#define SFM_NEAR(L, DX, DY)                                                        \
+  if (xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 && yi + (DY) < p.Y) {    \
+    const int m = ctr + (DY) * TW + (DX);                                          \
+    spring_xy<DX, DY>(xt0[m] - s0 + p.rest[L][0], xt1[m] - s1 + p.rest[L][1],      \
+                      l0[L], p.neg_k[L], p.prefer, f);                             \
+    acc0 = acc0 - f[0];                                                            \
+    acc1 = acc1 - f[1];                                                            \
+  }
+  SFM_FAR(0, 1, 0) SFM_FAR(1, 0, 1) SFM_FAR(2, 1, 1) SFM_FAR(3, -1, 1)
+  SFM_NEAR(0, 1, 0) SFM_NEAR(1, 0, 1) SFM_NEAR(2, 1, 1) SFM_NEAR(3, -1, 1)
+#undef SFM_FAR
+#undef SFM_NEAR
+  out[0] = acc0;
+  out[1] = acc1;
+}
+
+// Net spring force on the node at (xi, yi, zi).  `ld(c, dx, dy, dz)` returns
+// component c of the node at that offset (only called for in-range offsets).
+template <int C, typename Load>
+__device__ __forceinline__ void node_force_at(Load ld, const MeshParams& p, int xi,
+                                              int yi, int zi, const float* self,
+                                              float* out) {
   float acc[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) acc[c] = 0.f;
@@ -127,12 +185,10 @@ __device__ void node_force(const float* __restrict__ x, const MeshParams& p,
               nz = zi - p.dir[L][2];
     if (nx < 0 || nx >= p.X || ny < 0 || ny >= p.Y || nz < 0 || nz >= p.Z)
       return false;
-    const long long m =
-        n - p.dir[L][0] - (long long)p.dir[L][1] * p.X -
-        (long long)p.dir[L][2] * p.X * p.Y;
     float d[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) d[c] = self[c] - x[c * p.N + m] + p.rest[L][c];
+    for (int c = 0; c < C; ++c)
+      d[c] = self[c] - ld(c, -p.dir[L][0], -p.dir[L][1], -p.dir[L][2]) + p.rest[L][c];
     spring<C>(d, p.rest[L], p.dir[L], p.neg_k[L], p.prefer, f);
     return true;
   };
@@ -141,12 +197,10 @@ __device__ void node_force(const float* __restrict__ x, const MeshParams& p,
               nz = zi + p.dir[L][2];
     if (nx < 0 || nx >= p.X || ny < 0 || ny >= p.Y || nz < 0 || nz >= p.Z)
       return false;
-    const long long m =
-        n + p.dir[L][0] + (long long)p.dir[L][1] * p.X +
-        (long long)p.dir[L][2] * p.X * p.Y;
     float d[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) d[c] = x[c * p.N + m] - self[c] + p.rest[L][c];
+    for (int c = 0; c < C; ++c)
+      d[c] = ld(c, p.dir[L][0], p.dir[L][1], p.dir[L][2]) - self[c] + p.rest[L][c];
     spring<C>(d, p.rest[L], p.dir[L], p.neg_k[L], p.prefer, f);
     return true;
   };
@@ -179,6 +233,24 @@ __device__ void node_force(const float* __restrict__ x, const MeshParams& p,
   }
 #pragma unroll
   for (int c = 0; c < C; ++c) out[c] = acc[c];
+}
+
+template <int C>
+__device__ void node_force(const float* __restrict__ x, const MeshParams& p,
+                           long long n, float* out) {
+  const int xi = static_cast<int>(n % p.X);
+  long long r = n / p.X;
+  const int yi = static_cast<int>(r % p.Y);
+  r /= p.Y;
+  const int zi = static_cast<int>(r % p.Z);
+  float self[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) self[c] = x[c * p.N + n];
+  node_force_at<C>(
+      [&](int c, int dx, int dy, int dz) {
+        return x[c * p.N + n + dx + (long long)dy * p.X + (long long)dz * p.X * p.Y];
+      },
+      p, xi, yi, zi, self, out);
 }
 
 // clip(-k0 * nan_to_num(x - prev), -cap, cap)   (mesh.py:432-433)
@@ -224,16 +296,10 @@ __device__ void block_sum(float* vals, int nv, float* lds) {
   __syncthreads();
 }
 
-// Reduces the partials of the previous step and advances the FIRE scalars
-// (mesh.py:455-497).  Every block computes the identical result.
-__device__ void update_scalars(const Scalars& in, const float* partials,
-                               int n_part_rows, const MeshParams& p,
-                               float* lds, Scalars* out) {
-  float acc[kNP];
-  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
-  for (int r = threadIdx.x; r < n_part_rows; r += kBlock)
-    for (int i = 0; i < 7; ++i) acc[i] = acc[i] + partials[r * kNP + i];
-  block_sum(acc, 7, lds);
+// Advances the FIRE scalars from the summed partials of the previous step
+// (mesh.py:455-497).
+__device__ void scalars_from_sums(const Scalars& in, const float* acc,
+                                  const MeshParams& p, Scalars* out) {
   const float power = acc[0];
   Scalars s = in;
   const bool downhill = power >= 0.f;
@@ -257,6 +323,19 @@ __device__ void update_scalars(const Scalars& in, const float* partials,
   *out = s;
 }
 
+// Reduces the partials of the previous step and advances the FIRE scalars.
+// Every block computes the identical result.
+__device__ void update_scalars(const Scalars& in, const float* partials,
+                               int n_part_rows, const MeshParams& p,
+                               float* lds, Scalars* out) {
+  float acc[kNP];
+  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
+  for (int r = threadIdx.x; r < n_part_rows; r += kBlock)
+    for (int i = 0; i < 7; ++i) acc[i] = acc[i] + partials[r * kNP + i];
+  block_sum(acc, 7, lds);
+  scalars_from_sums(in, acc, p, out);
+}
+
 // x += dt v + dt^2/2 a, after applying the pending gate / drift of the
 // previous step (mesh.py:439, 492-497).
 template <int C>
@@ -269,8 +348,10 @@ advance_kernel(float* __restrict__ x, float* __restrict__ v,
   __shared__ float lds[kNP * kBlock];
   Scalars s;
   if (p.fire) {
-    if (pending) {
+    if (pending == 1) {
       update_scalars(*scal_in, partials, n_part_rows, p, lds, &s);
+    } else if (pending == 2) {
+      s = *scal_in;  // reduced by the last workgroup of the tiled integrator
     } else {
       s = *scal_in;
       s.gate = 1.f;
@@ -364,6 +445,211 @@ integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-tiled step for large in-plane meshes (state far beyond the caches).
+//
+// One workgroup owns a TY x TX tile of one section.  It loads x (FUSED: and
+// v, a) of the tile plus a one-node halo with coalesced loads that are all in
+// flight together, keeps the positions in LDS for the 8-neighbour stencil and
+// writes x, v, a of its own nodes once: ~59 bytes per node update against the
+// algorithmic 56 (the multi-launch pair moves 88 and waits for every
+// neighbour load separately).
+//
+// FUSED = true is the whole FIRE / Verlet step in one launch: the position
+// update x += dt v + dt^2/2 a of the halo nodes is recomputed from the
+// neighbours' (x, v, a), so the state ping-pongs between two buffer sets.
+// FUSED = false integrates positions that advance_kernel (and the native
+// prev_fn) already produced, in place.
+//
+// The per-tile partial sums are reduced by the LAST workgroup to finish (ticket
+// counter), in row order, so the result does not depend on which one is last;
+// it leaves the updated FIRE scalars for the next launch.
+// ---------------------------------------------------------------------------
+template <int TY, int TX, bool FUSED>
+__global__ void __launch_bounds__(kBlock)
+integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in,
+                         const float* __restrict__ prev, float* x_out, float* v_out,
+                         float* a_out, MeshParams p,
+                         const Scalars* __restrict__ scal_in,
+                         Scalars* __restrict__ scal_out, float fixed_cap,
+                         u64* __restrict__ partials, int* __restrict__ ticket,
+                         unsigned epoch, int pending, int nty, int ntx) {
+  constexpr int C = 2;
+  constexpr int TW = TX + 2;
+  constexpr int kRows = TY * TX / kBlock;  // nodes per thread
+  constexpr int kRowStep = kBlock / TX;
+  static_assert(TY * TX % kBlock == 0 && kBlock % TX == 0, "tile shape");
+  __shared__ float xt[C][(TY + 2) * TW];
+  __shared__ float lds[kNP * kBlock];
+  __shared__ int s_last;
+
+  Scalars s;
+  if (p.fire) {
+    s = *scal_in;
+    if (!pending) {
+      s.gate = 1.f;
+      for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+    }
+  } else {
+    s.dt = p.vv_dt;
+    s.alpha = 0.f;
+    s.cap = fixed_cap;
+    s.gate = 1.f;
+    for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+  }
+  const float dt = s.dt, alpha = s.alpha, cap = s.cap;
+  const float c2 = 0.5f * (dt * dt);
+  const bool fix = p.fire && pending;
+
+  const int tx = blockIdx.x % ntx;
+  const int ty = (blockIdx.x / ntx) % nty;
+  const long long plane = blockIdx.x / (ntx * nty);  // b * Z + z
+  const long long base = plane * p.Y * p.X;
+  const int gx0 = tx * TX, gy0 = ty * TY;
+
+  // Position of one node after the position update (FUSED) / as stored.
+  auto advanced = [&](long long n, int c, float* v_keep, float* a_keep) -> float {
+    float xv = x_in[c * p.N + n];
+    if (!FUSED) return xv;
+    float vv = v_in[c * p.N + n];
+    const float aa = a_in[c * p.N + n];
+    if (fix) {
+      vv = vv * s.gate;
+      if (p.remove_drift) {
+        xv = xv - s.mx[c];
+        vv = vv - s.mv[c];
+      }
+    }
+    if (v_keep) *v_keep = vv;
+    if (a_keep) *a_keep = aa;
+    return xv + (dt * vv + c2 * aa);
+  };
+
+  const int lx = threadIdx.x % TX, ly0 = threadIdx.x / TX;
+  float v_own[kRows][C], a_own[kRows][C], x_own[kRows][C];
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    const int ly = ly0 + k * kRowStep;
+    const int gy = gy0 + ly, gx = gx0 + lx;
+    if (gy < p.Y && gx < p.X) {
+      const long long n = base + (long long)gy * p.X + gx;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        x_own[k][c] = advanced(n, c, &v_own[k][c], &a_own[k][c]);
+        xt[c][(ly + 1) * TW + lx + 1] = x_own[k][c];
+      }
+    }
+  }
+  constexpr int kHalo = 2 * TW + 2 * TY;
+  for (int h = threadIdx.x; h < kHalo; h += kBlock) {
+    int hy, hx;  // tile coordinates in [-1, TY] x [-1, TX]
+    if (h < TW) {
+      hy = -1;
+      hx = h - 1;
+    } else if (h < 2 * TW) {
+      hy = TY;
+      hx = h - TW - 1;
+    } else {
+      const int r = h - 2 * TW;
+      hy = r >> 1;
+      hx = (r & 1) ? TX : -1;
+    }
+    const int gy = gy0 + hy, gx = gx0 + hx;
+    if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X) {
+      const long long n = base + (long long)gy * p.X + gx;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        xt[c][(hy + 1) * TW + hx + 1] = advanced(n, c, nullptr, nullptr);
+    }
+  }
+  __syncthreads();
+
+  const float hdtg = (0.5f * dt) * p.gamma;
+  const float fact0 = 1.0f / (1.0f + hdtg);
+  const float fact1 = 1.0f - hdtg;
+  const float hdt = 0.5f * dt;
+  float l0[4];
+#pragma unroll
+  for (int L = 0; L < 4; ++L) l0[L] = vec_len(p.rest[L], 2);
+  float part[kNP];
+  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    const int ly = ly0 + k * kRowStep;
+    const int gy = gy0 + ly, gx = gx0 + lx;
+    if (gy >= p.Y || gx >= p.X) continue;
+    const long long n = base + (long long)gy * p.X + gx;
+    const int ctr = (ly + 1) * TW + lx + 1;
+    float f[C], vn[C];
+    node_force_tile2d<TW>(xt[0], xt[1], ctr, p, gx, gy, x_own[k][0], x_own[k][1], l0, f);
+    float a2 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float xv = x_own[k][c];
+      if (p.has_prev) f[c] = f[c] + prev_pull(xv, prev[c * p.N + n], p.neg_k0, cap);
+      const float a_old = FUSED ? a_own[k][c] : a_in[c * p.N + n];
+      const float v_old = FUSED ? v_own[k][c] : v_in[c * p.N + n];
+      vn[c] = fact0 * (v_old * fact1 + hdt * (a_old + f[c]));
+      a_out[c * p.N + n] = f[c];
+      if (FUSED) x_out[c * p.N + n] = xv;
+      a2 = a2 + f[c] * f[c];
+      v2 = v2 + vn[c] * vn[c];
+      if (p.fire) {
+        part[0] = part[0] + f[c] * vn[c];
+        part[1 + c] = part[1 + c] + xv;
+      }
+    }
+    if (p.fire) {
+      const float a_norm = sqrtf(a2) + 1e-6f;
+      const float v_norm = sqrtf(v2);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
+        part[4 + c] = part[4 + c] + vn[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) v_out[c * p.N + n] = vn[c];
+  }
+  if (!p.fire) return;
+  block_sum(part, 7, lds);
+  // Hand-off without cache fences (a release fence would write back the whole
+  // L2 of this XCD, once per workgroup): every partial is an 8-byte
+  // {epoch, value} granule stored write-through at agent scope, so the datum
+  // is its own flag; the ticket only elects the reducing workgroup.
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 7; ++i)
+      __hip_atomic_store(&partials[blockIdx.x * kNP + i],
+                         (static_cast<u64>(epoch) << 32) | __float_as_uint(part[i]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged before the ticket
+    s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT) ==
+             static_cast<int>(gridDim.x) - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float acc[kNP];
+  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
+  for (int r = threadIdx.x; r < static_cast<int>(gridDim.x); r += kBlock)
+    for (int i = 0; i < 7; ++i) {
+      u64 gr = 0;
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        gr = __hip_atomic_load(&partials[r * kNP + i], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (static_cast<unsigned>(gr >> 32) == epoch) break;
+      }
+      acc[i] = acc[i] + __uint_as_float(static_cast<unsigned>(gr));
+    }
+  block_sum(acc, 7, lds);
+  if (threadIdx.x == 0) {
+    Scalars in = *scal_in, o;
+    scalars_from_sums(in, acc, p, &o);
+    *scal_out = o;
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Applies the pending gate / drift of the last step and emits the per-block
 // kinetic-energy partials (mesh.py:492-497, 584-586).
 template <int C>
@@ -377,8 +663,10 @@ finish_kernel(float* __restrict__ x, float* __restrict__ v, MeshParams p,
   s.gate = 1.f;
   for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
   if (p.fire) {
-    if (pending) {
+    if (pending == 1) {
       update_scalars(*scal_in, partials, n_part_rows, p, lds, &s);
+    } else if (pending == 2) {
+      s = *scal_in;
     } else {
       s = *scal_in;
       s.gate = 1.f;
@@ -478,7 +766,6 @@ constexpr int kPartGran = 8;   // power, sum x[3], sum v[3], pad
 constexpr int kMaxWg = 256;
 constexpr int kSpinLimit = 1 << 21;
 
-typedef unsigned long long u64;
 
 template <int T>
 struct Tile {
@@ -562,15 +849,15 @@ __device__ __forceinline__ float wave_sum63(float v) {
 __device__ __forceinline__ void spring2(float d0, float d1, float l0, const int* dir,
                                         float neg_k, int prefer, float* f) {
   const float l = sqrtf(d0 * d0 + d1 * d1);
+  const float r = l0 / l;  // see spring<C>
   const float d[2] = {d0, d1};
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    float num = l0;
+    float t = r;
     if (prefer && dir[c] != 0) {
       const float sg = d[c] > 0.f ? 1.f : (d[c] < 0.f ? -1.f : 0.f);
-      num = l0 * (static_cast<float>(dir[c]) * sg);
+      t = r * (static_cast<float>(dir[c]) * sg);
     }
-    const float t = num / l;
     const float u = 1.0f - t;
     float v = (neg_k * u) * d[c];
     if (!isfinite(v)) v = 0.f;
@@ -1027,13 +1314,51 @@ struct MeshWorkspace {
   int* abort;          // persistent path: timeout flag
   size_t comm_bytes;
   float* prev_buf;     // native prev_fn: prev = target_mesh(x), [ncomp * N]
+  float* alt[3];       // tiled path: second (x, v, a) set, [ncomp * N] each
+  u64* tile_part;      // tiled path: [n_tiles * kNP] {epoch, value} granules
+  int* ticket;         // tiled path: last-workgroup counter
   size_t bytes;
 };
 
-MeshWorkspace carve(void* ws, size_t prev_floats = 0) {
+// Tile shape of the LDS-tiled 2-D integrator: 0 = not applicable, else TX.
+struct TilePlan {
+  int tx = 0, ty = 0, nty = 0, ntx = 0;
+  long long tiles = 0;
+};
+
+bool tiled_enabled() {
+  const char* e = getenv("SFM_MESH_TILED");
+  return !(e && e[0] == '0');
+}
+
+TilePlan plan_tiles(int ncomp, long long planes, int Y, int X) {
+  TilePlan best;
+  if (ncomp != 2 || !tiled_enabled() || X < 16 || Y < 4) return best;
+  const int shapes[2][2] = {{16, 64}, {32, 32}};
+  long long best_cells = 0;
+  for (const auto& sh : shapes) {
+    const int nty = (Y + sh[0] - 1) / sh[0], ntx = (X + sh[1] - 1) / sh[1];
+    const long long cells = (long long)nty * sh[0] * ntx * sh[1];
+    if (best.tx == 0 || cells < best_cells) {
+      best.ty = sh[0];
+      best.tx = sh[1];
+      best.nty = nty;
+      best.ntx = ntx;
+      best.tiles = planes * nty * ntx;
+      best_cells = cells;
+    }
+  }
+  if (best.tiles > 0x7fffffffLL / kNP) best = TilePlan();
+  return best;
+}
+
+MeshWorkspace carve(void* ws, size_t prev_floats, size_t alt_floats, long long tiles) {
   sfm::Carver c(ws);
   MeshWorkspace w;
   w.prev_buf = prev_floats ? c.take<float>(prev_floats) : nullptr;
+  for (int i = 0; i < 3; ++i) w.alt[i] = alt_floats ? c.take<float>(alt_floats) : nullptr;
+  w.tile_part = tiles ? c.take<u64>((size_t)tiles * kNP) : nullptr;
+  w.ticket = c.take<int>(4);
   w.scal = c.take<Scalars>(2);
   w.partials = c.take<float>(kMaxBlocks * kNP);
   w.stat_part = c.take<float>(kMaxBlocks * 2);
@@ -1046,16 +1371,22 @@ MeshWorkspace carve(void* ws, size_t prev_floats = 0) {
   return w;
 }
 
+MeshWorkspace carve_for(const SfmMeshDesc* d, void* ws, TilePlan* plan) {
+  const size_t n = (size_t)d->shape[0] * d->shape[1] * d->shape[2] * d->shape[3];
+  const TilePlan t = plan_tiles(d->ncomp, (long long)d->shape[0] * d->shape[1],
+                                d->shape[2], d->shape[3]);
+  if (plan) *plan = t;
+  const size_t cn = (size_t)d->ncomp * n;
+  return carve(ws, d->target ? cn : 0, (t.tx && !d->target) ? cn : 0, t.tiles);
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t sfm_mesh_workspace_bytes(const SfmMeshDesc* d) {
-  size_t prev_floats = 0;
-  if (d && d->target)
-    prev_floats = (size_t)d->ncomp * d->shape[0] * d->shape[1] * d->shape[2] *
-                  d->shape[3];
-  return carve(nullptr, prev_floats).bytes;
+  if (!d) return 0;
+  return carve_for(d, nullptr, nullptr).bytes;
 }
 
 int sfm_mesh_force(const SfmMeshDesc* d, float* out) {
@@ -1089,7 +1420,8 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   if (d->target && d->prev)
     return sfm::fail(SFM_ERR_INVALID,
                      "Only one of: \"prev\" and \"prev_fn\" can be specified.");
-  MeshWorkspace w = carve(d->workspace, d->target ? (size_t)p.ncomp * p.N : 0);
+  TilePlan tiles;
+  MeshWorkspace w = carve_for(d, d->workspace, &tiles);
   if (!d->workspace || d->workspace_bytes < w.bytes)
     return sfm::fail(SFM_ERR_WORKSPACE, "mesh workspace needs %zu bytes, got %zu",
                      w.bytes, d->workspace_bytes);
@@ -1197,21 +1529,74 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   SFM_MESH_DISPATCH(force_kernel, d->x, prev_ptr, d->a, p, cap0, p.has_prev);
 
   int cur = 0;
-  for (int it = 0; it < d->num_iters; ++it) {
-    const int pending = it > 0;
-    SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
-                      &w.scal[cur ^ 1], w.partials, grid, pending);
-    cur ^= 1;
-    if (d->target)
-      if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
-    sfm::prof_begin(sfm::kProfMesh, st);
-    SFM_MESH_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
-                      &w.scal[cur], cap0, w.partials);
-    sfm::prof_end(sfm::kProfMesh, st);
+  int finish_mode = d->num_iters > 0 ? 1 : 0;
+  if (tiles.tx && d->num_iters > 0) {
+    // LDS-tiled integrator (2-D): one launch per step, or advance + prev_fn +
+    // integrate when the spring targets depend on the advanced positions.
+    SFM_HIP_CHECK(hipMemsetAsync(w.ticket, 0, sizeof(int), st));
+    SFM_HIP_CHECK(hipMemsetAsync(w.tile_part, 0, (size_t)tiles.tiles * kNP * sizeof(u64), st));
+    float* bufs[2][3] = {{d->x, d->v, d->a}, {w.alt[0], w.alt[1], w.alt[2]}};
+    int in = 0;
+    const bool fused = !d->target;
+    const int tgrid = static_cast<int>(tiles.tiles);
+#define SFM_TILED(TY, TX, FUSED, XI, VI, AI, XO, VO, AO, PEND)                      \
+  hipLaunchKernelGGL((integrate_tiled2d_kernel<TY, TX, FUSED>), dim3(tgrid),        \
+                     dim3(kBlock), 0, st, XI, VI, AI, prev_ptr, XO, VO, AO, p,      \
+                     &w.scal[cur], &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket,   \
+                     static_cast<unsigned>(it + 1), PEND, tiles.nty, tiles.ntx)
+    for (int it = 0; it < d->num_iters; ++it) {
+      const int pending = it > 0;
+      if (fused) {
+        float** bi = bufs[in];
+        float** bo = bufs[in ^ 1];
+        sfm::prof_begin(sfm::kProfMesh, st);
+        if (tiles.tx == 64)
+          SFM_TILED(16, 64, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
+        else
+          SFM_TILED(32, 32, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
+        sfm::prof_end(sfm::kProfMesh, st);
+        SFM_LAUNCH_CHECK();
+        in ^= 1;
+        if (p.fire) cur ^= 1;
+      } else {
+        SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
+                          &w.scal[cur ^ 1], w.partials, grid, pending ? 2 : 0);
+        cur ^= 1;
+        if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
+        sfm::prof_begin(sfm::kProfMesh, st);
+        if (tiles.tx == 64)
+          SFM_TILED(16, 64, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
+        else
+          SFM_TILED(32, 32, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
+        sfm::prof_end(sfm::kProfMesh, st);
+        SFM_LAUNCH_CHECK();
+        if (p.fire) cur ^= 1;
+      }
+    }
+#undef SFM_TILED
+    if (in == 1) {
+      const size_t bytes = (size_t)p.ncomp * p.N * sizeof(float);
+      SFM_HIP_CHECK(hipMemcpyAsync(d->x, w.alt[0], bytes, hipMemcpyDeviceToDevice, st));
+      SFM_HIP_CHECK(hipMemcpyAsync(d->v, w.alt[1], bytes, hipMemcpyDeviceToDevice, st));
+      SFM_HIP_CHECK(hipMemcpyAsync(d->a, w.alt[2], bytes, hipMemcpyDeviceToDevice, st));
+    }
+    finish_mode = 2;
+  } else {
+    for (int it = 0; it < d->num_iters; ++it) {
+      const int pending = it > 0;
+      SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
+                        &w.scal[cur ^ 1], w.partials, grid, pending);
+      cur ^= 1;
+      if (d->target)
+        if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
+      sfm::prof_begin(sfm::kProfMesh, st);
+      SFM_MESH_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
+                        &w.scal[cur], cap0, w.partials);
+      sfm::prof_end(sfm::kProfMesh, st);
+    }
   }
-  const int pending = d->num_iters > 0;
   SFM_MESH_DISPATCH(finish_kernel, d->x, d->v, p, &w.scal[cur],
-                    &w.scal[cur ^ 1], w.partials, grid, pending, w.stat_part);
+                    &w.scal[cur ^ 1], w.partials, grid, finish_mode, w.stat_part);
   cur ^= 1;
 #undef SFM_MESH_DISPATCH
   hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(kBlock), 0, st, w.stat_part,

@@ -215,3 +215,80 @@ def test_error_behaviour(gpu):
   with pytest.raises(ValueError):
     mesh.elastic_mesh_3d(np.zeros((3, 4, 4, 4)), 0.1, 10.0,
                          links=((2, 0, 0),))
+
+
+def _with_env(env, fn):
+  import os
+  old = {k: os.environ.get(k) for k in env}
+  os.environ.update(env)
+  try:
+    return fn()
+  finally:
+    for k, v in old.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', ['fire', 'fire_drift', 'verlet', 'no_prev',
+                                     'wide'])
+def test_integrator_paths_agree(gpu, variant):
+  """Persistent, LDS-tiled and multi-launch integrators give the same chunk.
+
+  The three differ only in the order the per-step partial sums (FIRE power,
+  drift means) are added, so the trajectories agree to round-off; each is also
+  checked against the oracle.
+  """
+  from sofima_amd import mesh
+  rng = np.random.default_rng(5)
+  shape = (2, 3, 40, 70) if variant != 'wide' else (2, 1, 37, 300)
+  from scipy import ndimage
+  prev = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, 3, 3))
+  prev = (prev * 30).astype(np.float32)
+  prev[:, :, :2] = np.nan
+  prev[:, :, :, -3:] = np.nan
+  kw = dict(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(40, 40), num_iters=40,
+            max_iters=40, stop_v_max=1e-9, dt_max=1000, start_cap=0.01,
+            final_cap=10, prefer_orig_order=True)
+  if variant == 'fire_drift':
+    kw['remove_drift'] = True
+  if variant == 'verlet':
+    kw.update(fire=False, gamma=0.5, dt=0.05, start_cap=10.0)
+  cfg = mesh.IntegrationConfig(**kw)
+  x0 = (rng.standard_normal(shape) * 0.5).astype(np.float32)
+  pv = None if variant == 'no_prev' else prev
+  run = lambda: mesh.relax_mesh(x0.copy(), None if pv is None else pv.copy(), cfg)
+  res = {
+      'default': run(),
+      'tiled': _with_env({'SFM_MESH_PERSISTENT': '0'}, run),
+      'multi': _with_env({'SFM_MESH_PERSISTENT': '0', 'SFM_MESH_TILED': '0'}, run),
+  }
+  wx, we, wt = mesh_oracle.relax_mesh(x0.copy(), None if pv is None else pv.copy(),
+                                      cfg)
+  scale = np.abs(wx).max()
+  for name, (gx, ge, gt) in res.items():
+    assert gt == wt, name
+    np.testing.assert_allclose(np.array(gx), wx, atol=1e-3 * scale, err_msg=name)
+    np.testing.assert_allclose(ge, we, rtol=1e-2, err_msg=name)
+  for name in ('default', 'tiled'):
+    np.testing.assert_allclose(np.array(res[name][0]), np.array(res['multi'][0]),
+                               atol=2e-4 * scale, err_msg=name)
+
+
+@pytest.mark.gpu
+def test_montage_relaxation_tiled_equals_multi_launch(gpu, golden):
+  """prev_fn path: advance + target mesh + tiled integrate == multi-launch."""
+  import json
+  from sofima_amd import mesh, stitch_elastic
+  from tests.util import cfg_from
+  g = golden('montage')
+  cfg = cfg_from(json.loads(str(g['cfg'])), mesh.IntegrationConfig)
+  fn = stitch_elastic.TargetMeshFn(g['nbors'], g['fx'], g['fy'], tuple(g['stride']))
+  run = lambda: mesh.relax_mesh(g['x'], None, cfg, prev_fn=fn)
+  a = run()
+  b = _with_env({'SFM_MESH_TILED': '0'}, run)
+  assert a[2] == b[2] == int(g['t'])
+  np.testing.assert_allclose(np.array(a[0]), np.array(b[0]), atol=2e-3)
+  np.testing.assert_allclose(np.array(a[0]), g['relaxed'], atol=2e-3)
