@@ -178,6 +178,28 @@ typedef struct SfmComposeDesc {
 int sfm_compose_maps(const SfmComposeDesc* desc, float* out);
 
 /* ------------------------------------------------------------------------
+ * Flow-field clean-up, the step between flow estimation and mesh relaxation.
+ * Replaces flow_utils.clean_flow (flow_utils.py:37-78): invalidates (NaN)
+ * vectors with low peak sharpness / peak ratio, too large components, or a
+ * too large deviation from the 3 x 3 (x 3) median of the nan_to_num'ed field
+ * (scipy.ndimage.median_filter, mode "reflect").
+ * ---------------------------------------------------------------------- */
+typedef struct SfmCleanFlowDesc {
+  int32_t dim;                  /* 2 or 3 spatial dimensions                 */
+  int32_t channels;             /* dim .. dim + 2 input channels             */
+  int32_t shape[3];             /* z, y, x                                   */
+  float min_peak_ratio;
+  float min_peak_sharpness;
+  float max_magnitude;          /* <= 0: not applied                         */
+  float max_deviation;          /* <= 0: not applied                         */
+  const float* flow;            /* device [channels, z, y, x]                */
+  void* stream;
+} SfmCleanFlowDesc;
+
+/* out: device float [dim, z, y, x]. */
+int sfm_clean_flow(const SfmCleanFlowDesc* desc, float* out);
+
+/* ------------------------------------------------------------------------
  * Target mesh of an elastic tile montage.
  * Replaces stitch_elastic.compute_target_mesh (stitch_elastic.py:624-676,
  * with _update_mesh :573-620 and _apply_flow :456-570) vmapped over all

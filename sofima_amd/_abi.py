@@ -99,6 +99,20 @@ class SfmComposeDesc(C.Structure):
   ]
 
 
+class SfmCleanFlowDesc(C.Structure):
+  _fields_ = [
+      ('dim', i32),
+      ('channels', i32),
+      ('shape', i32 * 3),
+      ('min_peak_ratio', C.c_float),
+      ('min_peak_sharpness', C.c_float),
+      ('max_magnitude', C.c_float),
+      ('max_deviation', C.c_float),
+      ('flow', C.c_void_p),
+      ('stream', C.c_void_p),
+  ]
+
+
 class SfmTargetMeshDesc(C.Structure):
   _fields_ = [
       ('ncomp', i32),
@@ -178,6 +192,7 @@ SIGNATURES = {
     'sfm_peaks_workspace_bytes': (C.c_size_t, [C.POINTER(SfmPeaksDesc)]),
     'sfm_peaks': (C.c_int, [C.POINTER(SfmPeaksDesc), C.c_void_p]),
     'sfm_compose_maps': (C.c_int, [C.POINTER(SfmComposeDesc), C.c_void_p]),
+    'sfm_clean_flow': (C.c_int, [C.POINTER(SfmCleanFlowDesc), C.c_void_p]),
     'sfm_target_mesh': (C.c_int, [C.POINTER(SfmTargetMeshDesc), C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     'sfm_mesh_workspace_bytes': (C.c_size_t, [C.POINTER(SfmMeshDesc)]),

@@ -20,6 +20,7 @@ SOURCES = {
     'sfm_xcorr_mfma.hip': (['-DSFM_MFMA_TIMING']
                            if os.environ.get('SFM_MFMA_TIMING') else []),
     'sfm_maps.hip': ['-ffp-contract=off'],
+    'sfm_flowutils.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
           '-Wno-unused-result']

@@ -1,0 +1,132 @@
+// Flow-field clean-up on the device: the
+// quality filter that runs between flow estimation and mesh relaxation.
+//
+//   sfm_clean_flow  <->  flow_utils.clean_flow (flow_utils.py:37-78)
+//
+// One thread per vector.  The field is small (one vector per patch), so the
+// point of the kernel is that the flow can stay in HBM from the correlation
+// peaks to the mesh relaxation; it is bound by launch latency.
+#include "sfm_common.h"
+
+#include <hip/hip_runtime.h>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct CleanArgs {
+  const float* flow;
+  float* out;
+  int dim, channels;
+  int Z, Y, X;
+  float min_ratio, min_sharp, max_mag, max_dev;
+};
+
+// np.nan_to_num for float32: NaN -> 0, +-inf -> +-FLT_MAX.
+__device__ __forceinline__ float nan_to_num(float v) {
+  if (isnan(v)) return 0.f;
+  if (isinf(v)) return v > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  return v;
+}
+
+// scipy.ndimage "reflect" boundary (d c b a | a b c d | d c b a) for a
+// one-element overhang.
+__device__ __forceinline__ int reflect(int i, int n) {
+  if (i < 0) return -i - 1 < n ? -i - 1 : n - 1;
+  if (i >= n) return 2 * n - 1 - i >= 0 ? 2 * n - 1 - i : 0;
+  return i;
+}
+
+// Median of the (1|3) x 3 x 3 window of nan_to_num(comp) around (z, y, x).
+__device__ float window_median(const float* comp, const CleanArgs& a, int z, int y,
+                               int x) {
+  float w[27];
+  int n = 0;
+  const int zr = a.dim == 3 ? 1 : 0;
+  for (int dz = -zr; dz <= zr; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int zz = reflect(z + dz, a.Z), yy = reflect(y + dy, a.Y),
+                  xx = reflect(x + dx, a.X);
+        const float v = nan_to_num(comp[((long long)zz * a.Y + yy) * a.X + xx]);
+        int k = n++;  // insertion sort
+        while (k > 0 && w[k - 1] > v) {
+          w[k] = w[k - 1];
+          --k;
+        }
+        w[k] = v;
+      }
+  return w[n / 2];
+}
+
+__global__ void __launch_bounds__(kBlock) clean_flow_kernel(CleanArgs a) {
+  const long long n_vec = (long long)a.Z * a.Y * a.X;
+  const long long i = blockIdx.x * (long long)kBlock + threadIdx.x;
+  if (i >= n_vec) return;
+  const int x = static_cast<int>(i % a.X);
+  const int y = static_cast<int>((i / a.X) % a.Y);
+  const int z = static_cast<int>(i / ((long long)a.X * a.Y));
+  bool bad = false;
+  if (a.channels == a.dim + 2) {
+    // comparisons with NaN are false, as in NumPy
+    bad = fabsf(a.flow[a.dim * n_vec + i]) < a.min_sharp;
+    const float pr = fabsf(a.flow[(a.dim + 1) * n_vec + i]);
+    bad = bad || (pr > 0.f && pr < a.min_ratio);
+  }
+  float v[3];
+  bool any_nan = false;
+  for (int c = 0; c < a.dim; ++c) {
+    v[c] = a.flow[c * n_vec + i];
+    any_nan = any_nan || isnan(v[c]);
+  }
+  // np.max over the components propagates NaN, and NaN > t is false
+  if (!any_nan) {
+    if (a.max_mag > 0.f) {
+      float m = 0.f;
+      for (int c = 0; c < a.dim; ++c) m = fmaxf(m, fabsf(v[c]));
+      bad = bad || m > a.max_mag;
+    }
+    if (a.max_dev > 0.f) {
+      float m = 0.f;
+      for (int c = 0; c < a.dim; ++c) {
+        const float med = window_median(a.flow + c * n_vec, a, z, y, x);
+        m = fmaxf(m, fabsf(med - v[c]));
+      }
+      bad = bad || m > a.max_dev;
+    }
+  }
+  for (int c = 0; c < a.dim; ++c) a.out[c * n_vec + i] = bad ? NAN : v[c];
+}
+
+}  // namespace
+
+extern "C" int sfm_clean_flow(const SfmCleanFlowDesc* d, float* out) {
+  if (!d || !d->flow || !out)
+    return sfm::fail(SFM_ERR_INVALID, "clean_flow: NULL argument");
+  if (d->dim != 2 && d->dim != 3)
+    return sfm::fail(SFM_ERR_INVALID, "clean_flow: dim must be 2 or 3");
+  if (d->channels < d->dim || d->channels > d->dim + 2)
+    return sfm::fail(SFM_ERR_INVALID, "clean_flow: %d channels for dim %d",
+                     d->channels, d->dim);
+  for (int i = 0; i < 3; ++i)
+    if (d->shape[i] < 1) return sfm::fail(SFM_ERR_INVALID, "clean_flow: bad shape");
+  CleanArgs a;
+  a.flow = d->flow;
+  a.out = out;
+  a.dim = d->dim;
+  a.channels = d->channels;
+  a.Z = d->shape[0];
+  a.Y = d->shape[1];
+  a.X = d->shape[2];
+  a.min_ratio = d->min_peak_ratio;
+  a.min_sharp = d->min_peak_sharpness;
+  a.max_mag = d->max_magnitude;
+  a.max_dev = d->max_deviation;
+  const long long n = (long long)a.Z * a.Y * a.X;
+  const long long grid = (n + kBlock - 1) / kBlock;
+  if (grid > 0x7fffffffLL) return sfm::fail(SFM_ERR_INVALID, "clean_flow: too large");
+  hipLaunchKernelGGL(clean_flow_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock),
+                     0, static_cast<hipStream_t>(d->stream), a);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}

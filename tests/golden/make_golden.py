@@ -302,6 +302,49 @@ def gen_maps():
   save('compose_maps', **out)
 
 
+def gen_clean_flow():
+  """flow_utils.clean_flow (pure NumPy / SciPy in the reference)."""
+  from sofima import flow_utils as rfu
+  rng = np.random.default_rng(21)
+  out = {}
+  # 2-D: a smooth field with outliers, NaNs, infs, weak peaks
+  f = np.zeros((4, 2, 33, 41), np.float32)
+  yy, xx = np.mgrid[:33, :41]
+  f[0] = 3 * np.sin(xx / 7.0) + rng.standard_normal((2, 33, 41)) * 0.3
+  f[1] = 2 * np.cos(yy / 5.0) + rng.standard_normal((2, 33, 41)) * 0.3
+  f[2] = 1.0 + rng.random((2, 33, 41)) * 3
+  f[3] = rng.random((2, 33, 41)) * 3
+  f[3][rng.random((2, 33, 41)) < 0.2] = 0.0
+  for _ in range(40):
+    z, y, x = rng.integers(0, 2), rng.integers(0, 33), rng.integers(0, 41)
+    f[rng.integers(0, 2), z, y, x] += rng.choice([-1, 1]) * rng.uniform(4, 30)
+  f[:, 0, 0, 0] = np.nan
+  f[0, 1, 5, 5] = np.nan
+  f[1, 0, 32, 40] = np.inf
+  f[0, 1, 16, 0] = -np.inf
+  f[:2, 0, 10:14, 20:23] = np.nan
+  out['f2'] = f
+  out['p2'] = np.array([1.5, 1.6, 8.0, 2.5], np.float32)
+  out['c2'] = rfu.clean_flow(f.copy(), 1.5, 1.6, 8.0, 2.5)
+  out['c2_nomag'] = rfu.clean_flow(f.copy(), 1.5, 1.6, 0.0, 2.5)
+  out['c2_nodev'] = rfu.clean_flow(f.copy(), 1.5, 1.6, 8.0, 0.0)
+  out['c2_2ch'] = rfu.clean_flow(f[:2].copy(), 1.5, 1.6, 8.0, 2.5)
+  # 3-D: [5, z, y, x]
+  g = (rng.standard_normal((5, 6, 9, 11)) * 1.5).astype(np.float32)
+  g[3] = 1.0 + rng.random((6, 9, 11)) * 3
+  g[4] = rng.random((6, 9, 11)) * 3
+  for _ in range(25):
+    z, y, x = rng.integers(0, 6), rng.integers(0, 9), rng.integers(0, 11)
+    g[rng.integers(0, 3), z, y, x] += rng.choice([-1, 1]) * rng.uniform(5, 20)
+  g[:, 2, 3, 4] = np.nan
+  g[1, 5, 8, 10] = np.nan
+  out['f3'] = g
+  out['p3'] = np.array([1.2, 1.4, 9.0, 3.0], np.float32)
+  out['c3'] = rfu.clean_flow(g.copy(), 1.2, 1.4, 9.0, 3.0, dim=3)
+  out['c3_3ch'] = rfu.clean_flow(g[:3].copy(), 1.2, 1.4, 9.0, 3.0, dim=3)
+  save('clean_flow', **out)
+
+
 def gen_montage():
   """2 x 2 montage of 512^2 tiles through the reference's stitch_rigid /
   stitch_elastic chain: the inputs and outputs of
@@ -368,7 +411,7 @@ def gen_montage():
 
 
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'montage']
+  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'montage']
   if 'xcorr' in which:
     gen_xcorr_np()
   if 'peaks' in which:
@@ -379,5 +422,7 @@ if __name__ == '__main__':
     gen_mesh()
   if 'maps' in which:
     gen_maps()
+  if 'clean' in which:
+    gen_clean_flow()
   if 'montage' in which:
     gen_montage()

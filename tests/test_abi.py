@@ -57,6 +57,7 @@ def test_struct_layouts_match_header():
                      ('SfmProfile', _abi.SfmProfile),
                      ('SfmMaskCountDesc', _abi.SfmMaskCountDesc),
                      ('SfmComposeDesc', _abi.SfmComposeDesc),
+                     ('SfmCleanFlowDesc', _abi.SfmCleanFlowDesc),
                      ('SfmTargetMeshDesc', _abi.SfmTargetMeshDesc)):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,
                      re.S).group(1)

@@ -84,3 +84,50 @@ def test_montage_relaxation_golden(gpu, golden):
     mesh.relax_mesh(g['x'], g['x'], cfg, prev_fn=fn)
   with pytest.raises(NotImplementedError):
     mesh.relax_mesh(g['x'], None, cfg, prev_fn=lambda a: a)
+
+
+@pytest.mark.gpu
+def test_clean_flow_kat(gpu):
+  """tests/flow_utils_test.py:38-64 against the HIP kernel."""
+  from sofima_amd import flow_utils
+  from tests.test_reference_kats import _clean_flow_kat
+  flow, kw, expected = _clean_flow_kat()
+  np.testing.assert_array_equal(np.asarray(flow_utils.clean_flow(flow, **kw)), expected)
+
+
+@pytest.mark.gpu
+def test_clean_flow_golden(gpu, golden):
+  """sfm_clean_flow == reference clean_flow, bit for bit (values pass through)."""
+  from sofima_amd import flow_utils
+  g = golden('clean_flow')
+  p2 = [float(v) for v in g['p2']]
+  cases = [
+      (g['f2'], p2, 2, g['c2']),
+      (g['f2'], [p2[0], p2[1], 0.0, p2[3]], 2, g['c2_nomag']),
+      (g['f2'], [p2[0], p2[1], p2[2], 0.0], 2, g['c2_nodev']),
+      (g['f2'][:2], p2, 2, g['c2_2ch']),
+      (g['f3'], [float(v) for v in g['p3']], 3, g['c3']),
+      (g['f3'][:3], [float(v) for v in g['p3']], 3, g['c3_3ch']),
+  ]
+  for flow, p, dim, want in cases:
+    got = np.asarray(flow_utils.clean_flow(flow, *p, dim=dim))
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_clean_flow_on_flow_field_output(gpu):
+  """flow_field -> clean_flow stays consistent with the oracle chain."""
+  from oracle import flow_utils_oracle
+  from sofima_amd import flow_field, flow_utils
+  rng = np.random.default_rng(3)
+  from scipy import ndimage
+  base = ndimage.gaussian_filter(rng.standard_normal((400, 400)), 2.0)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  pre, post = base[8:392, 8:392], base[5:389, 11:395].copy()
+  post[100:160, 100:200] = 7  # featureless region: unreliable vectors
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  flow = calc.flow_field(pre, post, 64, 16, batch_size=256)[:, np.newaxis]
+  got = np.asarray(flow_utils.clean_flow(flow, 1.4, 1.6, 20, 4))
+  want = flow_utils_oracle.clean_flow(flow, 1.4, 1.6, 20, 4)
+  np.testing.assert_array_equal(got, want)
+  assert 0 < np.isnan(got[0]).sum() < got[0].size

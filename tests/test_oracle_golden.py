@@ -184,3 +184,22 @@ def test_target_mesh_and_montage_relax_vs_golden(golden):
   assert t == int(g['t'])
   np.testing.assert_allclose(xs, g['relaxed'], atol=2e-3)
   np.testing.assert_allclose(ek, g['ekin'], rtol=2e-2)
+
+
+def test_clean_flow_vs_golden(golden):
+  """flow_utils.clean_flow restatement == the reference's output, exactly."""
+  from oracle import flow_utils_oracle as fu
+  g = golden('clean_flow')
+  p2 = [float(v) for v in g['p2']]
+  np.testing.assert_array_equal(fu.clean_flow(g['f2'], *p2), g['c2'])
+  np.testing.assert_array_equal(
+      fu.clean_flow(g['f2'], p2[0], p2[1], 0.0, p2[3]), g['c2_nomag'])
+  np.testing.assert_array_equal(
+      fu.clean_flow(g['f2'], p2[0], p2[1], p2[2], 0.0), g['c2_nodev'])
+  np.testing.assert_array_equal(fu.clean_flow(g['f2'][:2], *p2), g['c2_2ch'])
+  p3 = [float(v) for v in g['p3']]
+  np.testing.assert_array_equal(fu.clean_flow(g['f3'], *p3, dim=3), g['c3'])
+  np.testing.assert_array_equal(fu.clean_flow(g['f3'][:3], *p3, dim=3), g['c3_3ch'])
+  # the filter does something in every variant
+  assert np.isnan(g['c2']).sum() > np.isnan(g['f2'][:2]).sum()
+  assert np.isnan(g['c3']).sum() > np.isnan(g['f3'][:3]).sum()

@@ -123,3 +123,32 @@ def test_force_and_consistency():
         mo.inplane_force(x[:2], 0.01, (40.0, 40.0), poo)[:2],
         mo.elastic_mesh_3d(x, 0.01, (40.0, 40.0, 14.0), poo, links=planar)[:2],
         atol=1e-5)
+
+
+def _clean_flow_kat():
+  """Inputs / expected output of tests/flow_utils_test.py:38-64."""
+  flow = np.zeros((4, 1, 50, 40))
+  flow[2, ...] = 2.0
+  flow[2, 0, 10, 20] = 1.2
+  flow[3, 0, 10, 22] = 1.2
+  flow[3, 0, 10, 24] = 1.6
+  flow[0, 0, 5, 4] = 12
+  flow[1, 0, 5, 6] = -14
+  flow[:, 0, 5, 10] = 2
+  flow[:, 0, 15, 10] = 7
+  expected = np.zeros((2, 1, 50, 40))
+  expected[:, 0, 5, 10] = 2
+  expected[:, 0, 15, 10] = np.nan  # median filter
+  expected[:, 0, 10, 20] = np.nan  # peak sharpness
+  expected[:, 0, 10, 22] = np.nan  # peak ratio
+  expected[:, 0, 5, 4] = np.nan  # magnitude
+  expected[:, 0, 5, 6] = np.nan  # magnitude
+  return flow, dict(min_peak_ratio=1.4, min_peak_sharpness=1.6, max_magnitude=10,
+                    max_deviation=5), expected
+
+
+def test_clean_flow():
+  """tests/flow_utils_test.py:38-64 against the oracle."""
+  from oracle import flow_utils_oracle
+  flow, kw, expected = _clean_flow_kat()
+  np.testing.assert_array_equal(flow_utils_oracle.clean_flow(flow, **kw), expected)
