@@ -17,8 +17,10 @@ SOURCES = {
     'sfm_core.hip': [],
     'sfm_mesh.hip': ['-ffp-contract=off'],
     'sfm_xcorr.hip': [],
-    'sfm_xcorr_mfma.hip': (['-DSFM_MFMA_TIMING']
-                           if os.environ.get('SFM_MFMA_TIMING') else []),
+    # SFM_MFMA_TIMING / SFM_MFMA_FLAGS: instrumentation and tuning experiments
+    'sfm_xcorr_mfma.hip': ((['-DSFM_MFMA_TIMING']
+                            if os.environ.get('SFM_MFMA_TIMING') else []) +
+                           os.environ.get('SFM_MFMA_FLAGS', '').split()),
     'sfm_maps.hip': ['-ffp-contract=off'],
     'sfm_flowutils.hip': ['-ffp-contract=off'],
 }

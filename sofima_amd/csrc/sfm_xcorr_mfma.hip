@@ -51,6 +51,13 @@
 // 176 / 208 keep the b128 / b32 fragment reads bank-conflict free.
 #include "sfm_common.h"
 
+#ifndef SFM_EPI_QG
+#define SFM_EPI_QG 2
+#endif
+#ifndef SFM_EPI_DEPTH
+#define SFM_EPI_DEPTH 1
+#endif
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -105,7 +112,7 @@ struct MfmaArgs {
   int a_bytes, b_bytes;
   int r_bytes;        // aux arrays / reduction scratch behind the patches
   // static tile schedule: tiles (dy tile indices) per wave
-  unsigned char tiles[kWaves][kMaxTilesPerWave];
+  int tiles[kWaves][kMaxTilesPerWave];  // ints: scalar loads from the kernarg segment
   int n_tiles[kWaves];
   // fused first-peak search (flow_field.py:238-262); see FusedPeaks
   int do_peaks;
@@ -482,52 +489,84 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
 // ---------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------
-// Loads one patch into LDS as int8 (pixel - centre), 16 bytes per work item,
-// from arbitrarily aligned global rows.
-__device__ __forceinline__ void stage_patch(
-    const unsigned char* __restrict__ img, long long img_bytes, int W, int y0,
-    int x0, int py, int px, int centre, unsigned char* __restrict__ dst,
-    int pitch, int row_off, int col_off, int n_chunks) {
-  const unsigned* words = reinterpret_cast<const unsigned*>(img);
-  const long long n_words = (img_bytes + 3) >> 2;
-  const unsigned cc = static_cast<unsigned>(centre) * 0x01010101u;
-  constexpr int kBatch = 4;  // items whose loads are in flight together
-  const int n_items = py * n_chunks;
-  for (int item0 = threadIdx.x; item0 < n_items; item0 += kThreads * kBatch) {
-    unsigned w[kBatch][5];
-    unsigned shv[kBatch];
+// Loads the pre and the post patch into LDS as int8 (pixel - centre), 16 bytes
+// per work item, from arbitrarily aligned global rows.  The aligned dword
+// loads of BOTH patches are issued before anything is consumed (kStageBatch
+// items per thread and plane cover a 160 x 160 patch in one round), so a
+// patch costs one global-memory round trip.
+struct StagePlane {
+  const unsigned char* img;
+  long long img_bytes;
+  int W, y0, x0, py, px, centre;
+  unsigned char* dst;
+  int pitch, row_off, col_off, n_chunks;
+};
+
+constexpr int kStageBatch = 7;
+
+// 16 image bytes at an arbitrary byte offset (global memory takes unaligned
+// dwordx4 loads); only the last bytes of the image need the guarded path.
+__device__ __forceinline__ v4i load_16_bytes(const unsigned char* img, long long off,
+                                             long long img_bytes) {
+  v4i v;
+  if (off + 16 <= img_bytes) {
+    __builtin_memcpy(&v, img + off, 16);
+  } else {
+    unsigned char t[16];
 #pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const int item = item0 + u * kThreads;
-      const int y = item / n_chunks, ch = item - y * n_chunks;
-      const long long off = (long long)(y0 + y) * W + x0 + ch * 16;
-      const long long w0 = off >> 2;
-      shv[u] = static_cast<unsigned>(off & 3);
+    for (int k = 0; k < 16; ++k) t[k] = off + k < img_bytes ? img[off + k] : 0;
+    __builtin_memcpy(&v, t, 16);
+  }
+  return v;
+}
+
+__device__ __forceinline__ void stage_patches(const StagePlane& p0, const StagePlane& p1) {
+  const StagePlane* pl[2] = {&p0, &p1};
+  const int n_items0 = p0.py * p0.n_chunks, n_items1 = p1.py * p1.n_chunks;
+  const int n_max = max(n_items0, n_items1);
+  for (int item0 = threadIdx.x; item0 < n_max; item0 += kThreads * kStageBatch) {
+    v4i w[2][kStageBatch];
 #pragma unroll
-      for (int k = 0; k < 5; ++k)
-        w[u][k] = item < n_items ? load_u32_guarded(words, w0 + k, n_words) : 0u;
+    for (int s = 0; s < 2; ++s) {
+      const StagePlane& p = *pl[s];
+      const int n_items = p.py * p.n_chunks;
+#pragma unroll
+      for (int u = 0; u < kStageBatch; ++u) {
+        const int item = item0 + u * kThreads;
+        const int y = item / p.n_chunks, ch = item - y * p.n_chunks;
+        const long long off = (long long)(p.y0 + y) * p.W + p.x0 + ch * 16;
+        w[s][u] = item < n_items ? load_16_bytes(p.img, off, p.img_bytes)
+                                 : v4i{0, 0, 0, 0};
+      }
     }
 #pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const int item = item0 + u * kThreads;
-      if (item >= n_items) break;
-      const int y = item / n_chunks, ch = item - y * n_chunks;
-      v4i out;
+    for (int s = 0; s < 2; ++s) {
+      const StagePlane& p = *pl[s];
+      const unsigned cc = static_cast<unsigned>(p.centre) * 0x01010101u;
+      const int n_items = p.py * p.n_chunks;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        unsigned v = __builtin_amdgcn_alignbyte(w[u][k + 1], w[u][k], shv[u]);
-        // bytewise v - centre (mod 256) == int8 value of pixel - centre
-        const unsigned H = 0x80808080u;
-        v = ((v | H) - (cc & ~H)) ^ ((v ^ ~cc) & H);
-        // zero bytes beyond the patch width
-        const int xb = ch * 16 + k * 4;
-        if (xb + 4 > px) {
-          const int keep = px - xb;  // < 4
-          v = keep <= 0 ? 0u : (v & (0xffffffffu >> (8 * (4 - keep))));
+      for (int u = 0; u < kStageBatch; ++u) {
+        const int item = item0 + u * kThreads;
+        if (item >= n_items) break;
+        const int y = item / p.n_chunks, ch = item - y * p.n_chunks;
+        v4i out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          unsigned v = static_cast<unsigned>(w[s][u][k]);
+          // bytewise v - centre (mod 256) == int8 value of pixel - centre
+          const unsigned H = 0x80808080u;
+          v = ((v | H) - (cc & ~H)) ^ ((v ^ ~cc) & H);
+          // zero bytes beyond the patch width
+          const int xb = ch * 16 + k * 4;
+          if (xb + 4 > p.px) {
+            const int keep = p.px - xb;  // < 4
+            v = keep <= 0 ? 0u : (v & (0xffffffffu >> (8 * (4 - keep))));
+          }
+          out[k] = static_cast<int>(v);
         }
-        out[k] = static_cast<int>(v);
+        *reinterpret_cast<v4i*>(p.dst + (p.row_off + y) * p.pitch + p.col_off + ch * 16) =
+            out;
       }
-      *reinterpret_cast<v4i*>(dst + (row_off + y) * pitch + col_off + ch * 16) = out;
     }
   }
 }
@@ -831,6 +870,28 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
 
 constexpr int kModeGeneral = 0, kModeSame = 1, kModeRaw = 2;
 
+// Wave-wide maximum of non-negative values on the DPP network (no LDS round
+// trips): row shifts inside each 16-lane row, then row broadcasts; the result
+// is read from lane 63 into a scalar.
+#define SFM_DPP_MAXF(x, ctrl, rmask, bc)                                            \
+  fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl,   \
+                                                      rmask, 0xf, bc)))
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  v = SFM_DPP_MAXF(v, 0x111, 0xf, true);   // row_shr:1
+  v = SFM_DPP_MAXF(v, 0x112, 0xf, true);   // row_shr:2
+  v = SFM_DPP_MAXF(v, 0x114, 0xf, true);   // row_shr:4
+  v = SFM_DPP_MAXF(v, 0x118, 0xf, true);   // row_shr:8
+  v = SFM_DPP_MAXF(v, 0x142, 0xa, false);  // row_bcast:15
+  v = SFM_DPP_MAXF(v, 0x143, 0xc, false);  // row_bcast:31
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// base[byte_off]: a 32-bit byte offset on a wave-uniform base selects the
+// scalar-base + VGPR-offset addressing mode (no 64-bit VALU address math).
+__device__ __forceinline__ float at_byte(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 // One workgroup per surface; v1[b] holds the surface maximum on entry.
 __global__ void __launch_bounds__(kThreads) mfma_first_peak_kernel(MfmaArgs a) {
   __shared__ float scratch[2 * kThreads];
@@ -850,7 +911,8 @@ __device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_ld
   __syncthreads();
   if (threadIdx.x == 0) *next_lds = gridDim.x + atomicAdd(a.work_counter, 1);
   __syncthreads();
-  return *next_lds;
+  // wave-uniform: keeps every per-patch base address in scalar registers
+  return __builtin_amdgcn_readfirstlane(*next_lds);
 }
 
 template <int NCA, int NCE, int MODE>
@@ -859,6 +921,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   constexpr bool RAW = MODE == kModeRaw;
   constexpr int NQ = NCA + NCE - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float touch_junk[kThreads];  // sink of the LDS-direct G touches
   unsigned char* A_lds = smem;
   unsigned char* B_lds = smem + a.a_bytes;
   float* R_lds = reinterpret_cast<float*>(smem + a.a_bytes + a.b_bytes);
@@ -884,7 +947,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 
 #ifdef SFM_MFMA_TIMING
   const long long wstart = wall_clock64();
-  long long tph[8] = {0,0,0,0,0,0,0,0}; long long tc = clock64(); int npat = 0;
+  long long tph[10] = {0,0,0,0,0,0,0,0,0,0}; long long tc = clock64(); int npat = 0;
 #define TICK(i) { long long tn = clock64(); tph[i] += tn - tc; tc = tn; }
 #else
 #define TICK(i)
@@ -909,6 +972,11 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     __syncthreads();  // previous patch fully consumed / zero fill done
     TICK(0)
     const PatchParams pp = a.pp[b];
+    // covers aux_n <= 192 and Py Px <= 32768 in registers; taller patches
+    // take the remainder loops below
+    constexpr int kAuxRegs = 3;
+    float auxv[kAuxRegs];
+    float const_a = 0.f, const_b = 0.f;
     if (RAW) {
       stage_plane(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], a.mask[0],
                   (long long)a.mshape[0][0] * a.mshape[0][1], a.mshape[0][1],
@@ -919,37 +987,86 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                   pp.my0[1], pp.mx0[1], Qy, Qx, pp.c[1], a.plane[1], B_lds, a.pb, 0,
                   a.ml, (Qx + 15) / 16);
     } else {
-      stage_patch(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], Py, Px,
-                  pp.c[0], A_lds, a.pa, kPadTop, 0, NCA);
-      stage_patch(a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
-                  pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16);
+      // Everything staging needs from global memory is requested before the
+      // first wait (the four 1-D correction arrays and the pixels of both
+      // patches): loads return in order, so staging costs one round trip.
+      if (SAME) {
+        const float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
+#pragma unroll
+        for (int k = 0; k < kAuxRegs; ++k) {
+          const int i = threadIdx.x + k * kThreads;
+          auxv[k] = i < 4 * a.aux_n ? aux[i] : 0.f;
+        }
+        const_a = aux[4 * a.aux_n + 0];
+        const_b = aux[4 * a.aux_n + 1];
+      }
+      const StagePlane sa = {a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], Py, Px,
+                             pp.c[0], A_lds, a.pa, kPadTop, 0, NCA};
+      const StagePlane sb = {a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
+                             pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16};
+      stage_patches(sa, sb);
+      TICK(8)
     }
     if (threadIdx.x == 0) {
       *pmax_lds = 0;  // float bits of max(surface, 0)
       *hot_lds = 0;
     }
-    float const_a = 0.f, const_b = 0.f;
     if (SAME) {
+#pragma unroll
+      for (int k = 0; k < kAuxRegs; ++k) {
+        const int i = threadIdx.x + k * kThreads;
+        if (i < 4 * a.aux_n) R_lds[i] = auxv[k];
+      }
       const float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
-      for (int i = threadIdx.x; i < 4 * a.aux_n; i += kThreads) R_lds[i] = aux[i];
-      const_a = aux[4 * a.aux_n + 0];
-      const_b = aux[4 * a.aux_n + 1];
-      // Pull this patch's correction table (written by the prep kernel, by now
-      // in HBM / Infinity Cache) into the XCD's L2: one touch per 64-byte line.
-      // The epilogue gathers then hit L2 instead of paying ~2 us each.
-      const float* gt = a.gtab + (long long)b * Py * Px;
-      float touch = 0.f;
-      for (int i = threadIdx.x * 16; i < Py * Px; i += kThreads * 16) touch += gt[i];
-      if (touch == 1.2345e-30f) R_lds[0] = touch;  // keeps the loads alive
+      for (int i = threadIdx.x + kAuxRegs * kThreads; i < 4 * a.aux_n; i += kThreads)
+        R_lds[i] = aux[i];
     }
+    TICK(9)
     __syncthreads();
 
     TICK(1)
+    const float mua = pp.mu[0], mub = pp.mu[1];
+    float muab = mua * mub;
+    asm volatile("" : "+v"(muab));  // every global load so far has been consumed
+#ifndef SFM_NO_TOUCH
+    if (SAME) {
+      // Pull this patch's correction table G (written by the prep kernel, by now
+      // in HBM / Infinity Cache) into this XCD's L2, one touch per 64-byte line.
+      // It is first needed by the epilogue of the first tile, a whole matrix
+      // loop away, so the touches use the LDS-direct load path into a junk
+      // area: no VGPR result, and nothing waits for them before that epilogue.
+      // (The lane offset is made opaque so that the per-touch addresses are
+      // scalar base + one VGPR instead of loop-invariant VGPRs that spill.)
+      // (Written as inline assembly: the compiler's global_load_lds builtin does
+      // not initialise M0, the LDS destination base, on this toolchain.  The
+      // asm loads are invisible to the compiler's vmcnt bookkeeping, which is
+      // safe because every counted wait that follows is for YOUNGER loads and
+      // the counter retires in order.)
+      const char* gt = reinterpret_cast<const char*>(a.gtab + (long long)b * Py * Px);
+      const unsigned junk_off = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+          (__attribute__((address_space(3))) float*)touch_junk));
+      constexpr int kTouches = (32768 / 16 + kThreads - 1) / kThreads;
+      // opaque per patch: otherwise the eight lane addresses are hoisted out of
+      // the patch loop as 16 VGPRs and spilled
+      unsigned lane_off;
+      asm volatile("v_lshlrev_b32 %0, 6, %1" : "=v"(lane_off) : "v"(threadIdx.x));
+#pragma unroll
+      for (int k = 0; k < kTouches; ++k) {
+        const int i = (threadIdx.x + k * kThreads) * 16;
+        if (i < Py * Px) {
+          const char* src = gt + (size_t)k * kThreads * 64 + lane_off;
+          asm volatile(
+              "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+              :
+              : "v"(src), "s"(junk_off)
+              : "m0", "memory");
+        }
+      }
+    }
+#endif
     const int* IA = (SAME || RAW) ? nullptr : a.integ[0] + b * a.integ_stride[0];
     const int* IB = (SAME || RAW) ? nullptr : a.integ[1] + b * a.integ_stride[1];
     const float* G = SAME ? a.gtab + (long long)b * Py * Px : nullptr;
-    const float mua = pp.mu[0], mub = pp.mu[1];
-    const float muab = mua * mub;
     float* surf = a.surface + b * a.s_stride;
 
     const int n_my_tiles = __builtin_amdgcn_readfirstlane(a.n_tiles[wave]);
@@ -1051,7 +1168,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         int grow[4];
         float ey[4], a_neg[4], a_pos[4], fny[4];
         bool sy[4];
-        float* rowp[4];
+        unsigned rowp[4];  // byte offsets into `surf` (scalar base + 32-bit offset)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ky_raw = 16 * p + 4 * g + r;
@@ -1065,23 +1182,35 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           a_neg[r] = ey[r] * rrowB[yv] + (sy[r] ? 0.f : const_b);
           a_pos[r] = ey[r] * rrowA[yv] + (sy[r] ? const_a : 0.f);
           fny[r] = ky_raw < Sy ? muab * static_cast<float>(Py - abs(dy)) : NAN;
-          rowp[r] = surf + ky_raw * a.sx_pitch + nn;
+          rowp[r] = 4u * static_cast<unsigned>(ky_raw * a.sx_pitch + nn);
         }
         const bool paired = Px == 16 * NCA;
-        constexpr int kQG = 2;
+        constexpr int kQG = SFM_EPI_QG;        // output columns per gather group
+        constexpr int kDepth = SFM_EPI_DEPTH;  // groups in flight ahead of the stores
+        constexpr int kSlots = kDepth + 1;
         constexpr int kGroups = (NCA + kQG - 1) / kQG;
         auto xv_of = [&](int q) {
           const int dx = min(16 * q + nn, Sx - 1) - (Px - 1);
           return dx >= 0 ? dx : dx + Px;
         };
+        // Column terms of all NQ output columns, read from LDS in one batch
+        // (one round trip instead of one per column while the other waves
+        // keep the LDS pipeline busy with matrix fragments).
+        float rca[NQ], rcb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int xv = xv_of(q);
+          rca[q] = rcolA[xv];
+          rcb[q] = rcolB[xv];
+        }
         auto emit = [&](int q, const float* gv) {
           const int kx = 16 * q + nn;
           const int dx = min(kx, Sx - 1) - (Px - 1);
           const bool sx = dx >= 0;
           const int xv = sx ? dx : dx + Px;
           const float ex = sx ? -1.f : 1.f;
-          const float b_pos = ex * rcolA[xv];  // sy = 1
-          const float b_neg = ex * rcolB[xv];  // sy = 0
+          const float b_pos = ex * rca[q];  // sy = 1
+          const float b_neg = ex * rcb[q];  // sy = 0
           const float fnx = (q < NQ - 1 || kx < Sx)
                                 ? static_cast<float>(Px - abs(dx)) : NAN;
 #pragma unroll
@@ -1090,13 +1219,15 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             corr += sy[r] ? b_pos : b_neg;
             corr = fmaf(fny[r], fnx, corr);
             const float v = static_cast<float>(acc[q][r]) + corr;
-            __builtin_nontemporal_store(v, rowp[r] + 16 * q);
+            __builtin_nontemporal_store(
+                v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
+                                            (static_cast<size_t>(rowp[r]) + 64u * q)));
             tmax = fmaxf(tmax, v);
             acc[q][r] = __float_as_int(v);
           }
         };
         // gbuf[slot][u][0] = G for column q, [1] = G for column q + NCA
-        float gbuf[2][kQG][2][4];
+        float gbuf[kSlots][kQG][2][4];
         auto fetch = [&](int grp, int slot) {
 #pragma unroll
           for (int u = 0; u < kQG; ++u) {
@@ -1104,32 +1235,34 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             if (q >= NCA) break;
             const int x0 = xv_of(q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gbuf[slot][u][0][r] = G[grow[r] + x0];
+            for (int r = 0; r < 4; ++r) gbuf[slot][u][0][r] = at_byte(G, 4u * static_cast<unsigned>(grow[r] + x0));
             // Px == 16 NCA: column q + NCA reads the same table entries (the
             // copy is taken at use time; copying here would wait for the loads)
             if (q + NCA < NQ && !paired) {
               const int x1 = xv_of(q + NCA);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) gbuf[slot][u][1][r] = G[grow[r] + x1];
+              for (int r = 0; r < 4; ++r) gbuf[slot][u][1][r] = at_byte(G, 4u * static_cast<unsigned>(grow[r] + x1));
             }
           }
         };
-        fetch(0, 0);
+#pragma unroll
+        for (int grp = 0; grp < kDepth; ++grp)
+          if (grp < kGroups) fetch(grp, grp % kSlots);
 #pragma unroll
         for (int grp = 0; grp < kGroups; ++grp) {
           __builtin_amdgcn_sched_barrier(0);
-          if (grp + 1 < kGroups) fetch(grp + 1, (grp + 1) & 1);
+          if (grp + kDepth < kGroups) fetch(grp + kDepth, (grp + kDepth) % kSlots);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < kQG; ++u) {
             const int q = grp * kQG + u;
             if (q >= NCA) break;
-            emit(q, gbuf[grp & 1][u][0]);
+            emit(q, gbuf[grp % kSlots][u][0]);
             if (q + NCA < NQ) {
               float g1[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                g1[r] = paired ? gbuf[grp & 1][u][0][r] : gbuf[grp & 1][u][1][r];
+                g1[r] = paired ? gbuf[grp % kSlots][u][0][r] : gbuf[grp % kSlots][u][1][r];
               emit(q + NCA, g1);
             }
           }
@@ -1174,15 +1307,17 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       }
       TICK(3)
       if (a.do_peaks) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, d, 64));
-        // non-negative floats order like their bit patterns
-        if (lane == 0 && tmax > 0.f) atomicMax(pmax_lds, __float_as_int(tmax));
+        tmax = wave_max_nonneg(tmax);
+        // non-negative floats order like their bit patterns; the atomic hands
+        // back the running maximum of the tiles finished so far
+        int prev_bits = 0;
+        if (lane == 0) prev_bits = atomicMax(pmax_lds, __float_as_int(tmax));
+        prev_bits = __builtin_amdgcn_readfirstlane(prev_bits);
         // Hot list: every element above threshold_rel * (running maximum) can
         // still turn out to be a peak; the final filter runs when the surface
         // is complete.  The running maximum never exceeds the final one, so
         // nothing that matters is dropped.
-        const float mrun = fmaxf(tmax, __int_as_float(*pmax_lds));
+        const float mrun = fmaxf(tmax, __int_as_float(prev_bits));
         const float thr_t = a.threshold_rel * mrun;
         float* hv = a.hot_val + (long long)b * a.hot_cap;
         int* hi = a.hot_idx + (long long)b * a.hot_cap;
@@ -1228,8 +1363,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   if ((blockIdx.x == 7 || blockIdx.x == 300) && lane == 0 && wave == 0)
     printf("wg %d wall %lld (100MHz ticks) start %lld\n", blockIdx.x, (long long)(wall_clock64() - wstart), wstart % 100000000);
   if (blockIdx.x == 7 && lane == 0)
-    printf("wave %d patches %d: sync %lld stage %lld mfma %lld epi %lld hot %lld tail %lld peaks %lld\n",
-           wave, npat, tph[0] / npat, tph[1] / npat, tph[2] / npat, tph[3] / npat,
+    printf("wave %d patches %d: sync %lld pix %lld aux+touch %lld stagesync %lld mfma %lld epi %lld hot %lld tail %lld peaks %lld\n",
+           wave, npat, tph[0] / npat, tph[8] / npat, tph[9] / npat, tph[1] / npat, tph[2] / npat, tph[3] / npat,
            tph[4] / npat, tph[5] / npat, tph[6] / npat);
 #endif
 }
@@ -1422,7 +1557,7 @@ int fill_common(const SfmXcorrDesc* d, const Layout& l, MfmaArgs* ap) {
       if (load[k] < load[best]) best = k;
     if (a.n_tiles[best] >= kMaxTilesPerWave)
       return sfm::fail(SFM_ERR_INVALID, "too many dy tiles");
-    a.tiles[best][a.n_tiles[best]++] = static_cast<unsigned char>(t.second);
+    a.tiles[best][a.n_tiles[best]++] = t.second;
     load[best] += t.first + 1;  // + epilogue
   }
   return SFM_OK;
