@@ -1360,8 +1360,15 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     TICK(6)
   }
 #ifdef SFM_MFMA_TIMING
-  if ((blockIdx.x == 7 || blockIdx.x == 300) && lane == 0 && wave == 0)
-    printf("wg %d wall %lld (100MHz ticks) start %lld\n", blockIdx.x, (long long)(wall_clock64() - wstart), wstart % 100000000);
+  if (lane == 0 && wave == 0) {
+    // HW_REG_HW_ID (4): [11:8] CU, [12] SH, [15:13] SE; HW_REG_XCC_ID (20): [3:0]
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    printf("WG %d xcc %u se %u cu %u patches %d wall %lld mfma %lld epi %lld\n", blockIdx.x,
+           xcc & 15, (hw >> 13) & 7, (hw >> 8) & 15, npat,
+           (long long)(wall_clock64() - wstart), tph[2] / (npat ? npat : 1),
+           tph[3] / (npat ? npat : 1));
+  }
   if (blockIdx.x == 7 && lane == 0)
     printf("wave %d patches %d: sync %lld pix %lld aux+touch %lld stagesync %lld mfma %lld epi %lld hot %lld tail %lld peaks %lld\n",
            wave, npat, tph[0] / npat, tph[8] / npat, tph[9] / npat, tph[1] / npat, tph[2] / npat, tph[3] / npat,

@@ -166,6 +166,17 @@ def _make_desc(res: _Resident, patch_size, post_patch_size, mean, min_distance,
 
 # Patches per C call (a multiple of the reference batch is used).
 LAUNCH_PATCHES = 4096
+# Alternate consecutive calls between two streams (tail filling of the
+# persistent correlation kernel by the next call's prep kernel).
+OVERLAP_CALLS = False  # measured gain ~1 %: opt-in
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev) -> torch.cuda.Stream:
+  key = torch.device(dev).index
+  if key not in _SIDE_STREAMS:
+    _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+  return _SIDE_STREAMS[key]
 
 
 def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray,
@@ -192,20 +203,36 @@ def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray
   need = lib.sfm_xcorr_workspace_bytes(C.byref(desc))
   if need == 0:
     _abi.check(-1)
-  ws = _dev.workspace(need, res.dev)
-  desc.workspace = ws.data_ptr()
-  desc.workspace_bytes = ws.numel()
   row_bytes = batch_size * nd * 4
   it = iter(range(n_batches) if progress_fn is None else progress_fn)
-  for bi in range(0, n_batches, per_call):
+  # Consecutive calls alternate between the current stream and a side stream
+  # (each with its own workspace): the hardware then fills the tail of one
+  # call's correlation kernel -- workgroups retiring one by one -- with the
+  # prep kernel and the first workgroups of the next call.
+  n_calls = (n_batches + per_call - 1) // per_call
+  main = torch.cuda.current_stream(res.dev)
+  lanes = [(main, _dev.workspace(need, res.dev))]
+  if n_calls > 1 and OVERLAP_CALLS:
+    side = _side_stream(res.dev)
+    side.wait_stream(main)
+    lanes.append((side, _dev.workspace(need, res.dev)))
+  for ci, bi in enumerate(range(0, n_batches, per_call)):
+    stream, ws = lanes[ci % len(lanes)]
     nb = min(per_call, n_batches - bi)
     desc.batch = nb * batch_size
+    desc.workspace = ws.data_ptr()
+    desc.workspace_bytes = ws.numel()
+    desc.stream = stream.cuda_stream
     desc.pre_starts = starts.data_ptr() + bi * row_bytes
     desc.post_starts = starts.data_ptr() + (n_batches + bi) * row_bytes
     out_ptr = peaks.data_ptr() + bi * batch_size * (nd + 2) * 4
     _abi.check(lib.sfm_xcorr_peaks(C.byref(desc), out_ptr))
     for _ in range(nb):
       next(it, None)
+  for stream, ws in lanes[1:]:
+    main.wait_stream(stream)
+    ws.record_stream(stream)
+  desc.stream = main.cuda_stream
   return peaks.cpu().numpy()
 
 
