@@ -224,10 +224,12 @@ def main():
       for name, v in pmc.items():
         if 'xcorr_mfma_kernel<10, 11,' in name and size == 8192:
           roof['traffic'] = v['hbm_bytes_per_launch']
+          alg = (2 * 160 * 160 + 4 * 160 * 160 + 4 * 320 * 320) * patches_per_launch
           roof['traffic_note'] = (
-              'bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, '
-              'separate --pmc passes; algorithmic HBM bytes per launch = patches '
-              '52 MB + G tables 103 MB + surface 414 MB = 570 MB')
+              'bytes per launch (%d patches), FETCH_SIZE x2 (gfx950 correction) + '
+              'WRITE_SIZE, separate --pmc passes of this bench; algorithmic HBM '
+              'bytes per launch = patches 51 KB + G table 102 KB + padded surface '
+              '410 KB per patch = %.2f GB' % (round(patches_per_launch), alg / 1e9))
     except (OSError, ValueError):
       pass
 
