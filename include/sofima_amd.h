@@ -47,6 +47,7 @@ extern "C" {
 #define SFM_XCORR_AUTO 0
 #define SFM_XCORR_DIRECT 1    /* f32 shift-by-shift kernel, any dtype/dim/mask */
 #define SFM_XCORR_MFMA_I8 2   /* int8 MFMA Toeplitz kernel                   */
+#define SFM_XCORR_FFT 3       /* zero-padded rFFT form (3-D / large patches)  */
 
 int sfm_version(void);
 const char* sfm_last_error(void);

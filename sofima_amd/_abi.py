@@ -21,6 +21,7 @@ DTYPE_F32 = 1
 XCORR_AUTO = 0
 XCORR_DIRECT = 1
 XCORR_MFMA_I8 = 2
+XCORR_FFT = 3
 MAX_LINKS = 13
 
 i32 = C.c_int32

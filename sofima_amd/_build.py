@@ -17,6 +17,7 @@ SOURCES = {
     'sfm_core.hip': [],
     'sfm_mesh.hip': ['-ffp-contract=off'],
     'sfm_xcorr.hip': [],
+    'sfm_xcorr_fft.hip': [],
     # SFM_MFMA_TIMING / SFM_MFMA_FLAGS: instrumentation and tuning experiments
     'sfm_xcorr_mfma.hip': ((['-DSFM_MFMA_TIMING']
                             if os.environ.get('SFM_MFMA_TIMING') else []) +
@@ -63,8 +64,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
       subprocess.run(cmd, check=True)
       relink = True
   if relink or _stale(LIB_PATH, objs):
+    # hipFFT serves the FFT form of the correlation (3-D / large patches)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH
-           ] + objs
+           ] + objs + ['-L/opt/rocm/lib', '-lhipfft', '-Wl,-rpath,/opt/rocm/lib']
     if verbose:
       print(' '.join(cmd))
     subprocess.run(cmd, check=True)

@@ -31,6 +31,12 @@ size_t mfma_i8_workspace_bytes(const SfmXcorrDesc* d);
 int mfma_i8_surface(const SfmXcorrDesc* d, void* ws, float* surface,
                     const FusedPeaks* fused);
 void mfma_i8_padded_dims(const SfmXcorrDesc* d, int* rows, int* pitch);
+// sfm_xcorr_fft.hip
+bool fft_preferred(const SfmXcorrDesc* d);
+size_t fft_workspace_bytes(const SfmXcorrDesc* d);
+int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
+                  const float* va, const float* vb, float* surface, float* den,
+                  float* ov, unsigned int* maxima, void* ws);
 // Masked correlation: padded numerator / denominator / overlap + batch maxima.
 int mfma_i8_masked(const SfmXcorrDesc* d, void* ws, float* num, float* den,
                    float* ov, unsigned int* maxima);
@@ -309,6 +315,8 @@ struct PeakArgs {
   unsigned int* bitmap;    // [n_groups, bitmap_words]
   int group;               // rows per coupling group
   int bitmap_words;
+  unsigned int* smax;        // [B] ordered bits of the surface maximum (large surfaces)
+  unsigned long long* best;  // [B] packed (value, index) arg-max (large surfaces)
   float* out;              // [B, nd + 2]
 };
 
@@ -365,11 +373,11 @@ __device__ bool is_window_max(const float* s, const PeakArgs& p, int z, int y,
 }
 
 __device__ float surface_max(const float* s, const PeakArgs& p, float* lv,
-                             int* li) {
+                             int* li, int r0 = 0, int r1 = -1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rows = p.S[0] * p.S[1];
+  const int rows = r1 < 0 ? p.S[0] * p.S[1] : r1;
   float mx = -INFINITY;
-  for (int r = wave; r < rows; r += kBlock / 64) {
+  for (int r = r0 + wave; r < rows; r += kBlock / 64) {
     const float* row = s + (long long)r * p.pitch;
     for (int x = lane; x < p.S[2]; x += 64) mx = fmaxf(mx, row[x]);
   }
@@ -380,10 +388,11 @@ __device__ float surface_max(const float* s, const PeakArgs& p, float* lv,
 
 // Calls fn(flat_index, value) for every peak of the surface.
 template <typename F>
-__device__ void for_each_peak(const float* s, const PeakArgs& p, float thr, F fn) {
+__device__ void for_each_peak(const float* s, const PeakArgs& p, float thr, F fn,
+                              int r0 = 0, int r1 = -1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rows = p.S[0] * p.S[1];
-  for (int r = wave; r < rows; r += kBlock / 64) {
+  const int rows = r1 < 0 ? p.S[0] * p.S[1] : r1;
+  for (int r = r0 + wave; r < rows; r += kBlock / 64) {
     const int z = r / p.S[1], y = r - z * p.S[1];
     const float* row = s + (long long)r * p.pitch;
     for (int x = lane; x < p.S[2]; x += 64) {
@@ -423,6 +432,75 @@ __global__ void __launch_bounds__(kBlock) peaks_first_kernel(PeakArgs p) {
     atomicOr(&p.bitmap[(long long)(b / p.group) * p.bitmap_words + (i1 >> 5)],
              1u << (i1 & 31));
   }
+}
+
+// ---- first pass over LARGE surfaces (3-D, whole-overlap patches): several
+// workgroups per surface.  Floats are ordered through a monotonic uint map so
+// that the surface maximum and the (value, lowest index) arg-max can be merged
+// with integer atomics; the result is identical to peaks_first_kernel.
+__device__ __forceinline__ unsigned ord_bits(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_float(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+__device__ __forceinline__ void chunk_rows(const PeakArgs& p, int* r0, int* r1) {
+  const int rows = p.S[0] * p.S[1];
+  const int per = (rows + gridDim.x - 1) / gridDim.x;
+  *r0 = min(rows, static_cast<int>(blockIdx.x) * per);
+  *r1 = min(rows, *r0 + per);
+}
+
+__global__ void __launch_bounds__(kBlock) peaks_max_kernel(PeakArgs p) {
+  __shared__ float lv[kBlock];
+  __shared__ int li[kBlock];
+  const int b = blockIdx.y;
+  int r0, r1;
+  chunk_rows(p, &r0, &r1);
+  const float mx = surface_max(p.surf + b * p.bstride, p, lv, li, r0, r1);
+  if (threadIdx.x == 0 && r1 > r0) atomicMax(&p.smax[b], ord_bits(mx));
+}
+
+__global__ void __launch_bounds__(kBlock) peaks_scan_kernel(PeakArgs p) {
+  __shared__ float lv[kBlock];
+  __shared__ int li[kBlock];
+  const int b = blockIdx.y;
+  const float* s = p.surf + b * p.bstride;
+  int r0, r1;
+  chunk_rows(p, &r0, &r1);
+  const float thr = p.threshold_rel * ord_float(p.smax[b]);
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for_each_peak(s, p, thr, [&](int i, float v) {
+    if (better(v, i, bv, bi)) {
+      bv = v;
+      bi = i;
+    }
+    const int slot = atomicAdd(&p.cand_count[b], 1);
+    if (slot < kCandCap) {
+      p.cand_val[(long long)b * kCandCap + slot] = v;
+      p.cand_idx[(long long)b * kCandCap + slot] = i;
+    }
+    if (i == 0) p.zero_is_peak[b] = 1;
+  }, r0, r1);
+  block_argmax(&bv, &bi, lv, li);
+  if (threadIdx.x == 0 && bv != -INFINITY)
+    atomicMax(&p.best[b], (static_cast<unsigned long long>(ord_bits(bv)) << 32) |
+                              (0xffffffffu - static_cast<unsigned>(bi)));
+}
+
+__global__ void __launch_bounds__(kBlock) peaks_first_finish_kernel(PeakArgs p) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= p.batch) return;
+  const unsigned long long k = p.best[b];
+  const float bv = k ? ord_float(static_cast<unsigned>(k >> 32)) : -INFINITY;
+  const int i1 = k ? static_cast<int>(0xffffffffu - static_cast<unsigned>(k)) : 0;
+  p.idx1[b] = i1;
+  p.v1[b] = bv;
+  atomicOr(&p.bitmap[(long long)(b / p.group) * p.bitmap_words + (i1 >> 5)],
+           1u << (i1 & 31));
 }
 
 __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
@@ -534,6 +612,8 @@ struct PeakWs {
   int* cand_idx;
   unsigned int* bitmap;
   int group, bitmap_words;
+  unsigned int* smax;
+  unsigned long long* best;
   int* hot_count;      // fused MFMA path only
   float* hot_val;
   int* hot_idx;
@@ -556,6 +636,8 @@ PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn, bool hot = false,
   w.zero_is_peak = c.take<int>(batch);
   w.cand_count = c.take<int>(batch);
   w.hot_count = c.take<int>(batch);
+  w.smax = c.take<unsigned int>(batch);
+  w.best = c.take<unsigned long long>(batch);
   w.bitmap = c.take<unsigned int>(
       (size_t)((batch + w.group - 1) / w.group) * w.bitmap_words);
   w.zero_from = z0;
@@ -592,10 +674,23 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
   p.bitmap = w.bitmap;
   p.group = w.group;
   p.bitmap_words = w.bitmap_words;
+  p.smax = w.smax;
+  p.best = w.best;
   p.out = out;
   if (!first_pass_done) {
     SFM_HIP_CHECK(hipMemsetAsync(ws_base + w.zero_from, 0, w.zero_bytes, st));
-    hipLaunchKernelGGL(peaks_first_kernel, dim3(batch), dim3(kBlock), 0, st, p);
+    if (sn >= (1LL << 18)) {
+      // large surfaces: ~32 K elements per workgroup
+      const long long rows = (long long)S[0] * S[1];
+      const int chunks = static_cast<int>(std::min<long long>(
+          std::min<long long>(rows, 1024), std::max<long long>(1, sn >> 15)));
+      hipLaunchKernelGGL(peaks_max_kernel, dim3(chunks, batch), dim3(kBlock), 0, st, p);
+      hipLaunchKernelGGL(peaks_scan_kernel, dim3(chunks, batch), dim3(kBlock), 0, st, p);
+      hipLaunchKernelGGL(peaks_first_finish_kernel, dim3((batch + kBlock - 1) / kBlock),
+                         dim3(kBlock), 0, st, p);
+    } else {
+      hipLaunchKernelGGL(peaks_first_kernel, dim3(batch), dim3(kBlock), 0, st, p);
+    }
     SFM_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(peaks_second_kernel, dim3(batch), dim3(kBlock), 0, st, p);
@@ -610,6 +705,7 @@ struct XcorrWs {
   float *a0, *b0, *va, *vb, *surface, *den, *ov;
   unsigned int* maxima;
   void* mfma;
+  void* fft;
   PeakWs peaks;
   int srows, spitch;  // layout of `surface`: [B, srows, spitch]
   size_t bytes;
@@ -618,8 +714,16 @@ struct XcorrWs {
 bool is_masked(const SfmXcorrDesc* d) { return d->pre_mask || d->post_mask; }
 
 bool use_mfma(const SfmXcorrDesc* d) {
-  if (d->method == SFM_XCORR_DIRECT) return false;
+  if (d->method == SFM_XCORR_DIRECT || d->method == SFM_XCORR_FFT) return false;
   return sfm::mfma_i8_eligible(d);
+}
+
+// FFT form: on request, or automatically for the patches the matrix-core
+// kernel does not take once they are large enough (3-D, float, wide).
+bool use_fft(const SfmXcorrDesc* d) {
+  if (d->method == SFM_XCORR_FFT) return true;
+  if (d->method != SFM_XCORR_AUTO) return false;
+  return !sfm::mfma_i8_eligible(d) && sfm::fft_preferred(d);
 }
 
 XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
@@ -649,6 +753,7 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
       w.ov = c.take<float>(B * g.Sn);
       w.maxima = c.take<unsigned int>(2);
     }
+    if (use_fft(d)) w.fft = c.take<char>(sfm::fft_workspace_bytes(d));
   }
   w.srows = g.S[0] * g.S[1];
   w.spitch = g.S[2];
@@ -672,6 +777,8 @@ int check_desc(const SfmXcorrDesc* d) {
     return sfm::fail(SFM_ERR_INVALID, "image / starts pointers must be set");
   if (d->dtype != SFM_DTYPE_U8 && d->dtype != SFM_DTYPE_F32)
     return sfm::fail(SFM_ERR_INVALID, "unsupported dtype tag %d", d->dtype);
+  if (d->method < SFM_XCORR_AUTO || d->method > SFM_XCORR_FFT)
+    return sfm::fail(SFM_ERR_INVALID, "unknown method %d", d->method);
   if (d->method == SFM_XCORR_MFMA_I8 && !sfm::mfma_i8_eligible(d))
     return sfm::fail(SFM_ERR_INVALID,
                      "MFMA_I8 needs uint8 2-D images and patches up to 160 wide");
@@ -738,6 +845,23 @@ int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
   if (gz > 65535LL * 32768)
     return sfm::fail(SFM_ERR_INVALID, "batch * S_z too large");
   dim3 grid((g.S[2] + 63) / 64, (g.S[1] + 3) / 4, (unsigned)gz);
+  if (use_fft(d)) {
+    if (masked) SFM_HIP_CHECK(hipMemsetAsync(w.maxima, 0, 2 * sizeof(unsigned int), st));
+    sfm::prof_begin(sfm::kProfXcorr, st);
+    const int rc = sfm::fft_correlate(d, w.a0, w.b0, w.va, w.vb, surface, w.den, w.ov,
+                                      w.maxima, w.fft);
+    sfm::prof_end(sfm::kProfXcorr, st);
+    if (rc) return rc;
+    if (masked) {
+      const long long n = (long long)d->batch * g.Sn;
+      const int fg = (int)((n + kBlock - 1) / kBlock > 4096 ? 4096
+                                                             : (n + kBlock - 1) / kBlock);
+      hipLaunchKernelGGL(masked_finalize_kernel, dim3(fg), dim3(kBlock), 0, st,
+                         surface, w.den, w.ov, w.maxima, n);
+      SFM_LAUNCH_CHECK();
+    }
+    return SFM_OK;
+  }
   if (masked) {
     SFM_HIP_CHECK(hipMemsetAsync(w.maxima, 0, 2 * sizeof(unsigned int), st));
     hipLaunchKernelGGL(corr_direct_kernel<true>, grid, dim3(kBlock), 0, st, c);

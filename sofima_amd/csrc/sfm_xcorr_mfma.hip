@@ -1055,11 +1055,13 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         const int i = (threadIdx.x + k * kThreads) * 16;
         if (i < Py * Px) {
           const char* src = gt + (size_t)k * kThreads * 64 + lane_off;
+          unsigned saved_m0;  // M0 is the LDS base of the load; put it back
           asm volatile(
-              "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-              :
+              "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+              "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+              : "=&s"(saved_m0)
               : "v"(src), "s"(junk_off)
-              : "m0", "memory");
+              : "memory");
         }
       }
     }

@@ -394,3 +394,94 @@ def test_many_batches_per_call_equal_batch_by_batch(gpu, monkeypatch, method,
   assert one.shape[1] * one.shape[2] > 37 * 6
   np.testing.assert_array_equal(one, five)
   np.testing.assert_array_equal(one, every)
+
+
+# -- FFT form (3-D and large patches) ---------------------------------------------
+FFT = 3
+
+
+@pytest.mark.gpu
+def test_fft_flow_golden_2d_and_3d(gpu, golden):
+  """The hipFFT form reproduces the reference goldens like the direct kernel."""
+  from sofima_amd import flow_field
+  g = golden('flow3d')
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator(method=FFT)
+  check_flow(calc.flow_field(g['pre'], g['post'], (16, 24, 24), 8, batch_size=4),
+             g['plain'])
+  g = golden('flow2d')
+  # same batch size as the golden: the peak ratio depends on batch membership
+  check_flow(calc.flow_field(g['pre'], g['post'], 48, 24, batch_size=8), g['plain'])
+  check_flow(calc.flow_field(g['pre'], g['post'], 48, 24, pre_mask=g['pre_mask'],
+                             post_mask=g['post_mask'], batch_size=8), g['masked'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('masked', [False, True])
+@pytest.mark.parametrize('shape,p,q', [((70, 90), (48, 64), (48, 64)),
+                                       ((70, 90), (50, 33), (31, 20)),
+                                       ((20, 30, 34), (12, 20, 16), (12, 20, 16)),
+                                       ((20, 30, 34), (9, 14, 21), (5, 14, 10))])
+def test_fft_surface_matches_direct_kernel(gpu, shape, p, q, masked):
+  """masked_xcorr: FFT form == shift-by-shift kernel to float32 FFT accuracy."""
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(17)
+  b = 3
+  prev = rng.integers(0, 256, (b,) + p).astype(np.float32)
+  curr = rng.integers(0, 256, (b,) + q).astype(np.float32)
+  prev -= prev.mean(axis=tuple(range(1, prev.ndim)), keepdims=True)
+  curr -= curr.mean(axis=tuple(range(1, curr.ndim)), keepdims=True)
+  kw = {}
+  if masked:
+    kw = dict(prev_mask=rng.random(prev.shape) < 0.1, curr_mask=rng.random(curr.shape) < 0.1)
+  dim = len(p)
+  want = flow_field.masked_xcorr(prev, curr, dim=dim, method=1, **kw)
+  got = flow_field.masked_xcorr(prev, curr, dim=dim, method=FFT, **kw)
+  assert got.shape == want.shape
+  if masked:
+    np.testing.assert_allclose(got, want, atol=2e-4)
+  else:
+    np.testing.assert_allclose(got, want, atol=2e-6 * np.abs(want).max())
+
+
+@pytest.mark.gpu
+def test_fft_flow_3d_production_patch_vs_oracle(gpu):
+  """cfg-5 geometry (80^3 patches, step 40): exact shift recovered, oracle parity."""
+  from scipy import ndimage
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(23)
+  base = ndimage.gaussian_filter(rng.standard_normal((140, 140, 140)), 1.5)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  pre = base[8:128, 8:128, 8:128]
+  post = base[10:130, 5:125, 12:132]
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()   # AUTO -> FFT for 80^3
+  f = calc.flow_field(pre, post, (80, 80, 80), 40, batch_size=8)
+  assert f.shape == (5, 2, 2, 2)
+  # flow = position in pre - position in post of the same content, as (x, y, z)
+  np.testing.assert_array_equal(f[0], 4)
+  np.testing.assert_array_equal(f[1], -3)
+  np.testing.assert_array_equal(f[2], 2)
+  want = flow_oracle.flow_field(pre, post, (80, 80, 80), 40, batch_size=8)
+  check_flow(f, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,center,radius', [((3, 70, 72, 68), (30, 35, 33), (2, 3, 3)),
+                                                 ((4, 610, 590), (300, 290), 5)])
+def test_batched_peaks_large_surfaces_vs_oracle(gpu, shape, center, radius):
+  """Surfaces >= 2^18 elements take the multi-workgroup first pass: same result."""
+  from scipy import ndimage
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(31)
+  sig = (0,) + (2.5,) * (len(shape) - 1)
+  img = ndimage.gaussian_filter(rng.standard_normal(shape), sig).astype(np.float32)
+  img[1] = -np.abs(img[1])                  # no positive value: NaN row
+  img[2].flat[0] = img[2].max() * 3         # peak at flat index 0 (Q4)
+  got = flow_field._batched_peaks(img, center, 2, 0.5, radius)
+  want = flow_oracle.batched_peaks(img, center, 2, 0.5, radius)
+  np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+  nd = len(shape) - 1
+  np.testing.assert_array_equal(got[:, :nd], want[:, :nd])
+  ok = np.isfinite(want[:, nd])
+  np.testing.assert_allclose(got[ok, nd], want[ok, nd], rtol=1e-5)
+  ok = np.isfinite(want[:, nd + 1])
+  np.testing.assert_allclose(got[ok, nd + 1], want[ok, nd + 1], rtol=1e-5)
