@@ -160,6 +160,81 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(GatherArgs g0, GatherArg
   }
 }
 
+// Large patches (3-D, whole overlaps): kGatherChunks workgroups per patch.
+// PHASE 0 leaves per-chunk (sum, count) partials; PHASE 1 adds them in chunk
+// order (every workgroup gets the identical mean) and writes its chunk.
+constexpr int kGatherChunks = 32;
+
+template <typename T, int PHASE>
+__global__ void __launch_bounds__(kBlock)
+gather_big_kernel(GatherArgs g0, GatherArgs g1, double* __restrict__ partial) {
+  const GatherArgs& g = blockIdx.z == 0 ? g0 : g1;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  __shared__ double s_sum[kBlock];
+  __shared__ double s_cnt[kBlock];
+  int st[3] = {0, 0, 0}, ms[3] = {0, 0, 0};
+  for (int i = 0; i < g.nd; ++i) {
+    const int v = g.starts[b * g.nd + i];
+    const int ax = 3 - g.nd + i;
+    st[ax] = min(max(v, 0), g.ishape[ax] - g.psz[ax]);
+    ms[ax] = min(max(v, 0), g.mshape[ax] - g.psz[ax]);
+  }
+  const T* img = static_cast<const T*>(g.img);
+  const int py = g.psz[1], px = g.psz[2];
+  const int rows = g.psz[0] * py;
+  const int per = (rows + kGatherChunks - 1) / kGatherChunks;
+  const int r0 = min(rows, chunk * per), r1 = min(rows, r0 + per);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* part = partial + ((long long)(blockIdx.z * gridDim.y + b) * kGatherChunks) * 2;
+  float mu = g.mean;
+  if (PHASE == 1 && !g.use_mean) {
+    double s = 0.0, c = 0.0;
+    for (int k = 0; k < kGatherChunks; ++k) {
+      s += part[2 * k];
+      c += part[2 * k + 1];
+    }
+    mu = static_cast<float>(s / c);  // NaN when all masked
+  }
+  double s = 0.0, c = 0.0;
+  for (int r = r0 + wave; r < r1; r += kBlock / 64) {
+    const int z = r / py, y = r - z * py;
+    const long long io =
+        ((long long)(st[0] + z) * g.ishape[1] + (st[1] + y)) * g.ishape[2] + st[2];
+    const long long mo =
+        ((long long)(ms[0] + z) * g.mshape[1] + (ms[1] + y)) * g.mshape[2] + ms[2];
+    for (int x = lane; x < px; x += 64) {
+      const float v = static_cast<float>(img[io + x]);
+      const bool m = g.mask && g.mask[mo + x] != 0;
+      if (PHASE == 0) {
+        if (!m) {
+          s += v;
+          c += 1.0;
+        }
+      } else {
+        const long long o = b * g.pn + (long long)r * px + x;
+        g.out[o] = m ? 0.f : v - mu;
+        if (g.valid) g.valid[o] = m ? 0.f : 1.f;
+      }
+    }
+  }
+  if (PHASE == 0) {
+    s_sum[threadIdx.x] = s;
+    s_cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int k = kBlock / 2; k > 0; k >>= 1) {
+      if (threadIdx.x < k) {
+        s_sum[threadIdx.x] += s_sum[threadIdx.x + k];
+        s_cnt[threadIdx.x] += s_cnt[threadIdx.x + k];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      part[2 * chunk] = s_sum[0];
+      part[2 * chunk + 1] = s_cnt[0];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // general direct correlation (any dim / dtype / masks)
 // ---------------------------------------------------------------------------
@@ -706,6 +781,7 @@ struct XcorrWs {
   unsigned int* maxima;
   void* mfma;
   void* fft;
+  double* gather_part;  // large patches: per-chunk (sum, count) partials
   PeakWs peaks;
   int srows, spitch;  // layout of `surface`: [B, srows, spitch]
   size_t bytes;
@@ -754,6 +830,8 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
       w.maxima = c.take<unsigned int>(2);
     }
     if (use_fft(d)) w.fft = c.take<char>(sfm::fft_workspace_bytes(d));
+    if (std::max(g.Pn, g.Qn) >= (1LL << 16))
+      w.gather_part = c.take<double>(B * 2 * kGatherChunks * 2);
   }
   w.srows = g.S[0] * g.S[1];
   w.spitch = g.S[2];
@@ -823,12 +901,28 @@ int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
     a.valid = masked ? (k == 0 ? w.va : w.vb) : nullptr;
     a.pn = k == 0 ? g.Pn : g.Qn;
   }
-  if (d->dtype == SFM_DTYPE_U8)
+  if (w.gather_part) {
+    const dim3 grid(kGatherChunks, d->batch, 2);
+    if (d->dtype == SFM_DTYPE_U8) {
+      if (!d->use_mean)
+        hipLaunchKernelGGL((gather_big_kernel<unsigned char, 0>), grid, dim3(kBlock), 0,
+                           st, ga[0], ga[1], w.gather_part);
+      hipLaunchKernelGGL((gather_big_kernel<unsigned char, 1>), grid, dim3(kBlock), 0, st,
+                         ga[0], ga[1], w.gather_part);
+    } else {
+      if (!d->use_mean)
+        hipLaunchKernelGGL((gather_big_kernel<float, 0>), grid, dim3(kBlock), 0, st,
+                           ga[0], ga[1], w.gather_part);
+      hipLaunchKernelGGL((gather_big_kernel<float, 1>), grid, dim3(kBlock), 0, st, ga[0],
+                         ga[1], w.gather_part);
+    }
+  } else if (d->dtype == SFM_DTYPE_U8) {
     hipLaunchKernelGGL(gather_kernel<unsigned char>, dim3(d->batch, 2),
                        dim3(kBlock), 0, st, ga[0], ga[1]);
-  else
+  } else {
     hipLaunchKernelGGL(gather_kernel<float>, dim3(d->batch, 2), dim3(kBlock), 0,
                        st, ga[0], ga[1]);
+  }
   SFM_LAUNCH_CHECK();
 
   CorrArgs c;
