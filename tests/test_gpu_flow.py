@@ -485,3 +485,27 @@ def test_batched_peaks_large_surfaces_vs_oracle(gpu, shape, center, radius):
   np.testing.assert_allclose(got[ok, nd], want[ok, nd], rtol=1e-5)
   ok = np.isfinite(want[:, nd + 1])
   np.testing.assert_allclose(got[ok, nd + 1], want[ok, nd + 1], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_whole_overlap_offset_regime_vs_oracle(gpu):
+  """The call pattern of stitch_rigid._estimate_offset (stitch_rigid.py:38-66):
+  one patch = the whole overlap strip, dynamic-range masks, step 1, batch 1."""
+  from scipy import ndimage
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(2)
+  base = ndimage.gaussian_filter(rng.standard_normal((1100, 260)), 2.0)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  a = base[20:1044, 20:220]
+  b = base[31:1055, 14:214]
+  a_mask = (ndimage.maximum_filter(a, 10) - ndimage.minimum_filter(a, 10)) < 12
+  b_mask = (ndimage.maximum_filter(b, 10) - ndimage.minimum_filter(b, 10)) < 12
+  assert 0.02 < a_mask.mean() < 0.9
+  mfc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  got = mfc.flow_field(a, b, pre_mask=a_mask, post_mask=b_mask, patch_size=a.shape,
+                       step=(1, 1), batch_size=1)
+  want = flow_oracle.flow_field(a, b, a.shape, (1, 1), pre_mask=a_mask,
+                                post_mask=b_mask, batch_size=1)
+  xo, yo, _, pr = got.squeeze()
+  assert (xo, yo) == (-6.0, 11.0)
+  check_flow(got, want, sharp_rtol=2e-3)
