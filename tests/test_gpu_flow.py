@@ -498,8 +498,8 @@ def test_whole_overlap_offset_regime_vs_oracle(gpu):
   base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
   a = base[20:1044, 20:220]
   b = base[31:1055, 14:214]
-  a_mask = (ndimage.maximum_filter(a, 10) - ndimage.minimum_filter(a, 10)) < 12
-  b_mask = (ndimage.maximum_filter(b, 10) - ndimage.minimum_filter(b, 10)) < 12
+  a_mask = (ndimage.maximum_filter(a, 10) - ndimage.minimum_filter(a, 10)) < 65
+  b_mask = (ndimage.maximum_filter(b, 10) - ndimage.minimum_filter(b, 10)) < 65
   assert 0.02 < a_mask.mean() < 0.9
   mfc = flow_field.JAXMaskedXCorrWithStatsCalculator()
   got = mfc.flow_field(a, b, pre_mask=a_mask, post_mask=b_mask, patch_size=a.shape,
