@@ -201,6 +201,27 @@ typedef struct SfmCleanFlowDesc {
 int sfm_clean_flow(const SfmCleanFlowDesc* desc, float* out);
 
 /* ------------------------------------------------------------------------
+ * Fold / stretch detection on a relaxed mesh, the step after relaxation.
+ * Replaces map_utils.mask_irregular (map_utils.py:737-786): a node is bad when
+ * the distance to its +x (+y) neighbour leaves [frac, max_frac] * stride; the
+ * bad set is dilated `dilation_iters` times with the full 3 x 3 structure and
+ * the map is NaN'ed there in place.
+ * ---------------------------------------------------------------------- */
+typedef struct SfmMaskIrregularDesc {
+  int32_t shape[2];             /* y, x                                      */
+  float stride[2];              /* x, y (the reference's order)              */
+  float frac;
+  float max_frac;
+  int32_t dilation_iters;
+  void* stream;
+} SfmMaskIrregularDesc;
+
+/* coord_map: device float [2, y, x], modified in place; bad: device uint8
+ * [y, x] (1 = masked). */
+int sfm_mask_irregular(const SfmMaskIrregularDesc* desc, float* coord_map,
+                       uint8_t* bad);
+
+/* ------------------------------------------------------------------------
  * Target mesh of an elastic tile montage.
  * Replaces stitch_elastic.compute_target_mesh (stitch_elastic.py:624-676,
  * with _update_mesh :573-620 and _apply_flow :456-570) vmapped over all

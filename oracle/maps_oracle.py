@@ -123,3 +123,27 @@ def target_mesh_all(nbors, x, fx, fy, stride):
   """prev_fn of the montage relaxation: [2, N, y, x]."""
   return np.stack([compute_target_mesh(nb, x, fx, fy, stride) for nb in nbors],
                   axis=1)
+
+
+def mask_irregular(coord_map, stride, frac, max_frac=None, dilation_iters=1):
+  """map_utils.py:737-786: returns (masked copy of the map, bad mask).
+
+  The reference masks in place; the oracle returns the masked copy instead.
+  """
+  from scipy import ndimage
+  coord_map = np.array(coord_map, copy=True)
+  assert coord_map.ndim == 3 and coord_map.shape[0] == 2
+  if max_frac is None:
+    max_frac = 2 - frac
+  stride_x, stride_y = np.asarray(stride)
+  # map_utils.py:768-771
+  diff_x = np.pad(np.diff(coord_map[0], axis=-1), [[0, 0], [0, 1]]) + stride_x
+  diff_y = np.pad(np.diff(coord_map[1], axis=-2), [[0, 1], [0, 0]]) + stride_y
+  with np.errstate(invalid='ignore'):
+    bad = (diff_x < frac * stride_x) | (diff_y < frac * stride_y)
+    bad |= (diff_x > max_frac * stride_x) | (diff_y > max_frac * stride_y)
+  if dilation_iters > 0:  # map_utils.py:776-781
+    bad = ndimage.binary_dilation(bad, ndimage.generate_binary_structure(2, 2),
+                                  iterations=dilation_iters)
+  coord_map[:, bad] = np.nan
+  return coord_map, bad

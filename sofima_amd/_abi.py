@@ -114,6 +114,17 @@ class SfmCleanFlowDesc(C.Structure):
   ]
 
 
+class SfmMaskIrregularDesc(C.Structure):
+  _fields_ = [
+      ('shape', i32 * 2),
+      ('stride', C.c_float * 2),
+      ('frac', C.c_float),
+      ('max_frac', C.c_float),
+      ('dilation_iters', i32),
+      ('stream', C.c_void_p),
+  ]
+
+
 class SfmTargetMeshDesc(C.Structure):
   _fields_ = [
       ('ncomp', i32),
@@ -194,6 +205,8 @@ SIGNATURES = {
     'sfm_peaks': (C.c_int, [C.POINTER(SfmPeaksDesc), C.c_void_p]),
     'sfm_compose_maps': (C.c_int, [C.POINTER(SfmComposeDesc), C.c_void_p]),
     'sfm_clean_flow': (C.c_int, [C.POINTER(SfmCleanFlowDesc), C.c_void_p]),
+    'sfm_mask_irregular': (C.c_int, [C.POINTER(SfmMaskIrregularDesc), C.c_void_p,
+                                     C.c_void_p]),
     'sfm_target_mesh': (C.c_int, [C.POINTER(SfmTargetMeshDesc), C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     'sfm_mesh_workspace_bytes': (C.c_size_t, [C.POINTER(SfmMeshDesc)]),

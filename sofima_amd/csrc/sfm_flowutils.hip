@@ -1,7 +1,8 @@
 // Flow-field clean-up on the device: the
 // quality filter that runs between flow estimation and mesh relaxation.
 //
-//   sfm_clean_flow  <->  flow_utils.clean_flow (flow_utils.py:37-78)
+//   sfm_clean_flow      <->  flow_utils.clean_flow (flow_utils.py:37-78)
+//   sfm_mask_irregular  <->  map_utils.mask_irregular (map_utils.py:737-786)
 //
 // One thread per vector.  The field is small (one vector per patch), so the
 // point of the kernel is that the flow can stay in HBM from the correlation
@@ -98,7 +99,77 @@ __global__ void __launch_bounds__(kBlock) clean_flow_kernel(CleanArgs a) {
   for (int c = 0; c < a.dim; ++c) a.out[c * n_vec + i] = bad ? NAN : v[c];
 }
 
+struct IrregArgs {
+  float* map;          // [2, Y, X]
+  unsigned char* bad;  // [Y, X]
+  int Y, X, iters;
+  float sx, sy, lo_x, lo_y, hi_x, hi_y;
+};
+
+// bad before dilation (map_utils.py:768-775); out-of-range nodes are not bad.
+__device__ __forceinline__ bool irregular_at(const IrregArgs& a, int y, int x) {
+  if (y < 0 || y >= a.Y || x < 0 || x >= a.X) return false;
+  const long long n = (long long)a.Y * a.X, i = (long long)y * a.X + x;
+  // np.diff padded with 0 at the far edge, then + stride
+  const float dx = (x + 1 < a.X ? a.map[i + 1] - a.map[i] : 0.f) + a.sx;
+  const float dy = (y + 1 < a.Y ? a.map[n + i + a.X] - a.map[n + i] : 0.f) + a.sy;
+  return dx < a.lo_x || dy < a.lo_y || dx > a.hi_x || dy > a.hi_y;
+}
+
+// `iters` dilations with the full 3 x 3 structure == OR over the square window
+// of radius `iters` (border value 0).
+__global__ void __launch_bounds__(kBlock) irregular_mark_kernel(IrregArgs a) {
+  const long long n = (long long)a.Y * a.X;
+  const long long i = blockIdx.x * (long long)kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int x = static_cast<int>(i % a.X), y = static_cast<int>(i / a.X);
+  bool bad = false;
+  for (int dy = -a.iters; dy <= a.iters && !bad; ++dy)
+    for (int dx = -a.iters; dx <= a.iters; ++dx)
+      if (irregular_at(a, y + dy, x + dx)) {
+        bad = true;
+        break;
+      }
+  a.bad[i] = bad ? 1 : 0;
+}
+
+// Second launch: the NaN fill must not feed back into the differences above.
+__global__ void __launch_bounds__(kBlock) irregular_fill_kernel(IrregArgs a) {
+  const long long n = (long long)a.Y * a.X;
+  const long long i = blockIdx.x * (long long)kBlock + threadIdx.x;
+  if (i >= n || !a.bad[i]) return;
+  a.map[i] = NAN;
+  a.map[n + i] = NAN;
+}
+
 }  // namespace
+
+extern "C" int sfm_mask_irregular(const SfmMaskIrregularDesc* d, float* coord_map,
+                                  uint8_t* bad) {
+  if (!d || !coord_map || !bad)
+    return sfm::fail(SFM_ERR_INVALID, "mask_irregular: NULL argument");
+  if (d->shape[0] < 1 || d->shape[1] < 1 || d->dilation_iters < 0)
+    return sfm::fail(SFM_ERR_INVALID, "mask_irregular: bad shape / iterations");
+  IrregArgs a;
+  a.map = coord_map;
+  a.bad = bad;
+  a.Y = d->shape[0];
+  a.X = d->shape[1];
+  a.iters = d->dilation_iters;
+  a.sx = d->stride[0];
+  a.sy = d->stride[1];
+  a.lo_x = d->frac * a.sx;
+  a.lo_y = d->frac * a.sy;
+  a.hi_x = d->max_frac * a.sx;
+  a.hi_y = d->max_frac * a.sy;
+  const long long n = (long long)a.Y * a.X;
+  const unsigned grid = static_cast<unsigned>((n + kBlock - 1) / kBlock);
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  hipLaunchKernelGGL(irregular_mark_kernel, dim3(grid), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL(irregular_fill_kernel, dim3(grid), dim3(kBlock), 0, st, a);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
 
 extern "C" int sfm_clean_flow(const SfmCleanFlowDesc* d, float* out) {
   if (!d || !d->flow || !out)

@@ -1,8 +1,9 @@
 """Coordinate-map composition on MI355X.
 
 Drop-in for `map_utils.compose_maps_fast` of the reference
-(map_utils.py:616-734); the other functions of the reference's map_utils.py
-(Delaunay inversion, resampling, ...) are host geometry and out of scope.
+(map_utils.py:616-734) and `map_utils.mask_irregular` (:737-786); the other
+functions of the reference's map_utils.py (Delaunay inversion, resampling, ...)
+are host geometry and out of scope.
 """
 from __future__ import annotations
 
@@ -66,3 +67,38 @@ def compose_maps_fast(map1, start1: Sequence[float], stride1, map2,
   out = torch.empty_like(m1)
   _abi.check(_abi.load().sfm_compose_maps(C.byref(d), out.data_ptr()))
   return DeviceArray(out)
+
+
+def mask_irregular(coord_map, stride: Sequence[float], frac: float,
+                   max_frac: float | None = None,
+                   dilation_iters: int = 1) -> np.ndarray:
+  """Masks stretched / folded parts of a [2, y, x] relative coordinate map.
+
+  Same contract as the reference (map_utils.py:737-786): masked entries are
+  replaced with NaN IN PLACE (NumPy arrays are written back; torch tensors /
+  DeviceArrays are modified on the device) and the bool mask [y, x] is
+  returned.  `stride` is (x, y).  Computed in float32.
+  """
+  shape = np.shape(coord_map)
+  assert len(shape) == 3
+  assert shape[0] == 2
+  if max_frac is None:
+    max_frac = 2 - frac
+  stride_x, stride_y = (float(v) for v in np.asarray(stride).ravel())
+  dev = _dev.device()
+  host = coord_map if isinstance(coord_map, np.ndarray) else None
+  m = _dev.as_device_f32(coord_map, dev, copy=host is not None)
+  d = _abi.SfmMaskIrregularDesc()
+  d.shape = (C.c_int32 * 2)(int(shape[1]), int(shape[2]))
+  d.stride = (C.c_float * 2)(stride_x, stride_y)
+  d.frac = float(frac)
+  d.max_frac = float(max_frac)
+  d.dilation_iters = int(dilation_iters)
+  d.stream = _dev.stream_ptr()
+  bad = torch.empty(tuple(shape[1:]), dtype=torch.uint8, device=dev)
+  _abi.check(_abi.load().sfm_mask_irregular(C.byref(d), m.data_ptr(), bad.data_ptr()))
+  bad_h = bad.cpu().numpy().astype(bool)
+  if host is not None:
+    host[0][bad_h] = np.nan
+    host[1][bad_h] = np.nan
+  return bad_h

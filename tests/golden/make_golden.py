@@ -302,6 +302,30 @@ def gen_maps():
   save('compose_maps', **out)
 
 
+def gen_mask_irregular():
+  """map_utils.mask_irregular (pure NumPy / SciPy in the reference)."""
+  rng = np.random.default_rng(33)
+  yy, xx = np.mgrid[:37, :45]
+  m = np.stack([6 * np.sin(yy / 6.0) * np.cos(xx / 9.0),
+                5 * np.cos(yy / 7.0 + xx / 11.0)]).astype(np.float32)
+  m += rng.standard_normal(m.shape).astype(np.float32) * 0.8
+  for _ in range(12):   # folds / stretches
+    y, x = rng.integers(0, 37), rng.integers(0, 45)
+    m[rng.integers(0, 2), y, x] += rng.choice([-1, 1]) * rng.uniform(15, 40)
+  m[:, 3, 4] = np.nan
+  m[0, 30, 44] = np.nan
+  out = {'m': m}
+  for tag, kw in (('a', dict(frac=0.25, max_frac=1.1)),
+                  ('b', dict(frac=0.4)),
+                  ('c', dict(frac=0.25, max_frac=1.5, dilation_iters=0)),
+                  ('d', dict(frac=0.3, max_frac=1.3, dilation_iters=3))):
+    mm = m.copy()
+    bad = rmap.mask_irregular(mm, (20.0, 16.0), **kw)
+    out['bad_' + tag] = bad
+    out['map_' + tag] = mm
+  save('mask_irregular', **out)
+
+
 def gen_clean_flow():
   """flow_utils.clean_flow (pure NumPy / SciPy in the reference)."""
   from sofima import flow_utils as rfu
@@ -411,7 +435,7 @@ def gen_montage():
 
 
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'montage']
+  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'irregular', 'montage']
   if 'xcorr' in which:
     gen_xcorr_np()
   if 'peaks' in which:
@@ -424,5 +448,7 @@ if __name__ == '__main__':
     gen_maps()
   if 'clean' in which:
     gen_clean_flow()
+  if 'irregular' in which:
+    gen_mask_irregular()
   if 'montage' in which:
     gen_montage()

@@ -58,6 +58,7 @@ def test_struct_layouts_match_header():
                      ('SfmMaskCountDesc', _abi.SfmMaskCountDesc),
                      ('SfmComposeDesc', _abi.SfmComposeDesc),
                      ('SfmCleanFlowDesc', _abi.SfmCleanFlowDesc),
+                     ('SfmMaskIrregularDesc', _abi.SfmMaskIrregularDesc),
                      ('SfmTargetMeshDesc', _abi.SfmTargetMeshDesc)):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,
                      re.S).group(1)

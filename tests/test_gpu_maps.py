@@ -131,3 +131,28 @@ def test_clean_flow_on_flow_field_output(gpu):
   want = flow_utils_oracle.clean_flow(flow, 1.4, 1.6, 20, 4)
   np.testing.assert_array_equal(got, want)
   assert 0 < np.isnan(got[0]).sum() < got[0].size
+
+
+@pytest.mark.gpu
+def test_mask_irregular_kat_and_golden(gpu, golden):
+  """tests/map_utils_test.py:323-333 and the reference goldens, in-place contract."""
+  from sofima_amd import map_utils
+  from tests.test_oracle_golden import _IRREG
+  coord_map = np.zeros([2, 50, 50])
+  coord_map[0, 40, 10] = 10
+  bad = map_utils.mask_irregular(coord_map, (40, 40), 0.25, 1.1)
+  expected = np.zeros([2, 50, 50])
+  expected[:, 39:42, 8:11] = np.nan
+  np.testing.assert_array_equal(expected, coord_map)
+  np.testing.assert_array_equal(np.isnan(expected[0, ...]), bad)
+  g = golden('mask_irregular')
+  for tag, kw in _IRREG:
+    mm = g['m'].copy()
+    bad = map_utils.mask_irregular(mm, (20.0, 16.0), **kw)
+    np.testing.assert_array_equal(bad, g['bad_' + tag])
+    np.testing.assert_array_equal(mm, g['map_' + tag])
+  # device-resident input is modified in place on the device
+  import torch
+  t = torch.from_numpy(g['m'].copy()).cuda()
+  bad = map_utils.mask_irregular(t, (20.0, 16.0), frac=0.25, max_frac=1.1)
+  np.testing.assert_array_equal(t.cpu().numpy(), g['map_a'])

@@ -203,3 +203,18 @@ def test_clean_flow_vs_golden(golden):
   # the filter does something in every variant
   assert np.isnan(g['c2']).sum() > np.isnan(g['f2'][:2]).sum()
   assert np.isnan(g['c3']).sum() > np.isnan(g['f3'][:3]).sum()
+
+
+_IRREG = (('a', dict(frac=0.25, max_frac=1.1)), ('b', dict(frac=0.4)),
+          ('c', dict(frac=0.25, max_frac=1.5, dilation_iters=0)),
+          ('d', dict(frac=0.3, max_frac=1.3, dilation_iters=3)))
+
+
+def test_mask_irregular_vs_golden(golden):
+  from oracle import maps_oracle
+  g = golden('mask_irregular')
+  for tag, kw in _IRREG:
+    mm, bad = maps_oracle.mask_irregular(g['m'], (20.0, 16.0), **kw)
+    np.testing.assert_array_equal(bad, g['bad_' + tag])
+    np.testing.assert_array_equal(mm, g['map_' + tag])
+    assert 0 < bad.sum() < bad.size

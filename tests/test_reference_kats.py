@@ -152,3 +152,15 @@ def test_clean_flow():
   from oracle import flow_utils_oracle
   flow, kw, expected = _clean_flow_kat()
   np.testing.assert_array_equal(flow_utils_oracle.clean_flow(flow, **kw), expected)
+
+
+def test_mask_irregular():
+  """tests/map_utils_test.py:323-333 against the oracle."""
+  from oracle import maps_oracle
+  coord_map = np.zeros([2, 50, 50])
+  coord_map[0, 40, 10] = 10
+  masked, bad = maps_oracle.mask_irregular(coord_map, (40, 40), 0.25, 1.1)
+  expected = np.zeros([2, 50, 50])
+  expected[:, 39:42, 8:11] = np.nan
+  np.testing.assert_array_equal(expected, masked)
+  np.testing.assert_array_equal(np.isnan(expected[0, ...]), bad)
