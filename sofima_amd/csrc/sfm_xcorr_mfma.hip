@@ -57,6 +57,12 @@
 #ifndef SFM_EPI_DEPTH
 #define SFM_EPI_DEPTH 1
 #endif
+// Ping-pong prefetch of the A fragments across row groups: measured 6 % SLOWER
+// on the <10,11> variant (200 bytes of spills at the 256-VGPR limit), neutral on
+// the smaller ones; kept as an experiment switch.
+#ifndef SFM_AF_PREFETCH
+#define SFM_AF_PREFETCH 0
+#endif
 
 #include <algorithm>
 #include <cstdlib>
@@ -1100,15 +1106,23 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       const unsigned char* ap =
           A_lds + (kPadTop + ylo + g + dy0 + n) * a.pa;
       const unsigned char* bp = B_lds + (ylo + g) * a.pb + (pos0 & ~3);
-      for (int yb0 = ylo; yb0 < yhi; yb0 += 4) {
+      // One row group: the B dwords of THIS group and the A fragments of the
+      // NEXT group are requested together, then the NCA x NCE MFMAs run on the A
+      // fragments that were prefetched a group ago -- only the first B dwords
+      // are on the critical path at the loop head.  (The last prefetch reads up
+      // to 8 rows past the tile's last row: still inside the workgroup's LDS,
+      // never used.)
+      auto row_group = [&](const v4i* af, v4i* af_next, const unsigned char* ap_next,
+                           const unsigned char* bp_cur) {
         unsigned d[4 * NCE + 1];
 #pragma unroll
         for (int j = 0; j < 4 * NCE + 1; ++j)
-          d[j] = *reinterpret_cast<const unsigned*>(bp + 4 * j);
-        v4i af[NCA];
+          d[j] = *reinterpret_cast<const unsigned*>(bp_cur + 4 * j);
+        if (af_next) {
 #pragma unroll
-        for (int ca = 0; ca < NCA; ++ca)
-          af[ca] = *reinterpret_cast<const v4i*>(ap + 16 * ca);
+          for (int ca = 0; ca < NCA; ++ca)
+            af_next[ca] = *reinterpret_cast<const v4i*>(ap_next + 16 * ca);
+        }
 #pragma unroll
         for (int c = 0; c < NCE; ++c) {
           v4i bf;
@@ -1123,9 +1137,33 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                                                            0, 0);
           }
         }
+      };
+#if SFM_AF_PREFETCH
+      {
+        v4i afA[NCA], afB[NCA];
+#pragma unroll
+        for (int ca = 0; ca < NCA; ++ca)
+          afA[ca] = *reinterpret_cast<const v4i*>(ap + 16 * ca);
+        int yb0 = ylo;
+        for (; yb0 + 4 < yhi; yb0 += 8) {
+          row_group(afA, afB, ap + 4 * a.pa, bp);
+          row_group(afB, afA, ap + 8 * a.pa, bp + 4 * a.pb);
+          ap += 8 * a.pa;
+          bp += 8 * a.pb;
+        }
+        if (yb0 < yhi) row_group(afA, nullptr, nullptr, bp);
+      }
+#else
+      for (int yb0 = ylo; yb0 < yhi; yb0 += 4) {
+        v4i af[NCA];
+#pragma unroll
+        for (int ca = 0; ca < NCA; ++ca)
+          af[ca] = *reinterpret_cast<const v4i*>(ap + 16 * ca);
+        row_group(af, nullptr, nullptr, bp);
         ap += 4 * a.pa;
         bp += 4 * a.pb;
       }
+#endif
 
       TICK(2)
       // The epilogue's table addresses do not depend on the MFMA loop; without
