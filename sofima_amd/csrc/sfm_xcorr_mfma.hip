@@ -243,6 +243,22 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
   }
 }
 
+// 16 image bytes at an arbitrary byte offset (global memory takes unaligned
+// dwordx4 loads); only the last bytes of the image need the guarded path.
+__device__ __forceinline__ v4i load_16_bytes(const unsigned char* img, long long off,
+                                             long long img_bytes) {
+  v4i v;
+  if (off + 16 <= img_bytes) {
+    __builtin_memcpy(&v, img + off, 16);
+  } else {
+    unsigned char t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = off + k < img_bytes ? img[off + k] : 0;
+    __builtin_memcpy(&v, t, 16);
+  }
+  return v;
+}
+
 // ---------------------------------------------------------------------------
 // prep for P == Q: centres, means, combined correction table G and the 1-D
 // row / column arrays.  One 256-thread block per patch; LDS holds the two raw
@@ -286,76 +302,98 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* pix[2] = {smem, smem + ((py * px + 15) & ~15)};
+#ifdef SFM_MFMA_TIMING
+  long long pt[6]; pt[0] = clock64();
+#define PTICK(i) pt[i] = clock64();
+#else
+#define PTICK(i)
+#endif
 
-  // Phase 1: coalesced copy of both patches into LDS (16 bytes per item).
+  // Phase 1 + 2: copy both patches into LDS (unaligned 16-byte loads, all of a
+  // round in flight together) and take min / max / sum of the pixels on the
+  // way, from the registers.
   int y0[2], x0[2];
+  int mn[2] = {255, 255}, mx[2] = {0, 0}, sum[2] = {0, 0};
+  const int n_chunks = (px + 15) / 16;
+  const int n_items = py * n_chunks;
+  long long img_bytes[2];
   for (int s = 0; s < 2; ++s) {
     const int H = a.ishape[s][0], W = a.ishape[s][1];
     y0[s] = min(max(a.starts[s][b * 2 + 0], 0), H - py);
     x0[s] = min(max(a.starts[s][b * 2 + 1], 0), W - px);
-    const unsigned* words = reinterpret_cast<const unsigned*>(a.img[s]);
-    const long long n_words = ((long long)H * W + 3) >> 2;
-    const int n_chunks = (px + 15) / 16;
-    const int n_items = py * n_chunks;
-    constexpr int kBatch = 4;  // items whose loads are in flight together
-    for (int item0 = threadIdx.x; item0 < n_items; item0 += kPrepThreads * kBatch) {
-      unsigned w[kBatch][5];
-      unsigned shv[kBatch];
+    img_bytes[s] = (long long)H * W;
+  }
+  constexpr int kItems = 4;  // items per thread and plane whose loads are in flight
+  for (int item0 = threadIdx.x; item0 < n_items; item0 += kPrepThreads * kItems) {
+    v4i w[2][kItems];
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int u = 0; u < kItems; ++u) {
         const int item = item0 + u * kPrepThreads;
         const int y = item / n_chunks, ch = item - y * n_chunks;
-        const long long off = (long long)(y0[s] + y) * W + x0[s] + ch * 16;
-        const long long w0 = off >> 2;
-        shv[u] = static_cast<unsigned>(off & 3);
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-          w[u][k] = item < n_items ? load_u32_guarded(words, w0 + k, n_words) : 0u;
+        const long long off = (long long)(y0[s] + y) * a.ishape[s][1] + x0[s] + ch * 16;
+        w[s][u] = item < n_items ? load_16_bytes(a.img[s], off, img_bytes[s])
+                                 : v4i{0, 0, 0, 0};
       }
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int u = 0; u < kItems; ++u) {
         const int item = item0 + u * kPrepThreads;
         if (item >= n_items) break;
         const int y = item / n_chunks, ch = item - y * n_chunks;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const unsigned v = __builtin_amdgcn_alignbyte(w[u][k + 1], w[u][k], shv[u]);
+          const unsigned v = static_cast<unsigned>(w[s][u][k]);
           const int xb = ch * 16 + k * 4;
+          const int keep = min(4, px - xb);  // valid bytes of this dword
+          if (keep <= 0) continue;
           unsigned char* dst = pix[s] + y * px + xb;
-          if (xb + 4 <= px && ((y * px + xb) & 3) == 0) {
+          if (keep == 4 && ((y * px + xb) & 3) == 0) {
             *reinterpret_cast<unsigned*>(dst) = v;
           } else {
-            for (int t = 0; t < 4; ++t)
-              if (xb + t < px) dst[t] = static_cast<unsigned char>(v >> (8 * t));
+            for (int t = 0; t < keep; ++t) dst[t] = static_cast<unsigned char>(v >> (8 * t));
+          }
+          const unsigned live = keep == 4 ? 0xffffffffu : (0xffffffffu >> (8 * (4 - keep)));
+          sum[s] = static_cast<int>(__builtin_amdgcn_sad_u8(v & live, 0u, sum[s]));
+          const unsigned lo = v | ~live, hi = v & live;  // dead bytes: 255 for min, 0 for max
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            mn[s] = min(mn[s], static_cast<int>((lo >> (8 * t)) & 0xffu));
+            mx[s] = max(mx[s], static_cast<int>((hi >> (8 * t)) & 0xffu));
           }
         }
       }
-    }
   }
-  __syncthreads();
-
-  // Phase 2: min / max / sum per patch -> integer centre and residual mean.
+  // wave reduction on the shuffle network, then one LDS exchange across waves
+#pragma unroll
   for (int s = 0; s < 2; ++s) {
-    int mn = 255, mx = 0, sum = 0;
-    for (int i = threadIdx.x; i < py * px; i += kPrepThreads) {
-      const int v = pix[s][i];
-      mn = min(mn, v);
-      mx = max(mx, v);
-      sum += v;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      mn[s] = min(mn[s], __shfl_xor(mn[s], d, 64));
+      mx[s] = max(mx[s], __shfl_xor(mx[s], d, 64));
+      sum[s] += __shfl_xor(sum[s], d, 64);
     }
-    red[s][0][threadIdx.x] = mn;
-    red[s][1][threadIdx.x] = mx;
-    red[s][2][threadIdx.x] = sum;
+    if (lane == 0) {
+      red[s][0][wave] = mn[s];
+      red[s][1][wave] = mx[s];
+      red[s][2][wave] = sum[s];
+    }
   }
   __syncthreads();
-  for (int k = kPrepThreads / 2; k > 0; k >>= 1) {
-    if (threadIdx.x < k)
-      for (int s = 0; s < 2; ++s) {
-        red[s][0][threadIdx.x] = min(red[s][0][threadIdx.x], red[s][0][threadIdx.x + k]);
-        red[s][1][threadIdx.x] = max(red[s][1][threadIdx.x], red[s][1][threadIdx.x + k]);
-        red[s][2][threadIdx.x] += red[s][2][threadIdx.x + k];
-      }
-    __syncthreads();
+  PTICK(1)
+  if (threadIdx.x < 2) {
+    const int s = threadIdx.x;
+    int r_mn = 255, r_mx = 0, r_sum = 0;
+    for (int w2 = 0; w2 < kPrepWaves; ++w2) {
+      r_mn = min(r_mn, red[s][0][w2]);
+      r_mx = max(r_mx, red[s][1][w2]);
+      r_sum += red[s][2][w2];
+    }
+    red[s][0][0] = r_mn;
+    red[s][1][0] = r_mx;
+    red[s][2][0] = r_sum;
   }
   if (threadIdx.x < 2) {
     const int s = threadIdx.x;
@@ -377,6 +415,7 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
     p->mu[s] = s_mu[s];
   }
   __syncthreads();  // `red` (aliased with band_tot) fully consumed
+  PTICK(2)
 
   // Phase 3a: per-band column totals (band w = rows [w R, (w + 1) R)).
   // Lane l owns the kPrepCols consecutive columns kPrepCols * l + k, so one
@@ -428,6 +467,7 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
       }
     }
   }
+  PTICK(3)
   // Sweep.  The last wave also emits the yv == py row (pre-patch totals).
   const int y_end = wave == kPrepWaves - 1 ? py + 1 : ra1;
   for (int yv = ra0; yv < y_end; ++yv) {
@@ -490,6 +530,12 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
       }
     }
   }
+#ifdef SFM_MFMA_TIMING
+  PTICK(4)
+  if (blockIdx.x == 100 && lane == 0 && (wave == 0 || wave == 7))
+    printf("PREP wave %d: load %lld reduce %lld bands %lld sweep %lld\n", wave, pt[1] - pt[0],
+           pt[2] - pt[1], pt[3] - pt[2], pt[4] - pt[3]);
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -509,22 +555,6 @@ struct StagePlane {
 };
 
 constexpr int kStageBatch = 7;
-
-// 16 image bytes at an arbitrary byte offset (global memory takes unaligned
-// dwordx4 loads); only the last bytes of the image need the guarded path.
-__device__ __forceinline__ v4i load_16_bytes(const unsigned char* img, long long off,
-                                             long long img_bytes) {
-  v4i v;
-  if (off + 16 <= img_bytes) {
-    __builtin_memcpy(&v, img + off, 16);
-  } else {
-    unsigned char t[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = off + k < img_bytes ? img[off + k] : 0;
-    __builtin_memcpy(&v, t, 16);
-  }
-  return v;
-}
 
 __device__ __forceinline__ void stage_patches(const StagePlane& p0, const StagePlane& p1) {
   const StagePlane* pl[2] = {&p0, &p1};
@@ -1185,6 +1215,17 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         srow[r] = (16 * p + 4 * g + r) * a.sx_pitch + n;
         rowok[r] = 16 * p + 4 * g + r < Sy;
       }
+#ifdef SFM_ABLATE_EPILOGUE
+      // timing experiment only (results are garbage): how fast is the kernel
+      // when a tile costs nothing after its matrix loop?
+      {
+        int sink = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) sink ^= acc[q][0] ^ acc[q][1] ^ acc[q][2] ^ acc[q][3];
+        if (sink == 0x7fffffff) a.surface[0] = 1.f;
+        continue;
+      }
+#endif
       if (RAW) {
         // exact integer products; the Padfield assembly happens afterwards
         int* raw = a.raw_out + b * a.s_stride;
