@@ -229,14 +229,14 @@ int sfm_mask_irregular(const SfmMaskIrregularDesc* desc, float* coord_map,
  * flow fields say its nodes correspond to; NaN where no neighbour overlaps.
  * ---------------------------------------------------------------------- */
 typedef struct SfmTargetMeshDesc {
-  int32_t ncomp;                /* 2 (in-plane montage)                      */
+  int32_t ncomp;                /* 2 (in-plane montage) or 3 (volumetric)    */
   int32_t n_tiles;
-  int32_t mesh_shape[3];        /* z, y, x of one tile mesh (z = 1)          */
+  int32_t mesh_shape[3];        /* z, y, x of one tile mesh (z = 1 for 2)    */
   int32_t fx_shape[3];          /* z, y, x of one flow array in fx           */
   int32_t fy_shape[3];
   int32_t n_fx;                 /* flow arrays in fx (its dimension 1)       */
   int32_t n_fy;
-  int32_t nbor_fields;          /* 8 (NeighborInfo, stitch_elastic.py:43-72) */
+  int32_t nbor_fields;          /* 8, or 11 with the z fields (ncomp 3)      */
   float stride[3];              /* zyx stride of flow and mesh               */
   const int32_t* nbors;         /* device [n_tiles, 4, nbor_fields]          */
   const float* fx;              /* device [ncomp, n_fx, *fx_shape]           */

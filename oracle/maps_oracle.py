@@ -88,11 +88,14 @@ def compose_maps_fast(map1, start1, stride1, map2, start2, stride2,
 
 
 def compute_target_mesh(nbor_data, x, fx, fy, stride):
-  """[2, y, x] target positions of one tile (2-D montage)."""
+  """[2, y, x] / [3, z, y, x] target positions of one tile
+  (stitch_elastic.py:624-676 with _update_mesh :573-620, _apply_flow :456-570)."""
   x = np.asarray(x, f32)
-  my, mx = x.shape[-2:]
-  ext = [my + max(fy.shape[-2], fx.shape[-2]), mx + max(fy.shape[-1], fx.shape[-1])]
-  canvas = np.full([2] + ext, np.nan, f32)
+  ncomp = x.shape[0]
+  msz = x.shape[-ncomp:]                      # [z]yx size of one tile mesh
+  my, mx = msz[-2:]
+  ext = [msz[i] + max(fy.shape[-ncomp + i], fx.shape[-ncomp + i]) for i in range(ncomp)]
+  canvas = np.full([ncomp] + ext, np.nan, f32)
   for nd in np.asarray(nbor_data):
     nbor, flow_idx, off_ortho, f_ortho, f_overlap, fine_x, fine_y, dim = (
         int(v) for v in nd[:8])
@@ -106,21 +109,32 @@ def compute_target_mesh(nbor_data, x, fx, fy, stride):
     s_hi = (mult == 1 and off_ortho > 0) or (mult == -1 and off_ortho < 0)
     start_ortho = ortho_n - f_ortho if s_hi else 0
     start = (start_ortho, start_par) if dim == 0 else (start_par, start_ortho)
-    nflow = (mult * np.asarray(flow[:, flow_idx], f32))[:, None]
-    upd = compose_maps_fast(nflow, start, stride, x[:, nbor][:, None], (0, 0),
-                            stride, mode='constant')[:, 0]
-    upd = upd + f32(mult) * np.array([fine_x, fine_y], f32).reshape(2, 1, 1)
     tg_par = 0 if mult == 1 else par_n - f_overlap
     t_hi = (mult == 1 and off_ortho < 0) or (mult == -1 and off_ortho > 0)
     tg_ortho = ortho_n - f_ortho if t_hi else 0
-    ty, tx = (tg_ortho, tg_par) if dim == 0 else (tg_par, tg_ortho)
-    sl = (slice(None), slice(ty, ty + upd.shape[1]), slice(tx, tx + upd.shape[2]))
+    tg = (tg_ortho, tg_par) if dim == 0 else (tg_par, tg_ortho)
+    nflow = mult * np.asarray(flow[:, flow_idx], f32)
+    if ncomp == 3:
+      # stitch_elastic.py:509-518, 556-561
+      off_z, f_z, fine_z = int(nd[8]), int(nd[9]), int(nd[10])
+      sz_hi = (mult == 1 and off_z > 0) or (mult == -1 and off_z < 0)
+      start = (msz[0] - f_z if sz_hi else 0,) + start
+      tz_hi = (mult == 1 and off_z < 0) or (mult == -1 and off_z > 0)
+      tg = (msz[0] - f_z if tz_hi else 0,) + tg
+      upd = compose_maps_fast(nflow, start, stride, x[:, nbor], (0, 0, 0), stride,
+                              mode='constant')
+      upd = upd + f32(mult) * np.array([fine_x, fine_y, fine_z], f32).reshape(3, 1, 1, 1)
+    else:
+      upd = compose_maps_fast(nflow[:, None], start, stride, x[:, nbor][:, None],
+                              (0, 0), stride, mode='constant')[:, 0]
+      upd = upd + f32(mult) * np.array([fine_x, fine_y], f32).reshape(2, 1, 1)
+    sl = (slice(None),) + tuple(slice(t, t + n) for t, n in zip(tg, upd.shape[1:]))
     canvas[sl] = np.where(np.isnan(upd), canvas[sl], upd)
-  return canvas[:, :my, :mx]
+  return canvas[(slice(None),) + tuple(slice(0, n) for n in msz)]
 
 
 def target_mesh_all(nbors, x, fx, fy, stride):
-  """prev_fn of the montage relaxation: [2, N, y, x]."""
+  """prev_fn of the montage relaxation: [2, N, y, x] or [3, N, z, y, x]."""
   return np.stack([compute_target_mesh(nb, x, fx, fy, stride) for nb in nbors],
                   axis=1)
 

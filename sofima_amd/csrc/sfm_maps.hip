@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(kBlock) compose_kernel(ComposeArgs a) {
 
 // NeighborInfo field indices (stitch_elastic.py:43-72).
 enum { kNbor = 0, kFlow = 1, kOffOrtho = 2, kSizeOrtho = 3, kSizeOverlap = 4,
-       kFineX = 5, kFineY = 6, kDim = 7 };
+       kFineX = 5, kFineY = 6, kDim = 7, kOffZ = 8, kSizeZ = 9, kFineZ = 10 };
 
 struct TargetArgs {
   SfmTargetMeshDesc d;
@@ -150,19 +150,24 @@ struct TargetArgs {
 
 // One thread per (tile, node).  The reference pastes the four neighbour
 // updates in order into a NaN canvas, keeping the previous value where the
-// update is NaN (per component); the last non-NaN update wins.
+// update is NaN (per component); the last non-NaN update wins.  In-plane
+// montages (ncomp 2, one section) and volumetric ones (ncomp 3: z start /
+// target offsets and the z fine offset of stitch_elastic.py:509-518, 544-561).
 __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
   const SfmTargetMeshDesc& d = a.d;
-  const int my = d.mesh_shape[1], mx = d.mesh_shape[2];
-  const long long mn = (long long)my * mx;
+  const int nc = d.ncomp;
+  const int mz = d.mesh_shape[0], my = d.mesh_shape[1], mx = d.mesh_shape[2];
+  const long long mn = (long long)mz * my * mx;
   const long long total = (long long)d.n_tiles * mn;
-  const float sy = d.stride[1], sx = d.stride[2];
+  const float sz = d.stride[0], sy = d.stride[1], sx = d.stride[2];
   for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < total;
        i += (long long)gridDim.x * kBlock) {
     const int tile = static_cast<int>(i / mn);
     const int node = static_cast<int>(i - tile * mn);
-    const int ty = node / mx, tx = node - ty * mx;
-    float rx = NAN, ry = NAN;
+    const int tx = node % mx;
+    const int ty = (node / mx) % my;
+    const int tz = node / (mx * my);
+    float rx = NAN, ry = NAN, rz = NAN;
     for (int j = 0; j < 4; ++j) {
       const int* nb = d.nbors + ((long long)tile * 4 + j) * d.nbor_fields;
       const int nbor = nb[kNbor];
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
       const int* fshape = dim == 0 ? d.fx_shape : d.fy_shape;
       const int n_f = dim == 0 ? d.n_fx : d.n_fy;
       const float* farr = dim == 0 ? d.fx : d.fy;
-      const int fy_n = fshape[1], fx_n = fshape[2];
+      const int fz_n = fshape[0], fy_n = fshape[1], fx_n = fshape[2];
       // size of the neighbour mesh along / across the overlap direction
       const int par_n = dim == 0 ? mx : my;
       const int ortho_n = dim == 0 ? my : mx;
@@ -189,14 +194,24 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
       const int tg_ortho = t_hi ? ortho_n - f_ortho : 0;
       const int tg_y = dim == 0 ? tg_ortho : tg_par;
       const int tg_x = dim == 0 ? tg_par : tg_ortho;
-      const int uy = ty - tg_y, ux = tx - tg_x;
-      if (uy < 0 || uy >= fy_n || ux < 0 || ux >= fx_n) continue;
+      int st_z = 0, tg_z = 0;
+      if (nc == 3) {
+        const int off_z = nb[kOffZ], f_z = nb[kSizeZ];
+        const bool sz_hi = (mult == 1 && off_z > 0) || (mult == -1 && off_z < 0);
+        const bool tz_hi = (mult == 1 && off_z < 0) || (mult == -1 && off_z > 0);
+        st_z = sz_hi ? mz - f_z : 0;
+        tg_z = tz_hi ? mz - f_z : 0;
+      }
+      const int uz = tz - tg_z, uy = ty - tg_y, ux = tx - tg_x;
+      if (uz < 0 || uz >= fz_n || uy < 0 || uy >= fy_n || ux < 0 || ux >= fx_n) continue;
       // jax clamps the dynamic index; valid data never needs it
       const int fi = min(max(flow_idx, 0), n_f - 1);
-      const long long fplane = (long long)fy_n * fx_n;
-      const long long fo = (long long)fi * fplane + (long long)uy * fx_n + ux;
-      const float m1x = static_cast<float>(mult) * farr[fo];
-      const float m1y = static_cast<float>(mult) * farr[(long long)n_f * fplane + fo];
+      const long long fvol = (long long)fz_n * fy_n * fx_n;
+      const long long fo =
+          (long long)fi * fvol + ((long long)uz * fy_n + uy) * fx_n + ux;
+      const float fm = static_cast<float>(mult);
+      const float m1x = fm * farr[fo];
+      const float m1y = fm * farr[(long long)n_f * fvol + fo];
       // compose_maps_fast(flow @ start, neighbour mesh @ 0, mode constant)
       const float ref1x = (static_cast<float>(ux) + static_cast<float>(st_x)) * sx;
       const float ref1y = (static_cast<float>(uy) + static_cast<float>(st_y)) * sy;
@@ -205,15 +220,29 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
       const int nb_i = min(max(nbor, 0), d.n_tiles - 1);
       const float* nx0 = a.x + (long long)nb_i * mn;
       const float* nx1 = a.x + ((long long)d.n_tiles + nb_i) * mn;
-      float ux_v = sample2(nx0, my, mx, qy, qx, true, 1, 0.f, sx) - ref1x;
-      float uy_v = sample2(nx1, my, mx, qy, qx, true, 0, 0.f, sy) - ref1y;
+      float ux_v, uy_v, uz_v = NAN;
+      if (nc == 2) {
+        ux_v = sample2(nx0, my, mx, qy, qx, true, 1, 0.f, sx) - ref1x;
+        uy_v = sample2(nx1, my, mx, qy, qx, true, 0, 0.f, sy) - ref1y;
+      } else {
+        const float m1z = fm * farr[2LL * n_f * fvol + fo];
+        const float ref1z = (static_cast<float>(uz) + static_cast<float>(st_z)) * sz;
+        const float qz = (ref1z + m1z) / sz;
+        const float* nx2 = a.x + (2LL * d.n_tiles + nb_i) * mn;
+        ux_v = sample3(nx0, mz, my, mx, qz, qy, qx, true, 2, 0.f, sx) - ref1x;
+        uy_v = sample3(nx1, mz, my, mx, qz, qy, qx, true, 1, 0.f, sy) - ref1y;
+        uz_v = sample3(nx2, mz, my, mx, qz, qy, qx, true, 0, 0.f, sz) - ref1z;
+        uz_v = uz_v + static_cast<float>(mult * nb[kFineZ]);
+      }
       ux_v = ux_v + static_cast<float>(mult * nb[kFineX]);
       uy_v = uy_v + static_cast<float>(mult * nb[kFineY]);
       if (!isnan(ux_v)) rx = ux_v;
       if (!isnan(uy_v)) ry = uy_v;
+      if (!isnan(uz_v)) rz = uz_v;
     }
     a.out[(long long)tile * mn + node] = rx;
     a.out[((long long)d.n_tiles + tile) * mn + node] = ry;
+    if (nc == 3) a.out[(2LL * d.n_tiles + tile) * mn + node] = rz;
   }
 }
 
@@ -229,16 +258,19 @@ namespace sfm {
 int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
                        hipStream_t st) {
   if (!d || !x || !out) return fail(SFM_ERR_INVALID, "target mesh: NULL argument");
-  if (d->ncomp != 2 || d->mesh_shape[0] != 1)
-    return fail(SFM_ERR_INVALID, "target mesh: only in-plane montages (ncomp 2)");
-  if (d->nbor_fields < 8 || !d->nbors || !d->fx || !d->fy || d->n_tiles < 1)
+  if (d->ncomp != 2 && d->ncomp != 3)
+    return fail(SFM_ERR_INVALID, "target mesh: ncomp must be 2 or 3");
+  if (d->ncomp == 2 && d->mesh_shape[0] != 1)
+    return fail(SFM_ERR_INVALID, "target mesh: in-plane montages have one section");
+  if (d->nbor_fields < (d->ncomp == 3 ? 11 : 8) || !d->nbors || !d->fx || !d->fy ||
+      d->n_tiles < 1)
     return fail(SFM_ERR_INVALID, "target mesh: bad neighbour / flow arrays");
   TargetArgs a;
   a.d = *d;
   a.x = x;
   a.out = out;
   const long long total =
-      (long long)d->n_tiles * d->mesh_shape[1] * d->mesh_shape[2];
+      (long long)d->n_tiles * d->mesh_shape[0] * d->mesh_shape[1] * d->mesh_shape[2];
   hipLaunchKernelGGL(target_mesh_kernel, dim3(grid_for(total)), dim3(kBlock), 0, st,
                      a);
   SFM_LAUNCH_CHECK();

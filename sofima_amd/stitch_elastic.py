@@ -42,7 +42,12 @@ class NeighborInfo(enum.IntEnum):
 
 
 class TargetMeshFn:
-  """prev_fn(x) for all tiles of a 2-D montage: [2, N, y, x] -> [2, N, y, x]."""
+  """prev_fn(x) for all tiles of a montage.
+
+  In-plane: x [2, N, y, x] -> [2, N, y, x] (flows fx / fy [2, n, y, x], stride
+  yx, 8 neighbour fields).  Volumetric: x [3, N, z, y, x] -> the same (flows
+  [3, n, z, y, x], stride zyx, 11 neighbour fields).
+  """
 
   def __init__(self, nbors, fx, fy, stride=(20, 20)):
     dev = _dev.device()
@@ -51,28 +56,36 @@ class TargetMeshFn:
       raise ValueError('nbors must be [n_tiles, 4, 8 or 11]')
     self.fx = _dev.as_device_f32(fx, dev, copy=False)
     self.fy = _dev.as_device_f32(fy, dev, copy=False)
-    if self.fx.ndim != 4 or self.fx.shape[0] != 2:
-      raise NotImplementedError('only in-plane montages ([2, n, y, x] flows)')
+    ncomp = int(self.fx.shape[0])
+    if ncomp not in (2, 3) or self.fx.ndim != ncomp + 2 or self.fy.ndim != ncomp + 2:
+      raise ValueError('flows must be [2, n, y, x] or [3, n, z, y, x]')
+    if ncomp == 3 and nb.shape[2] < 11:
+      raise ValueError('volumetric montages need the 11-field NeighborInfo rows')
+    if len(stride) != ncomp:
+      raise ValueError('stride must be [z]yx with one entry per spatial dimension')
+    self.ncomp = ncomp
     self.nbors = torch.from_numpy(nb).to(dev)
     self.stride = tuple(float(s) for s in stride)
     d = _abi.SfmTargetMeshDesc()
-    d.ncomp = 2
+    d.ncomp = ncomp
     d.n_tiles = nb.shape[0]
-    d.fx_shape = (C.c_int32 * 3)(1, *self.fx.shape[2:])
-    d.fy_shape = (C.c_int32 * 3)(1, *self.fy.shape[2:])
+    lead = [1] * (3 - ncomp)
+    d.fx_shape = (C.c_int32 * 3)(*lead, *self.fx.shape[2:])
+    d.fy_shape = (C.c_int32 * 3)(*lead, *self.fy.shape[2:])
     d.n_fx = self.fx.shape[1]
     d.n_fy = self.fy.shape[1]
     d.nbor_fields = nb.shape[2]
-    d.stride = (C.c_float * 3)(1.0, *self.stride)
+    d.stride = (C.c_float * 3)(*([1.0] * (3 - ncomp)), *self.stride)
     d.nbors = self.nbors.data_ptr()
     d.fx = self.fx.data_ptr()
     d.fy = self.fy.data_ptr()
     self.desc = d
 
   def bind(self, x_t: torch.Tensor) -> _abi.SfmTargetMeshDesc:
-    if x_t.ndim != 4 or x_t.shape[0] != 2 or x_t.shape[1] != self.desc.n_tiles:
-      raise ValueError('x must be [2, n_tiles, y, x]')
-    self.desc.mesh_shape = (C.c_int32 * 3)(1, *x_t.shape[2:])
+    if (x_t.ndim != self.ncomp + 2 or x_t.shape[0] != self.ncomp or
+        x_t.shape[1] != self.desc.n_tiles):
+      raise ValueError('x must be [2, n_tiles, y, x] or [3, n_tiles, z, y, x]')
+    self.desc.mesh_shape = (C.c_int32 * 3)(*([1] * (3 - self.ncomp)), *x_t.shape[2:])
     return self.desc
 
   def __call__(self, x) -> DeviceArray:
@@ -88,7 +101,8 @@ class TargetMeshFn:
 def compute_target_mesh(nbor_data, x, fx, fy, stride=(20, 20)) -> np.ndarray:
   """Target positions for ONE tile mesh (stitch_elastic.py:624-676).
 
-  nbor_data: [4, 8] neighbour info of the tile; x, fx, fy as in the reference.
+  nbor_data: [4, 8 or 11] neighbour info of the tile; x, fx, fy as in the
+  reference (in-plane [2, n, y, x] or volumetric [3, n, z, y, x]).
   Evaluates the whole montage and returns the entry of the tile whose
   neighbour rows were given (the tile is identified by position 0 of a
   one-tile batch).

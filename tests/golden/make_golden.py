@@ -302,6 +302,62 @@ def gen_maps():
   save('compose_maps', **out)
 
 
+def gen_montage3d():
+  """compute_target_mesh for a synthetic 2 x 2 montage of 3-D tiles: hand-made
+  neighbour table (11 fields), smooth random meshes and flows."""
+  import functools as ft
+  from sofima import stitch_elastic
+  jax = sys.modules['jax']
+  jnp = sys.modules['jax.numpy']
+  rng = np.random.default_rng(77)
+  n, (mz, my, mx) = 4, (6, 10, 12)
+  stride = (8.0, 16.0, 16.0)  # zyx
+
+  def smooth(shape, amp):
+    a = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, 1, 1.5, 1.5))
+    return (a / np.abs(a).max() * amp).astype(np.float32)
+
+  x = smooth((3, n, mz, my, mx), 6.0)
+  fx = smooth((3, n, 5, 9, 4), 5.0)    # horizontal pairs: z, ortho (y), overlap (x)
+  fy = smooth((3, n, 5, 3, 11), 5.0)   # vertical pairs:   z, overlap (y), ortho (x)
+  fx[:, 0, 1, 2, 1] = np.nan
+  fy[:, 2, 3, 1, 5] = np.nan
+  x[:, 3, 2, 4, 4] = np.nan
+  nb = -np.ones((n, 4, 11), np.int32)
+  NI = stitch_elastic.NeighborInfo
+
+  def entry(nbor, flow_idx, dim, flow, off_o, off_z):
+    e = -np.ones(11, np.int32)
+    e[NI.nbor_idx], e[NI.flow_idx], e[NI.dim] = nbor, flow_idx, dim
+    fz, fyy, fxx = flow.shape[-3:]
+    e[NI.flow_size_z] = fz
+    e[NI.flow_size_overlap] = fxx if dim == 0 else fyy
+    e[NI.flow_size_ortho] = fyy if dim == 0 else fxx
+    e[NI.coarse_offset_ortho], e[NI.coarse_offset_z] = off_o, off_z
+    e[NI.fine_off_x], e[NI.fine_off_y], e[NI.fine_off_z] = rng.integers(-3, 4, 3)
+    return e
+
+  offs = {0: (3, -2), 1: (-4, 1), 2: (0, 0), 3: (2, 2)}
+  for t in range(n):
+    tx, ty = t % 2, t // 2
+    k = 0
+    if tx == 1:   # left neighbour: flow stored with the left tile
+      nb[t, k] = entry(t - 1, t - 1, 0, fx, *offs[t - 1]); k += 1
+    if tx == 0:
+      nb[t, k] = entry(t + 1, t, 0, fx, *offs[t]); k += 1
+    if ty == 1:
+      nb[t, k] = entry(t - 2, t - 2, 1, fy, *offs[(t - 2 + 1) % 4]); k += 1
+    if ty == 0:
+      nb[t, k] = entry(t + 2, t, 1, fy, *offs[(t + 1) % 4]); k += 1
+  tf = ft.partial(stitch_elastic.compute_target_mesh, x=jnp.asarray(x),
+                  fx=jnp.asarray(fx), fy=jnp.asarray(fy), stride=stride)
+  r = np.asarray(jax.vmap(tf)(jnp.asarray(nb)))
+  tg = np.transpose(r, [1, 0, 2, 3, 4]).astype(np.float32)
+  assert np.isfinite(tg).mean() > 0.1
+  save('montage3d', x=x, fx=fx, fy=fy, nbors=nb, stride=np.array(stride, np.float32),
+       tg=tg)
+
+
 def gen_mask_irregular():
   """map_utils.mask_irregular (pure NumPy / SciPy in the reference)."""
   rng = np.random.default_rng(33)
@@ -435,7 +491,7 @@ def gen_montage():
 
 
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'irregular', 'montage']
+  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'irregular', 'montage3d', 'montage']
   if 'xcorr' in which:
     gen_xcorr_np()
   if 'peaks' in which:
@@ -450,5 +506,7 @@ if __name__ == '__main__':
     gen_clean_flow()
   if 'irregular' in which:
     gen_mask_irregular()
+  if 'montage3d' in which:
+    gen_montage3d()
   if 'montage' in which:
     gen_montage()

@@ -156,3 +156,34 @@ def test_mask_irregular_kat_and_golden(gpu, golden):
   t = torch.from_numpy(g['m'].copy()).cuda()
   bad = map_utils.mask_irregular(t, (20.0, 16.0), frac=0.25, max_frac=1.1)
   np.testing.assert_array_equal(t.cpu().numpy(), g['map_a'])
+
+
+@pytest.mark.gpu
+def test_target_mesh_3d_golden_and_relax(gpu, golden):
+  """Volumetric montage: sfm_target_mesh vs the reference, and as the native
+  prev_fn of a 3-D relaxation vs the oracle."""
+  from oracle import maps_oracle, mesh_oracle
+  from sofima_amd import mesh, stitch_elastic
+  g = golden('montage3d')
+  stride = tuple(float(v) for v in g['stride'])
+  fn = stitch_elastic.TargetMeshFn(g['nbors'], g['fx'], g['fy'], stride)
+  got = np.array(fn(g['x']))
+  np.testing.assert_array_equal(np.isnan(got), np.isnan(g['tg']))
+  np.testing.assert_allclose(got, g['tg'], rtol=1e-5, atol=1e-4)
+  one = stitch_elastic.compute_target_mesh(g['nbors'][2], g['x'], g['fx'], g['fy'], stride)
+  np.testing.assert_allclose(one, g['tg'][:, 2], rtol=1e-5, atol=1e-4)
+  # relaxation with the volumetric target mesh as prev_fn
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.05, k=0.1,
+                               stride=stride[::-1], num_iters=30, max_iters=30,
+                               stop_v_max=1e-9, dt_max=100, start_cap=1.0,
+                               final_cap=10.0, prefer_orig_order=False)
+  x0 = np.nan_to_num(g['x']).astype(np.float32)
+  gx, ge, gt = mesh.relax_mesh(x0, None, cfg, mesh_force=mesh.elastic_mesh_3d,
+                               prev_fn=fn)
+  wx, we, wt = mesh_oracle.relax_mesh(
+      x0, None, cfg, mesh_force=mesh_oracle.elastic_mesh_3d,
+      prev_fn=lambda xx: maps_oracle.target_mesh_all(g['nbors'], xx, g['fx'], g['fy'],
+                                                     stride))
+  assert gt == wt == 30
+  np.testing.assert_allclose(np.array(gx), wx, atol=2e-3 * np.abs(wx).max())
+  np.testing.assert_allclose(ge, we, rtol=2e-2)

@@ -218,3 +218,14 @@ def test_mask_irregular_vs_golden(golden):
     np.testing.assert_array_equal(bad, g['bad_' + tag])
     np.testing.assert_array_equal(mm, g['map_' + tag])
     assert 0 < bad.sum() < bad.size
+
+
+def test_target_mesh_3d_vs_golden(golden):
+  """Volumetric compute_target_mesh restatement vs the reference (11 fields)."""
+  from oracle import maps_oracle
+  g = golden('montage3d')
+  got = maps_oracle.target_mesh_all(g['nbors'], g['x'], g['fx'], g['fy'],
+                                    tuple(g['stride']))
+  np.testing.assert_array_equal(np.isnan(got), np.isnan(g['tg']))
+  np.testing.assert_allclose(got, g['tg'], rtol=1e-5, atol=1e-4)
+  assert np.isfinite(g['tg']).mean() > 0.1
