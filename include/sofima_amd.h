@@ -276,7 +276,9 @@ typedef struct SfmMeshDesc {
   double final_cap;
   double cap_scale;
   int32_t cap_upscale_every;
-  int32_t remove_drift;
+  int32_t remove_drift;         /* 0 no; 1 subtract the global mean of x, v;
+                                   2 per-x-column means: what the reference
+                                   does for 5-D states (mesh.py:496-497)   */
   /* state, device float [ncomp, batch, z, y, x] */
   float* x;
   float* v;

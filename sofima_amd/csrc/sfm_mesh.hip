@@ -58,6 +58,8 @@ struct MeshParams {
   // integrator
   int fire;
   int remove_drift;
+  int drift_cols;  // reference quirk for 5-D arrays: drift means per x column
+  float n_col;     // nodes per x column (B * Z * Y) as the f32 mean divisor
   float gamma;
   float vv_dt;  // damped Verlet: fixed dt
   float f_alpha, f_inc, f_dec, alpha0;
@@ -344,7 +346,7 @@ advance_kernel(float* __restrict__ x, float* __restrict__ v,
                const float* __restrict__ a, MeshParams p,
                const Scalars* __restrict__ scal_in, Scalars* __restrict__ scal_out,
                const float* __restrict__ partials, int n_part_rows,
-               int pending) {
+               int pending, const float* __restrict__ colsum) {
   __shared__ float lds[kNP * kBlock];
   Scalars s;
   if (p.fire) {
@@ -373,7 +375,11 @@ advance_kernel(float* __restrict__ x, float* __restrict__ v,
       float vv = v[c * p.N + n];
       if (p.fire && pending) {
         vv = vv * s.gate;
-        if (p.remove_drift) {
+        if (p.drift_cols) {
+          const int xi = static_cast<int>(n % p.X);
+          xv = xv - colsum[c * p.X + xi] / p.n_col;
+          vv = vv - (colsum[(3 + c) * p.X + xi] / p.n_col) * s.gate;
+        } else if (p.remove_drift) {
           xv = xv - s.mx[c];
           vv = vv - s.mv[c];
         }
@@ -650,6 +656,29 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
   }
 }
 
+// Reference quirk Q3 (mesh.py:496-497): the drift means are taken over axes
+// (1, 2, 3); for a 5-D state [3, N, z, y, x] that is a mean per x COLUMN.
+// colsum[c][xi] = sum of x, colsum[3 + c][xi] = sum of v over the column, in a
+// fixed order (one workgroup per column and component).
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+drift_cols_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                  MeshParams p, float* __restrict__ colsum) {
+  __shared__ float lds[kNP * kBlock];
+  const int xi = blockIdx.x, c = blockIdx.y;
+  const long long rows = p.N / p.X;
+  float acc[2] = {0.f, 0.f};
+  for (long long r = threadIdx.x; r < rows; r += kBlock) {
+    acc[0] = acc[0] + x[c * p.N + r * p.X + xi];
+    acc[1] = acc[1] + v[c * p.N + r * p.X + xi];
+  }
+  block_sum(acc, 2, lds);
+  if (threadIdx.x == 0) {
+    colsum[c * p.X + xi] = acc[0];
+    colsum[(3 + c) * p.X + xi] = acc[1];
+  }
+}
+
 // Applies the pending gate / drift of the last step and emits the per-block
 // kinetic-energy partials (mesh.py:492-497, 584-586).
 template <int C>
@@ -657,7 +686,7 @@ __global__ void __launch_bounds__(kBlock)
 finish_kernel(float* __restrict__ x, float* __restrict__ v, MeshParams p,
               const Scalars* __restrict__ scal_in, Scalars* __restrict__ scal_out,
               const float* __restrict__ partials, int n_part_rows, int pending,
-              float* __restrict__ stat_partials) {
+              float* __restrict__ stat_partials, const float* __restrict__ colsum) {
   __shared__ float lds[kNP * kBlock];
   Scalars s;
   s.gate = 1.f;
@@ -683,7 +712,11 @@ finish_kernel(float* __restrict__ x, float* __restrict__ v, MeshParams p,
       float vv = v[c * p.N + n];
       if (p.fire && pending) {
         vv = vv * s.gate;
-        if (p.remove_drift) {
+        if (p.drift_cols) {
+          const int xi = static_cast<int>(n % p.X);
+          x[c * p.N + n] = x[c * p.N + n] - colsum[c * p.X + xi] / p.n_col;
+          vv = vv - (colsum[(3 + c) * p.X + xi] / p.n_col) * s.gate;
+        } else if (p.remove_drift) {
           x[c * p.N + n] = x[c * p.N + n] - s.mx[c];
           vv = vv - s.mv[c];
         }
@@ -1278,6 +1311,8 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
   }
   p->fire = d->fire;
   p->remove_drift = d->remove_drift;
+  p->drift_cols = d->remove_drift == 2;
+  p->n_col = static_cast<float>(p->N / p->X);
   p->gamma = static_cast<float>(d->gamma);
   p->vv_dt = static_cast<float>(d->dt);
   p->f_alpha = static_cast<float>(d->f_alpha);
@@ -1317,6 +1352,7 @@ struct MeshWorkspace {
   float* alt[3];       // tiled path: second (x, v, a) set, [ncomp * N] each
   u64* tile_part;      // tiled path: [n_tiles * kNP] {epoch, value} granules
   int* ticket;         // tiled path: last-workgroup counter
+  float* colsum;       // per-column drift sums [6][X] (remove_drift == 2)
   size_t bytes;
 };
 
@@ -1352,13 +1388,15 @@ TilePlan plan_tiles(int ncomp, long long planes, int Y, int X) {
   return best;
 }
 
-MeshWorkspace carve(void* ws, size_t prev_floats, size_t alt_floats, long long tiles) {
+MeshWorkspace carve(void* ws, size_t prev_floats, size_t alt_floats, long long tiles,
+                    int ncols) {
   sfm::Carver c(ws);
   MeshWorkspace w;
   w.prev_buf = prev_floats ? c.take<float>(prev_floats) : nullptr;
   for (int i = 0; i < 3; ++i) w.alt[i] = alt_floats ? c.take<float>(alt_floats) : nullptr;
   w.tile_part = tiles ? c.take<u64>((size_t)tiles * kNP) : nullptr;
   w.ticket = c.take<int>(4);
+  w.colsum = c.take<float>(6 * (size_t)(ncols > 0 ? ncols : 1));
   w.scal = c.take<Scalars>(2);
   w.partials = c.take<float>(kMaxBlocks * kNP);
   w.stat_part = c.take<float>(kMaxBlocks * 2);
@@ -1377,7 +1415,8 @@ MeshWorkspace carve_for(const SfmMeshDesc* d, void* ws, TilePlan* plan) {
                                 d->shape[2], d->shape[3]);
   if (plan) *plan = t;
   const size_t cn = (size_t)d->ncomp * n;
-  return carve(ws, d->target ? cn : 0, (t.tx && !d->target) ? cn : 0, t.tiles);
+  return carve(ws, d->target ? cn : 0, (t.tx && !d->target) ? cn : 0, t.tiles,
+               d->shape[3]);
 }
 
 }  // namespace
@@ -1413,10 +1452,10 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     return sfm::fail(SFM_ERR_INVALID, "x/v/a must be device pointers");
   if (!fire || !stats) return sfm::fail(SFM_ERR_INVALID, "fire/stats is NULL");
   if (d->num_iters < 0) return sfm::fail(SFM_ERR_INVALID, "num_iters < 0");
-  if (d->remove_drift && d->ncomp == 3 && d->shape[0] > 1)
+  if (d->remove_drift < 0 || d->remove_drift > 2 ||
+      (d->remove_drift == 2 && d->ncomp != 3))
     return sfm::fail(SFM_ERR_INVALID,
-                     "remove_drift on 5-D arrays (per-column means of the "
-                     "reference) is not implemented");
+                     "remove_drift: 0 none, 1 global mean, 2 per x column (3-D only)");
   if (d->target && d->prev)
     return sfm::fail(SFM_ERR_INVALID,
                      "Only one of: \"prev\" and \"prev_fn\" can be specified.");
@@ -1560,7 +1599,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
         if (p.fire) cur ^= 1;
       } else {
         SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
-                          &w.scal[cur ^ 1], w.partials, grid, pending ? 2 : 0);
+                          &w.scal[cur ^ 1], w.partials, grid, pending ? 2 : 0, w.colsum);
         cur ^= 1;
         if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
         sfm::prof_begin(sfm::kProfMesh, st);
@@ -1585,7 +1624,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     for (int it = 0; it < d->num_iters; ++it) {
       const int pending = it > 0;
       SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
-                        &w.scal[cur ^ 1], w.partials, grid, pending);
+                        &w.scal[cur ^ 1], w.partials, grid, pending, w.colsum);
       cur ^= 1;
       if (d->target)
         if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
@@ -1593,10 +1632,16 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       SFM_MESH_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
                         &w.scal[cur], cap0, w.partials);
       sfm::prof_end(sfm::kProfMesh, st);
+      if (p.fire && p.drift_cols) {
+        hipLaunchKernelGGL(drift_cols_kernel<3>, dim3(p.X, 3), dim3(kBlock), 0, st, d->x,
+                           d->v, p, w.colsum);
+        SFM_LAUNCH_CHECK();
+      }
     }
   }
   SFM_MESH_DISPATCH(finish_kernel, d->x, d->v, p, &w.scal[cur],
-                    &w.scal[cur ^ 1], w.partials, grid, finish_mode, w.stat_part);
+                    &w.scal[cur ^ 1], w.partials, grid, finish_mode, w.stat_part,
+                    w.colsum);
   cur ^= 1;
 #undef SFM_MESH_DISPATCH
   hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(kBlock), 0, st, w.stat_part,

@@ -249,7 +249,9 @@ def _chunk_desc(x_t, v_t, a_t, prev_t, config: IntegrationConfig, ncomp, links,
   d.final_cap = float(config.final_cap)
   d.cap_scale = float(config.cap_scale)
   d.cap_upscale_every = int(config.cap_upscale_every)
-  d.remove_drift = int(bool(config.remove_drift))
+  # The reference takes the drift means over axes (1, 2, 3) (mesh.py:496-497):
+  # global for [c, z, y, x] states, per x column for 5-D [c, n, z, y, x] states.
+  d.remove_drift = (2 if x_t.ndim == 5 else 1) if config.remove_drift else 0
   d.v = v_t.data_ptr()
   d.a = a_t.data_ptr()
   d.prev = prev_t.data_ptr() if prev_t is not None else None

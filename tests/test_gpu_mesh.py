@@ -292,3 +292,25 @@ def test_montage_relaxation_tiled_equals_multi_launch(gpu, golden):
   assert a[2] == b[2] == int(g['t'])
   np.testing.assert_allclose(np.array(a[0]), np.array(b[0]), atol=2e-3)
   np.testing.assert_allclose(np.array(a[0]), g['relaxed'], atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 5, 6, 7, 9), (3, 1, 6, 7, 9), (3, 6, 7, 9)])
+def test_remove_drift_axes_quirk_3d(gpu, shape):
+  """remove_drift takes means over axes (1, 2, 3) (mesh.py:496-497): global for
+  4-D states, per x column for 5-D ones (also with a batch of one)."""
+  from sofima_amd import mesh
+  rng = np.random.default_rng(9)
+  x0 = (rng.standard_normal(shape) * 2).astype(np.float32)
+  prev = (rng.standard_normal(shape) * 4).astype(np.float32)
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.05, k=0.1,
+                               stride=(10, 10, 10), num_iters=25, max_iters=25,
+                               stop_v_max=1e-9, dt_max=100, start_cap=1.0,
+                               final_cap=10.0, remove_drift=True)
+  gx, ge, gt = mesh.relax_mesh(x0.copy(), prev.copy(), cfg,
+                               mesh_force=mesh.elastic_mesh_3d)
+  wx, we, wt = mesh_oracle.relax_mesh(x0.copy(), prev.copy(), cfg,
+                                      mesh_force=mesh_oracle.elastic_mesh_3d)
+  assert gt == wt == 25
+  np.testing.assert_allclose(np.array(gx), wx, atol=1e-3 * np.abs(wx).max())
+  np.testing.assert_allclose(ge, we, rtol=1e-2)
