@@ -1,4 +1,4 @@
-import sys, time, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, time, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from sofima_amd import mesh
 shapes = [(2, 64, 204, 204), (2, 1, 2048, 2048), (3, 4, 100, 100, 100)]
