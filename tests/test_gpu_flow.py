@@ -509,3 +509,36 @@ def test_whole_overlap_offset_regime_vs_oracle(gpu):
   xo, yo, _, pr = got.squeeze()
   assert (xo, yo) == (-6.0, 11.0)
   check_flow(got, want, sharp_rtol=2e-3)
+
+
+@pytest.mark.gpu
+def test_full_size_bench_workload_properties(gpu):
+  """BASELINE configs[1] at full size (8192^2 pair, 40401 patches of 160^2).
+
+  Size-independent properties: a rigid integer content shift (plus noise) is
+  recovered EXACTLY by every patch; the field does not depend on how many
+  reference batches share a launch; a sample of patches agrees with the
+  oracle's FFT form.
+  """
+  from bench import synth_pair
+  from sofima_amd import flow_field as ff
+  pre, post = synth_pair(8192, 1002, shift=(3, -5))
+  calc = ff.JAXMaskedXCorrWithStatsCalculator()
+  f = calc.flow_field(pre, post, 160, 40, batch_size=1024)
+  assert f.shape == (4, 201, 201)
+  assert not np.isnan(f).any()
+  np.testing.assert_array_equal(f[0], -5.0)   # x: pre - post position of the content
+  np.testing.assert_array_equal(f[1], 3.0)
+  assert np.isfinite(f[2]).all()
+  old = ff.LAUNCH_PATCHES
+  try:
+    ff.LAUNCH_PATCHES = 1
+    g = calc.flow_field(pre, post, 160, 40, batch_size=1024)
+  finally:
+    ff.LAUNCH_PATCHES = old
+  np.testing.assert_array_equal(f, g)
+  # oracle on a corner crop with the same batch membership for its 64 patches
+  crop = (slice(0, 160 + 7 * 40), slice(0, 160 + 7 * 40))
+  fc = calc.flow_field(pre[crop], post[crop], 160, 40, batch_size=64)
+  want = flow_oracle.flow_field(pre[crop], post[crop], 160, 40, batch_size=64, workers=8)
+  check_flow(fc, want, sharp_rtol=2e-3)
