@@ -542,3 +542,41 @@ def test_full_size_bench_workload_properties(gpu):
   fc = calc.flow_field(pre[crop], post[crop], 160, 40, batch_size=64)
   want = flow_oracle.flow_field(pre[crop], post[crop], 160, 40, batch_size=64, workers=8)
   check_flow(fc, want, sharp_rtol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(8))
+def test_mfma_random_geometry_fuzz(gpu, seed):
+  """Random patch / post-patch sizes (odd, non multiples of 16, P != Q), image
+  sizes and starts that touch every image border: int8 MFMA == direct kernel."""
+  from scipy import ndimage
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(1000 + seed)
+  py, px = int(rng.integers(17, 201)), int(rng.integers(17, 161))
+  if py * px > 32768:
+    py = 32768 // px
+  qy, qx = int(rng.integers(9, py + 1)), int(rng.integers(9, px + 1))
+  if rng.random() < 0.4:
+    qy, qx = py, px
+  h, w = py + int(rng.integers(0, 90)), px + int(rng.integers(0, 90))
+  base = ndimage.gaussian_filter(rng.standard_normal((h + 8, w + 8)), 1.3)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  pre = np.ascontiguousarray(base[4:4 + h, 4:4 + w])
+  post = np.ascontiguousarray(base[5:5 + h, 2:2 + w])
+  b = 9
+  starts = np.stack([rng.integers(-5, h - py + 6, b), rng.integers(-5, w - px + 6, b)],
+                    axis=1)
+  starts[0] = (0, 0)
+  starts[1] = (h - py, w - px)              # last rows / columns of the image
+  post_starts = starts + np.array([(py - qy) // 2, (px - qx) // 2])
+  kw = dict(min_distance=2, threshold_rel=0.5, peak_radius=5,
+            post_patch_size=(qy, qx), post_starts=post_starts)
+  ref = flow_field.batched_xcorr_peaks(pre, post, None, None, (py, px), starts, None,
+                                       method=1, **kw)
+  got = flow_field.batched_xcorr_peaks(pre, post, None, None, (py, px), starts, None,
+                                       method=2, **kw)
+  np.testing.assert_array_equal(np.isnan(got), np.isnan(ref), err_msg=str((py, px, qy, qx)))
+  np.testing.assert_array_equal(got[:, :2], ref[:, :2], err_msg=str((py, px, qy, qx)))
+  ok = np.isfinite(ref[:, 2])
+  np.testing.assert_allclose(got[ok, 2], ref[ok, 2], rtol=1e-2)
+  np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=2e-3, atol=1e-6)
