@@ -46,9 +46,25 @@
 //    by the prep kernel: one coalesced gather per output instead of eight.
 //    For P != Q (post_patch_size) the general 8-lookup box-sum form is used.
 //
+// 4. Schedule.  Workgroups are persistent (two per CU) and take patches from
+//    a dynamic queue (the issue arbiter favours the older workgroup of a CU);
+//    staging is one global round trip (unaligned 16-byte loads of both
+//    patches), the table G is pulled into L2 by LDS-direct loads nothing waits
+//    for; the first-peak search runs on what the kernel leaves behind (surface
+//    maximum + hot list) in mfma_first_peak_kernel.  One launch carries several
+//    reference batches (SfmXcorrDesc.group keeps their coupling apart).
+//
+// 5. Masked images (MODE raw): the same kernel forms exact integer products of
+//    operand planes (value, validity, split square); eight passes + an f64
+//    assembly kernel give Padfield's normalised correlation.
+//
 // LDS per workgroup (P = Q = 160): pre patch (Py + 34) x 176 B + post patch
 // (Qy + 3) x 208 B = 68 KB -> two workgroups (8 waves) per CU.  Row pitches
 // 176 / 208 keep the b128 / b32 fragment reads bank-conflict free.
+//
+// Build switches (experiments): SFM_MFMA_TIMING
+// (in-kernel phase ticks), SFM_ABLATE_EPILOGUE, SFM_NO_TOUCH, SFM_AF_PREFETCH,
+// SFM_EPI_QG / SFM_EPI_DEPTH.
 #include "sfm_common.h"
 
 #ifndef SFM_EPI_QG
