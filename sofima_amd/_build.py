@@ -22,7 +22,7 @@ SOURCES = {
     'sfm_xcorr_mfma.hip': ((['-DSFM_MFMA_TIMING']
                             if os.environ.get('SFM_MFMA_TIMING') else []) +
                            os.environ.get('SFM_MFMA_FLAGS', '').split()),
-    'sfm_maps.hip': ['-ffp-contract=off'],
+    'sfm_maps.hip': ['-ffp-contract=off'] + os.environ.get('SFM_MAPS_FLAGS', '').split(),
     'sfm_flowutils.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',

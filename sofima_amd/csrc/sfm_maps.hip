@@ -9,6 +9,7 @@
 // thread per output node, coalesced along x.
 #include "sfm_common.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace {
@@ -153,71 +154,110 @@ struct TargetArgs {
 // update is NaN (per component); the last non-NaN update wins.  In-plane
 // montages (ncomp 2, one section) and volumetric ones (ncomp 3: z start /
 // target offsets and the z fine offset of stitch_elastic.py:509-518, 544-561).
+// Everything about one neighbour entry that does not depend on the node,
+// derived once per workgroup (a workgroup works on ONE tile) and held in
+// scalar registers.
+struct NbEntry {
+  int valid, mult, dim;
+  int tg[3], st[3], fsz[3];  // zyx: paste origin, compose start, flow size
+  int n_f, fi, nb_i;
+  int fine[3];               // x, y, z fine offsets times mult
+};
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
   const SfmTargetMeshDesc& d = a.d;
   const int nc = d.ncomp;
   const int mz = d.mesh_shape[0], my = d.mesh_shape[1], mx = d.mesh_shape[2];
   const long long mn = (long long)mz * my * mx;
-  const long long total = (long long)d.n_tiles * mn;
   const float sz = d.stride[0], sy = d.stride[1], sx = d.stride[2];
-  for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < total;
-       i += (long long)gridDim.x * kBlock) {
-    const int tile = static_cast<int>(i / mn);
-    const int node = static_cast<int>(i - tile * mn);
-    const int tx = node % mx;
-    const int ty = (node / mx) % my;
-    const int tz = node / (mx * my);
+  const int tile = blockIdx.y;
+  __shared__ NbEntry s_e[4];
+  if (threadIdx.x < 4) {
+    const int* nb = d.nbors + ((long long)tile * 4 + threadIdx.x) * d.nbor_fields;
+    NbEntry e;
+    const int nbor = nb[kNbor];
+    e.valid = nbor != -1;
+    const int flow_idx = nb[kFlow];
+    e.dim = nb[kDim] == 0 ? 0 : 1;
+    e.mult = nbor == flow_idx ? 1 : -1;
+    const int off_ortho = nb[kOffOrtho];
+    const int f_ortho = nb[kSizeOrtho], f_overlap = nb[kSizeOverlap];
+    const int* fshape = e.dim == 0 ? d.fx_shape : d.fy_shape;
+    e.n_f = e.dim == 0 ? d.n_fx : d.n_fy;
+    for (int k = 0; k < 3; ++k) e.fsz[k] = fshape[k];
+    // size of the neighbour mesh along / across the overlap direction
+    const int par_n = e.dim == 0 ? mx : my;
+    const int ortho_n = e.dim == 0 ? my : mx;
+    const int start_par = e.mult == 1 ? par_n - f_overlap : 0;
+    const bool s_hi = (e.mult == 1 && off_ortho > 0) || (e.mult == -1 && off_ortho < 0);
+    const int start_ortho = s_hi ? ortho_n - f_ortho : 0;
+    e.st[1] = e.dim == 0 ? start_ortho : start_par;
+    e.st[2] = e.dim == 0 ? start_par : start_ortho;
+    const int tg_par = e.mult == 1 ? 0 : par_n - f_overlap;
+    const bool t_hi = (e.mult == 1 && off_ortho < 0) || (e.mult == -1 && off_ortho > 0);
+    const int tg_ortho = t_hi ? ortho_n - f_ortho : 0;
+    e.tg[1] = e.dim == 0 ? tg_ortho : tg_par;
+    e.tg[2] = e.dim == 0 ? tg_par : tg_ortho;
+    e.st[0] = e.tg[0] = 0;
+    e.fine[2] = 0;
+    if (nc == 3) {
+      const int off_z = nb[kOffZ], f_z = nb[kSizeZ];
+      const bool sz_hi = (e.mult == 1 && off_z > 0) || (e.mult == -1 && off_z < 0);
+      const bool tz_hi = (e.mult == 1 && off_z < 0) || (e.mult == -1 && off_z > 0);
+      e.st[0] = sz_hi ? mz - f_z : 0;
+      e.tg[0] = tz_hi ? mz - f_z : 0;
+      e.fine[2] = e.mult * nb[kFineZ];
+    }
+    e.fine[0] = e.mult * nb[kFineX];
+    e.fine[1] = e.mult * nb[kFineY];
+    // jax clamps the dynamic indices; valid data never needs it
+    e.fi = min(max(flow_idx, 0), e.n_f - 1);
+    e.nb_i = min(max(nbor, 0), d.n_tiles - 1);
+    s_e[threadIdx.x] = e;
+  }
+  __syncthreads();
+  // A wave covers 16 columns x 4 rows, a workgroup 16 x 16 nodes: waves are
+  // either inside an overlap strip or outside (with one row of 64 nodes per
+  // wave, every wave crossing a 20-node wide left / right strip ran the
+  // sampling path with 10 % of its lanes).
+  const int n_bx = (mx + 15) >> 4;
+  const int bx = blockIdx.x % n_bx, by = blockIdx.x / n_bx;
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = bx * 16 + (lane & 15);
+    const int row = by * 16 + wave * 4 + (lane >> 4);  // tz * my + ty
+    if (tx >= mx || row >= mz * my) return;
+    const int tz = mz == 1 ? 0 : row / my;
+    const int ty = row - tz * my;
+    const int node = row * mx + tx;
     float rx = NAN, ry = NAN, rz = NAN;
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int* nb = d.nbors + ((long long)tile * 4 + j) * d.nbor_fields;
-      const int nbor = nb[kNbor];
-      if (nbor == -1) continue;
-      const int flow_idx = nb[kFlow];
-      const int dim = nb[kDim] == 0 ? 0 : 1;
-      const int mult = nbor == flow_idx ? 1 : -1;
-      const int off_ortho = nb[kOffOrtho];
-      const int f_ortho = nb[kSizeOrtho], f_overlap = nb[kSizeOverlap];
-      const int* fshape = dim == 0 ? d.fx_shape : d.fy_shape;
-      const int n_f = dim == 0 ? d.n_fx : d.n_fy;
-      const float* farr = dim == 0 ? d.fx : d.fy;
-      const int fz_n = fshape[0], fy_n = fshape[1], fx_n = fshape[2];
-      // size of the neighbour mesh along / across the overlap direction
-      const int par_n = dim == 0 ? mx : my;
-      const int ortho_n = dim == 0 ? my : mx;
-      const int start_par = mult == 1 ? par_n - f_overlap : 0;
-      const bool s_hi = (mult == 1 && off_ortho > 0) || (mult == -1 && off_ortho < 0);
-      const int start_ortho = s_hi ? ortho_n - f_ortho : 0;
-      const int st_y = dim == 0 ? start_ortho : start_par;
-      const int st_x = dim == 0 ? start_par : start_ortho;
-      const int tg_par = mult == 1 ? 0 : par_n - f_overlap;
-      const bool t_hi = (mult == 1 && off_ortho < 0) || (mult == -1 && off_ortho > 0);
-      const int tg_ortho = t_hi ? ortho_n - f_ortho : 0;
-      const int tg_y = dim == 0 ? tg_ortho : tg_par;
-      const int tg_x = dim == 0 ? tg_par : tg_ortho;
-      int st_z = 0, tg_z = 0;
-      if (nc == 3) {
-        const int off_z = nb[kOffZ], f_z = nb[kSizeZ];
-        const bool sz_hi = (mult == 1 && off_z > 0) || (mult == -1 && off_z < 0);
-        const bool tz_hi = (mult == 1 && off_z < 0) || (mult == -1 && off_z > 0);
-        st_z = sz_hi ? mz - f_z : 0;
-        tg_z = tz_hi ? mz - f_z : 0;
-      }
-      const int uz = tz - tg_z, uy = ty - tg_y, ux = tx - tg_x;
+      if (!uniform(s_e[j].valid)) continue;
+      const int uz = tz - uniform(s_e[j].tg[0]);
+      const int uy = ty - uniform(s_e[j].tg[1]);
+      const int ux = tx - uniform(s_e[j].tg[2]);
+      const int fz_n = uniform(s_e[j].fsz[0]), fy_n = uniform(s_e[j].fsz[1]),
+                fx_n = uniform(s_e[j].fsz[2]);
       if (uz < 0 || uz >= fz_n || uy < 0 || uy >= fy_n || ux < 0 || ux >= fx_n) continue;
-      // jax clamps the dynamic index; valid data never needs it
-      const int fi = min(max(flow_idx, 0), n_f - 1);
+      const int dim = uniform(s_e[j].dim), n_f = uniform(s_e[j].n_f);
+      const float* farr = dim == 0 ? d.fx : d.fy;
       const long long fvol = (long long)fz_n * fy_n * fx_n;
-      const long long fo =
-          (long long)fi * fvol + ((long long)uz * fy_n + uy) * fx_n + ux;
-      const float fm = static_cast<float>(mult);
+      const long long fo = (long long)uniform(s_e[j].fi) * fvol +
+                           ((long long)uz * fy_n + uy) * fx_n + ux;
+      const float fm = static_cast<float>(uniform(s_e[j].mult));
       const float m1x = fm * farr[fo];
       const float m1y = fm * farr[(long long)n_f * fvol + fo];
       // compose_maps_fast(flow @ start, neighbour mesh @ 0, mode constant)
-      const float ref1x = (static_cast<float>(ux) + static_cast<float>(st_x)) * sx;
-      const float ref1y = (static_cast<float>(uy) + static_cast<float>(st_y)) * sy;
+      const float ref1x =
+          (static_cast<float>(ux) + static_cast<float>(uniform(s_e[j].st[2]))) * sx;
+      const float ref1y =
+          (static_cast<float>(uy) + static_cast<float>(uniform(s_e[j].st[1]))) * sy;
       const float qx = (ref1x + m1x) / sx;
       const float qy = (ref1y + m1y) / sy;
-      const int nb_i = min(max(nbor, 0), d.n_tiles - 1);
+      const int nb_i = uniform(s_e[j].nb_i);
       const float* nx0 = a.x + (long long)nb_i * mn;
       const float* nx1 = a.x + ((long long)d.n_tiles + nb_i) * mn;
       float ux_v, uy_v, uz_v = NAN;
@@ -226,16 +266,17 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
         uy_v = sample2(nx1, my, mx, qy, qx, true, 0, 0.f, sy) - ref1y;
       } else {
         const float m1z = fm * farr[2LL * n_f * fvol + fo];
-        const float ref1z = (static_cast<float>(uz) + static_cast<float>(st_z)) * sz;
+        const float ref1z =
+            (static_cast<float>(uz) + static_cast<float>(uniform(s_e[j].st[0]))) * sz;
         const float qz = (ref1z + m1z) / sz;
         const float* nx2 = a.x + (2LL * d.n_tiles + nb_i) * mn;
         ux_v = sample3(nx0, mz, my, mx, qz, qy, qx, true, 2, 0.f, sx) - ref1x;
         uy_v = sample3(nx1, mz, my, mx, qz, qy, qx, true, 1, 0.f, sy) - ref1y;
         uz_v = sample3(nx2, mz, my, mx, qz, qy, qx, true, 0, 0.f, sz) - ref1z;
-        uz_v = uz_v + static_cast<float>(mult * nb[kFineZ]);
+        uz_v = uz_v + static_cast<float>(uniform(s_e[j].fine[2]));
       }
-      ux_v = ux_v + static_cast<float>(mult * nb[kFineX]);
-      uy_v = uy_v + static_cast<float>(mult * nb[kFineY]);
+      ux_v = ux_v + static_cast<float>(uniform(s_e[j].fine[0]));
+      uy_v = uy_v + static_cast<float>(uniform(s_e[j].fine[1]));
       if (!isnan(ux_v)) rx = ux_v;
       if (!isnan(uy_v)) ry = uy_v;
       if (!isnan(uz_v)) rz = uz_v;
@@ -269,10 +310,15 @@ int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
   a.d = *d;
   a.x = x;
   a.out = out;
-  const long long total =
-      (long long)d->n_tiles * d->mesh_shape[0] * d->mesh_shape[1] * d->mesh_shape[2];
-  hipLaunchKernelGGL(target_mesh_kernel, dim3(grid_for(total)), dim3(kBlock), 0, st,
-                     a);
+  const long long per_tile =
+      (long long)d->mesh_shape[0] * d->mesh_shape[1] * d->mesh_shape[2];
+  if (d->nbor_fields > 11)
+    return fail(SFM_ERR_INVALID, "target mesh: at most 11 neighbour fields");
+  if (per_tile > 0x7fffffffLL) return fail(SFM_ERR_INVALID, "target mesh: tile too large");
+  const long long gx = (long long)((d->mesh_shape[2] + 15) / 16) *
+                       (((long long)d->mesh_shape[0] * d->mesh_shape[1] + 15) / 16);
+  hipLaunchKernelGGL(target_mesh_kernel, dim3(static_cast<unsigned>(gx), d->n_tiles),
+                     dim3(kBlock), 0, st, a);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }
