@@ -93,3 +93,17 @@ def test_product_code_never_imports_the_oracle():
       if f.endswith(('.py', '.hip', '.h', '.cpp')):
         src = open(os.path.join(dirpath, f)).read()
         assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+
+
+def test_integration_md_binding_matches_header():
+  """The maintainer-side ctypes stub shown in INTEGRATION.md lists the fields of
+  SfmXcorrDesc in the order of include/sofima_amd.h."""
+  import os
+  import re
+  from sofima_amd import _abi
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  text = open(os.path.join(root, 'INTEGRATION.md')).read()
+  block = text[text.index('class SfmXcorrDesc(C.Structure):'):]
+  block = block[:block.index('lib.sfm_xcorr_workspace_bytes.restype')]
+  names = re.findall(r"\('(\w+)',", block)
+  assert names == [f[0] for f in _abi.SfmXcorrDesc._fields_]
