@@ -479,7 +479,7 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
                          const Scalars* __restrict__ scal_in,
                          Scalars* __restrict__ scal_out, float fixed_cap,
                          u64* __restrict__ partials, int* __restrict__ ticket,
-                         unsigned epoch, int pending, int nty, int ntx) {
+                         int pending, int nty, int ntx) {
   constexpr int C = 2;
   constexpr int TW = TX + 2;
   constexpr int kRows = TY * TX / kBlock;  // nodes per thread
@@ -488,6 +488,10 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
   __shared__ float xt[C][(TY + 2) * TW];
   __shared__ float lds[kNP * kBlock];
   __shared__ int s_last;
+  // step counter in device memory (advanced by the reducing workgroup), so
+  // that a launch has no per-step argument and steps can be replayed from a
+  // hipGraph
+  const unsigned epoch = static_cast<unsigned>(ticket[1]) + 1u;
 
   Scalars s;
   if (p.fire) {
@@ -652,6 +656,7 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
     Scalars in = *scal_in, o;
     scalars_from_sums(in, acc, p, &o);
     *scal_out = o;
+    ticket[1] = static_cast<int>(epoch);
     __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -1309,6 +1314,27 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
   return SFM_OK;
 }
 
+// hipGraph replay of the step loop.  Measured on MI355X / ROCm 7.2 it is 10-17 %
+// SLOWER than enqueueing the kernels (28.0 -> 30.7 us/step on [3,16,12,12,12],
+// 14.5 -> 16.9 on [2,4,17,17]): the step loop is bound by the device-side
+// launch latency of dependent kernels, not by host enqueue cost, and a graph
+// node costs more than an async launch.  Opt-in with SFM_MESH_GRAPH=1.
+constexpr long long kGraphMaxNodes = 400000;
+
+bool graph_enabled() {
+  const char* e = getenv("SFM_MESH_GRAPH");
+  return e && e[0] == '1';
+}
+
+// Stream capture is not allowed on the legacy default stream the caller may
+// hand us, so the two-step graph is captured on a private stream (nothing
+// executes during capture) and launched on the caller's stream.
+hipStream_t capture_stream() {
+  static thread_local hipStream_t cs = nullptr;
+  if (!cs && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) cs = nullptr;
+  return cs;
+}
+
 bool persistent_enabled() {
   const char* e = getenv("SFM_MESH_PERSISTENT");
   return !(e && e[0] == '0');
@@ -1550,75 +1576,124 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
 
   int cur = 0;
   int finish_mode = d->num_iters > 0 ? 1 : 0;
-  if (tiles.tx && d->num_iters > 0) {
+  const bool tiled = tiles.tx && d->num_iters > 0;
+  float* bufs[2][3] = {{d->x, d->v, d->a}, {w.alt[0], w.alt[1], w.alt[2]}};
+  int in = 0;
+  const bool fused = tiled && !d->target;
+  const int tgrid = static_cast<int>(tiles.tiles);
+  if (tiled) {
     // LDS-tiled integrator (2-D): one launch per step, or advance + prev_fn +
     // integrate when the spring targets depend on the advanced positions.
-    SFM_HIP_CHECK(hipMemsetAsync(w.ticket, 0, sizeof(int), st));
+    SFM_HIP_CHECK(hipMemsetAsync(w.ticket, 0, 2 * sizeof(int), st));
     SFM_HIP_CHECK(hipMemsetAsync(w.tile_part, 0, (size_t)tiles.tiles * kNP * sizeof(u64), st));
-    float* bufs[2][3] = {{d->x, d->v, d->a}, {w.alt[0], w.alt[1], w.alt[2]}};
-    int in = 0;
-    const bool fused = !d->target;
-    const int tgrid = static_cast<int>(tiles.tiles);
+    finish_mode = 2;
+  }
+  // One integration step, enqueued on `ls`.  The host-side state it toggles
+  // (scalar / buffer ping-pong) has period two, and no launch carries a
+  // per-step argument, so two consecutive steps can be replayed from a graph.
+  hipStream_t ls = st;
+  bool timing = true;
 #define SFM_TILED(TY, TX, FUSED, XI, VI, AI, XO, VO, AO, PEND)                      \
   hipLaunchKernelGGL((integrate_tiled2d_kernel<TY, TX, FUSED>), dim3(tgrid),        \
-                     dim3(kBlock), 0, st, XI, VI, AI, prev_ptr, XO, VO, AO, p,      \
+                     dim3(kBlock), 0, ls, XI, VI, AI, prev_ptr, XO, VO, AO, p,      \
                      &w.scal[cur], &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket,   \
-                     static_cast<unsigned>(it + 1), PEND, tiles.nty, tiles.ntx)
-    for (int it = 0; it < d->num_iters; ++it) {
-      const int pending = it > 0;
-      if (fused) {
-        float** bi = bufs[in];
-        float** bo = bufs[in ^ 1];
-        sfm::prof_begin(sfm::kProfMesh, st);
-        if (tiles.tx == 64)
-          SFM_TILED(16, 64, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
-        else
-          SFM_TILED(32, 32, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
-        sfm::prof_end(sfm::kProfMesh, st);
-        SFM_LAUNCH_CHECK();
-        in ^= 1;
-        if (p.fire) cur ^= 1;
-      } else {
-        SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
-                          &w.scal[cur ^ 1], w.partials, grid, pending ? 2 : 0, w.colsum);
-        cur ^= 1;
-        if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
-        sfm::prof_begin(sfm::kProfMesh, st);
-        if (tiles.tx == 64)
-          SFM_TILED(16, 64, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
-        else
-          SFM_TILED(32, 32, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
-        sfm::prof_end(sfm::kProfMesh, st);
-        SFM_LAUNCH_CHECK();
-        if (p.fire) cur ^= 1;
-      }
-    }
-#undef SFM_TILED
-    if (in == 1) {
-      const size_t bytes = (size_t)p.ncomp * p.N * sizeof(float);
-      SFM_HIP_CHECK(hipMemcpyAsync(d->x, w.alt[0], bytes, hipMemcpyDeviceToDevice, st));
-      SFM_HIP_CHECK(hipMemcpyAsync(d->v, w.alt[1], bytes, hipMemcpyDeviceToDevice, st));
-      SFM_HIP_CHECK(hipMemcpyAsync(d->a, w.alt[2], bytes, hipMemcpyDeviceToDevice, st));
-    }
-    finish_mode = 2;
-  } else {
-    for (int it = 0; it < d->num_iters; ++it) {
-      const int pending = it > 0;
-      SFM_MESH_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
+                     PEND, tiles.nty, tiles.ntx)
+#define SFM_STEP_DISPATCH(KERNEL, ...)                                       \
+  do {                                                                       \
+    if (p.ncomp == 2)                                                        \
+      hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(kBlock), 0, ls,         \
+                         __VA_ARGS__);                                       \
+    else                                                                     \
+      hipLaunchKernelGGL(KERNEL<3>, dim3(grid), dim3(kBlock), 0, ls,         \
+                         __VA_ARGS__);                                       \
+    SFM_LAUNCH_CHECK();                                                      \
+  } while (0)
+  auto step = [&](int pending) -> int {
+    if (fused) {
+      float** bi = bufs[in];
+      float** bo = bufs[in ^ 1];
+      if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
+      if (tiles.tx == 64)
+        SFM_TILED(16, 64, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
+      else
+        SFM_TILED(32, 32, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
+      if (timing) sfm::prof_end(sfm::kProfMesh, ls);
+      SFM_LAUNCH_CHECK();
+      in ^= 1;
+      if (p.fire) cur ^= 1;
+    } else if (tiled) {
+      SFM_STEP_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
+                        &w.scal[cur ^ 1], w.partials, grid, pending ? 2 : 0, w.colsum);
+      cur ^= 1;
+      if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, ls)) return rc;
+      if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
+      if (tiles.tx == 64)
+        SFM_TILED(16, 64, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
+      else
+        SFM_TILED(32, 32, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
+      if (timing) sfm::prof_end(sfm::kProfMesh, ls);
+      SFM_LAUNCH_CHECK();
+      if (p.fire) cur ^= 1;
+    } else {
+      SFM_STEP_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
                         &w.scal[cur ^ 1], w.partials, grid, pending, w.colsum);
       cur ^= 1;
       if (d->target)
-        if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
-      sfm::prof_begin(sfm::kProfMesh, st);
-      SFM_MESH_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
+        if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, ls)) return rc;
+      if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
+      SFM_STEP_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
                         &w.scal[cur], cap0, w.partials);
-      sfm::prof_end(sfm::kProfMesh, st);
+      if (timing) sfm::prof_end(sfm::kProfMesh, ls);
       if (p.fire && p.drift_cols) {
-        hipLaunchKernelGGL(drift_cols_kernel<3>, dim3(p.X, 3), dim3(kBlock), 0, st, d->x,
+        hipLaunchKernelGGL(drift_cols_kernel<3>, dim3(p.X, 3), dim3(kBlock), 0, ls, d->x,
                            d->v, p, w.colsum);
         SFM_LAUNCH_CHECK();
       }
     }
+    return SFM_OK;
+  };
+#undef SFM_STEP_DISPATCH
+
+  int it = 0;
+  if (d->num_iters > 0) {
+    if (int rc = step(0)) return rc;
+    it = 1;
+  }
+  // Launch-bound meshes (small, several launches per step): replay pairs of
+  // steps from a hipGraph instead of enqueueing every kernel from the host.
+  if (graph_enabled() && !sfm::profiling() && p.N <= kGraphMaxNodes &&
+      d->num_iters - it >= 8) {
+    const int pairs = (d->num_iters - it) / 2;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cs = capture_stream();
+    bool ok = cs != nullptr &&
+              hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      ls = cs;
+      timing = false;
+      const int rc0 = step(1);
+      const int rc1 = rc0 ? rc0 : step(1);
+      ls = st;
+      timing = true;
+      ok = hipStreamEndCapture(cs, &graph) == hipSuccess && graph && !rc1;
+      ok = ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      for (int k = 0; ok && k < pairs; ++k) ok = hipGraphLaunch(exec, st) == hipSuccess;
+      if (exec) (void)hipGraphExecDestroy(exec);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!ok) return sfm::fail(SFM_ERR_HIP, "mesh: hipGraph capture / replay failed");
+      it += 2 * pairs;
+    }
+    (void)hipGetLastError();
+  }
+  for (; it < d->num_iters; ++it)
+    if (int rc = step(1)) return rc;
+#undef SFM_TILED
+  if (in == 1) {
+    const size_t bytes = (size_t)p.ncomp * p.N * sizeof(float);
+    SFM_HIP_CHECK(hipMemcpyAsync(d->x, w.alt[0], bytes, hipMemcpyDeviceToDevice, st));
+    SFM_HIP_CHECK(hipMemcpyAsync(d->v, w.alt[1], bytes, hipMemcpyDeviceToDevice, st));
+    SFM_HIP_CHECK(hipMemcpyAsync(d->a, w.alt[2], bytes, hipMemcpyDeviceToDevice, st));
   }
   SFM_MESH_DISPATCH(finish_kernel, d->x, d->v, p, &w.scal[cur],
                     &w.scal[cur ^ 1], w.partials, grid, finish_mode, w.stat_part,

@@ -314,3 +314,21 @@ def test_remove_drift_axes_quirk_3d(gpu, shape):
   assert gt == wt == 25
   np.testing.assert_allclose(np.array(gx), wx, atol=1e-3 * np.abs(wx).max())
   np.testing.assert_allclose(ge, we, rtol=1e-2)
+
+
+@pytest.mark.gpu
+def test_graph_replay_is_identical_to_async_launches(gpu):
+  """SFM_MESH_GRAPH=1 replays pairs of steps from a hipGraph: bit-identical."""
+  from sofima_amd import mesh
+  rng = np.random.default_rng(4)
+  shape = (3, 6, 8, 9, 10)
+  x0 = (rng.standard_normal(shape)).astype(np.float32)
+  prev = (rng.standard_normal(shape) * 3).astype(np.float32)
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.05, k=0.1, stride=(10, 10, 10),
+                               num_iters=41, max_iters=41, stop_v_max=1e-9, dt_max=100,
+                               start_cap=1.0, final_cap=10.0, remove_drift=True)
+  run = lambda: mesh.relax_mesh(x0.copy(), prev.copy(), cfg, mesh_force=mesh.elastic_mesh_3d)
+  a = _with_env({'SFM_MESH_GRAPH': '0'}, run)
+  b = _with_env({'SFM_MESH_GRAPH': '1'}, run)
+  np.testing.assert_array_equal(np.array(a[0]), np.array(b[0]))
+  assert a[1] == b[1] and a[2] == b[2] == 41
