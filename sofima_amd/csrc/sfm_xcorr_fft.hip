@@ -137,6 +137,7 @@ int grid_for(long long n) {
 
 // Plan cache: (rank, F, batch, type) -> handle.  Plans own their work areas.
 std::mutex g_plan_mu;
+std::mutex g_exec_mu;  // plans carry their stream: enqueueing on a plan is serialised
 std::map<std::tuple<int, int, int, int, int, int>, hipfftHandle> g_plans;
 
 int get_plan(const FftGeo& g, int batch, hipfftType type, hipfftHandle* out) {
@@ -221,6 +222,7 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
                   const float* va, const float* vb, float* surface, float* den,
                   float* ov, unsigned int* maxima, void* ws) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
+  std::lock_guard<std::mutex> exec_lock(g_exec_mu);
   const FftGeo g = make_fft_geo(d);
   const bool masked = d->pre_mask || d->post_mask;
   const int nb_max = sub_batch(g, masked, d->batch);
