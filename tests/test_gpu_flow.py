@@ -580,3 +580,50 @@ def test_mfma_random_geometry_fuzz(gpu, seed):
   ok = np.isfinite(ref[:, 2])
   np.testing.assert_allclose(got[ok, 2], ref[ok, 2], rtol=1e-2)
   np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_concurrent_python_threads(gpu):
+  """The boundary is re-entrant: flow on the matrix cores, the FFT
+  form and a mesh relaxation called from four threads at once give the results
+  of the same calls made one after the other."""
+  import threading
+  from scipy import ndimage
+  from sofima_amd import flow_field, mesh
+  rng = np.random.default_rng(12)
+  base = ndimage.gaussian_filter(rng.standard_normal((400, 420)), 1.5)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  vol = ndimage.gaussian_filter(rng.standard_normal((60, 70, 72)), 1.2)
+  vol = ((vol - vol.min()) / (vol.max() - vol.min()) * 255).astype(np.uint8)
+  prev = (rng.standard_normal((2, 1, 60, 70)) * 3).astype(np.float32)
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(40, 40),
+                               num_iters=50, max_iters=50, stop_v_max=1e-9, dt_max=100,
+                               start_cap=0.1, final_cap=10.0)
+  jobs = [
+      lambda: flow_field.JAXMaskedXCorrWithStatsCalculator().flow_field(
+          base[:384, :400], base[3:387, 5:405], 96, 24, batch_size=64),
+      lambda: flow_field.JAXMaskedXCorrWithStatsCalculator().flow_field(
+          base[8:392, 4:404], base[5:389, 9:409], 64, 16, batch_size=128),
+      lambda: flow_field.JAXMaskedXCorrWithStatsCalculator(method=3).flow_field(
+          vol[:56, :64, :64], vol[2:58, 3:67, 1:65], (32, 40, 40), 8, batch_size=4),
+      lambda: np.array(mesh.relax_mesh(np.zeros_like(prev), prev, cfg)[0]),
+  ]
+  want = [j() for j in jobs]
+  for _ in range(3):
+    got = [None] * len(jobs)
+    errs = []
+
+    def run(i):
+      try:
+        got[i] = jobs[i]()
+      except Exception as e:  # pylint: disable=broad-except
+        errs.append(e)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+      t.start()
+    for t in threads:
+      t.join()
+    assert not errs, errs
+    for g, w in zip(got, want):
+      np.testing.assert_array_equal(g, w)
