@@ -181,16 +181,20 @@ def _side_stream(dev) -> torch.cuda.Stream:
 
 def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray,
                  post_starts: np.ndarray, batch_size: int,
-                 progress_fn=None) -> np.ndarray:
+                 progress_fn=None, starts_cache=None) -> np.ndarray:
   """Enqueues every batch, returns peaks [n_batches * batch_size, dim + 2]."""
   lib = _abi.load()
   nd = res.ndim
   n = pre_starts.shape[0]
   assert n % batch_size == 0
   n_batches = n // batch_size
-  starts = torch.from_numpy(
-      np.ascontiguousarray(
-          np.stack([pre_starts, post_starts]).astype(np.int32))).to(res.dev)
+  starts = None if starts_cache is None else starts_cache.get(res.dev)
+  if starts is None:
+    starts = torch.from_numpy(
+        np.ascontiguousarray(
+            np.stack([pre_starts, post_starts]).astype(np.int32))).to(res.dev)
+    if starts_cache is not None:
+      starts_cache[res.dev] = starts
   peaks = torch.empty((n, nd + 2), dtype=torch.float32, device=res.dev)
   # One C call carries several reference batches (`group` rows each keep the
   # batch-coupled behaviours): fewer, larger launches fill the chip even when
@@ -375,6 +379,7 @@ class JAXMaskedXCorrWithStatsCalculator:
     self._min_distance = peak_min_distance
     self._peak_radius = peak_radius
     self._method = method
+    self._plans = {}  # geometry -> host plan of plain (un-masked, un-targeted) calls
 
   # -- host planning -------------------------------------------------------
   @staticmethod
@@ -493,11 +498,23 @@ class JAXMaskedXCorrWithStatsCalculator:
     post_patch_size = tuple(int(p) for p in post_patch_size)
     step = tuple(int(s) for s in step)
 
-    plan = self.plan(tuple(pre_image.shape), tuple(post_image.shape),
-                     patch_size, step, pre_mask, post_mask, selection_mask,
-                     max_masked, batch_size, post_patch_size,
-                     pre_targeting_field, pre_targeting_step,
-                     post_targeting_field, post_targeting_step)
+    # Section after section with the same geometry and no masks / selection /
+    # targeting (the production loop): the host-side plan is reused.
+    plain = (pre_mask is None and post_mask is None and selection_mask is None and
+             pre_targeting_field is None and post_targeting_field is None)
+    key = (tuple(pre_image.shape), tuple(post_image.shape), patch_size, step,
+           post_patch_size, int(batch_size))
+    plan = self._plans.get(key) if plain else None
+    if plan is None:
+      plan = self.plan(tuple(pre_image.shape), tuple(post_image.shape),
+                       patch_size, step, pre_mask, post_mask, selection_mask,
+                       max_masked, batch_size, post_patch_size,
+                       pre_targeting_field, pre_targeting_step,
+                       post_targeting_field, post_targeting_step)
+      if plain:
+        if len(self._plans) >= 8:
+          self._plans.pop(next(iter(self._plans)))
+        self._plans[key] = plan
     pos = plan['positions']
     n = pos.shape[0]
     if n == 0:
@@ -531,7 +548,9 @@ class JAXMaskedXCorrWithStatsCalculator:
       pre_st, post_st = pre_st[sel], post_st[sel]
       if len(sel) == 0:
         return np.zeros((0, res.ndim + 2), np.float32)
-    return _run_batches(res, desc, pre_st, post_st, batch_size, progress)
+    # the device copy of the start coordinates lives with a reused plan
+    cache = plan.setdefault('_starts_dev', {}) if batch_ids is None else None
+    return _run_batches(res, desc, pre_st, post_st, batch_size, progress, cache)
 
   @classmethod
   def assemble(cls, plan, nd, peaks) -> np.ndarray:
