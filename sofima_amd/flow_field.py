@@ -569,5 +569,8 @@ class JAXMaskedXCorrWithStatsCalculator:
       peaks[:, :nd] += plan['tg_offsets'][:n, ::-1]  # xy[z]
     if plan['post_offsets'] is not None:
       peaks[:, :nd] -= plan['post_offsets'][:n, ::-1]
-    output[(slice(None),) + tuple(pos.T)] = peaks.T
+    lin = plan.get('_lin')
+    if lin is None:
+      lin = plan['_lin'] = np.ravel_multi_index(tuple(pos.T), tuple(out_shape.tolist()))
+    output.reshape(output.shape[0], -1)[:, lin] = peaks.T
     return output
