@@ -278,8 +278,11 @@ def masked_xcorr(prev: Array, curr: Array, prev_mask: Array | None = None,
     prev_mask = np.broadcast_to(np.asarray(prev_mask), prev.shape)
   if curr_mask is not None:
     curr_mask = np.broadcast_to(np.asarray(curr_mask), curr.shape)
-  res = _Resident(stack(prev.astype(np.float32, copy=False), p),
-                  stack(curr.astype(np.float32, copy=False), q),
+  if not (prev.dtype == np.uint8 and curr.dtype == np.uint8):
+    # uint8 batches stay uint8 (eligible for the matrix-core kernel)
+    prev = prev.astype(np.float32, copy=False)
+    curr = curr.astype(np.float32, copy=False)
+  res = _Resident(stack(prev, p), stack(curr, q),
                   stack(prev_mask, p), stack(curr_mask, q), dev)
   desc = _make_desc(res, p, q, 0.0, 2, 0.5, 5, method)
   st_pre = np.zeros((b, dim), np.int32)

@@ -627,3 +627,36 @@ def test_concurrent_python_threads(gpu):
     assert not errs, errs
     for g, w in zip(got, want):
       np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(6))
+def test_masked_paths_random_geometry_fuzz(gpu, seed):
+  """Random sizes, P != Q, random masks (incl. a fully masked corner): the
+  masked int8 MFMA path and the FFT form against the direct f32 kernel."""
+  from scipy import ndimage
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(2000 + seed)
+  py, px = int(rng.integers(20, 150)), int(rng.integers(20, 150))
+  qy, qx = (py, px) if rng.random() < 0.5 else (int(rng.integers(12, py + 1)),
+                                                 int(rng.integers(12, px + 1)))
+  b = 5
+  base = ndimage.gaussian_filter(rng.standard_normal((b, py + 8, px + 8)), (0, 1.3, 1.3))
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  prev = np.ascontiguousarray(base[:, 4:4 + py, 4:4 + px]).astype(np.float32)
+  curr = np.ascontiguousarray(base[:, 5:5 + qy, 3:3 + qx]).astype(np.float32)
+  pm = rng.random(prev.shape) < rng.uniform(0.0, 0.2)
+  cm = rng.random(curr.shape) < rng.uniform(0.0, 0.2)
+  pm[0, :py // 3, :px // 3] = True
+  # float64 FFT restatement of the reference as the arbiter: the exact-integer
+  # MFMA path must be the closest, the f32 direct kernel and the f32 FFT form
+  # carry float32 accumulation error of un-centred 8-bit data
+  ref = flow_oracle.xcorr_surface(prev, curr, pm, cm, dtype=np.float64)
+  for method, atol in ((2, 5e-5), (3, 2e-3), (1, 2e-3)):
+    got = flow_field.masked_xcorr(prev.astype(np.uint8), curr.astype(np.uint8), pm, cm,
+                                  method=method)
+    assert got.shape == ref.shape
+    # entries at the 0.3 max-overlap cut can flip between 0 and a value
+    bad = ~np.isclose(got, ref, atol=atol, rtol=0)
+    assert bad.mean() < 2e-3, (method, py, px, qy, qx, bad.mean(),
+                               np.abs(got - ref)[bad].max() if bad.any() else 0)
