@@ -146,22 +146,32 @@ __device__ __forceinline__ void node_force_tile2d(const float* xt0, const float*
                                                   int ctr, const MeshParams& p, int xi,
                                                   int yi, float s0, float s1,
                                                   const float* l0, float* out) {
-  float acc0 = 0.f, acc1 = 0.f, f[2];
+  float acc0 = 0.f, acc1 = 0.f;
+  // Branch free: every spring is evaluated (the neighbour cell always exists in
+  // the LDS tile, possibly with stale contents) and a missing one contributes
+  // +0: eight independent chains the scheduler can interleave, instead of
+  // eight exec-masked blocks padded with hazard nops.
 #define SFM_FAR(L, DX, DY)                                                         \
-  if (xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 && yi - (DY) < p.Y) {    \
+  {                                                                                \
+    const bool ok = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&         \
+                    yi - (DY) < p.Y;                                               \
     const int m = ctr - (DY) * TW - (DX);                                          \
+    float f[2];                                                                    \
     spring_xy<DX, DY>(s0 - xt0[m] + p.rest[L][0], s1 - xt1[m] + p.rest[L][1],      \
                       l0[L], p.neg_k[L], p.prefer, f);                             \
-    acc0 = acc0 + f[0];                                                            \
-    acc1 = acc1 + f[1];                                                            \
+    acc0 = acc0 + (ok ? f[0] : 0.f);                                               \
+    acc1 = acc1 + (ok ? f[1] : 0.f);                                               \
   }
 #define SFM_NEAR(L, DX, DY)                                                        \
-  if (xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 && yi + (DY) < p.Y) {    \
+  {                                                                                \
+    const bool ok = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&         \
+                    yi + (DY) < p.Y;                                               \
     const int m = ctr + (DY) * TW + (DX);                                          \
+    float f[2];                                                                    \
     spring_xy<DX, DY>(xt0[m] - s0 + p.rest[L][0], xt1[m] - s1 + p.rest[L][1],      \
                       l0[L], p.neg_k[L], p.prefer, f);                             \
-    acc0 = acc0 - f[0];                                                            \
-    acc1 = acc1 - f[1];                                                            \
+    acc0 = acc0 - (ok ? f[0] : 0.f);                                               \
+    acc1 = acc1 - (ok ? f[1] : 0.f);                                               \
   }
   SFM_FAR(0, 1, 0) SFM_FAR(1, 0, 1) SFM_FAR(2, 1, 1) SFM_FAR(3, -1, 1)
   SFM_NEAR(0, 1, 0) SFM_NEAR(1, 0, 1) SFM_NEAR(2, 1, 1) SFM_NEAR(3, -1, 1)
@@ -984,22 +994,29 @@ mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ 
     // identical operation order to node_force<2> with order2d; the four link
     // families of build_params unrolled with compile-time directions
     const float s0 = xt[0][ly + 1][lx + 1], s1 = xt[1][ly + 1][lx + 1];
-    float acc0 = 0.f, acc1 = 0.f, f[2];
+    float acc0 = 0.f, acc1 = 0.f;
+    // (branch free, see node_force_tile2d)
 #define SFM_FAR(L, DX, DY)                                                          \
-    if (xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 && yi - (DY) < p.Y) {     \
+    {                                                                               \
+      const bool ok = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&        \
+                      yi - (DY) < p.Y;                                              \
+      float f[2];                                                                   \
       spring_xy<DX, DY>(s0 - xt[0][ly + 1 - (DY)][lx + 1 - (DX)] + p.rest[L][0],     \
                         s1 - xt[1][ly + 1 - (DY)][lx + 1 - (DX)] + p.rest[L][1],     \
                         l0[L], p.neg_k[L], p.prefer, f);                            \
-      acc0 = acc0 + f[0];                                                           \
-      acc1 = acc1 + f[1];                                                           \
+      acc0 = acc0 + (ok ? f[0] : 0.f);                                              \
+      acc1 = acc1 + (ok ? f[1] : 0.f);                                              \
     }
 #define SFM_NEAR(L, DX, DY)                                                         \
-    if (xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 && yi + (DY) < p.Y) {     \
+    {                                                                               \
+      const bool ok = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&        \
+                      yi + (DY) < p.Y;                                              \
+      float f[2];                                                                   \
       spring_xy<DX, DY>(xt[0][ly + 1 + (DY)][lx + 1 + (DX)] - s0 + p.rest[L][0],     \
                         xt[1][ly + 1 + (DY)][lx + 1 + (DX)] - s1 + p.rest[L][1],     \
                         l0[L], p.neg_k[L], p.prefer, f);                            \
-      acc0 = acc0 - f[0];                                                           \
-      acc1 = acc1 - f[1];                                                           \
+      acc0 = acc0 - (ok ? f[0] : 0.f);                                              \
+      acc1 = acc1 - (ok ? f[1] : 0.f);                                              \
     }
     SFM_FAR(0, 1, 0) SFM_FAR(1, 0, 1) SFM_FAR(2, 1, 1) SFM_FAR(3, -1, 1)
     SFM_NEAR(0, 1, 0) SFM_NEAR(1, 0, 1) SFM_NEAR(2, 1, 1) SFM_NEAR(3, -1, 1)
