@@ -49,6 +49,7 @@ struct MeshParams {
   long long N;  // nodes = B*Z*Y*X
   int n_links;
   int order2d;  // reference summation order of inplane_force
+  int default_links;  // ncomp 3 with MESH_LINK_DIRECTIONS: compile-time unrolled path
   int dir[SFM_MESH_MAX_LINKS][3];     // xyz
   float rest[SFM_MESH_MAX_LINKS][3];  // xyz rest vector
   float neg_k[SFM_MESH_MAX_LINKS];    // -k_eff
@@ -247,6 +248,70 @@ __device__ __forceinline__ void node_force_at(Load ld, const MeshParams& p, int 
   for (int c = 0; c < C; ++c) out[c] = acc[c];
 }
 
+// Volumetric spring with compile-time link direction (see spring<C>).
+template <int DX, int DY, int DZ>
+__device__ __forceinline__ void spring_xyz(const float* d, float l0, float neg_k,
+                                           int prefer, float* f) {
+  const float l = vec_len(d, 3);
+  const float r = l0 / l;
+  constexpr int dir[3] = {DX, DY, DZ};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float t = r;
+    if (prefer && dir[c] != 0) {
+      const float sg = d[c] > 0.f ? 1.f : (d[c] < 0.f ? -1.f : 0.f);
+      t = r * (static_cast<float>(dir[c]) * sg);
+    }
+    float v = (neg_k * (1.0f - t)) * d[c];
+    if (!isfinite(v)) v = 0.f;
+    f[c] = v;
+  }
+}
+
+// elastic_mesh_3d with the 13 default links (MESH_LINK_DIRECTIONS), unrolled
+// with compile-time directions and branch free: a spring whose other end lies
+// outside the mesh is evaluated against the node itself, which gives d = rest,
+// l = l0 and a force of exactly (+-)0.  Same per-link order as node_force_at:
+// += far end, -= near end (mesh.py:271-277).  26 independent chains instead of
+// 26 exec-masked blocks: the small 3-D meshes of a volumetric montage are
+// bound by this kernel's latency.
+__device__ __forceinline__ void node_force_default3d(const float* __restrict__ x,
+                                                     const MeshParams& p, long long n,
+                                                     int xi, int yi, int zi,
+                                                     const float* self, float* out) {
+  float acc[3] = {0.f, 0.f, 0.f};
+  const long long sy = p.X, sz = (long long)p.X * p.Y;
+#define SFM_LINK(L, DX, DY, DZ)                                                      \
+  {                                                                                  \
+    const float l0 = vec_len(p.rest[L], 3);                                          \
+    const bool okf = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&          \
+                     yi - (DY) < p.Y && zi - (DZ) >= 0 && zi - (DZ) < p.Z;            \
+    const bool okn = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&          \
+                     yi + (DY) < p.Y && zi + (DZ) >= 0 && zi + (DZ) < p.Z;            \
+    const long long off = (DX) + (DY) * sy + (DZ) * sz;                              \
+    const long long mf = okf ? n - off : n, mn = okn ? n + off : n;                  \
+    float df[3], dn[3], ff[3], fn[3];                                                \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                  \
+      df[c] = self[c] - x[c * p.N + mf] + p.rest[L][c];                              \
+      dn[c] = x[c * p.N + mn] - self[c] + p.rest[L][c];                              \
+    }                                                                                \
+    spring_xyz<DX, DY, DZ>(df, l0, p.neg_k[L], p.prefer, ff);                        \
+    spring_xyz<DX, DY, DZ>(dn, l0, p.neg_k[L], p.prefer, fn);                        \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                  \
+      acc[c] = acc[c] + (okf ? ff[c] : 0.f);                                         \
+      acc[c] = acc[c] - (okn ? fn[c] : 0.f);                                         \
+    }                                                                                \
+  }
+  SFM_LINK(0, 1, 0, 0) SFM_LINK(1, 0, 1, 0) SFM_LINK(2, 0, 0, 1) SFM_LINK(3, 1, 1, 0)
+  SFM_LINK(4, -1, 1, 0) SFM_LINK(5, 1, 0, 1) SFM_LINK(6, -1, 0, 1) SFM_LINK(7, 0, 1, 1)
+  SFM_LINK(8, 0, -1, 1) SFM_LINK(9, 1, 1, 1) SFM_LINK(10, 1, 1, -1) SFM_LINK(11, 1, -1, 1)
+  SFM_LINK(12, -1, 1, 1)
+#undef SFM_LINK
+  out[0] = acc[0];
+  out[1] = acc[1];
+  out[2] = acc[2];
+}
+
 template <int C>
 __device__ void node_force(const float* __restrict__ x, const MeshParams& p,
                            long long n, float* out) {
@@ -258,6 +323,10 @@ __device__ void node_force(const float* __restrict__ x, const MeshParams& p,
   float self[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) self[c] = x[c * p.N + n];
+  if (C == 3 && p.default_links) {
+    node_force_default3d(x, p, n, xi, yi, zi, self, out);
+    return;
+  }
   node_force_at<C>(
       [&](int c, int dx, int dy, int dz) {
         return x[c * p.N + n + dx + (long long)dy * p.X + (long long)dz * p.X * p.Y];
@@ -1293,6 +1362,7 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
     }
   } else {
     p->n_links = d->n_links > 0 ? d->n_links : 13;
+    p->default_links = d->n_links == 0;
     if (p->n_links > SFM_MESH_MAX_LINKS)
       return sfm::fail(SFM_ERR_INVALID, "too many links: %d", p->n_links);
     for (int L = 0; L < p->n_links; ++L) {
