@@ -15,7 +15,7 @@ OBJ_DIR = os.path.join(PKG_DIR, 'build')
 # reference's f32 operation order, so FMA contraction is disabled there.
 SOURCES = {
     'sfm_core.hip': [],
-    'sfm_mesh.hip': ['-ffp-contract=off'],
+    'sfm_mesh.hip': ['-ffp-contract=off'] + os.environ.get('SFM_MESH_FLAGS', '').split(),
     'sfm_xcorr.hip': [],
     'sfm_xcorr_fft.hip': [],
     # SFM_MFMA_TIMING / SFM_MFMA_FLAGS: instrumentation and tuning experiments

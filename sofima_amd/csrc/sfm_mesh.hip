@@ -1115,8 +1115,15 @@ mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ 
   }
   float my_part = 0.f;  // threads < nred: this workgroup's partial sum #tid
 
+#ifdef SFM_MESH_TIMING
+  long long mt[6] = {0, 0, 0, 0, 0, 0}, mtc = clock64();
+#define MTICK(i) { const long long tn = clock64(); mt[i] += tn - mtc; mtc = tn; }
+#else
+#define MTICK(i)
+#endif
   bool ok = true;
   for (int k = 1; k <= q.num_iters + 1; ++k) {
+    MTICK(5)
     const unsigned epoch = static_cast<unsigned>(k);
     const bool last = k == q.num_iters + 1;
     const long long slot_off = (long long)(k & 1) * TL::kSlot;
@@ -1160,6 +1167,7 @@ mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ 
       ok = false;
       break;
     }
+    MTICK(0)
     // ---- FIRE scalars from the partials of step k - 1 -------------------------------
     if (reduce_now) {
       // value i is summed over workgroups by wave i mod #waves (fixed order:
@@ -1202,6 +1210,7 @@ mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ 
         v1 = v1 - s.mv[1];
       }
     }
+    MTICK(1)
     if (last) break;
 
     // ---- advance: x += dt v + dt^2/2 a for own and halo nodes --------------------
@@ -1228,6 +1237,7 @@ mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ 
       xt[1][hy][hx] = hx1 + (dt * hv1 + c2 * hval[tid][5]);
     }
     __syncthreads();
+    MTICK(2)
 
     // ---- integrate ------------------------------------------------------------------
     float part[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1268,6 +1278,7 @@ mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ 
       v0 = n0;
       v1 = n1;
     }
+    MTICK(3)
     if (p.fire) {
       // block sums in a fixed order: DPP tree per wave, then waves in order
       for (int i = 0; i < nred; ++i) {
@@ -1283,7 +1294,14 @@ mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ 
     } else {
       __syncthreads();
     }
+    MTICK(4)
   }
+#ifdef SFM_MESH_TIMING
+  if (wg == 0 && tid == 0)
+    printf("MESH wg0 per step: exchange %lld scalars %lld advance %lld force %lld sums %lld other %lld\n",
+           mt[0] / q.num_iters, mt[1] / q.num_iters, mt[2] / q.num_iters, mt[3] / q.num_iters,
+           mt[4] / q.num_iters, mt[5] / q.num_iters);
+#endif
 
   if (!ok) return;  // timed out: leave the global state untouched
   // ---- write back, chunk statistics ------------------------------------------------
@@ -1585,7 +1603,9 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     // Small tiles spread the (latency bound) step over more CUs; fall back to
     // 32 x 32 tiles when there would be more workgroups than CUs.
     int tile = 0;
+    const char* force_tile = getenv("SFM_MESH_TILE");  // experiment: 16 or 32
     for (int t : {16, 32}) {
+      if (force_tile && atoi(force_tile) != t) continue;
       const long long nw = (long long)p.B * ((p.Y + t - 1) / t) * ((p.X + t - 1) / t);
       if (nw <= kMaxWg && nw <= cus) {
         tile = t;
