@@ -84,16 +84,20 @@ def _query_integral_image(svt, diam, stride):
   return total
 
 
+def _host_masked_counts(mask, patch_size, step):
+  """Host form of the patch-selection counts (summed-area table, as in the
+  reference): for planning without a GPU (`plan(..., counts_fn=...)`) and as the
+  comparison in the tests.  flow_field() never uses it."""
+  return _query_integral_image(_integral_image(mask), patch_size, step)
+
+
 def _masked_counts(mask, patch_size, step):
   """Number of masked pixels in every grid patch, [*(shape - patch)//step + 1].
 
   Device replacement for `_integral_image` + the summed-area-table query of
-  the reference (flow_field.py:575-589): `sfm_mask_patch_counts`.  Falls back
-  to the host summed-area table only when no GPU is visible (planning-only
-  use, e.g. the CPU unit tests of `plan()`).
+  the reference (flow_field.py:575-589): `sfm_mask_patch_counts`.  Needs the
+  GPU like every other compute step (no fallback).
   """
-  if not torch.cuda.is_available():
-    return _query_integral_image(_integral_image(mask), patch_size, step)
   dev = _dev.device()
   m = _dev.as_device_mask(mask, dev)
   nd = m.ndim
@@ -405,8 +409,11 @@ class JAXMaskedXCorrWithStatsCalculator:
            post_mask=None, selection_mask=None, max_masked=0.75,
            batch_size=4096, post_patch_size=None, pre_targeting_field=None,
            pre_targeting_step=None, post_targeting_field=None,
-           post_targeting_step=None):
+           post_targeting_step=None, counts_fn=None):
     """Everything flow_field() decides on the host before touching the GPU.
+
+    `counts_fn(mask, patch, step)` overrides the device kernel that counts the
+    masked pixels per grid patch (planning on a machine without a GPU).
 
     Returns a dict with the output shape, the row-major grid positions, the
     per-batch (edge-padded) pre/post start coordinates and targeting offsets.
@@ -421,7 +428,7 @@ class JAXMaskedXCorrWithStatsCalculator:
     for mask, psz in ((pre_mask, patch_size), (post_mask, post_patch_size)):
       if mask is None:
         continue
-      s = _masked_counts(mask, psz, step)
+      s = (counts_fn or _masked_counts)(mask, psz, step)
       m = (s / np.prod(psz) >= max_masked)[out_sel]
       selection_mask[m] = False
 

@@ -12,7 +12,8 @@ def _plan(calc, pre_shape, post_shape, patch, step, **kw):
   nd = len(pre_shape)
   post_patch = kw.pop('post_patch_size', None) or patch
   return calc.plan(pre_shape, post_shape, patch, step,
-                   post_patch_size=post_patch, **kw)
+                   post_patch_size=post_patch,
+                   counts_fn=flow_field._host_masked_counts, **kw)
 
 
 def test_plan_matches_oracle_selection():
