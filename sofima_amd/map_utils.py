@@ -99,6 +99,10 @@ def mask_irregular(coord_map, stride: Sequence[float], frac: float,
   _abi.check(_abi.load().sfm_mask_irregular(C.byref(d), m.data_ptr(), bad.data_ptr()))
   bad_h = bad.cpu().numpy().astype(bool)
   if host is not None:
-    host[0][bad_h] = np.nan
-    host[1][bad_h] = np.nan
+    # in-place contract: the masked map computed on the device is copied back
+    # (unmasked entries round-trip through float32 unchanged for float32 input)
+    if host.dtype == np.float32:
+      host[...] = m.cpu().numpy()
+    else:
+      host[:, bad_h] = np.nan
   return bad_h
