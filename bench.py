@@ -69,7 +69,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=1)
   ap.add_argument('--size', type=int, default=8192)
   ap.add_argument('--method', type=int, default=0,
-                  help='0 auto, 1 direct f32, 2 int8 MFMA')
+                  help='0 auto, 1 direct f32, 2 int8 MFMA, 3 FFT form')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--mesh-iters', type=int, default=MESH_ITERS)
   args = ap.parse_args()
