@@ -920,7 +920,9 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
   }
 }
 
-constexpr int kModeGeneral = 0, kModeSame = 1, kModeRaw = 2;
+// kModeSameExact: P == Q and Px == 16 NCA (production 160, 128, 96, 64, 48): the
+// per-column sign / index arithmetic of the epilogue becomes compile-time.
+constexpr int kModeGeneral = 0, kModeSame = 1, kModeRaw = 2, kModeSameExact = 3;
 
 // Wave-wide maximum of non-negative values on the DPP network (no LDS round
 // trips): row shifts inside each 16-lane row, then row broadcasts; the result
@@ -969,7 +971,8 @@ __device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_ld
 
 template <int NCA, int NCE, int MODE>
 __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
-  constexpr bool SAME = MODE == kModeSame;
+  constexpr bool SAME = MODE == kModeSame || MODE == kModeSameExact;
+  constexpr bool EXACT = MODE == kModeSameExact;
   constexpr bool RAW = MODE == kModeRaw;
   constexpr int NQ = NCA + NCE - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1281,6 +1284,99 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           fny[r] = ky_raw < Sy ? muab * static_cast<float>(Py - abs(dy)) : NAN;
           rowp[r] = 4u * static_cast<unsigned>(ky_raw * a.sx_pitch + nn);
         }
+        if constexpr (EXACT) {
+          // Px == 16 NCA: column tile q < NCA holds kx = 16 q + n < Px - 1 (dx < 0,
+          // xv = kx + 1, ex = +1, fnx = kx + 1); tile q + NCA holds the shifts
+          // dx = kx + 1 > 0 with the SAME xv (ex = -1, fnx = Px - xv).  The only
+          // lanes that deviate are n = 15 of tile NCA - 1 (dx = 0: xv = 0) and of
+          // tile 2 NCA - 1 (kx = Sx: padding).  Table addresses are one VGPR per
+          // row plus an immediate, signs are folded into the instruction.
+          const int xvb = nn + 1;                         // xv of tile 0
+          const bool last = nn == 15;                     // the deviating lane
+          const float fxb = static_cast<float>(xvb);
+          const float* rcolA = R_lds + 2 * a.aux_n;
+          const float* rcolB = R_lds + 3 * a.aux_n;
+          unsigned gofs[4];                               // byte offsets of G[yv][xvb]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gofs[r] = 4u * static_cast<unsigned>(grow[r] + xvb);
+          constexpr int kQG = SFM_EPI_QG;
+          constexpr int kGroupsE = (NCA + kQG - 1) / kQG;
+          float gb[2][kQG][4];
+          float rca_e[NCA], rcb_e[NCA];
+#pragma unroll
+          for (int qq = 0; qq < NCA; ++qq) {
+            // the deviating lane of the last tile reads xv = 0 (first half); its
+            // second-half value is padding
+            const int xv = (qq == NCA - 1 && last) ? 0 : xvb + 16 * qq;
+            rca_e[qq] = rcolA[xv];
+            rcb_e[qq] = rcolB[xv];
+          }
+          auto fetch_e = [&](int grp, int slot) {
+#pragma unroll
+            for (int u = 0; u < kQG; ++u) {
+              const int qq = grp * kQG + u;
+              if (qq >= NCA) break;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                unsigned off = gofs[r] + 64u * qq;
+                if (qq == NCA - 1)  // xv = 0 for the deviating lane (also keeps the
+                  off = last ? 4u * static_cast<unsigned>(grow[r]) : off;  // read in bounds)
+                gb[slot][u][r] = at_byte(G, off);
+              }
+            }
+          };
+          auto store4 = [&](int q, int r, float v) {
+            __builtin_nontemporal_store(
+                v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
+                                            (static_cast<size_t>(rowp[r]) + 64u * q)));
+            tmax = fmaxf(tmax, v);
+            acc[q][r] = __float_as_int(v);
+          };
+          auto emit_e = [&](int qq, const float* gv) {
+            // first half: dx < 0 (except the deviating lane of tile NCA - 1: dx = 0)
+            {
+              const int q = qq;
+              const bool dev = qq == NCA - 1 && last;
+              const float fnx = dev ? static_cast<float>(Px) : fxb + static_cast<float>(16 * qq);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float bsel = sy[r] ? rca_e[qq] : rcb_e[qq];
+                float corr = dev ? fmaf(-ey[r], gv[r], a_pos[r]) - bsel
+                                 : fmaf(ey[r], gv[r], a_neg[r]) + bsel;
+                corr = fmaf(fny[r], fnx, corr);
+                store4(q, r, static_cast<float>(acc[q][r]) + corr);
+              }
+            }
+            // second half: dx = 16 qq + n + 1 > 0, same xv; the deviating lane of
+            // the last tile is the padding column kx = Sx
+            if (qq + NCA < NQ) {
+              const int q = qq + NCA;
+              const bool dev = qq == NCA - 1 && last;
+              const float fnx =
+                  dev ? NAN : static_cast<float>(Px) - (fxb + static_cast<float>(16 * qq));
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float bsel = sy[r] ? rca_e[qq] : rcb_e[qq];
+                float corr = fmaf(-ey[r], gv[r], a_pos[r]) - bsel;
+                corr = fmaf(fny[r], fnx, corr);
+                store4(q, r, static_cast<float>(acc[q][r]) + corr);
+              }
+            }
+          };
+          fetch_e(0, 0);
+#pragma unroll
+          for (int grp = 0; grp < kGroupsE; ++grp) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp + 1 < kGroupsE) fetch_e(grp + 1, (grp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < kQG; ++u) {
+              const int qq = grp * kQG + u;
+              if (qq >= NCA) break;
+              emit_e(qq, gb[grp & 1][u]);
+            }
+          }
+        } else {
         const bool paired = Px == 16 * NCA;
         constexpr int kQG = SFM_EPI_QG;        // output columns per gather group
         constexpr int kDepth = SFM_EPI_DEPTH;  // groups in flight ahead of the stores
@@ -1364,6 +1460,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             }
           }
         }
+        }  // generic (not EXACT) column handling
       } else {
         const int ipa = Px + 1, ipb = Qx + 1;
         int oa0[4], oa1[4], ob0[4], ob1[4], ny[4];
@@ -1479,6 +1576,11 @@ struct Variant {
 // Instantiated chunk geometries: NCA >= ceil(Px / 16), NCE >= floor((Qx + 14) / 16) + 1.
 constexpr Variant kVariants[] = {{3, 4}, {4, 5}, {5, 6}, {6, 7}, {8, 9}, {10, 11}};
 
+bool exact_enabled() {
+  const char* e = std::getenv("SFM_MFMA_EXACT");
+  return !(e && e[0] == '0');
+}
+
 int pick_variant(int px, int qx) {
   const int nca = (px + 15) / 16, nce = (qx + 14) / 16 + 1;
   for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
@@ -1580,6 +1682,7 @@ int launch_variant(const MfmaArgs& a, int mode, int grid, size_t lds,
                    hipStream_t st) {
   switch (mode) {
     case kModeSame: return launch_one<NCA, NCE, kModeSame>(a, grid, lds, st);
+    case kModeSameExact: return launch_one<NCA, NCE, kModeSameExact>(a, grid, lds, st);
     case kModeRaw: return launch_one<NCA, NCE, kModeRaw>(a, grid, lds, st);
     default: return launch_one<NCA, NCE, kModeGeneral>(a, grid, lds, st);
   }
@@ -1795,7 +1898,9 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   const int grid = std::min(d->batch, device_cus() * per_cu);
-  if (int rc = launch_mode(vi, a, same ? kModeSame : kModeGeneral, grid, lds, st))
+  const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
+  if (int rc = launch_mode(vi, a, same ? (exact ? kModeSameExact : kModeSame) : kModeGeneral,
+                           grid, lds, st))
     return rc;
   if (fp) {
     hipLaunchKernelGGL(mfma_first_peak_kernel, dim3(d->batch), dim3(kThreads), 0, st, a);
