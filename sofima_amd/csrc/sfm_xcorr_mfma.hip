@@ -1660,6 +1660,8 @@ Ws carve_ws(const SfmXcorrDesc* d, void* base) {
   return w;
 }
 
+int device_cus();
+
 template <int NCA, int NCE, int MODE>
 int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   static size_t attr_set = 0;
@@ -1669,6 +1671,22 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     attr_set = lds;
   }
+  // Persistent grid: as many workgroups as the CUs hold at once (registers and
+  // LDS decide: 2 per CU for 160-wide patches, 3-4 for the small variants).
+  static int per_cu = 0;
+  static size_t per_cu_lds = 0;
+  if (per_cu == 0 || per_cu_lds != lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &n, reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE, MODE>), kThreads,
+            lds) != hipSuccess || n < 1)
+      n = lds * 2 <= 160 * 1024 ? 2 : 1;
+    const char* cap = std::getenv("SFM_MFMA_MAX_WG_PER_CU");
+    if (cap && std::atoi(cap) > 0) n = std::min(n, std::atoi(cap));
+    per_cu = n;
+    per_cu_lds = lds;
+  }
+  grid = std::min(grid, device_cus() * per_cu);
   sfm::prof_begin(sfm::kProfXcorr, st);
   hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, MODE>), dim3(grid),
                      dim3(kThreads), lds, st, a);
@@ -1896,8 +1914,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   r_bytes = (r_bytes + 15) / 16 * 16;
   a.r_bytes = static_cast<int>(r_bytes);
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
-  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
-  const int grid = std::min(d->batch, device_cus() * per_cu);
+  const int grid = d->batch;  // capped to the resident workgroups in launch_one
   const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
   if (int rc = launch_mode(vi, a, same ? (exact ? kModeSameExact : kModeSame) : kModeGeneral,
                            grid, lds, st))
@@ -1934,8 +1951,6 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* num, float* den,
   size_t r_bytes = (size_t)kThreads * 8;
   a.r_bytes = static_cast<int>(r_bytes);
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
-  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
-  const int cus = device_cus();
   const long long elems = a.s_stride;
   for (int lo = 0; lo < d->batch; lo += kMaskedChunk) {
     const int nb = std::min(kMaskedChunk, d->batch - lo);
@@ -1943,7 +1958,7 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* num, float* den,
     MfmaArgs c = a;
     c.batch = nb;
     c.pp = w.pp + lo;
-    const int grid = std::min(nb, cus * per_cu);
+    const int grid = nb;
     for (int pass = 0; pass < 8; ++pass) {
       c.plane[0] = kMaskedPasses[pass][0];
       c.plane[1] = kMaskedPasses[pass][1];
