@@ -74,6 +74,11 @@ def main():
   ap.add_argument('--mesh-iters', type=int, default=MESH_ITERS)
   args = ap.parse_args()
 
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    # `python bench.py --gpus N` without a launcher: start the N ranks here
+    # (one process per GPU, RCCL), exactly as the driver's torchrun line does.
+    sys.exit(spawn_ranks(args.gpus))
+
   import torch
   import torch.distributed as dist
   from sofima_amd import _abi, flow_field, mesh
@@ -93,7 +98,14 @@ def main():
                               device_id=torch.device('cuda', local_rank))
     else:
       dist.init_process_group(backend, rank=rank, world_size=world)
-  assert world == args.gpus or world == 1, (world, args.gpus)
+  if world != args.gpus:
+    raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
+  if world > 1 and backend == 'nccl':
+    # every rank must sit on its own GPU and RCCL must see all of them
+    assert torch.cuda.device_count() >= world, (torch.cuda.device_count(), world)
+    probe = torch.ones(1, device=torch.device('cuda', local_rank))
+    dist.all_reduce(probe)
+    assert int(probe.item()) == world, (probe.item(), world)
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
   lib = _abi.load()
@@ -262,6 +274,22 @@ def main():
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+  """Re-executes this script as n ranks under torch.distributed.run."""
+  import socket
+  import subprocess
+  sock = socket.socket()
+  sock.bind(('127.0.0.1', 0))
+  port = sock.getsockname()[1]
+  sock.close()
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(pre, post, cfg):

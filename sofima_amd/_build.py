@@ -36,11 +36,27 @@ def _hipcc() -> str:
   return exe
 
 
-def _stale(target: str, deps: list[str]) -> bool:
+def _stale(target: str, deps: list[str], cmd: list[str] | None = None) -> bool:
+  """Out of date by mtime, or built with a different command line (the extra
+  flags come from environment variables: an instrumented build must not
+  silently stay the production library, nor the reverse)."""
   if not os.path.exists(target):
     return True
   t = os.path.getmtime(target)
-  return any(os.path.getmtime(d) > t for d in deps)
+  if any(os.path.getmtime(d) > t for d in deps):
+    return True
+  if cmd is not None:
+    try:
+      with open(target + '.cmd') as f:
+        return f.read() != ' '.join(cmd)
+    except OSError:
+      return True
+  return False
+
+
+def _record(target: str, cmd: list[str]) -> None:
+  with open(target + '.cmd', 'w') as f:
+    f.write(' '.join(cmd))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -57,11 +73,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     src_path = os.path.join(CSRC, src)
     obj = os.path.join(OBJ_DIR, src + '.o')
     objs.append(obj)
-    if force or _stale(obj, [src_path] + headers):
-      cmd = [hipcc] + COMMON + extra + ['-c', src_path, '-o', obj]
+    cmd = [hipcc] + COMMON + extra + ['-c', src_path, '-o', obj]
+    if force or _stale(obj, [src_path] + headers, cmd):
       if verbose:
         print(' '.join(cmd))
       subprocess.run(cmd, check=True)
+      _record(obj, cmd)
       relink = True
   if relink or _stale(LIB_PATH, objs):
     # hipFFT serves the FFT form of the correlation (3-D / large patches)

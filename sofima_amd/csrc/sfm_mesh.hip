@@ -981,9 +981,10 @@ __device__ __forceinline__ void halo_coord(int h, int* hy, int* hx) {
 
 template <int T>
 __global__ void __launch_bounds__(T * T)
-mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ vg,
-                      float* __restrict__ ag, const float* __restrict__ prevg,
-                      PersistArgs q) {
+mesh_persist2d_kernel(MeshParams p, const float* __restrict__ xg,
+                      const float* __restrict__ vg, float* __restrict__ xo,
+                      float* __restrict__ vo, float* __restrict__ ao,
+                      const float* __restrict__ prevg, PersistArgs q) {
   using TL = Tile<T>;
   constexpr int NT = TL::kThreads;
   __shared__ float xt[2][T + 2][T + 3];
@@ -1303,16 +1304,19 @@ mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ 
            mt[4] / q.num_iters, mt[5] / q.num_iters);
 #endif
 
-  if (!ok) return;  // timed out: leave the global state untouched
+  if (!ok) return;  // timed out (the abort flag is set)
   // ---- write back, chunk statistics ------------------------------------------------
+  // The result goes to a staging set (xo, vo, ao); persist_commit_kernel copies
+  // it over the caller's state only when NO workgroup raised the abort flag, so
+  // a timeout leaves the caller's x, v, a untouched as a whole.
   float ek = 0.f, vm2 = 0.f;
   if (active) {
-    xg[n] = x0;
-    xg[p.N + n] = x1;
-    vg[n] = v0;
-    vg[p.N + n] = v1;
-    ag[n] = a0;
-    ag[p.N + n] = a1;
+    xo[n] = x0;
+    xo[p.N + n] = x1;
+    vo[n] = v0;
+    vo[p.N + n] = v1;
+    ao[n] = a0;
+    ao[p.N + n] = a1;
     ek = v0 * v0 + v1 * v1;
     vm2 = ek;
   }
@@ -1336,6 +1340,21 @@ mesh_persist2d_kernel(MeshParams p, float* __restrict__ xg, float* __restrict__ 
     q.stat_partials[wg * 2] = e;
     q.stat_partials[wg * 2 + 1] = m;
     if (wg == 0) *q.scal_out = s;
+  }
+}
+
+// All-or-nothing hand-over of the persistent kernel's result.
+__global__ void __launch_bounds__(kBlock)
+persist_commit_kernel(const int* __restrict__ abort, const float* __restrict__ xs,
+                      const float* __restrict__ vs, const float* __restrict__ as,
+                      float* __restrict__ x, float* __restrict__ v,
+                      float* __restrict__ a, long long n) {
+  if (*abort) return;
+  for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n;
+       i += (long long)gridDim.x * kBlock) {
+    x[i] = xs[i];
+    v[i] = vs[i];
+    a[i] = as[i];
   }
 }
 
@@ -1527,7 +1546,9 @@ MeshWorkspace carve_for(const SfmMeshDesc* d, void* ws, TilePlan* plan) {
                                 d->shape[2], d->shape[3]);
   if (plan) *plan = t;
   const size_t cn = (size_t)d->ncomp * n;
-  return carve(ws, d->target ? cn : 0, (t.tx && !d->target) ? cn : 0, t.tiles,
+  // second (x, v, a) set: ping-pong of the fused tiled step, staging of the
+  // persistent kernel's result
+  return carve(ws, d->target ? cn : 0, (d->ncomp == 2 && !d->target) ? cn : 0, t.tiles,
                d->shape[3]);
 }
 
@@ -1630,11 +1651,15 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       sfm::prof_begin(sfm::kProfMesh, st);
       if (tile == 16)
         hipLaunchKernelGGL(mesh_persist2d_kernel<16>, dim3(q.n_wg), dim3(256), 0, st,
-                           p, d->x, d->v, d->a, d->prev, q);
+                           p, d->x, d->v, w.alt[0], w.alt[1], w.alt[2], d->prev, q);
       else
         hipLaunchKernelGGL(mesh_persist2d_kernel<32>, dim3(q.n_wg), dim3(1024), 0, st,
-                           p, d->x, d->v, d->a, d->prev, q);
+                           p, d->x, d->v, w.alt[0], w.alt[1], w.alt[2], d->prev, q);
       sfm::prof_end(sfm::kProfMesh, st);
+      SFM_LAUNCH_CHECK();
+      hipLaunchKernelGGL(persist_commit_kernel, dim3(grid_for((long long)p.ncomp * p.N)),
+                         dim3(kBlock), 0, st, w.abort, w.alt[0], w.alt[1], w.alt[2], d->x,
+                         d->v, d->a, (long long)p.ncomp * p.N);
       SFM_LAUNCH_CHECK();
       hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(kBlock), 0, st, w.stat_part,
                          q.n_wg, w.stats);
@@ -1659,8 +1684,9 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
         stats->v_max = hs[1];
         return SFM_OK;
       }
-      // Timed out (workgroups not co-resident?): the state is untouched, fall
-      // through to the multi-launch path.
+      // Timed out (workgroups not co-resident?): the commit kernel saw the
+      // abort flag and left x, v, a untouched; fall through to the
+      // multi-launch path.
       SFM_HIP_CHECK(hipMemcpyAsync(&w.scal[0], &s0, sizeof(s0),
                                    hipMemcpyHostToDevice, st));
     }

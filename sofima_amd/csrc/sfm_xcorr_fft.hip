@@ -135,19 +135,38 @@ int grid_for(long long n) {
   return static_cast<int>(g > 65535 * 4 ? 65535 * 4 : (g < 1 ? 1 : g));
 }
 
-// Plan cache: (rank, F, batch, type) -> handle.  Plans own their work areas.
+// Plan cache: (device, stream, rank, F, batch, type) -> handle.  A plan owns its
+// (auto-allocated) work area, so it must never serve two streams at once: the
+// stream is part of the key and calls on the same stream are ordered by the
+// stream itself.  The device is part of the key because a handle belongs to
+// the device it was created on.  g_exec_mu serialises the host-side
+// enqueueing (hipfftSetStream + Exec are not atomic).
 std::mutex g_plan_mu;
-std::mutex g_exec_mu;  // plans carry their stream: enqueueing on a plan is serialised
-std::map<std::tuple<int, int, int, int, int, int>, hipfftHandle> g_plans;
+std::mutex g_exec_mu;
+typedef std::tuple<int, const void*, int, int, int, int, int, int> PlanKey;
+std::map<PlanKey, hipfftHandle> g_plans;
+constexpr size_t kMaxPlans = 96;
 
-int get_plan(const FftGeo& g, int batch, hipfftType type, hipfftHandle* out) {
-  const auto key = std::make_tuple(g.rank, g.F[0], g.F[1], g.F[2], batch,
-                                   static_cast<int>(type));
+int get_plan(const FftGeo& g, int batch, hipfftType type, hipStream_t st,
+             hipfftHandle* out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(SFM_ERR_HIP, "hipGetDevice failed");
+  const PlanKey key = std::make_tuple(dev, static_cast<const void*>(st), g.rank, g.F[0],
+                                      g.F[1], g.F[2], batch, static_cast<int>(type));
   std::lock_guard<std::mutex> lk(g_plan_mu);
   auto it = g_plans.find(key);
   if (it != g_plans.end()) {
     *out = it->second;
     return SFM_OK;
+  }
+  if (g_plans.size() >= kMaxPlans) {
+    // Streams come and go (per-thread torch streams): drop everything rather
+    // than grow without bound.  Callers hold g_exec_mu, and a destroyed plan's
+    // enqueued work keeps its work area alive until the stream drains
+    // (hipfftDestroy frees with stream-ordered semantics after a device sync).
+    (void)hipDeviceSynchronize();
+    for (auto& kv : g_plans) (void)hipfftDestroy(kv.second);
+    g_plans.clear();
   }
   int n[3];
   for (int i = 0; i < g.rank; ++i) n[i] = g.F[3 - g.rank + i];
@@ -156,6 +175,10 @@ int get_plan(const FftGeo& g, int batch, hipfftType type, hipfftHandle* out) {
       hipfftPlanMany(&h, g.rank, n, nullptr, 1, 0, nullptr, 1, 0, type, batch);
   if (rc != HIPFFT_SUCCESS)
     return fail(SFM_ERR_HIP, "hipfftPlanMany failed with %d", static_cast<int>(rc));
+  if (hipfftSetStream(h, st) != HIPFFT_SUCCESS) {
+    (void)hipfftDestroy(h);
+    return fail(SFM_ERR_HIP, "hipfftSetStream failed");
+  }
   g_plans[key] = h;
   *out = h;
   return SFM_OK;
@@ -238,11 +261,8 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
   for (int lo = 0; lo < d->batch; lo += nb_max) {
     const int nb = d->batch - lo < nb_max ? d->batch - lo : nb_max;
     hipfftHandle fwd, inv;
-    if (int rc = get_plan(g, nb, HIPFFT_R2C, &fwd)) return rc;
-    if (int rc = get_plan(g, nb, HIPFFT_C2R, &inv)) return rc;
-    if (hipfftSetStream(fwd, st) != HIPFFT_SUCCESS ||
-        hipfftSetStream(inv, st) != HIPFFT_SUCCESS)
-      return fail(SFM_ERR_HIP, "hipfftSetStream failed");
+    if (int rc = get_plan(g, nb, HIPFFT_R2C, st, &fwd)) return rc;
+    if (int rc = get_plan(g, nb, HIPFFT_C2R, st, &inv)) return rc;
 
     auto forward = [&](const float* src, bool pre, int square, float2* out) -> int {
       PadArgs p;

@@ -26,6 +26,7 @@ from __future__ import annotations
 import collections.abc
 import ctypes as C
 import itertools
+import threading
 from typing import Callable, Iterator, Sequence, TypeVar
 
 import numpy as np
@@ -174,13 +175,15 @@ LAUNCH_PATCHES = 4096
 # persistent correlation kernel by the next call's prep kernel).
 OVERLAP_CALLS = False  # measured gain ~1 %: opt-in
 _SIDE_STREAMS = {}
+_SIDE_LOCK = threading.Lock()
 
 
 def _side_stream(dev) -> torch.cuda.Stream:
-  key = torch.device(dev).index
-  if key not in _SIDE_STREAMS:
-    _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-  return _SIDE_STREAMS[key]
+  key = (torch.device(dev).index, threading.get_ident())
+  with _SIDE_LOCK:
+    if key not in _SIDE_STREAMS:
+      _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
 
 
 def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray,
@@ -386,7 +389,10 @@ class JAXMaskedXCorrWithStatsCalculator:
     self._min_distance = peak_min_distance
     self._peak_radius = peak_radius
     self._method = method
-    self._plans = {}  # geometry -> host plan of plain (un-masked, un-targeted) calls
+    # geometry -> host plan of plain (un-masked, un-targeted) calls; LRU of 8,
+    # guarded because one calculator may be shared between Python threads
+    self._plans = collections.OrderedDict()
+    self._plans_lock = threading.Lock()
 
   # -- host planning -------------------------------------------------------
   @staticmethod
@@ -514,7 +520,12 @@ class JAXMaskedXCorrWithStatsCalculator:
              pre_targeting_field is None and post_targeting_field is None)
     key = (tuple(pre_image.shape), tuple(post_image.shape), patch_size, step,
            post_patch_size, int(batch_size))
-    plan = self._plans.get(key) if plain else None
+    plan = None
+    if plain:
+      with self._plans_lock:
+        plan = self._plans.get(key)
+        if plan is not None:
+          self._plans.move_to_end(key)
     if plan is None:
       plan = self.plan(tuple(pre_image.shape), tuple(post_image.shape),
                        patch_size, step, pre_mask, post_mask, selection_mask,
@@ -522,9 +533,11 @@ class JAXMaskedXCorrWithStatsCalculator:
                        pre_targeting_field, pre_targeting_step,
                        post_targeting_field, post_targeting_step)
       if plain:
-        if len(self._plans) >= 8:
-          self._plans.pop(next(iter(self._plans)))
-        self._plans[key] = plan
+        with self._plans_lock:
+          plan = self._plans.setdefault(key, plan)
+          while len(self._plans) > 8:
+            # the evicted plan's cached device start coordinates go with it
+            self._plans.popitem(last=False)
     pos = plan['positions']
     n = pos.shape[0]
     if n == 0:
@@ -559,7 +572,11 @@ class JAXMaskedXCorrWithStatsCalculator:
       if len(sel) == 0:
         return np.zeros((0, res.ndim + 2), np.float32)
     # the device copy of the start coordinates lives with a reused plan
-    cache = plan.setdefault('_starts_dev', {}) if batch_ids is None else None
+    if batch_ids is None:
+      with self._plans_lock:
+        cache = plan.setdefault('_starts_dev', {})
+    else:
+      cache = None
     return _run_batches(res, desc, pre_st, post_st, batch_size, progress, cache)
 
   @classmethod
@@ -580,7 +597,7 @@ class JAXMaskedXCorrWithStatsCalculator:
     if plan['post_offsets'] is not None:
       peaks[:, :nd] -= plan['post_offsets'][:n, ::-1]
     lin = plan.get('_lin')
-    if lin is None:
+    if lin is None:  # benign race: every thread computes the same array
       lin = plan['_lin'] = np.ravel_multi_index(tuple(pos.T), tuple(out_shape.tolist()))
     output.reshape(output.shape[0], -1)[:, lin] = peaks.T
     return output

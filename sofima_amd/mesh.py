@@ -360,7 +360,9 @@ def relax_mesh(x, prev, config: IntegrationConfig, mesh_force=inplane_force,
           t, dt, alpha, n_pos, cap, v_max, e_kin[-1])
 
     if v_max < config.stop_v_max:
-      if cap >= config.final_cap:
+      # float32 comparison like the reference's weakly typed JAX scalars
+      # (final_cap = 0.7 must compare equal to the kernel's float32 cap)
+      if np.float32(cap) >= np.float32(config.final_cap):
         break
       # Increase cap to ensure progress towards the termination condition.
       cap = min(cap * config.cap_scale, config.final_cap)
