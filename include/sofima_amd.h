@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 1
+#define SFM_ABI_VERSION 2
 
 #define SFM_OK 0
 #define SFM_ERR_INVALID (-1)     /* bad argument / unsupported combination */
@@ -222,6 +222,28 @@ int sfm_mask_irregular(const SfmMaskIrregularDesc* desc, float* coord_map,
                        uint8_t* bad);
 
 /* ------------------------------------------------------------------------
+ * Dynamic-range mask of an overlap strip, the step in front of the
+ * whole-overlap correlation of a tile pair.
+ * Replaces the mask construction of stitch_rigid._estimate_offset
+ * (stitch_rigid.py:47-60): out = (maximum_filter(img, size) -
+ * minimum_filter(img, size)) < range_limit, OR-ed with `extra_mask`
+ * (scipy.ndimage filters: mode "reflect", window [i - size/2, i - size/2 +
+ * size - 1]; uint8 images subtract in uint8).
+ * ---------------------------------------------------------------------- */
+typedef struct SfmRangeMaskDesc {
+  int32_t dtype;                /* SFM_DTYPE_* of the image                  */
+  int32_t shape[2];             /* y, x                                      */
+  int32_t filter_size;
+  double range_limit;
+  const void* image;            /* device [y, x]                             */
+  const uint8_t* extra_mask;    /* device bool bytes [y, x] or NULL          */
+  void* stream;
+} SfmRangeMaskDesc;
+
+/* out: device uint8 [y, x] (1 = masked). */
+int sfm_range_mask(const SfmRangeMaskDesc* desc, uint8_t* out);
+
+/* ------------------------------------------------------------------------
  * Target mesh of an elastic tile montage.
  * Replaces stitch_elastic.compute_target_mesh (stitch_elastic.py:624-676,
  * with _update_mesh :573-620 and _apply_flow :456-570) vmapped over all
@@ -251,6 +273,22 @@ int sfm_target_mesh(const SfmTargetMeshDesc* desc, const float* x, float* out,
  * Spring mesh.
  * ---------------------------------------------------------------------- */
 #define SFM_MESH_MAX_LINKS 13
+
+/* Which mesh_force the integrator evaluates (the `mesh_force` argument of
+ * mesh.relax_mesh / velocity_verlet, mesh.py:372-382). */
+#define SFM_FORCE_SPRINGS 0    /* inplane_force / elastic_mesh_3d link stencils  */
+#define SFM_FORCE_TILE_MESH 1  /* stitch_rigid.elastic_tile_mesh (stitch_rigid.py:
+                                  330-388) for ncomp 2, elastic_tile_mesh_3d
+                                  (:391-473) for ncomp 3: every node is a tile,
+                                  cx / cy are the desired offsets to the +x / +y
+                                  tile, force = displacement mismatch          */
+#define SFM_FORCE_EXTERNAL 2   /* produced by the caller through force_cb        */
+
+/* SFM_FORCE_EXTERNAL: called on the host before every force evaluation (once
+ * for the initial a = F(x), then once per step after the position update).
+ * It must enqueue, on SfmMeshDesc.stream, work that leaves mesh_force(x) in
+ * SfmMeshDesc.ext_force.  Non-zero return aborts the chunk with SFM_ERR_INVALID. */
+typedef int (*SfmForceCallback)(void* user);
 
 typedef struct SfmMeshDesc {
   int32_t ncomp;                /* 2: inplane_force (mesh.py:42-169)
@@ -290,6 +328,13 @@ typedef struct SfmMeshDesc {
   /* Optional native prev_fn (mesh.py:429-430): when set, `prev` must be NULL
      and prev = target_mesh(x) is re-evaluated inside every force evaluation. */
   const SfmTargetMeshDesc* target;
+  /* Force model; zero-initialised descriptors get the spring stencils. */
+  int32_t force_kind;           /* SFM_FORCE_*                               */
+  const float* cx;              /* TILE_MESH: device [ncomp, batch*z, y, x]  */
+  const float* cy;
+  float* ext_force;             /* EXTERNAL: device, same shape as x         */
+  SfmForceCallback force_cb;
+  void* force_user;
 } SfmMeshDesc;
 
 /* FIRE scalars carried between chunks (mesh.py:449, :513, :589). */

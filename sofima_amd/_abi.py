@@ -125,6 +125,18 @@ class SfmMaskIrregularDesc(C.Structure):
   ]
 
 
+class SfmRangeMaskDesc(C.Structure):
+  _fields_ = [
+      ('dtype', i32),
+      ('shape', i32 * 2),
+      ('filter_size', i32),
+      ('range_limit', C.c_double),
+      ('image', C.c_void_p),
+      ('extra_mask', C.c_void_p),
+      ('stream', C.c_void_p),
+  ]
+
+
 class SfmTargetMeshDesc(C.Structure):
   _fields_ = [
       ('ncomp', i32),
@@ -140,6 +152,12 @@ class SfmTargetMeshDesc(C.Structure):
       ('fx', C.c_void_p),
       ('fy', C.c_void_p),
   ]
+
+
+FORCE_SPRINGS = 0
+FORCE_TILE_MESH = 1
+FORCE_EXTERNAL = 2
+SfmForceCallback = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
 class SfmMeshDesc(C.Structure):
@@ -174,6 +192,12 @@ class SfmMeshDesc(C.Structure):
       ('workspace_bytes', C.c_size_t),
       ('stream', C.c_void_p),
       ('target', C.POINTER(SfmTargetMeshDesc)),
+      ('force_kind', i32),
+      ('cx', C.c_void_p),
+      ('cy', C.c_void_p),
+      ('ext_force', C.c_void_p),
+      ('force_cb', SfmForceCallback),
+      ('force_user', C.c_void_p),
   ]
 
 
@@ -207,6 +231,7 @@ SIGNATURES = {
     'sfm_clean_flow': (C.c_int, [C.POINTER(SfmCleanFlowDesc), C.c_void_p]),
     'sfm_mask_irregular': (C.c_int, [C.POINTER(SfmMaskIrregularDesc), C.c_void_p,
                                      C.c_void_p]),
+    'sfm_range_mask': (C.c_int, [C.POINTER(SfmRangeMaskDesc), C.c_void_p]),
     'sfm_target_mesh': (C.c_int, [C.POINTER(SfmTargetMeshDesc), C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     'sfm_mesh_workspace_bytes': (C.c_size_t, [C.POINTER(SfmMeshDesc)]),

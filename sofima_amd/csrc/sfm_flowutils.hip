@@ -3,6 +3,8 @@
 //
 //   sfm_clean_flow      <->  flow_utils.clean_flow (flow_utils.py:37-78)
 //   sfm_mask_irregular  <->  map_utils.mask_irregular (map_utils.py:737-786)
+//   sfm_range_mask      <->  the dynamic-range mask of stitch_rigid._estimate_offset
+//                            (stitch_rigid.py:47-60)
 //
 // One thread per vector.  The field is small (one vector per patch), so the
 // point of the kernel is that the flow can stay in HBM from the correlation
@@ -167,6 +169,79 @@ extern "C" int sfm_mask_irregular(const SfmMaskIrregularDesc* d, float* coord_ma
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   hipLaunchKernelGGL(irregular_mark_kernel, dim3(grid), dim3(kBlock), 0, st, a);
   hipLaunchKernelGGL(irregular_fill_kernel, dim3(grid), dim3(kBlock), 0, st, a);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Dynamic-range mask (stitch_rigid.py:47-60):
+//   (maximum_filter(img, size) - minimum_filter(img, size)) < range_limit  [| extra]
+// scipy.ndimage filters, mode "reflect", origin 0: the window of pixel i covers
+// [i - size / 2, i - size / 2 + size - 1] per axis.  uint8 images subtract in
+// uint8 (max >= min: no wrap) and compare as integers against the limit;
+// float images subtract and compare in float32.
+// ---------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int reflect_any(int i, int n) {
+  // whole-period reflection: valid for any overhang
+  if (n == 1) return 0;
+  const int period = 2 * n;
+  int m = i % period;
+  if (m < 0) m += period;
+  return m < n ? m : period - 1 - m;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+range_mask_kernel(const T* __restrict__ img, const uint8_t* __restrict__ extra,
+                  uint8_t* __restrict__ out, int Y, int X, int size, double limit) {
+  const long long n = (long long)Y * X;
+  const long long i = blockIdx.x * (long long)kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int y = static_cast<int>(i / X), x = static_cast<int>(i % X);
+  const int lo = size / 2;
+  T mx = img[i], mn = img[i];
+  for (int dy = 0; dy < size; ++dy) {
+    const int yy = reflect_any(y - lo + dy, Y);
+    for (int dx = 0; dx < size; ++dx) {
+      const int xx = reflect_any(x - lo + dx, X);
+      const T v = img[(long long)yy * X + xx];
+      mx = v > mx ? v : mx;
+      mn = v < mn ? v : mn;
+    }
+  }
+  // NumPy compares the (uint8 | float32) difference with the Python scalar in
+  // double precision for floats' sake; both are exact in double.
+  const T diff = static_cast<T>(mx - mn);
+  uint8_t m = static_cast<double>(diff) < limit ? 1 : 0;
+  if (extra) m |= extra[i] != 0;
+  out[i] = m;
+}
+
+}  // namespace
+
+extern "C" int sfm_range_mask(const SfmRangeMaskDesc* d, uint8_t* out) {
+  if (!d || !d->image || !out)
+    return sfm::fail(SFM_ERR_INVALID, "range_mask: NULL argument");
+  if (d->shape[0] < 1 || d->shape[1] < 1 || d->filter_size < 1)
+    return sfm::fail(SFM_ERR_INVALID, "range_mask: bad shape / filter size");
+  const long long n = (long long)d->shape[0] * d->shape[1];
+  const long long grid = (n + kBlock - 1) / kBlock;
+  if (grid > 0x7fffffffLL) return sfm::fail(SFM_ERR_INVALID, "range_mask: too large");
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  if (d->dtype == SFM_DTYPE_U8)
+    hipLaunchKernelGGL(range_mask_kernel<uint8_t>, dim3(static_cast<unsigned>(grid)),
+                       dim3(kBlock), 0, st, static_cast<const uint8_t*>(d->image),
+                       d->extra_mask, out, d->shape[0], d->shape[1], d->filter_size,
+                       d->range_limit);
+  else if (d->dtype == SFM_DTYPE_F32)
+    hipLaunchKernelGGL(range_mask_kernel<float>, dim3(static_cast<unsigned>(grid)),
+                       dim3(kBlock), 0, st, static_cast<const float*>(d->image),
+                       d->extra_mask, out, d->shape[0], d->shape[1], d->filter_size,
+                       d->range_limit);
+  else
+    return sfm::fail(SFM_ERR_INVALID, "range_mask: dtype %d", d->dtype);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }

@@ -69,6 +69,10 @@ struct MeshParams {
   float final_cap, cap_scale;
   int cap_every;
   float n_f;  // N as the f32 mean divisor (mean = sum / N)
+  int force_kind;       // SFM_FORCE_*
+  const float* cx;      // tile mesh: desired offset to the +x tile, [C, B, Y, X]
+  const float* cy;      // tile mesh: desired offset to the +y tile
+  const float* ext;     // external force, [C, N]
 };
 
 struct Scalars {
@@ -312,14 +316,66 @@ __device__ __forceinline__ void node_force_default3d(const float* __restrict__ x
   out[2] = acc[2];
 }
 
+// jnp.nan_to_num with its defaults: nan -> 0, +-inf -> +-FLT_MAX.
+__device__ __forceinline__ float nan_to_num_default(float v) {
+  if (isnan(v)) return 0.f;
+  if (isinf(v)) return v > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  return v;
+}
+
+// stitch_rigid.elastic_tile_mesh (stitch_rigid.py:330-388) / elastic_tile_mesh_3d
+// (:391-473) at one node.  Every node is a tile; the pair (i, i+1) along x
+// contributes t = nan_to_num((x_c[i+1] - x_c[i]) - cx_c[i]) to node i and -t to
+// node i+1, likewise along y with cy, for every vector component c.  The
+// reference adds the terms family by family (f_tot += pad(f); f_tot -= pad(f)):
+// component 0: x pairs, then y pairs; component 1: y pairs, then x pairs;
+// component 2: x pairs, then y pairs.  Sections (z) are independent.
+template <int C>
+__device__ __forceinline__ void tile_mesh_force(const float* __restrict__ x,
+                                                const MeshParams& p, long long n,
+                                                int xi, int yi, float* out) {
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float* xc = x + c * p.N;
+    const float s = xc[n];
+    float ax_p = 0.f, ax_m = 0.f, ay_p = 0.f, ay_m = 0.f;
+    if (xi + 1 < p.X) ax_p = nan_to_num_default((xc[n + 1] - s) - p.cx[c * p.N + n]);
+    if (xi > 0) ax_m = nan_to_num_default((s - xc[n - 1]) - p.cx[c * p.N + n - 1]);
+    if (yi + 1 < p.Y) ay_p = nan_to_num_default((xc[n + p.X] - s) - p.cy[c * p.N + n]);
+    if (yi > 0) ay_m = nan_to_num_default((s - xc[n - p.X]) - p.cy[c * p.N + n - p.X]);
+    float acc = 0.f;
+    if (c == 1) {
+      acc = acc + ay_p;
+      acc = acc - ay_m;
+      acc = acc + ax_p;
+      acc = acc - ax_m;
+    } else {
+      acc = acc + ax_p;
+      acc = acc - ax_m;
+      acc = acc + ay_p;
+      acc = acc - ay_m;
+    }
+    out[c] = acc;
+  }
+}
+
 template <int C>
 __device__ void node_force(const float* __restrict__ x, const MeshParams& p,
                            long long n, float* out) {
+  if (p.force_kind == SFM_FORCE_EXTERNAL) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = p.ext[c * p.N + n];
+    return;
+  }
   const int xi = static_cast<int>(n % p.X);
   long long r = n / p.X;
   const int yi = static_cast<int>(r % p.Y);
   r /= p.Y;
   const int zi = static_cast<int>(r % p.Z);
+  if (p.force_kind == SFM_FORCE_TILE_MESH) {
+    tile_mesh_force<C>(x, p, n, xi, yi, out);
+    return;
+  }
   float self[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) self[c] = x[c * p.N + n];
@@ -1380,7 +1436,25 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
   p->prefer = d->prefer_orig_order;
   p->neg_k0 = static_cast<float>(-d->k0);
   p->has_prev = d->prev != nullptr || d->target != nullptr;
-  if (d->ncomp == 2) {
+  p->force_kind = d->force_kind;
+  if (d->force_kind < SFM_FORCE_SPRINGS || d->force_kind > SFM_FORCE_EXTERNAL)
+    return sfm::fail(SFM_ERR_INVALID, "force_kind %d", d->force_kind);
+  if (d->force_kind == SFM_FORCE_TILE_MESH) {
+    if (!d->cx || !d->cy)
+      return sfm::fail(SFM_ERR_INVALID, "tile mesh force needs cx and cy");
+    p->cx = d->cx;
+    p->cy = d->cy;
+  }
+  if (d->force_kind == SFM_FORCE_EXTERNAL) {
+    if (!d->ext_force || !d->force_cb)
+      return sfm::fail(SFM_ERR_INVALID, "external force needs ext_force and force_cb");
+    p->ext = d->ext_force;
+  }
+  if (d->force_kind != SFM_FORCE_SPRINGS) {
+    // no link stencil: sections (batch and z) are independent planes
+    p->Z = 1;
+    p->B = d->shape[0] * d->shape[1];
+  } else if (d->ncomp == 2) {
     // Batch and z are both independent slices for the in-plane force; fold
     // them so the stencil never crosses a slice (Z extent of the stencil = 1).
     p->Z = 1;
@@ -1542,13 +1616,17 @@ MeshWorkspace carve(void* ws, size_t prev_floats, size_t alt_floats, long long t
 
 MeshWorkspace carve_for(const SfmMeshDesc* d, void* ws, TilePlan* plan) {
   const size_t n = (size_t)d->shape[0] * d->shape[1] * d->shape[2] * d->shape[3];
-  const TilePlan t = plan_tiles(d->ncomp, (long long)d->shape[0] * d->shape[1],
-                                d->shape[2], d->shape[3]);
+  const TilePlan t = d->force_kind == SFM_FORCE_SPRINGS
+                         ? plan_tiles(d->ncomp, (long long)d->shape[0] * d->shape[1],
+                                      d->shape[2], d->shape[3])
+                         : TilePlan();
   if (plan) *plan = t;
   const size_t cn = (size_t)d->ncomp * n;
   // second (x, v, a) set: ping-pong of the fused tiled step, staging of the
   // persistent kernel's result
-  return carve(ws, d->target ? cn : 0, (d->ncomp == 2 && !d->target) ? cn : 0, t.tiles,
+  return carve(ws, d->target ? cn : 0,
+               (d->ncomp == 2 && !d->target && d->force_kind == SFM_FORCE_SPRINGS) ? cn : 0,
+               t.tiles,
                d->shape[3]);
 }
 
@@ -1565,6 +1643,8 @@ int sfm_mesh_force(const SfmMeshDesc* d, float* out) {
   MeshParams p;
   if (int rc = build_params(d, &p)) return rc;
   if (!d->x || !out) return sfm::fail(SFM_ERR_INVALID, "x/out is NULL");
+  if (p.force_kind == SFM_FORCE_EXTERNAL)
+    return sfm::fail(SFM_ERR_INVALID, "sfm_mesh_force: the external force is the caller's");
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const int grid = grid_for(p.N);
   if (p.ncomp == 2)
@@ -1614,7 +1694,8 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   const float cap0 = fire->cap;
 
   // Persistent single-launch path for in-plane meshes that fit the chip.
-  if (persistent_enabled() && p.ncomp == 2 && d->num_iters >= 1 && !d->target) {
+  if (persistent_enabled() && p.ncomp == 2 && d->num_iters >= 1 && !d->target &&
+      p.force_kind == SFM_FORCE_SPRINGS) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess) {
       hipDeviceProp_t prop;
@@ -1702,9 +1783,19 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     SFM_LAUNCH_CHECK();                                                      \
   } while (0)
 
+  // The caller's mesh_force (SFM_FORCE_EXTERNAL) is evaluated on the host's
+  // initiative right before the kernel that consumes it.
+  auto external_force = [&]() -> int {
+    if (p.force_kind != SFM_FORCE_EXTERNAL) return SFM_OK;
+    if (d->force_cb(d->force_user) != 0)
+      return sfm::fail(SFM_ERR_INVALID, "mesh: the external force callback failed");
+    return SFM_OK;
+  };
+
   // a = F(x) + pull(prev, cap)   (mesh.py:501); prev = prev_fn(x) if native
   if (d->target)
     if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
+  if (int rc = external_force()) return rc;
   SFM_MESH_DISPATCH(force_kernel, d->x, prev_ptr, d->a, p, cap0, p.has_prev);
 
   int cur = 0;
@@ -1773,6 +1864,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       cur ^= 1;
       if (d->target)
         if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, ls)) return rc;
+      if (int rc = external_force()) return rc;
       if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
       SFM_STEP_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
                         &w.scal[cur], cap0, w.partials);
@@ -1795,6 +1887,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   // Launch-bound meshes (small, several launches per step): replay pairs of
   // steps from a hipGraph instead of enqueueing every kernel from the host.
   if (graph_enabled() && !sfm::profiling() && p.N <= kGraphMaxNodes &&
+      p.force_kind != SFM_FORCE_EXTERNAL &&
       d->num_iters - it >= 8) {
     const int pairs = (d->num_iters - it) / 2;
     hipGraph_t graph = nullptr;

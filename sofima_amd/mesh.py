@@ -60,12 +60,22 @@ MESH_LINK_DIRECTIONS = (  # xyz
 )
 
 
-def _base_desc(x_t: torch.Tensor, ncomp: int, k: float, stride,
-               prefer_orig_order: bool, links=None) -> _abi.SfmMeshDesc:
+def _base_desc(x_t: torch.Tensor, spec, k: float, stride,
+               prefer_orig_order: bool) -> _abi.SfmMeshDesc:
   d = _abi.SfmMeshDesc()
+  ncomp = spec.ncomp if spec.ncomp is not None else int(x_t.shape[0])
+  if ncomp not in (2, 3) or x_t.shape[0] != ncomp:
+    raise ValueError(f'x must be [{ncomp}, ...], got {tuple(x_t.shape)}')
+  links = spec.links
   d.ncomp = ncomp
   sp = tuple(x_t.shape[1:])
-  if ncomp == 2:
+  if spec.kind != _abi.FORCE_SPRINGS:
+    # no link stencil across sections: every leading axis is a batch of planes
+    if len(sp) < 2:
+      raise ValueError('mesh states must be [c, ..., y, x]')
+    lead = int(np.prod(sp[:-2])) if len(sp) > 2 else 1
+    shape = (1, lead) + sp[-2:]
+  elif ncomp == 2:
     if len(sp) != 3:
       raise ValueError('in-plane meshes must be [2, z, y, x]')
     shape = (1,) + sp
@@ -75,7 +85,8 @@ def _base_desc(x_t: torch.Tensor, ncomp: int, k: float, stride,
     batch = int(np.prod(sp[:-3])) if len(sp) > 3 else 1
     shape = (batch,) + sp[-3:]
   d.shape = (C.c_int32 * 4)(*[int(s) for s in shape])
-  st = [float(s) for s in stride] + [0.0] * (3 - len(stride))
+  st = [float(s) for s in stride][:3]
+  st += [0.0] * (3 - len(st))
   d.stride = (C.c_double * 3)(*st)
   d.k = float(k)
   d.prefer_orig_order = int(bool(prefer_orig_order))
@@ -92,16 +103,23 @@ def _base_desc(x_t: torch.Tensor, ncomp: int, k: float, stride,
         d.links[i][c] = l[c]
   d.x = x_t.data_ptr()
   d.stream = _dev.stream_ptr()
+  d.force_kind = spec.kind
+  if spec.tile is not None:
+    spec.tile.bind(d, x_t)
   return d
 
 
 def _force(x, ncomp, k, stride, prefer_orig_order, links=None) -> DeviceArray:
   dev = _dev.device()
   x_t = _dev.as_device_f32(x, dev, copy=False)
-  d = _base_desc(x_t, ncomp, k, stride, prefer_orig_order, links)
+  d = _base_desc(x_t, _SpringSpec(ncomp, links), k, stride, prefer_orig_order)
   out = torch.empty_like(x_t)
   _abi.check(_abi.load().sfm_mesh_force(C.byref(d), out.data_ptr()))
   return DeviceArray(out)
+
+
+def _SpringSpec(ncomp, links=None):
+  return _ForceSpec(_abi.FORCE_SPRINGS, ncomp, links=links)
 
 
 def inplane_force(x, k: float, stride: Sequence[float],
@@ -203,20 +221,76 @@ class IntegrationConfig(_JsonMixin):
 # ---------------------------------------------------------------------------
 # integrator
 # ---------------------------------------------------------------------------
-def _resolve_force(mesh_force):
-  """Maps a `mesh_force` callable to (ncomp, links) of a native kernel."""
+class TileMeshForce:
+  """Native `mesh_force` of a tile mesh: stitch_rigid.elastic_tile_mesh
+  (stitch_rigid.py:330-388) for [2, z, y, x] states, elastic_tile_mesh_3d
+  (:391-473) for [3, z, y, x] states, closed over the desired tile offsets
+  `cx` / `cy` like the `_mesh_force` closure of optimize_coarse_mesh (:509-510).
+  Passing it as `mesh_force=` keeps the whole relaxation in the HIP integrator.
+  """
+
+  def __init__(self, cx, cy):
+    dev = _dev.device()
+    self.cx = _dev.as_device_f32(cx, dev, copy=False)
+    self.cy = _dev.as_device_f32(cy, dev, copy=False)
+    if self.cx.shape != self.cy.shape or self.cx.ndim != 4 or \
+        self.cx.shape[0] not in (2, 3):
+      raise ValueError('cx, cy must be [2 or 3, z, y, x] arrays of one shape')
+    self.ncomp = int(self.cx.shape[0])
+
+  def bind(self, d: _abi.SfmMeshDesc, x_t: torch.Tensor):
+    if tuple(x_t.shape) != tuple(self.cx.shape):
+      raise ValueError(f'x {tuple(x_t.shape)} and cx/cy {tuple(self.cx.shape)} '
+                       'must have the same shape')
+    d.force_kind = _abi.FORCE_TILE_MESH
+    d.cx = self.cx.data_ptr()
+    d.cy = self.cy.data_ptr()
+
+  def __call__(self, x, k=None, stride=None, prefer_orig_order=False,
+               links=None) -> DeviceArray:
+    del k, stride, prefer_orig_order, links
+    dev = _dev.device()
+    x_t = _dev.as_device_f32(x, dev, copy=False)
+    d = _base_desc(x_t, _ForceSpec(_abi.FORCE_TILE_MESH, self.ncomp, tile=self),
+                   0.0, (1.0,) * self.ncomp, False)
+    out = torch.empty_like(x_t)
+    _abi.check(_abi.load().sfm_mesh_force(C.byref(d), out.data_ptr()))
+    return DeviceArray(out)
+
+
+@dataclasses.dataclass
+class _ForceSpec:
+  """What the integrator evaluates as `mesh_force`."""
+  kind: int                     # _abi.FORCE_*
+  ncomp: int | None             # None: taken from x (external callables)
+  links: Any = None             # spring stencils: custom link subset
+  tile: TileMeshForce | None = None
+  fn: Any = None                # external: the caller's callable
+
+
+def _resolve_force(mesh_force) -> _ForceSpec:
+  """Maps a `mesh_force` callable to the force model of the HIP integrator.
+
+  The package's own force functions run fused inside the integrator kernels.
+  Any other callable `f(x, k, stride, prefer_orig_order) -> force` (the
+  reference's contract, mesh.py:427-428) is evaluated between the position
+  update and the velocity update of every step, on the device: it receives the
+  live positions as a `DeviceArray` (`.tensor` is the torch CUDA tensor) and
+  may return a DeviceArray, a torch tensor or a NumPy array.
+  """
   if mesh_force is inplane_force:
-    return 2, None
+    return _ForceSpec(_abi.FORCE_SPRINGS, 2)
   if mesh_force is elastic_mesh_3d:
-    return 3, None
+    return _ForceSpec(_abi.FORCE_SPRINGS, 3)
   if isinstance(mesh_force, functools.partial) and \
       mesh_force.func is elastic_mesh_3d and not mesh_force.args and \
       set(mesh_force.keywords) <= {'links'}:
-    return 3, mesh_force.keywords.get('links')
-  raise NotImplementedError(
-      'mesh_force must be sofima_amd.mesh.inplane_force, elastic_mesh_3d or '
-      'functools.partial(elastic_mesh_3d, links=...); arbitrary Python '
-      'callables cannot be fused into the HIP integrator (see DESIGN.md).')
+    return _ForceSpec(_abi.FORCE_SPRINGS, 3, links=mesh_force.keywords.get('links'))
+  if isinstance(mesh_force, TileMeshForce):
+    return _ForceSpec(_abi.FORCE_TILE_MESH, mesh_force.ncomp, tile=mesh_force)
+  if callable(mesh_force):
+    return _ForceSpec(_abi.FORCE_EXTERNAL, None, fn=mesh_force)
+  raise TypeError('mesh_force must be callable')
 
 
 def _native_prev_fn(prev_fn):
@@ -229,11 +303,11 @@ def _native_prev_fn(prev_fn):
       'Python callables cannot be fused into the HIP integrator (DESIGN.md)')
 
 
-def _chunk_desc(x_t, v_t, a_t, prev_t, config: IntegrationConfig, ncomp, links,
+def _chunk_desc(x_t, v_t, a_t, prev_t, config: IntegrationConfig, spec,
                 ws) -> _abi.SfmMeshDesc:
-  d = _base_desc(x_t, ncomp, config.k, config.stride, config.prefer_orig_order,
-                 links)
-  if ncomp == 2 and len(config.stride) != 2:
+  d = _base_desc(x_t, spec, config.k, config.stride, config.prefer_orig_order)
+  if spec.kind == _abi.FORCE_SPRINGS and spec.ncomp == 2 and \
+      len(config.stride) != 2:
     raise ValueError('stride must be 2D.')
   d.k0 = float(config.k0)
   d.dt = float(config.dt)
@@ -260,30 +334,62 @@ def _chunk_desc(x_t, v_t, a_t, prev_t, config: IntegrationConfig, ncomp, links,
   return d
 
 
-def _run_chunk(x_t, v_t, prev_t, config, force_cap, fire_dt, fire_alpha, ncomp,
-               links, target=None):
+def _external_force(spec, x_t, config):
+  """(force buffer, ctypes callback, error list) for a caller-provided
+  mesh_force: the callback evaluates it on the live positions and leaves the
+  result in the buffer the integrate kernel reads (same stream)."""
+  f_t = torch.empty_like(x_t)
+  errors = []
+  x_view = DeviceArray(x_t)
+
+  def call(_user):
+    try:
+      f = spec.fn(x_view, config.k, config.stride, config.prefer_orig_order)
+      f = _dev.as_device_f32(f, x_t.device, copy=False)
+      if tuple(f.shape) != tuple(x_t.shape):
+        raise ValueError(f'mesh_force returned shape {tuple(f.shape)}, '
+                         f'expected {tuple(x_t.shape)}')
+      f_t.copy_(f)
+      return 0
+    except BaseException as e:  # pylint: disable=broad-except
+      errors.append(e)
+      return 1
+
+  return f_t, _abi.SfmForceCallback(call), errors
+
+
+def _run_chunk(x_t, v_t, prev_t, config, force_cap, fire_dt, fire_alpha, spec,
+               target=None):
   """One velocity_verlet call on device tensors (x_t, v_t updated in place)."""
   lib = _abi.load()
   a_t = torch.empty_like(x_t)
-  probe = _base_desc(x_t, ncomp, config.k, config.stride,
-                     config.prefer_orig_order, links)
+  ext = None
+  if spec.kind == _abi.FORCE_EXTERNAL:
+    ext = _external_force(spec, x_t, config)
+  probe = _base_desc(x_t, spec, config.k, config.stride,
+                     config.prefer_orig_order)
   tdesc = None
   if target is not None:
     tdesc = target.bind(x_t)
     probe.target = C.pointer(tdesc)
   ws = _dev.workspace(lib.sfm_mesh_workspace_bytes(C.byref(probe)),
                       x_t.device)
-  d = _chunk_desc(x_t, v_t, a_t, prev_t, config, ncomp, links, ws)
+  d = _chunk_desc(x_t, v_t, a_t, prev_t, config, spec, ws)
   if tdesc is not None:
     d.target = C.pointer(tdesc)
+  if ext is not None:
+    d.ext_force = ext[0].data_ptr()
+    d.force_cb = ext[1]
   fire = _abi.SfmFireState()
   fire.dt = np.float32(config.dt if fire_dt is None else fire_dt)
   fire.alpha = np.float32(config.alpha if fire_alpha is None else fire_alpha)
   fire.n_pos = 0
   fire.cap = np.float32(force_cap)
   stats = _abi.SfmChunkStats()
-  _abi.check(lib.sfm_mesh_relax_chunk(C.byref(d), C.byref(fire),
-                                      C.byref(stats)))
+  rc = lib.sfm_mesh_relax_chunk(C.byref(d), C.byref(fire), C.byref(stats))
+  if ext is not None and ext[2]:
+    raise ext[2][0]  # the caller's mesh_force raised: surface its exception
+  _abi.check(rc)
   return a_t, fire, stats
 
 
@@ -300,13 +406,13 @@ def velocity_verlet(x, v, prev, config: IntegrationConfig, force_cap: float,
   target = None if prev_fn is None else _native_prev_fn(prev_fn)
   if target is not None and prev is not None:
     raise ValueError('Only one of: "prev" and "prev_fn" can be specified.')
-  ncomp, links = _resolve_force(mesh_force)
+  spec = _resolve_force(mesh_force)
   dev = _dev.device()
   x_t = _dev.as_device_f32(x, dev, copy=True)
   v_t = _dev.as_device_f32(v, dev, copy=True)
   prev_t = None if prev is None else _dev.as_device_f32(prev, dev, copy=False)
   a_t, fire, _ = _run_chunk(x_t, v_t, prev_t, config, force_cap, fire_dt,
-                            fire_alpha, ncomp, links, target)
+                            fire_alpha, spec, target)
   out = (DeviceArray(x_t), DeviceArray(v_t), DeviceArray(a_t))
   if config.fire:
     out += (np.float32(fire.dt), np.float32(fire.alpha), int(fire.n_pos),
@@ -339,7 +445,7 @@ def relax_mesh(x, prev, config: IntegrationConfig, mesh_force=inplane_force,
     raise ValueError('Only one of: "prev" and "prev_fn" can be specified.')
   target = None if prev_fn is None else _native_prev_fn(prev_fn)
 
-  ncomp, links = _resolve_force(mesh_force)
+  spec = _resolve_force(mesh_force)
   dev = _dev.device()
   x_t = _dev.as_device_f32(x, dev, copy=True)
   v_t = torch.zeros_like(x_t)
@@ -347,7 +453,7 @@ def relax_mesh(x, prev, config: IntegrationConfig, mesh_force=inplane_force,
 
   while t < config.max_iters:
     _, fire, stats = _run_chunk(x_t, v_t, prev_t, config, cap, dt, alpha,
-                                ncomp, links, target)
+                                spec, target)
     t += config.num_iters
     e_kin.append(float(stats.e_kin))
     v_max = float(stats.v_max)

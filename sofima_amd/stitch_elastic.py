@@ -113,3 +113,67 @@ def compute_target_mesh(nbor_data, x, fx, fy, stride=(20, 20)) -> np.ndarray:
   # every "tile" of the batch uses the same neighbour rows; entry 0 is the
   # result the reference returns for this nbor_data
   return np.asarray(fn(x))[:, 0]
+
+
+def _overlap_strips(pre, post, off_xy, axis: int, stride):
+  """Overlap strips of an adjacent tile pair, aligned to the flow stride
+  (stitch_elastic.py:232-262), and the offset recorded for them (:277-280).
+
+  off_xy: coarse (x, y) offset of `post`; stride is yx.
+  """
+  along = 1 - axis                    # image axis of the tile-tile connection
+  # strip width: the start inside `pre` is moved down to a stride multiple
+  extent = pre.shape[along]
+  start = (extent + int(off_xy[axis])) // stride[along] * stride[along]
+  overlap = extent - start
+  # orthogonal shift, rounded to the stride of that image axis
+  s_ortho = stride[::-1][1 - axis]
+  ortho = int(s_ortho * np.round(off_xy[1 - axis] / s_ortho))
+  pre_sl = [slice(None), slice(None)]
+  post_sl = [slice(None), slice(None)]
+  pre_sl[along] = slice(start, None)
+  post_sl[along] = slice(0, overlap)
+  if ortho > 0:                       # post sits further along the ortho axis
+    pre_sl[axis] = slice(ortho, None)
+    post_sl[axis] = slice(None, -ortho)
+  elif ortho < 0:
+    pre_sl[axis] = slice(None, ortho)
+    post_sl[axis] = slice(-ortho, None)
+  off = (-overlap, ortho) if axis == 0 else (ortho, -overlap)
+  return pre[tuple(pre_sl)], post[tuple(post_sl)], off
+
+
+def compute_flow_map(tile_map, offset_map: np.ndarray, axis: int,
+                     patch_size=(120, 120), stride=(20, 20),
+                     batch_size: int = 256):
+  """Fine flow between horizontally (axis 0) or vertically (axis 1) adjacent
+  2-d tiles (stitch_elastic.py:198-282).
+
+  tile_map: (x, y) -> tile image; offset_map: [2, y, x] coarse XY offsets of
+  the (x+1, y) / (x, y+1) tile.  Returns ({(x, y): flow [4, gy, gx]},
+  {(x, y): (off_x, off_y) at which the flow was computed}); the flow arrays are
+  NaN-padded by patch // 2 // stride nodes so that they are aligned with the
+  tile's mesh.  Every pair is one `flow_field` call on the overlap strips,
+  i.e. the int8 matrix-core correlation for uint8 tiles.
+  """
+  from . import flow_field
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  patch_size = tuple(int(p) for p in patch_size)
+  stride = tuple(int(s) for s in stride)
+  pads = [(0, 0)] + [(p // 2 // s, p // 2 // s - 1)
+                     for p, s in zip(patch_size, stride)]
+  grid_y, grid_x = offset_map.shape[-2:]
+  flows, offsets = {}, {}
+  for y in range(grid_y - axis):
+    for x in range(grid_x - (1 - axis)):
+      off_xy = offset_map[:, y, x]
+      if np.isnan(off_xy[0]):
+        continue
+      pre, post, off = _overlap_strips(
+          tile_map[x, y], tile_map[x + (1 - axis), y + axis], off_xy, axis,
+          stride)
+      f = calc.flow_field(pre, post, patch_size=patch_size, step=stride,
+                          batch_size=batch_size)
+      flows[x, y] = np.pad(f, pads, constant_values=np.nan)
+      offsets[x, y] = off
+  return flows, offsets

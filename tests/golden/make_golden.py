@@ -425,6 +425,98 @@ def gen_clean_flow():
   save('clean_flow', **out)
 
 
+def _cfg1_tiles():
+  """The four 512^2 tiles of the configs[0] montage (same recipe and seed as
+  gen_montage, so both fixtures describe one chain)."""
+  rng = np.random.default_rng(1001)
+  t, ov = 512, 64
+  canvas = ndimage.gaussian_filter(rng.standard_normal((2 * t, 2 * t)), 2.0)
+  canvas = ((canvas - canvas.min()) / (canvas.max() - canvas.min()) * 255
+            ).astype(np.uint8)
+  jit = {(0, 0): (0, 0), (1, 0): (3, -2), (0, 1): (-4, 5), (1, 1): (2, 1)}
+  tile_map = {}
+  for (tx, ty), (dy, dx) in jit.items():
+    y0 = 20 + ty * (t - ov) + dy
+    x0 = 20 + tx * (t - ov) + dx
+    tile_map[(tx, ty)] = canvas[y0:y0 + t, x0:x0 + t]
+  return tile_map
+
+
+def gen_stitch():
+  """configs[0] flow leg and the stitch_rigid callers of the hot path, through
+  the reference: _estimate_offset / compute_coarse_offsets (whole-overlap masked
+  correlation), elastic_tile_mesh[_3d] + optimize_coarse_mesh (relax_mesh with a
+  custom mesh_force), compute_flow_map (the 512^2 strips, patch 64 step 32)."""
+  import json
+  from sofima import stitch_rigid, stitch_elastic
+  jnp = sys.modules['jax.numpy']
+  rng = np.random.default_rng(2024)
+  tile_map = _cfg1_tiles()
+  out = {}
+  keys = sorted(tile_map)
+  out['tile_keys'] = np.array(keys, np.int32)
+  out['tiles'] = np.stack([tile_map[k] for k in keys])
+  cx, cy = stitch_rigid.compute_coarse_offsets(
+      (2, 2), tile_map, overlaps_xy=((96, 128), (96, 128)), min_overlap=32)
+  out['cx'], out['cy'] = cx, cy
+  # direct _estimate_offset calls: plain, custom masks, other filter / range
+  a = tile_map[(0, 0)][:, -96:]
+  b = tile_map[(1, 0)][:, :96]
+  off, pr = stitch_rigid._estimate_offset(a, b, 10)
+  out['eo0'] = np.array(off + [pr], np.float64)
+  ma = np.zeros(a.shape, bool)
+  ma[:100, :40] = True
+  mb = rng.random(b.shape) < 0.05
+  out['eo1_ma'], out['eo1_mb'] = ma, mb
+  off, pr = stitch_rigid._estimate_offset(a, b, 40, filter_size=7, masks=(ma, mb))
+  out['eo1'] = np.array(off + [pr], np.float64)
+  off, pr = stitch_rigid._estimate_offset(a, b, 250, filter_size=7, masks=(ma, mb))
+  out['eo3'] = np.array(off + [pr], np.float64)   # everything masked -> NaN
+  a2 = tile_map[(0, 0)][-128:, :]
+  b2 = tile_map[(0, 1)][:128, :]
+  off, pr = stitch_rigid._estimate_offset(a2, b2, 0)
+  out['eo2'] = np.array(off + [pr], np.float64)
+  coarse = stitch_rigid.optimize_coarse_mesh(cx, cy)
+  out['coarse'] = np.asarray(coarse, np.float32)
+
+  # tile-mesh forces on a 3 x 4 tile grid (NaN = missing tile pair)
+  tx = (rng.standard_normal((2, 1, 3, 4)) * 20).astype(np.float32)
+  tcx = (rng.standard_normal((2, 1, 3, 4)) * 30 - [[[[400]]], [[[0]]]]).astype(np.float32)
+  tcy = (rng.standard_normal((2, 1, 3, 4)) * 30 - [[[[0]]], [[[400]]]]).astype(np.float32)
+  tcx[:, 0, 1, 2] = np.nan
+  tcy[:, 0, 0, 3] = np.nan
+  out['tm_x'], out['tm_cx'], out['tm_cy'] = tx, tcx, tcy
+  out['tm_f'] = np.asarray(stitch_rigid.elastic_tile_mesh(
+      jnp.asarray(tx), jnp.asarray(tcx), jnp.asarray(tcy)), np.float32)
+  cfg = rmesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.0, k=0.1, stride=(1, 1),
+                                num_iters=1000, max_iters=20000, stop_v_max=0.001,
+                                dt_max=100)
+  out['tm_cfg'] = np.array(json.dumps(cfg_dict(cfg)))
+  out['tm_relaxed'] = np.asarray(
+      stitch_rigid.optimize_coarse_mesh(tcx, tcy, cfg), np.float32)
+  t3x = (rng.standard_normal((3, 2, 3, 4)) * 20).astype(np.float32)
+  t3cx = (rng.standard_normal((3, 2, 3, 4)) * 30).astype(np.float32)
+  t3cy = (rng.standard_normal((3, 2, 3, 4)) * 30).astype(np.float32)
+  t3cx[:, 1, 2, 1] = np.nan
+  out['tm3_x'], out['tm3_cx'], out['tm3_cy'] = t3x, t3cx, t3cy
+  out['tm3_f'] = np.asarray(stitch_rigid.elastic_tile_mesh_3d(
+      jnp.asarray(t3x), jnp.asarray(t3cx), jnp.asarray(t3cy)), np.float32)
+  out['tm3_relaxed'] = np.asarray(stitch_rigid.optimize_coarse_mesh(
+      t3cx, t3cy, cfg, mesh_fn=stitch_rigid.elastic_tile_mesh_3d), np.float32)
+
+  # configs[0] flow leg: fine flow of every adjacent tile pair
+  stride = (32, 32)
+  for name, conn, axis in (('fx', cx[:, 0], 0), ('fy', cy[:, 0], 1)):
+    flows, offs = stitch_elastic.compute_flow_map(
+        tile_map, conn, axis, patch_size=(64, 64), stride=stride, batch_size=64)
+    ks = sorted(flows)
+    out[name + '_keys'] = np.array(ks, np.int32)
+    out[name + '_offsets'] = np.array([offs[k] for k in ks], np.int32)
+    for i, k in enumerate(ks):
+      out[f'{name}_{i}'] = np.asarray(flows[k], np.float32)
+  save('stitch_cfg1', **out)
+
+
 def gen_montage():
   """2 x 2 montage of 512^2 tiles through the reference's stitch_rigid /
   stitch_elastic chain: the inputs and outputs of
@@ -491,7 +583,7 @@ def gen_montage():
 
 
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'irregular', 'montage3d', 'montage']
+  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'irregular', 'montage3d', 'montage', 'stitch']
   if 'xcorr' in which:
     gen_xcorr_np()
   if 'peaks' in which:
@@ -510,3 +602,5 @@ if __name__ == '__main__':
     gen_montage3d()
   if 'montage' in which:
     gen_montage()
+  if 'stitch' in which:
+    gen_stitch()

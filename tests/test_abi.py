@@ -33,7 +33,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_channel(lib):
-  assert lib.sfm_version() == 1
+  assert lib.sfm_version() == 2
   # A NULL descriptor is rejected with a message, not a crash.
   rc = lib.sfm_mesh_force(None, None)
   assert rc == -1
@@ -59,6 +59,7 @@ def test_struct_layouts_match_header():
                      ('SfmComposeDesc', _abi.SfmComposeDesc),
                      ('SfmCleanFlowDesc', _abi.SfmCleanFlowDesc),
                      ('SfmMaskIrregularDesc', _abi.SfmMaskIrregularDesc),
+                     ('SfmRangeMaskDesc', _abi.SfmRangeMaskDesc),
                      ('SfmTargetMeshDesc', _abi.SfmTargetMeshDesc)):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,
                      re.S).group(1)

@@ -134,3 +134,57 @@ def test_integral_image_query():
                     for y in range(0, 11 - 5 + 1, 3)]
                    for z in range(0, 9 - 4 + 1, 2)])
   np.testing.assert_array_equal(got, want)
+
+
+def test_overlap_strips_match_oracle():
+  """Strip selection of stitch_elastic.compute_flow_map (host logic)."""
+  from oracle import stitch_oracle as so
+  from sofima_amd import stitch_elastic
+  rng = np.random.default_rng(0)
+  for _ in range(200):
+    h, w = rng.integers(100, 200, 2)
+    pre = rng.integers(0, 255, (h, w)).astype(np.uint8)
+    post = rng.integers(0, 255, (h, w)).astype(np.uint8)
+    axis = int(rng.integers(0, 2))
+    stride = (int(rng.integers(4, 20)), int(rng.integers(4, 20)))
+    off = np.zeros(2)
+    off[axis] = -rng.integers(20, 60)
+    off[1 - axis] = rng.integers(-30, 30) + rng.random()
+    a, b, o = stitch_elastic._overlap_strips(pre, post, off, axis, stride)
+    wa, wb, wo = so.flow_map_strips(pre, post, off, axis, stride)
+    np.testing.assert_array_equal(a, wa)
+    np.testing.assert_array_equal(b, wb)
+    assert tuple(o) == tuple(wo)
+
+
+def test_interpolate_missing_offsets():
+  from sofima_amd import stitch_rigid
+  conn = np.zeros((2, 1, 3, 5))
+  conn[0, 0] = np.arange(15).reshape(3, 5)
+  conn[1, 0] = -np.arange(15).reshape(3, 5)
+  conn[:, 0, 1, 2] = np.inf          # neighbours at distance 1 on both sides
+  conn[:, 0, 0, 0] = np.inf          # only a right neighbour
+  conn[:, 0, 2, 3:] = np.inf         # (2, 3): left at r=1; (2, 4): left at r=2
+  out = stitch_rigid.interpolate_missing_offsets(conn.copy(), -1)
+  np.testing.assert_array_equal(out[:, 0, 1, 2], [(6 + 8) / 2, -(6 + 8) / 2])
+  np.testing.assert_array_equal(out[:, 0, 0, 0], [1, -1])
+  np.testing.assert_array_equal(out[:, 0, 2, 3], [12, -12])
+  # the search runs on the array being modified: (2, 3) is finite by now
+  np.testing.assert_array_equal(out[:, 0, 2, 4], [12, -12])
+  out = stitch_rigid.interpolate_missing_offsets(conn.copy(), -2, max_r=2)
+  np.testing.assert_array_equal(out[:, 0, 1, 2], [(2 + 12) / 2, -(2 + 12) / 2])
+  with pytest.raises(ValueError):
+    stitch_rigid.interpolate_missing_offsets(np.zeros((2, 3, 5)), -1)
+
+
+def test_force_spec_resolution():
+  import functools
+  spec = mesh._resolve_force(mesh.inplane_force)
+  assert (spec.kind, spec.ncomp) == (0, 2)
+  spec = mesh._resolve_force(functools.partial(mesh.elastic_mesh_3d,
+                                               links=((1, 0, 0),)))
+  assert (spec.kind, spec.ncomp, spec.links) == (0, 3, ((1, 0, 0),))
+  spec = mesh._resolve_force(lambda x, *a, **k: x)
+  assert spec.kind == 2 and spec.ncomp is None
+  with pytest.raises(TypeError):
+    mesh._resolve_force(3)

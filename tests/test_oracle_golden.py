@@ -229,3 +229,54 @@ def test_target_mesh_3d_vs_golden(golden):
   np.testing.assert_array_equal(np.isnan(got), np.isnan(g['tg']))
   np.testing.assert_allclose(got, g['tg'], rtol=1e-5, atol=1e-4)
   assert np.isfinite(g['tg']).mean() > 0.1
+
+
+def _stitch_tiles(g):
+  return {tuple(int(v) for v in k): t for k, t in zip(g['tile_keys'], g['tiles'])}
+
+
+def test_stitch_rigid_oracle_vs_golden(golden):
+  """_estimate_offset, elastic_tile_mesh[_3d], optimize_coarse_mesh."""
+  from oracle import stitch_oracle as so
+  g = golden('stitch_cfg1')
+  tiles = _stitch_tiles(g)
+  a, b = tiles[(0, 0)][:, -96:], tiles[(1, 0)][:, :96]
+  off, pr = so.estimate_offset(a, b, 10)
+  np.testing.assert_array_equal(off + [pr], g['eo0'])
+  off, pr = so.estimate_offset(a, b, 40, filter_size=7,
+                               masks=(g['eo1_ma'], g['eo1_mb']))
+  np.testing.assert_array_equal(off + [pr], g['eo1'])
+  off, pr = so.estimate_offset(tiles[(0, 0)][-128:, :], tiles[(0, 1)][:128, :], 0)
+  np.testing.assert_array_equal(off + [pr], g['eo2'])
+  off, pr = so.estimate_offset(a, b, 250, filter_size=7,
+                               masks=(g['eo1_ma'], g['eo1_mb']))
+  assert np.isnan(off).all() and np.isnan(pr) and np.isnan(g['eo3']).all()
+
+  np.testing.assert_allclose(so.elastic_tile_mesh(g['tm_x'], g['tm_cx'], g['tm_cy']),
+                             g['tm_f'], rtol=1e-6, atol=1e-5)
+  np.testing.assert_allclose(
+      so.elastic_tile_mesh_3d(g['tm3_x'], g['tm3_cx'], g['tm3_cy']), g['tm3_f'],
+      rtol=1e-6, atol=1e-5)
+  cfg = cfg_from(__import__('json').loads(str(g['tm_cfg'])))
+  np.testing.assert_allclose(so.optimize_coarse_mesh(g['tm_cx'], g['tm_cy'], cfg),
+                             g['tm_relaxed'], atol=2e-3)
+  np.testing.assert_allclose(
+      so.optimize_coarse_mesh(g['tm3_cx'], g['tm3_cy'], cfg,
+                              mesh_fn=so.elastic_tile_mesh_3d),
+      g['tm3_relaxed'], atol=2e-3)
+  np.testing.assert_allclose(so.optimize_coarse_mesh(g['cx'], g['cy']), g['coarse'],
+                             atol=2e-3)
+
+
+def test_flow_map_cfg1_oracle_vs_golden(golden):
+  """configs[0] flow leg: the 512^2 tile strips, patch 64, step 32."""
+  from oracle import stitch_oracle as so
+  g = golden('stitch_cfg1')
+  tiles = _stitch_tiles(g)
+  for name, conn, axis in (('fx', g['cx'][:, 0], 0), ('fy', g['cy'][:, 0], 1)):
+    flows, offs = so.compute_flow_map(tiles, conn, axis, (64, 64), (32, 32), 64)
+    keys = [tuple(int(v) for v in k) for k in g[name + '_keys']]
+    assert sorted(flows) == sorted(keys)
+    for i, k in enumerate(keys):
+      assert tuple(offs[k]) == tuple(g[name + '_offsets'][i])
+      check_flow(flows[k], g[f'{name}_{i}'])

@@ -32,3 +32,62 @@ def cfg_from(d, cls=None):
 
 def load_cfgs(npz):
   return json.loads(str(npz['cfgs']))
+
+
+def em_texture(rng, shape, sigma=2.0):
+  """uint8 EM-like texture (low-pass noise stretched to 0..255)."""
+  from scipy import ndimage
+  img = ndimage.gaussian_filter(rng.standard_normal(shape, dtype=np.float32), sigma)
+  img = (img - img.min()) / (img.max() - img.min()) * 255
+  return img.astype(np.uint8)
+
+
+def synth_montage(rng, gx, gy, mesh_shape, overlap, amp=4.0):
+  """Synthetic tile montage for the target-mesh `prev_fn`: gx x gy tiles,
+  mesh_shape = (y, x) nodes (in-plane) or (z, y, x) (volumetric), flow strips
+  `overlap` nodes wide between all adjacent tiles, consistent NeighborInfo rows
+  (stitch_elastic.py:43-72).  Returns (nbors, fx, fy, x0)."""
+  from scipy import ndimage
+  nd = len(mesh_shape)
+  n = gx * gy
+  my, mx = mesh_shape[-2:]
+  lead = tuple(mesh_shape[:-2])
+  fz = tuple(max(1, s - 1) for s in lead)
+
+  def smooth(shape, a):
+    sig = (0, 0) + (1.0,) * len(lead) + (3.0, 3.0)
+    v = ndimage.gaussian_filter(rng.standard_normal(shape), sig)
+    return (v / np.abs(v).max() * a).astype(np.float32)
+
+  fx = smooth((nd, n) + fz + (my - 2, overlap), amp)   # x pairs: ortho y, overlap x
+  fy = smooth((nd, n) + fz + (overlap, mx - 3), amp)   # y pairs: overlap y, ortho x
+  x0 = smooth((nd, n) + tuple(mesh_shape), amp / 2)
+  fields = 8 if nd == 2 else 11
+  nb = -np.ones((n, 4, fields), np.int32)
+
+  def entry(nbor, flow_idx, dim, flow, off_o, off_z):
+    e = -np.ones(fields, np.int32)
+    e[0], e[1], e[7] = nbor, flow_idx, dim
+    fyy, fxx = flow.shape[-2:]
+    e[4] = fxx if dim == 0 else fyy     # flow_size_overlap
+    e[3] = fyy if dim == 0 else fxx     # flow_size_ortho
+    e[2] = off_o                        # coarse_offset_ortho
+    e[5], e[6] = rng.integers(-2, 3, 2)
+    if nd == 3:
+      e[8], e[9], e[10] = off_z, flow.shape[-3], rng.integers(-2, 3)
+    return e
+
+  offs_x = rng.integers(-2, 3, (n, 2))
+  offs_y = rng.integers(-2, 3, (n, 2))
+  for t in range(n):
+    tx, ty = t % gx, t // gx
+    k = 0
+    if tx > 0:
+      nb[t, k] = entry(t - 1, t - 1, 0, fx, *offs_x[t - 1]); k += 1
+    if tx < gx - 1:
+      nb[t, k] = entry(t + 1, t, 0, fx, *offs_x[t]); k += 1
+    if ty > 0:
+      nb[t, k] = entry(t - gx, t - gx, 1, fy, *offs_y[t - gx]); k += 1
+    if ty < gy - 1:
+      nb[t, k] = entry(t + gx, t, 1, fy, *offs_y[t]); k += 1
+  return nb, fx, fy, x0
