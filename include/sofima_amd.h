@@ -362,6 +362,72 @@ int sfm_mesh_force(const SfmMeshDesc* desc, float* out);
 int sfm_mesh_relax_chunk(const SfmMeshDesc* desc, SfmFireState* fire,
                          SfmChunkStats* stats);
 
+/* ------------------------------------------------------------------------
+ * One mesh across GPUs (one process per GPU).  The reference has no
+ * multi-device code; these entry points split the step of
+ * sfm_mesh_relax_chunk (mesh.velocity_verlet, mesh.py:436-499) at its two
+ * exchange points so that bands of rows of ONE mesh can live on different GPUs:
+ * the 1-node halo of the 8 / 26-neighbour stencil (mesh.py:106-167, :230-277)
+ * and the whole-array reductions of FIRE (power :455, drift means :494-497,
+ * e_kin / v_max mesh.py:584-586).
+ *
+ * A band holds rows [own_y0, own_y1) of the local array plus the halo rows
+ * next to them.  Per step the caller
+ *   1. brings (x, v, a) of the halo rows from the neighbour bands and gathers
+ *      every band's `my_sums` row into `sums` (sfm_comm_* below, or any other
+ *      transport),
+ *   2. sfm_mesh_shard_advance  (FIRE scalars from `sums`, reduced in rank order
+ *      on every band -> identical everywhere; pending gate / drift; position
+ *      update of owned and halo rows),
+ *   3. sfm_mesh_shard_integrate (force, velocity update, partial sums of the
+ *      owned rows -> my_sums).
+ * Only SfmMeshDesc.prev (no prev_fn), spring / tile-mesh forces and
+ * remove_drift 0 | 1 are supported.  Everything is enqueued on desc->stream;
+ * only sfm_mesh_shard_finish synchronises.
+ * ---------------------------------------------------------------------- */
+typedef struct SfmMeshShard {
+  int32_t own_y0, own_y1;       /* owned rows of the local [.., y, x] arrays  */
+  int64_t global_nodes;         /* nodes of the whole mesh (drift mean)       */
+  int32_t n_ranks;              /* rows of `sums`                             */
+  float* sums;                  /* device [n_ranks, 8], gathered by the caller */
+  float* my_sums;               /* device [8]: power, sum x[3], sum v[3], 0   */
+  int32_t phase;                /* library state: steps advanced so far       */
+  float cap0;                   /* library state: force cap without FIRE      */
+} SfmMeshShard;
+
+/* a = F(x) + pull on the local rows; FIRE scalars of the chunk from `fire`. */
+int sfm_mesh_shard_begin(const SfmMeshDesc* desc, SfmMeshShard* shard,
+                         const SfmFireState* fire);
+int sfm_mesh_shard_advance(const SfmMeshDesc* desc, SfmMeshShard* shard);
+int sfm_mesh_shard_integrate(const SfmMeshDesc* desc, SfmMeshShard* shard);
+/* Pending gate / drift of the last step (needs the last `sums`); `fire` gets
+ * the chunk's final scalars, `stats` e_kin and v_max of the OWNED rows. */
+int sfm_mesh_shard_finish(const SfmMeshDesc* desc, SfmMeshShard* shard,
+                          SfmFireState* fire, SfmChunkStats* stats);
+
+/* RCCL transport of those exchanges (resolved at run time; SFM_ERR_NO_DEVICE
+ * when no librccl can be loaded).  One communicator per process on the
+ * current device; rank 0 creates the id and hands its SFM_COMM_ID_BYTES bytes
+ * to the other ranks out of band. */
+#define SFM_COMM_ID_BYTES 128
+#define SFM_REDUCE_SUM 0
+#define SFM_REDUCE_MAX 1
+typedef struct SfmComm SfmComm;
+int sfm_comm_unique_id(void* id128);
+int sfm_comm_init(SfmComm** comm, const void* id128, int rank, int n_ranks);
+int sfm_comm_destroy(SfmComm* comm);
+/* Sends `count` floats to each existing neighbour and receives as many, as one
+ * grouped send/recv (peer = -1: no neighbour on that side). */
+int sfm_comm_halo_exchange(SfmComm* comm, int peer_lo, const float* send_lo,
+                           float* recv_lo, int peer_hi, const float* send_hi,
+                           float* recv_hi, size_t count, void* stream);
+/* recv[r * count .. (r + 1) * count) = `send` of rank r. */
+int sfm_comm_allgather(SfmComm* comm, const float* send, float* recv, size_t count,
+                       void* stream);
+/* In-place all-reduce of a few scalars (chunk statistics). */
+int sfm_comm_allreduce_scalars(SfmComm* comm, float* inout, size_t count, int op,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

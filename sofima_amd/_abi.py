@@ -201,6 +201,24 @@ class SfmMeshDesc(C.Structure):
   ]
 
 
+class SfmMeshShard(C.Structure):
+  _fields_ = [
+      ('own_y0', i32),
+      ('own_y1', i32),
+      ('global_nodes', C.c_int64),
+      ('n_ranks', i32),
+      ('sums', C.c_void_p),
+      ('my_sums', C.c_void_p),
+      ('phase', i32),
+      ('cap0', C.c_float),
+  ]
+
+
+COMM_ID_BYTES = 128
+REDUCE_SUM = 0
+REDUCE_MAX = 1
+
+
 class SfmFireState(C.Structure):
   _fields_ = [('dt', C.c_float), ('alpha', C.c_float), ('n_pos', i32),
               ('cap', C.c_float)]
@@ -240,6 +258,27 @@ SIGNATURES = {
                                        C.POINTER(SfmFireState),
                                        C.POINTER(SfmChunkStats)]),
 }
+SIGNATURES.update({
+    'sfm_mesh_shard_begin': (C.c_int, [C.POINTER(SfmMeshDesc), C.POINTER(SfmMeshShard),
+                                       C.POINTER(SfmFireState)]),
+    'sfm_mesh_shard_advance': (C.c_int, [C.POINTER(SfmMeshDesc),
+                                         C.POINTER(SfmMeshShard)]),
+    'sfm_mesh_shard_integrate': (C.c_int, [C.POINTER(SfmMeshDesc),
+                                           C.POINTER(SfmMeshShard)]),
+    'sfm_mesh_shard_finish': (C.c_int, [C.POINTER(SfmMeshDesc), C.POINTER(SfmMeshShard),
+                                        C.POINTER(SfmFireState),
+                                        C.POINTER(SfmChunkStats)]),
+    'sfm_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'sfm_comm_init': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    'sfm_comm_destroy': (C.c_int, [C.c_void_p]),
+    'sfm_comm_halo_exchange': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
+    'sfm_comm_allgather': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
+    'sfm_comm_allreduce_scalars': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.c_int, C.c_void_p]),
+})
 
 
 class SofimaAmdError(RuntimeError):

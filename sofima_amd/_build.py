@@ -24,6 +24,7 @@ SOURCES = {
                            os.environ.get('SFM_MFMA_FLAGS', '').split()),
     'sfm_maps.hip': ['-ffp-contract=off'] + os.environ.get('SFM_MAPS_FLAGS', '').split(),
     'sfm_flowutils.hip': ['-ffp-contract=off'],
+    'sfm_comm.hip': [],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
           '-Wno-unused-result']
@@ -83,7 +84,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
   if relink or _stale(LIB_PATH, objs):
     # hipFFT serves the FFT form of the correlation (3-D / large patches)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH
-           ] + objs + ['-L/opt/rocm/lib', '-lhipfft', '-Wl,-rpath,/opt/rocm/lib']
+           ] + objs + ['-L/opt/rocm/lib', '-lhipfft', '-ldl', '-Wl,-rpath,/opt/rocm/lib']
     if verbose:
       print(' '.join(cmd))
     subprocess.run(cmd, check=True)

@@ -69,6 +69,7 @@ struct MeshParams {
   float final_cap, cap_scale;
   int cap_every;
   float n_f;  // N as the f32 mean divisor (mean = sum / N)
+  int own_y0, own_y1;   // band shards: rows that count in sums / statistics
   int force_kind;       // SFM_FORCE_*
   const float* cx;      // tile mesh: desired offset to the +x tile, [C, B, Y, X]
   const float* cy;      // tile mesh: desired offset to the +y tile
@@ -552,6 +553,10 @@ integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
        n += (long long)gridDim.x * kBlock) {
     float f[C], vn[C];
     node_force<C>(x, p, n, f);
+    // halo rows of a band shard are integrated (their values are replaced by
+    // the owner's at the next exchange) but do not count in the sums
+    const int yrow = static_cast<int>((n / p.X) % p.Y);
+    const bool own = yrow >= p.own_y0 && yrow < p.own_y1;
     float a2 = 0.f, v2 = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -562,7 +567,7 @@ integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
       a[c * p.N + n] = f[c];
       a2 = a2 + f[c] * f[c];
       v2 = v2 + vn[c] * vn[c];
-      if (p.fire) {
+      if (p.fire && own) {
         part[0] = part[0] + f[c] * vn[c];
         part[1 + c] = part[1 + c] + xv;
       }
@@ -573,7 +578,7 @@ integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
-        part[4 + c] = part[4 + c] + vn[c];
+        if (own) part[4 + c] = part[4 + c] + vn[c];
       }
     }
 #pragma unroll
@@ -864,8 +869,11 @@ finish_kernel(float* __restrict__ x, float* __restrict__ v, MeshParams p,
       }
       v2 = v2 + vv * vv;
     }
-    ek = ek + v2;
-    vmax2 = fmaxf(vmax2, v2);
+    const int yrow = static_cast<int>((n / p.X) % p.Y);
+    if (yrow >= p.own_y0 && yrow < p.own_y1) {
+      ek = ek + v2;
+      vmax2 = fmaxf(vmax2, v2);
+    }
   }
   lds[threadIdx.x] = ek;
   lds[kBlock + threadIdx.x] = vmax2;
@@ -1509,6 +1517,8 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
   p->cap_scale = static_cast<float>(d->cap_scale);
   p->cap_every = d->cap_upscale_every > 0 ? d->cap_upscale_every : 1;
   p->n_f = static_cast<float>(p->N);
+  p->own_y0 = 0;
+  p->own_y1 = p->Y;
   return SFM_OK;
 }
 
@@ -1946,5 +1956,164 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   stats->v_max = hs[1];
   return SFM_OK;
 }
+
+// ---------------------------------------------------------------------------
+// One mesh across GPUs: the multi-launch step split at its exchange points.
+// A rank holds a band of rows [own_y0, own_y1) of every section plus the halo
+// rows next to it.  Per step the caller (sofima_amd/dist.py)
+//   1. exchanges (x, v, a) of the boundary rows with the neighbour bands and
+//      all-gathers the per-band partial sums of the previous step into `sums`,
+//   2. sfm_mesh_shard_advance: every band reduces `sums` in rank order -> the
+//      same FIRE scalars everywhere; pending gate / drift; x += dt v + dt^2/2 a
+//      on the owned AND the halo rows,
+//   3. sfm_mesh_shard_integrate: force + velocity update; partial sums of the
+//      owned rows -> `my_sums`.
+// All of it is enqueued on desc->stream; nothing synchronises until
+// sfm_mesh_shard_finish.
+// ---------------------------------------------------------------------------
+namespace {
+
+// One row of sums from the per-block partials of integrate_kernel (fixed order).
+__global__ void __launch_bounds__(kBlock)
+shard_sums_kernel(const float* __restrict__ partials, int rows, float* __restrict__ out) {
+  __shared__ float lds[kNP * kBlock];
+  float acc[kNP];
+  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
+  for (int r = threadIdx.x; r < rows; r += kBlock)
+    for (int i = 0; i < 7; ++i) acc[i] = acc[i] + partials[r * kNP + i];
+  block_sum(acc, 7, lds);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kNP; ++i) out[i] = i < 7 ? acc[i] : 0.f;
+}
+
+int shard_setup(const SfmMeshDesc* d, const SfmMeshShard* sh, MeshParams* p,
+                MeshWorkspace* w) {
+  if (int rc = build_params(d, p)) return rc;
+  if (!sh) return sfm::fail(SFM_ERR_INVALID, "shard is NULL");
+  if (!d->x || !d->v || !d->a)
+    return sfm::fail(SFM_ERR_INVALID, "x/v/a must be device pointers");
+  if (d->target || d->force_kind == SFM_FORCE_EXTERNAL)
+    return sfm::fail(SFM_ERR_INVALID, "band shards: prev_fn / external forces unsupported");
+  if (d->remove_drift == 2)
+    return sfm::fail(SFM_ERR_INVALID, "band shards: per-column drift removal unsupported");
+  if (sh->own_y0 < 0 || sh->own_y1 > p->Y || sh->own_y0 >= sh->own_y1)
+    return sfm::fail(SFM_ERR_INVALID, "band shards: owned rows [%d, %d) of %d",
+                     sh->own_y0, sh->own_y1, p->Y);
+  if (sh->n_ranks < 1 || sh->n_ranks > kMaxBlocks || !sh->sums || !sh->my_sums)
+    return sfm::fail(SFM_ERR_INVALID, "band shards: sums buffers / n_ranks");
+  if (sh->global_nodes < p->N / ((long long)p->Y) * (sh->own_y1 - sh->own_y0))
+    return sfm::fail(SFM_ERR_INVALID, "band shards: global_nodes too small");
+  p->own_y0 = sh->own_y0;
+  p->own_y1 = sh->own_y1;
+  p->n_f = static_cast<float>(sh->global_nodes);
+  *w = carve_for(d, d->workspace, nullptr);
+  if (!d->workspace || d->workspace_bytes < w->bytes)
+    return sfm::fail(SFM_ERR_WORKSPACE, "mesh workspace needs %zu bytes, got %zu",
+                     w->bytes, d->workspace_bytes);
+  return SFM_OK;
+}
+
+#define SFM_SHARD_DISPATCH(KERNEL, ...)                                      \
+  do {                                                                       \
+    if (p.ncomp == 2)                                                        \
+      hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(kBlock), 0, st,         \
+                         __VA_ARGS__);                                       \
+    else                                                                     \
+      hipLaunchKernelGGL(KERNEL<3>, dim3(grid), dim3(kBlock), 0, st,         \
+                         __VA_ARGS__);                                       \
+    SFM_LAUNCH_CHECK();                                                      \
+  } while (0)
+
+}  // namespace
+
+int sfm_mesh_shard_begin(const SfmMeshDesc* d, SfmMeshShard* sh,
+                         const SfmFireState* fire) {
+  MeshParams p;
+  MeshWorkspace w;
+  if (int rc = shard_setup(d, sh, &p, &w)) return rc;
+  if (!fire) return sfm::fail(SFM_ERR_INVALID, "fire is NULL");
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  const int grid = grid_for(p.N);
+  Scalars s0;
+  std::memset(&s0, 0, sizeof(s0));
+  s0.dt = fire->dt;
+  s0.alpha = fire->alpha;
+  s0.n_pos = 0;
+  s0.cap = fire->cap;
+  s0.gate = 1.f;
+  SFM_HIP_CHECK(hipMemcpyAsync(&w.scal[0], &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+  sh->phase = 0;
+  sh->cap0 = fire->cap;
+  // a = F(x) + pull(prev, cap) on every local row; the halo rows' values are
+  // replaced by the owners' at the first exchange
+  SFM_SHARD_DISPATCH(force_kernel, d->x, d->prev, d->a, p, fire->cap, p.has_prev);
+  return SFM_OK;
+}
+
+int sfm_mesh_shard_advance(const SfmMeshDesc* d, SfmMeshShard* sh) {
+  MeshParams p;
+  MeshWorkspace w;
+  if (int rc = shard_setup(d, sh, &p, &w)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  const int grid = grid_for(p.N);
+  const int cur = sh->phase & 1;
+  const int pending = sh->phase > 0 ? 1 : 0;
+  SFM_SHARD_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur], &w.scal[cur ^ 1],
+                     sh->sums, sh->n_ranks, pending, w.colsum);
+  sh->phase += 1;
+  return SFM_OK;
+}
+
+int sfm_mesh_shard_integrate(const SfmMeshDesc* d, SfmMeshShard* sh) {
+  MeshParams p;
+  MeshWorkspace w;
+  if (int rc = shard_setup(d, sh, &p, &w)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  const int grid = grid_for(p.N);
+  const int cur = sh->phase & 1;
+  sfm::prof_begin(sfm::kProfMesh, st);
+  SFM_SHARD_DISPATCH(integrate_kernel, d->x, d->v, d->a, d->prev, p, &w.scal[cur],
+                     sh->cap0, w.partials);
+  sfm::prof_end(sfm::kProfMesh, st);
+  if (p.fire) {
+    hipLaunchKernelGGL(shard_sums_kernel, dim3(1), dim3(kBlock), 0, st, w.partials, grid,
+                       sh->my_sums);
+    SFM_LAUNCH_CHECK();
+  }
+  return SFM_OK;
+}
+
+int sfm_mesh_shard_finish(const SfmMeshDesc* d, SfmMeshShard* sh, SfmFireState* fire,
+                          SfmChunkStats* stats) {
+  MeshParams p;
+  MeshWorkspace w;
+  if (int rc = shard_setup(d, sh, &p, &w)) return rc;
+  if (!fire || !stats) return sfm::fail(SFM_ERR_INVALID, "fire/stats is NULL");
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  const int grid = grid_for(p.N);
+  int cur = sh->phase & 1;
+  const int pending = sh->phase > 0 ? 1 : 0;
+  SFM_SHARD_DISPATCH(finish_kernel, d->x, d->v, p, &w.scal[cur], &w.scal[cur ^ 1],
+                     sh->sums, sh->n_ranks, pending, w.stat_part, w.colsum);
+  cur ^= 1;
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(kBlock), 0, st, w.stat_part, grid,
+                     w.stats);
+  SFM_LAUNCH_CHECK();
+  Scalars s1;
+  float hs[2];
+  SFM_HIP_CHECK(hipMemcpyAsync(&s1, &w.scal[cur], sizeof(s1), hipMemcpyDeviceToHost, st));
+  SFM_HIP_CHECK(hipMemcpyAsync(hs, w.stats, sizeof(hs), hipMemcpyDeviceToHost, st));
+  SFM_HIP_CHECK(hipStreamSynchronize(st));
+  if (p.fire) {
+    fire->dt = s1.dt;
+    fire->alpha = s1.alpha;
+    fire->n_pos = s1.n_pos;
+    fire->cap = s1.cap;
+  }
+  stats->e_kin = hs[0];   // of the owned rows: the caller adds the bands up
+  stats->v_max = hs[1];   // max over the owned rows
+  return SFM_OK;
+}
+#undef SFM_SHARD_DISPATCH
 
 }  // extern "C"

@@ -107,3 +107,389 @@ def map_units(units: Sequence, fn: Callable, group=None) -> list:
     for k, i in enumerate(shard_units(len(units), r, ws)):
       out[i] = part[k]
   return out
+
+
+# ---------------------------------------------------------------------------
+# One mesh across GPUs: bands of rows with a 1-node halo.
+# ---------------------------------------------------------------------------
+def band_bounds(n_rows: int, n_bands: int) -> list[tuple[int, int]]:
+  """Even split of the mesh rows into `n_bands` contiguous bands."""
+  if n_bands < 1 or n_rows < n_bands:
+    raise ValueError(f'cannot split {n_rows} rows into {n_bands} bands')
+  edges = [n_rows * i // n_bands for i in range(n_bands + 1)]
+  return list(zip(edges[:-1], edges[1:]))
+
+
+class HipBand:
+  """One band of a mesh on the current GPU, stepped through the C ABI
+  (sfm_mesh_shard_*).  Local arrays are [C, ..., rows, X]: the owned rows plus
+  one halo row towards every neighbouring band."""
+
+  def __init__(self, x, prev, config, spec, own, global_nodes, n_bands):
+    import ctypes as C
+    import torch
+    from . import _abi, _dev, mesh
+    self._C, self._abi, self._mesh = C, _abi, mesh
+    dev = _dev.device()
+    self.config = config
+    self.spec = spec
+    self.own = own
+    self.x = _dev.as_device_f32(x, dev, copy=True)
+    self.v = torch.zeros_like(self.x)
+    self.a = torch.empty_like(self.x)
+    self.prev = None if prev is None else _dev.as_device_f32(prev, dev, copy=True)
+    self.sums = torch.zeros((n_bands, 8), dtype=torch.float32, device=dev)
+    self.my_sums = torch.zeros((8,), dtype=torch.float32, device=dev)
+    lib = _abi.load()
+    probe = mesh._base_desc(self.x, spec, config.k, config.stride,
+                            config.prefer_orig_order)
+    self.ws = _dev.workspace(lib.sfm_mesh_workspace_bytes(C.byref(probe)), dev)
+    self.desc = mesh._chunk_desc(self.x, self.v, self.a, self.prev, config, spec,
+                                 self.ws)
+    sh = _abi.SfmMeshShard()
+    sh.own_y0, sh.own_y1 = own
+    sh.global_nodes = int(global_nodes)
+    sh.n_ranks = n_bands
+    sh.sums = self.sums.data_ptr()
+    sh.my_sums = self.my_sums.data_ptr()
+    self.shard = sh
+    self.lib = lib
+
+  def _refresh(self):
+    from . import _dev
+    self.desc.stream = _dev.stream_ptr()
+
+  def begin(self, dt, alpha, cap):
+    C, _abi = self._C, self._abi
+    self._refresh()
+    fire = _abi.SfmFireState()
+    fire.dt, fire.alpha, fire.n_pos, fire.cap = (
+        np.float32(dt), np.float32(alpha), 0, np.float32(cap))
+    _abi.check(self.lib.sfm_mesh_shard_begin(C.byref(self.desc),
+                                             C.byref(self.shard), C.byref(fire)))
+
+  def advance(self):
+    self._abi.check(self.lib.sfm_mesh_shard_advance(
+        self._C.byref(self.desc), self._C.byref(self.shard)))
+
+  def integrate(self):
+    self._abi.check(self.lib.sfm_mesh_shard_integrate(
+        self._C.byref(self.desc), self._C.byref(self.shard)))
+
+  def finish(self):
+    C, _abi = self._C, self._abi
+    fire = _abi.SfmFireState()
+    stats = _abi.SfmChunkStats()
+    _abi.check(self.lib.sfm_mesh_shard_finish(C.byref(self.desc), C.byref(self.shard),
+                                              C.byref(fire), C.byref(stats)))
+    return (np.float32(fire.dt), np.float32(fire.alpha), int(fire.n_pos),
+            np.float32(fire.cap), np.float32(stats.e_kin), np.float32(stats.v_max))
+
+  # -- halo rows -------------------------------------------------------------
+  def boundary(self, side):
+    """(x, v, a) of the owned edge row at `side`, packed [3, C, ..., X]."""
+    import torch
+    row = self.own[0] if side == 'lo' else self.own[1] - 1
+    return torch.stack([t[..., row, :] for t in (self.x, self.v, self.a)]).contiguous()
+
+  def set_halo(self, side, packed):
+    row = self.own[0] - 1 if side == 'lo' else self.own[1]
+    for t, src in zip((self.x, self.v, self.a), packed):
+      t[..., row, :] = src
+
+  def owned_x(self) -> np.ndarray:
+    return self.x[..., self.own[0]:self.own[1], :].cpu().numpy()
+
+
+class BandTransport:
+  """Moves halo rows and partial sums between the bands of one mesh.
+
+  Bands that live in the same process exchange by direct copies; the first /
+  last band of a process talks to the neighbouring rank through
+  torch.distributed (gloo on CPU, nccl = RCCL on GPUs) or, with `comm`, through
+  the library's own RCCL entry points (sfm_comm_halo_exchange /
+  sfm_comm_allgather, one band per rank).
+  """
+
+  def __init__(self, group=None, comm=None):
+    self.group = group
+    self.rank, self.world = world(group)
+    self.comm = comm
+
+  def exchange(self, bands):
+    for lo_band, hi_band in zip(bands[:-1], bands[1:]):
+      up, down = lo_band.boundary('hi'), hi_band.boundary('lo')
+      lo_band.set_halo('hi', down)
+      hi_band.set_halo('lo', up)
+    if self.world == 1:
+      return
+    first, last = bands[0], bands[-1]
+    has_lo, has_hi = self.rank > 0, self.rank < self.world - 1
+    send_lo = first.boundary('lo') if has_lo else None
+    send_hi = last.boundary('hi') if has_hi else None
+    import torch
+    recv_lo = torch.empty_like(send_lo) if has_lo else None
+    recv_hi = torch.empty_like(send_hi) if has_hi else None
+    if self.comm is not None:
+      self.comm.halo_exchange(self.rank - 1 if has_lo else -1, send_lo, recv_lo,
+                              self.rank + 1 if has_hi else -1, send_hi, recv_hi)
+    else:
+      ops = []
+      if has_lo:
+        ops += [dist.P2POp(dist.isend, send_lo, self.rank - 1, self.group),
+                dist.P2POp(dist.irecv, recv_lo, self.rank - 1, self.group)]
+      if has_hi:
+        ops += [dist.P2POp(dist.isend, send_hi, self.rank + 1, self.group),
+                dist.P2POp(dist.irecv, recv_hi, self.rank + 1, self.group)]
+      for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if has_lo:
+      first.set_halo('lo', recv_lo)
+    if has_hi:
+      last.set_halo('hi', recv_hi)
+
+  def gather_sums(self, bands):
+    """Every band's `sums` = the my_sums rows of ALL bands in global order."""
+    import torch
+    local = torch.stack([b.my_sums for b in bands]).contiguous()
+    if self.world == 1:
+      full = local
+    elif self.comm is not None:
+      full = self.comm.allgather(local)
+    else:
+      parts = [torch.empty_like(local) for _ in range(self.world)]
+      dist.all_gather(parts, local, group=self.group)
+      full = torch.cat(parts)
+    for b in bands:
+      b.sums.copy_(full)
+
+  def gather_stats(self, local: list) -> list:
+    """Chunk statistics of all bands, in global band order (host objects)."""
+    return [s for part in gather_objects(local, self.group) for s in part]
+
+
+class RcclComm:
+  """The library's RCCL communicator (sfm_comm_*), bootstrapped over the
+  torch.distributed store: rank 0 creates the id, everyone joins."""
+
+  def __init__(self, group=None):
+    import ctypes as C
+    from . import _abi
+    self._C, self._abi = C, _abi
+    self.lib = _abi.load()
+    self.rank, self.world = world(group)
+    ident = [None]
+    if self.rank == 0:
+      buf = C.create_string_buffer(_abi.COMM_ID_BYTES)
+      _abi.check(self.lib.sfm_comm_unique_id(buf))
+      ident = [bytes(buf.raw)]
+    if self.world > 1:
+      dist.broadcast_object_list(ident, src=0, group=group)
+    handle = C.c_void_p()
+    _abi.check(self.lib.sfm_comm_init(C.byref(handle), ident[0], self.rank,
+                                      self.world))
+    self.handle = handle
+
+  def close(self):
+    if self.handle:
+      self._abi.check(self.lib.sfm_comm_destroy(self.handle))
+      self.handle = None
+
+  @staticmethod
+  def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+  def halo_exchange(self, peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi):
+    from . import _dev
+    ref = send_lo if send_lo is not None else send_hi
+    count = 0 if ref is None else ref.numel()
+    self._abi.check(self.lib.sfm_comm_halo_exchange(
+        self.handle, peer_lo, self._ptr(send_lo), self._ptr(recv_lo), peer_hi,
+        self._ptr(send_hi), self._ptr(recv_hi), count, _dev.stream_ptr()))
+
+  def allgather(self, local):
+    import torch
+    from . import _dev
+    out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype,
+                      device=local.device)
+    self._abi.check(self.lib.sfm_comm_allgather(
+        self.handle, local.data_ptr(), out.data_ptr(), local.numel(),
+        _dev.stream_ptr()))
+    return out.reshape((-1,) + tuple(local.shape[1:]))
+
+  def allreduce(self, t, op='sum'):
+    from . import _dev
+    self._abi.check(self.lib.sfm_comm_allreduce_scalars(
+        self.handle, t.data_ptr(), t.numel(),
+        self._abi.REDUCE_SUM if op == 'sum' else self._abi.REDUCE_MAX,
+        _dev.stream_ptr()))
+    return t
+
+
+def relax_mesh_sharded(x, prev, config, mesh_force=None, group=None,
+                       bands_per_rank: int = 1, band_factory=None,
+                       transport: BandTransport | None = None):
+  """`mesh.relax_mesh(x, prev, config)` for ONE mesh spread over the ranks.
+
+  The rows (y) of every section are split into world_size * bands_per_rank
+  bands; a rank relaxes its bands and exchanges, per step, the boundary rows
+  with the neighbouring bands plus 7 floats of partial sums per band (FIRE
+  power, drift means), which every band reduces in the same order -- all ranks
+  take the same FIRE branches.  Chunk logic (force-cap schedule, stopping) is
+  the reference's (mesh.py:570-606) on the global statistics.
+
+  Every rank passes the full arrays and gets the full relaxed mesh back:
+  (x [np.ndarray], e_kin history, steps).  `band_factory(x, prev, config, spec,
+  own, global_nodes, n_bands)` replaces the HIP band (CPU tests).
+  """
+  rank, ws = world(group)
+  x = np.asarray(x, dtype=np.float32)
+  prev = None if prev is None else np.asarray(prev, dtype=np.float32)
+  if config.start_cap != config.final_cap:
+    if not config.fire:
+      raise NotImplementedError(
+          'Adaptive force capping is only supported with FIRE.')
+    if config.cap_scale <= 1:
+      raise ValueError(
+          'The scaling factor for the force cap has to be larger '
+          'than 1 when the initial and final cap are different.')
+  if config.remove_drift and x.ndim == 5:
+    raise NotImplementedError('per-column drift removal is not sharded')
+  spec = None
+  if band_factory is None:
+    from . import mesh
+    spec = mesh._resolve_force(mesh.inplane_force if mesh_force is None else mesh_force)
+    band_factory = HipBand
+  n_bands = ws * bands_per_rank
+  bounds = band_bounds(x.shape[-2], n_bands)
+  global_nodes = int(np.prod(x.shape[1:]))
+  bands = []
+  for i in range(bands_per_rank):
+    g = rank * bands_per_rank + i
+    y0, y1 = bounds[g]
+    lo = y0 - (1 if g > 0 else 0)
+    hi = y1 + (1 if g < n_bands - 1 else 0)
+    bands.append(band_factory(
+        x[..., lo:hi, :], None if prev is None else prev[..., lo:hi, :], config,
+        spec, (y0 - lo, y1 - lo), global_nodes, n_bands))
+  transport = transport or BandTransport(group)
+
+  t = 0
+  dt, alpha, cap = config.dt, config.alpha, config.start_cap
+  e_kin = []
+  while t < config.max_iters:
+    for b in bands:
+      b.begin(dt, alpha, cap)
+    for k in range(config.num_iters):
+      transport.exchange(bands)
+      if config.fire and k > 0:
+        transport.gather_sums(bands)
+      for b in bands:
+        b.advance()
+      for b in bands:
+        b.integrate()
+    if config.fire and config.num_iters > 0:
+      transport.gather_sums(bands)
+    stats = transport.gather_stats([b.finish() for b in bands])
+    t += config.num_iters
+    ek = np.float32(0)
+    for s in stats:                      # fixed (global band) order
+      ek = np.float32(ek + s[4])
+    e_kin.append(float(ek))
+    v_max = float(max(s[5] for s in stats))
+    if config.fire:
+      dt, alpha, _, cap = stats[0][:4]
+    if v_max < config.stop_v_max:
+      if np.float32(cap) >= np.float32(config.final_cap):
+        break
+      cap = min(cap * config.cap_scale, config.final_cap)
+
+  owned = transport.gather_stats([b.owned_x() for b in bands])
+  return np.concatenate(owned, axis=-2), e_kin, t
+
+
+# ---------------------------------------------------------------------------
+# Section alignment in blocks (BASELINE configs[3]; em_alignment notebook,
+# cells 25 and 38-48): sections depend on the previous solved section, so the
+# z axis is split into blocks that are solved independently, one (or more) per
+# rank; the LAST solved mesh of every block is the block's boundary and is sent
+# to all ranks, where it forms the "cross-block" flow field that a second, much
+# smaller relaxation (one virtual section per block) aligns.
+# ---------------------------------------------------------------------------
+def block_ranges(n_sections: int, n_blocks: int) -> list[tuple[int, int]]:
+  """[start, stop) section ranges of the blocks (consecutive blocks share the
+  boundary section like the notebook's [0..50], [50..100], ...)."""
+  if n_blocks < 1 or n_sections < n_blocks:
+    raise ValueError(f'cannot split {n_sections} sections into {n_blocks} blocks')
+  edges = [n_sections * i // n_blocks for i in range(n_blocks + 1)]
+  return list(zip(edges[:-1], edges[1:]))
+
+
+def solve_section_block(flow, config, stride, relax_fn=None, compose_fn=None):
+  """Sequential section-by-section relaxation of one block (notebook cell 25):
+  prev = compose_maps_fast(flow[z], solved[-1]); x = relax_mesh(0, prev).
+
+  flow: [2, n, y, x] cleaned flow of the block's sections.  Returns the solved
+  meshes [2, n + 1, y, x] (entry 0 is the zero mesh of the block's first
+  section).  The state stays on the device between the two ops.
+  """
+  if relax_fn is None or compose_fn is None:
+    from . import map_utils, mesh
+    relax_fn = relax_fn or mesh.relax_mesh
+    compose_fn = compose_fn or map_utils.compose_maps_fast
+  origin = (0.0, 0.0)
+  flow = np.asarray(flow, dtype=np.float32)
+  zero = np.zeros_like(flow[:, 0:1])
+  solved = [zero]
+  for z in range(flow.shape[1]):
+    # solved[-1] is whatever relax_fn returned (a DeviceArray on the HIP path):
+    # no host round trip between relaxation and composition
+    prev = compose_fn(flow[:, z:z + 1], origin, stride, solved[-1], origin, stride)
+    x, _, _ = relax_fn(zero, prev, config)
+    solved.append(x)
+  return np.concatenate([np.asarray(s, dtype=np.float32) for s in solved], axis=1)
+
+
+def align_sections_blocked(flow, config, stride, n_blocks=None, group=None,
+                           xblk_config=None, relax_fn=None, compose_fn=None):
+  """Block-parallel section alignment.
+
+  flow: [2, n_sections, y, x] (every rank passes the same array, or at least
+  its own blocks' sections).  Blocks are dealt round-robin to the ranks and
+  solved independently; the last-section mesh of every block ([2, 1, y, x],
+  336 KB for an 8192^2 section at stride 40) is the only data that crosses
+  ranks.  Returns (blocks: {block index: [2, n_b + 1, y, x]} of THIS rank,
+  last: [2, n_blocks, y, x] boundary meshes of all blocks, xblk: the solved
+  cross-block mesh [2, n_blocks, y, x], identical on every rank).
+  """
+  rank, ws = world(group)
+  flow = np.asarray(flow, dtype=np.float32)
+  n_blocks = ws if n_blocks is None else n_blocks
+  ranges = block_ranges(flow.shape[1], n_blocks)
+  mine = shard_units(n_blocks, rank, ws)
+  blocks = {b: solve_section_block(flow[:, ranges[b][0]:ranges[b][1]], config, stride,
+                                   relax_fn, compose_fn) for b in mine}
+  # mesh-boundary exchange: last solved section of every block, to every rank
+  last_local = [blocks[b][:, -1] for b in mine]
+  last = [None] * n_blocks
+  for r, part in enumerate(gather_objects(last_local, group)):
+    for k, b in enumerate(shard_units(n_blocks, r, ws)):
+      last[b] = part[k]
+  last = np.stack(last, axis=1)
+  # cross-block mesh: every block is a virtual section (notebook cell 47); it
+  # is tiny, so every rank solves it redundantly instead of broadcasting it
+  xcfg = xblk_config or config
+  if relax_fn is None or compose_fn is None:
+    from . import map_utils, mesh
+    relax_fn = relax_fn or mesh.relax_mesh
+    compose_fn = compose_fn or map_utils.compose_maps_fast
+  xblk = []
+  origin = (0.0, 0.0)
+  for z in range(n_blocks):
+    if z == 0:
+      prev = last[:, z:z + 1]
+    else:
+      prev = compose_fn(last[:, z:z + 1], origin, stride, xblk[-1], origin, stride)
+    x, _, _ = relax_fn(np.zeros_like(last[:, 0:1]), prev, xcfg)
+    xblk.append(np.array(x, dtype=np.float32))
+  return blocks, last, np.concatenate(xblk, axis=1)

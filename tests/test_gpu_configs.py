@@ -141,9 +141,10 @@ def test_cfg4_3d_overlap_strip_flow_vs_oracle(gpu):
   calc = ff.JAXMaskedXCorrWithStatsCalculator()
   got = calc.flow_field(pre, post, (80, 80, 80), 40, batch_size=16)
   assert got.shape == (5, 11, 4, 2)
-  np.testing.assert_array_equal(got[0], -3)
-  np.testing.assert_array_equal(got[1], 3)
-  np.testing.assert_array_equal(got[2], -2)
+  # flow = position in pre - position in post of the same content, as (x, y, z)
+  np.testing.assert_array_equal(got[0], 3)
+  np.testing.assert_array_equal(got[1], -3)
+  np.testing.assert_array_equal(got[2], 2)
   want = flow_oracle.flow_field(pre, post, (80, 80, 80), 40, batch_size=16,
                                 workers=16)
   check_flow(got, want, sharp_rtol=1e-3)
