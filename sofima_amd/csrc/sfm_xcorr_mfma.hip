@@ -79,6 +79,12 @@
 #ifndef SFM_AF_PREFETCH
 #define SFM_AF_PREFETCH 0
 #endif
+// Row-group loop with the A chunk outermost and in-place prefetch (see the
+// kernel): the production order.  0 selects the round-1 order (B fragment
+// outermost, all LDS fragment loads at the loop head).
+#ifndef SFM_LOOP_CA_OUTER
+#define SFM_LOOP_CA_OUTER 1
+#endif
 
 #include <algorithm>
 #include <cstdlib>
@@ -1187,6 +1193,71 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           }
         }
       };
+      // (the general P != Q epilogue needs the registers: old order there)
+      if constexpr (SFM_LOOP_CA_OUTER && MODE != kModeGeneral) {
+        // Software-pipelined order: A chunk outer, B fragment inner.  All NCE B
+        // fragments of the row group stay in registers (4 NCE VGPRs) and every A
+        // fragment is reloaded IN PLACE for the next row group right after its
+        // last MFMA has been issued; the B dwords of the next group arrive in
+        // small batches between the A chunks and are funnel-shifted into the
+        // fragment registers behind the last chunk's MFMAs.  Nothing is waited
+        // for at the loop head: the matrix pipe never drains between row
+        // groups, even when the wave is alone on its SIMD.  (The prefetches of
+        // the last group read up to 4 rows past the tile: inside the
+        // workgroup's LDS, never used.)
+        constexpr int kND = 4 * NCE + 1;
+        constexpr int kPerCa = (kND + NCA - 2) / (NCA - 1);  // dwords fetched per chunk
+        // A fragments live in a rotating window of kW register sets: chunk ca
+        // uses set ca % kW and, once its MFMAs are issued, the set is reloaded
+        // with the chunk kW positions ahead (of this row group or the next).
+        constexpr int kW = NCA > 6 ? NCA / 2 : NCA;
+        static_assert(NCA % kW == 0, "window must divide the chunk count");
+        v4i af[kW], bf[NCE];
+        unsigned dn[kND];
+#pragma unroll
+        for (int j = 0; j < kND; ++j) dn[j] = *reinterpret_cast<const unsigned*>(bp + 4 * j);
+#pragma unroll
+        for (int w = 0; w < kW; ++w)
+          af[w] = *reinterpret_cast<const v4i*>(ap + 16 * w);
+#pragma unroll
+        for (int c = 0; c < NCE; ++c)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            bf[c][k] = static_cast<int>(
+                __builtin_amdgcn_alignbyte(dn[4 * c + k + 1], dn[4 * c + k], sh));
+        for (int yb0 = ylo; yb0 < yhi; yb0 += 4) {
+          bp += 4 * a.pb;
+#pragma unroll
+          for (int ca = 0; ca < NCA; ++ca) {
+#pragma unroll
+            for (int c = 0; c < NCE; ++c) {
+              const int q = ca - c + cq0;
+              acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ca % kW], bf[c], acc[q], 0,
+                                                             0, 0);
+              if (ca == NCA - 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  bf[c][k] = static_cast<int>(
+                      __builtin_amdgcn_alignbyte(dn[4 * c + k + 1], dn[4 * c + k], sh));
+              }
+            }
+            if (ca + kW < NCA)
+              af[ca % kW] = *reinterpret_cast<const v4i*>(ap + 16 * (ca + kW));
+            else
+              af[ca % kW] =
+                  *reinterpret_cast<const v4i*>(ap + 4 * a.pa + 16 * (ca + kW - NCA));
+            if (ca < NCA - 1) {
+#pragma unroll
+              for (int j = ca * kPerCa; j < (ca + 1) * kPerCa && j < kND; ++j)
+                dn[j] = *reinterpret_cast<const unsigned*>(bp + 4 * j);
+            }
+            // keep the chunk order: the machine scheduler would otherwise sink
+            // every prefetch to the end of the body (= no prefetch distance)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          ap += 4 * a.pa;
+        }
+      } else
 #if SFM_AF_PREFETCH
       {
         v4i afA[NCA], afB[NCA];
@@ -1203,14 +1274,16 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         if (yb0 < yhi) row_group(afA, nullptr, nullptr, bp);
       }
 #else
-      for (int yb0 = ylo; yb0 < yhi; yb0 += 4) {
-        v4i af[NCA];
+      {
+        for (int yb0 = ylo; yb0 < yhi; yb0 += 4) {
+          v4i af[NCA];
 #pragma unroll
-        for (int ca = 0; ca < NCA; ++ca)
-          af[ca] = *reinterpret_cast<const v4i*>(ap + 16 * ca);
-        row_group(af, nullptr, nullptr, bp);
-        ap += 4 * a.pa;
-        bp += 4 * a.pb;
+          for (int ca = 0; ca < NCA; ++ca)
+            af[ca] = *reinterpret_cast<const v4i*>(ap + 16 * ca);
+          row_group(af, nullptr, nullptr, bp);
+          ap += 4 * a.pa;
+          bp += 4 * a.pb;
+        }
       }
 #endif
 
