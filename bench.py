@@ -204,6 +204,14 @@ def main():
         'patches_per_launch': round(patches_per_launch, 1),
         'flop_per_patch': flop_per_patch, 'traffic': None,
     }
+    clk = float(prof.clock_mhz[0])
+    if clk > 0 and uses_mfma:
+      # DVFS: the chip clocks to its power budget under this kernel; `peak` is the
+      # 2.4 GHz figure.  The matrix pipes' ceiling at the clock the kernel
+      # actually sustained, and the issued (tile-padded) fraction of it:
+      roof['sustained_clock_mhz'] = round(clk, 1)
+      roof['peak_at_sustained_clock'] = round(peak * clk / 2400.0, 1)
+      roof['frac_at_sustained_clock'] = round(achieved / (peak * clk / 2400.0), 4)
   mesh_obj = {
       'value': node_updates_s, 'unit': 'node-updates/s',
       'nodes': mesh_nodes, 'iterations_per_step': mesh_steps_done // max(args.steps, 1),

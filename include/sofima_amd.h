@@ -63,6 +63,9 @@ int sfm_device_count(int* count);
 typedef struct SfmProfile {
   double kernel_ms[2];
   int64_t launches[2];
+  double clock_mhz[2];          /* sustained shader clock inside the kernels of
+                                   that kind (s_memtime / s_memrealtime of one
+                                   workgroup); 0 when not sampled             */
 } SfmProfile;
 int sfm_profile_enable(int on);
 int sfm_profile_read(SfmProfile* out);

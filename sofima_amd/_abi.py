@@ -225,7 +225,8 @@ class SfmFireState(C.Structure):
 
 
 class SfmProfile(C.Structure):
-  _fields_ = [('kernel_ms', C.c_double * 2), ('launches', C.c_int64 * 2)]
+  _fields_ = [('kernel_ms', C.c_double * 2), ('launches', C.c_int64 * 2),
+              ('clock_mhz', C.c_double * 2)]
 
 
 class SfmChunkStats(C.Structure):

@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -30,6 +31,10 @@ struct Span {
 std::vector<Span> g_spans[2];
 std::vector<Span> g_free;
 Span g_open[2];
+struct ClockSample {
+  long long v[2];
+};
+std::deque<ClockSample> g_clock[2];  // stable addresses: targets of async copies
 }  // namespace
 
 bool profiling() { return g_prof_on.load(std::memory_order_relaxed); }
@@ -56,6 +61,14 @@ void prof_end(int kind, hipStream_t st) {
   g_spans[kind].push_back(g_open[kind]);
 }
 
+void prof_clock(int kind, const long long* dev_pair, hipStream_t st) {
+  if (!profiling() || !dev_pair) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_clock[kind].push_back(ClockSample{{0, 0}});
+  (void)hipMemcpyAsync(g_clock[kind].back().v, dev_pair, sizeof(long long) * 2,
+                       hipMemcpyDeviceToHost, st);
+}
+
 }  // namespace sfm
 
 extern "C" {
@@ -68,6 +81,8 @@ int sfm_profile_enable(int on) {
 int sfm_profile_read(SfmProfile* out) {
   if (!out) return sfm::fail(SFM_ERR_INVALID, "out is NULL");
   std::lock_guard<std::mutex> lk(sfm::g_prof_mu);
+  if (!sfm::g_clock[0].empty() || !sfm::g_clock[1].empty())
+    SFM_HIP_CHECK(hipDeviceSynchronize());  // the probe copies trail the events
   for (int k = 0; k < 2; ++k) {
     double ms = 0.0;
     for (auto& s : sfm::g_spans[k]) {
@@ -80,6 +95,14 @@ int sfm_profile_read(SfmProfile* out) {
     out->kernel_ms[k] = ms;
     out->launches[k] = static_cast<int64_t>(sfm::g_spans[k].size());
     sfm::g_spans[k].clear();
+    // the events above are later in stream order than the probe copies
+    long long cyc = 0, ticks = 0;
+    for (auto& c : sfm::g_clock[k]) {
+      cyc += c.v[0];
+      ticks += c.v[1];
+    }
+    out->clock_mhz[k] = ticks > 0 ? static_cast<double>(cyc) * 100.0 / ticks : 0.0;
+    sfm::g_clock[k].clear();
   }
   return SFM_OK;
 }

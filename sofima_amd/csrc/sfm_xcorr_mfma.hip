@@ -85,6 +85,14 @@
 #ifndef SFM_LOOP_CA_OUTER
 #define SFM_LOOP_CA_OUTER 1
 #endif
+// The waves of a workgroup take dy tiles from a shared longest-first list (LDS
+// counter) instead of a static deal: the four SIMDs do not run at the same
+// speed (each shares its matrix pipe with a wave of the other workgroup of the
+// CU), and with the static deal ~17 % of a workgroup's time was spent waiting
+// for its slowest wave at the end of every patch.
+#ifndef SFM_DYNAMIC_TILES
+#define SFM_DYNAMIC_TILES 1
+#endif
 
 #include <algorithm>
 #include <cstdlib>
@@ -142,6 +150,10 @@ struct MfmaArgs {
   // static tile schedule: tiles (dy tile indices) per wave
   int tiles[kWaves][kMaxTilesPerWave];  // ints: scalar loads from the kernarg segment
   int n_tiles[kWaves];
+  // dynamic tile schedule: all dy tiles, longest first; the waves of a
+  // workgroup draw from it through an LDS counter
+  int order[kWaves * kMaxTilesPerWave];
+  int n_order;
   // fused first-peak search (flow_field.py:238-262); see FusedPeaks
   int do_peaks;
   float threshold_rel;
@@ -168,6 +180,9 @@ struct MfmaArgs {
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
   // dynamic patch queue (NULL: static striding over the workgroups)
   int* work_counter;
+  // shader-clock probe: workgroup 0 leaves (core cycles, 10 ns wall ticks) of its
+  // residency here (bench.py reports the sustained clock under this kernel)
+  long long* clk;
   int prio_mode;      // experiment knob: 0 natural, 1 alternate per tile, 2 static
 };
 
@@ -995,6 +1010,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   const int Py = a.P[0], Px = a.P[1], Qy = a.Q[0], Qx = a.Q[1];
   const int Sy = a.S[0], Sx = a.S[1];
 
+  const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
   // Zero the whole LDS image once: pad rows / margins stay zero afterwards.
   for (int i = threadIdx.x * 16; i < a.a_bytes + a.b_bytes; i += kThreads * 16)
     *reinterpret_cast<v4i*>(smem + i) = v4i{0, 0, 0, 0};
@@ -1008,6 +1024,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 
 #ifdef SFM_MFMA_TIMING
   const long long wstart = wall_clock64();
+  const long long cstart = clock64();
   long long tph[10] = {0,0,0,0,0,0,0,0,0,0}; long long tc = clock64(); int npat = 0;
 #define TICK(i) { long long tn = clock64(); tph[i] += tn - tc; tc = tn; }
 #else
@@ -1071,6 +1088,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     if (threadIdx.x == 0) {
       *pmax_lds = 0;  // float bits of max(surface, 0)
       *hot_lds = 0;
+      pmax_lds[3] = 0;  // tile counter of this patch
     }
     if (SAME) {
 #pragma unroll
@@ -1132,9 +1150,18 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     const float* G = SAME ? a.gtab + (long long)b * Py * Px : nullptr;
     float* surf = a.surface + b * a.s_stride;
 
+#if SFM_DYNAMIC_TILES
+    for (;;) {
+      int ti = 0;
+      if (lane == 0) ti = atomicAdd(pmax_lds + 3, 1);
+      ti = __builtin_amdgcn_readfirstlane(ti);
+      if (ti >= a.n_order) break;
+      const int p = __builtin_amdgcn_readfirstlane(a.order[ti]);
+#else
     const int n_my_tiles = __builtin_amdgcn_readfirstlane(a.n_tiles[wave]);
     for (int ti = 0; ti < n_my_tiles; ++ti) {
       const int p = __builtin_amdgcn_readfirstlane(a.tiles[wave][ti]);
+#endif
       // The two workgroups of a CU share each SIMD's MFMA pipe, and the issue
       // arbiter always favours the older wave: the younger workgroup would
       // run ~25 % slower and finish long after its partner.  Alternating the
@@ -1626,19 +1653,24 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     }
     TICK(6)
   }
+  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.clk[0] = clock64() - probe_c0;
+    a.clk[1] = wall_clock64() - probe_w0;
+  }
 #ifdef SFM_MFMA_TIMING
   if (lane == 0 && wave == 0) {
     // HW_REG_HW_ID (4): [11:8] CU, [12] SH, [15:13] SE; HW_REG_XCC_ID (20): [3:0]
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-    printf("WG %d xcc %u se %u cu %u patches %d wall %lld mfma %lld epi %lld\n", blockIdx.x,
-           xcc & 15, (hw >> 13) & 7, (hw >> 8) & 15, npat,
-           (long long)(wall_clock64() - wstart), tph[2] / (npat ? npat : 1),
+    const long long wall = wall_clock64() - wstart, cyc = clock64() - cstart;
+    printf("WG %d xcc %u se %u cu %u patches %d wall %lld cycles %lld MHz %lld mfma %lld epi %lld\n",
+           blockIdx.x, xcc & 15, (hw >> 13) & 7, (hw >> 8) & 15, npat, wall, cyc,
+           wall ? cyc * 100 / wall : 0, tph[2] / (npat ? npat : 1),
            tph[3] / (npat ? npat : 1));
   }
   if (blockIdx.x == 7 && lane == 0)
-    printf("wave %d patches %d: sync %lld pix %lld aux+touch %lld stagesync %lld mfma %lld epi %lld hot %lld tail %lld peaks %lld\n",
-           wave, npat, tph[0] / npat, tph[8] / npat, tph[9] / npat, tph[1] / npat, tph[2] / npat, tph[3] / npat,
+    printf("wave %d patches %d: next %lld sync %lld pix %lld aux+touch %lld stagesync %lld mfma %lld epi %lld hot %lld tail %lld peaks %lld\n",
+           wave, npat, tph[7] / npat, tph[0] / npat, tph[8] / npat, tph[9] / npat, tph[1] / npat, tph[2] / npat, tph[3] / npat,
            tph[4] / npat, tph[5] / npat, tph[6] / npat);
 #endif
 }
@@ -1764,6 +1796,7 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, MODE>), dim3(grid),
                      dim3(kThreads), lds, st, a);
   sfm::prof_end(sfm::kProfXcorr, st);
+  sfm::prof_clock(sfm::kProfXcorr, a.clk, st);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }
@@ -1848,6 +1881,10 @@ int fill_common(const SfmXcorrDesc* d, const Layout& l, MfmaArgs* ap) {
             [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
               return x.first > y.first || (x.first == y.first && x.second < y.second);
             });
+  if (work.size() > sizeof(a.order) / sizeof(a.order[0]))
+    return sfm::fail(SFM_ERR_INVALID, "too many dy tiles");
+  a.n_order = static_cast<int>(work.size());
+  for (size_t i = 0; i < work.size(); ++i) a.order[i] = work[i].second;
   int load[kWaves] = {0, 0, 0, 0};
   for (auto& t : work) {
     int best = 0;
@@ -1940,6 +1977,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   {
     const char* e = std::getenv("SFM_MFMA_QUEUE");
     a.work_counter = (e && e[0] == '0') ? nullptr : w.counter;
+    a.clk = reinterpret_cast<long long*>(w.counter + 16);
     const char* p = std::getenv("SFM_MFMA_PRIO");
     a.prio_mode = p ? std::atoi(p) : 0;
   }
