@@ -40,6 +40,8 @@ extern "C" {
 
 #define SFM_DTYPE_U8 0
 #define SFM_DTYPE_F32 1
+#define SFM_DTYPE_U16 2          /* warping only                               */
+#define SFM_DTYPE_I32 3          /* warping only: contiguous segment ids       */
 
 /* Which correlation kernel family to use. AUTO picks MFMA_I8 whenever the
  * inputs qualify (uint8 images, 2-D, no masks in the correlation) and DIRECT
@@ -223,6 +225,37 @@ typedef struct SfmMaskIrregularDesc {
  * [y, x] (1 = masked). */
 int sfm_mask_irregular(const SfmMaskIrregularDesc* desc, float* coord_map,
                        uint8_t* bad);
+
+/* ------------------------------------------------------------------------
+ * Warping one image section by an inverse coordinate map.
+ * Replaces the per-section body of warp.warp_subvolume (warp.py:145-167):
+ * linear (extrapolating) interpolation of the map nodes to every output
+ * pixel, cv2.convertMaps to 1/32-pixel fixed point, cv2.remap with a zero
+ * border -- fused, one pass over the output.
+ * ---------------------------------------------------------------------- */
+#define SFM_WARP_NEAREST 0
+#define SFM_WARP_TABLE 1         /* taps weighted by `weights` (linear, cubic,
+                                    lanczos4 differ only in the table)        */
+typedef struct SfmWarpDesc {
+  int32_t dtype;                /* SFM_DTYPE_* of image and out              */
+  int32_t interpolation;        /* SFM_WARP_*                                */
+  int32_t ksize;                /* taps per axis: 2, 4 or 8                  */
+  int32_t image_shape[2];       /* y, x                                      */
+  int32_t map_shape[2];         /* y, x nodes (>= 2 x 2)                     */
+  int32_t out_shape[2];         /* y, x                                      */
+  double map_origin[2];         /* y, x of map node (0, 0) in output pixels  */
+  double stride;                /* output pixels per map node                */
+  const void* image;            /* device [y, x]                             */
+  const float* coord_map;       /* device [2, y, x]: ABSOLUTE source (x, y)
+                                   coordinates in image pixels               */
+  const void* weights;          /* device [32 * 32, ksize * ksize]: int16 with
+                                   15 fractional bits for u8 images, float
+                                   otherwise; phase = 32 * fy + fx            */
+  void* out;                    /* device [y, x]                             */
+  void* stream;
+} SfmWarpDesc;
+
+int sfm_warp_section(const SfmWarpDesc* desc);
 
 /* ------------------------------------------------------------------------
  * Dynamic-range mask of an overlap strip, the step in front of the

@@ -212,3 +212,38 @@ def relax_mesh(x, prev, cfg, mesh_force=inplane_force, prev_fn=None):
         break
       cap = min(cap * cfg.cap_scale, cfg.final_cap)
   return x, e_kin, t
+
+
+def relax_mesh_passes(x, prev, cfg, mask=None, mesh_min_frac=0.5, start_fn=None):
+  """The three-pass driver of processor/mesh.py:428-513 (RelaxMesh.relax_mesh):
+  relax; on folds relax a fresh mesh towards the solution with k0 / 10; if that
+  is regular, relax it against the real targets.  Returns (x, e_kin, steps,
+  status) with status 0 regular, 1 prep failed, 2 regularised.  `start_fn(x0,
+  prev)` plays maybe_update_init_state (processor/mesh.py:387-398)."""
+  import copy
+  from oracle import maps_oracle
+
+  def mask_irregular(m, **kw):      # in place, like map_utils.mask_irregular
+    masked, bad = maps_oracle.mask_irregular(m[:, 0], cfg.stride, mesh_min_frac, **kw)
+    m[:, 0] = masked
+    return bad
+
+  x = np.array(x, f32)
+  if mask is not None:
+    x[:, mask] = np.nan
+  x, e_kin, steps = relax_mesh(x, prev, cfg)
+  orig = x.copy()
+  if not mask_irregular(x, dilation_iters=5).any():
+    return x, e_kin, steps, 0
+  start = np.zeros_like(x)
+  if start_fn is not None:
+    start = start_fn(start, prev)
+  soft = copy.copy(cfg)
+  soft.k0 = cfg.k0 / 10.0
+  x, _, prep = relax_mesh(start, x, soft)
+  if mask_irregular(x).any():
+    return orig, e_kin, steps + prep, 1
+  if mask is not None:
+    x[:, mask] = np.nan
+  x, e_kin2, reg = relax_mesh(x, prev, cfg)
+  return x, e_kin2, steps + prep + reg, 2

@@ -1,0 +1,160 @@
+"""CPU oracle for image warping.  TEST INFRASTRUCTURE.
+
+A NumPy / SciPy restatement of `warp.warp_subvolume` (/root/reference/warp.py:
+58-186): scipy.interpolate.RegularGridInterpolator for the dense coordinates
+(the reference's own call), followed by a restatement of the two OpenCV calls
+the reference makes (`cv2.convertMaps` to CV_16SC2, `cv2.remap` with a zero
+constant border).  Never imported by anything under `sofima_amd/`.
+
+PARITY UNPINNED beyond the reference's known-answer tests: OpenCV (cv2) cannot
+be installed in the build container, so neither this oracle nor the HIP path
+could be compared with the reference's output; the fixed-point semantics below
+follow OpenCV's published implementation (imgwarp.cpp: initInterTab2D,
+remapNearest / remapBilinear / remapLanczos4, 5 fractional map bits, 15-bit
+weights for 8-bit images).  Pinned by tests/warp_test.py:27-82 (re-typed in
+tests/test_reference_kats.py / tests/test_gpu_warp.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy import interpolate
+
+TAB = 32
+SCALE = 1 << 15
+
+
+def _lanczos4(x):
+  if x < np.finfo(np.float32).eps:
+    c = np.zeros(8, np.float32)
+    c[3] = 1
+    return c
+  s45 = 0.70710678118654752440084436210485
+  cs = [(1, 0), (-s45, -s45), (0, 1), (s45, -s45), (-1, 0), (s45, s45), (0, -1),
+        (-s45, s45)]
+  y0 = -(x + 3) * np.pi * 0.25
+  s0, c0 = np.sin(y0), np.cos(y0)
+  c = np.zeros(8, np.float32)
+  for i in range(8):
+    y = -(x + 3 - i) * np.pi * 0.25
+    c[i] = np.float32((cs[i][0] * s0 + cs[i][1] * c0) / (y * y))
+  return c * (np.float32(1) / np.sum(c, dtype=np.float32))
+
+
+def _taps(kind, x):
+  x = np.float32(x)
+  if kind == 'linear':
+    return np.array([1 - x, x], np.float32)
+  if kind == 'cubic':
+    a = np.float32(-0.75)
+    c = np.zeros(4, np.float32)
+    c[0] = ((a * (x + 1) - 5 * a) * (x + 1) + 8 * a) * (x + 1) - 4 * a
+    c[1] = ((a + 2) * x - (a + 3)) * x * x + 1
+    c[2] = ((a + 2) * (1 - x) - (a + 3)) * (1 - x) * (1 - x) + 1
+    c[3] = 1 - c[0] - c[1] - c[2]
+    return c
+  return _lanczos4(float(x))
+
+
+def weight_table(kind, fixed):
+  """[32, 32, ks, ks] weights; int32 with unit sum 2^15 when `fixed`."""
+  one = [_taps(kind, i / TAB) for i in range(TAB)]
+  ks = len(one[0])
+  out = np.zeros((TAB, TAB, ks, ks), np.int32 if fixed else np.float32)
+  for i in range(TAB):
+    for j in range(TAB):
+      w = np.outer(one[i], one[j]).astype(np.float32)
+      if not fixed:
+        out[i, j] = w
+        continue
+      iw = np.clip(np.rint(w * np.float32(SCALE)), -32768, 32767).astype(np.int32)
+      diff = int(iw.sum()) - SCALE
+      if diff:
+        lo = ks // 2 - 1
+        cen = iw[lo:lo + 2, lo:lo + 2]
+        k = np.unravel_index(np.argmax(cen) if diff < 0 else np.argmin(cen), (2, 2))
+        iw[lo + k[0], lo + k[1]] = min(iw[lo + k[0], lo + k[1]] - diff, 32767)
+      out[i, j] = iw
+  return out
+
+
+def _cv_round(v):
+  v = np.asarray(v, np.float64)
+  bad = ~((v > -2147483648.0) & (v < 2147483647.0))
+  r = np.rint(np.where(bad, 0, v)).astype(np.int64)
+  return np.where(bad, -2147483648, r)
+
+
+def remap(img, dx, dy, kind):
+  """cv2.remap(img, *cv2.convertMaps(dx, dy, CV_16SC2, nn), interpolation)."""
+  h, w = img.shape
+
+  def px(y, x):
+    ok = (y >= 0) & (y < h) & (x >= 0) & (x < w)
+    return np.where(ok, img[np.clip(y, 0, h - 1), np.clip(x, 0, w - 1)], 0)
+
+  if kind == 'nearest':
+    x = np.clip(_cv_round(dx), -32768, 32767)
+    y = np.clip(_cv_round(dy), -32768, 32767)
+    return px(y, x).astype(img.dtype)
+  fx = _cv_round(dx.astype(np.float64) * TAB)
+  fy = _cv_round(dy.astype(np.float64) * TAB)
+  x0 = np.clip(fx >> 5, -32768, 32767)
+  y0 = np.clip(fy >> 5, -32768, 32767)
+  fixed = img.dtype == np.uint8
+  tab = weight_table(kind, fixed)[fy & 31, fx & 31]   # [oy, ox, ks, ks]
+  ks = tab.shape[-1]
+  ofs = ks // 2 - 1
+  if fixed:
+    acc = np.zeros(dx.shape, np.int64)
+    for k1 in range(ks):
+      for k2 in range(ks):
+        acc += tab[..., k1, k2].astype(np.int64) * px(y0 + k1 - ofs, x0 + k2 - ofs)
+    return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+  acc = np.zeros(dx.shape, np.float32)
+  for k1 in range(ks):
+    for k2 in range(ks):
+      acc = acc + tab[..., k1, k2] * px(y0 + k1 - ofs, x0 + k2 - ofs).astype(np.float32)
+  if img.dtype == np.uint16:
+    return np.clip(_cv_round(acc), 0, 65535).astype(np.uint16)
+  return acc.astype(img.dtype)
+
+
+def warp_subvolume(image, image_box, coord_map, map_box, stride, out_box,
+                   interpolation=None, offset=0.0):
+  """Boxes are (start xyz, size xyz) pairs."""
+  image = np.asarray(image)
+  ids = None
+  if image.dtype == np.uint64:
+    kind = 'nearest'
+    ids, inv = np.unique(image, return_inverse=True)
+    if ids[0] != 0:
+      ids = np.concatenate([[0], ids]).astype(np.uint64)
+      inv = inv + 1
+    image = inv.reshape(image.shape).astype(np.int32)
+  else:
+    kind = 'lanczos' if interpolation is None else interpolation
+  img_start, map_start = np.asarray(image_box[0]), np.asarray(map_box[0])
+  out_start, out_size = np.asarray(out_box[0]), np.asarray(out_box[1])
+  skipped = np.all(np.isnan(coord_map), axis=(0, 2, 3))
+  my, mx = coord_map.shape[2:]
+  hy, hx = np.mgrid[:my, :mx]
+  abs_map = np.array(coord_map, np.float64)
+  abs_map[0] += hx[None] * stride
+  abs_map[1] += hy[None] * stride
+  abs_map += (map_start[:2] * stride - img_start[:2] + offset).reshape(2, 1, 1, 1)
+  map_y = (np.arange(my) + map_start[1]) * stride - out_start[1] + offset
+  map_x = (np.arange(mx) + map_start[0]) * stride - out_start[0] + offset
+  out_y, out_x = np.mgrid[:out_size[1], :out_size[0]]
+  warped = np.zeros((image.shape[0], image.shape[1], out_size[1], out_size[0]),
+                    image.dtype)
+  for z in range(image.shape[1]):
+    if skipped[z]:
+      continue
+    # the kernel receives the node coordinates as float32
+    nodes = abs_map[:, z].astype(np.float32).astype(np.float64)
+    dense = [interpolate.RegularGridInterpolator(
+        (map_y, map_x), nodes[c], bounds_error=False, fill_value=None)(
+            (out_y, out_x)).astype(np.float32) for c in (0, 1)]
+    for c in range(image.shape[0]):
+      warped[c, z] = remap(image[c, z], dense[0], dense[1], kind)
+  return ids[warped] if ids is not None else warped

@@ -18,6 +18,10 @@ _lock = threading.Lock()
 SFM_OK = 0
 DTYPE_U8 = 0
 DTYPE_F32 = 1
+DTYPE_U16 = 2
+DTYPE_I32 = 3
+WARP_NEAREST = 0
+WARP_TABLE = 1
 XCORR_AUTO = 0
 XCORR_DIRECT = 1
 XCORR_MFMA_I8 = 2
@@ -121,6 +125,24 @@ class SfmMaskIrregularDesc(C.Structure):
       ('frac', C.c_float),
       ('max_frac', C.c_float),
       ('dilation_iters', i32),
+      ('stream', C.c_void_p),
+  ]
+
+
+class SfmWarpDesc(C.Structure):
+  _fields_ = [
+      ('dtype', i32),
+      ('interpolation', i32),
+      ('ksize', i32),
+      ('image_shape', i32 * 2),
+      ('map_shape', i32 * 2),
+      ('out_shape', i32 * 2),
+      ('map_origin', C.c_double * 2),
+      ('stride', C.c_double),
+      ('image', C.c_void_p),
+      ('coord_map', C.c_void_p),
+      ('weights', C.c_void_p),
+      ('out', C.c_void_p),
       ('stream', C.c_void_p),
   ]
 
@@ -250,6 +272,7 @@ SIGNATURES = {
     'sfm_clean_flow': (C.c_int, [C.POINTER(SfmCleanFlowDesc), C.c_void_p]),
     'sfm_mask_irregular': (C.c_int, [C.POINTER(SfmMaskIrregularDesc), C.c_void_p,
                                      C.c_void_p]),
+    'sfm_warp_section': (C.c_int, [C.POINTER(SfmWarpDesc)]),
     'sfm_range_mask': (C.c_int, [C.POINTER(SfmRangeMaskDesc), C.c_void_p]),
     'sfm_target_mesh': (C.c_int, [C.POINTER(SfmTargetMeshDesc), C.c_void_p,
                                   C.c_void_p, C.c_void_p]),

@@ -25,6 +25,7 @@ SOURCES = {
     'sfm_maps.hip': ['-ffp-contract=off'] + os.environ.get('SFM_MAPS_FLAGS', '').split(),
     'sfm_flowutils.hip': ['-ffp-contract=off'],
     'sfm_comm.hip': [],
+    'sfm_warp.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
           '-Wno-unused-result']

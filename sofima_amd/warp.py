@@ -1,0 +1,194 @@
+"""Image warping by coordinate maps on MI355X.
+
+Drop-in for `warp.warp_subvolume` of the reference (warp.py:58-186), the
+rendering step that follows mesh relaxation.  Every
+section is ONE kernel (`sfm_warp_section`): linear interpolation of the map
+nodes to the output pixels (scipy RegularGridInterpolator in the reference),
+conversion to OpenCV's 1/32-pixel fixed-point map format and the `cv2.remap`
+resampling are fused, so the two dense float maps per section never exist.
+
+Parity note: OpenCV is not installable in the build container, so the
+resampling semantics (convertMaps rounding, the 32 x 32-phase weight tables of
+initInterTab2D with 15-bit fixed point for 8-bit images, constant zero border)
+are restated from OpenCV's published algorithm and pinned by the reference's
+own tests (tests/warp_test.py:27-82) only: "parity unpinned" beyond those.
+The other functions of the reference's warp.py (ndimage_warp, render_tiles,
+warp_points) are host-side rendering utilities and out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+
+import numpy as np
+import torch
+
+from . import _abi
+from . import _dev
+
+_INTER = {'nearest': 0, 'linear': 1, 'cubic': 2, 'lanczos': 3}
+_TAB = 32            # INTER_TAB_SIZE
+_COEF_SCALE = 1 << 15  # INTER_REMAP_COEF_SCALE
+
+
+def _coeffs_1d(kind: int) -> np.ndarray:
+  """[32, ksize] float32 tap weights per sub-pixel phase."""
+  x = np.arange(_TAB, dtype=np.float32) / np.float32(_TAB)
+  if kind == 1:
+    return np.stack([1 - x, x], axis=1).astype(np.float32)
+  if kind == 2:
+    a = np.float32(-0.75)
+    c0 = ((a * (x + 1) - 5 * a) * (x + 1) + 8 * a) * (x + 1) - 4 * a
+    c1 = ((a + 2) * x - (a + 3)) * x * x + 1
+    c2 = ((a + 2) * (1 - x) - (a + 3)) * (1 - x) * (1 - x) + 1
+    return np.stack([c0, c1, c2, 1 - c0 - c1 - c2], axis=1).astype(np.float32)
+  # Lanczos, a = 4: sin(pi t) sin(pi t / 4) / t^2 through the angle-addition
+  # table OpenCV uses for the eight taps
+  s45 = 0.70710678118654752440084436210485
+  cs = np.array([[1, 0], [-s45, -s45], [0, 1], [s45, -s45], [-1, 0], [s45, s45],
+                 [0, -1], [-s45, s45]])
+  out = np.zeros((_TAB, 8), np.float32)
+  for i, xv in enumerate(x):
+    if xv < np.finfo(np.float32).eps:
+      out[i, 3] = 1
+      continue
+    y0 = -(float(xv) + 3) * np.pi * 0.25
+    s0, c0 = np.sin(y0), np.cos(y0)
+    y = -(float(xv) + 3 - np.arange(8)) * np.pi * 0.25
+    c = ((cs[:, 0] * s0 + cs[:, 1] * c0) / (y * y)).astype(np.float32)
+    out[i] = c * (np.float32(1) / c.sum(dtype=np.float32))
+  return out
+
+
+@functools.lru_cache(maxsize=None)
+def _inter_tab(kind: int, fixed: bool) -> np.ndarray:
+  """[32 * 32, ksize * ksize] 2-d weights (phase = 32 * fy + fx); int16 with 15
+  fractional bits and an exact unit sum when `fixed` (8-bit images)."""
+  c = _coeffs_1d(kind)
+  ks = c.shape[1]
+  tab = (c[:, None, :, None] * c[None, :, None, :]).reshape(_TAB * _TAB, ks * ks)
+  tab = tab.astype(np.float32)
+  if not fixed:
+    return np.ascontiguousarray(tab)
+  it = np.clip(np.rint(tab * np.float32(_COEF_SCALE)), -32768, 32767).astype(np.int32)
+  # the rounding error of every phase goes to the largest (deficit) or the
+  # smallest (excess) of the four central taps
+  lo = ks // 2 - 1
+  central = [(lo + a) * ks + lo + b for a in (0, 1) for b in (0, 1)]
+  for row in it:
+    diff = int(row.sum()) - _COEF_SCALE
+    if diff:
+      vals = row[central]
+      k = central[int(np.argmax(vals))] if diff < 0 else central[int(np.argmin(vals))]
+      row[k] = min(row[k] - diff, 32767)   # a unit weight stays 32767 (int16)
+  return np.ascontiguousarray(it.astype(np.int16))
+
+
+def _box(b):
+  """(start xyz, size xyz) of a bounding box object or (start, size) pair."""
+  if hasattr(b, 'start') and hasattr(b, 'size'):
+    return np.asarray(b.start), np.asarray(b.size)
+  return np.asarray(b[0]), np.asarray(b[1])
+
+
+def _make_contiguous(image: np.ndarray):
+  """uint64 segment ids -> dense int32 ids (0 stays 0) and the inverse table."""
+  ids, inv = np.unique(image, return_inverse=True)
+  if ids[0] != 0:
+    ids = np.concatenate([[0], ids]).astype(np.uint64)
+    inv = inv + 1
+  assert len(ids) < 2**31
+  return inv.reshape(image.shape).astype(np.int32), ids
+
+
+def warp_subvolume(image: np.ndarray, image_box, coord_map: np.ndarray, map_box,
+                   stride: float, out_box, interpolation: str | None = None,
+                   offset: float = 0.0, parallelism: int = 1) -> np.ndarray:
+  """Warps a subvolume of data according to a coordinate map (warp.py:58-186).
+
+  image: [n, z, y, x] uint8 / uint16 / float32 data, or uint64 segmentation
+  (nearest neighbour on contiguous ids, mapped back afterwards); coord_map:
+  [2, z, y, x] xy 'inverse' map in relative format; boxes: objects with
+  `.start` / `.size` in xyz (or (start, size) pairs); `stride`: image pixels
+  per map node.  Sections whose map is all NaN are skipped (left zero).
+  `parallelism` is accepted for compatibility: sections are enqueued back to
+  back on the GPU.
+  """
+  del parallelism
+  dev = _dev.device()
+  image = np.asarray(image)
+  ids = None
+  orig_dtype = image.dtype
+  if image.dtype == np.uint64:
+    kind = 0
+    image, ids = _make_contiguous(image)
+    dtype = _abi.DTYPE_I32
+  else:
+    kind = 3 if interpolation is None else _INTER[interpolation]
+    if image.dtype == np.uint32:
+      if image.max() >= 2**16:
+        raise ValueError(
+            'Image warping supported up to uint16 only. For segmentation data, '
+            'use uint64.')
+      image = image.astype(np.uint16)
+    if image.dtype == np.uint8:
+      dtype = _abi.DTYPE_U8
+    elif image.dtype == np.uint16:
+      dtype = _abi.DTYPE_U16
+    else:
+      image = image.astype(np.float32, copy=False)
+      dtype = _abi.DTYPE_F32
+  img_start, _ = _box(image_box)
+  map_start, _ = _box(map_box)
+  out_start, out_size = _box(out_box)
+  coord_map = np.asarray(coord_map)
+  skipped = np.all(np.isnan(coord_map), axis=(0, 2, 3))
+
+  # absolute source coordinates in the local frame of `image`
+  # (map_utils.to_absolute + the box shift, warp.py:128-133), in float64 like
+  # the reference, handed to the kernel as float32 node values
+  my, mx = coord_map.shape[2:]
+  hy, hx = np.mgrid[:my, :mx]
+  shift = map_start[:2] * stride - img_start[:2] + offset
+  abs_map = np.empty(coord_map.shape, np.float64)
+  abs_map[0] = coord_map[0] + hx * stride + shift[0]
+  abs_map[1] = coord_map[1] + hy * stride + shift[1]
+  map_t = torch.from_numpy(abs_map.astype(np.float32)).to(dev)
+
+  img_t = torch.from_numpy(np.ascontiguousarray(image).view(
+      np.int16 if image.dtype == np.uint16 else image.dtype)).to(dev)
+  out_t = torch.zeros((image.shape[0], image.shape[1], int(out_size[1]),
+                       int(out_size[0])), dtype=img_t.dtype, device=dev)
+  d = _abi.SfmWarpDesc()
+  d.dtype = dtype
+  d.interpolation = _abi.WARP_NEAREST if kind == 0 else _abi.WARP_TABLE
+  tab_t = None
+  if kind != 0:
+    tab = _inter_tab(kind, dtype == _abi.DTYPE_U8)
+    tab_t = torch.from_numpy(tab).to(dev)
+    d.ksize = int(round(np.sqrt(tab.shape[1])))
+    d.weights = tab_t.data_ptr()
+  d.image_shape = (C.c_int32 * 2)(*image.shape[2:])
+  d.map_shape = (C.c_int32 * 2)(my, mx)
+  d.out_shape = (C.c_int32 * 2)(int(out_size[1]), int(out_size[0]))
+  d.map_origin = (C.c_double * 2)(
+      float(map_start[1] * stride - out_start[1] + offset),
+      float(map_start[0] * stride - out_start[0] + offset))
+  d.stride = float(stride)
+  d.stream = _dev.stream_ptr()
+  lib = _abi.load()
+  for z in range(image.shape[1]):
+    if skipped[z]:
+      continue
+    zmap = map_t[:, z].contiguous()   # kept alive until the launches are enqueued
+    d.coord_map = zmap.data_ptr()
+    for c in range(image.shape[0]):
+      d.image = img_t[c, z].data_ptr()
+      d.out = out_t[c, z].data_ptr()
+      _abi.check(lib.sfm_warp_section(C.byref(d)))
+  warped = out_t.cpu().numpy()
+  if ids is not None:
+    return ids[warped]
+  if orig_dtype == np.uint16 or image.dtype == np.uint16:
+    warped = warped.view(np.uint16)
+  return warped.astype(orig_dtype)

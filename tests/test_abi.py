@@ -60,6 +60,7 @@ def test_struct_layouts_match_header():
                      ('SfmCleanFlowDesc', _abi.SfmCleanFlowDesc),
                      ('SfmMaskIrregularDesc', _abi.SfmMaskIrregularDesc),
                      ('SfmRangeMaskDesc', _abi.SfmRangeMaskDesc),
+                     ('SfmWarpDesc', _abi.SfmWarpDesc),
                      ('SfmMeshShard', _abi.SfmMeshShard),
                      ('SfmTargetMeshDesc', _abi.SfmTargetMeshDesc)):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,

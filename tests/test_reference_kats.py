@@ -164,3 +164,41 @@ def test_mask_irregular():
   expected[:, 39:42, 8:11] = np.nan
   np.testing.assert_array_equal(expected, masked)
   np.testing.assert_array_equal(np.isnan(expected[0, ...]), bad)
+
+
+# -- tests/warp_test.py:27-82 against the warp oracle ---------------------------
+def test_warp_subvolume_segmentation_translate_oracle():
+  from oracle import warp_oracle
+  image = np.zeros((1, 2, 100, 100), dtype=np.uint64)
+  image[0, 0, 40, 30] = 42
+  image[0, 1, 50, 40] = 2**40
+  coord_map = np.zeros((2, 2, 15, 15))
+  coord_map[0, 0, :, :] = 10
+  coord_map[1, 1, :, :] = 17
+  warped = warp_oracle.warp_subvolume(
+      image, ((0, 0, 0), (100, 100, 2)), coord_map, ((0, 0, 0), (15, 15, 2)), 10,
+      ((10, 20, 0), (90, 80, 2)))
+  expected = np.zeros((1, 2, 80, 90))
+  expected[0, 0, 20, 10] = 42
+  expected[0, 1, 13, 30] = 2**40
+  np.testing.assert_array_equal(warped, expected)
+
+
+def test_warp_subvolume_rotate_oracle():
+  from oracle import warp_oracle
+  hy, hx = np.mgrid[-50:50, -50:50]
+  image = np.zeros((1, 1, 100, 100), dtype=np.uint8)
+  image[0, 0, ...][np.abs(hy) + np.abs(hx) < 25] = 255
+  angle = np.pi / 4
+  coord_map = np.zeros((2, 1, 10, 10))
+  coord_map[0, 0] = (np.cos(angle) * hx[::10, ::10] - np.sin(angle) * hy[::10, ::10]
+                     ) - hx[::10, ::10]
+  coord_map[1, 0] = (np.sin(angle) * hx[::10, ::10] + np.cos(angle) * hy[::10, ::10]
+                     ) - hy[::10, ::10]
+  box = ((0, 0, 0), (100, 100, 1))
+  warped = warp_oracle.warp_subvolume(image, box, coord_map, ((0, 0, 0), (10, 10, 1)),
+                                      10, box)
+  mask = np.zeros((1, 1, 100, 100), dtype=bool)
+  mask[0, 0, 33:68, 33:68] = True
+  assert np.all(warped[mask] > 128)
+  assert np.all(warped[~mask] < 64)
