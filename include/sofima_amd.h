@@ -138,6 +138,54 @@ typedef struct SfmMaskCountDesc {
 /* counts: device int32 [prod((shape - patch) / step + 1)], row-major. */
 int sfm_mask_patch_counts(const SfmMaskCountDesc* desc, int32_t* counts);
 
+/* ------------------------------------------------------------------------
+ * The host loop of flow_field() on the device.
+ * sfm_flow_starts replaces the per-batch start arithmetic (flow_field.py:
+ * 620-680): post start = grid position * step; pre start = post start -
+ * (patch - post_patch) / 2 clipped at 0; optional integer shifts looked up in
+ * the targeting fields (nearest cell, nan_to_num, truncation) and kept inside
+ * the images; final clip at 0.  sfm_flow_scatter replaces the per-patch result
+ * scatter (:701-709), undoing the targeting shifts.
+ * All shapes / steps are [z]yx padded to 3 entries in front.
+ * ---------------------------------------------------------------------- */
+typedef struct SfmFlowStartsDesc {
+  int32_t ndim;
+  int32_t n;                    /* patches (rows of `positions`)             */
+  int32_t step[3];
+  int32_t patch[3];
+  int32_t post_patch[3];
+  int32_t pre_shape[3];         /* image shapes                              */
+  int32_t post_shape[3];
+  const int32_t* positions;     /* device [n, ndim] grid positions, [z]yx    */
+  const float* pre_targeting_field;   /* device [ndim, *shape] (x, y[, z]) or NULL */
+  const float* post_targeting_field;
+  int32_t pre_targeting_shape[3];
+  int32_t post_targeting_shape[3];
+  int32_t pre_targeting_step[3];
+  int32_t post_targeting_step[3];
+  int32_t* pre_starts;          /* out, device [n, ndim]                     */
+  int32_t* post_starts;
+  int32_t* pre_offsets;         /* out, device [n, ndim]; required with the  */
+  int32_t* post_offsets;        /* corresponding targeting field             */
+  void* stream;
+} SfmFlowStartsDesc;
+
+int sfm_flow_starts(const SfmFlowStartsDesc* desc);
+
+typedef struct SfmFlowScatterDesc {
+  int32_t ndim;
+  int32_t n;
+  int32_t grid[3];              /* output grid, [z]yx                        */
+  const float* peaks;           /* device [n, ndim + 2]                      */
+  const int32_t* positions;     /* device [n, ndim]                          */
+  const int32_t* pre_offsets;   /* device [n, ndim] or NULL                  */
+  const int32_t* post_offsets;
+  float* out;                   /* device [ndim + 2, *grid], pre-filled (NaN) */
+  void* stream;
+} SfmFlowScatterDesc;
+
+int sfm_flow_scatter(const SfmFlowScatterDesc* desc);
+
 /* Stand-alone peak statistics, replaces _batched_peaks (flow_field.py:205-275)
  * for a caller-provided batch of surfaces. */
 typedef struct SfmPeaksDesc {

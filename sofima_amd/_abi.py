@@ -129,6 +129,44 @@ class SfmMaskIrregularDesc(C.Structure):
   ]
 
 
+class SfmFlowStartsDesc(C.Structure):
+  _fields_ = [
+      ('ndim', i32),
+      ('n', i32),
+      ('step', i32 * 3),
+      ('patch', i32 * 3),
+      ('post_patch', i32 * 3),
+      ('pre_shape', i32 * 3),
+      ('post_shape', i32 * 3),
+      ('positions', C.c_void_p),
+      ('pre_targeting_field', C.c_void_p),
+      ('post_targeting_field', C.c_void_p),
+      ('pre_targeting_shape', i32 * 3),
+      ('post_targeting_shape', i32 * 3),
+      ('pre_targeting_step', i32 * 3),
+      ('post_targeting_step', i32 * 3),
+      ('pre_starts', C.c_void_p),
+      ('post_starts', C.c_void_p),
+      ('pre_offsets', C.c_void_p),
+      ('post_offsets', C.c_void_p),
+      ('stream', C.c_void_p),
+  ]
+
+
+class SfmFlowScatterDesc(C.Structure):
+  _fields_ = [
+      ('ndim', i32),
+      ('n', i32),
+      ('grid', i32 * 3),
+      ('peaks', C.c_void_p),
+      ('positions', C.c_void_p),
+      ('pre_offsets', C.c_void_p),
+      ('post_offsets', C.c_void_p),
+      ('out', C.c_void_p),
+      ('stream', C.c_void_p),
+  ]
+
+
 class SfmWarpDesc(C.Structure):
   _fields_ = [
       ('dtype', i32),
@@ -272,6 +310,8 @@ SIGNATURES = {
     'sfm_clean_flow': (C.c_int, [C.POINTER(SfmCleanFlowDesc), C.c_void_p]),
     'sfm_mask_irregular': (C.c_int, [C.POINTER(SfmMaskIrregularDesc), C.c_void_p,
                                      C.c_void_p]),
+    'sfm_flow_starts': (C.c_int, [C.POINTER(SfmFlowStartsDesc)]),
+    'sfm_flow_scatter': (C.c_int, [C.POINTER(SfmFlowScatterDesc)]),
     'sfm_warp_section': (C.c_int, [C.POINTER(SfmWarpDesc)]),
     'sfm_range_mask': (C.c_int, [C.POINTER(SfmRangeMaskDesc), C.c_void_p]),
     'sfm_target_mesh': (C.c_int, [C.POINTER(SfmTargetMeshDesc), C.c_void_p,

@@ -5,6 +5,9 @@
 //   sfm_mask_irregular  <->  map_utils.mask_irregular (map_utils.py:737-786)
 //   sfm_range_mask      <->  the dynamic-range mask of stitch_rigid._estimate_offset
 //                            (stitch_rigid.py:47-60)
+//   sfm_flow_starts     <->  the start-coordinate / targeting arithmetic of
+//                            flow_field() (flow_field.py:620-680)
+//   sfm_flow_scatter    <->  the result scatter of flow_field() (:701-709)
 //
 // One thread per vector.  The field is small (one vector per patch), so the
 // point of the kernel is that the flow can stay in HBM from the correlation
@@ -242,6 +245,181 @@ extern "C" int sfm_range_mask(const SfmRangeMaskDesc* d, uint8_t* out) {
                        d->range_limit);
   else
     return sfm::fail(SFM_ERR_INVALID, "range_mask: dtype %d", d->dtype);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Host loop of JAXMaskedXCorrWithStatsCalculator.flow_field on the device.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct StartsArgs {
+  const int* pos;       // [n, nd] grid positions, [z]yx
+  int n, nd;
+  int step[3], patch[3], post_patch[3], pre_shape[3], post_shape[3];
+  const float* tf[2];   // targeting fields [nd, *tshape] (xy[z] components) or NULL
+  int tshape[2][3];
+  int tstep[2][3];
+  int* pre_starts;      // [n, nd]
+  int* post_starts;
+  int* tg[2];           // [n, nd] offsets applied to the pre / post starts ([z]yx)
+};
+
+// np.round (half to even) of a double
+__device__ __forceinline__ long long round_even(double v) {
+  return static_cast<long long>(rint(v));
+}
+
+// Integer patch shift from a targeting field, kept inside the image
+// (flow_field.py:626-649 / :652-677).  `starts` is [z]yx.
+__device__ void target_offset(const StartsArgs& a, int side, const int* starts,
+                              const int* psize, const int* img_shape, int* off) {
+  int q[3];
+  long long cell = 0;
+  long long plane = 1;
+  for (int i = 0; i < a.nd; ++i) plane *= a.tshape[side][i];
+  for (int i = 0; i < a.nd; ++i) {
+    const double c = static_cast<double>(starts[i] + psize[i] / 2) /
+                     static_cast<double>(a.tstep[side][i]);
+    long long v = round_even(c);
+    v = v < 0 ? 0 : (v > a.tshape[side][i] - 1 ? a.tshape[side][i] - 1 : v);
+    q[i] = static_cast<int>(v);
+    cell = cell * a.tshape[side][i] + q[i];
+  }
+  for (int i = 0; i < a.nd; ++i) {
+    // field component for image axis i: components are x, y[, z] = reversed axes
+    float f = a.tf[side][(long long)(a.nd - 1 - i) * plane + cell];
+    if (isnan(f)) f = 0.f;
+    if (isinf(f)) f = f > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+    // .astype(int): truncation; out-of-range values are INT64_MIN in NumPy --
+    // fields hold pixel offsets, far inside the int range
+    int o = static_cast<int>(f);
+    const int ns = starts[i] + o;
+    o = o - (ns < 0 ? ns : 0);
+    const int hi = ns + psize[i];
+    const int over = (hi > img_shape[i] ? hi : img_shape[i]) - img_shape[i];
+    off[i] = o - over;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) flow_starts_kernel(StartsArgs a) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= a.n) return;
+  int post[3], pre[3], off[3];
+  for (int i = 0; i < a.nd; ++i) {
+    post[i] = a.pos[b * a.nd + i] * a.step[i];
+    const int p = post[i] - (a.patch[i] - a.post_patch[i]) / 2;
+    pre[i] = p < 0 ? 0 : p;
+  }
+  if (a.tf[0]) {
+    target_offset(a, 0, pre, a.patch, a.pre_shape, off);
+    for (int i = 0; i < a.nd; ++i) {
+      pre[i] += off[i];
+      a.tg[0][b * a.nd + i] = off[i];
+    }
+  }
+  if (a.tf[1]) {
+    target_offset(a, 1, post, a.post_patch, a.post_shape, off);
+    for (int i = 0; i < a.nd; ++i) {
+      post[i] += off[i];
+      a.tg[1][b * a.nd + i] = off[i];
+    }
+  }
+  for (int i = 0; i < a.nd; ++i) {
+    a.pre_starts[b * a.nd + i] = pre[i] < 0 ? 0 : pre[i];
+    a.post_starts[b * a.nd + i] = post[i] < 0 ? 0 : post[i];
+  }
+}
+
+struct ScatterArgs {
+  const float* peaks;   // [n, nd + 2]
+  const int* pos;       // [n, nd]
+  const int* tg[2];     // or NULL
+  float* out;           // [nd + 2, *grid], NaN filled by the caller
+  int n, nd;
+  int grid[3];
+};
+
+__global__ void __launch_bounds__(kBlock) flow_scatter_kernel(ScatterArgs a) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= a.n) return;
+  long long cell = 0, cells = 1;
+  for (int i = 0; i < a.nd; ++i) {
+    cell = cell * a.grid[i] + a.pos[b * a.nd + i];
+    cells *= a.grid[i];
+  }
+  for (int c = 0; c < a.nd + 2; ++c) {
+    float v = a.peaks[b * (a.nd + 2) + c];
+    if (c < a.nd) {  // vector component c <-> image axis nd - 1 - c
+      if (a.tg[0]) v = v + static_cast<float>(a.tg[0][b * a.nd + a.nd - 1 - c]);
+      if (a.tg[1]) v = v - static_cast<float>(a.tg[1][b * a.nd + a.nd - 1 - c]);
+    }
+    a.out[c * cells + cell] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int sfm_flow_starts(const SfmFlowStartsDesc* d) {
+  if (!d || !d->positions || !d->pre_starts || !d->post_starts)
+    return sfm::fail(SFM_ERR_INVALID, "flow_starts: NULL argument");
+  if (d->ndim != 2 && d->ndim != 3) return sfm::fail(SFM_ERR_INVALID, "flow_starts: ndim");
+  if (d->n < 0) return sfm::fail(SFM_ERR_INVALID, "flow_starts: n");
+  if (d->n == 0) return SFM_OK;
+  StartsArgs a;
+  a.pos = d->positions;
+  a.n = d->n;
+  a.nd = d->ndim;
+  const int o = 3 - d->ndim;  // descriptors pad [z]yx to 3 entries in front
+  for (int i = 0; i < d->ndim; ++i) {
+    a.step[i] = d->step[o + i];
+    a.patch[i] = d->patch[o + i];
+    a.post_patch[i] = d->post_patch[o + i];
+    a.pre_shape[i] = d->pre_shape[o + i];
+    a.post_shape[i] = d->post_shape[o + i];
+    if (a.step[i] < 1) return sfm::fail(SFM_ERR_INVALID, "flow_starts: step");
+  }
+  const float* tf[2] = {d->pre_targeting_field, d->post_targeting_field};
+  const int32_t* tsh[2] = {d->pre_targeting_shape, d->post_targeting_shape};
+  const int32_t* tst[2] = {d->pre_targeting_step, d->post_targeting_step};
+  int* tg[2] = {d->pre_offsets, d->post_offsets};
+  for (int s2 = 0; s2 < 2; ++s2) {
+    a.tf[s2] = tf[s2];
+    a.tg[s2] = tg[s2];
+    if (tf[s2] && !tg[s2])
+      return sfm::fail(SFM_ERR_INVALID, "flow_starts: offsets buffer missing");
+    for (int i = 0; i < d->ndim; ++i) {
+      a.tshape[s2][i] = tsh[s2][o + i];
+      a.tstep[s2][i] = tst[s2][o + i];
+      if (tf[s2] && (a.tshape[s2][i] < 1 || a.tstep[s2][i] < 1))
+        return sfm::fail(SFM_ERR_INVALID, "flow_starts: targeting shape / step");
+    }
+  }
+  a.pre_starts = d->pre_starts;
+  a.post_starts = d->post_starts;
+  hipLaunchKernelGGL(flow_starts_kernel, dim3((d->n + kBlock - 1) / kBlock), dim3(kBlock),
+                     0, static_cast<hipStream_t>(d->stream), a);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+extern "C" int sfm_flow_scatter(const SfmFlowScatterDesc* d) {
+  if (!d || !d->peaks || !d->positions || !d->out)
+    return sfm::fail(SFM_ERR_INVALID, "flow_scatter: NULL argument");
+  if (d->ndim != 2 && d->ndim != 3) return sfm::fail(SFM_ERR_INVALID, "flow_scatter: ndim");
+  if (d->n <= 0) return d->n == 0 ? SFM_OK : sfm::fail(SFM_ERR_INVALID, "flow_scatter: n");
+  ScatterArgs a;
+  a.peaks = d->peaks;
+  a.pos = d->positions;
+  a.tg[0] = d->pre_offsets;
+  a.tg[1] = d->post_offsets;
+  a.out = d->out;
+  a.n = d->n;
+  a.nd = d->ndim;
+  for (int i = 0; i < d->ndim; ++i) a.grid[i] = d->grid[3 - d->ndim + i];
+  hipLaunchKernelGGL(flow_scatter_kernel, dim3((d->n + kBlock - 1) / kBlock), dim3(kBlock),
+                     0, static_cast<hipStream_t>(d->stream), a);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }

@@ -92,7 +92,7 @@ def _host_masked_counts(mask, patch_size, step):
   return _query_integral_image(_integral_image(mask), patch_size, step)
 
 
-def _masked_counts(mask, patch_size, step):
+def _masked_counts(mask, patch_size, step, on_device=False):
   """Number of masked pixels in every grid patch, [*(shape - patch)//step + 1].
 
   Device replacement for `_integral_image` + the summed-area-table query of
@@ -113,7 +113,7 @@ def _masked_counts(mask, patch_size, step):
           for s, p, t in zip(m.shape, patch_size, step)]
   out = torch.empty(grid, dtype=torch.int32, device=dev)
   _abi.check(_abi.load().sfm_mask_patch_counts(C.byref(d), out.data_ptr()))
-  return out.cpu().numpy()
+  return out if on_device else out.cpu().numpy()
 
 
 # ---------------------------------------------------------------------------
@@ -186,22 +186,15 @@ def _side_stream(dev) -> torch.cuda.Stream:
     return _SIDE_STREAMS[key]
 
 
-def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray,
-                 post_starts: np.ndarray, batch_size: int,
-                 progress_fn=None, starts_cache=None) -> np.ndarray:
-  """Enqueues every batch, returns peaks [n_batches * batch_size, dim + 2]."""
+def _run_batches_dev(res: _Resident, desc: _abi.SfmXcorrDesc, starts: torch.Tensor,
+                     batch_size: int, progress_fn=None) -> torch.Tensor:
+  """Enqueues every batch; `starts` is the device tensor [2, n, dim] of pre /
+  post start coordinates.  Returns the device peaks [n, dim + 2]."""
   lib = _abi.load()
   nd = res.ndim
-  n = pre_starts.shape[0]
+  n = starts.shape[1]
   assert n % batch_size == 0
   n_batches = n // batch_size
-  starts = None if starts_cache is None else starts_cache.get(res.dev)
-  if starts is None:
-    starts = torch.from_numpy(
-        np.ascontiguousarray(
-            np.stack([pre_starts, post_starts]).astype(np.int32))).to(res.dev)
-    if starts_cache is not None:
-      starts_cache[res.dev] = starts
   peaks = torch.empty((n, nd + 2), dtype=torch.float32, device=res.dev)
   # One C call carries several reference batches (`group` rows each keep the
   # batch-coupled behaviours): fewer, larger launches fill the chip even when
@@ -244,7 +237,22 @@ def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray
     main.wait_stream(stream)
     ws.record_stream(stream)
   desc.stream = main.cuda_stream
-  return peaks.cpu().numpy()
+  return peaks
+
+
+def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray,
+                 post_starts: np.ndarray, batch_size: int,
+                 progress_fn=None, starts_cache=None) -> np.ndarray:
+  """Host-array form: uploads the start coordinates (or reuses the cached
+  device copy) and returns peaks [n_batches * batch_size, dim + 2] on the host."""
+  starts = None if starts_cache is None else starts_cache.get(res.dev)
+  if starts is None:
+    starts = torch.from_numpy(
+        np.ascontiguousarray(
+            np.stack([pre_starts, post_starts]).astype(np.int32))).to(res.dev)
+    if starts_cache is not None:
+      starts_cache[res.dev] = starts
+  return _run_batches_dev(res, desc, starts, batch_size, progress_fn).cpu().numpy()
 
 
 # ---------------------------------------------------------------------------
@@ -484,11 +492,14 @@ class JAXMaskedXCorrWithStatsCalculator:
       post_targeting_field: np.ndarray | None = None,
       post_targeting_step: int | Sequence[int] | None = None,
       progress_fn: Callable[[list[T]], Iterator[T]] = _silent_fn,
+      device_output: bool = False,
   ):
     """Computes the flow field from post to pre (flow_field.py:474-712).
 
     Arguments and result are those of the reference method.  Images may also
     be torch CUDA tensors (uint8 or float32) that are already resident in HBM.
+    `device_output=True` (an extension) returns the field as a DeviceArray
+    that stays in HBM, e.g. for flow_utils.clean_flow / compose_maps_fast.
     """
     assert pre_image.ndim == post_image.ndim
     nd = pre_image.ndim
@@ -514,12 +525,17 @@ class JAXMaskedXCorrWithStatsCalculator:
     post_patch_size = tuple(int(p) for p in post_patch_size)
     step = tuple(int(s) for s in step)
 
-    # Section after section with the same geometry and no masks / selection /
-    # targeting (the production loop): the host-side plan is reused.
+    # The reference's host loop (selection, start coordinates, targeting
+    # lookups, scatter: flow_field.py:557-709) runs on the device; only the
+    # finished [dim + 2, *grid] field crosses PCIe (or nothing with
+    # device_output).  Section after section with the same geometry and no
+    # masks / selection / targeting (the production loop) reuses the device plan.
+    dev = _dev.device()
+    res = _Resident(pre_image, post_image, pre_mask, post_mask, dev)
     plain = (pre_mask is None and post_mask is None and selection_mask is None and
              pre_targeting_field is None and post_targeting_field is None)
     key = (tuple(pre_image.shape), tuple(post_image.shape), patch_size, step,
-           post_patch_size, int(batch_size))
+           post_patch_size, int(batch_size), str(dev))
     plan = None
     if plain:
       with self._plans_lock:
@@ -527,31 +543,115 @@ class JAXMaskedXCorrWithStatsCalculator:
         if plan is not None:
           self._plans.move_to_end(key)
     if plan is None:
-      plan = self.plan(tuple(pre_image.shape), tuple(post_image.shape),
-                       patch_size, step, pre_mask, post_mask, selection_mask,
-                       max_masked, batch_size, post_patch_size,
-                       pre_targeting_field, pre_targeting_step,
-                       post_targeting_field, post_targeting_step)
+      plan = self.device_plan(res, patch_size, step, selection_mask, max_masked,
+                              batch_size, post_patch_size, pre_targeting_field,
+                              pre_targeting_step, post_targeting_field,
+                              post_targeting_step)
       if plain:
         with self._plans_lock:
           plan = self._plans.setdefault(key, plan)
           while len(self._plans) > 8:
-            # the evicted plan's cached device start coordinates go with it
-            self._plans.popitem(last=False)
-    pos = plan['positions']
-    n = pos.shape[0]
-    if n == 0:
-      return self.assemble(plan, nd, np.zeros((0, nd + 2), np.float32))
+            self._plans.popitem(last=False)   # its device tensors go with it
+    out_shape = plan['out_shape']
+    out = torch.full([nd + 2] + list(out_shape), float('nan'), dtype=torch.float32,
+                     device=dev)
+    n = plan['n']
+    if n > 0:
+      if mask_only_for_patch_selection:
+        res.pre_mask = res.post_mask = None
+      desc = _make_desc(res, patch_size, post_patch_size, self._mean,
+                        self._min_distance, 0.5, self._peak_radius, self._method)
+      # progress_fn receives the per-batch grid positions like the reference's
+      # (flow_field.py:610) and is only iterated for its side effects.
+      progress = None
+      if progress_fn is not _silent_fn:
+        pos_h = plan['positions'][:n].cpu().numpy()
+        progress = progress_fn([pos_h[i:i + batch_size]
+                                for i in range(0, n, batch_size)])
+      peaks = _run_batches_dev(res, desc, plan['starts'], batch_size, progress)
+      sd = _abi.SfmFlowScatterDesc()
+      sd.ndim = nd
+      sd.n = n
+      sd.grid = _i3(_pad3(out_shape, 1))
+      sd.peaks = peaks.data_ptr()
+      sd.positions = plan['positions'].data_ptr()
+      if plan['tg'] is not None:
+        sd.pre_offsets = plan['tg'].data_ptr()
+      if plan['po'] is not None:
+        sd.post_offsets = plan['po'].data_ptr()
+      sd.out = out.data_ptr()
+      sd.stream = _dev.stream_ptr()
+      _abi.check(_abi.load().sfm_flow_scatter(C.byref(sd)))
+    if device_output:
+      return _dev.DeviceArray(out)
+    return out.cpu().numpy()
 
-    if mask_only_for_patch_selection:
-      pre_mask = post_mask = None
-    # progress_fn receives the list of per-batch grid positions like the
-    # reference's (flow_field.py:610) and is only iterated for its side effects.
-    batches = [pos[i:i + batch_size] for i in range(0, n, batch_size)]
-    peaks = self.compute_batches(pre_image, post_image, pre_mask, post_mask,
-                                 patch_size, post_patch_size, plan, batch_size,
-                                 None, progress_fn(batches))
-    return self.assemble(plan, nd, peaks)
+  def device_plan(self, res: _Resident, patch_size, step, selection_mask=None,
+                  max_masked=0.75, batch_size=4096, post_patch_size=None,
+                  pre_targeting_field=None, pre_targeting_step=None,
+                  post_targeting_field=None, post_targeting_step=None) -> dict:
+    """What `plan()` decides, computed and kept on the device: selected grid
+    positions (row-major), edge-padded to whole batches, the pre / post start
+    coordinates [2, n_padded, dim] and the targeting offsets."""
+    dev = res.dev
+    nd = res.ndim
+    pre_shape, post_shape = tuple(res.pre.shape), tuple(res.post.shape)
+    out_shape = [int(v) for v in
+                 (np.array(post_shape) - (np.array(post_patch_size) - step)) // step]
+    out_sel = tuple(slice(0, s) for s in out_shape)
+    if selection_mask is None:
+      sel = torch.ones(out_shape, dtype=torch.bool, device=dev)
+    else:
+      sel = _dev.as_device_mask(np.asarray(selection_mask)[out_sel], dev).bool().clone()
+    for mask, psz in ((res.pre_mask, patch_size), (res.post_mask, post_patch_size)):
+      if mask is None:
+        continue
+      counts = _masked_counts(mask, psz, step, on_device=True)
+      m = (counts.double() / float(np.prod(psz)) >= max_masked)[out_sel]
+      sel[m] = False
+    pos = torch.nonzero(sel).to(torch.int32)          # row-major, like np.where
+    n = int(pos.shape[0])
+    n_batches = (n + batch_size - 1) // batch_size
+    pad = n_batches * batch_size - n
+    if pad and n:
+      # every batch is padded to `batch_size` by repeating the LAST position
+      # (flow_field.py:614-618): batch-coupled results do not change
+      pos = torch.cat([pos, pos[-1:].expand(pad, nd)])
+    pos = pos.contiguous()
+    plan = dict(out_shape=out_shape, n=n, n_batches=n_batches, positions=pos,
+                starts=None, tg=None, po=None)
+    if n == 0:
+      return plan
+    total = int(pos.shape[0])
+    starts = torch.empty((2, total, nd), dtype=torch.int32, device=dev)
+    d = _abi.SfmFlowStartsDesc()
+    d.ndim = nd
+    d.n = total
+    d.step = _i3(_pad3(step, 1))
+    d.patch = _i3(_pad3(patch_size, 1))
+    d.post_patch = _i3(_pad3(post_patch_size, 1))
+    d.pre_shape = _i3(_pad3(pre_shape, 1))
+    d.post_shape = _i3(_pad3(post_shape, 1))
+    d.positions = pos.data_ptr()
+    keep = []
+    for side, field, tstep in (('pre', pre_targeting_field, pre_targeting_step),
+                               ('post', post_targeting_field, post_targeting_step)):
+      if field is None or tstep is None:
+        continue
+      f = _dev.as_device_f32(field, dev, copy=False)
+      offs = torch.empty((total, nd), dtype=torch.int32, device=dev)
+      keep += [f, offs]
+      setattr(d, side + '_targeting_field', f.data_ptr())
+      setattr(d, side + '_targeting_shape', _i3(_pad3(f.shape[1:], 1)))
+      setattr(d, side + '_targeting_step', _i3(_pad3(tstep, 1)))
+      setattr(d, side + '_offsets', offs.data_ptr())
+      plan['tg' if side == 'pre' else 'po'] = offs
+    d.pre_starts = starts[0].data_ptr()
+    d.post_starts = starts[1].data_ptr()
+    d.stream = _dev.stream_ptr()
+    _abi.check(_abi.load().sfm_flow_starts(C.byref(d)))
+    plan['starts'] = starts
+    return plan
 
   # -- pieces shared with sofima_amd.dist ---------------------------------------
   def compute_batches(self, pre_image, post_image, pre_mask, post_mask,

@@ -61,6 +61,8 @@ def test_struct_layouts_match_header():
                      ('SfmMaskIrregularDesc', _abi.SfmMaskIrregularDesc),
                      ('SfmRangeMaskDesc', _abi.SfmRangeMaskDesc),
                      ('SfmWarpDesc', _abi.SfmWarpDesc),
+                     ('SfmFlowStartsDesc', _abi.SfmFlowStartsDesc),
+                     ('SfmFlowScatterDesc', _abi.SfmFlowScatterDesc),
                      ('SfmMeshShard', _abi.SfmMeshShard),
                      ('SfmTargetMeshDesc', _abi.SfmTargetMeshDesc)):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,

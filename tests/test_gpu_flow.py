@@ -660,3 +660,74 @@ def test_masked_paths_random_geometry_fuzz(gpu, seed):
     bad = ~np.isclose(got, ref, atol=atol, rtol=0)
     assert bad.mean() < 2e-3, (method, py, px, qy, qx, bad.mean(),
                                np.abs(got - ref)[bad].max() if bad.any() else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nd', [2, 3])
+def test_device_plan_equals_host_plan(gpu, nd):
+  """sfm_flow_starts (start coordinates, targeting lookups, clamping) and the
+  device-side selection == the host planning of flow_field.py:557-680."""
+  from sofima_amd import flow_field as ff
+  rng = np.random.default_rng(40 + nd)
+  for trial in range(6):
+    shape = tuple(int(v) for v in rng.integers(60, 110, nd))
+    if nd == 3:
+      shape = (int(rng.integers(20, 30)),) + shape[1:]
+    patch = tuple(int(v) for v in rng.integers(8, 20, nd))
+    post_patch = patch if trial % 2 else tuple(max(4, p - int(rng.integers(0, 6)))
+                                               for p in patch)
+    step = tuple(int(v) for v in rng.integers(3, 9, nd))
+    pre = rng.integers(0, 256, shape).astype(np.uint8)
+    post = rng.integers(0, 256, shape).astype(np.uint8)
+    kw = {}
+    if trial >= 2:
+      kw['pre_mask'] = rng.random(shape) < 0.5
+      kw['post_mask'] = rng.random(tuple(s + 3 for s in shape)) < 0.3
+      kw['max_masked'] = 0.45
+    if trial >= 3:
+      tsh = tuple(int(v) for v in rng.integers(3, 7, nd))
+      f = (rng.standard_normal((nd,) + tsh) * 25).astype(np.float32)
+      f[:, tuple(0 for _ in tsh)] = np.nan
+      kw['pre_targeting_field'], kw['pre_targeting_step'] = f, tuple(
+          int(v) for v in rng.integers(10, 30, nd))
+      kw['post_targeting_field'] = (rng.standard_normal((nd,) + tsh) * 25).astype(np.float32)
+      kw['post_targeting_step'] = tuple(int(v) for v in rng.integers(10, 30, nd))
+    if trial == 5:
+      out_shape = (np.array(shape) - (np.array(post_patch) - step)) // step
+      kw['selection_mask'] = rng.random(tuple(out_shape + 2)) < 0.7
+    calc = ff.JAXMaskedXCorrWithStatsCalculator()
+    host = calc.plan(shape, shape, patch, step, batch_size=7, post_patch_size=post_patch,
+                     **kw)
+    res = ff._Resident(pre, post, kw.get('pre_mask'), kw.get('post_mask'), gpu)
+    dev = calc.device_plan(res, patch, step, kw.get('selection_mask'),
+                           kw.get('max_masked', 0.75), 7, post_patch,
+                           kw.get('pre_targeting_field'), kw.get('pre_targeting_step'),
+                           kw.get('post_targeting_field'), kw.get('post_targeting_step'))
+    n = dev['n']
+    assert n == host['positions'].shape[0] and n > 0
+    np.testing.assert_array_equal(dev['out_shape'], host['out_shape'])
+    np.testing.assert_array_equal(dev['positions'][:n].cpu().numpy(), host['positions'])
+    st = dev['starts'].cpu().numpy()
+    np.testing.assert_array_equal(st[0], host['pre_starts'])
+    np.testing.assert_array_equal(st[1], host['post_starts'])
+    for dk, hk in (('tg', 'tg_offsets'), ('po', 'post_offsets')):
+      assert (dev[dk] is None) == (host[hk] is None)
+      if dev[dk] is not None:
+        np.testing.assert_array_equal(dev[dk].cpu().numpy(), host[hk])
+
+
+@pytest.mark.gpu
+def test_flow_stays_on_device_through_clean_flow(gpu, golden):
+  """flow_field(device_output=True) -> clean_flow without a host round trip ==
+  the host path (and the reference's clean_flow on the golden flow)."""
+  from oracle import flow_utils_oracle
+  from sofima_amd import _dev, flow_field, flow_utils
+  g = golden('flow2d')
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  host = calc.flow_field(g['pre'], g['post'], 48, 24, batch_size=8)
+  devf = calc.flow_field(g['pre'], g['post'], 48, 24, batch_size=8, device_output=True)
+  assert isinstance(devf, _dev.DeviceArray)
+  np.testing.assert_array_equal(np.asarray(devf), host)
+  cleaned = flow_utils.clean_flow(devf.tensor[:, None], 1.4, 1.4, 0, 5)
+  want = flow_utils_oracle.clean_flow(host[:, None], 1.4, 1.4, 0, 5)
+  np.testing.assert_array_equal(np.asarray(cleaned), want)
