@@ -801,6 +801,228 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-tiled fused step for volumetric meshes (elastic_mesh_3d with the 13
+// default links).  The multi-launch path re-reads 78 neighbour values per node
+// through L1 / L2 (26 springs x 3 components) and needs two launches per step;
+// here one workgroup owns a TZ x TY x TX brick, loads (x, v, a) of the brick
+// and of its one-node shell once, applies the position update to all of them
+// (the shell's update is recomputed from the neighbours' state, like
+// integrate_tiled2d_kernel<.., FUSED>), keeps the advanced positions in LDS for
+// the 26-neighbour stencil and writes x, v, a of its own nodes to the second
+// buffer set: the whole FIRE / Verlet step is ONE launch.
+// ---------------------------------------------------------------------------
+constexpr int kTZ3 = 8, kTY3 = 8, kTX3 = 16;
+
+__global__ void __launch_bounds__(kBlock)
+integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in,
+                         const float* __restrict__ prev, float* x_out, float* v_out,
+                         float* a_out, MeshParams p, const Scalars* __restrict__ scal_in,
+                         Scalars* __restrict__ scal_out, float fixed_cap,
+                         u64* __restrict__ partials, int* __restrict__ ticket, int pending,
+                         int ntz, int nty, int ntx) {
+  constexpr int C = 3;
+  constexpr int PZ = kTZ3 + 2, PY = kTY3 + 2, PX = kTX3 + 2;
+  constexpr int kCells = PZ * PY * PX;
+  constexpr int kOwn = kTZ3 * kTY3 * kTX3 / kBlock;  // nodes per thread
+  static_assert(kTZ3 * kTY3 * kTX3 % kBlock == 0, "brick shape");
+  __shared__ float xt[C][kCells];
+  __shared__ float lds[kNP * kBlock];
+  __shared__ int s_last;
+  const unsigned epoch = static_cast<unsigned>(ticket[1]) + 1u;
+
+  Scalars s;
+  if (p.fire) {
+    s = *scal_in;
+    if (!pending) {
+      s.gate = 1.f;
+      for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+    }
+  } else {
+    s.dt = p.vv_dt;
+    s.alpha = 0.f;
+    s.cap = fixed_cap;
+    s.gate = 1.f;
+    for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+  }
+  const float dt = s.dt, alpha = s.alpha, cap = s.cap;
+  const float c2 = 0.5f * (dt * dt);
+  const bool fix = p.fire && pending;
+
+  int t = blockIdx.x;
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  t /= nty;
+  const int tz = t % ntz;
+  const long long batch = t / ntz;
+  const long long vol = (long long)p.Z * p.Y * p.X;
+  const long long base = batch * vol;
+  const int gx0 = tx * kTX3, gy0 = ty * kTY3, gz0 = tz * kTZ3;
+
+  auto advanced = [&](long long n, int c, float* v_keep, float* a_keep) -> float {
+    float xv = x_in[c * p.N + n];
+    float vv = v_in[c * p.N + n];
+    const float aa = a_in[c * p.N + n];
+    if (fix) {
+      vv = vv * s.gate;
+      if (p.remove_drift) {
+        xv = xv - s.mx[c];
+        vv = vv - s.mv[c];
+      }
+    }
+    if (v_keep) *v_keep = vv;
+    if (a_keep) *a_keep = aa;
+    return xv + (dt * vv + c2 * aa);
+  };
+
+  // own nodes: thread t owns brick cells t, t + 256, ... (x fastest)
+  float x_own[kOwn][C], v_own[kOwn][C], a_own[kOwn][C];
+  bool live[kOwn];
+  long long n_own[kOwn];
+  int ctr[kOwn];
+#pragma unroll
+  for (int k = 0; k < kOwn; ++k) {
+    const int cell = threadIdx.x + k * kBlock;
+    const int lx = cell % kTX3, ly = (cell / kTX3) % kTY3, lz = cell / (kTX3 * kTY3);
+    const int gx = gx0 + lx, gy = gy0 + ly, gz = gz0 + lz;
+    live[k] = gx < p.X && gy < p.Y && gz < p.Z;
+    ctr[k] = ((lz + 1) * PY + ly + 1) * PX + lx + 1;
+    n_own[k] = base + ((long long)gz * p.Y + gy) * p.X + gx;
+    if (live[k]) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        x_own[k][c] = advanced(n_own[k], c, &v_own[k][c], &a_own[k][c]);
+        xt[c][ctr[k]] = x_own[k][c];
+      }
+    }
+  }
+  // shell cells
+  for (int cell = threadIdx.x; cell < kCells; cell += kBlock) {
+    const int hx = cell % PX, hy = (cell / PX) % PY, hz = cell / (PX * PY);
+    const bool inner = hx >= 1 && hx <= kTX3 && hy >= 1 && hy <= kTY3 && hz >= 1 &&
+                       hz <= kTZ3;
+    if (inner) continue;
+    const int gx = gx0 + hx - 1, gy = gy0 + hy - 1, gz = gz0 + hz - 1;
+    if (gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
+      const long long n = base + ((long long)gz * p.Y + gy) * p.X + gx;
+#pragma unroll
+      for (int c = 0; c < C; ++c) xt[c][cell] = advanced(n, c, nullptr, nullptr);
+    }
+  }
+  __syncthreads();
+
+  const float hdtg = (0.5f * dt) * p.gamma;
+  const float fact0 = 1.0f / (1.0f + hdtg);
+  const float fact1 = 1.0f - hdtg;
+  const float hdt = 0.5f * dt;
+  float part[kNP];
+  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < kOwn; ++k) {
+    if (!live[k]) continue;
+    const int cell = threadIdx.x + k * kBlock;
+    const int lx = cell % kTX3, ly = (cell / kTX3) % kTY3, lz = cell / (kTX3 * kTY3);
+    const int xi = gx0 + lx, yi = gy0 + ly, zi = gz0 + lz;
+    const float* self = x_own[k];
+    float acc[3] = {0.f, 0.f, 0.f};
+    // same per-link order and branch-free form as node_force_default3d: a
+    // spring whose other end is outside the mesh is evaluated against the
+    // node itself (d = rest: force exactly +-0)
+#define SFM_LINK(L, DX, DY, DZ)                                                      \
+    {                                                                                \
+      const float l0 = vec_len(p.rest[L], 3);                                        \
+      const bool okf = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&        \
+                       yi - (DY) < p.Y && zi - (DZ) >= 0 && zi - (DZ) < p.Z;          \
+      const bool okn = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&        \
+                       yi + (DY) < p.Y && zi + (DZ) >= 0 && zi + (DZ) < p.Z;          \
+      constexpr int off = (DX) + (DY) * PX + (DZ) * PX * PY;                         \
+      const int mf = okf ? ctr[k] - off : ctr[k], mn = okn ? ctr[k] + off : ctr[k];  \
+      float df[3], dn[3], ff[3], fn[3];                                              \
+      _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                \
+        df[c] = self[c] - xt[c][mf] + p.rest[L][c];                                  \
+        dn[c] = xt[c][mn] - self[c] + p.rest[L][c];                                  \
+      }                                                                              \
+      spring_xyz<DX, DY, DZ>(df, l0, p.neg_k[L], p.prefer, ff);                      \
+      spring_xyz<DX, DY, DZ>(dn, l0, p.neg_k[L], p.prefer, fn);                      \
+      _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                \
+        acc[c] = acc[c] + (okf ? ff[c] : 0.f);                                       \
+        acc[c] = acc[c] - (okn ? fn[c] : 0.f);                                       \
+      }                                                                              \
+    }
+    SFM_LINK(0, 1, 0, 0) SFM_LINK(1, 0, 1, 0) SFM_LINK(2, 0, 0, 1) SFM_LINK(3, 1, 1, 0)
+    SFM_LINK(4, -1, 1, 0) SFM_LINK(5, 1, 0, 1) SFM_LINK(6, -1, 0, 1) SFM_LINK(7, 0, 1, 1)
+    SFM_LINK(8, 0, -1, 1) SFM_LINK(9, 1, 1, 1) SFM_LINK(10, 1, 1, -1)
+    SFM_LINK(11, 1, -1, 1) SFM_LINK(12, -1, 1, 1)
+#undef SFM_LINK
+    const long long n = n_own[k];
+    float f[C], vn[C];
+    float a2 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float xv = self[c];
+      f[c] = acc[c];
+      if (p.has_prev) f[c] = f[c] + prev_pull(xv, prev[c * p.N + n], p.neg_k0, cap);
+      vn[c] = fact0 * (v_own[k][c] * fact1 + hdt * (a_own[k][c] + f[c]));
+      a_out[c * p.N + n] = f[c];
+      x_out[c * p.N + n] = xv;
+      a2 = a2 + f[c] * f[c];
+      v2 = v2 + vn[c] * vn[c];
+      if (p.fire) {
+        part[0] = part[0] + f[c] * vn[c];
+        part[1 + c] = part[1 + c] + xv;
+      }
+    }
+    if (p.fire) {
+      const float a_norm = sqrtf(a2) + 1e-6f;
+      const float v_norm = sqrtf(v2);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
+        part[4 + c] = part[4 + c] + vn[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) v_out[c * p.N + n] = vn[c];
+  }
+  if (!p.fire) return;
+  // per-brick partial sums -> {epoch, value} granules; the last workgroup to
+  // arrive reduces them in brick order (see integrate_tiled2d_kernel)
+  block_sum(part, 7, lds);
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 7; ++i)
+      __hip_atomic_store(&partials[blockIdx.x * kNP + i],
+                         (static_cast<u64>(epoch) << 32) | __float_as_uint(part[i]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);
+    s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT) ==
+             static_cast<int>(gridDim.x) - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float acc[kNP];
+  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
+  for (int r = threadIdx.x; r < static_cast<int>(gridDim.x); r += kBlock)
+    for (int i = 0; i < 7; ++i) {
+      u64 gr = 0;
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        gr = __hip_atomic_load(&partials[r * kNP + i], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (static_cast<unsigned>(gr >> 32) == epoch) break;
+      }
+      acc[i] = acc[i] + __uint_as_float(static_cast<unsigned>(gr));
+    }
+  block_sum(acc, 7, lds);
+  if (threadIdx.x == 0) {
+    Scalars in = *scal_in, o;
+    scalars_from_sums(in, acc, p, &o);
+    *scal_out = o;
+    ticket[1] = static_cast<int>(epoch);
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Reference quirk Q3 (mesh.py:496-497): the drift means are taken over axes
 // (1, 2, 3); for a 5-D state [3, N, z, y, x] that is a mean per x COLUMN.
 // colsum[c][xi] = sum of x, colsum[3 + c][xi] = sum of v over the column, in a
@@ -1574,12 +1796,32 @@ struct MeshWorkspace {
 // Tile shape of the LDS-tiled 2-D integrator: 0 = not applicable, else TX.
 struct TilePlan {
   int tx = 0, ty = 0, nty = 0, ntx = 0;
+  int ntz = 0;  // > 0: the volumetric brick kernel (kTZ3 x kTY3 x kTX3)
   long long tiles = 0;
 };
 
 bool tiled_enabled() {
   const char* e = getenv("SFM_MESH_TILED");
   return !(e && e[0] == '0');
+}
+
+// Bricks of the volumetric fused step: default links, prev given or absent (no
+// prev_fn), global or no drift removal.
+TilePlan plan_bricks(const SfmMeshDesc* d) {
+  TilePlan t;
+  if (d->ncomp != 3 || !tiled_enabled() || d->n_links != 0 || d->target ||
+      d->remove_drift == 2 || d->force_kind != SFM_FORCE_SPRINGS)
+    return t;
+  const int Z = d->shape[1], Y = d->shape[2], X = d->shape[3];
+  if ((long long)Z * Y * X < 4096) return t;  // tiny volumes stay launch bound either way
+  t.tx = kTX3;
+  t.ty = kTY3;
+  t.ntz = (Z + kTZ3 - 1) / kTZ3;
+  t.nty = (Y + kTY3 - 1) / kTY3;
+  t.ntx = (X + kTX3 - 1) / kTX3;
+  t.tiles = (long long)d->shape[0] * t.ntz * t.nty * t.ntx;
+  if (t.tiles > 0x7fffffffLL / kNP) t = TilePlan();
+  return t;
 }
 
 TilePlan plan_tiles(int ncomp, long long planes, int Y, int X) {
@@ -1626,16 +1868,18 @@ MeshWorkspace carve(void* ws, size_t prev_floats, size_t alt_floats, long long t
 
 MeshWorkspace carve_for(const SfmMeshDesc* d, void* ws, TilePlan* plan) {
   const size_t n = (size_t)d->shape[0] * d->shape[1] * d->shape[2] * d->shape[3];
-  const TilePlan t = d->force_kind == SFM_FORCE_SPRINGS
-                         ? plan_tiles(d->ncomp, (long long)d->shape[0] * d->shape[1],
-                                      d->shape[2], d->shape[3])
-                         : TilePlan();
+  TilePlan t = d->force_kind == SFM_FORCE_SPRINGS
+                   ? plan_tiles(d->ncomp, (long long)d->shape[0] * d->shape[1],
+                                d->shape[2], d->shape[3])
+                   : TilePlan();
+  if (d->ncomp == 3) t = plan_bricks(d);
   if (plan) *plan = t;
   const size_t cn = (size_t)d->ncomp * n;
   // second (x, v, a) set: ping-pong of the fused tiled step, staging of the
   // persistent kernel's result
   return carve(ws, d->target ? cn : 0,
-               (d->ncomp == 2 && !d->target && d->force_kind == SFM_FORCE_SPRINGS) ? cn : 0,
+               ((d->ncomp == 2 && !d->target && d->force_kind == SFM_FORCE_SPRINGS) ||
+                t.ntz > 0) ? cn : 0,
                t.tiles,
                d->shape[3]);
 }
@@ -1843,7 +2087,19 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     SFM_LAUNCH_CHECK();                                                      \
   } while (0)
   auto step = [&](int pending) -> int {
-    if (fused) {
+    if (fused && tiles.ntz > 0) {
+      float** bi = bufs[in];
+      float** bo = bufs[in ^ 1];
+      if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
+      hipLaunchKernelGGL(integrate_tiled3d_kernel, dim3(tgrid), dim3(kBlock), 0, ls, bi[0],
+                         bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
+                         &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.ntz,
+                         tiles.nty, tiles.ntx);
+      if (timing) sfm::prof_end(sfm::kProfMesh, ls);
+      SFM_LAUNCH_CHECK();
+      in ^= 1;
+      if (p.fire) cur ^= 1;
+    } else if (fused) {
       float** bi = bufs[in];
       float** bo = bufs[in ^ 1];
       if (timing) sfm::prof_begin(sfm::kProfMesh, ls);

@@ -374,3 +374,44 @@ def test_three_pass_relaxation_driver_vs_oracle(gpu, case):
   scale = np.nanmax(np.abs(wx))
   np.testing.assert_allclose(np.nan_to_num(gx), np.nan_to_num(wx), atol=2e-3 * scale)
   np.testing.assert_allclose(ge, we, rtol=5e-2, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', ['fire', 'fire_drift', 'verlet', 'no_prev', 'order'])
+def test_brick_kernel_3d_agrees_with_multi_launch_and_oracle(gpu, variant):
+  """Volumetric meshes of >= 4096 nodes take the LDS-tiled fused step
+  (integrate_tiled3d_kernel, one launch per step): same chunk as the
+  multi-launch path and the oracle; odd extents exercise partial bricks."""
+  from scipy import ndimage
+  from sofima_amd import mesh
+  rng = np.random.default_rng(15)
+  shape = (3, 2, 9, 21, 35)
+  prev = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, 2, 3, 3)) * 30
+  prev = prev.astype(np.float32)
+  prev[:, 0, :2] = np.nan
+  prev[:, 1, 4:6, 8:12, 20:30] = np.nan
+  kw = dict(dt=0.001, gamma=0.0, k0=0.02, k=0.1, stride=(10.0, 12.0, 14.0), num_iters=30,
+            max_iters=30, stop_v_max=1e-9, dt_max=1000, start_cap=0.05, final_cap=10,
+            prefer_orig_order=variant == 'order')
+  if variant == 'verlet':
+    kw.update(fire=False, gamma=0.5, dt=0.05, start_cap=10.0, final_cap=10.0)
+  x0 = (rng.standard_normal(shape) * 0.5).astype(np.float32)
+  pv = None if variant == 'no_prev' else prev
+  if variant == 'fire_drift':
+    # global drift removal only exists for 4-D states [3, z, y, x]
+    shape4 = (3, 12, 21, 35)
+    x0 = x0.reshape((3, 18, 21, 35))[:, :12].copy()
+    pv = prev.reshape((3, 18, 21, 35))[:, :12].copy()
+    kw['remove_drift'] = True
+  cfg = mesh.IntegrationConfig(**kw)
+  run = lambda: mesh.relax_mesh(x0.copy(), None if pv is None else pv.copy(), cfg,
+                                mesh_force=mesh.elastic_mesh_3d)
+  a = run()
+  b = _with_env({'SFM_MESH_TILED': '0'}, run)
+  wx, we, wt = mesh_oracle.relax_mesh(x0.copy(), None if pv is None else pv.copy(), cfg,
+                                      mesh_force=mesh_oracle.elastic_mesh_3d)
+  assert a[2] == b[2] == wt == 30
+  scale = np.abs(wx).max()
+  np.testing.assert_allclose(np.array(a[0]), np.array(b[0]), atol=2e-4 * scale)
+  np.testing.assert_allclose(np.array(a[0]), wx, atol=1e-3 * scale)
+  np.testing.assert_allclose(a[1], we, rtol=1e-2)
