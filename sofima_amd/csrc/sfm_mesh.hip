@@ -1807,8 +1807,20 @@ bool tiled_enabled() {
 
 // Bricks of the volumetric fused step: default links, prev given or absent (no
 // prev_fn), global or no drift removal.
+// Measured on MI355X: SLOWER than the multi-launch pair (446 vs 357 us per step
+// on [3,4,100^3], 408 vs 375 on [3,1,64,256,256]): the volumetric step is bound
+// by the ~3000 IEEE-exact VALU operations per node (26 spring evaluations with
+// correctly rounded sqrt and division each), not by the neighbour re-reads the
+// bricks remove, and the shell recomputation adds to it.  Opt-in
+// (SFM_MESH_BRICKS=1), kept as the measured experiment.
+bool bricks_enabled() {
+  const char* e = getenv("SFM_MESH_BRICKS");
+  return e && e[0] == '1';
+}
+
 TilePlan plan_bricks(const SfmMeshDesc* d) {
   TilePlan t;
+  if (!bricks_enabled()) return t;
   if (d->ncomp != 3 || !tiled_enabled() || d->n_links != 0 || d->target ||
       d->remove_drift == 2 || d->force_kind != SFM_FORCE_SPRINGS)
     return t;

@@ -379,9 +379,10 @@ def test_three_pass_relaxation_driver_vs_oracle(gpu, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize('variant', ['fire', 'fire_drift', 'verlet', 'no_prev', 'order'])
 def test_brick_kernel_3d_agrees_with_multi_launch_and_oracle(gpu, variant):
-  """Volumetric meshes of >= 4096 nodes take the LDS-tiled fused step
-  (integrate_tiled3d_kernel, one launch per step): same chunk as the
-  multi-launch path and the oracle; odd extents exercise partial bricks."""
+  """The opt-in LDS-tiled fused step for volumetric meshes
+  (integrate_tiled3d_kernel, SFM_MESH_BRICKS=1; measured slower than the
+  multi-launch pair, see sfm_mesh.hip): same chunk as the multi-launch path and
+  the oracle; odd extents exercise partial bricks."""
   from scipy import ndimage
   from sofima_amd import mesh
   rng = np.random.default_rng(15)
@@ -406,8 +407,8 @@ def test_brick_kernel_3d_agrees_with_multi_launch_and_oracle(gpu, variant):
   cfg = mesh.IntegrationConfig(**kw)
   run = lambda: mesh.relax_mesh(x0.copy(), None if pv is None else pv.copy(), cfg,
                                 mesh_force=mesh.elastic_mesh_3d)
-  a = run()
-  b = _with_env({'SFM_MESH_TILED': '0'}, run)
+  a = _with_env({'SFM_MESH_BRICKS': '1'}, run)
+  b = run()
   wx, we, wt = mesh_oracle.relax_mesh(x0.copy(), None if pv is None else pv.copy(), cfg,
                                       mesh_force=mesh_oracle.elastic_mesh_3d)
   assert a[2] == b[2] == wt == 30
