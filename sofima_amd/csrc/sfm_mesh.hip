@@ -1629,6 +1629,357 @@ mesh_persist2d_kernel(MeshParams p, const float* __restrict__ xg,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Speculative FIRE variant of the persistent kernel (no drift removal).
+//
+// In mesh_persist2d_kernel every step waits for the partial `power` sums of ALL
+// workgroups before it can advance (FIRE's dt, alpha, cap and the velocity gate
+// of step k depend on the sign of power(k-1), mesh.py:455-492): a 169-way
+// all-gather on the critical path of every step, ~60 % of the step time.  But
+// power >= 0 (downhill) is by far the common case, and the update is a pure
+// function of (previous scalars, sign).  So this kernel
+//   1. publishes its halo and its partial of step k-1 and waits for the HALO
+//      of its 8 neighbours only (one-to-one hand-offs),
+//   2. runs step k with the scalars of the downhill branch,
+//   3. then collects the partials of step k-1 -- published a whole step ago --
+//      reduces them in the same fixed order as always, and
+//   4. if the power was negative after all, restores the state saved before
+//      the step and redoes it with the uphill scalars (dt *= f_dec, v = 0).
+// Every workgroup sees the same sums, takes the same decision and redoes the
+// same steps: the trajectory is bit-identical to the non-speculative kernel.
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(T * T)
+mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
+                           const float* __restrict__ vg, float* __restrict__ xo,
+                           float* __restrict__ vo, float* __restrict__ ao,
+                           const float* __restrict__ prevg, PersistArgs q) {
+  using TL = Tile<T>;
+  constexpr int NT = TL::kThreads;
+  constexpr int kPartPolls1 = (kMaxWg + NT - 1) / NT;  // one value per workgroup
+  __shared__ float xt[2][T + 2][T + 3];
+  __shared__ float hval[TL::kHalo][kNodeGran];
+  __shared__ float part_all[kMaxWg];
+  __shared__ float wred[TL::kWavesT];
+  __shared__ float s_power;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ly = tid / T, lx = tid % T;
+  const int wg = blockIdx.x;
+  const int tx_i = wg % q.ntx;
+  const int ty_i = (wg / q.ntx) % q.nty;
+  const int slice = wg / (q.ntx * q.nty);
+  const int yi = ty_i * T + ly, xi = tx_i * T + lx;
+  const bool active = yi < p.Y && xi < p.X;
+  const long long plane = (long long)p.Y * p.X;
+  const long long n = slice * plane + (long long)yi * p.X + xi;
+  const int pidx = perim_index<T>(ly, lx);
+
+  int hy = 0, hx = 0;
+  long long h_n = -1;
+  if (tid < TL::kHalo) {
+    halo_coord<T>(tid, &hy, &hx);
+    const int gy = ty_i * T + hy - 1, gx = tx_i * T + hx - 1;
+    if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X)
+      h_n = slice * plane + (long long)gy * p.X + gx;
+  }
+  long long h_off[TL::kHaloPolls];
+  float* h_dst[TL::kHaloPolls];
+#pragma unroll
+  for (int u = 0; u < TL::kHaloPolls; ++u) {
+    h_off[u] = -1;
+    h_dst[u] = nullptr;
+    const int t = tid + u * NT;
+    if (t < TL::kHalo * kNodeGran) {
+      const int h = t / kNodeGran, j = t - h * kNodeGran;
+      int qy, qx;
+      halo_coord<T>(h, &qy, &qx);
+      const int gy = ty_i * T + qy - 1, gx = tx_i * T + qx - 1;
+      if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X) {
+        const int oty = gy / T, otx = gx / T;
+        const int owg = (slice * q.nty + oty) * q.ntx + otx;
+        h_off[u] = (long long)owg * 2 * TL::kSlot +
+                   perim_index<T>(gy - oty * T, gx - otx * T) * kNodeGran + j;
+        h_dst[u] = &hval[h][j];
+      }
+    }
+  }
+
+  float x0 = 0.f, x1 = 0.f, v0 = 0.f, v1 = 0.f, a0 = 0.f, a1 = 0.f;
+  float pr0 = 0.f, pr1 = 0.f;
+  if (active) {
+    x0 = xg[n];
+    x1 = xg[p.N + n];
+    v0 = vg[n];
+    v1 = vg[p.N + n];
+    if (p.has_prev) {
+      pr0 = prevg[n];
+      pr1 = prevg[p.N + n];
+    }
+  }
+  Scalars s = *q.scal_in;
+  s.gate = 1.f;
+  float l0[4];
+#pragma unroll
+  for (int L = 0; L < 4; ++L) l0[L] = vec_len(p.rest[L], 2);
+
+  auto tile_force = [&](float* out) {
+    const float s0 = xt[0][ly + 1][lx + 1], s1 = xt[1][ly + 1][lx + 1];
+    float acc0 = 0.f, acc1 = 0.f;
+#define SFM_FAR(L, DX, DY)                                                          \
+    {                                                                               \
+      const bool ok = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&        \
+                      yi - (DY) < p.Y;                                              \
+      float f[2];                                                                   \
+      spring_xy<DX, DY>(s0 - xt[0][ly + 1 - (DY)][lx + 1 - (DX)] + p.rest[L][0],     \
+                        s1 - xt[1][ly + 1 - (DY)][lx + 1 - (DX)] + p.rest[L][1],     \
+                        l0[L], p.neg_k[L], p.prefer, f);                            \
+      acc0 = acc0 + (ok ? f[0] : 0.f);                                              \
+      acc1 = acc1 + (ok ? f[1] : 0.f);                                              \
+    }
+#define SFM_NEAR(L, DX, DY)                                                         \
+    {                                                                               \
+      const bool ok = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&        \
+                      yi + (DY) < p.Y;                                              \
+      float f[2];                                                                   \
+      spring_xy<DX, DY>(xt[0][ly + 1 + (DY)][lx + 1 + (DX)] - s0 + p.rest[L][0],     \
+                        xt[1][ly + 1 + (DY)][lx + 1 + (DX)] - s1 + p.rest[L][1],     \
+                        l0[L], p.neg_k[L], p.prefer, f);                            \
+      acc0 = acc0 - (ok ? f[0] : 0.f);                                              \
+      acc1 = acc1 - (ok ? f[1] : 0.f);                                              \
+    }
+    SFM_FAR(0, 1, 0) SFM_FAR(1, 0, 1) SFM_FAR(2, 1, 1) SFM_FAR(3, -1, 1)
+    SFM_NEAR(0, 1, 0) SFM_NEAR(1, 0, 1) SFM_NEAR(2, 1, 1) SFM_NEAR(3, -1, 1)
+#undef SFM_FAR
+#undef SFM_NEAR
+    out[0] = acc0;
+    out[1] = acc1;
+  };
+
+  // FIRE scalar update of mesh.py:459-490 for a known sign of the power.
+  auto next_scalars = [&](const Scalars& in, bool downhill) -> Scalars {
+    Scalars t = in;
+    t.n_pos = downhill ? in.n_pos + 1 : 0;
+    if (downhill) {
+      if (t.n_pos > p.n_min) {
+        t.dt = fminf(in.dt * p.f_inc, p.dt_cap);
+        t.alpha = in.alpha * p.f_alpha;
+      }
+      if (t.n_pos > 0 && (t.n_pos % p.cap_every) == 0) t.cap = p.cap_scale * in.cap;
+    } else {
+      t.dt = in.dt * p.f_dec;
+      t.alpha = p.alpha0;
+    }
+    t.cap = fminf(t.cap, p.final_cap);
+    t.gate = downhill ? 1.f : 0.f;
+    return t;
+  };
+
+  // a = F(x) + pull at the initial positions
+  xt[0][ly + 1][lx + 1] = x0;
+  xt[1][ly + 1][lx + 1] = x1;
+  if (h_n >= 0) {
+    xt[0][hy][hx] = xg[h_n];
+    xt[1][hy][hx] = xg[p.N + h_n];
+  }
+  __syncthreads();
+  if (active) {
+    float f[2];
+    tile_force(f);
+    if (p.has_prev) {
+      f[0] = f[0] + prev_pull(x0, pr0, p.neg_k0, s.cap);
+      f[1] = f[1] + prev_pull(x1, pr1, p.neg_k0, s.cap);
+    }
+    a0 = f[0];
+    a1 = f[1];
+  }
+  float my_part = 0.f;  // thread 0: this workgroup's partial power of the last step
+
+  // One step with scalars `sk`; `gate` (0 / 1) is the pending velocity gate of
+  // the previous step, applied to the node's own and the halo velocities.
+  auto do_step = [&](const Scalars& sk, float gate) {
+    v0 = v0 * gate;
+    v1 = v1 * gate;
+    const float dt = sk.dt;
+    const float c2 = 0.5f * (dt * dt);
+    x0 = x0 + (dt * v0 + c2 * a0);
+    x1 = x1 + (dt * v1 + c2 * a1);
+    xt[0][ly + 1][lx + 1] = x0;
+    xt[1][ly + 1][lx + 1] = x1;
+    if (h_n >= 0) {
+      const float hv0 = hval[tid][2] * gate, hv1 = hval[tid][3] * gate;
+      xt[0][hy][hx] = hval[tid][0] + (dt * hv0 + c2 * hval[tid][4]);
+      xt[1][hy][hx] = hval[tid][1] + (dt * hv1 + c2 * hval[tid][5]);
+    }
+    __syncthreads();
+    float pw = 0.f;
+    if (active) {
+      const float hdtg = (0.5f * dt) * p.gamma;
+      const float fact0 = 1.0f / (1.0f + hdtg);
+      const float fact1 = 1.0f - hdtg;
+      const float hdt = 0.5f * dt;
+      float f[2];
+      tile_force(f);
+      if (p.has_prev) {
+        f[0] = f[0] + prev_pull(x0, pr0, p.neg_k0, sk.cap);
+        f[1] = f[1] + prev_pull(x1, pr1, p.neg_k0, sk.cap);
+      }
+      float n0 = fact0 * (v0 * fact1 + hdt * (a0 + f[0]));
+      float n1 = fact0 * (v1 * fact1 + hdt * (a1 + f[1]));
+      a0 = f[0];
+      a1 = f[1];
+      float a2 = 0.f, v2 = 0.f;
+      a2 = a2 + f[0] * f[0];
+      v2 = v2 + n0 * n0;
+      pw = pw + f[0] * n0;
+      a2 = a2 + f[1] * f[1];
+      v2 = v2 + n1 * n1;
+      pw = pw + f[1] * n1;
+      const float a_norm = sqrtf(a2) + 1e-6f;
+      const float v_norm = sqrtf(v2);
+      n0 = n0 + sk.alpha * (f[0] / a_norm * v_norm - n0);
+      n1 = n1 + sk.alpha * (f[1] / a_norm * v_norm - n1);
+      v0 = n0;
+      v1 = n1;
+    }
+    const float t = wave_sum63(pw);
+    if (lane == 63) wred[wave] = t;
+    __syncthreads();  // also: everyone is done with xt / hval
+    if (tid == 0) {
+      float acc = 0.f;
+      for (int w2 = 0; w2 < TL::kWavesT; ++w2) acc = acc + wred[w2];
+      my_part = acc;
+    }
+  };
+
+  bool ok = true;
+  for (int k = 1; k <= q.num_iters + 1; ++k) {
+    const unsigned epoch = static_cast<unsigned>(k);
+    const bool last = k == q.num_iters + 1;
+    const long long slot_off = (long long)(k & 1) * TL::kSlot;
+    u64* my_slot = q.comm + (long long)wg * 2 * TL::kSlot + slot_off;
+    // ---- publish the (verified) state after k - 1 steps -------------------------
+    if (!last && active && pidx >= 0) {
+      u64* g = my_slot + pidx * kNodeGran;
+      put_granule(g + 0, epoch, x0);
+      put_granule(g + 1, epoch, x1);
+      put_granule(g + 2, epoch, v0);
+      put_granule(g + 3, epoch, v1);
+      put_granule(g + 4, epoch, a0);
+      put_granule(g + 5, epoch, a1);
+    }
+    if (k > 1 && tid == 0) put_granule(my_slot + TL::kPerim * kNodeGran, epoch, my_part);
+    // ---- the halo of the 8 neighbours: the only wait in front of the step --------
+    if (!last) {
+      const u64* g[TL::kHaloPolls];
+      float* d[TL::kHaloPolls];
+#pragma unroll
+      for (int u = 0; u < TL::kHaloPolls; ++u) {
+        g[u] = h_off[u] >= 0 ? q.comm + h_off[u] + slot_off : nullptr;
+        d[u] = h_dst[u];
+      }
+      const bool mine_ok = poll_granules<TL::kHaloPolls>(g, d, epoch, q.abort);
+      if (!__syncthreads_and(mine_ok ? 1 : 0)) {
+        ok = false;
+        break;
+      }
+    }
+    // ---- speculative step k on the downhill branch --------------------------------
+    const Scalars s_before = s;  // scalars of step k - 1 (verified)
+    const float bx0 = x0, bx1 = x1, bv0 = v0, bv1 = v1, ba0 = a0, ba1 = a1;
+    const float part_before = my_part;
+    Scalars s_try = s;
+    if (!last) {
+      if (k > 1) s_try = next_scalars(s_before, true);
+      do_step(s_try, 1.f);
+    }
+    if (k == 1) continue;  // no power yet: nothing to verify
+    // ---- collect the partial powers of step k - 1 and verify ------------------------
+    {
+      const u64* g[kPartPolls1];
+      float* d[kPartPolls1];
+#pragma unroll
+      for (int u = 0; u < kPartPolls1; ++u) {
+        const int w2 = tid + u * NT;
+        const bool want = w2 < q.n_wg && w2 != wg;
+        g[u] = want ? q.comm + (long long)w2 * 2 * TL::kSlot + slot_off +
+                          TL::kPerim * kNodeGran
+                    : nullptr;
+        d[u] = want ? &part_all[w2] : nullptr;
+      }
+      if (tid == 0) part_all[wg] = part_before;  // own: no round trip
+      const bool mine_ok = poll_granules<kPartPolls1>(g, d, epoch, q.abort);
+      if (!__syncthreads_and(mine_ok ? 1 : 0)) {
+        ok = false;
+        break;
+      }
+      if (wave == 0) {  // fixed order: strided per lane, then the DPP tree
+        float t = 0.f;
+        for (int w2 = lane; w2 < q.n_wg; w2 += 64) t = t + part_all[w2];
+        t = wave_sum63(t);
+        if (lane == 63) s_power = t;
+      }
+      __syncthreads();
+    }
+    const bool downhill = s_power >= 0.f;
+    if (last) {
+      s = next_scalars(s_before, downhill);
+      v0 = v0 * s.gate;
+      v1 = v1 * s.gate;
+      break;
+    }
+    if (downhill) {
+      s = s_try;
+    } else {
+      // misprediction: back to the state before the step, uphill scalars, v = 0
+      x0 = bx0;
+      x1 = bx1;
+      v0 = bv0;
+      v1 = bv1;
+      a0 = ba0;
+      a1 = ba1;
+      s = next_scalars(s_before, false);
+      do_step(s, 0.f);
+    }
+  }
+
+  if (!ok) return;  // timed out (the abort flag is set)
+  float ek = 0.f, vm2 = 0.f;
+  if (active) {
+    xo[n] = x0;
+    xo[p.N + n] = x1;
+    vo[n] = v0;
+    vo[p.N + n] = v1;
+    ao[n] = a0;
+    ao[p.N + n] = a1;
+    ek = v0 * v0 + v1 * v1;
+    vm2 = ek;
+  }
+#pragma unroll
+  for (int dd = 32; dd > 0; dd >>= 1) {
+    ek = ek + __shfl_xor(ek, dd, 64);
+    vm2 = fmaxf(vm2, __shfl_xor(vm2, dd, 64));
+  }
+  __shared__ float fin[TL::kWavesT][2];
+  __syncthreads();
+  if (lane == 0) {
+    fin[wave][0] = ek;
+    fin[wave][1] = vm2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float e = 0.f, m = 0.f;
+    for (int w2 = 0; w2 < TL::kWavesT; ++w2) {
+      e = e + fin[w2][0];
+      m = fmaxf(m, fin[w2][1]);
+    }
+    q.stat_partials[wg * 2] = e;
+    q.stat_partials[wg * 2 + 1] = m;
+    if (wg == 0) *q.scal_out = s;
+  }
+}
+
 // All-or-nothing hand-over of the persistent kernel's result.
 __global__ void __launch_bounds__(kBlock)
 persist_commit_kernel(const int* __restrict__ abort, const float* __restrict__ xs,
@@ -1996,7 +2347,15 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       q.n_wg = static_cast<int>(n_wg);
       SFM_HIP_CHECK(hipMemsetAsync(w.comm, 0, w.comm_bytes, st));
       sfm::prof_begin(sfm::kProfMesh, st);
-      if (tile == 16)
+      const char* spec_env = getenv("SFM_MESH_SPECULATE");
+      const bool spec = p.fire && !p.remove_drift && !(spec_env && spec_env[0] == '0');
+      if (spec && tile == 16)
+        hipLaunchKernelGGL(mesh_persist2d_spec_kernel<16>, dim3(q.n_wg), dim3(256), 0, st,
+                           p, d->x, d->v, w.alt[0], w.alt[1], w.alt[2], d->prev, q);
+      else if (spec)
+        hipLaunchKernelGGL(mesh_persist2d_spec_kernel<32>, dim3(q.n_wg), dim3(1024), 0, st,
+                           p, d->x, d->v, w.alt[0], w.alt[1], w.alt[2], d->prev, q);
+      else if (tile == 16)
         hipLaunchKernelGGL(mesh_persist2d_kernel<16>, dim3(q.n_wg), dim3(256), 0, st,
                            p, d->x, d->v, w.alt[0], w.alt[1], w.alt[2], d->prev, q);
       else

@@ -416,3 +416,36 @@ def test_brick_kernel_3d_agrees_with_multi_launch_and_oracle(gpu, variant):
   np.testing.assert_allclose(np.array(a[0]), np.array(b[0]), atol=2e-4 * scale)
   np.testing.assert_allclose(np.array(a[0]), wx, atol=1e-3 * scale)
   np.testing.assert_allclose(a[1], we, rtol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 1, 205, 205), (2, 3, 40, 70), (2, 1, 33, 300)])
+def test_speculative_fire_is_bit_identical(gpu, shape):
+  """mesh_persist2d_spec_kernel runs every step on the downhill branch and
+  redoes it when the power turns out negative: bit-identical to the kernel
+  that waits for the power, including chunks with many uphill events."""
+  from scipy import ndimage
+  from sofima_amd import mesh
+  rng = np.random.default_rng(21)
+  prev = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, 3, 3)) * 40
+  prev = (prev + rng.standard_normal(shape) * 2).astype(np.float32)
+  prev[:, :, :2] = np.nan
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.05, k=0.1, stride=(40, 40),
+                               num_iters=150, max_iters=450, stop_v_max=1e-9, dt_max=1000,
+                               start_cap=0.01, final_cap=10, prefer_orig_order=True)
+  x0 = np.zeros(shape, np.float32)
+  vv = lambda: mesh.velocity_verlet(x0, np.zeros_like(x0), prev, cfg, cfg.start_cap)
+  a = _with_env({'SFM_MESH_SPECULATE': '1'}, vv)
+  b = _with_env({'SFM_MESH_SPECULATE': '0'}, vv)
+  for u, w in zip(a[:3], b[:3]):
+    np.testing.assert_array_equal(np.array(u), np.array(w))
+  assert a[3:] == b[3:]
+  assert a[5] < 150          # the power went negative at least once in the chunk
+  run = lambda: mesh.relax_mesh(x0, prev, cfg)
+  c = _with_env({'SFM_MESH_SPECULATE': '1'}, run)
+  d = _with_env({'SFM_MESH_SPECULATE': '0'}, run)
+  np.testing.assert_array_equal(np.array(c[0]), np.array(d[0]))
+  assert c[1] == d[1] and c[2] == d[2]
+  wx, we, wt = mesh_oracle.relax_mesh(x0, prev, cfg)
+  assert c[2] == wt
+  np.testing.assert_allclose(np.array(c[0]), wx, atol=2e-3 * np.abs(wx).max())
