@@ -1889,27 +1889,39 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     const Scalars s_before = s;  // scalars of step k - 1 (verified)
     const float bx0 = x0, bx1 = x1, bv0 = v0, bv1 = v1, ba0 = a0, ba1 = a1;
     const float part_before = my_part;
+    // The partial powers of step k - 1 were published at the top of this
+    // iteration by everyone: request them now, look at them after the step
+    // (the round trip hides behind the force evaluation).
+    const u64* pg[kPartPolls1];
+    float* pd[kPartPolls1];
+    u64 early[kPartPolls1];
+#pragma unroll
+    for (int u = 0; u < kPartPolls1; ++u) {
+      const int w2 = tid + u * NT;
+      const bool want = k > 1 && w2 < q.n_wg && w2 != wg;
+      pg[u] = want ? q.comm + (long long)w2 * 2 * TL::kSlot + slot_off +
+                         TL::kPerim * kNodeGran
+                   : nullptr;
+      pd[u] = want ? &part_all[w2] : nullptr;
+      early[u] = want ? __hip_atomic_load(pg[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : 0;
+    }
     Scalars s_try = s;
     if (!last) {
       if (k > 1) s_try = next_scalars(s_before, true);
       do_step(s_try, 1.f);
     }
     if (k == 1) continue;  // no power yet: nothing to verify
-    // ---- collect the partial powers of step k - 1 and verify ------------------------
+    // ---- the partial powers of step k - 1: verify the speculation -------------------
     {
-      const u64* g[kPartPolls1];
-      float* d[kPartPolls1];
 #pragma unroll
-      for (int u = 0; u < kPartPolls1; ++u) {
-        const int w2 = tid + u * NT;
-        const bool want = w2 < q.n_wg && w2 != wg;
-        g[u] = want ? q.comm + (long long)w2 * 2 * TL::kSlot + slot_off +
-                          TL::kPerim * kNodeGran
-                    : nullptr;
-        d[u] = want ? &part_all[w2] : nullptr;
-      }
+      for (int u = 0; u < kPartPolls1; ++u)
+        if (pg[u] && static_cast<unsigned>(early[u] >> 32) == epoch) {
+          *pd[u] = __uint_as_float(static_cast<unsigned>(early[u]));
+          pg[u] = nullptr;  // arrived: nothing left to poll
+        }
       if (tid == 0) part_all[wg] = part_before;  // own: no round trip
-      const bool mine_ok = poll_granules<kPartPolls1>(g, d, epoch, q.abort);
+      const bool mine_ok = poll_granules<kPartPolls1>(pg, pd, epoch, q.abort);
       if (!__syncthreads_and(mine_ok ? 1 : 0)) {
         ok = false;
         break;
