@@ -1,0 +1,29 @@
+#!/bin/bash
+# End-of-round measurement (round 2): tests, bench, kernel trace, PMC passes.
+# Run on the GPU box:  gpurun -- bash tools/measure/profile_round2.sh
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2; mkdir -p $O
+cd $R
+SHA=$(cat $R/.build_sha 2>/dev/null || echo unknown)
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest.log
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o r2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/trace.log 2>&1
+python $R/tools/rocpd_summary.py $(find $O/trace -name '*.db' | head -1) > $O/trace_summary.md 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --mesh-iters 1000 > $O/pmc_f.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o w -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --mesh-iters 1000 > $O/pmc_w.log 2>&1
+python $R/tools/pmc_summary.py $(find $O/pmc_f -name '*counter_collection.csv' | head -1) $(find $O/pmc_w -name '*counter_collection.csv' | head -1) $O/pmc_traffic.json $SHA > $O/pmc_summary.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o sq -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --mesh-iters 10 > $O/pmc_sq.log 2>&1
+python - <<PY > $O/pmc_sq_summary.txt 2>&1
+import csv, collections, glob
+f = glob.glob('$O/pmc_sq/**/*counter_collection.csv', recursive=True)[0]
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for r in csv.DictReader(open(f)):
+  a = agg[r['Kernel_Name'][:60]][r['Counter_Name']]; a[0] += 1; a[1] += float(r['Counter_Value'])
+for k, v in agg.items():
+  print(k, {c: (n, s / n) for c, (n, s) in v.items()})
+PY
+python $R/tools/measure/configs_time.py > $O/configs_time.log 2>&1
+python $R/tools/measure/montage_time.py > $O/montage_time.log 2>&1
+python $R/tools/measure/mesh3d_time.py > $O/mesh3d_time.log 2>&1
+rm -rf $O/trace/*/*.db.tmp; find $O -name '*.db' -size +20M -delete
+cat $O/pytest.log $O/bench.json; tail -3 $O/bench.err

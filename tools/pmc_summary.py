@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarises two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) per kernel.
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json [git sha]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 counter values are KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide
@@ -25,7 +25,7 @@ def per_kernel(path, counter):
   return agg
 
 
-def main(fetch_csv, write_csv, out):
+def main(fetch_csv, write_csv, out, build='unknown'):
   f = per_kernel(fetch_csv, 'FETCH_SIZE')
   w = per_kernel(write_csv, 'WRITE_SIZE')
   res = {}
@@ -40,10 +40,12 @@ def main(fetch_csv, write_csv, out):
         'write_bytes': round(write),
         'hbm_bytes_per_launch': round(2 * fetch + write),
     }
+  # the build the counters belong to (bench.py reports it next to the traffic)
+  res['_meta'] = {'git_sha': build}
   json.dump(res, open(out, 'w'), indent=1)
-  for k, v in list(res.items())[:6]:
+  for k, v in [kv for kv in res.items() if kv[0] != '_meta'][:6]:
     print(k[:70], v)
 
 
 if __name__ == '__main__':
-  main(*sys.argv[1:4])
+  main(*sys.argv[1:5])
