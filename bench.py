@@ -231,7 +231,7 @@ def main():
     gbs = mesh_nodes * 56.0 / (us_per_step * 1e-6) / 1e9
     persistent = steps_per_launch > 1.5
     mesh_obj['roofline'] = {
-        'kernel': 'mesh_persist2d_kernel<16>' if persistent else 'integrate_kernel<2>',
+        'kernel': 'mesh_persist2d_spec_kernel<16>' if persistent else 'integrate_kernel<2>',
         'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS,
         'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
         'kernel_us_per_step': round(us_per_step, 3), 'launches': int(ms_n),
@@ -243,21 +243,26 @@ def main():
     }
     mesh_obj['steps_per_s'] = mesh_steps_done / t_mesh
 
-  # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes
-  # (profiles/r01_pmc_traffic.json, written by tools/pmc_summary.py); null when
-  # no measurement of this build's kernel is on file.
+  # HBM traffic of the dominant kernel: PMC counters cannot be read from inside
+  # the run, so the figure comes from the separate rocprofv3 --pmc passes of THIS
+  # bench (tools/measure/profile_round2.sh -> profiles/r02_pmc_traffic.json,
+  # stamped with the git revision it was measured on); null when none is on file.
   if roof and uses_mfma:
     try:
-      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
       for name, v in pmc.items():
         if 'xcorr_mfma_kernel<10, 11,' in name and size == 8192:
           roof['traffic'] = v['hbm_bytes_per_launch']
           alg = (2 * 160 * 160 + 4 * 160 * 160 + 4 * 320 * 320) * patches_per_launch
+          roof['traffic_source'] = {
+              'file': 'profiles/r02_pmc_traffic.json',
+              'measured_on_git_sha': pmc.get('_meta', {}).get('git_sha'),
+              'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of '
+                        'this bench; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per '
+                        'launch of %d patches' % round(patches_per_launch)}
           roof['traffic_note'] = (
-              'bytes per launch (%d patches), FETCH_SIZE x2 (gfx950 correction) + '
-              'WRITE_SIZE, separate --pmc passes of this bench; algorithmic HBM '
-              'bytes per launch = patches 51 KB + G table 102 KB + padded surface '
-              '410 KB per patch = %.2f GB' % (round(patches_per_launch), alg / 1e9))
+              'bytes the kernel itself needs per launch: patches 51 KB + G table 102 KB '
+              '+ padded surface 410 KB per patch = %.2f GB' % (alg / 1e9))
     except (OSError, ValueError):
       pass
 
