@@ -1853,8 +1853,15 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     }
   };
 
+#ifdef SFM_MESH_TIMING
+  long long st[5] = {0, 0, 0, 0, 0}, stc = clock64();
+#define STICK(i) { const long long tn = clock64(); st[i] += tn - stc; stc = tn; }
+#else
+#define STICK(i)
+#endif
   bool ok = true;
   for (int k = 1; k <= q.num_iters + 1; ++k) {
+    STICK(4)
     const unsigned epoch = static_cast<unsigned>(k);
     const bool last = k == q.num_iters + 1;
     const long long slot_off = (long long)(k & 1) * TL::kSlot;
@@ -1870,6 +1877,7 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       put_granule(g + 5, epoch, a1);
     }
     if (k > 1 && tid == 0) put_granule(my_slot + TL::kPerim * kNodeGran, epoch, my_part);
+    STICK(0)
     // ---- the halo of the 8 neighbours: the only wait in front of the step --------
     if (!last) {
       const u64* g[TL::kHaloPolls];
@@ -1885,6 +1893,7 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
         break;
       }
     }
+    STICK(1)
     // ---- speculative step k on the downhill branch --------------------------------
     const Scalars s_before = s;  // scalars of step k - 1 (verified)
     const float bx0 = x0, bx1 = x1, bv0 = v0, bv1 = v1, ba0 = a0, ba1 = a1;
@@ -1911,6 +1920,7 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       if (k > 1) s_try = next_scalars(s_before, true);
       do_step(s_try, 1.f);
     }
+    STICK(2)
     if (k == 1) continue;  // no power yet: nothing to verify
     // ---- the partial powers of step k - 1: verify the speculation -------------------
     {
@@ -1934,6 +1944,7 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       }
       __syncthreads();
     }
+    STICK(3)
     const bool downhill = s_power >= 0.f;
     if (last) {
       s = next_scalars(s_before, downhill);
@@ -1956,6 +1967,12 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     }
   }
 
+#ifdef SFM_MESH_TIMING
+  if ((wg == 0 || wg == q.n_wg / 2) && tid == 0)
+    printf("SPEC wg %d per step: publish %lld halo-wait %lld step %lld verify %lld other %lld\n", wg,
+           st[0] / q.num_iters, st[1] / q.num_iters, st[2] / q.num_iters, st[3] / q.num_iters,
+           st[4] / q.num_iters);
+#endif
   if (!ok) return;  // timed out (the abort flag is set)
   float ek = 0.f, vm2 = 0.f;
   if (active) {

@@ -169,8 +169,13 @@ def _make_desc(res: _Resident, patch_size, post_patch_size, mean, min_distance,
   return d
 
 
-# Patches per C call (a multiple of the reference batch is used).
-LAUNCH_PATCHES = 4096
+# Patches per C call (a multiple of the reference batch is used).  One launch
+# carries a whole 8192^2 section pair (40401 patches of 160^2, 26 GB of
+# workspace -- sized for the 288 GB of an MI355X): every launch ends with a
+# tail in which the CUs run dry one by one (the slower workgroup of a CU needs
+# ~400 us per patch), so 1 launch instead of 10 is worth 3-4 % (22.8 vs 23.7 ms).
+import os as _os
+LAUNCH_PATCHES = int(_os.environ.get('SFM_LAUNCH_PATCHES', '45056'))
 # Alternate consecutive calls between two streams (tail filling of the
 # persistent correlation kernel by the next call's prep kernel).
 OVERLAP_CALLS = False  # measured gain ~1 %: opt-in
