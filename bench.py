@@ -252,7 +252,9 @@ def main():
       pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
       for name, v in pmc.items():
         if 'xcorr_mfma_kernel<10, 11,' in name and size == 8192:
-          roof['traffic'] = v['hbm_bytes_per_launch']
+          # measured per launch of `meta_ppl` patches; scaled to this run's launches
+          meta_ppl = float(pmc.get('_meta', {}).get('patches_per_launch', 4040.1))
+          roof['traffic'] = int(v['hbm_bytes_per_launch'] / meta_ppl * patches_per_launch)
           alg = (2 * 160 * 160 + 4 * 160 * 160 + 4 * 320 * 320) * patches_per_launch
           roof['traffic_source'] = {
               'file': 'profiles/r02_pmc_traffic.json',

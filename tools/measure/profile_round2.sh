@@ -11,7 +11,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o r2 -- python $R/benc
 python $R/tools/rocpd_summary.py $(find $O/trace -name '*.db' | head -1) > $O/trace_summary.md 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --mesh-iters 1000 > $O/pmc_f.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o w -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --mesh-iters 1000 > $O/pmc_w.log 2>&1
-python $R/tools/pmc_summary.py $(find $O/pmc_f -name '*counter_collection.csv' | head -1) $(find $O/pmc_w -name '*counter_collection.csv' | head -1) $O/pmc_traffic.json $SHA > $O/pmc_summary.log 2>&1
+python $R/tools/pmc_summary.py $(find $O/pmc_f -name '*counter_collection.csv' | head -1) $(find $O/pmc_w -name '*counter_collection.csv' | head -1) $O/pmc_traffic.json $SHA 40401 > $O/pmc_summary.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o sq -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --mesh-iters 10 > $O/pmc_sq.log 2>&1
 python - <<PY > $O/pmc_sq_summary.txt 2>&1
 import csv, collections, glob

@@ -25,7 +25,7 @@ def per_kernel(path, counter):
   return agg
 
 
-def main(fetch_csv, write_csv, out, build='unknown'):
+def main(fetch_csv, write_csv, out, build='unknown', patches_per_launch=None):
   f = per_kernel(fetch_csv, 'FETCH_SIZE')
   w = per_kernel(write_csv, 'WRITE_SIZE')
   res = {}
@@ -42,10 +42,12 @@ def main(fetch_csv, write_csv, out, build='unknown'):
     }
   # the build the counters belong to (bench.py reports it next to the traffic)
   res['_meta'] = {'git_sha': build}
+  if patches_per_launch:
+    res['_meta']['patches_per_launch'] = float(patches_per_launch)
   json.dump(res, open(out, 'w'), indent=1)
   for k, v in [kv for kv in res.items() if kv[0] != '_meta'][:6]:
     print(k[:70], v)
 
 
 if __name__ == '__main__':
-  main(*sys.argv[1:5])
+  main(*sys.argv[1:6])
