@@ -330,7 +330,6 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   __shared__ int s_c[2];
   __shared__ float s_mu[2];
   __shared__ int band_tot[2][kPrepWaves][64 * kPrepCols];
-  __shared__ int row_scr[kPrepWaves][2][64 * kPrepCols + 2];
   // reduction scratch of phase 2, aliased onto band_tot (separated by a barrier)
   static_assert(sizeof(band_tot) >= sizeof(int) * 2 * 3 * kPrepThreads, "alias");
   int (*red)[3][kPrepThreads] = reinterpret_cast<int (*)[3][kPrepThreads]>(&band_tot[0][0][0]);
@@ -467,7 +466,7 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
     if (x < px)
       for (int y = ra0; y < ra1; ++y) {
         ta += pix[0][y * px + x];
-        tb += pix[1][y * px + x];
+        tb += pix[1][y * px + (px - 1 - x)];  // post patch: mirrored columns
       }
     band_tot[0][wave][xl + k] = ta;
     band_tot[1][wave][xl + k] = tb;
@@ -481,8 +480,6 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   float* rrowB = aux + a.aux_n;
   float* rcolA = aux + 2 * a.aux_n;
   float* rcolB = aux + 3 * a.aux_n;
-  int* rowA = row_scr[wave][0];  // IrawA[yv][0..px]
-  int* rowB = row_scr[wave][1];  // IrawB[py - yv][0..px]
 
   // Phase 3b: running column sums at the first row of the band.
   //   colA = sum of pre rows  [0, yv)      at yv = ra0
@@ -500,16 +497,21 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
       } else if (lo < py - ra0) {
         const int x = xl + k;  // partial band: rows [lo, py - ra0)
         if (x < px)
-          for (int y = lo; y < py - ra0; ++y) colB[k] += pix[1][y * px + x];
+          for (int y = lo; y < py - ra0; ++y) colB[k] += pix[1][y * px + (px - 1 - x)];
       }
     }
   }
   PTICK(3)
   // Sweep.  The last wave also emits the yv == py row (pre-patch totals).
+  // The post patch is scanned in MIRRORED column order (lane l owns columns
+  // px - 1 - (3 l + k)): the table needs IB[py - yv][px - xv], and
+  //     sum_{x < px - xv} b[.][x]  =  TB - (mirrored prefix up to xv),
+  // so the lane that holds IA[yv][xv] also holds the matching IB value and a
+  // row of G leaves the registers directly -- no transposition through LDS, no
+  // intra-wave fences (the first version spent 1.8 k cycles per row on them).
   const int y_end = wave == kPrepWaves - 1 ? py + 1 : ra1;
   for (int yv = ra0; yv < y_end; ++yv) {
     const int yw = py - yv;
-    // Inclusive prefix over the lane's own columns, then across lanes.
     int pa[kPrepCols], pb[kPrepCols];
     int sa = 0, sb = 0;
 #pragma unroll
@@ -519,42 +521,49 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
       pa[k] = sa;
       pb[k] = sb;
     }
-    const int ea = wave_scan_incl(sa) - sa;  // exclusive prefix of lane totals
-    const int eb = wave_scan_incl(sb) - sb;
-    if (lane == 0) {
-      rowA[0] = 0;
-      rowB[0] = 0;
-    }
-#pragma unroll
-    for (int k = 0; k < kPrepCols; ++k)
-      if (xl + k < px) {
-        rowA[xl + k + 1] = ea + pa[k];
-        rowB[xl + k + 1] = eb + pb[k];
-      }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int inc_a = wave_scan_incl(sa), inc_b = wave_scan_incl(sb);
+    const int ea = inc_a - sa, eb = inc_b - sb;   // exclusive prefixes of the lane totals
+    const int ta = __builtin_amdgcn_readlane(inc_a, 63);  // IrawA[yv][px]
+    const int tb = __builtin_amdgcn_readlane(inc_b, 63);  // IrawB[py - yv][px]
     // centred integral images: I'[y][x] = Iraw[y][x] - c y x
-    auto ia = [&](int x) { return static_cast<float>(rowA[x] - ca * yv * x); };
-    auto ib = [&](int x) { return static_cast<float>(rowB[x] - cb * yw * x); };
+    auto ia = [&](int raw, int x) { return static_cast<float>(raw - ca * yv * x); };
+    auto ib = [&](int raw, int x) { return static_cast<float>(raw - cb * yw * x); };
+    const float ia_px = ia(ta, px), ib_px = ib(tb, px);
     if (yv < py) {
-      for (int xv = lane; xv < px; xv += 64)
-        G[yv * px + xv] = -mub * ia(xv) - mua * ib(px - xv);
+#pragma unroll
+      for (int k = 0; k < kPrepCols; ++k) {
+        const int xv = xl + k + 1;
+        if (xv < px)
+          G[yv * px + xv] = -mub * ia(ea + pa[k], xv) - mua * ib(tb - (eb + pb[k]), px - xv);
+      }
       if (lane == 0) {
-        rrowA[yv] = -mub * ia(px);
-        rrowB[yv] = mua * ib(px);
+        G[yv * px] = -mub * ia(0, 0) - mua * ib_px;
+        rrowA[yv] = -mub * ia_px;
+        rrowB[yv] = mua * ib_px;
       }
     }
     if (yv == 0) {
-      for (int xv = lane; xv < px; xv += 64) rcolB[xv] = mua * ib(px - xv);
-      if (lane == 0) aux[4 * a.aux_n + 1] = -mua * ib(px);
+#pragma unroll
+      for (int k = 0; k < kPrepCols; ++k) {
+        const int xv = xl + k + 1;
+        if (xv < px) rcolB[xv] = mua * ib(tb - (eb + pb[k]), px - xv);
+      }
+      if (lane == 0) {
+        rcolB[0] = mua * ib_px;
+        aux[4 * a.aux_n + 1] = -mua * ib_px;
+      }
     }
     if (yv == py) {
-      for (int xv = lane; xv < px; xv += 64) rcolA[xv] = -mub * ia(xv);
-      if (lane == 0) aux[4 * a.aux_n + 0] = -mub * ia(px);
+#pragma unroll
+      for (int k = 0; k < kPrepCols; ++k) {
+        const int xv = xl + k + 1;
+        if (xv < px) rcolA[xv] = -mub * ia(ea + pa[k], xv);
+      }
+      if (lane == 0) {
+        rcolA[0] = -mub * ia(0, 0);
+        aux[4 * a.aux_n + 0] = -mub * ia_px;
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     // advance to row yv + 1
     if (yv < py) {
 #pragma unroll
@@ -562,7 +571,7 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
         const int x = xl + k;
         if (x < px) {
           colA[k] += pix[0][yv * px + x];
-          colB[k] -= pix[1][(yw - 1) * px + x];
+          colB[k] -= pix[1][(yw - 1) * px + (px - 1 - x)];
         }
       }
     }
