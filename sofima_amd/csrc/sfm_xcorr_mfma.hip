@@ -90,6 +90,11 @@
 // speed (each shares its matrix pipe with a wave of the other workgroup of the
 // CU), and with the static deal ~17 % of a workgroup's time was spent waiting
 // for its slowest wave at the end of every patch.
+// One LDS instruction per MFMA gap instead of a burst of four behind every
+// chunk (see the row-group loop).
+#ifndef SFM_LOOP_INTERLEAVE
+#define SFM_LOOP_INTERLEAVE 1
+#endif
 #ifndef SFM_DYNAMIC_TILES
 #define SFM_DYNAMIC_TILES 1
 #endif
@@ -1265,6 +1270,24 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           bp += 4 * a.pb;
 #pragma unroll
           for (int ca = 0; ca < NCA; ++ca) {
+#if SFM_LOOP_INTERLEAVE
+            // the register set of the PREVIOUS chunk is free now: its reload and
+            // this chunk's share of the next B dwords can sit in the MFMA gaps
+            // (one LDS instruction per gap) instead of in a burst behind them
+            if (ca > 0) {
+              const int cp = ca - 1;
+              if (cp + kW < NCA)
+                af[cp % kW] = *reinterpret_cast<const v4i*>(ap + 16 * (cp + kW));
+              else
+                af[cp % kW] =
+                    *reinterpret_cast<const v4i*>(ap + 4 * a.pa + 16 * (cp + kW - NCA));
+            }
+            if (ca < NCA - 1) {
+#pragma unroll
+              for (int j = ca * kPerCa; j < (ca + 1) * kPerCa && j < kND; ++j)
+                dn[j] = *reinterpret_cast<const unsigned*>(bp + 4 * j);
+            }
+#endif
 #pragma unroll
             for (int c = 0; c < NCE; ++c) {
               const int q = ca - c + cq0;
@@ -1277,6 +1300,19 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                       __builtin_amdgcn_alignbyte(dn[4 * c + k + 1], dn[4 * c + k], sh));
               }
             }
+#if SFM_LOOP_INTERLEAVE
+            if (ca == NCA - 1)  // the last chunk's set: nothing follows in this group
+              af[ca % kW] =
+                  *reinterpret_cast<const v4i*>(ap + 4 * a.pa + 16 * (ca + kW - NCA));
+            if (ca < NCA - 1) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+              }
+              __builtin_amdgcn_sched_group_barrier(0x008, NCE - 4, 0);
+            }
+#else
             if (ca + kW < NCA)
               af[ca % kW] = *reinterpret_cast<const v4i*>(ap + 16 * (ca + kW));
             else
@@ -1287,6 +1323,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
               for (int j = ca * kPerCa; j < (ca + 1) * kPerCa && j < kND; ++j)
                 dn[j] = *reinterpret_cast<const unsigned*>(bp + 4 * j);
             }
+#endif
             // keep the chunk order: the machine scheduler would otherwise sink
             // every prefetch to the end of the body (= no prefetch distance)
             __builtin_amdgcn_sched_barrier(0);
