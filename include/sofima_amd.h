@@ -347,9 +347,13 @@ typedef struct SfmTargetMeshDesc {
   const int32_t* nbors;         /* device [n_tiles, 4, nbor_fields]          */
   const float* fx;              /* device [ncomp, n_fx, *fx_shape]           */
   const float* fy;              /* device [ncomp, n_fy, *fy_shape]           */
+  int32_t n_eval;               /* 0: all tiles; > 0: only the first n_eval
+                                   rows of `nbors` are evaluated (the meshes in
+                                   x still number n_tiles)                   */
 } SfmTargetMeshDesc;
 
-/* x, out: device float [ncomp, n_tiles, *mesh_shape]. */
+/* x: device float [ncomp, n_tiles, *mesh_shape]; out: [ncomp, n_eval or
+ * n_tiles, *mesh_shape]. */
 int sfm_target_mesh(const SfmTargetMeshDesc* desc, const float* x, float* out,
                     void* stream);
 

@@ -211,6 +211,7 @@ class SfmTargetMeshDesc(C.Structure):
       ('nbors', C.c_void_p),
       ('fx', C.c_void_p),
       ('fy', C.c_void_p),
+      ('n_eval', i32),
   ]
 
 

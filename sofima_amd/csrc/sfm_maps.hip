@@ -281,9 +281,11 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
       if (!isnan(uy_v)) ry = uy_v;
       if (!isnan(uz_v)) rz = uz_v;
     }
+    // out holds the evaluated tiles only: [ncomp, n_eval, *mesh]
+    const long long n_out = d.n_eval > 0 ? d.n_eval : d.n_tiles;
     a.out[(long long)tile * mn + node] = rx;
-    a.out[((long long)d.n_tiles + tile) * mn + node] = ry;
-    if (nc == 3) a.out[(2LL * d.n_tiles + tile) * mn + node] = rz;
+    a.out[(n_out + tile) * mn + node] = ry;
+    if (nc == 3) a.out[(2 * n_out + tile) * mn + node] = rz;
   }
 }
 
@@ -304,8 +306,10 @@ int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
   if (d->ncomp == 2 && d->mesh_shape[0] != 1)
     return fail(SFM_ERR_INVALID, "target mesh: in-plane montages have one section");
   if (d->nbor_fields < (d->ncomp == 3 ? 11 : 8) || !d->nbors || !d->fx || !d->fy ||
-      d->n_tiles < 1)
+      d->n_tiles < 1 || d->n_eval < 0)
     return fail(SFM_ERR_INVALID, "target mesh: bad neighbour / flow arrays");
+  if (d->n_eval > 0 && out == x)
+    return fail(SFM_ERR_INVALID, "target mesh: partial evaluation needs its own output");
   TargetArgs a;
   a.d = *d;
   a.x = x;
@@ -317,7 +321,8 @@ int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
   if (per_tile > 0x7fffffffLL) return fail(SFM_ERR_INVALID, "target mesh: tile too large");
   const long long gx = (long long)((d->mesh_shape[2] + 15) / 16) *
                        (((long long)d->mesh_shape[0] * d->mesh_shape[1] + 15) / 16);
-  hipLaunchKernelGGL(target_mesh_kernel, dim3(static_cast<unsigned>(gx), d->n_tiles),
+  hipLaunchKernelGGL(target_mesh_kernel,
+                     dim3(static_cast<unsigned>(gx), d->n_eval > 0 ? d->n_eval : d->n_tiles),
                      dim3(kBlock), 0, st, a);
   SFM_LAUNCH_CHECK();
   return SFM_OK;

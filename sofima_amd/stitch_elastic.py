@@ -103,16 +103,21 @@ def compute_target_mesh(nbor_data, x, fx, fy, stride=(20, 20)) -> np.ndarray:
 
   nbor_data: [4, 8 or 11] neighbour info of the tile; x, fx, fy as in the
   reference (in-plane [2, n, y, x] or volumetric [3, n, z, y, x]).
-  Evaluates the whole montage and returns the entry of the tile whose
-  neighbour rows were given (the tile is identified by position 0 of a
-  one-tile batch).
+  Only this tile is evaluated (`SfmTargetMeshDesc.n_eval = 1`).
   """
-  nb = np.asarray(nbor_data)[None]
-  x = np.asarray(x)
-  fn = TargetMeshFn(np.repeat(nb, x.shape[1], axis=0), fx, fy, stride)
-  # every "tile" of the batch uses the same neighbour rows; entry 0 is the
-  # result the reference returns for this nbor_data
-  return np.asarray(fn(x))[:, 0]
+  dev = _dev.device()
+  x_t = _dev.as_device_f32(x, dev, copy=False)
+  fn = TargetMeshFn(np.asarray(nbor_data)[None], fx, fy, stride)
+  d = fn.desc
+  # ONE row of neighbour info evaluated against the meshes of all n tiles
+  d.n_tiles = int(x_t.shape[1])
+  d.n_eval = 1
+  d.mesh_shape = (C.c_int32 * 3)(*([1] * (3 - fn.ncomp)), *x_t.shape[2:])
+  out = torch.empty((fn.ncomp, 1) + tuple(x_t.shape[2:]), dtype=torch.float32,
+                    device=dev)
+  _abi.check(_abi.load().sfm_target_mesh(C.byref(d), x_t.data_ptr(), out.data_ptr(),
+                                         _dev.stream_ptr()))
+  return out[:, 0].cpu().numpy()
 
 
 def _overlap_strips(pre, post, off_xy, axis: int, stride):

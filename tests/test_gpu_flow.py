@@ -736,3 +736,33 @@ def test_flow_stays_on_device_through_clean_flow(gpu, golden):
   cleaned = flow_utils.clean_flow(devf.tensor[:, None], 1.4, 1.4, 0, 5)
   want = flow_utils_oracle.clean_flow(host[:, None], 1.4, 1.4, 0, 5)
   np.testing.assert_array_equal(np.asarray(cleaned), want)
+
+
+@pytest.mark.gpu
+def test_sharpness_numerator_and_window_min_separately(gpu):
+  """the sharpness quotient is ill-conditioned (window minimum near
+  0 on raw surfaces), so its two ingredients are pinned separately on
+  production-size patches: the peak value of the matrix-core surface to 1e-6
+  relative and the minimum of the 11 x 11 window to 2e-6 of the peak, against
+  the float64 evaluation of the same sums."""
+  from sofima_amd import flow_field
+  pre, post = _em_pair(5, 640, 720, warp=3.0)
+  rng = np.random.default_rng(3)
+  ys = rng.integers(0, 640 - 160, 6)
+  xs = rng.integers(0, 720 - 160, 6)
+  a = np.stack([pre[y:y + 160, x:x + 160] for y, x in zip(ys, xs)])
+  b = np.stack([post[y:y + 160, x:x + 160] for y, x in zip(ys, xs)])
+  got = flow_field.masked_xcorr(a, b, method=2)        # int8 matrix cores
+  a0 = a.astype(np.float64) - a.mean(axis=(1, 2), keepdims=True)
+  b0 = b.astype(np.float64) - b.mean(axis=(1, 2), keepdims=True)
+  want = flow_oracle.xcorr_surface(a0, b0, dtype=np.float64)
+  for g, w in zip(got, want):
+    iy, ix = np.unravel_index(np.argmax(w), w.shape)
+    assert (iy, ix) == np.unravel_index(np.argmax(g), g.shape)
+    peak = w[iy, ix]
+    np.testing.assert_allclose(g[iy, ix], peak, rtol=1e-6)
+    y0 = min(max(iy - 5, 0), w.shape[0] - 11)
+    x0 = min(max(ix - 5, 0), w.shape[1] - 11)
+    wg, ww = g[y0:y0 + 11, x0:x0 + 11], w[y0:y0 + 11, x0:x0 + 11]
+    np.testing.assert_allclose(wg.min(), ww.min(), atol=2e-6 * peak)
+    np.testing.assert_allclose(wg, ww, atol=2e-6 * peak)
