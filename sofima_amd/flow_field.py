@@ -265,7 +265,8 @@ def _run_batches(res: _Resident, desc: _abi.SfmXcorrDesc, pre_starts: np.ndarray
 # ---------------------------------------------------------------------------
 def masked_xcorr(prev: Array, curr: Array, prev_mask: Array | None = None,
                  curr_mask: Array | None = None, use_jax: bool = False,
-                 dim: int = 2, method: int = _abi.XCORR_AUTO) -> np.ndarray:
+                 dim: int = 2, method: int = _abi.XCORR_AUTO,
+                 mean: float | None = 0.0) -> np.ndarray:
   """Cross-correlation between two (masked) image batches.
 
   Same contract as flow_field.masked_xcorr (flow_field.py:36-156): full linear
@@ -273,7 +274,9 @@ def masked_xcorr(prev: Array, curr: Array, prev_mask: Array | None = None,
   without masks, Padfield-normalised values in [-1, 1] with masks; the
   normalisation tolerances use maxima over the whole batch.  `use_jax` is
   accepted for signature compatibility; the computation always runs on the
-  GPU in float32.
+  GPU in float32.  `mean` (an extension) is subtracted from both inputs first:
+  0.0 = the reference's behaviour (inputs are used as they are), None = every
+  patch's own mean like `_batched_xcorr` does (flow_field.py:340-353).
   """
   del use_jax
   dev = _dev.device()
@@ -304,7 +307,7 @@ def masked_xcorr(prev: Array, curr: Array, prev_mask: Array | None = None,
     curr = curr.astype(np.float32, copy=False)
   res = _Resident(stack(prev, p), stack(curr, q),
                   stack(prev_mask, p), stack(curr_mask, q), dev)
-  desc = _make_desc(res, p, q, 0.0, 2, 0.5, 5, method)
+  desc = _make_desc(res, p, q, mean, 2, 0.5, 5, method)
   st_pre = np.zeros((b, dim), np.int32)
   st_post = np.zeros((b, dim), np.int32)
   st_pre[:, 0] = np.arange(b) * p[0]
