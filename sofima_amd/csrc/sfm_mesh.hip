@@ -620,6 +620,45 @@ integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
   }
 }
 
+// The reducing (last) workgroup of a tiled step gathers the per-tile partial
+// sums.  Every producer's stores were acknowledged before it took its ticket,
+// so the granules are there: the loads of a batch are issued back to back
+// (independent, one round trip per batch instead of one per granule -- the
+// first version's 91 dependent round trips per thread were ~20 % of a step on
+// [2,64,204,204]) and only a granule with a stale tag is polled.  Without
+// drift removal only the power sum is read.  Rows are added in tile order.
+__device__ __forceinline__ void tile_tail_gather(const u64* __restrict__ partials, int rows,
+                                                 int nval, unsigned epoch, float* acc) {
+  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
+  constexpr int kBatchRows = 8;
+  for (int r0 = threadIdx.x; r0 < rows; r0 += kBlock * kBatchRows) {
+    u64 gr[kBatchRows][7];
+#pragma unroll
+    for (int u = 0; u < kBatchRows; ++u) {
+      const int r = r0 + u * kBlock;
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+        gr[u][i] = (r < rows && i < nval)
+                       ? __hip_atomic_load(&partials[r * kNP + i], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT)
+                       : (static_cast<u64>(epoch) << 32);
+    }
+#pragma unroll
+    for (int u = 0; u < kBatchRows; ++u) {
+      const int r = r0 + u * kBlock;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        u64 g = gr[u][i];
+        for (int spin = 0; static_cast<unsigned>(g >> 32) != epoch && spin < (1 << 22);
+             ++spin)
+          g = __hip_atomic_load(&partials[r * kNP + i], __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT);
+        acc[i] = acc[i] + __uint_as_float(static_cast<unsigned>(g));
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // LDS-tiled step for large in-plane meshes (state far beyond the caches).
 //
@@ -809,17 +848,7 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
   __syncthreads();
   if (!s_last) return;
   float acc[kNP];
-  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
-  for (int r = threadIdx.x; r < static_cast<int>(gridDim.x); r += kBlock)
-    for (int i = 0; i < 7; ++i) {
-      u64 gr = 0;
-      for (int spin = 0; spin < (1 << 22); ++spin) {
-        gr = __hip_atomic_load(&partials[r * kNP + i], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        if (static_cast<unsigned>(gr >> 32) == epoch) break;
-      }
-      acc[i] = acc[i] + __uint_as_float(static_cast<unsigned>(gr));
-    }
+  tile_tail_gather(partials, static_cast<int>(gridDim.x), p.remove_drift ? 7 : 1, epoch, acc);
   block_sum(acc, 7, lds);
   if (threadIdx.x == 0) {
     Scalars in = *scal_in, o;
@@ -1031,17 +1060,7 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
   __syncthreads();
   if (!s_last) return;
   float acc[kNP];
-  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
-  for (int r = threadIdx.x; r < static_cast<int>(gridDim.x); r += kBlock)
-    for (int i = 0; i < 7; ++i) {
-      u64 gr = 0;
-      for (int spin = 0; spin < (1 << 22); ++spin) {
-        gr = __hip_atomic_load(&partials[r * kNP + i], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        if (static_cast<unsigned>(gr >> 32) == epoch) break;
-      }
-      acc[i] = acc[i] + __uint_as_float(static_cast<unsigned>(gr));
-    }
+  tile_tail_gather(partials, static_cast<int>(gridDim.x), p.remove_drift ? 7 : 1, epoch, acc);
   block_sum(acc, 7, lds);
   if (threadIdx.x == 0) {
     Scalars in = *scal_in, o;
