@@ -468,11 +468,14 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   for (int k = 0; k < kPrepCols; ++k) {
     const int x = xl + k;
     int ta = 0, tb = 0;
-    if (x < px)
+    if (x < px) {
+      // several rows per trip: the byte loads of a trip are in flight together
+#pragma unroll 5
       for (int y = ra0; y < ra1; ++y) {
         ta += pix[0][y * px + x];
         tb += pix[1][y * px + (px - 1 - x)];  // post patch: mirrored columns
       }
+    }
     band_tot[0][wave][xl + k] = ta;
     band_tot[1][wave][xl + k] = tb;
   }
@@ -517,6 +520,16 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   const int y_end = wave == kPrepWaves - 1 ? py + 1 : ra1;
   for (int yv = ra0; yv < y_end; ++yv) {
     const int yw = py - yv;
+    // the pixels that move the column sums to row yv + 1: requested now, added
+    // at the end of the trip (their LDS latency hides behind the scans)
+    int nxt_a[kPrepCols], nxt_b[kPrepCols];
+#pragma unroll
+    for (int k = 0; k < kPrepCols; ++k) {
+      const int x = xl + k;
+      const bool live = yv < py && x < px;
+      nxt_a[k] = live ? pix[0][yv * px + x] : 0;
+      nxt_b[k] = live ? pix[1][(yw - 1) * px + (px - 1 - x)] : 0;
+    }
     int pa[kPrepCols], pb[kPrepCols];
     int sa = 0, sb = 0;
 #pragma unroll
@@ -570,15 +583,10 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
       }
     }
     // advance to row yv + 1
-    if (yv < py) {
 #pragma unroll
-      for (int k = 0; k < kPrepCols; ++k) {
-        const int x = xl + k;
-        if (x < px) {
-          colA[k] += pix[0][yv * px + x];
-          colB[k] -= pix[1][(yw - 1) * px + (px - 1 - x)];
-        }
-      }
+    for (int k = 0; k < kPrepCols; ++k) {
+      colA[k] += nxt_a[k];
+      colB[k] -= nxt_b[k];
     }
   }
 #ifdef SFM_MFMA_TIMING
