@@ -41,6 +41,19 @@ namespace {
 typedef unsigned long long u64;
 constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 1024;
+// Minimum waves per SIMD the register allocator must leave room for
+// (__launch_bounds__ second argument).  Measured on [3,4,100^3] / [2,64,204^2]:
+// the volumetric stencil takes 180 VGPRs unconstrained (2 waves per SIMD, 369 us
+// per step); 3 waves (167 VGPRs, no scratch) 334 us; 4 and 5 waves spill and are
+// slower (456 / 638 us).  The tiled in-plane step (127 VGPRs, 4 waves) only
+// loses with 5, 6 or 8 waves (73 -> 87 / 110 / 134 us): both are bound by the
+// latency of their long dependent chains, not by occupancy.
+#ifndef SFM_LB3
+#define SFM_LB3 3
+#endif
+#ifndef SFM_LBT
+#define SFM_LBT 1
+#endif
 constexpr int kNP = 8;  // partials per block: power, sx[3], sv[3], pad
 
 struct MeshParams {
@@ -431,7 +444,7 @@ __device__ __forceinline__ float prev_pull(float x, float prev, float neg_k0,
 }
 
 template <int C>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, C == 3 ? SFM_LB3 : 1)
 force_kernel(const float* __restrict__ x, const float* __restrict__ prev,
              float* __restrict__ out, MeshParams p, float cap, int add_prev) {
   for (long long n = blockIdx.x * (long long)kBlock + threadIdx.x; n < p.N;
@@ -556,7 +569,7 @@ advance_kernel(float* __restrict__ x, float* __restrict__ v,
 }
 
 template <int C>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, C == 3 ? SFM_LB3 : 1)
 integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
                  float* __restrict__ a, const float* __restrict__ prev,
                  MeshParams p, const Scalars* __restrict__ scal,
@@ -680,7 +693,7 @@ __device__ __forceinline__ void tile_tail_gather(const u64* __restrict__ partial
 // it leaves the updated FIRE scalars for the next launch.
 // ---------------------------------------------------------------------------
 template <int TY, int TX, bool FUSED>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, SFM_LBT)
 integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in,
                          const float* __restrict__ prev, float* x_out, float* v_out,
                          float* a_out, MeshParams p,
