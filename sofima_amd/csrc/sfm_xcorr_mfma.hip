@@ -313,10 +313,7 @@ __device__ __forceinline__ v4i load_16_bytes(const unsigned char* img, long long
 // the centre is folded in afterwards (I'[y][x] = Iraw[y][x] - c y x).
 // ---------------------------------------------------------------------------
 constexpr int kPrepCols = 3;  // columns per lane: Px <= 192
-#ifndef SFM_PREP_WAVES
-#define SFM_PREP_WAVES 8
-#endif
-constexpr int kPrepWaves = SFM_PREP_WAVES;  // bands of rows swept concurrently
+constexpr int kPrepWaves = 8;  // bands of rows swept concurrently
 constexpr int kPrepThreads = 64 * kPrepWaves;
 
 // Wave-wide inclusive add scan on the DPP network (row shifts inside each
@@ -331,8 +328,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
   return v;
 }
 
-__global__ void __launch_bounds__(kPrepThreads, 2 * kPrepWaves / 4)
-mfma_prep_same_kernel(MfmaArgs a) {
+__global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a) {
   if (a.work_counter && blockIdx.x == 0 && threadIdx.x == 0)
     *a.work_counter = 0;  // the correlation kernel's patch queue
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -368,9 +364,7 @@ mfma_prep_same_kernel(MfmaArgs a) {
     x0[s] = min(max(a.starts[s][b * 2 + 1], 0), W - px);
     img_bytes[s] = (long long)H * W;
   }
-  // items per thread and plane whose loads are in flight (one round covers a
-  // 160 x 160 patch: 1600 items)
-  constexpr int kItems = 2048 / kPrepThreads;
+  constexpr int kItems = 4;  // items per thread and plane whose loads are in flight
   for (int item0 = threadIdx.x; item0 < n_items; item0 += kPrepThreads * kItems) {
     v4i w[2][kItems];
 #pragma unroll
@@ -465,16 +459,14 @@ mfma_prep_same_kernel(MfmaArgs a) {
   PTICK(2)
 
   // Phase 3a: per-band column totals (band w = rows [w R, (w + 1) R)).
-  // Lane l owns the INTERLEAVED columns l, l + 64, l + 128: pixel bytes and the
-  // rows of G are then consecutive across the lanes of a wave (conflict-free
-  // LDS reads, fully coalesced stores); the prefix along x is one wave scan
-  // per 64-column block plus the totals of the blocks before it.
+  // Lane l owns the kPrepCols consecutive columns kPrepCols * l + k, so one
+  // wave scan over the per-lane totals gives the prefix along x.
   const int R = (py + kPrepWaves - 1) / kPrepWaves;
   const int ra0 = min(wave * R, py), ra1 = min(ra0 + R, py);
-  const int xl = lane;  // column of slot k: xl + 64 * k
+  const int xl = kPrepCols * lane;
 #pragma unroll
   for (int k = 0; k < kPrepCols; ++k) {
-    const int x = xl + 64 * k;
+    const int x = xl + k;
     int ta = 0, tb = 0;
     if (x < px) {
       // several rows per trip: the byte loads of a trip are in flight together
@@ -484,8 +476,8 @@ mfma_prep_same_kernel(MfmaArgs a) {
         tb += pix[1][y * px + (px - 1 - x)];  // post patch: mirrored columns
       }
     }
-    band_tot[0][wave][xl + 64 * k] = ta;
-    band_tot[1][wave][xl + 64 * k] = tb;
+    band_tot[0][wave][xl + k] = ta;
+    band_tot[1][wave][xl + k] = tb;
   }
   __syncthreads();
   const int ca = s_c[0], cb = s_c[1];
@@ -507,11 +499,11 @@ mfma_prep_same_kernel(MfmaArgs a) {
     colB[k] = 0;
     for (int w2 = 0; w2 < kPrepWaves; ++w2) {
       const int lo = min(w2 * R, py), hi = min(lo + R, py);
-      if (hi <= ra0) colA[k] += band_tot[0][w2][xl + 64 * k];
+      if (hi <= ra0) colA[k] += band_tot[0][w2][xl + k];
       if (hi <= py - ra0) {
-        colB[k] += band_tot[1][w2][xl + 64 * k];
+        colB[k] += band_tot[1][w2][xl + k];
       } else if (lo < py - ra0) {
-        const int x = xl + 64 * k;  // partial band: rows [lo, py - ra0)
+        const int x = xl + k;  // partial band: rows [lo, py - ra0)
         if (x < px)
           for (int y = lo; y < py - ra0; ++y) colB[k] += pix[1][y * px + (px - 1 - x)];
       }
@@ -520,7 +512,7 @@ mfma_prep_same_kernel(MfmaArgs a) {
   PTICK(3)
   // Sweep.  The last wave also emits the yv == py row (pre-patch totals).
   // The post patch is scanned in MIRRORED column order (lane l owns columns
-  // px - 1 - (l + 64 k)): the table needs IB[py - yv][px - xv], and
+  // px - 1 - (3 l + k)): the table needs IB[py - yv][px - xv], and
   //     sum_{x < px - xv} b[.][x]  =  TB - (mirrored prefix up to xv),
   // so the lane that holds IA[yv][xv] also holds the matching IB value and a
   // row of G leaves the registers directly -- no transposition through LDS, no
@@ -533,24 +525,24 @@ mfma_prep_same_kernel(MfmaArgs a) {
     int nxt_a[kPrepCols], nxt_b[kPrepCols];
 #pragma unroll
     for (int k = 0; k < kPrepCols; ++k) {
-      const int x = xl + 64 * k;
+      const int x = xl + k;
       const bool live = yv < py && x < px;
       nxt_a[k] = live ? pix[0][yv * px + x] : 0;
       nxt_b[k] = live ? pix[1][(yw - 1) * px + (px - 1 - x)] : 0;
     }
-    // inclusive prefix up to and including the lane's column of every block
     int pa[kPrepCols], pb[kPrepCols];
-    int ta = 0, tb = 0;  // running totals of the blocks before -> IrawA[yv][px], IrawB[py - yv][px]
+    int sa = 0, sb = 0;
 #pragma unroll
     for (int k = 0; k < kPrepCols; ++k) {
-      const bool live = xl + 64 * k < px;
-      const int ia_k = wave_scan_incl(live ? colA[k] : 0);
-      const int ib_k = wave_scan_incl(live ? colB[k] : 0);
-      pa[k] = ta + ia_k;
-      pb[k] = tb + ib_k;
-      ta += __builtin_amdgcn_readlane(ia_k, 63);
-      tb += __builtin_amdgcn_readlane(ib_k, 63);
+      sa += xl + k < px ? colA[k] : 0;
+      sb += xl + k < px ? colB[k] : 0;
+      pa[k] = sa;
+      pb[k] = sb;
     }
+    const int inc_a = wave_scan_incl(sa), inc_b = wave_scan_incl(sb);
+    const int ea = inc_a - sa, eb = inc_b - sb;   // exclusive prefixes of the lane totals
+    const int ta = __builtin_amdgcn_readlane(inc_a, 63);  // IrawA[yv][px]
+    const int tb = __builtin_amdgcn_readlane(inc_b, 63);  // IrawB[py - yv][px]
     // centred integral images: I'[y][x] = Iraw[y][x] - c y x
     auto ia = [&](int raw, int x) { return static_cast<float>(raw - ca * yv * x); };
     auto ib = [&](int raw, int x) { return static_cast<float>(raw - cb * yw * x); };
@@ -558,9 +550,9 @@ mfma_prep_same_kernel(MfmaArgs a) {
     if (yv < py) {
 #pragma unroll
       for (int k = 0; k < kPrepCols; ++k) {
-        const int xv = xl + 64 * k + 1;
+        const int xv = xl + k + 1;
         if (xv < px)
-          G[yv * px + xv] = -mub * ia(pa[k], xv) - mua * ib(tb - pb[k], px - xv);
+          G[yv * px + xv] = -mub * ia(ea + pa[k], xv) - mua * ib(tb - (eb + pb[k]), px - xv);
       }
       if (lane == 0) {
         G[yv * px] = -mub * ia(0, 0) - mua * ib_px;
@@ -571,8 +563,8 @@ mfma_prep_same_kernel(MfmaArgs a) {
     if (yv == 0) {
 #pragma unroll
       for (int k = 0; k < kPrepCols; ++k) {
-        const int xv = xl + 64 * k + 1;
-        if (xv < px) rcolB[xv] = mua * ib(tb - pb[k], px - xv);
+        const int xv = xl + k + 1;
+        if (xv < px) rcolB[xv] = mua * ib(tb - (eb + pb[k]), px - xv);
       }
       if (lane == 0) {
         rcolB[0] = mua * ib_px;
@@ -582,8 +574,8 @@ mfma_prep_same_kernel(MfmaArgs a) {
     if (yv == py) {
 #pragma unroll
       for (int k = 0; k < kPrepCols; ++k) {
-        const int xv = xl + 64 * k + 1;
-        if (xv < px) rcolA[xv] = -mub * ia(pa[k], xv);
+        const int xv = xl + k + 1;
+        if (xv < px) rcolA[xv] = -mub * ia(ea + pa[k], xv);
       }
       if (lane == 0) {
         rcolA[0] = -mub * ia(0, 0);
