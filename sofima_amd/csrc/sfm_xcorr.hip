@@ -39,7 +39,11 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
                   float* ov, unsigned int* maxima, void* ws);
 // Masked correlation: padded numerator / denominator / overlap + batch maxima.
 int mfma_i8_masked(const SfmXcorrDesc* d, void* ws, float* num, float* den,
-                   float* ov, unsigned int* maxima);
+                   float* ov, unsigned int* maxima, unsigned int* smax);
+// True when mfma_i8_masked takes its fast form for this call: `num` then
+// receives the final normalised surface, den / ov are not touched, and `smax`
+// (optional, zeroed by the caller) the ordered bits of every surface maximum.
+bool mfma_i8_masked_is_fast(const SfmXcorrDesc* d);
 }  // namespace sfm
 
 namespace {
@@ -725,7 +729,8 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
               long long bstride, int nd, const int* S, long long sn, int batch,
               const float* center,
               int min_distance, float threshold_rel, const int* radius,
-              float* out, hipStream_t st, bool first_pass_done = false) {
+              float* out, hipStream_t st, bool first_pass_done = false,
+              bool smax_done = false) {
   PeakArgs p;
   p.surf = surf;
   p.nd = nd;
@@ -753,13 +758,17 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
   p.best = w.best;
   p.out = out;
   if (!first_pass_done) {
-    SFM_HIP_CHECK(hipMemsetAsync(ws_base + w.zero_from, 0, w.zero_bytes, st));
-    if (sn >= (1LL << 18)) {
+    // smax_done: the producer of the surfaces already left their maxima in
+    // w.smax (and the per-batch state was cleared before it ran)
+    if (!smax_done)
+      SFM_HIP_CHECK(hipMemsetAsync(ws_base + w.zero_from, 0, w.zero_bytes, st));
+    if (sn >= (1LL << 18) || smax_done) {
       // large surfaces: ~32 K elements per workgroup
       const long long rows = (long long)S[0] * S[1];
       const int chunks = static_cast<int>(std::min<long long>(
           std::min<long long>(rows, 1024), std::max<long long>(1, sn >> 15)));
-      hipLaunchKernelGGL(peaks_max_kernel, dim3(chunks, batch), dim3(kBlock), 0, st, p);
+      if (!smax_done)
+        hipLaunchKernelGGL(peaks_max_kernel, dim3(chunks, batch), dim3(kBlock), 0, st, p);
       hipLaunchKernelGGL(peaks_scan_kernel, dim3(chunks, batch), dim3(kBlock), 0, st, p);
       hipLaunchKernelGGL(peaks_first_finish_kernel, dim3((batch + kBlock - 1) / kBlock),
                          dim3(kBlock), 0, st, p);
@@ -815,8 +824,10 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
     if (masked) {
       int rows = 0, pitch = 0;
       sfm::mfma_i8_padded_dims(d, &rows, &pitch);
-      w.den = c.take<float>(B * (size_t)rows * pitch);
-      w.ov = c.take<float>(B * (size_t)rows * pitch);
+      if (!sfm::mfma_i8_masked_is_fast(d)) {
+        w.den = c.take<float>(B * (size_t)rows * pitch);
+        w.ov = c.take<float>(B * (size_t)rows * pitch);
+      }
       w.maxima = c.take<unsigned int>(2);
     }
   } else {
@@ -864,14 +875,16 @@ int check_desc(const SfmXcorrDesc* d) {
 }
 
 int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
-                    float* surface, const sfm::FusedPeaks* fused = nullptr) {
+                    float* surface, const sfm::FusedPeaks* fused = nullptr,
+                    unsigned int* smax = nullptr) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const bool masked = is_masked(d);
   if (use_mfma(d) && masked) {
     // eight exact integer correlations on the matrix cores + Padfield assembly,
     // then the same batch-global finalize step as the direct path
-    if (int rc = sfm::mfma_i8_masked(d, w.mfma, surface, w.den, w.ov, w.maxima))
+    if (int rc = sfm::mfma_i8_masked(d, w.mfma, surface, w.den, w.ov, w.maxima, smax))
       return rc;
+    if (sfm::mfma_i8_masked_is_fast(d)) return SFM_OK;  // already normalised
     const long long n = (long long)d->batch * w.srows * w.spitch;
     const int fg = (int)((n + kBlock - 1) / kBlock > 4096 ? 4096
                                                            : (n + kBlock - 1) / kBlock);
@@ -1021,10 +1034,13 @@ int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
   // surface; its per-batch state has to be cleared before the launch.
   const bool fuse = use_mfma(d) && !is_masked(d);
   sfm::FusedPeaks fp;
-  if (fuse) {
+  // masked matrix-core path, fast form: the surface maxima come with the surfaces
+  const bool smax_pre = use_mfma(d) && is_masked(d) && sfm::mfma_i8_masked_is_fast(d);
+  if (fuse || smax_pre)
     SFM_HIP_CHECK(hipMemsetAsync(static_cast<char*>(d->workspace) + w.peaks.zero_from,
                                  0, w.peaks.zero_bytes,
                                  static_cast<hipStream_t>(d->stream)));
+  if (fuse) {
     fp.cand_cap = kCandCap;
     fp.idx1 = w.peaks.idx1;
     fp.v1 = w.peaks.v1;
@@ -1040,7 +1056,9 @@ int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
     fp.hot_val = w.peaks.hot_val;
     fp.hot_idx = w.peaks.hot_idx;
   }
-  if (int rc = compute_surface(d, g, w, w.surface, fuse ? &fp : nullptr)) return rc;
+  if (int rc = compute_surface(d, g, w, w.surface, fuse ? &fp : nullptr,
+                               smax_pre ? w.peaks.smax : nullptr))
+    return rc;
   float center[3];
   for (int i = 0; i < 3; ++i)
     center[i] = static_cast<float>((g.P[i] + g.Q[i]) / 2 - 1);
@@ -1048,7 +1066,7 @@ int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
                    w.spitch, (long long)w.srows * w.spitch, d->ndim, g.S, g.Sn,
                    d->batch, center, d->min_distance,
                    d->threshold_rel, d->peak_radius, peaks,
-                   static_cast<hipStream_t>(d->stream), fuse);
+                   static_cast<hipStream_t>(d->stream), fuse, smax_pre);
 }
 
 }  // namespace

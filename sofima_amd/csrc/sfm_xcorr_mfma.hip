@@ -182,6 +182,11 @@ struct MfmaArgs {
   int mshape[2][2];
   int plane[2];       // Plane of the pre / post operand
   int* raw_out;       // [batch, rows, sx_pitch] int32 products
+  int* nvalid;        // [batch, 2] un-masked pixels per patch side (prep output)
+  // dirty-patch passes: item i = (slot i / 7, pass 1 + i % 7) over the patches
+  // list[0 .. *n_list); products go to raw_out[(slot * 7 + pass - 1)]
+  const int* list;
+  const int* n_list;
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
   // dynamic patch queue (NULL: static striding over the workgroups)
   int* work_counter;
@@ -780,6 +785,7 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_masked_kernel(MfmaArgs a) 
     p->x0[s] = x0;
     p->my0[s] = my0;
     p->mx0[s] = mx0;
+    if (a.nvalid) a.nvalid[b * 2 + s] = cnt;
     int c = 128;
     float mu = 0.f;
     if (cnt > 0) {
@@ -813,6 +819,41 @@ struct AssembleArgs {
   unsigned int* maxima;    // batch-global max |den|, max overlap (float bits)
 };
 
+// One element of the Padfield assembly in double precision.  Inputs are exact
+// integers: xc = sum a'b', s_a / s_b = sums of a' / b', sq_a / sq_b = sums of
+// a'^2 / b'^2, n = number of pixel pairs, all over the pairs valid on both
+// sides at this shift; mua / mub = mean - centre of the two patches.
+struct PadfieldTerms {
+  double num;
+  float den, ov;
+};
+
+__device__ __forceinline__ PadfieldTerms padfield_terms(double xc_raw, double s_a,
+                                                        double s_b, double n_ov,
+                                                        double sq_a, double sq_b,
+                                                        double mua, double mub) {
+  PadfieldTerms t;
+  const double ov = fmax(n_ov, 1.1920928955078125e-07);
+  const double r_ov = 1.0 / ov;
+  const double mc_p = s_a - mua * n_ov;   // sum of a0 over curr-valid overlap
+  const double mc_c = s_b - mub * n_ov;
+  const double xc = xc_raw - mub * s_a - mua * s_b + mua * mub * n_ov;
+  t.num = xc - mc_p * mc_c * r_ov;
+  const double sa2 = sq_a - 2.0 * mua * s_a + mua * mua * n_ov;
+  const double sb2 = sq_b - 2.0 * mub * s_b + mub * mub * n_ov;
+  const double pd = fmax(sa2 - mc_p * mc_p * r_ov, 0.0);
+  const double cd = fmax(sb2 - mc_c * mc_c * r_ov, 0.0);
+  // the product is formed in double (no cancellation left), the root in float
+  t.den = sqrtf(static_cast<float>(pd * cd));
+  t.ov = static_cast<float>(ov);
+  return t;
+}
+
+// SQHI / SQLO products back to the sum of squares (exact in double).
+__device__ __forceinline__ double square_sum(int hi, int lo, double n_ov) {
+  return 128.0 * static_cast<double>(hi) + static_cast<double>(lo) + 8192.0 * n_ov;
+}
+
 __global__ void __launch_bounds__(kThreads) mfma_assemble_masked_kernel(AssembleArgs g) {
   const long long total = g.elems * g.n_patches;
   float mden = 0.f, mov = 0.f;
@@ -820,27 +861,18 @@ __global__ void __launch_bounds__(kThreads) mfma_assemble_masked_kernel(Assemble
        i += (long long)gridDim.x * kThreads) {
     const int b = static_cast<int>(i / g.elems);
     const double mua = g.pp[b].mu[0], mub = g.pp[b].mu[1];
-    double P[8];
+    int P[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) P[k] = static_cast<double>(g.raw[k * g.plane_stride + i]);
+    for (int k = 0; k < 8; ++k) P[k] = g.raw[k * g.plane_stride + i];
     const double n_ov = P[3];
-    const double ov = fmax(n_ov, 1.1920928955078125e-07);
-    const double mc_p = P[1] - mua * n_ov;   // sum of a0 over curr-valid overlap
-    const double mc_c = P[2] - mub * n_ov;
-    const double xc = P[0] - mub * P[1] - mua * P[2] + mua * mub * n_ov;
-    const double num = xc - mc_p * mc_c / ov;
-    const double sa2 = 128.0 * P[4] + P[5] + 8192.0 * n_ov - 2.0 * mua * P[1] +
-                       mua * mua * n_ov;
-    const double sb2 = 128.0 * P[6] + P[7] + 8192.0 * n_ov - 2.0 * mub * P[2] +
-                       mub * mub * n_ov;
-    const double pd = fmax(sa2 - mc_p * mc_p / ov, 0.0);
-    const double cd = fmax(sb2 - mc_c * mc_c / ov, 0.0);
-    const float den = static_cast<float>(sqrt(pd * cd));
-    g.num[i] = static_cast<float>(num);
-    g.den[i] = den;
-    g.ov[i] = static_cast<float>(ov);
-    mden = fmaxf(mden, fabsf(den));
-    mov = fmaxf(mov, static_cast<float>(ov));
+    const PadfieldTerms t =
+        padfield_terms(P[0], P[1], P[2], n_ov, square_sum(P[4], P[5], n_ov),
+                       square_sum(P[6], P[7], n_ov), mua, mub);
+    g.num[i] = static_cast<float>(t.num);
+    g.den[i] = t.den;
+    g.ov[i] = t.ov;
+    mden = fmaxf(mden, t.den);
+    mov = fmaxf(mov, t.ov);
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
@@ -850,6 +882,230 @@ __global__ void __launch_bounds__(kThreads) mfma_assemble_masked_kernel(Assemble
   if ((threadIdx.x & 63) == 0) {
     atomicMax(&g.maxima[0], __float_as_uint(mden));
     atomicMax(&g.maxima[1], __float_as_uint(mov));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Masked path, fast form.  A patch without a masked pixel on either side
+// ("clean") needs only ONE matrix pass (a' * b'): the other seven Padfield
+// products are box sums of a', a'^2, b', b'^2 over the overlap rectangle, read
+// from per-patch integral images.  Patches with masked pixels ("dirty") take
+// all eight passes.  The assembly runs twice over the integer data (batch
+// maxima first, then the normalised surface) instead of spilling numerator,
+// denominator and overlap surfaces in between.
+// ---------------------------------------------------------------------------
+struct MaskedFastArgs {
+  const PatchParams* pp;
+  const int* nvalid;    // [batch, 2]
+  int* slot;            // [batch] dirty slot or -1
+  int* list;            // [batch] dirty patches in patch order
+  int* n_list;
+  int* tab;             // [batch, 4, tab_elems] integral images IA, IA2, IB, IB2
+  long long tab_elems;  // (Py + 1) * (Px + 1)
+  const int* raw0;      // [batch, elems]   a' * b'
+  const int* rawd;      // [n dirty, 7, elems]
+  long long elems;      // padded surface elements per patch
+  int pitch;
+  const unsigned char* img[2];
+  int ishape[2][2];
+  int P[2], Q[2], S[2];
+  int batch;
+  unsigned int* maxima;
+  float* out;           // [batch, elems] final normalised surface
+  unsigned int* smax;   // [batch] or NULL: per-surface maximum (ordered bits)
+};
+
+// One workgroup: dirty slots in patch order (batch <= 1024).
+__global__ void __launch_bounds__(1024) masked_classify_kernel(MaskedFastArgs g) {
+  __shared__ int wsum[16];
+  const int b = threadIdx.x, lane = b & 63, wave = b >> 6;
+  const bool dirty = b < g.batch && (g.nvalid[2 * b] < g.P[0] * g.P[1] ||
+                                     g.nvalid[2 * b + 1] < g.Q[0] * g.Q[1]);
+  const int incl = wave_scan_incl(dirty ? 1 : 0);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  if (b < g.batch) {
+    const int s = base + incl - 1;
+    g.slot[b] = dirty ? s : -1;
+    if (dirty) g.list[s] = b;
+  }
+  if (b == 1023) *g.n_list = base + incl;
+}
+
+// Integral images (zero first row / column) of a', a'^2, b', b'^2 of the clean
+// patches: wave w of the workgroup builds table w, walking down the rows with
+// the running column sums of the row prefixes in registers.
+__global__ void __launch_bounds__(kThreads) masked_tables_kernel(MaskedFastArgs g) {
+  const int b = blockIdx.x;
+  if (g.slot[b] >= 0) return;
+  const int lane = threadIdx.x & 63;
+  const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = t >> 1;
+  const bool sq = t & 1;
+  const int py = s ? g.Q[0] : g.P[0], px = s ? g.Q[1] : g.P[1];
+  const int ip = px + 1;
+  const PatchParams pp = g.pp[b];
+  const int c = pp.c[s];
+  const int W = g.ishape[s][1];
+  const unsigned char* src = g.img[s] + (long long)pp.y0[s] * W + pp.x0[s];
+  int* I = g.tab + ((long long)b * 4 + t) * g.tab_elems;
+  constexpr int kCols = 3;  // px <= 192
+  constexpr int kAhead = 16;  // rows in flight per wave (the loads are latency bound)
+  for (int x = lane; x <= px; x += 64) I[x] = 0;
+  int acc[kCols] = {0, 0, 0};
+  for (int y0 = 0; y0 < py; y0 += kAhead) {
+    int pix[kAhead][kCols];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u)
+#pragma unroll
+      for (int k = 0; k < kCols; ++k) {
+        const int x = lane + 64 * k;
+        pix[u][k] = (y0 + u < py && x < px) ? src[(long long)(y0 + u) * W + x] - c : 0;
+      }
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int y = y0 + u;
+      if (y >= py) break;
+      int carry = 0;
+#pragma unroll
+      for (int k = 0; k < kCols; ++k) {
+        const int x = lane + 64 * k;
+        const int v = sq ? pix[u][k] * pix[u][k] : pix[u][k];
+        const int r = wave_scan_incl(v) + carry;
+        carry = __builtin_amdgcn_readlane(r, 63);
+        acc[k] += r;
+        if (x < px) I[(y + 1) * ip + x + 1] = acc[k];
+      }
+      if (lane == 0) I[(y + 1) * ip] = 0;
+    }
+  }
+}
+
+// Padfield assembly from the integer data.  FINAL = false: batch maxima of the
+// denominator and the overlap only; FINAL = true: the normalised surface
+// (flow_field.py:132-156) with the tolerance / overlap threshold of those maxima.
+// Grid (row blocks, batch); a wave takes whole surface rows; for a clean patch
+// it first differences the integral images over the row range of the shift
+// into four 1-D arrays in LDS, so that a box sum is two LDS reads.
+constexpr int kAsmRowsPerWave = 4;
+constexpr int kAsmMaxCols = 208;
+
+template <bool FINAL>
+__global__ void __launch_bounds__(kThreads) masked_phase_kernel(MaskedFastArgs g) {
+  __shared__ int D[kWaves][4][kAsmMaxCols];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Py = g.P[0], Px = g.P[1], Qy = g.Q[0], Qx = g.Q[1];
+  const int Sy = g.S[0], Sx = g.S[1];
+  const int slot = g.slot[b];
+  const double mua = g.pp[b].mu[0], mub = g.pp[b].mu[1];
+  const int* raw0 = g.raw0 + (long long)b * g.elems;
+  const int* rawd = slot >= 0 ? g.rawd + (long long)slot * 7 * g.elems : nullptr;
+  const int* IA = g.tab + (long long)b * 4 * g.tab_elems;
+  const int* IA2 = IA + g.tab_elems;
+  const int* IB = IA2 + g.tab_elems;
+  const int* IB2 = IB + g.tab_elems;
+  const int ipa = Px + 1, ipb = Qx + 1;
+  float tol = 0.f, px_thr = 0.f;
+  if (FINAL) {
+    tol = 1e3f * 1.1920928955078125e-07f * __uint_as_float(g.maxima[0]);
+    px_thr = 0.3f * __uint_as_float(g.maxima[1]);
+  }
+  float mden = 0.f, mov = 0.f, rmax = -INFINITY;
+  for (int i = 0; i < kAsmRowsPerWave; ++i) {
+    const int ky = (blockIdx.x * kWaves + wave) * kAsmRowsPerWave + i;
+    const bool row_ok = ky < Sy;
+    const int dy = ky - (Qy - 1);
+    const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
+    const int ny = ya1 - ya0;
+    if (slot < 0) {
+      __syncthreads();  // previous row's arrays consumed
+      if (row_ok) {
+        for (int x = lane; x <= Px; x += 64) {
+          D[wave][0][x] = IA[ya1 * ipa + x] - IA[ya0 * ipa + x];
+          D[wave][1][x] = IA2[ya1 * ipa + x] - IA2[ya0 * ipa + x];
+        }
+        for (int x = lane; x <= Qx; x += 64) {
+          D[wave][2][x] = IB[(ya1 - dy) * ipb + x] - IB[(ya0 - dy) * ipb + x];
+          D[wave][3][x] = IB2[(ya1 - dy) * ipb + x] - IB2[(ya0 - dy) * ipb + x];
+        }
+      }
+      __syncthreads();
+    }
+    if (!row_ok) continue;
+    const long long row = (long long)ky * g.pitch;
+    for (int kx = lane; kx < Sx; kx += 64) {
+      const int xc_raw = raw0[row + kx];
+      int s_a, s_b, n, sqa_i = 0, sqb_i = 0, hi_a = 0, lo_a = 0, hi_b = 0, lo_b = 0;
+      if (slot < 0) {
+        const int dx = kx - (Qx - 1);
+        const int xa0 = max(0, dx), xa1 = min(Px, Qx + dx);
+        const int xb0 = xa0 - dx, xb1 = xa1 - dx;
+        n = ny * (xa1 - xa0);
+        s_a = D[wave][0][xa1] - D[wave][0][xa0];
+        sqa_i = D[wave][1][xa1] - D[wave][1][xa0];
+        s_b = D[wave][2][xb1] - D[wave][2][xb0];
+        sqb_i = D[wave][3][xb1] - D[wave][3][xb0];
+      } else {
+        const int* p = rawd + row + kx;
+        s_a = p[0];
+        s_b = p[g.elems];
+        n = p[2 * g.elems];
+        hi_a = p[3 * g.elems];
+        lo_a = p[4 * g.elems];
+        hi_b = p[5 * g.elems];
+        lo_b = p[6 * g.elems];
+      }
+      const double n_ov = n;
+      const double sq_a = slot < 0 ? static_cast<double>(sqa_i) : square_sum(hi_a, lo_a, n_ov);
+      const double sq_b = slot < 0 ? static_cast<double>(sqb_i) : square_sum(hi_b, lo_b, n_ov);
+      const PadfieldTerms t = padfield_terms(xc_raw, s_a, s_b, n_ov, sq_a, sq_b, mua, mub);
+      if (FINAL) {
+        float v = t.den > tol ? static_cast<float>(t.num) / t.den : 0.f;
+        v = fminf(fmaxf(v, -1.f), 1.f);
+        if (t.ov < px_thr) v = 0.f;
+        g.out[(long long)b * g.elems + row + kx] = v;
+        rmax = fmaxf(rmax, v);
+      } else {
+        mden = fmaxf(mden, t.den);
+        mov = fmaxf(mov, t.ov);
+      }
+    }
+  }
+  if (FINAL) {
+    // surface maximum for the peak search (monotonic uint image of the float)
+    if (g.smax) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, d, 64));
+      if (lane == 0 && rmax > -INFINITY) {
+        const unsigned u = __float_as_uint(rmax);
+        atomicMax(&g.smax[b], (u & 0x80000000u) ? ~u : (u | 0x80000000u));
+      }
+    }
+  } else {
+    // one pair of atomics per workgroup, and only when it can raise a maximum
+    // (tens of thousands of same-address atomics serialise in the L2)
+    __shared__ float red[2][kWaves];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      mden = fmaxf(mden, __shfl_xor(mden, d, 64));
+      mov = fmaxf(mov, __shfl_xor(mov, d, 64));
+    }
+    if (lane == 0) {
+      red[0][wave] = mden;
+      red[1][wave] = mov;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      float m = red[threadIdx.x][0];
+      for (int w = 1; w < kWaves; ++w) m = fmaxf(m, red[threadIdx.x][w]);
+      const unsigned bits = __float_as_uint(m);
+      if (bits > __atomic_load_n(&g.maxima[threadIdx.x], __ATOMIC_RELAXED))
+        atomicMax(&g.maxima[threadIdx.x], bits);
+    }
   }
 }
 
@@ -1064,7 +1320,23 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     else
       __builtin_amdgcn_s_setprio(0);
   }
-  for (int b = blockIdx.x; b < a.batch; b = next_patch(a, b, next_lds)) {
+  // Work items: patches, or (dirty patch, operand-plane pair) for the masked
+  // passes that only patches with masked pixels need.
+  const int n_items = (RAW && a.list) ? 7 * *a.n_list : a.batch;
+  for (int item = blockIdx.x; item < n_items; item = next_patch(a, item, next_lds)) {
+    int b = item;
+    int plane0 = a.plane[0], plane1 = a.plane[1];
+    if (RAW && a.list) {
+      const int slot = item / 7, pass = item - 7 * slot;  // kMaskedPasses[1 + pass]
+      b = a.list[slot];
+      plane0 = pass == 0 ? kPlaneVal : pass == 3 ? kPlaneSqHi : pass == 4 ? kPlaneSqLo
+                                                                          : kPlaneValid;
+      plane1 = (pass == 0 || pass == 2) ? kPlaneValid
+               : pass == 1              ? kPlaneVal
+               : pass == 5              ? kPlaneSqHi
+               : pass == 6              ? kPlaneSqLo
+                                        : kPlaneValid;
+    }
 #ifdef SFM_MFMA_TIMING
     ++npat;
 #endif
@@ -1080,11 +1352,11 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     if (RAW) {
       stage_plane(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], a.mask[0],
                   (long long)a.mshape[0][0] * a.mshape[0][1], a.mshape[0][1],
-                  pp.my0[0], pp.mx0[0], Py, Px, pp.c[0], a.plane[0], A_lds, a.pa,
+                  pp.my0[0], pp.mx0[0], Py, Px, pp.c[0], plane0, A_lds, a.pa,
                   kPadTop, 0, NCA);
       stage_plane(a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], a.mask[1],
                   (long long)a.mshape[1][0] * a.mshape[1][1], a.mshape[1][1],
-                  pp.my0[1], pp.mx0[1], Qy, Qx, pp.c[1], a.plane[1], B_lds, a.pb, 0,
+                  pp.my0[1], pp.mx0[1], Qy, Qx, pp.c[1], plane1, B_lds, a.pb, 0,
                   a.ml, (Qx + 15) / 16);
     } else {
       // Everything staging needs from global memory is requested before the
@@ -1401,7 +1673,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #endif
       if (RAW) {
         // exact integer products; the Padfield assembly happens afterwards
-        int* raw = a.raw_out + b * a.s_stride;
+        int* raw = a.raw_out + (a.list ? item : b) * a.s_stride;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -1959,20 +2231,45 @@ const int kMaskedPasses[8][2] = {
     {kPlaneValid, kPlaneValid}, {kPlaneSqHi, kPlaneValid}, {kPlaneSqLo, kPlaneValid},
     {kPlaneValid, kPlaneSqHi},  {kPlaneValid, kPlaneSqLo}};
 
+// Fast form (clean patches take one pass): used for batches up to this size; it
+// keeps the integer products of the whole batch until the batch maxima are known.
+constexpr int kMaskedFastMax = 1024;
+
+bool masked_fast(const SfmXcorrDesc* d) {
+  const char* e = std::getenv("SFM_MASKED_FAST");  // "0": eight passes for every patch
+  return !(e && e[0] == '0') && d->batch <= kMaskedFastMax;
+}
+
 struct MaskedWs {
   PatchParams* pp;
-  int* raw;  // [8][kMaskedChunk][rows * pitch]
+  int* raw;  // eight-pass form: [8][kMaskedChunk][rows * pitch]
+  // fast form
+  int *nvalid, *slot, *list, *n_list, *tab, *raw0, *rawd;
+  long long tab_elems;
   size_t bytes;
 };
 
 MaskedWs carve_masked(const SfmXcorrDesc* d, void* base) {
   sfm::Carver c(base);
   MaskedWs w;
+  std::memset(&w, 0, sizeof(w));
   int rows = 0, pitch = 0;
   sfm::mfma_i8_padded_dims(d, &rows, &pitch);
-  const size_t chunk = std::min<size_t>(d->batch, kMaskedChunk);
-  w.pp = c.take<PatchParams>(d->batch);
-  w.raw = c.take<int>((size_t)8 * chunk * rows * pitch);
+  const size_t B = d->batch;
+  w.pp = c.take<PatchParams>(B);
+  if (masked_fast(d)) {
+    w.nvalid = c.take<int>(2 * B);
+    w.slot = c.take<int>(B);
+    w.list = c.take<int>(B);
+    w.n_list = c.take<int>(16);
+    w.tab_elems = (long long)(d->patch[1] + 1) * (d->patch[2] + 1);
+    w.tab = c.take<int>(B * 4 * (size_t)w.tab_elems);
+    w.raw0 = c.take<int>(B * (size_t)rows * pitch);
+    w.rawd = c.take<int>(B * 7 * (size_t)rows * pitch);
+  } else {
+    const size_t chunk = std::min<size_t>(B, kMaskedChunk);
+    w.raw = c.take<int>((size_t)8 * chunk * rows * pitch);
+  }
   w.bytes = c.total();
   return w;
 }
@@ -2094,8 +2391,10 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
 // Masked (Padfield) correlation on the matrix cores.  Outputs, all padded to
 // whole tiles [batch, rows, pitch]: num (numerator), den, ov, and the
 // batch-global maxima the finalize step needs (flow_field.py:137, 151).
+bool mfma_i8_masked_is_fast(const SfmXcorrDesc* d) { return masked_fast(d); }
+
 int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* num, float* den,
-                   float* ov, unsigned int* maxima) {
+                   float* ov, unsigned int* maxima, unsigned int* smax) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const int vi = pick_variant(d->patch[2], d->post_patch[2]);
   if (vi < 0) return fail(SFM_ERR_INVALID, "patch too wide for the MFMA path");
@@ -2109,6 +2408,7 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* num, float* den,
       return fail(SFM_ERR_INVALID, "mask smaller than patch");
   a.pp = w.pp;
   a.prio_mode = 1;
+  a.nvalid = w.nvalid;
   hipLaunchKernelGGL(mfma_prep_masked_kernel, dim3(d->batch, 2), dim3(kThreads), 0,
                      st, a);
   SFM_LAUNCH_CHECK();
@@ -2117,6 +2417,52 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* num, float* den,
   a.r_bytes = static_cast<int>(r_bytes);
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
   const long long elems = a.s_stride;
+  if (masked_fast(d)) {
+    // `num` receives the FINAL surface; den / ov are not used.
+    MaskedFastArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.pp = w.pp;
+    g.nvalid = w.nvalid;
+    g.slot = w.slot;
+    g.list = w.list;
+    g.n_list = w.n_list;
+    g.tab = w.tab;
+    g.tab_elems = w.tab_elems;
+    g.raw0 = w.raw0;
+    g.rawd = w.rawd;
+    g.elems = elems;
+    g.pitch = a.sx_pitch;
+    for (int k = 0; k < 2; ++k) {
+      g.img[k] = a.img[k];
+      g.ishape[k][0] = a.ishape[k][0];
+      g.ishape[k][1] = a.ishape[k][1];
+      g.P[k] = a.P[k];
+      g.Q[k] = a.Q[k];
+      g.S[k] = a.S[k];
+    }
+    g.batch = d->batch;
+    g.maxima = maxima;
+    g.out = num;
+    g.smax = smax;
+    hipLaunchKernelGGL(masked_classify_kernel, dim3(1), dim3(1024), 0, st, g);
+    hipLaunchKernelGGL(masked_tables_kernel, dim3(d->batch), dim3(kThreads), 0, st, g);
+    SFM_LAUNCH_CHECK();
+    MfmaArgs c = a;
+    c.plane[0] = kPlaneVal;
+    c.plane[1] = kPlaneVal;
+    c.raw_out = w.raw0;
+    if (int rc = launch_mode(vi, c, kModeRaw, d->batch, lds, st)) return rc;
+    c.raw_out = w.rawd;
+    c.list = w.list;
+    c.n_list = w.n_list;
+    if (int rc = launch_mode(vi, c, kModeRaw, 7 * d->batch, lds, st)) return rc;
+    const int rows_per_wg = kWaves * kAsmRowsPerWave;
+    const dim3 grid((a.S[0] + rows_per_wg - 1) / rows_per_wg, d->batch);
+    hipLaunchKernelGGL(masked_phase_kernel<false>, grid, dim3(kThreads), 0, st, g);
+    hipLaunchKernelGGL(masked_phase_kernel<true>, grid, dim3(kThreads), 0, st, g);
+    SFM_LAUNCH_CHECK();
+    return SFM_OK;
+  }
   for (int lo = 0; lo < d->batch; lo += kMaskedChunk) {
     const int nb = std::min(kMaskedChunk, d->batch - lo);
     const long long plane_stride = (long long)nb * elems;

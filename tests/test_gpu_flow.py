@@ -766,3 +766,88 @@ def test_sharpness_numerator_and_window_min_separately(gpu):
     wg, ww = g[y0:y0 + 11, x0:x0 + 11], w[y0:y0 + 11, x0:x0 + 11]
     np.testing.assert_allclose(wg.min(), ww.min(), atol=2e-6 * peak)
     np.testing.assert_allclose(wg, ww, atol=2e-6 * peak)
+
+
+def _masked_patch_batch(seed, b, py, px, qy, qx):
+  """Textured uint8 patch batch; every third patch has no masked pixel, the
+  others have masked pixels on the pre side, the post side or both."""
+  from scipy import ndimage
+  rng = np.random.default_rng(seed)
+  base = ndimage.gaussian_filter(rng.standard_normal((b, py + 8, px + 8)), (0, 1.5, 1.5))
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  prev = base[:, 2:2 + py, 3:3 + px].copy()
+  oy, ox = (py - qy) // 2, (px - qx) // 2
+  curr = base[:, 4 + oy:4 + oy + qy, 1 + ox:1 + ox + qx].copy()
+  prev[0, :3] = 0        # full-range pixels: a - centre = -128
+  prev[0, 3:6] = 255
+  pm = np.zeros(prev.shape, bool)
+  cm = np.zeros(curr.shape, bool)
+  for k in range(b):
+    kind = k % 3           # 0: clean
+    if kind == 0:
+      continue
+    if kind == 1 or k % 5 == 0:
+      pm[k, py // 4:py // 2, px // 3:px // 3 + 9] = True
+      pm[k][rng.random((py, px)) < 0.02] = True
+    if kind == 2:
+      cm[k, :qy // 5] = True
+      cm[k][rng.random((qy, qx)) < 0.01] = True
+  return prev, curr, pm, cm
+
+
+@pytest.mark.parametrize('py,px,qy,qx', [(160, 160, 160, 160), (64, 80, 40, 64),
+                                         (48, 48, 48, 48), (96, 96, 96, 80)])
+def test_masked_clean_patch_shortcut_is_bit_identical(gpu, monkeypatch, py, px, qy, qx):
+  """Patches without masked pixels take ONE matrix pass + box sums instead of
+  eight passes: same surface, bit for bit, as the eight-pass form; both agree
+  with the oracle."""
+  from sofima_amd import flow_field
+  prev, curr, pm, cm = _masked_patch_batch(py + qx, 13, py, px, qy, qx)
+  monkeypatch.setenv('SFM_MASKED_FAST', '0')
+  eight = flow_field.masked_xcorr(prev, curr, pm, cm, mean=None)
+  monkeypatch.delenv('SFM_MASKED_FAST')
+  fast = flow_field.masked_xcorr(prev, curr, pm, cm, mean=None)
+  np.testing.assert_array_equal(fast, eight)
+  assert np.abs(fast[0]).max() > 0.5       # a clean patch with a real peak
+  a0 = prev.astype(np.float32) - np.array(
+      [prev[k][~pm[k]].mean(dtype=np.float64) for k in range(len(prev))],
+      np.float32)[:, None, None]
+  b0 = curr.astype(np.float32) - np.array(
+      [curr[k][~cm[k]].mean(dtype=np.float64) for k in range(len(curr))],
+      np.float32)[:, None, None]
+  want = flow_oracle.xcorr_surface(a0, b0, pm, cm, dtype=np.float64, workers=4)
+  # elements whose denominator sits at the tolerance may flip to 0 on one side
+  flipped = (fast == 0) != (want == 0)
+  assert flipped.mean() < 1e-3, flipped.mean()
+  bad = (np.abs(fast - want) > 3e-5) & ~flipped
+  assert bad.mean() < 2e-5, (bad.mean(), np.abs(fast - want)[bad].max())
+  # all patches clean / all dirty / one-sided mask arrays
+  none = np.zeros_like(pm)
+  for masks in ((none, np.zeros_like(cm)), (pm, None), (None, cm)):
+    monkeypatch.setenv('SFM_MASKED_FAST', '0')
+    eight = flow_field.masked_xcorr(prev, curr, masks[0], masks[1], mean=None)
+    monkeypatch.delenv('SFM_MASKED_FAST')
+    fast = flow_field.masked_xcorr(prev, curr, masks[0], masks[1], mean=None)
+    np.testing.assert_array_equal(fast, eight)
+
+
+def test_masked_flow_mostly_clean_vs_oracle(gpu, monkeypatch):
+  """flow_field with mask_only_for_patch_selection=False and a localised mask
+  (most patches clean, the ones around the blob dirty) vs the oracle, and vs
+  the eight-pass form (identical output)."""
+  from sofima_amd import flow_field
+  pre, post = _em_pair(21, 600, 640, warp=2.0)
+  pre_mask = np.zeros(pre.shape, bool)
+  pre_mask[250:300, 280:360] = True
+  post_mask = np.zeros(post.shape, bool)
+  post_mask[255:310, 270:350] = True
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  kw = dict(pre_mask=pre_mask, post_mask=post_mask, batch_size=64,
+            mask_only_for_patch_selection=False)
+  got = calc.flow_field(pre, post, 160, 40, **kw)
+  monkeypatch.setenv('SFM_MASKED_FAST', '0')
+  eight = calc.flow_field(pre, post, 160, 40, **kw)
+  monkeypatch.delenv('SFM_MASKED_FAST')
+  np.testing.assert_array_equal(got, eight)
+  want = flow_oracle.flow_field(pre, post, 160, 40, workers=4, **kw)
+  check_flow(got, want, sharp_rtol=5e-3, ratio_rtol=2e-3)
