@@ -37,13 +37,11 @@ size_t fft_workspace_bytes(const SfmXcorrDesc* d);
 int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
                   const float* va, const float* vb, float* surface, float* den,
                   float* ov, unsigned int* maxima, void* ws);
-// Masked correlation: padded numerator / denominator / overlap + batch maxima.
-int mfma_i8_masked(const SfmXcorrDesc* d, void* ws, float* num, float* den,
-                   float* ov, unsigned int* maxima, unsigned int* smax);
-// True when mfma_i8_masked takes its fast form for this call: `num` then
-// receives the final normalised surface, den / ov are not touched, and `smax`
-// (optional, zeroed by the caller) the ordered bits of every surface maximum.
-bool mfma_i8_masked_is_fast(const SfmXcorrDesc* d);
+// Masked correlation: the normalised surface, padded to whole tiles; `smax`
+// (optional, zeroed by the caller) receives the ordered bits of every surface
+// maximum for the peak search.
+int mfma_i8_masked(const SfmXcorrDesc* d, void* ws, float* surface,
+                   unsigned int* maxima, unsigned int* smax);
 }  // namespace sfm
 
 namespace {
@@ -821,15 +819,7 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
   if (use_mfma(d)) {
     const size_t n = sfm::mfma_i8_workspace_bytes(d);
     w.mfma = c.take<char>(n);
-    if (masked) {
-      int rows = 0, pitch = 0;
-      sfm::mfma_i8_padded_dims(d, &rows, &pitch);
-      if (!sfm::mfma_i8_masked_is_fast(d)) {
-        w.den = c.take<float>(B * (size_t)rows * pitch);
-        w.ov = c.take<float>(B * (size_t)rows * pitch);
-      }
-      w.maxima = c.take<unsigned int>(2);
-    }
+    if (masked) w.maxima = c.take<unsigned int>(2);
   } else {
     w.a0 = c.take<float>(B * g.Pn);
     w.b0 = c.take<float>(B * g.Qn);
@@ -880,18 +870,8 @@ int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const bool masked = is_masked(d);
   if (use_mfma(d) && masked) {
-    // eight exact integer correlations on the matrix cores + Padfield assembly,
-    // then the same batch-global finalize step as the direct path
-    if (int rc = sfm::mfma_i8_masked(d, w.mfma, surface, w.den, w.ov, w.maxima, smax))
-      return rc;
-    if (sfm::mfma_i8_masked_is_fast(d)) return SFM_OK;  // already normalised
-    const long long n = (long long)d->batch * w.srows * w.spitch;
-    const int fg = (int)((n + kBlock - 1) / kBlock > 4096 ? 4096
-                                                           : (n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(masked_finalize_kernel, dim3(fg), dim3(kBlock), 0, st,
-                       surface, w.den, w.ov, w.maxima, n);
-    SFM_LAUNCH_CHECK();
-    return SFM_OK;
+    // exact integer correlations on the matrix cores + Padfield assembly
+    return sfm::mfma_i8_masked(d, w.mfma, surface, w.maxima, smax);
   }
   if (use_mfma(d)) return sfm::mfma_i8_surface(d, w.mfma, surface, fused);
   GatherArgs ga[2];
@@ -1034,8 +1014,8 @@ int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
   // surface; its per-batch state has to be cleared before the launch.
   const bool fuse = use_mfma(d) && !is_masked(d);
   sfm::FusedPeaks fp;
-  // masked matrix-core path, fast form: the surface maxima come with the surfaces
-  const bool smax_pre = use_mfma(d) && is_masked(d) && sfm::mfma_i8_masked_is_fast(d);
+  // masked matrix-core path: the surface maxima come with the surfaces
+  const bool smax_pre = use_mfma(d) && is_masked(d);
   if (fuse || smax_pre)
     SFM_HIP_CHECK(hipMemsetAsync(static_cast<char*>(d->workspace) + w.peaks.zero_from,
                                  0, w.peaks.zero_bytes,

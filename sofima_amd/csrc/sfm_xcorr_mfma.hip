@@ -181,10 +181,11 @@ struct MfmaArgs {
   const unsigned char* mask[2];
   int mshape[2][2];
   int plane[2];       // Plane of the pre / post operand
-  int* raw_out;       // [batch, rows, sx_pitch] int32 products
+  int* raw_out;       // [batch, raw_stride] int32 products (rows x sx_pitch used)
+  long long raw_stride;
   int* nvalid;        // [batch, 2] un-masked pixels per patch side (prep output)
-  // dirty-patch passes: item i = (slot i / 7, pass 1 + i % 7) over the patches
-  // list[0 .. *n_list); products go to raw_out[(slot * 7 + pass - 1)]
+  // extra masked passes: item i = (patch list[i] >> 3, kMaskedPasses[list[i] & 7]),
+  // i < *n_list; its products go to raw_out[i]
   const int* list;
   const int* n_list;
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
@@ -804,156 +805,144 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_masked_kernel(MfmaArgs a) 
   }
 }
 
-// Masked path: Padfield assembly (flow_field.py:113-131) from the eight exact
-// integer product surfaces, in double precision.
-//   raw: [8][n_patches][elems] in the order of kMaskedPasses below.
-struct AssembleArgs {
-  const int* raw;
-  long long plane_stride;  // ints between consecutive product surfaces
-  const PatchParams* pp;
-  long long elems;         // padded elements per patch
-  int n_patches;
-  float* num;              // out: numerator   [n_patches, elems]
-  float* den;              // out: denominator
-  float* ov;               // out: overlap
-  unsigned int* maxima;    // batch-global max |den|, max overlap (float bits)
-};
-
-// One element of the Padfield assembly in double precision.  Inputs are exact
-// integers: xc = sum a'b', s_a / s_b = sums of a' / b', sq_a / sq_b = sums of
-// a'^2 / b'^2, n = number of pixel pairs, all over the pairs valid on both
-// sides at this shift; mua / mub = mean - centre of the two patches.
+// One element of the Padfield assembly (flow_field.py:113-131).  Inputs are
+// exact integers: xc = sum a'b', s_a / s_b = sums of a' / b', sq_a / sq_b =
+// sums of a'^2 / b'^2, n = number of pixel pairs, all over the pairs valid on
+// both sides at this shift (a', b' = pixel - integer centre).
+//
+// The reference subtracts the masked patch means first and then removes the
+// overlap means again; in exact arithmetic the patch means (and the centres)
+// cancel, and multiplying numerator and denominator by n leaves
+//     NCC = (n xc - s_a s_b) / sqrt((n sq_a - s_a^2)(n sq_b - s_b^2)),
+// three differences of integers below 2^53: exact in double, no division and
+// no cancellation error.  `den` (the reference's denominator, = den_n / n) is
+// only compared with the batch tolerance, so float precision is enough for it.
 struct PadfieldTerms {
-  double num;
+  double num_n;  // n * numerator
+  float den_n;   // n * denominator
   float den, ov;
 };
 
-__device__ __forceinline__ PadfieldTerms padfield_terms(double xc_raw, double s_a,
-                                                        double s_b, double n_ov,
-                                                        double sq_a, double sq_b,
-                                                        double mua, double mub) {
+__device__ __forceinline__ PadfieldTerms padfield_terms(int xc, int s_a, int s_b, int n,
+                                                        double sq_a, double sq_b) {
   PadfieldTerms t;
-  const double ov = fmax(n_ov, 1.1920928955078125e-07);
-  const double r_ov = 1.0 / ov;
-  const double mc_p = s_a - mua * n_ov;   // sum of a0 over curr-valid overlap
-  const double mc_c = s_b - mub * n_ov;
-  const double xc = xc_raw - mub * s_a - mua * s_b + mua * mub * n_ov;
-  t.num = xc - mc_p * mc_c * r_ov;
-  const double sa2 = sq_a - 2.0 * mua * s_a + mua * mua * n_ov;
-  const double sb2 = sq_b - 2.0 * mub * s_b + mub * mub * n_ov;
-  const double pd = fmax(sa2 - mc_p * mc_p * r_ov, 0.0);
-  const double cd = fmax(sb2 - mc_c * mc_c * r_ov, 0.0);
-  // the product is formed in double (no cancellation left), the root in float
-  t.den = sqrtf(static_cast<float>(pd * cd));
-  t.ov = static_cast<float>(ov);
+  const double nd = n, sa = s_a, sb = s_b;
+  const double pd = fmax(fma(nd, sq_a, -(sa * sa)), 0.0);
+  const double cd = fmax(fma(nd, sq_b, -(sb * sb)), 0.0);
+  t.num_n = fma(nd, static_cast<double>(xc), -(sa * sb));
+  t.den_n = __builtin_amdgcn_sqrtf(static_cast<float>(pd * cd));  // 1 ulp
+  t.ov = fmaxf(static_cast<float>(n), 1.1920928955078125e-07f);
+  t.den = t.den_n * __builtin_amdgcn_rcpf(t.ov);
   return t;
 }
 
 // SQHI / SQLO products back to the sum of squares (exact in double).
-__device__ __forceinline__ double square_sum(int hi, int lo, double n_ov) {
-  return 128.0 * static_cast<double>(hi) + static_cast<double>(lo) + 8192.0 * n_ov;
-}
-
-__global__ void __launch_bounds__(kThreads) mfma_assemble_masked_kernel(AssembleArgs g) {
-  const long long total = g.elems * g.n_patches;
-  float mden = 0.f, mov = 0.f;
-  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total;
-       i += (long long)gridDim.x * kThreads) {
-    const int b = static_cast<int>(i / g.elems);
-    const double mua = g.pp[b].mu[0], mub = g.pp[b].mu[1];
-    int P[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) P[k] = g.raw[k * g.plane_stride + i];
-    const double n_ov = P[3];
-    const PadfieldTerms t =
-        padfield_terms(P[0], P[1], P[2], n_ov, square_sum(P[4], P[5], n_ov),
-                       square_sum(P[6], P[7], n_ov), mua, mub);
-    g.num[i] = static_cast<float>(t.num);
-    g.den[i] = t.den;
-    g.ov[i] = t.ov;
-    mden = fmaxf(mden, t.den);
-    mov = fmaxf(mov, t.ov);
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    mden = fmaxf(mden, __shfl_xor(mden, d, 64));
-    mov = fmaxf(mov, __shfl_xor(mov, d, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(&g.maxima[0], __float_as_uint(mden));
-    atomicMax(&g.maxima[1], __float_as_uint(mov));
-  }
+__device__ __forceinline__ double square_sum(int hi, int lo, int n) {
+  return 128.0 * static_cast<double>(hi) + static_cast<double>(lo) +
+         8192.0 * static_cast<double>(n);
 }
 
 // ---------------------------------------------------------------------------
-// Masked path, fast form.  A patch without a masked pixel on either side
-// ("clean") needs only ONE matrix pass (a' * b'): the other seven Padfield
-// products are box sums of a', a'^2, b', b'^2 over the overlap rectangle, read
-// from per-patch integral images.  Patches with masked pixels ("dirty") take
-// all eight passes.  The assembly runs twice over the integer data (batch
-// maxima first, then the normalised surface) instead of spilling numerator,
-// denominator and overlap surfaces in between.
+// Masked path, fast form.  Of the eight Padfield products only a' * b' always
+// needs the matrix cores: a product with the VALID plane of a side WITHOUT
+// masked pixels is a box sum of the other operand over the overlap rectangle,
+// read from per-patch integral images.  Per patch:
+//   class 0  no masked pixel on either side   1 matrix pass, 4 tables
+//   class 1  pre side masked, post side clean 4 passes, 3 tables (pre planes)
+//   class 2  pre side clean, post side masked 4 passes, 3 tables (post planes)
+//   class 3  both sides masked                8 passes
+// The assembly runs twice over the integer data (batch maxima first, then the
+// normalised surface) instead of spilling numerator, denominator and overlap
+// surfaces in between.
 // ---------------------------------------------------------------------------
 struct MaskedFastArgs {
   const PatchParams* pp;
   const int* nvalid;    // [batch, 2]
-  int* slot;            // [batch] dirty slot or -1
-  int* list;            // [batch] dirty patches in patch order
-  int* n_list;
-  int* tab;             // [batch, 4, tab_elems] integral images IA, IA2, IB, IB2
-  long long tab_elems;  // (Py + 1) * (Px + 1)
+  int* cls;             // [batch] class
+  int* first;           // [batch] index of the patch's first extra product surface
+  int* items;           // extra passes: patch * 8 + index into kMaskedPasses
+  int* n_items;
+  int* tab;             // [batch, 4, tab_elems] inclusive integral images
+  long long tab_elems;  // Py * Px
   const int* raw0;      // [batch, elems]   a' * b'
-  const int* rawd;      // [n dirty, 7, elems]
+  const int* rawd;      // [n_items, elems] extra products
   long long elems;      // padded surface elements per patch
+  long long raw_stride; // ints between consecutive product surfaces
   int pitch;
   const unsigned char* img[2];
-  int ishape[2][2];
+  const unsigned char* mask[2];
+  int ishape[2][2], mshape[2][2];
   int P[2], Q[2], S[2];
   int batch;
+  int xcd_map;
+  int all_passes;       // test switch: every patch takes the eight passes (class 3)
+  int row_blocks;       // workgroups per surface in the assembly kernels
   unsigned int* maxima;
   float* out;           // [batch, elems] final normalised surface
   unsigned int* smax;   // [batch] or NULL: per-surface maximum (ordered bits)
 };
 
-// One workgroup: dirty slots in patch order (batch <= 1024).
+// One workgroup: classes and the list of extra passes in patch order.
 __global__ void __launch_bounds__(1024) masked_classify_kernel(MaskedFastArgs g) {
   __shared__ int wsum[16];
-  const int b = threadIdx.x, lane = b & 63, wave = b >> 6;
-  const bool dirty = b < g.batch && (g.nvalid[2 * b] < g.P[0] * g.P[1] ||
-                                     g.nvalid[2 * b + 1] < g.Q[0] * g.Q[1]);
-  const int incl = wave_scan_incl(dirty ? 1 : 0);
-  if (lane == 63) wsum[wave] = incl;
+  __shared__ int s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  if (b < g.batch) {
-    const int s = base + incl - 1;
-    g.slot[b] = dirty ? s : -1;
-    if (dirty) g.list[s] = b;
+  for (int b0 = 0; b0 < g.batch; b0 += 1024) {
+    const int b = b0 + threadIdx.x;
+    int cls = 0;
+    if (b < g.batch)
+      cls = g.all_passes ? 3
+                         : (g.nvalid[2 * b] < g.P[0] * g.P[1] ? 1 : 0) +
+                               (g.nvalid[2 * b + 1] < g.Q[0] * g.Q[1] ? 2 : 0);
+    const int k = b < g.batch ? (cls == 0 ? 0 : cls == 3 ? 7 : 3) : 0;
+    const int incl = wave_scan_incl(k);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = s_base;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const int first = base + incl - k;
+    if (b < g.batch) {
+      g.cls[b] = cls;
+      g.first[b] = first;
+      // class 1: VALID_A * {VAL, SQHI, SQLO}_B; class 2: {VAL, SQHI, SQLO}_A * VALID_B
+      for (int j = 0; j < k; ++j) {
+        const int pass =
+            cls == 3 ? 1 + j : cls == 1 ? (j == 0 ? 2 : 5 + j) : (j == 0 ? 1 : 3 + j);
+        g.items[first + j] = b * 8 + pass;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) s_base = base + incl;
+    __syncthreads();
   }
-  if (b == 1023) *g.n_list = base + incl;
+  if (threadIdx.x == 0) *g.n_items = s_base;
 }
 
-// Integral images (zero first row / column) of a', a'^2, b', b'^2 of the clean
-// patches: wave w of the workgroup builds table w, walking down the rows with
-// the running column sums of the row prefixes in registers.
+// Inclusive integral images T[y][x] = sum over rows <= y, columns <= x of the
+// planes a patch's box sums need (masked pixels count as 0): wave w of the
+// workgroup builds table w, walking down the rows with the running column sums
+// of the row prefixes in registers.
+//   class 0: a', a'^2, b', b'^2;  class 1: a', a'^2, valid_a;  class 2: b', b'^2, valid_b
 __global__ void __launch_bounds__(kThreads) masked_tables_kernel(MaskedFastArgs g) {
   const int b = blockIdx.x;
-  if (g.slot[b] >= 0) return;
+  const int cls = g.cls[b];
   const int lane = threadIdx.x & 63;
   const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int s = t >> 1;
-  const bool sq = t & 1;
+  if (cls == 3 || (cls != 0 && t == 3)) return;
+  const int s = cls == 0 ? t >> 1 : cls - 1;
+  const int kind = cls == 0 ? (t & 1) : t;  // 0 value, 1 square, 2 valid
   const int py = s ? g.Q[0] : g.P[0], px = s ? g.Q[1] : g.P[1];
-  const int ip = px + 1;
   const PatchParams pp = g.pp[b];
   const int c = pp.c[s];
-  const int W = g.ishape[s][1];
+  const int W = g.ishape[s][1], MW = g.mshape[s][1];
   const unsigned char* src = g.img[s] + (long long)pp.y0[s] * W + pp.x0[s];
-  int* I = g.tab + ((long long)b * 4 + t) * g.tab_elems;
+  const unsigned char* msk =
+      cls != 0 && g.mask[s] ? g.mask[s] + (long long)pp.my0[s] * MW + pp.mx0[s] : nullptr;
+  int* T = g.tab + ((long long)b * 4 + t) * g.tab_elems;
   constexpr int kCols = 3;  // px <= 192
-  constexpr int kAhead = 16;  // rows in flight per wave (the loads are latency bound)
-  for (int x = lane; x <= px; x += 64) I[x] = 0;
+  constexpr int kAhead = 8;
   int acc[kCols] = {0, 0, 0};
   for (int y0 = 0; y0 < py; y0 += kAhead) {
     int pix[kAhead][kCols];
@@ -961,8 +950,17 @@ __global__ void __launch_bounds__(kThreads) masked_tables_kernel(MaskedFastArgs 
     for (int u = 0; u < kAhead; ++u)
 #pragma unroll
       for (int k = 0; k < kCols; ++k) {
+        // unconditional loads from clamped addresses (a load under a per-lane
+        // condition ends up in its own block and the 24 loads of a batch would
+        // be waited for one by one)
         const int x = lane + 64 * k;
-        pix[u][k] = (y0 + u < py && x < px) ? src[(long long)(y0 + u) * W + x] - c : 0;
+        const bool in = y0 + u < py && x < px;
+        const int yc = min(y0 + u, py - 1), xc = min(x, px - 1);
+        int v = src[(long long)yc * W + xc] - c;
+        const int m = msk ? msk[(long long)yc * MW + xc] : 0;
+        const bool valid = in && m == 0;
+        v = kind == 2 ? (valid ? 1 : 0) : (valid ? v : 0);
+        pix[u][k] = v;
       }
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
@@ -972,13 +970,12 @@ __global__ void __launch_bounds__(kThreads) masked_tables_kernel(MaskedFastArgs 
 #pragma unroll
       for (int k = 0; k < kCols; ++k) {
         const int x = lane + 64 * k;
-        const int v = sq ? pix[u][k] * pix[u][k] : pix[u][k];
+        const int v = kind == 1 ? pix[u][k] * pix[u][k] : pix[u][k];
         const int r = wave_scan_incl(v) + carry;
         carry = __builtin_amdgcn_readlane(r, 63);
         acc[k] += r;
-        if (x < px) I[(y + 1) * ip + x + 1] = acc[k];
+        if (x < px) T[y * px + x] = acc[k];
       }
-      if (lane == 0) I[(y + 1) * ip] = 0;
     }
   }
 }
@@ -986,95 +983,179 @@ __global__ void __launch_bounds__(kThreads) masked_tables_kernel(MaskedFastArgs 
 // Padfield assembly from the integer data.  FINAL = false: batch maxima of the
 // denominator and the overlap only; FINAL = true: the normalised surface
 // (flow_field.py:132-156) with the tolerance / overlap threshold of those maxima.
-// Grid (row blocks, batch); a wave takes whole surface rows; for a clean patch
-// it first differences the integral images over the row range of the shift
-// into four 1-D arrays in LDS, so that a box sum is two LDS reads.
-constexpr int kAsmRowsPerWave = 4;
+// Grid (row blocks, batch); a wave takes whole surface rows; where box sums
+// are used it first differences the integral images over the row range of the
+// shift into 1-D arrays in LDS (D[x] = sum over those rows, columns < x), so
+// that a box sum is two LDS reads.
+constexpr int kAsmRowsPerWave = 8;
 constexpr int kAsmMaxCols = 208;
 
-template <bool FINAL>
-__global__ void __launch_bounds__(kThreads) masked_phase_kernel(MaskedFastArgs g) {
-  __shared__ int D[kWaves][4][kAsmMaxCols];
-  const int b = blockIdx.y;
+struct PhaseOut {
+  float mden, mov, rmax;
+};
+
+// The rows of one wave for a patch of class CLS (compile-time: every register
+// array below is indexed with constants).  D0 / D1: this wave's LDS arrays,
+//   class 0: D0[x] = (a', a'^2) sums, D1[x] = (b', b'^2) sums,
+//   class 1: D0[x] = (a', a'^2),      D1[x].x = valid_a count,
+//   class 2: D0[x] = (b', b'^2),      D1[x].x = valid_b count
+// over the row range of the shift and columns < x.
+template <int CLS, bool FINAL>
+__device__ __forceinline__ void masked_phase_rows(const MaskedFastArgs& g, int b,
+                                                  int row_block, int2* D0, int2* D1,
+                                                  float tol, float px_thr,
+                                                  PhaseOut* po) {
+  constexpr int kTabs = CLS == 0 ? 4 : CLS == 3 ? 0 : 3;
+  constexpr int kRaw = CLS == 0 ? 1 : CLS == 3 ? 8 : 4;  // product surfaces read
+  constexpr int kTabCols = 3;  // table columns per lane: Px <= 192
+  constexpr int kOutCols = 5;  // surface columns per lane: Sx <= 319 (patches <= 160 wide)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Py = g.P[0], Px = g.P[1], Qy = g.Q[0], Qx = g.Q[1];
   const int Sy = g.S[0], Sx = g.S[1];
-  const int slot = g.slot[b];
-  const double mua = g.pp[b].mu[0], mub = g.pp[b].mu[1];
-  const int* raw0 = g.raw0 + (long long)b * g.elems;
-  const int* rawd = slot >= 0 ? g.rawd + (long long)slot * 7 * g.elems : nullptr;
-  const int* IA = g.tab + (long long)b * 4 * g.tab_elems;
-  const int* IA2 = IA + g.tab_elems;
-  const int* IB = IA2 + g.tab_elems;
-  const int* IB2 = IB + g.tab_elems;
-  const int ipa = Px + 1, ipb = Qx + 1;
-  float tol = 0.f, px_thr = 0.f;
-  if (FINAL) {
-    tol = 1e3f * 1.1920928955078125e-07f * __uint_as_float(g.maxima[0]);
-    px_thr = 0.3f * __uint_as_float(g.maxima[1]);
-  }
-  float mden = 0.f, mov = 0.f, rmax = -INFINITY;
+  const int* raw0 = g.raw0 + (long long)b * g.raw_stride;
+  const int* rawd = g.rawd + (long long)g.first[b] * g.raw_stride;
+  const int* tab = g.tab + (long long)b * 4 * g.tab_elems;
+  // Every global load of a row is issued before the first one is used: the
+  // integral-image rows of the NEXT surface row travel while this one is
+  // assembled, and the product surfaces of a row are requested together.
+  int thi[kTabs ? kTabs : 1][kTabCols], tlo[kTabs ? kTabs : 1][kTabCols];
+  const int row_base = (row_block * kWaves + wave) * kAsmRowsPerWave;
+  auto fetch_tables = [&](int ky) {
+    if (ky >= Sy) return;
+    const int dy = ky - (Qy - 1);
+    const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
+#pragma unroll
+    for (int j = 0; j < kTabs; ++j) {
+      // side of table j: class 0: A A B B, class 1: A A A, class 2: B B B
+      const bool side_b = CLS == 2 || (CLS == 0 && j >= 2);
+      const int w = side_b ? Qx : Px;
+      const int y0 = side_b ? ya0 - dy : ya0, y1 = side_b ? ya1 - dy : ya1;
+      const int* T = tab + j * g.tab_elems;
+#pragma unroll
+      for (int k = 0; k < kTabCols; ++k) {
+        // (clamped addresses, unconditional loads: see masked_tables_kernel)
+        const int x = min(lane + 64 * k, w - 1);
+        thi[j][k] = T[(y1 - 1) * w + x];  // y1 >= 1 on every valid row
+        const int lo = T[max(y0 - 1, 0) * w + x];
+        tlo[j][k] = y0 > 0 ? lo : 0;
+      }
+    }
+  };
+  // product surfaces: row r of the current surface row, also one row ahead
+  int rv[kRaw][kOutCols];
+  auto fetch_raw = [&](int ky) {
+    if (ky >= Sy) return;
+    const long long row = (long long)ky * g.pitch;
+#pragma unroll
+    for (int c = 0; c < kOutCols; ++c) {
+      const int kx = lane + 64 * c;
+#pragma unroll
+      for (int q = 0; q < kRaw; ++q) {
+        if (!FINAL && q == 0) continue;  // the maxima do not involve a' * b'
+        const int* src = q == 0 ? raw0 : rawd + (long long)(q - 1) * g.raw_stride;
+        rv[q][c] = src[row + min(kx, Sx - 1)];
+      }
+    }
+  };
+  if (kTabs) fetch_tables(row_base);
+  fetch_raw(row_base);
   for (int i = 0; i < kAsmRowsPerWave; ++i) {
-    const int ky = (blockIdx.x * kWaves + wave) * kAsmRowsPerWave + i;
+    const int ky = row_base + i;
     const bool row_ok = ky < Sy;
     const int dy = ky - (Qy - 1);
     const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
     const int ny = ya1 - ya0;
-    if (slot < 0) {
+    if (kTabs) {
       __syncthreads();  // previous row's arrays consumed
       if (row_ok) {
-        for (int x = lane; x <= Px; x += 64) {
-          D[wave][0][x] = IA[ya1 * ipa + x] - IA[ya0 * ipa + x];
-          D[wave][1][x] = IA2[ya1 * ipa + x] - IA2[ya0 * ipa + x];
+#pragma unroll
+        for (int k = 0; k < kTabCols; ++k) {
+          const int x = lane + 64 * k + 1;
+          D0[x] = make_int2(thi[0][k] - tlo[0][k], thi[1 % (kTabs ? kTabs : 1)][k] -
+                                                       tlo[1 % (kTabs ? kTabs : 1)][k]);
+          D1[x] = make_int2(thi[2 % (kTabs ? kTabs : 1)][k] - tlo[2 % (kTabs ? kTabs : 1)][k],
+                            kTabs == 4 ? thi[3 % (kTabs ? kTabs : 1)][k] -
+                                             tlo[3 % (kTabs ? kTabs : 1)][k]
+                                       : 0);
         }
-        for (int x = lane; x <= Qx; x += 64) {
-          D[wave][2][x] = IB[(ya1 - dy) * ipb + x] - IB[(ya0 - dy) * ipb + x];
-          D[wave][3][x] = IB2[(ya1 - dy) * ipb + x] - IB2[(ya0 - dy) * ipb + x];
+        if (lane == 0) {
+          D0[0] = make_int2(0, 0);
+          D1[0] = make_int2(0, 0);
         }
       }
       __syncthreads();
+      if (i + 1 < kAsmRowsPerWave) fetch_tables(ky + 1);
     }
     if (!row_ok) continue;
     const long long row = (long long)ky * g.pitch;
-    for (int kx = lane; kx < Sx; kx += 64) {
-      const int xc_raw = raw0[row + kx];
-      int s_a, s_b, n, sqa_i = 0, sqb_i = 0, hi_a = 0, lo_a = 0, hi_b = 0, lo_b = 0;
-      if (slot < 0) {
+    // this row's products move to `cur`; the next row's loads are issued now
+    int cur[kRaw][kOutCols];
+#pragma unroll
+    for (int c = 0; c < kOutCols; ++c)
+#pragma unroll
+      for (int q = 0; q < kRaw; ++q) cur[q][c] = (!FINAL && q == 0) ? 0 : rv[q][c];
+    if (i + 1 < kAsmRowsPerWave) fetch_raw(ky + 1);
+#pragma unroll
+    for (int c = 0; c < kOutCols; ++c) {
+      const int kx = lane + 64 * c;
+      if (kx < Sx) {
         const int dx = kx - (Qx - 1);
         const int xa0 = max(0, dx), xa1 = min(Px, Qx + dx);
         const int xb0 = xa0 - dx, xb1 = xa1 - dx;
-        n = ny * (xa1 - xa0);
-        s_a = D[wave][0][xa1] - D[wave][0][xa0];
-        sqa_i = D[wave][1][xa1] - D[wave][1][xa0];
-        s_b = D[wave][2][xb1] - D[wave][2][xb0];
-        sqb_i = D[wave][3][xb1] - D[wave][3][xb0];
-      } else {
-        const int* p = rawd + row + kx;
-        s_a = p[0];
-        s_b = p[g.elems];
-        n = p[2 * g.elems];
-        hi_a = p[3 * g.elems];
-        lo_a = p[4 * g.elems];
-        hi_b = p[5 * g.elems];
-        lo_b = p[6 * g.elems];
-      }
-      const double n_ov = n;
-      const double sq_a = slot < 0 ? static_cast<double>(sqa_i) : square_sum(hi_a, lo_a, n_ov);
-      const double sq_b = slot < 0 ? static_cast<double>(sqb_i) : square_sum(hi_b, lo_b, n_ov);
-      const PadfieldTerms t = padfield_terms(xc_raw, s_a, s_b, n_ov, sq_a, sq_b, mua, mub);
-      if (FINAL) {
-        float v = t.den > tol ? static_cast<float>(t.num) / t.den : 0.f;
-        v = fminf(fmaxf(v, -1.f), 1.f);
-        if (t.ov < px_thr) v = 0.f;
-        g.out[(long long)b * g.elems + row + kx] = v;
-        rmax = fmaxf(rmax, v);
-      } else {
-        mden = fmaxf(mden, t.den);
-        mov = fmaxf(mov, t.ov);
+        int s_a, s_b, n;
+        double sq_a, sq_b;
+        if (CLS == 0) {
+          const int2 a1 = D0[xa1], a0 = D0[xa0], b1 = D1[xb1], b0 = D1[xb0];
+          n = ny * (xa1 - xa0);
+          s_a = a1.x - a0.x;
+          sq_a = a1.y - a0.y;
+          s_b = b1.x - b0.x;
+          sq_b = b1.y - b0.y;
+        } else if (CLS == 1) {
+          const int2 a1 = D0[xa1], a0 = D0[xa0];
+          n = D1[xa1].x - D1[xa0].x;
+          s_a = a1.x - a0.x;
+          sq_a = a1.y - a0.y;
+          s_b = cur[1 % kRaw][c];
+          sq_b = square_sum(cur[2 % kRaw][c], cur[3 % kRaw][c], n);
+        } else if (CLS == 2) {
+          const int2 b1 = D0[xb1], b0 = D0[xb0];
+          n = D1[xb1].x - D1[xb0].x;
+          s_b = b1.x - b0.x;
+          sq_b = b1.y - b0.y;
+          s_a = cur[1 % kRaw][c];
+          sq_a = square_sum(cur[2 % kRaw][c], cur[3 % kRaw][c], n);
+        } else {
+          s_a = cur[1 % kRaw][c];
+          s_b = cur[2 % kRaw][c];
+          n = cur[3 % kRaw][c];
+          sq_a = square_sum(cur[4 % kRaw][c], cur[5 % kRaw][c], n);
+          sq_b = square_sum(cur[6 % kRaw][c], cur[7 % kRaw][c], n);
+        }
+        const PadfieldTerms t = padfield_terms(cur[0][c], s_a, s_b, n, sq_a, sq_b);
+        if (FINAL) {
+          float v = t.den > tol ? static_cast<float>(t.num_n) / t.den_n : 0.f;
+          v = fminf(fmaxf(v, -1.f), 1.f);
+          if (t.ov < px_thr) v = 0.f;
+          g.out[(long long)b * g.elems + row + kx] = v;
+          po->rmax = fmaxf(po->rmax, v);
+        } else {
+          po->mden = fmaxf(po->mden, t.den);
+          po->mov = fmaxf(po->mov, t.ov);
+        }
       }
     }
   }
+}
+
+// End of an assembly workgroup: surface maximum (FINAL) or batch maxima.
+template <bool FINAL>
+__device__ __forceinline__ void phase_finish(const MaskedFastArgs& g, int b,
+                                             const PhaseOut& po) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float mden = po.mden, mov = po.mov, rmax = po.rmax;
   if (FINAL) {
     // surface maximum for the peak search (monotonic uint image of the float)
     if (g.smax) {
@@ -1107,6 +1188,102 @@ __global__ void __launch_bounds__(kThreads) masked_phase_kernel(MaskedFastArgs g
         atomicMax(&g.maxima[threadIdx.x], bits);
     }
   }
+}
+
+template <bool FINAL>
+__global__ void __launch_bounds__(kThreads) masked_phase_kernel(MaskedFastArgs g) {
+  __shared__ int2 D[kWaves][2][kAsmMaxCols];
+  // Workgroups are dealt to the 8 XCDs round robin; the row blocks of a patch
+  // share its integral images, so they are mapped to ONE XCD (one L2): XCD x
+  // takes the x-th eighth of the (patch, row block) list.  Grid = 8 * chunk.
+  const int chunk = gridDim.x >> 3;
+  const int item = g.xcd_map ? (blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : blockIdx.x;
+  const int b = item / g.row_blocks;
+  if (b >= g.batch) return;
+  const int row_block = item - b * g.row_blocks;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cls = g.cls[b];
+  float tol = 0.f, px_thr = 0.f;
+  if (FINAL) {
+    tol = 1e3f * 1.1920928955078125e-07f * __uint_as_float(g.maxima[0]);
+    px_thr = 0.3f * __uint_as_float(g.maxima[1]);
+  }
+  PhaseOut po = {0.f, 0.f, -INFINITY};
+  if (cls == 3) return;  // masked_phase3_kernel
+  switch (cls) {
+    case 0: masked_phase_rows<0, FINAL>(g, b, row_block, D[wave][0], D[wave][1], tol, px_thr, &po); break;
+    case 1: masked_phase_rows<1, FINAL>(g, b, row_block, D[wave][0], D[wave][1], tol, px_thr, &po); break;
+    default: masked_phase_rows<2, FINAL>(g, b, row_block, D[wave][0], D[wave][1], tol, px_thr, &po); break;
+  }
+  phase_finish<FINAL>(g, b, po);
+}
+
+// Class 3 (both sides masked): all eight products come from memory and no
+// row structure is needed, so the surface is walked flat, four elements per
+// thread with 16-byte loads, the next four in flight while these are assembled.
+template <bool FINAL>
+__global__ void __launch_bounds__(kThreads) masked_phase3_kernel(MaskedFastArgs g) {
+  const int chunk = gridDim.x >> 3;
+  const int item = g.xcd_map ? (blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : blockIdx.x;
+  const int b = item / g.row_blocks;
+  if (b >= g.batch || g.cls[b] != 3) return;
+  const int row_block = item - b * g.row_blocks;
+  const int Sy = g.S[0], Sx = g.S[1];
+  float tol = 0.f, px_thr = 0.f;
+  if (FINAL) {
+    tol = 1e3f * 1.1920928955078125e-07f * __uint_as_float(g.maxima[0]);
+    px_thr = 0.3f * __uint_as_float(g.maxima[1]);
+  }
+  const long long e0 = (long long)row_block * kWaves * kAsmRowsPerWave * g.pitch;
+  const int n4 = static_cast<int>(
+      min((long long)kWaves * kAsmRowsPerWave * g.pitch, g.elems - e0) >> 2);
+  const v4i* src[8];
+  src[0] = reinterpret_cast<const v4i*>(g.raw0 + (long long)b * g.raw_stride + e0);
+#pragma unroll
+  for (int q = 1; q < 8; ++q)
+    src[q] = reinterpret_cast<const v4i*>(g.rawd + (long long)(g.first[b] + q - 1) * g.raw_stride + e0);
+  float* out = g.out + (long long)b * g.elems + e0;
+  PhaseOut po = {0.f, 0.f, -INFINITY};
+  v4i nxt[8];
+  auto fetch = [&](int f) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (!FINAL && q == 0) continue;  // the maxima do not involve a' * b'
+      nxt[q] = src[q][min(f, n4 - 1)];
+    }
+  };
+  fetch(threadIdx.x);
+  for (int f = threadIdx.x; f < n4; f += kThreads) {
+    v4i cur[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cur[q] = (!FINAL && q == 0) ? v4i{0, 0, 0, 0} : nxt[q];
+    fetch(f + kThreads);
+    const long long e = e0 + 4LL * f;
+    const int ky = static_cast<int>(e / g.pitch);
+    const int kx0 = static_cast<int>(e - (long long)ky * g.pitch);
+    float v4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = cur[3][j];
+      const PadfieldTerms t =
+          padfield_terms(cur[0][j], cur[1][j], cur[2][j], n, square_sum(cur[4][j], cur[5][j], n),
+                         square_sum(cur[6][j], cur[7][j], n));
+      const bool ok = ky < Sy && kx0 + j < Sx;
+      if (FINAL) {
+        float v = t.den > tol ? static_cast<float>(t.num_n) / t.den_n : 0.f;
+        v = fminf(fmaxf(v, -1.f), 1.f);
+        if (t.ov < px_thr) v = 0.f;
+        v4[j] = v;
+        if (ok) po.rmax = fmaxf(po.rmax, v);
+      } else if (ok) {
+        po.mden = fmaxf(po.mden, t.den);
+        po.mov = fmaxf(po.mov, t.ov);
+      }
+    }
+    if (FINAL) *reinterpret_cast<float4*>(out + 4 * f) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+  }
+  phase_finish<FINAL>(g, b, po);
 }
 
 __device__ __forceinline__ int box_sum(const int* __restrict__ I, int ip, int y0,
@@ -1320,22 +1497,19 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     else
       __builtin_amdgcn_s_setprio(0);
   }
-  // Work items: patches, or (dirty patch, operand-plane pair) for the masked
-  // passes that only patches with masked pixels need.
-  const int n_items = (RAW && a.list) ? 7 * *a.n_list : a.batch;
+  // Work items: patches, or the extra (patch, operand-plane pair) passes of
+  // the masked path (see masked_classify_kernel).
+  const int n_items = (RAW && a.list) ? *a.n_list : a.batch;
   for (int item = blockIdx.x; item < n_items; item = next_patch(a, item, next_lds)) {
     int b = item;
     int plane0 = a.plane[0], plane1 = a.plane[1];
     if (RAW && a.list) {
-      const int slot = item / 7, pass = item - 7 * slot;  // kMaskedPasses[1 + pass]
-      b = a.list[slot];
-      plane0 = pass == 0 ? kPlaneVal : pass == 3 ? kPlaneSqHi : pass == 4 ? kPlaneSqLo
+      const int code = a.list[item], pass = code & 7;  // kMaskedPasses[pass]
+      b = code >> 3;
+      plane0 = pass == 1 ? kPlaneVal : pass == 4 ? kPlaneSqHi : pass == 5 ? kPlaneSqLo
                                                                           : kPlaneValid;
-      plane1 = (pass == 0 || pass == 2) ? kPlaneValid
-               : pass == 1              ? kPlaneVal
-               : pass == 5              ? kPlaneSqHi
-               : pass == 6              ? kPlaneSqLo
-                                        : kPlaneValid;
+      plane1 = pass == 2 ? kPlaneVal : pass == 6 ? kPlaneSqHi : pass == 7 ? kPlaneSqLo
+                                                                          : kPlaneValid;
     }
 #ifdef SFM_MFMA_TIMING
     ++npat;
@@ -1673,7 +1847,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #endif
       if (RAW) {
         // exact integer products; the Padfield assembly happens afterwards
-        int* raw = a.raw_out + (a.list ? item : b) * a.s_stride;
+        int* raw = a.raw_out + (a.list ? item : b) * a.raw_stride;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -2224,28 +2398,23 @@ int fill_common(const SfmXcorrDesc* d, const Layout& l, MfmaArgs* ap) {
   return SFM_OK;
 }
 
-// Masked path: eight raw-product passes over sub-batches, then the assembly.
-constexpr int kMaskedChunk = 512;
+// Masked path.  Pass index -> operand planes (pre, post); pass 0 runs for every
+// patch, the others only where a side has masked pixels (masked_classify_kernel).
 const int kMaskedPasses[8][2] = {
     {kPlaneVal, kPlaneVal},     {kPlaneVal, kPlaneValid},  {kPlaneValid, kPlaneVal},
     {kPlaneValid, kPlaneValid}, {kPlaneSqHi, kPlaneValid}, {kPlaneSqLo, kPlaneValid},
     {kPlaneValid, kPlaneSqHi},  {kPlaneValid, kPlaneSqLo}};
 
-// Fast form (clean patches take one pass): used for batches up to this size; it
-// keeps the integer products of the whole batch until the batch maxima are known.
-constexpr int kMaskedFastMax = 1024;
-
-bool masked_fast(const SfmXcorrDesc* d) {
-  const char* e = std::getenv("SFM_MASKED_FAST");  // "0": eight passes for every patch
-  return !(e && e[0] == '0') && d->batch <= kMaskedFastMax;
+// SFM_MASKED_FAST=0 (tests): every patch takes all eight passes.
+bool masked_all_passes() {
+  const char* e = std::getenv("SFM_MASKED_FAST");
+  return e && e[0] == '0';
 }
 
 struct MaskedWs {
   PatchParams* pp;
-  int* raw;  // eight-pass form: [8][kMaskedChunk][rows * pitch]
-  // fast form
-  int *nvalid, *slot, *list, *n_list, *tab, *raw0, *rawd;
-  long long tab_elems;
+  int *nvalid, *cls, *first, *items, *n_items, *tab, *raw0, *rawd;
+  long long tab_elems, raw_stride;
   size_t bytes;
 };
 
@@ -2257,19 +2426,18 @@ MaskedWs carve_masked(const SfmXcorrDesc* d, void* base) {
   sfm::mfma_i8_padded_dims(d, &rows, &pitch);
   const size_t B = d->batch;
   w.pp = c.take<PatchParams>(B);
-  if (masked_fast(d)) {
-    w.nvalid = c.take<int>(2 * B);
-    w.slot = c.take<int>(B);
-    w.list = c.take<int>(B);
-    w.n_list = c.take<int>(16);
-    w.tab_elems = (long long)(d->patch[1] + 1) * (d->patch[2] + 1);
-    w.tab = c.take<int>(B * 4 * (size_t)w.tab_elems);
-    w.raw0 = c.take<int>(B * (size_t)rows * pitch);
-    w.rawd = c.take<int>(B * 7 * (size_t)rows * pitch);
-  } else {
-    const size_t chunk = std::min<size_t>(B, kMaskedChunk);
-    w.raw = c.take<int>((size_t)8 * chunk * rows * pitch);
-  }
+  w.nvalid = c.take<int>(2 * B);
+  w.cls = c.take<int>(B);
+  w.first = c.take<int>(B);
+  w.items = c.take<int>(7 * B);
+  w.n_items = c.take<int>(16);
+  // + 64 ints: consecutive tables (and product surfaces below) of a patch are read
+  // together; strides that are multiples of 4 KB would put them on one memory channel
+  w.tab_elems = (long long)d->patch[1] * d->patch[2] + 64;
+  w.tab = c.take<int>(B * 4 * (size_t)w.tab_elems);
+  w.raw_stride = (long long)rows * pitch + 64;
+  w.raw0 = c.take<int>(B * (size_t)w.raw_stride);
+  w.rawd = c.take<int>(B * 7 * (size_t)w.raw_stride);
   w.bytes = c.total();
   return w;
 }
@@ -2391,10 +2559,12 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
 // Masked (Padfield) correlation on the matrix cores.  Outputs, all padded to
 // whole tiles [batch, rows, pitch]: num (numerator), den, ov, and the
 // batch-global maxima the finalize step needs (flow_field.py:137, 151).
-bool mfma_i8_masked_is_fast(const SfmXcorrDesc* d) { return masked_fast(d); }
-
-int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* num, float* den,
-                   float* ov, unsigned int* maxima, unsigned int* smax) {
+// Masked (Padfield) correlation on the matrix cores: writes the normalised
+// surface, padded to whole tiles [batch, rows, pitch]; `maxima` = scratch for
+// the batch maxima (flow_field.py:137, 151); `smax` (optional, zeroed by the
+// caller) receives the ordered bits of every surface maximum.
+int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
+                   unsigned int* maxima, unsigned int* smax) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const int vi = pick_variant(d->patch[2], d->post_patch[2]);
   if (vi < 0) return fail(SFM_ERR_INVALID, "patch too wide for the MFMA path");
@@ -2416,81 +2586,65 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* num, float* den,
   size_t r_bytes = (size_t)kThreads * 8;
   a.r_bytes = static_cast<int>(r_bytes);
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
-  const long long elems = a.s_stride;
-  if (masked_fast(d)) {
-    // `num` receives the FINAL surface; den / ov are not used.
-    MaskedFastArgs g;
-    std::memset(&g, 0, sizeof(g));
-    g.pp = w.pp;
-    g.nvalid = w.nvalid;
-    g.slot = w.slot;
-    g.list = w.list;
-    g.n_list = w.n_list;
-    g.tab = w.tab;
-    g.tab_elems = w.tab_elems;
-    g.raw0 = w.raw0;
-    g.rawd = w.rawd;
-    g.elems = elems;
-    g.pitch = a.sx_pitch;
-    for (int k = 0; k < 2; ++k) {
-      g.img[k] = a.img[k];
-      g.ishape[k][0] = a.ishape[k][0];
-      g.ishape[k][1] = a.ishape[k][1];
-      g.P[k] = a.P[k];
-      g.Q[k] = a.Q[k];
-      g.S[k] = a.S[k];
-    }
-    g.batch = d->batch;
-    g.maxima = maxima;
-    g.out = num;
-    g.smax = smax;
-    hipLaunchKernelGGL(masked_classify_kernel, dim3(1), dim3(1024), 0, st, g);
-    hipLaunchKernelGGL(masked_tables_kernel, dim3(d->batch), dim3(kThreads), 0, st, g);
-    SFM_LAUNCH_CHECK();
-    MfmaArgs c = a;
-    c.plane[0] = kPlaneVal;
-    c.plane[1] = kPlaneVal;
-    c.raw_out = w.raw0;
-    if (int rc = launch_mode(vi, c, kModeRaw, d->batch, lds, st)) return rc;
-    c.raw_out = w.rawd;
-    c.list = w.list;
-    c.n_list = w.n_list;
-    if (int rc = launch_mode(vi, c, kModeRaw, 7 * d->batch, lds, st)) return rc;
-    const int rows_per_wg = kWaves * kAsmRowsPerWave;
-    const dim3 grid((a.S[0] + rows_per_wg - 1) / rows_per_wg, d->batch);
-    hipLaunchKernelGGL(masked_phase_kernel<false>, grid, dim3(kThreads), 0, st, g);
-    hipLaunchKernelGGL(masked_phase_kernel<true>, grid, dim3(kThreads), 0, st, g);
-    SFM_LAUNCH_CHECK();
-    return SFM_OK;
+  MaskedFastArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.pp = w.pp;
+  g.nvalid = w.nvalid;
+  g.cls = w.cls;
+  g.first = w.first;
+  g.items = w.items;
+  g.n_items = w.n_items;
+  g.tab = w.tab;
+  g.tab_elems = w.tab_elems;
+  g.raw0 = w.raw0;
+  g.rawd = w.rawd;
+  g.elems = a.s_stride;
+  g.raw_stride = w.raw_stride;
+  a.raw_stride = w.raw_stride;
+  g.pitch = a.sx_pitch;
+  for (int k = 0; k < 2; ++k) {
+    g.img[k] = a.img[k];
+    g.mask[k] = a.mask[k];
+    g.ishape[k][0] = a.ishape[k][0];
+    g.ishape[k][1] = a.ishape[k][1];
+    g.mshape[k][0] = a.mshape[k][0];
+    g.mshape[k][1] = a.mshape[k][1];
+    g.P[k] = a.P[k];
+    g.Q[k] = a.Q[k];
+    g.S[k] = a.S[k];
   }
-  for (int lo = 0; lo < d->batch; lo += kMaskedChunk) {
-    const int nb = std::min(kMaskedChunk, d->batch - lo);
-    const long long plane_stride = (long long)nb * elems;
-    MfmaArgs c = a;
-    c.batch = nb;
-    c.pp = w.pp + lo;
-    const int grid = nb;
-    for (int pass = 0; pass < 8; ++pass) {
-      c.plane[0] = kMaskedPasses[pass][0];
-      c.plane[1] = kMaskedPasses[pass][1];
-      c.raw_out = w.raw + pass * plane_stride;
-      if (int rc = launch_mode(vi, c, kModeRaw, grid, lds, st)) return rc;
-    }
-    AssembleArgs g;
-    g.raw = w.raw;
-    g.plane_stride = plane_stride;
-    g.pp = w.pp + lo;
-    g.elems = elems;
-    g.n_patches = nb;
-    g.num = num + (long long)lo * elems;
-    g.den = den + (long long)lo * elems;
-    g.ov = ov + (long long)lo * elems;
-    g.maxima = maxima;
-    const long long total = plane_stride;
-    const int ag = static_cast<int>(std::min<long long>((total + kThreads - 1) / kThreads, 4096));
-    hipLaunchKernelGGL(mfma_assemble_masked_kernel, dim3(ag), dim3(kThreads), 0, st, g);
-    SFM_LAUNCH_CHECK();
+  g.batch = d->batch;
+  g.all_passes = masked_all_passes() ? 1 : 0;
+  {
+    const char* e = std::getenv("SFM_PHASE_XCD");
+    g.xcd_map = !(e && e[0] == '0');
   }
+  g.maxima = maxima;
+  g.out = surface;
+  g.smax = smax;
+  const int rows_per_wg = kWaves * kAsmRowsPerWave;
+  g.row_blocks = (a.S[0] + rows_per_wg - 1) / rows_per_wg;
+  hipLaunchKernelGGL(masked_classify_kernel, dim3(1), dim3(1024), 0, st, g);
+  hipLaunchKernelGGL(masked_tables_kernel, dim3(d->batch), dim3(kThreads), 0, st, g);
+  SFM_LAUNCH_CHECK();
+  MfmaArgs c = a;
+  c.plane[0] = kMaskedPasses[0][0];
+  c.plane[1] = kMaskedPasses[0][1];
+  c.raw_out = w.raw0;
+  if (int rc = launch_mode(vi, c, kModeRaw, d->batch, lds, st)) return rc;
+  c.raw_out = w.rawd;
+  c.list = w.items;
+  c.n_list = w.n_items;
+  const long long extra = 7LL * d->batch;
+  if (int rc = launch_mode(vi, c, kModeRaw, static_cast<int>(std::min<long long>(extra, 1 << 20)),
+                           lds, st))
+    return rc;
+  const dim3 grid(static_cast<unsigned>(((long long)g.row_blocks * d->batch + 7) / 8 * 8));
+  hipLaunchKernelGGL(masked_phase_kernel<false>, grid, dim3(kThreads), 0, st, g);
+  hipLaunchKernelGGL(masked_phase3_kernel<false>, grid, dim3(kThreads), 0, st, g);
+  hipLaunchKernelGGL(masked_phase_kernel<true>, grid, dim3(kThreads), 0, st, g);
+  hipLaunchKernelGGL(masked_phase3_kernel<true>, grid, dim3(kThreads), 0, st, g);
+  SFM_LAUNCH_CHECK();
   return SFM_OK;
 }
 
