@@ -921,10 +921,11 @@ __global__ void __launch_bounds__(1024) masked_classify_kernel(MaskedFastArgs g)
 }
 
 // Inclusive integral images T[y][x] = sum over rows <= y, columns <= x of the
-// planes a patch's box sums need (masked pixels count as 0): wave w of the
-// workgroup builds table w, walking down the rows with the running column sums
-// of the row prefixes in registers.
+// planes a patch's box sums need (masked pixels count as 0):
 //   class 0: a', a'^2, b', b'^2;  class 1: a', a'^2, valid_a;  class 2: b', b'^2, valid_b
+// Wave w of the workgroup builds table w: a lane owns four adjacent columns
+// (one dword of pixels per row), so a row costs one wave scan; the running
+// column sums of the row prefixes stay in registers while it walks down.
 __global__ void __launch_bounds__(kThreads) masked_tables_kernel(MaskedFastArgs g) {
   const int b = blockIdx.x;
   const int cls = g.cls[b];
@@ -941,40 +942,60 @@ __global__ void __launch_bounds__(kThreads) masked_tables_kernel(MaskedFastArgs 
   const unsigned char* msk =
       cls != 0 && g.mask[s] ? g.mask[s] + (long long)pp.my0[s] * MW + pp.mx0[s] : nullptr;
   int* T = g.tab + ((long long)b * 4 + t) * g.tab_elems;
-  constexpr int kCols = 3;  // px <= 192
   constexpr int kAhead = 8;
-  int acc[kCols] = {0, 0, 0};
+  // Columns 4 lane .. 4 lane + 3; a lane whose dword would cross the end of the
+  // row fetches the last whole dword of the row instead (unconditional loads: a
+  // load under a per-lane condition ends up in its own block and the loads of
+  // a batch would be waited for one by one).
+  const int x0 = 4 * lane;
+  const int xl = min(x0, max(px - 4, 0));
+  const bool vec = (px & 3) == 0 && px >= 4;
+  int acc[4] = {0, 0, 0, 0};
   for (int y0 = 0; y0 < py; y0 += kAhead) {
-    int pix[kAhead][kCols];
+    unsigned pw[kAhead], mw[kAhead];
 #pragma unroll
-    for (int u = 0; u < kAhead; ++u)
-#pragma unroll
-      for (int k = 0; k < kCols; ++k) {
-        // unconditional loads from clamped addresses (a load under a per-lane
-        // condition ends up in its own block and the 24 loads of a batch would
-        // be waited for one by one)
-        const int x = lane + 64 * k;
-        const bool in = y0 + u < py && x < px;
-        const int yc = min(y0 + u, py - 1), xc = min(x, px - 1);
-        int v = src[(long long)yc * W + xc] - c;
-        const int m = msk ? msk[(long long)yc * MW + xc] : 0;
-        const bool valid = in && m == 0;
-        v = kind == 2 ? (valid ? 1 : 0) : (valid ? v : 0);
-        pix[u][k] = v;
+    for (int u = 0; u < kAhead; ++u) {
+      const int yc = min(y0 + u, py - 1);
+      if (px >= 4) {
+        __builtin_memcpy(&pw[u], src + (long long)yc * W + xl, 4);
+        mw[u] = 0;
+        if (msk) __builtin_memcpy(&mw[u], msk + (long long)yc * MW + xl, 4);
+      } else {  // patches narrower than a dword: byte by byte
+        pw[u] = mw[u] = 0;
+        for (int j = 0; j < px; ++j) {
+          pw[u] |= static_cast<unsigned>(src[(long long)yc * W + j]) << (8 * j);
+          if (msk) mw[u] |= static_cast<unsigned>(msk[(long long)yc * MW + j]) << (8 * j);
+        }
       }
+    }
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
       const int y = y0 + u;
       if (y >= py) break;
-      int carry = 0;
+      int v[4];
 #pragma unroll
-      for (int k = 0; k < kCols; ++k) {
-        const int x = lane + 64 * k;
-        const int v = kind == 1 ? pix[u][k] * pix[u][k] : pix[u][k];
-        const int r = wave_scan_incl(v) + carry;
-        carry = __builtin_amdgcn_readlane(r, 63);
-        acc[k] += r;
-        if (x < px) T[y * px + x] = acc[k];
+      for (int j = 0; j < 4; ++j) {
+        // a re-based dword (row tail) holds column x0 + j in byte j + x0 - xl
+        const bool in = x0 + j < px;
+        const int sh = in ? 8 * (j + x0 - xl) : 0;
+        const int pv = static_cast<int>((pw[u] >> sh) & 0xffu) - c;
+        const bool valid = in && ((mw[u] >> sh) & 0xffu) == 0;
+        const int val = kind == 2 ? 1 : kind == 1 ? pv * pv : pv;
+        v[j] = valid ? val : 0;
+      }
+      const int p1 = v[0] + v[1], p2 = p1 + v[2], p3 = p2 + v[3];
+      const int incl = wave_scan_incl(p3);
+      const int excl = incl - p3;
+      acc[0] += excl + v[0];
+      acc[1] += excl + p1;
+      acc[2] += excl + p2;
+      acc[3] += incl;
+      if (vec) {
+        if (x0 < px) *reinterpret_cast<v4i*>(T + y * px + x0) = v4i{acc[0], acc[1], acc[2], acc[3]};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (x0 + j < px) T[y * px + x0 + j] = acc[j];
       }
     }
   }

@@ -796,7 +796,8 @@ def _masked_patch_batch(seed, b, py, px, qy, qx):
 
 
 @pytest.mark.parametrize('py,px,qy,qx', [(160, 160, 160, 160), (64, 80, 40, 64),
-                                         (48, 48, 48, 48), (96, 96, 96, 80)])
+                                         (48, 48, 48, 48), (96, 96, 96, 80),
+                                         (50, 46, 37, 31), (33, 3, 20, 2)])
 def test_masked_clean_patch_shortcut_is_bit_identical(gpu, monkeypatch, py, px, qy, qx):
   """Patches without masked pixels take ONE matrix pass + box sums instead of
   eight passes: same surface, bit for bit, as the eight-pass form; both agree
