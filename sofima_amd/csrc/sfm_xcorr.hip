@@ -367,6 +367,82 @@ __global__ void __launch_bounds__(kBlock) mask_count_kernel(MaskCountArgs a) {
   if (threadIdx.x == 0) a.out[o] = red[0];
 }
 
+// Same counts for patch rows that are not too wide: one workgroup per (tile of
+// x outputs, oy, oz) adds the mask rows of the window column-wise (16 columns
+// per thread, one 16-byte load per row), prefix-sums the column sums in LDS and
+// writes every output of the tile as a difference of two prefix values.  Each
+// mask byte is read P_y / T_y times instead of P_y P_x / (T_y T_x) times.
+constexpr int kMcCols = 16 * kBlock;  // columns per tile
+
+// 1 in every byte of w that is not zero
+__device__ __forceinline__ unsigned nonzero_bytes(unsigned w) {
+  return ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u) >> 7;
+}
+
+__global__ void __launch_bounds__(kBlock) mask_count_rows_kernel(MaskCountArgs a, int ot) {
+  __shared__ int pref[kMcCols + 1];
+  __shared__ int wsum[kBlock / 64];
+  const int oy = blockIdx.y, oz = blockIdx.z;
+  const int ox0 = blockIdx.x * ot;
+  const int nout = min(ot, a.O[2] - ox0);
+  const int x0 = ox0 * a.T[2];
+  const int ncol = (nout - 1) * a.T[2] + a.P[2];  // <= kMcCols
+  const int c0 = 16 * threadIdx.x;
+  const long long rows = (long long)a.P[0] * a.P[1];
+  int cs[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) cs[j] = 0;
+  unsigned pk[4] = {0, 0, 0, 0};  // packed byte counters, flushed before they overflow
+  int in_pk = 0;
+  const bool whole = c0 + 16 <= ncol;  // x0 + ncol <= S[2] by construction
+  for (long long r = 0; r < rows; ++r) {
+    const int z = static_cast<int>(r / a.P[1]), y = static_cast<int>(r - (long long)z * a.P[1]);
+    const unsigned char* row =
+        a.mask + (((long long)oz * a.T[0] + z) * a.S[1] + (long long)oy * a.T[1] + y) * a.S[2] +
+        x0 + c0;
+    unsigned w[4] = {0, 0, 0, 0};
+    if (whole) {
+      __builtin_memcpy(w, row, 16);
+    } else {
+      for (int j = 0; j < 16; ++j)
+        if (c0 + j < ncol) w[j >> 2] |= static_cast<unsigned>(row[j]) << (8 * (j & 3));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk[k] += nonzero_bytes(w[k]);
+    if (++in_pk == 255 || r + 1 == rows) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cs[j] += (pk[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      pk[0] = pk[1] = pk[2] = pk[3] = 0;
+      in_pk = 0;
+    }
+  }
+  // inclusive prefix over the tile's columns
+  int run = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    run += cs[j];
+    cs[j] = run;
+  }
+  int incl = run;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - run;
+  for (int k = 0; k < wave; ++k) base += wsum[k];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) pref[c0 + j + 1] = base + cs[j];
+  if (threadIdx.x == 0) pref[0] = 0;
+  __syncthreads();
+  for (int o = threadIdx.x; o < nout; o += kBlock)
+    a.out[((long long)oz * a.O[1] + oy) * a.O[2] + ox0 + o] =
+        pref[o * a.T[2] + a.P[2]] - pref[o * a.T[2]];
+}
+
 // ---------------------------------------------------------------------------
 // peaks
 // ---------------------------------------------------------------------------
@@ -449,14 +525,27 @@ __device__ bool is_window_max(const float* s, const PeakArgs& p, int z, int y,
   return v == wm;
 }
 
+// Row sweeps of the peak search: a wave takes whole rows, eight 64-wide column
+// groups at a time, and issues all the loads of such a piece before it looks at
+// the first value (clamped addresses, no load under a per-lane condition:
+// otherwise every load is waited for on its own).
+constexpr int kRowGroups = 8;
+
 __device__ float surface_max(const float* s, const PeakArgs& p, float* lv,
                              int* li, int r0 = 0, int r1 = -1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rows = r1 < 0 ? p.S[0] * p.S[1] : r1;
+  const int w = p.S[2];
   float mx = -INFINITY;
   for (int r = r0 + wave; r < rows; r += kBlock / 64) {
     const float* row = s + (long long)r * p.pitch;
-    for (int x = lane; x < p.S[2]; x += 64) mx = fmaxf(mx, row[x]);
+    for (int xb = 0; xb < w; xb += 64 * kRowGroups) {
+      float v[kRowGroups];
+#pragma unroll
+      for (int k = 0; k < kRowGroups; ++k) v[k] = row[min(xb + lane + 64 * k, w - 1)];
+#pragma unroll
+      for (int k = 0; k < kRowGroups; ++k) mx = fmaxf(mx, v[k]);  // duplicates are harmless
+    }
   }
   int dummy = 0;
   block_argmax(&mx, &dummy, lv, li);
@@ -469,13 +558,20 @@ __device__ void for_each_peak(const float* s, const PeakArgs& p, float thr, F fn
                               int r0 = 0, int r1 = -1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rows = r1 < 0 ? p.S[0] * p.S[1] : r1;
+  const int w = p.S[2];
   for (int r = r0 + wave; r < rows; r += kBlock / 64) {
     const int z = r / p.S[1], y = r - z * p.S[1];
     const float* row = s + (long long)r * p.pitch;
-    for (int x = lane; x < p.S[2]; x += 64) {
-      const float v = row[x];
-      if (v > thr && is_window_max(s, p, z, y, x, v))
-        fn(r * p.S[2] + x, v);
+    for (int xb = 0; xb < w; xb += 64 * kRowGroups) {
+      float v[kRowGroups];
+#pragma unroll
+      for (int k = 0; k < kRowGroups; ++k) v[k] = row[min(xb + lane + 64 * k, w - 1)];
+#pragma unroll
+      for (int k = 0; k < kRowGroups; ++k) {
+        const int x = xb + lane + 64 * k;
+        if (x < w && v[k] > thr && is_window_max(s, p, z, y, x, v[k]))
+          fn(r * w + x, v[k]);
+      }
     }
   }
 }
@@ -1112,8 +1208,15 @@ int sfm_mask_patch_counts(const SfmMaskCountDesc* d, int32_t* counts) {
     n *= a.O[i];
   }
   if (n > 0x7fffffffLL) return sfm::fail(SFM_ERR_INVALID, "mask counts: grid too large");
-  hipLaunchKernelGGL(mask_count_kernel, dim3(static_cast<unsigned>(n)), dim3(kBlock),
-                     0, static_cast<hipStream_t>(d->stream), a);
+  if (a.P[2] <= kMcCols / 2 && a.O[1] <= 65535 && a.O[0] <= 65535) {
+    const int ot = (kMcCols - a.P[2]) / a.T[2] + 1;  // x outputs per tile
+    const dim3 grid((a.O[2] + ot - 1) / ot, a.O[1], a.O[0]);
+    hipLaunchKernelGGL(mask_count_rows_kernel, grid, dim3(kBlock), 0,
+                       static_cast<hipStream_t>(d->stream), a, ot);
+  } else {
+    hipLaunchKernelGGL(mask_count_kernel, dim3(static_cast<unsigned>(n)), dim3(kBlock),
+                       0, static_cast<hipStream_t>(d->stream), a);
+  }
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }

@@ -753,14 +753,34 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_masked_kernel(MfmaArgs a) 
   const int my0 = mask ? min(max(sy, 0), MH - py) : 0;
   const int mx0 = mask ? min(max(sx, 0), MW - px) : 0;
   int mn = 255, mx = 0, sum = 0, cnt = 0;
-  for (int i = threadIdx.x; i < py * px; i += kThreads) {
-    const int y = i / px, x = i - y * px;
-    if (mask && mask[(long long)(my0 + y) * MW + mx0 + x]) continue;
-    const int v = a.img[s][(long long)(y0 + y) * W + x0 + x];
-    mn = min(mn, v);
-    mx = max(mx, v);
-    sum += v;
-    ++cnt;
+  // 16 pixels per work item: one 16-byte load of pixels and one of the mask
+  // (byte loads only in the last, partial item of a row)
+  const int n_chunks = (px + 15) >> 4;
+  const int n_items = py * n_chunks;
+  for (int item = threadIdx.x; item < n_items; item += kThreads) {
+    const int y = item / n_chunks, ch = item - y * n_chunks;
+    const int x = 16 * ch, nx = min(16, px - x);
+    const unsigned char* ip = a.img[s] + (long long)(y0 + y) * W + x0 + x;
+    const unsigned char* mp = mask ? mask + (long long)(my0 + y) * MW + mx0 + x : nullptr;
+    unsigned pw[4] = {0, 0, 0, 0}, mw[4] = {0, 0, 0, 0};
+    if (nx == 16) {
+      __builtin_memcpy(pw, ip, 16);
+      if (mp) __builtin_memcpy(mw, mp, 16);
+    } else {
+      for (int j = 0; j < nx; ++j) {
+        pw[j >> 2] |= static_cast<unsigned>(ip[j]) << (8 * (j & 3));
+        if (mp) mw[j >> 2] |= static_cast<unsigned>(mp[j]) << (8 * (j & 3));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int v = static_cast<int>((pw[j >> 2] >> (8 * (j & 3))) & 0xffu);
+      const bool ok = j < nx && ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) == 0;
+      mn = ok ? min(mn, v) : mn;
+      mx = ok ? max(mx, v) : mx;
+      sum += ok ? v : 0;
+      cnt += ok ? 1 : 0;
+    }
   }
   red[0][threadIdx.x] = mn;
   red[1][threadIdx.x] = mx;

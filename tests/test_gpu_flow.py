@@ -347,12 +347,15 @@ def test_masked_flow_production_geometry_vs_oracle(gpu):
     ((97, 64), (17, 32), (5, 8)),
     ((9, 40, 50), (4, 16, 16), (2, 8, 8)),
     ((33, 33), (33, 33), (7, 7)),
+    ((40, 9000), (16, 160), (8, 40)),      # several column tiles per row of patches
+    ((20, 5000), (8, 3000), (4, 500)),     # patch wider than a tile
+    ((300, 70), (280, 33), (5, 3)),        # more rows than a packed byte counter holds
 ])
 def test_mask_patch_counts_match_summed_area_table(gpu, shape, patch, step):
   """sfm_mask_patch_counts == flow_field.py:575-589 box query, exactly."""
   from sofima_amd import flow_field as ff
   rng = np.random.default_rng(7)
-  mask = rng.random(shape) < 0.3
+  mask = rng.random(shape) < (0.97 if shape[0] == 300 else 0.3)
   want = ff._host_masked_counts(mask, patch, step)
   got = ff._masked_counts(mask, patch, step)
   assert got.shape == want.shape
