@@ -311,8 +311,11 @@ __global__ void __launch_bounds__(kBlock) corr_direct_kernel(CorrArgs c) {
   c.ov[o] = ovv;
   // Batch-global maxima (flow_field.py:137, 151); values are >= 0 so the
   // integer order of the bit patterns is the float order.
-  atomicMax(&c.maxima[0], __float_as_uint(fabsf(den)));
-  atomicMax(&c.maxima[1], __float_as_uint(ovv));
+  // (same-address atomics serialise: only the elements that raise a maximum)
+  if (__float_as_uint(fabsf(den)) > __atomic_load_n(&c.maxima[0], __ATOMIC_RELAXED))
+    atomicMax(&c.maxima[0], __float_as_uint(fabsf(den)));
+  if (__float_as_uint(ovv) > __atomic_load_n(&c.maxima[1], __ATOMIC_RELAXED))
+    atomicMax(&c.maxima[1], __float_as_uint(ovv));
 }
 
 __global__ void __launch_bounds__(kBlock)

@@ -12,6 +12,7 @@
 //           = irfft(rfft(a_pad) conj(rfft(b_pad)))[(k - (Q - 1)) mod F]
 #include "sfm_common.h"
 
+#include <cstdint>
 #include <hipfft/hipfft.h>
 
 #include <map>
@@ -51,21 +52,38 @@ struct PadArgs {
   long long total;   // nb * Fn
 };
 
+// A wave per padded row (b, z, y): the row decomposition is wave-uniform
+// (scalar divisions, once per row) and the lanes sweep x with coalesced stores,
+// 16 bytes per lane when the row lengths allow it.
+template <bool VEC4>
 __global__ void __launch_bounds__(kBlock) pad_kernel(PadArgs a) {
-  for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < a.total;
-       i += (long long)gridDim.x * kBlock) {
-    const long long b = i / a.Fn;
-    long long r = i - b * a.Fn;
-    const int x = static_cast<int>(r % a.F[2]);
-    r /= a.F[2];
-    const int y = static_cast<int>(r % a.F[1]);
-    const int z = static_cast<int>(r / a.F[1]);
-    float v = 0.f;
-    if (z < a.P[0] && y < a.P[1] && x < a.P[2]) {
-      v = a.src[b * a.Pn + ((long long)z * a.P[1] + y) * a.P[2] + x];
-      if (a.square) v = v * v;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long n_rows = a.total / a.F[2];
+  const int rows_per_patch = a.F[0] * a.F[1];
+  for (long long row = blockIdx.x * (long long)(kBlock / 64) + wave; row < n_rows;
+       row += (long long)gridDim.x * (kBlock / 64)) {
+    const long long b = row / rows_per_patch;
+    const int r = static_cast<int>(row - b * rows_per_patch);
+    const int z = r / a.F[1], y = r - z * a.F[1];
+    float* dst = a.dst + row * a.F[2];
+    const bool inside = z < a.P[0] && y < a.P[1];
+    const float* src = a.src + b * a.Pn + ((long long)(inside ? z : 0) * a.P[1] + (inside ? y : 0)) * a.P[2];
+    if (VEC4) {
+      for (int x = 4 * lane; x < a.F[2]; x += 256) {
+        // unconditional load, clamped address
+        float4 v = *reinterpret_cast<const float4*>(src + min(x, a.P[2] - 4));
+        if (a.square) v = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+        if (!(inside && x < a.P[2])) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(dst + x) = v;
+      }
+    } else {
+      for (int x = lane; x < a.F[2]; x += 64) {
+        float v = src[min(x, a.P[2] - 1)];
+        if (a.square) v = v * v;
+        dst[x] = (inside && x < a.P[2]) ? v : 0.f;
+      }
     }
-    a.dst[i] = v;
   }
 }
 
@@ -92,41 +110,63 @@ struct CropArgs {
   long long total;    // nb * Sn
 };
 
+// A wave per surface row (b, kz, ky); see pad_kernel.
 template <bool MASKED>
 __global__ void __launch_bounds__(kBlock) crop_kernel(CropArgs c) {
-  for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < c.total;
-       i += (long long)gridDim.x * kBlock) {
-    const long long b = i / c.Sn;
-    long long r = i - b * c.Sn;
-    const int kx = static_cast<int>(r % c.S[2]);
-    r /= c.S[2];
-    const int ky = static_cast<int>(r % c.S[1]);
-    const int kz = static_cast<int>(r / c.S[1]);
-    int dz = kz - (c.Q[0] - 1), dy = ky - (c.Q[1] - 1), dx = kx - (c.Q[2] - 1);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long n_rows = c.total / c.S[2];
+  const int rows_per_patch = c.S[0] * c.S[1];
+  float mden = 0.f, mov = 0.f;
+  for (long long row = blockIdx.x * (long long)(kBlock / 64) + wave; row < n_rows;
+       row += (long long)gridDim.x * (kBlock / 64)) {
+    const long long b = row / rows_per_patch;
+    const int r = static_cast<int>(row - b * rows_per_patch);
+    const int kz = r / c.S[1], ky = r - kz * c.S[1];
+    int dz = kz - (c.Q[0] - 1), dy = ky - (c.Q[1] - 1);
     if (dz < 0) dz += c.F[0];
     if (dy < 0) dy += c.F[1];
-    if (dx < 0) dx += c.F[2];
-    const long long s = b * c.Fn + ((long long)dz * c.F[1] + dy) * c.F[2] + dx;
-    const float xc = c.r[0][s] * c.scale;
-    if (!MASKED) {
-      c.out[i] = xc;
-      continue;
+    const long long s0 = b * c.Fn + ((long long)dz * c.F[1] + dy) * c.F[2];
+    const long long o0 = row * c.S[2];
+    for (int kx = lane; kx < c.S[2]; kx += 64) {
+      int dx = kx - (c.Q[2] - 1);
+      if (dx < 0) dx += c.F[2];
+      const long long s = s0 + dx;
+      const float xc = c.r[0][s] * c.scale;
+      if (!MASKED) {
+        c.out[o0 + kx] = xc;
+        continue;
+      }
+      const float sa = c.r[1][s] * c.scale, sb = c.r[2][s] * c.scale;
+      const float nov = c.r[3][s] * c.scale;
+      const float qa = c.r[4][s] * c.scale, qb = c.r[5][s] * c.scale;
+      // Padfield assembly (flow_field.py:113-131), as in corr_direct_kernel
+      const float ovv = fmaxf(rintf(nov), kEps);
+      const float inv = 1.0f / ovv;
+      const float num = xc - sa * sb * inv;
+      const float pd = fmaxf(qa - sa * sa * inv, 0.f);
+      const float cd = fmaxf(qb - sb * sb * inv, 0.f);
+      const float den = sqrtf(pd * cd);
+      c.out[o0 + kx] = num;
+      c.den[o0 + kx] = den;
+      c.ov[o0 + kx] = ovv;
+      mden = fmaxf(mden, fabsf(den));
+      mov = fmaxf(mov, ovv);
     }
-    const float sa = c.r[1][s] * c.scale, sb = c.r[2][s] * c.scale;
-    const float nov = c.r[3][s] * c.scale;
-    const float qa = c.r[4][s] * c.scale, qb = c.r[5][s] * c.scale;
-    // Padfield assembly (flow_field.py:113-131), as in corr_direct_kernel
-    const float ovv = fmaxf(rintf(nov), kEps);
-    const float inv = 1.0f / ovv;
-    const float num = xc - sa * sb * inv;
-    const float pd = fmaxf(qa - sa * sa * inv, 0.f);
-    const float cd = fmaxf(qb - sb * sb * inv, 0.f);
-    const float den = sqrtf(pd * cd);
-    c.out[i] = num;
-    c.den[i] = den;
-    c.ov[i] = ovv;
-    atomicMax(&c.maxima[0], __float_as_uint(fabsf(den)));
-    atomicMax(&c.maxima[1], __float_as_uint(ovv));
+  }
+  if (MASKED) {
+    // one pair of atomics per wave, and only when it can raise a maximum
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      mden = fmaxf(mden, __shfl_xor(mden, d, 64));
+      mov = fmaxf(mov, __shfl_xor(mov, d, 64));
+    }
+    if (lane == 0) {
+      if (__float_as_uint(mden) > __atomic_load_n(&c.maxima[0], __ATOMIC_RELAXED))
+        atomicMax(&c.maxima[0], __float_as_uint(mden));
+      if (__float_as_uint(mov) > __atomic_load_n(&c.maxima[1], __ATOMIC_RELAXED))
+        atomicMax(&c.maxima[1], __float_as_uint(mov));
+    }
   }
 }
 
@@ -276,7 +316,16 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
       p.Fn = g.Fn;
       p.square = square;
       p.total = (long long)nb * g.Fn;
-      hipLaunchKernelGGL(pad_kernel, dim3(grid_for(p.total)), dim3(kBlock), 0, st, p);
+      // 16-byte lanes need rows that start on 16-byte boundaries on both sides
+      const bool vec4 = p.P[2] % 4 == 0 && p.F[2] % 4 == 0 && p.Pn % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(p.dst) & 15) == 0;
+      if (vec4)
+        hipLaunchKernelGGL(pad_kernel<true>, dim3(grid_for(p.total / g.F[2] * 64)),
+                           dim3(kBlock), 0, st, p);
+      else
+        hipLaunchKernelGGL(pad_kernel<false>, dim3(grid_for(p.total / g.F[2] * 64)),
+                           dim3(kBlock), 0, st, p);
       SFM_LAUNCH_CHECK();
       if (hipfftExecR2C(fwd, pad, reinterpret_cast<hipfftComplex*>(out)) != HIPFFT_SUCCESS)
         return fail(SFM_ERR_HIP, "hipfftExecR2C failed");
@@ -311,8 +360,8 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
       if (int rc = forward(b0, false, 0, spec[1])) return rc;
       if (int rc = product(spec[0], spec[1], spec[0], pad)) return rc;
       for (int i = 0; i < 6; ++i) cr.r[i] = pad;
-      hipLaunchKernelGGL(crop_kernel<false>, dim3(grid_for(cr.total)), dim3(kBlock), 0,
-                         st, cr);
+      hipLaunchKernelGGL(crop_kernel<false>, dim3(grid_for(cr.total / g.S[2] * 64)),
+                         dim3(kBlock), 0, st, cr);
       SFM_LAUNCH_CHECK();
     } else {
       float2 *FA = spec[0], *FVA = spec[1], *FA2 = spec[2];
@@ -330,8 +379,8 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
         if (int rc = product(lhs[i], rhs[i], prod, real[i])) return rc;
         cr.r[i] = real[i];
       }
-      hipLaunchKernelGGL(crop_kernel<true>, dim3(grid_for(cr.total)), dim3(kBlock), 0,
-                         st, cr);
+      hipLaunchKernelGGL(crop_kernel<true>, dim3(grid_for(cr.total / g.S[2] * 64)),
+                         dim3(kBlock), 0, st, cr);
       SFM_LAUNCH_CHECK();
     }
   }
