@@ -511,19 +511,18 @@ __device__ bool is_window_max(const float* s, const PeakArgs& p, int z, int y,
                               int x, float v) {
   const int m = p.min_distance;
   const int mz = p.nd == 3 ? m : 0;
+  // window maximum from clamped addresses: unconditional loads (all in flight
+  // together); a clamped position repeats an element of the window, which cannot
+  // change the maximum
   float wm = -INFINITY;
-  bool outside = false;
+  const bool outside = z - mz < 0 || z + mz >= p.S[0] || y - m < 0 || y + m >= p.S[1] ||
+                       x - m < 0 || x + m >= p.S[2];
   for (int dz = -mz; dz <= mz; ++dz)
     for (int dy = -m; dy <= m; ++dy)
-      for (int dx = -m; dx <= m; ++dx) {
-        const int zz = z + dz, yy = y + dy, xx = x + dx;
-        if (zz < 0 || zz >= p.S[0] || yy < 0 || yy >= p.S[1] || xx < 0 ||
-            xx >= p.S[2]) {
-          outside = true;
-          continue;
-        }
-        wm = fmaxf(wm, surf_at(s, p, zz, yy, xx));
-      }
+      for (int dx = -m; dx <= m; ++dx)
+        wm = fmaxf(wm, surf_at(s, p, min(max(z + dz, 0), p.S[0] - 1),
+                               min(max(y + dy, 0), p.S[1] - 1),
+                               min(max(x + dx, 0), p.S[2] - 1)));
   if (outside) wm = fmaxf(wm, 0.f);
   return v == wm;
 }

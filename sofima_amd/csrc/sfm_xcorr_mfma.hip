@@ -1360,17 +1360,15 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
   // Tests one element that exceeds the threshold and records it if it is a
   // window maximum.
   auto consider = [&](int y, int x, float v) {
+    // window maximum from clamped addresses: unconditional loads (all in flight
+    // together); a clamped position repeats an element of the window, which
+    // cannot change the maximum
     float wm = -INFINITY;
-    bool outside = false;
-    for (int dy = -m; dy <= m; ++dy)
-      for (int dx = -m; dx <= m; ++dx) {
-        const int yy = y + dy, xx = x + dx;
-        if (yy < 0 || yy >= Sy || xx < 0 || xx >= Sx) {
-          outside = true;
-          continue;
-        }
-        wm = fmaxf(wm, surf[(long long)yy * pitch + xx]);
-      }
+    const bool outside = y - m < 0 || y + m >= Sy || x - m < 0 || x + m >= Sx;
+    for (int dy = -m; dy <= m; ++dy) {
+      const float* wrow = surf + (long long)min(max(y + dy, 0), Sy - 1) * pitch;
+      for (int dx = -m; dx <= m; ++dx) wm = fmaxf(wm, wrow[min(max(x + dx, 0), Sx - 1)]);
+    }
     if (outside) wm = fmaxf(wm, 0.f);
     if (v != wm) return;
     const int i = y * Sx + x;
