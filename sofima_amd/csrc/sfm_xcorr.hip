@@ -382,23 +382,30 @@ __device__ __forceinline__ unsigned nonzero_bytes(unsigned w) {
   return ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u) >> 7;
 }
 
-__global__ void __launch_bounds__(kBlock) mask_count_rows_kernel(MaskCountArgs a, int ot) {
+// `splits` > 1: few outputs with tall windows (whole-overlap patches): the window
+// rows are divided among `splits` workgroups per tile, which add their partial
+// counts atomically into the zeroed output (integers: order does not matter).
+__global__ void __launch_bounds__(kBlock) mask_count_rows_kernel(MaskCountArgs a, int ot,
+                                                                 int splits) {
   __shared__ int pref[kMcCols + 1];
   __shared__ int wsum[kBlock / 64];
   const int oy = blockIdx.y, oz = blockIdx.z;
-  const int ox0 = blockIdx.x * ot;
+  const int tile = blockIdx.x / splits, split = blockIdx.x - tile * splits;
+  const int ox0 = tile * ot;
   const int nout = min(ot, a.O[2] - ox0);
   const int x0 = ox0 * a.T[2];
   const int ncol = (nout - 1) * a.T[2] + a.P[2];  // <= kMcCols
   const int c0 = 16 * threadIdx.x;
   const long long rows = (long long)a.P[0] * a.P[1];
+  const long long per = (rows + splits - 1) / splits;
+  const long long r_lo = min(rows, split * per), r_hi = min(rows, r_lo + per);
   int cs[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) cs[j] = 0;
   unsigned pk[4] = {0, 0, 0, 0};  // packed byte counters, flushed before they overflow
   int in_pk = 0;
   const bool whole = c0 + 16 <= ncol;  // x0 + ncol <= S[2] by construction
-  for (long long r = 0; r < rows; ++r) {
+  for (long long r = r_lo; r < r_hi; ++r) {
     const int z = static_cast<int>(r / a.P[1]), y = static_cast<int>(r - (long long)z * a.P[1]);
     const unsigned char* row =
         a.mask + (((long long)oz * a.T[0] + z) * a.S[1] + (long long)oy * a.T[1] + y) * a.S[2] +
@@ -412,7 +419,7 @@ __global__ void __launch_bounds__(kBlock) mask_count_rows_kernel(MaskCountArgs a
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) pk[k] += nonzero_bytes(w[k]);
-    if (++in_pk == 255 || r + 1 == rows) {
+    if (++in_pk == 255 || r + 1 == r_hi) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) cs[j] += (pk[j >> 2] >> (8 * (j & 3))) & 0xffu;
       pk[0] = pk[1] = pk[2] = pk[3] = 0;
@@ -441,9 +448,56 @@ __global__ void __launch_bounds__(kBlock) mask_count_rows_kernel(MaskCountArgs a
   for (int j = 0; j < 16; ++j) pref[c0 + j + 1] = base + cs[j];
   if (threadIdx.x == 0) pref[0] = 0;
   __syncthreads();
-  for (int o = threadIdx.x; o < nout; o += kBlock)
-    a.out[((long long)oz * a.O[1] + oy) * a.O[2] + ox0 + o] =
-        pref[o * a.T[2] + a.P[2]] - pref[o * a.T[2]];
+  for (int o = threadIdx.x; o < nout; o += kBlock) {
+    int* dst = &a.out[((long long)oz * a.O[1] + oy) * a.O[2] + ox0 + o];
+    const int cnt = pref[o * a.T[2] + a.P[2]] - pref[o * a.T[2]];
+    if (splits > 1)
+      atomicAdd(dst, cnt);
+    else
+      *dst = cnt;
+  }
+}
+
+// Patches wider than a tile (whole-overlap strips): every output is cut into
+// column segments of kMcCols and row ranges; a workgroup counts one piece and
+// adds it atomically to the zeroed output.
+__global__ void __launch_bounds__(kBlock) mask_count_wide_kernel(MaskCountArgs a, int nseg,
+                                                                 int splits) {
+  __shared__ int red[kBlock];
+  const long long o = blockIdx.y;
+  const int ox = static_cast<int>(o % a.O[2]);
+  const int oy = static_cast<int>((o / a.O[2]) % a.O[1]);
+  const int oz = static_cast<int>(o / ((long long)a.O[2] * a.O[1]));
+  const int seg = blockIdx.x / splits, split = blockIdx.x - seg * splits;
+  const int c0 = seg * kMcCols + 16 * threadIdx.x;  // first column of this thread
+  const long long rows = (long long)a.P[0] * a.P[1];
+  const long long per = (rows + splits - 1) / splits;
+  const long long r_lo = min(rows, split * per), r_hi = min(rows, r_lo + per);
+  const int nb = min(16, a.P[2] - c0);  // bytes of this thread inside the window
+  int cnt = 0;
+  if (nb > 0) {
+    for (long long r = r_lo; r < r_hi; ++r) {
+      const int z = static_cast<int>(r / a.P[1]), y = static_cast<int>(r - (long long)z * a.P[1]);
+      const unsigned char* row =
+          a.mask + (((long long)oz * a.T[0] + z) * a.S[1] + (long long)oy * a.T[1] + y) * a.S[2] +
+          (long long)ox * a.T[2] + c0;
+      unsigned w[4] = {0, 0, 0, 0};
+      if (nb == 16) {
+        __builtin_memcpy(w, row, 16);
+      } else {
+        for (int j = 0; j < nb; ++j) w[j >> 2] |= static_cast<unsigned>(row[j]) << (8 * (j & 3));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cnt += __builtin_popcount(nonzero_bytes(w[k]));
+    }
+  }
+  red[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int k = kBlock / 2; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && red[0]) atomicAdd(&a.out[o], red[0]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1212,9 +1266,27 @@ int sfm_mask_patch_counts(const SfmMaskCountDesc* d, int32_t* counts) {
   if (n > 0x7fffffffLL) return sfm::fail(SFM_ERR_INVALID, "mask counts: grid too large");
   if (a.P[2] <= kMcCols / 2 && a.O[1] <= 65535 && a.O[0] <= 65535) {
     const int ot = (kMcCols - a.P[2]) / a.T[2] + 1;  // x outputs per tile
-    const dim3 grid((a.O[2] + ot - 1) / ot, a.O[1], a.O[0]);
-    hipLaunchKernelGGL(mask_count_rows_kernel, grid, dim3(kBlock), 0,
-                       static_cast<hipStream_t>(d->stream), a, ot);
+    const int tiles = (a.O[2] + ot - 1) / ot;
+    const long long wgs = (long long)tiles * a.O[1] * a.O[0];
+    const long long rows = (long long)a.P[0] * a.P[1];
+    int splits = 1;
+    if (wgs < 512)  // not enough workgroups to fill the chip: divide the window rows
+      splits = static_cast<int>(std::max<long long>(
+          1, std::min<long long>((1024 + wgs - 1) / wgs, (rows + 31) / 32)));
+    hipStream_t st = static_cast<hipStream_t>(d->stream);
+    if (splits > 1) SFM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)n * sizeof(int32_t), st));
+    const dim3 grid(tiles * splits, a.O[1], a.O[0]);
+    hipLaunchKernelGGL(mask_count_rows_kernel, grid, dim3(kBlock), 0, st, a, ot, splits);
+  } else if (n <= 65535) {
+    hipStream_t st = static_cast<hipStream_t>(d->stream);
+    const int nseg = (a.P[2] + kMcCols - 1) / kMcCols;
+    const long long rows = (long long)a.P[0] * a.P[1];
+    const long long wgs = n * nseg;
+    const int splits = static_cast<int>(std::max<long long>(
+        1, std::min<long long>((1024 + wgs - 1) / wgs, (rows + 31) / 32)));
+    SFM_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)n * sizeof(int32_t), st));
+    hipLaunchKernelGGL(mask_count_wide_kernel, dim3(nseg * splits, static_cast<unsigned>(n)),
+                       dim3(kBlock), 0, st, a, nseg, splits);
   } else {
     hipLaunchKernelGGL(mask_count_kernel, dim3(static_cast<unsigned>(n)), dim3(kBlock),
                        0, static_cast<hipStream_t>(d->stream), a);

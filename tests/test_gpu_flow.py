@@ -350,6 +350,8 @@ def test_masked_flow_production_geometry_vs_oracle(gpu):
     ((40, 9000), (16, 160), (8, 40)),      # several column tiles per row of patches
     ((20, 5000), (8, 3000), (4, 500)),     # patch wider than a tile
     ((300, 70), (280, 33), (5, 3)),        # more rows than a packed byte counter holds
+    ((4096, 300), (4096, 300), (1, 1)),    # whole-overlap strip: one output, rows split
+    ((300, 5000), (290, 4990), (4, 6)),    # wide whole-overlap patches: column segments
 ])
 def test_mask_patch_counts_match_summed_area_table(gpu, shape, patch, step):
   """sfm_mask_patch_counts == flow_field.py:575-589 box query, exactly."""
