@@ -633,6 +633,119 @@ integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
   }
 }
 
+// Meshes of at most one workgroup's worth of nodes (tile meshes of rigid
+// stitching, single small volumes): all `iters` steps of the advance /
+// integrate pair above in ONE launch of ONE workgroup -- a thread owns a node,
+// the neighbours' positions are exchanged through global memory (one CU, one
+// L1) across workgroup barriers.  Same arithmetic in the same order as the
+// two kernels with a grid of one block: bit-identical results, ~8 us of
+// launch-bound step become ~1.5 us.
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+mesh_small_kernel(float* x, float* v, float* a, const float* prev, MeshParams p,
+                  Scalars* scal, float fixed_cap, float* partials, int iters) {
+  __shared__ float lds[kNP * kBlock];
+  const long long n = threadIdx.x;
+  const bool live = n < p.N;
+  Scalars s = scal[0];
+  float part[kNP];
+  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    // -- advance_kernel (pending = it > 0) --
+    if (p.fire) {
+      if (it > 0) {
+        // update_scalars over one row of partials: the block reduction adds
+        // zeros to it (x + 0 keeps every value; -0 becomes +0 like there)
+        float acc[kNP];
+        for (int i = 0; i < kNP; ++i) acc[i] = part[i] + 0.f;
+        Scalars sn;
+        scalars_from_sums(s, acc, p, &sn);
+        s = sn;
+      } else {
+        s.gate = 1.f;
+        for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+      }
+    } else {
+      s.dt = p.vv_dt;
+      s.gate = 1.f;
+      for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+    }
+    const float dt = s.dt;
+    const float c2 = 0.5f * (dt * dt);
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float xv = x[c * p.N + n];
+        float vv = v[c * p.N + n];
+        if (p.fire && it > 0) {
+          vv = vv * s.gate;
+          if (p.remove_drift) {
+            xv = xv - s.mx[c];
+            vv = vv - s.mv[c];
+          }
+          v[c * p.N + n] = vv;
+        }
+        x[c * p.N + n] = xv + (dt * vv + c2 * a[c * p.N + n]);
+      }
+    }
+    __syncthreads();  // every position of this step is visible
+    // -- integrate_kernel --
+    float alpha, cap;
+    if (p.fire) {
+      alpha = s.alpha;
+      cap = s.cap;
+    } else {
+      alpha = 0.f;
+      cap = fixed_cap;
+    }
+    const float hdtg = (0.5f * dt) * p.gamma;
+    const float fact0 = 1.0f / (1.0f + hdtg);
+    const float fact1 = 1.0f - hdtg;
+    const float hdt = 0.5f * dt;
+    for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+    if (live) {
+      float f[C], vn[C];
+      node_force<C>(x, p, n, f);
+      float a2 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float xv = x[c * p.N + n];
+        if (p.has_prev) f[c] = f[c] + prev_pull(xv, prev[c * p.N + n], p.neg_k0, cap);
+        const float a_old = a[c * p.N + n];
+        vn[c] = fact0 * (v[c * p.N + n] * fact1 + hdt * (a_old + f[c]));
+        a[c * p.N + n] = f[c];
+        a2 = a2 + f[c] * f[c];
+        v2 = v2 + vn[c] * vn[c];
+        if (p.fire) {
+          part[0] = part[0] + f[c] * vn[c];
+          part[1 + c] = part[1 + c] + xv;
+        }
+      }
+      if (p.fire) {
+        const float a_norm = sqrtf(a2) + 1e-6f;
+        const float v_norm = sqrtf(v2);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
+          part[4 + c] = part[4 + c] + vn[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[c * p.N + n] = vn[c];
+    }
+    if (p.fire)
+      block_sum(part, 7, lds);  // ends with a barrier: positions may move again
+    else
+      __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // what the last advance / integrate pair leaves behind for finish_kernel
+    scal[0] = s;
+    scal[1] = s;
+    for (int i = 0; i < kNP; ++i) partials[i] = part[i];
+  }
+}
+
 // The reducing (last) workgroup of a tiled step gathers the per-tile partial
 // sums.  Every producer's stores were acknowledged before it took its ticket,
 // so the granules are there: the loads of a batch are issued back to back
@@ -2206,6 +2319,11 @@ hipStream_t capture_stream() {
   return cs;
 }
 
+bool small_enabled() {
+  const char* e = std::getenv("SFM_MESH_SMALL");  // "0": the launch-per-kernel path
+  return !(e && e[0] == '0');
+}
+
 bool persistent_enabled() {
   const char* e = getenv("SFM_MESH_PERSISTENT");
   return !(e && e[0] == '0');
@@ -2515,6 +2633,21 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
 
   int cur = 0;
   int finish_mode = d->num_iters > 0 ? 1 : 0;
+  // One workgroup's worth of nodes: every step in one launch (mesh_small_kernel).
+  const bool small = small_enabled() && grid == 1 && d->num_iters > 0 && !d->target &&
+                     p.force_kind != SFM_FORCE_EXTERNAL && !p.drift_cols &&
+                     p.own_y0 <= 0 && p.own_y1 >= p.Y;
+  if (small) {
+    sfm::prof_begin(sfm::kProfMesh, st);
+    if (p.ncomp == 2)
+      hipLaunchKernelGGL(mesh_small_kernel<2>, dim3(1), dim3(kBlock), 0, st, d->x, d->v, d->a,
+                         prev_ptr, p, w.scal, cap0, w.partials, d->num_iters);
+    else
+      hipLaunchKernelGGL(mesh_small_kernel<3>, dim3(1), dim3(kBlock), 0, st, d->x, d->v, d->a,
+                         prev_ptr, p, w.scal, cap0, w.partials, d->num_iters);
+    sfm::prof_end(sfm::kProfMesh, st);
+    SFM_LAUNCH_CHECK();
+  }
   const bool tiled = tiles.tx && d->num_iters > 0;
   float* bufs[2][3] = {{d->x, d->v, d->a}, {w.alt[0], w.alt[1], w.alt[2]}};
   int in = 0;
@@ -2606,8 +2739,8 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   };
 #undef SFM_STEP_DISPATCH
 
-  int it = 0;
-  if (d->num_iters > 0) {
+  int it = small ? d->num_iters : 0;
+  if (!small && d->num_iters > 0) {
     if (int rc = step(0)) return rc;
     it = 1;
   }

@@ -449,3 +449,60 @@ def test_speculative_fire_is_bit_identical(gpu, shape):
   wx, we, wt = mesh_oracle.relax_mesh(x0, prev, cfg)
   assert c[2] == wt
   np.testing.assert_allclose(np.array(c[0]), wx, atol=2e-3 * np.abs(wx).max())
+
+
+@pytest.mark.parametrize('case', ['tile2d', 'tile3d', 'vol3d', 'plane_vv'])
+def test_small_mesh_single_launch_is_bit_identical(gpu, case):
+  """mesh_small_kernel (meshes of at most one workgroup's worth of nodes: all
+  steps of a chunk in one launch) == the kernel-per-phase path, bit for bit."""
+  from sofima_amd import mesh, stitch_rigid
+  rng = np.random.default_rng(33)
+  if case in ('tile2d', 'tile3d'):
+    nc = 2 if case == 'tile2d' else 3
+    shape = (nc, 1, 5, 7)
+    cx = (rng.standard_normal(shape) * 30).astype(np.float32)
+    cy = (rng.standard_normal(shape) * 30).astype(np.float32)
+    cx[0] -= 400
+    cy[1] -= 400
+    cx[:, 0, 2, 3] = np.nan          # a missing pair
+    cx[:, :, :, -1] = np.inf
+    cy[:, :, -1, :] = np.inf
+    cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.0, k=0.1, stride=(1, 1),
+                                 num_iters=300, max_iters=1500, stop_v_max=0.001, dt_max=100)
+    fn = stitch_rigid.elastic_tile_mesh if nc == 2 else stitch_rigid.elastic_tile_mesh_3d
+    run = lambda: stitch_rigid.optimize_coarse_mesh(cx, cy, cfg, mesh_fn=fn)
+    a = _with_env({'SFM_MESH_SMALL': '1'}, run)
+    b = _with_env({'SFM_MESH_SMALL': '0'}, run)
+    np.testing.assert_array_equal(a, b)
+    assert np.isfinite(a).all() and np.abs(a).max() > 100
+    return
+  if case == 'vol3d':
+    shape = (3, 1, 6, 6, 6)
+    stride = (40.0, 40.0, 40.0)
+    kw = dict(mesh_force=mesh.elastic_mesh_3d)
+    cfg_kw = dict(remove_drift=True, prefer_orig_order=False)
+  else:
+    shape = (2, 1, 9, 13)
+    stride = (40.0, 40.0)
+    kw = {}
+    cfg_kw = dict(fire=False, prefer_orig_order=True)
+    # the in-plane spring mesh would take the persistent kernel: switch it off too
+  prev = (rng.standard_normal(shape) * 6).astype(np.float32)
+  prev.reshape(shape[0], -1)[:, :3] = np.nan
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.5 if case == 'plane_vv' else 0.0, k0=0.05,
+                               k=0.1, stride=stride, num_iters=120, max_iters=360,
+                               stop_v_max=1e-9, dt_max=100,
+                               start_cap=10 if case == 'plane_vv' else 0.05, final_cap=10,
+                               **cfg_kw)
+  x0 = np.zeros(shape, np.float32)
+  vv = lambda: mesh.velocity_verlet(x0, np.zeros_like(x0), prev, cfg, cfg.start_cap, **kw)
+  a = _with_env({'SFM_MESH_SMALL': '1', 'SFM_MESH_PERSISTENT': '0'}, vv)
+  b = _with_env({'SFM_MESH_SMALL': '0', 'SFM_MESH_PERSISTENT': '0'}, vv)
+  for u, w in zip(a[:3], b[:3]):
+    np.testing.assert_array_equal(np.array(u), np.array(w))
+  assert a[3:] == b[3:]
+  run = lambda: mesh.relax_mesh(x0, prev, cfg, **kw)
+  c = _with_env({'SFM_MESH_SMALL': '1', 'SFM_MESH_PERSISTENT': '0'}, run)
+  d = _with_env({'SFM_MESH_SMALL': '0', 'SFM_MESH_PERSISTENT': '0'}, run)
+  np.testing.assert_array_equal(np.array(c[0]), np.array(d[0]))
+  assert c[1] == d[1] and c[2] == d[2]
