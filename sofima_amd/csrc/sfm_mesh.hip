@@ -871,17 +871,23 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
 
   const int lx = threadIdx.x % TX, ly0 = threadIdx.x / TX;
   float v_own[kRows][C], a_own[kRows][C], x_own[kRows][C];
+  // Loads from clamped coordinates, unconditional: a load under a per-lane
+  // condition gets its own block and the rows would be fetched one after the
+  // other (nodes beyond the mesh read a neighbour's state; never stored).
 #pragma unroll
   for (int k = 0; k < kRows; ++k) {
     const int ly = ly0 + k * kRowStep;
-    const int gy = gy0 + ly, gx = gx0 + lx;
-    if (gy < p.Y && gx < p.X) {
-      const long long n = base + (long long)gy * p.X + gx;
+    const int gy = min(gy0 + ly, p.Y - 1), gx = min(gx0 + lx, p.X - 1);
+    const long long n = base + (long long)gy * p.X + gx;
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        x_own[k][c] = advanced(n, c, &v_own[k][c], &a_own[k][c]);
-        xt[c][(ly + 1) * TW + lx + 1] = x_own[k][c];
-      }
+    for (int c = 0; c < C; ++c) x_own[k][c] = advanced(n, c, &v_own[k][c], &a_own[k][c]);
+  }
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    const int ly = ly0 + k * kRowStep;
+    if (gy0 + ly < p.Y && gx0 + lx < p.X) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) xt[c][(ly + 1) * TW + lx + 1] = x_own[k][c];
     }
   }
   constexpr int kHalo = 2 * TW + 2 * TY;
@@ -899,11 +905,14 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
       hx = (r & 1) ? TX : -1;
     }
     const int gy = gy0 + hy, gx = gx0 + hx;
-    if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X) {
-      const long long n = base + (long long)gy * p.X + gx;
+    const bool inside = gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X;
+    const long long n = base + (long long)min(max(gy, 0), p.Y - 1) * p.X + min(max(gx, 0), p.X - 1);
+    float hv[C];
 #pragma unroll
-      for (int c = 0; c < C; ++c)
-        xt[c][(hy + 1) * TW + hx + 1] = advanced(n, c, nullptr, nullptr);
+    for (int c = 0; c < C; ++c) hv[c] = advanced(n, c, nullptr, nullptr);
+    if (inside) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) xt[c][(hy + 1) * TW + hx + 1] = hv[c];
     }
   }
   __syncthreads();
@@ -917,6 +926,21 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
   for (int L = 0; L < 4; ++L) l0[L] = vec_len(p.rest[L], 2);
   float part[kNP];
   for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+  // the remaining per-node inputs, again all requested up front
+  float pv_own[kRows][C];
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    const int gy = min(gy0 + ly0 + k * kRowStep, p.Y - 1), gx = min(gx0 + lx, p.X - 1);
+    const long long n = base + (long long)gy * p.X + gx;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      pv_own[k][c] = p.has_prev ? prev[c * p.N + n] : 0.f;
+      if (!FUSED) {
+        a_own[k][c] = a_in[c * p.N + n];
+        v_own[k][c] = v_in[c * p.N + n];
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kRows; ++k) {
     const int ly = ly0 + k * kRowStep;
@@ -930,9 +954,9 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const float xv = x_own[k][c];
-      if (p.has_prev) f[c] = f[c] + prev_pull(xv, prev[c * p.N + n], p.neg_k0, cap);
-      const float a_old = FUSED ? a_own[k][c] : a_in[c * p.N + n];
-      const float v_old = FUSED ? v_own[k][c] : v_in[c * p.N + n];
+      if (p.has_prev) f[c] = f[c] + prev_pull(xv, pv_own[k][c], p.neg_k0, cap);
+      const float a_old = a_own[k][c];
+      const float v_old = v_own[k][c];
       vn[c] = fact0 * (v_old * fact1 + hdt * (a_old + f[c]));
       a_out[c * p.N + n] = f[c];
       if (FUSED) x_out[c * p.N + n] = xv;
@@ -1073,27 +1097,71 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
     live[k] = gx < p.X && gy < p.Y && gz < p.Z;
     ctr[k] = ((lz + 1) * PY + ly + 1) * PX + lx + 1;
     n_own[k] = base + ((long long)gz * p.Y + gy) * p.X + gx;
+    // loads from clamped coordinates, unconditional (a load under a per-lane
+    // condition gets its own block: the groups would be fetched one by one)
+    const long long nc = base + ((long long)min(gz, p.Z - 1) * p.Y + min(gy, p.Y - 1)) * p.X +
+                         min(gx, p.X - 1);
+#pragma unroll
+    for (int c = 0; c < C; ++c) x_own[k][c] = advanced(nc, c, &v_own[k][c], &a_own[k][c]);
+  }
+  // shell cells (the six faces of the padded brick), enumerated directly
+  constexpr int kFaceZ = PY * PX, kFaceY = (PZ - 2) * PX, kFaceX = (PZ - 2) * (PY - 2);
+  constexpr int kShell = 2 * (kFaceZ + kFaceY + kFaceX);
+  constexpr int kShellIt = (kShell + kBlock - 1) / kBlock;
+  float sh[kShellIt][C];
+  int sh_cell[kShellIt];
+#pragma unroll
+  for (int it = 0; it < kShellIt; ++it) {
+    const int sidx = min(threadIdx.x + it * kBlock, kShell - 1);
+    int hx, hy, hz;
+    if (sidx < 2 * kFaceZ) {
+      const int r = sidx % kFaceZ;
+      hz = sidx < kFaceZ ? 0 : PZ - 1;
+      hy = r / PX;
+      hx = r % PX;
+    } else if (sidx < 2 * (kFaceZ + kFaceY)) {
+      const int t2 = sidx - 2 * kFaceZ, r = t2 % kFaceY;
+      hy = t2 < kFaceY ? 0 : PY - 1;
+      hz = 1 + r / PX;
+      hx = r % PX;
+    } else {
+      const int t2 = sidx - 2 * (kFaceZ + kFaceY), r = t2 % kFaceX;
+      hx = t2 < kFaceX ? 0 : PX - 1;
+      hz = 1 + r / (PY - 2);
+      hy = 1 + r % (PY - 2);
+    }
+    const int gx = gx0 + hx - 1, gy = gy0 + hy - 1, gz = gz0 + hz - 1;
+    const bool inside = threadIdx.x + it * kBlock < kShell && gx >= 0 && gx < p.X &&
+                        gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z;
+    sh_cell[it] = inside ? (hz * PY + hy) * PX + hx : -1;
+    const long long n = base + ((long long)min(max(gz, 0), p.Z - 1) * p.Y +
+                                min(max(gy, 0), p.Y - 1)) * p.X + min(max(gx, 0), p.X - 1);
+#pragma unroll
+    for (int c = 0; c < C; ++c) sh[it][c] = advanced(n, c, nullptr, nullptr);
+  }
+  // the remaining per-node input
+  float pv_own[kOwn][C];
+#pragma unroll
+  for (int k = 0; k < kOwn; ++k) {
+    const int cell = threadIdx.x + k * kBlock;
+    const int lx = cell % kTX3, ly = (cell / kTX3) % kTY3, lz = cell / (kTX3 * kTY3);
+    const long long nc = base + ((long long)min(gz0 + lz, p.Z - 1) * p.Y + min(gy0 + ly, p.Y - 1)) * p.X +
+                         min(gx0 + lx, p.X - 1);
+#pragma unroll
+    for (int c = 0; c < C; ++c) pv_own[k][c] = p.has_prev ? prev[c * p.N + nc] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < kOwn; ++k)
     if (live[k]) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        x_own[k][c] = advanced(n_own[k], c, &v_own[k][c], &a_own[k][c]);
-        xt[c][ctr[k]] = x_own[k][c];
-      }
+      for (int c = 0; c < C; ++c) xt[c][ctr[k]] = x_own[k][c];
     }
-  }
-  // shell cells
-  for (int cell = threadIdx.x; cell < kCells; cell += kBlock) {
-    const int hx = cell % PX, hy = (cell / PX) % PY, hz = cell / (PX * PY);
-    const bool inner = hx >= 1 && hx <= kTX3 && hy >= 1 && hy <= kTY3 && hz >= 1 &&
-                       hz <= kTZ3;
-    if (inner) continue;
-    const int gx = gx0 + hx - 1, gy = gy0 + hy - 1, gz = gz0 + hz - 1;
-    if (gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
-      const long long n = base + ((long long)gz * p.Y + gy) * p.X + gx;
 #pragma unroll
-      for (int c = 0; c < C; ++c) xt[c][cell] = advanced(n, c, nullptr, nullptr);
+  for (int it = 0; it < kShellIt; ++it)
+    if (sh_cell[it] >= 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) xt[c][sh_cell[it]] = sh[it][c];
     }
-  }
   __syncthreads();
 
   const float hdtg = (0.5f * dt) * p.gamma;
@@ -1146,7 +1214,7 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
     for (int c = 0; c < C; ++c) {
       const float xv = self[c];
       f[c] = acc[c];
-      if (p.has_prev) f[c] = f[c] + prev_pull(xv, prev[c * p.N + n], p.neg_k0, cap);
+      if (p.has_prev) f[c] = f[c] + prev_pull(xv, pv_own[k][c], p.neg_k0, cap);
       vn[c] = fact0 * (v_own[k][c] * fact1 + hdt * (a_own[k][c] + f[c]));
       a_out[c * p.N + n] = f[c];
       x_out[c * p.N + n] = xv;
