@@ -1010,6 +1010,251 @@ integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in
 }
 
 // ---------------------------------------------------------------------------
+// In-plane step with every spring evaluated ONCE.
+//
+// A spring between node n and n + dir is the "near side" term of n and the "far
+// side" term of n + dir: the same d = x[n + dir] - x[n] + rest, the same force,
+// bit for bit (mesh.py:107-169 adds it to one end and subtracts it from the
+// other).  integrate_tiled2d_kernel evaluates it at both ends: 8 evaluations
+// of ~54 VALU slots per node, which is what bounds that kernel.  Here a lane
+// owns one COLUMN of a 16-row tile (a wave = 4 consecutive rows x 64 columns:
+// 62 owned + the two halo columns), evaluates only the four near-side springs
+// of its nodes (and three of the row above its rows), and receives the
+// far-side terms from the lane to its left / right with DPP wave shifts (the
+// vertical one from its own registers): 19 evaluations + 24 shifts per four
+// nodes instead of 32 evaluations.  Sums are taken in the reference's order
+// (far sides of links 0..3, then near sides), so the forces are bit-identical
+// to the other kernels'.
+// ---------------------------------------------------------------------------
+constexpr int kSX = 62, kSY = 16;
+
+// value of the lane to the left / right (lane 0 / 63 receive 0)
+__device__ __forceinline__ float lane_left(float v) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));  // wave_shr:1
+}
+__device__ __forceinline__ float lane_right(float v) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));  // wave_shl:1
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(kBlock, SFM_LBT)
+integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_in,
+                          const float* __restrict__ prev, float* x_out, float* v_out,
+                          float* a_out, MeshParams p,
+                          const Scalars* __restrict__ scal_in,
+                          Scalars* __restrict__ scal_out, float fixed_cap,
+                          u64* __restrict__ partials, int* __restrict__ ticket,
+                          int pending, int nty, int ntx) {
+  constexpr int C = 2;
+  constexpr int TW = 64;         // columns -1 .. kSX of the tile
+  constexpr int kRows = 4;       // rows per thread
+  __shared__ float xt[C][(kSY + 2) * TW];
+  __shared__ float lds[kNP * kBlock];
+  __shared__ int s_last;
+  const unsigned epoch = static_cast<unsigned>(ticket[1]) + 1u;
+
+  Scalars s;
+  if (p.fire) {
+    s = *scal_in;
+    if (!pending) {
+      s.gate = 1.f;
+      for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+    }
+  } else {
+    s.dt = p.vv_dt;
+    s.alpha = 0.f;
+    s.cap = fixed_cap;
+    s.gate = 1.f;
+    for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+  }
+  const float dt = s.dt, alpha = s.alpha, cap = s.cap;
+  const float c2 = 0.5f * (dt * dt);
+  const bool fix = p.fire && pending;
+
+  const int tx = blockIdx.x % ntx;
+  const int ty = (blockIdx.x / ntx) % nty;
+  const long long plane = blockIdx.x / (ntx * nty);  // b * Z + z
+  const long long base = plane * p.Y * p.X;
+  const int gx0 = tx * kSX, gy0 = ty * kSY;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gx = gx0 + lane - 1;                 // this lane's column
+  const int gxc = min(max(gx, 0), p.X - 1);      // clamped for the loads
+  const bool col_in = gx >= 0 && gx < p.X;
+  const bool col_own = lane >= 1 && lane <= kSX && gx < p.X;
+  const int r0 = kRows * wave;                   // first tile row of this thread
+
+  // Position of one node after the position update (FUSED) / as stored.
+  auto advanced = [&](long long n, int c, float* v_keep, float* a_keep) -> float {
+    float xv = x_in[c * p.N + n];
+    if (!FUSED) return xv;
+    float vv = v_in[c * p.N + n];
+    const float aa = a_in[c * p.N + n];
+    if (fix) {
+      vv = vv * s.gate;
+      if (p.remove_drift) {
+        xv = xv - s.mx[c];
+        vv = vv - s.mv[c];
+      }
+    }
+    if (v_keep) *v_keep = vv;
+    if (a_keep) *a_keep = aa;
+    return xv + (dt * vv + c2 * aa);
+  };
+
+  // All loads up front, unconditional, from clamped coordinates.
+  float x_own[kRows][C], v_own[kRows][C], a_own[kRows][C], pv_own[kRows][C];
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    const long long n = base + (long long)min(gy0 + r0 + k, p.Y - 1) * p.X + gxc;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      x_own[k][c] = advanced(n, c, &v_own[k][c], &a_own[k][c]);
+      pv_own[k][c] = p.has_prev ? prev[c * p.N + n] : 0.f;
+      if (!FUSED) {
+        a_own[k][c] = a_in[c * p.N + n];
+        v_own[k][c] = v_in[c * p.N + n];
+      }
+    }
+  }
+  // halo rows: the row above the tile (wave 0) and the row below it (wave 1)
+  const int hrow = wave == 0 ? -1 : kSY;
+  float x_halo[C] = {0.f, 0.f};
+  if (wave < 2) {
+    const long long n = base + (long long)min(max(gy0 + hrow, 0), p.Y - 1) * p.X + gxc;
+#pragma unroll
+    for (int c = 0; c < C; ++c) x_halo[c] = advanced(n, c, nullptr, nullptr);
+  }
+#pragma unroll
+  for (int k = 0; k < kRows; ++k)
+#pragma unroll
+    for (int c = 0; c < C; ++c) xt[c][(r0 + k + 1) * TW + lane] = x_own[k][c];
+  if (wave < 2) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) xt[c][(hrow + 1) * TW + lane] = x_halo[c];
+  }
+  __syncthreads();
+
+  float l0[4];
+#pragma unroll
+  for (int L = 0; L < 4; ++L) l0[L] = vec_len(p.rest[L], 2);
+  // Near-side springs of rows r0 - 1 .. r0 + 3 of this column: ns[L][k + 1][c].
+  // (Nodes or neighbours outside the mesh give garbage that the `ok` selects
+  // below discard; columns beyond the tile are clamped, their values unused.)
+  float ns[4][kRows + 1][C];
+  const int lc = lane;
+  const int lp = min(lane + 1, TW - 1), lm = max(lane - 1, 0);
+#pragma unroll
+  for (int k = -1; k < kRows; ++k) {
+    const int row = (r0 + k + 1) * TW;  // LDS row of tile row r0 + k
+    const float s0 = xt[0][row + lc], s1 = xt[1][row + lc];
+    if (k >= 0)
+      spring_xy<1, 0>(xt[0][row + lp] - s0 + p.rest[0][0], xt[1][row + lp] - s1 + p.rest[0][1],
+                      l0[0], p.neg_k[0], p.prefer, ns[0][k + 1]);
+    spring_xy<0, 1>(xt[0][row + TW + lc] - s0 + p.rest[1][0],
+                    xt[1][row + TW + lc] - s1 + p.rest[1][1], l0[1], p.neg_k[1], p.prefer,
+                    ns[1][k + 1]);
+    spring_xy<1, 1>(xt[0][row + TW + lp] - s0 + p.rest[2][0],
+                    xt[1][row + TW + lp] - s1 + p.rest[2][1], l0[2], p.neg_k[2], p.prefer,
+                    ns[2][k + 1]);
+    spring_xy<-1, 1>(xt[0][row + TW + lm] - s0 + p.rest[3][0],
+                     xt[1][row + TW + lm] - s1 + p.rest[3][1], l0[3], p.neg_k[3], p.prefer,
+                     ns[3][k + 1]);
+  }
+
+  const float hdtg = (0.5f * dt) * p.gamma;
+  const float fact0 = 1.0f / (1.0f + hdtg);
+  const float fact1 = 1.0f - hdtg;
+  const float hdt = 0.5f * dt;
+  float part[kNP];
+  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    const int gy = gy0 + r0 + k;
+    // far-side terms: the near-side spring of the node at -dir (wave shifts
+    // run on every lane, owners or not)
+    float fs[4][C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      fs[0][c] = lane_left(ns[0][k + 1][c]);   // (x - 1, y)
+      fs[1][c] = ns[1][k][c];                  // (x, y - 1)
+      fs[2][c] = lane_left(ns[2][k][c]);       // (x - 1, y - 1)
+      fs[3][c] = lane_right(ns[3][k][c]);      // (x + 1, y - 1)
+    }
+    const bool own = col_own && gy < p.Y;
+    if (!own) continue;
+    const bool xm = gx - 1 >= 0, xp = gx + 1 < p.X, ym = gy - 1 >= 0, yp = gy + 1 < p.Y;
+    const bool okf[4] = {xm, ym, xm && ym, xp && ym};
+    const bool okn[4] = {xp, yp, xp && yp, xm && yp};
+    float f[C] = {0.f, 0.f}, vn[C];
+#pragma unroll
+    for (int L = 0; L < 4; ++L)
+#pragma unroll
+      for (int c = 0; c < C; ++c) f[c] = f[c] + (okf[L] ? fs[L][c] : 0.f);
+#pragma unroll
+    for (int L = 0; L < 4; ++L)
+#pragma unroll
+      for (int c = 0; c < C; ++c) f[c] = f[c] - (okn[L] ? ns[L][k + 1][c] : 0.f);
+    const long long n = base + (long long)gy * p.X + gx;
+    float a2 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float xv = x_own[k][c];
+      if (p.has_prev) f[c] = f[c] + prev_pull(xv, pv_own[k][c], p.neg_k0, cap);
+      const float a_old = a_own[k][c];
+      const float v_old = v_own[k][c];
+      vn[c] = fact0 * (v_old * fact1 + hdt * (a_old + f[c]));
+      a_out[c * p.N + n] = f[c];
+      if (FUSED) x_out[c * p.N + n] = xv;
+      a2 = a2 + f[c] * f[c];
+      v2 = v2 + vn[c] * vn[c];
+      if (p.fire) {
+        part[0] = part[0] + f[c] * vn[c];
+        part[1 + c] = part[1 + c] + xv;
+      }
+    }
+    if (p.fire) {
+      const float a_norm = sqrtf(a2) + 1e-6f;
+      const float v_norm = sqrtf(v2);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
+        part[4 + c] = part[4 + c] + vn[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) v_out[c * p.N + n] = vn[c];
+  }
+  if (!p.fire) return;
+  block_sum(part, 7, lds);
+  // (hand-off as in integrate_tiled2d_kernel)
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 7; ++i)
+      __hip_atomic_store(&partials[blockIdx.x * kNP + i],
+                         (static_cast<u64>(epoch) << 32) | __float_as_uint(part[i]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged before the ticket
+    s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT) ==
+             static_cast<int>(gridDim.x) - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float acc[kNP];
+  tile_tail_gather(partials, static_cast<int>(gridDim.x), p.remove_drift ? 7 : 1, epoch, acc);
+  block_sum(acc, 7, lds);
+  if (threadIdx.x == 0) {
+    Scalars in = *scal_in, o;
+    scalars_from_sums(in, acc, p, &o);
+    *scal_out = o;
+    ticket[1] = static_cast<int>(epoch);
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // LDS-tiled fused step for volumetric meshes (elastic_mesh_3d with the 13
 // default links).  The multi-launch path re-reads 78 neighbour values per node
 // through L1 / L2 (26 springs x 3 components) and needs two launches per step;
@@ -2427,6 +2672,11 @@ struct TilePlan {
   long long tiles = 0;
 };
 
+bool shared_enabled() {
+  const char* e = getenv("SFM_MESH_SHARED");  // "0": both ends evaluate every spring
+  return !(e && e[0] == '0');
+}
+
 bool tiled_enabled() {
   const char* e = getenv("SFM_MESH_TILED");
   return !(e && e[0] == '0');
@@ -2466,6 +2716,17 @@ TilePlan plan_bricks(const SfmMeshDesc* d) {
 TilePlan plan_tiles(int ncomp, long long planes, int Y, int X) {
   TilePlan best;
   if (ncomp != 2 || !tiled_enabled() || X < 16 || Y < 4) return best;
+  // every spring once (integrate_shared2d_kernel): 16 x 62 tiles, a lane per
+  // column; pays off unless most of a 64-lane row would hang over the mesh
+  if (shared_enabled() && X >= 40) {
+    best.ty = kSY;
+    best.tx = kSX;
+    best.nty = (Y + kSY - 1) / kSY;
+    best.ntx = (X + kSX - 1) / kSX;
+    best.tiles = planes * best.nty * best.ntx;
+    if (best.tiles > 0x7fffffffLL / kNP) best = TilePlan();
+    return best;
+  }
   const int shapes[2][2] = {{16, 64}, {32, 32}};
   long long best_cells = 0;
   for (const auto& sh : shapes) {
@@ -2765,7 +3026,12 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       float** bi = bufs[in];
       float** bo = bufs[in ^ 1];
       if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
-      if (tiles.tx == 64)
+      if (tiles.tx == kSX)
+        hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(tgrid), dim3(kBlock), 0, ls,
+                           bi[0], bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
+                           &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.nty,
+                           tiles.ntx);
+      else if (tiles.tx == 64)
         SFM_TILED(16, 64, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
       else
         SFM_TILED(32, 32, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
@@ -2779,7 +3045,12 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       cur ^= 1;
       if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, ls)) return rc;
       if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
-      if (tiles.tx == 64)
+      if (tiles.tx == kSX)
+        hipLaunchKernelGGL(integrate_shared2d_kernel<false>, dim3(tgrid), dim3(kBlock), 0, ls,
+                           d->x, d->v, d->a, prev_ptr, d->x, d->v, d->a, p, &w.scal[cur],
+                           &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, 1, tiles.nty,
+                           tiles.ntx);
+      else if (tiles.tx == 64)
         SFM_TILED(16, 64, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
       else
         SFM_TILED(32, 32, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
