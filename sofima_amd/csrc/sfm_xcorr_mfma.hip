@@ -295,14 +295,21 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
 // dwordx4 loads); only the last bytes of the image need the guarded path.
 __device__ __forceinline__ v4i load_16_bytes(const unsigned char* img, long long off,
                                              long long img_bytes) {
+  // ONE unconditional load from an address clamped into the image (a load
+  // under a per-lane condition gets its own basic block, and the loads of a
+  // staging round would be waited for one by one); at the very end of the image
+  // the bytes are shifted into place afterwards and the rest is zero.
+  // img_bytes >= 16 (mfma_i8_eligible).
+  const long long last = img_bytes - 16;
+  const long long o = off > last ? last : off;
   v4i v;
-  if (off + 16 <= img_bytes) {
-    __builtin_memcpy(&v, img + off, 16);
-  } else {
-    unsigned char t[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = off + k < img_bytes ? img[off + k] : 0;
-    __builtin_memcpy(&v, t, 16);
+  __builtin_memcpy(&v, img + o, 16);
+  const long long sh = off - o;
+  if (sh != 0) {
+    unsigned __int128 x;
+    __builtin_memcpy(&x, &v, 16);
+    x = sh >= 16 ? 0 : x >> (8 * static_cast<int>(sh));
+    __builtin_memcpy(&v, &x, 16);
   }
   return v;
 }
@@ -377,11 +384,10 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int u = 0; u < kItems; ++u) {
-        const int item = item0 + u * kPrepThreads;
+        const int item = min(item0 + u * kPrepThreads, n_items - 1);  // extra items: ignored
         const int y = item / n_chunks, ch = item - y * n_chunks;
         const long long off = (long long)(y0[s] + y) * a.ishape[s][1] + x0[s] + ch * 16;
-        w[s][u] = item < n_items ? load_16_bytes(a.img[s], off, img_bytes[s])
-                                 : v4i{0, 0, 0, 0};
+        w[s][u] = load_16_bytes(a.img[s], off, img_bytes[s]);
       }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -633,11 +639,10 @@ __device__ __forceinline__ void stage_patches(const StagePlane& p0, const StageP
       const int n_items = p.py * p.n_chunks;
 #pragma unroll
       for (int u = 0; u < kStageBatch; ++u) {
-        const int item = item0 + u * kThreads;
+        const int item = min(item0 + u * kThreads, n_items - 1);  // extra items: ignored
         const int y = item / p.n_chunks, ch = item - y * p.n_chunks;
         const long long off = (long long)(p.y0 + y) * p.W + p.x0 + ch * 16;
-        w[s][u] = item < n_items ? load_16_bytes(p.img, off, p.img_bytes)
-                                 : v4i{0, 0, 0, 0};
+        w[s][u] = load_16_bytes(p.img, off, p.img_bytes);
       }
     }
 #pragma unroll
@@ -2495,6 +2500,10 @@ bool mfma_i8_eligible(const SfmXcorrDesc* d) {
   if ((long long)py * px > 32768) return false;        // prep kernel LDS copy
   if ((long long)qy * qx * 16384 > 0x7fffffffLL) return false;  // int32 sums
   if ((py + qy - 1 + 15) / 16 > kWaves * kMaxTilesPerWave) return false;
+  // (the staging loads are 16 bytes wide and clamped into the image)
+  if ((long long)d->pre_shape[1] * d->pre_shape[2] < 16 ||
+      (long long)d->post_shape[1] * d->post_shape[2] < 16)
+    return false;
   if ((reinterpret_cast<uintptr_t>(d->pre_image) & 3) ||
       (reinterpret_cast<uintptr_t>(d->post_image) & 3))
     return false;
