@@ -36,7 +36,7 @@ bool fft_preferred(const SfmXcorrDesc* d);
 size_t fft_workspace_bytes(const SfmXcorrDesc* d);
 int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
                   const float* va, const float* vb, float* surface, float* den,
-                  float* ov, unsigned int* maxima, void* ws);
+                  float* ov, unsigned int* maxima, void* ws, unsigned int* smax);
 // Masked correlation: the normalised surface, padded to whole tiles; `smax`
 // (optional, zeroed by the caller) receives the ordered bits of every surface
 // maximum for the peak search.
@@ -1088,7 +1088,7 @@ int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
     if (masked) SFM_HIP_CHECK(hipMemsetAsync(w.maxima, 0, 2 * sizeof(unsigned int), st));
     sfm::prof_begin(sfm::kProfXcorr, st);
     const int rc = sfm::fft_correlate(d, w.a0, w.b0, w.va, w.vb, surface, w.den, w.ov,
-                                      w.maxima, w.fft);
+                                      w.maxima, w.fft, masked ? nullptr : smax);
     sfm::prof_end(sfm::kProfXcorr, st);
     if (rc) return rc;
     if (masked) {
@@ -1166,8 +1166,9 @@ int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
   // surface; its per-batch state has to be cleared before the launch.
   const bool fuse = use_mfma(d) && !is_masked(d);
   sfm::FusedPeaks fp;
-  // masked matrix-core path: the surface maxima come with the surfaces
-  const bool smax_pre = use_mfma(d) && is_masked(d);
+  // masked matrix-core path and un-masked FFT form: the surface maxima come with
+  // the surfaces
+  const bool smax_pre = (use_mfma(d) && is_masked(d)) || (!use_mfma(d) && use_fft(d) && !is_masked(d));
   if (fuse || smax_pre)
     SFM_HIP_CHECK(hipMemsetAsync(static_cast<char*>(d->workspace) + w.peaks.zero_from,
                                  0, w.peaks.zero_bytes,

@@ -12,6 +12,7 @@
 //           = irfft(rfft(a_pad) conj(rfft(b_pad)))[(k - (Q - 1)) mod F]
 #include "sfm_common.h"
 
+#include <algorithm>
 #include <cstdint>
 #include <hipfft/hipfft.h>
 
@@ -104,6 +105,7 @@ struct CropArgs {
   float* den;
   float* ov;
   unsigned int* maxima;
+  unsigned int* smax;  // [nb] or NULL: un-masked surfaces' maxima (ordered bits)
   int S[3], F[3], Q[3];
   long long Sn, Fn;
   float scale;        // 1 / Fn (hipFFT's inverse is unnormalised)
@@ -115,12 +117,14 @@ template <bool MASKED>
 __global__ void __launch_bounds__(kBlock) crop_kernel(CropArgs c) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long n_rows = c.total / c.S[2];
   const int rows_per_patch = c.S[0] * c.S[1];
   float mden = 0.f, mov = 0.f;
-  for (long long row = blockIdx.x * (long long)(kBlock / 64) + wave; row < n_rows;
-       row += (long long)gridDim.x * (kBlock / 64)) {
-    const long long b = row / rows_per_patch;
+  // grid.y = surface: the rows of a wave belong to one surface, so its maximum
+  // stays in a register until the end; waves of a workgroup take adjacent rows
+  const long long b = blockIdx.y;
+  float smax_run = -INFINITY;
+  for (long long row = b * rows_per_patch + blockIdx.x * (kBlock / 64) + wave;
+       row < (b + 1) * rows_per_patch; row += (long long)gridDim.x * (kBlock / 64)) {
     const int r = static_cast<int>(row - b * rows_per_patch);
     const int kz = r / c.S[1], ky = r - kz * c.S[1];
     int dz = kz - (c.Q[0] - 1), dy = ky - (c.Q[1] - 1);
@@ -128,15 +132,34 @@ __global__ void __launch_bounds__(kBlock) crop_kernel(CropArgs c) {
     if (dy < 0) dy += c.F[1];
     const long long s0 = b * c.Fn + ((long long)dz * c.F[1] + dy) * c.F[2];
     const long long o0 = row * c.S[2];
+    float rmax = -INFINITY;
+    if (!MASKED) {
+      // four 64-wide column groups per round, loads first (clamped columns)
+      for (int k0 = 0; k0 < c.S[2]; k0 += 256) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int dx = min(k0 + lane + 64 * j, c.S[2] - 1) - (c.Q[2] - 1);
+          if (dx < 0) dx += c.F[2];
+          v[j] = c.r[0][s0 + dx] * c.scale;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kx = k0 + lane + 64 * j;
+          if (kx < c.S[2]) {
+            c.out[o0 + kx] = v[j];
+            rmax = fmaxf(rmax, v[j]);
+          }
+        }
+      }
+      smax_run = fmaxf(smax_run, rmax);
+      continue;
+    }
     for (int kx = lane; kx < c.S[2]; kx += 64) {
       int dx = kx - (c.Q[2] - 1);
       if (dx < 0) dx += c.F[2];
       const long long s = s0 + dx;
       const float xc = c.r[0][s] * c.scale;
-      if (!MASKED) {
-        c.out[o0 + kx] = xc;
-        continue;
-      }
       const float sa = c.r[1][s] * c.scale, sb = c.r[2][s] * c.scale;
       const float nov = c.r[3][s] * c.scale;
       const float qa = c.r[4][s] * c.scale, qb = c.r[5][s] * c.scale;
@@ -152,6 +175,18 @@ __global__ void __launch_bounds__(kBlock) crop_kernel(CropArgs c) {
       c.ov[o0 + kx] = ovv;
       mden = fmaxf(mden, fabsf(den));
       mov = fmaxf(mov, ovv);
+    }
+    smax_run = fmaxf(smax_run, rmax);
+  }
+  if (!MASKED && c.smax) {
+    // the surface maximum for the peak search (monotonic uint image of the float)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) smax_run = fmaxf(smax_run, __shfl_xor(smax_run, d, 64));
+    if (lane == 0 && smax_run > -INFINITY) {
+      const unsigned u = __float_as_uint(smax_run);
+      const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      // (same-address atomics serialise: only the waves that raise the maximum)
+      if (o > __atomic_load_n(&c.smax[b], __ATOMIC_RELAXED)) atomicMax(&c.smax[b], o);
     }
   }
   if (MASKED) {
@@ -283,7 +318,7 @@ size_t fft_workspace_bytes(const SfmXcorrDesc* d) {
 // (raw correlation, or the Padfield numerator), den, ov, maxima.
 int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
                   const float* va, const float* vb, float* surface, float* den,
-                  float* ov, unsigned int* maxima, void* ws) {
+                  float* ov, unsigned int* maxima, void* ws, unsigned int* smax) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   std::lock_guard<std::mutex> exec_lock(g_exec_mu);
   const FftGeo g = make_fft_geo(d);
@@ -321,10 +356,10 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
                         (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(p.dst) & 15) == 0;
       if (vec4)
-        hipLaunchKernelGGL(pad_kernel<true>, dim3(grid_for(p.total / g.F[2] * 64)),
+        hipLaunchKernelGGL(pad_kernel<true>, dim3(std::min(grid_for(p.total / g.F[2] * 64), 8192)),
                            dim3(kBlock), 0, st, p);
       else
-        hipLaunchKernelGGL(pad_kernel<false>, dim3(grid_for(p.total / g.F[2] * 64)),
+        hipLaunchKernelGGL(pad_kernel<false>, dim3(std::min(grid_for(p.total / g.F[2] * 64), 8192)),
                            dim3(kBlock), 0, st, p);
       SFM_LAUNCH_CHECK();
       if (hipfftExecR2C(fwd, pad, reinterpret_cast<hipfftComplex*>(out)) != HIPFFT_SUCCESS)
@@ -355,12 +390,16 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
     cr.den = den ? den + (long long)lo * g.Sn : nullptr;
     cr.ov = ov ? ov + (long long)lo * g.Sn : nullptr;
     cr.maxima = maxima;
+    // (x: workgroups striding over the rows of one surface, y: surface)
+    const int crop_rows = g.S[0] * g.S[1];
+    const dim3 crop_grid(std::max(1, std::min((crop_rows + 3) / 4, 8192 / std::max(nb, 1))), nb);
+    cr.smax = smax ? smax + lo : nullptr;
     if (!masked) {
       if (int rc = forward(a0, true, 0, spec[0])) return rc;
       if (int rc = forward(b0, false, 0, spec[1])) return rc;
       if (int rc = product(spec[0], spec[1], spec[0], pad)) return rc;
       for (int i = 0; i < 6; ++i) cr.r[i] = pad;
-      hipLaunchKernelGGL(crop_kernel<false>, dim3(grid_for(cr.total / g.S[2] * 64)),
+      hipLaunchKernelGGL(crop_kernel<false>, crop_grid,
                          dim3(kBlock), 0, st, cr);
       SFM_LAUNCH_CHECK();
     } else {
@@ -379,7 +418,7 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
         if (int rc = product(lhs[i], rhs[i], prod, real[i])) return rc;
         cr.r[i] = real[i];
       }
-      hipLaunchKernelGGL(crop_kernel<true>, dim3(grid_for(cr.total / g.S[2] * 64)),
+      hipLaunchKernelGGL(crop_kernel<true>, crop_grid,
                          dim3(kBlock), 0, st, cr);
       SFM_LAUNCH_CHECK();
     }

@@ -1209,7 +1209,8 @@ __device__ __forceinline__ void phase_finish(const MaskedFastArgs& g, int b,
       for (int d = 32; d > 0; d >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, d, 64));
       if (lane == 0 && rmax > -INFINITY) {
         const unsigned u = __float_as_uint(rmax);
-        atomicMax(&g.smax[b], (u & 0x80000000u) ? ~u : (u | 0x80000000u));
+        const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        if (o > __atomic_load_n(&g.smax[b], __ATOMIC_RELAXED)) atomicMax(&g.smax[b], o);
       }
     }
   } else {
