@@ -1255,6 +1255,292 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
 }
 
 // ---------------------------------------------------------------------------
+// Volumetric force + velocity update with every spring evaluated ONCE
+// (replaces integrate_kernel<3> for the 13 default links).
+//
+// As in integrate_shared2d_kernel a spring is the near-side term of one end
+// and the far-side term of the other, bit for bit.  A workgroup of 8 waves owns
+// a 6 x 62 patch of (y, x) columns -- wave = row -1 .. 6, lane = column -1 ..
+// 62, the outer ones are halo rows / columns that only evaluate the springs
+// their neighbours need -- and MARCHES along z.  At plane z a thread evaluates
+// the 13 springs from its node towards +dir (link 10 = (1,1,-1) from its far
+// end, so that every spring of the plane pair (z, z+1) is formed at plane z):
+//   same row, same plane (link 0)          -> neighbour lane, DPP wave shift
+//   row + 1, same plane (links 1, 3, 4)    -> LDS, read after a barrier
+//   same row, next plane (links 2, 5, 6)   -> kept in registers (+ wave shift)
+//   row +- 1, next plane (7, 9, 12 / 8, 11, 10) -> LDS, read one plane later
+// 13 evaluations per node (+ the halo rows: 14.5) instead of 26.  Positions of
+// three planes rotate through LDS.  The sums follow the reference's order
+// (per link: += far side, -= near side), so the forces are bit-identical to
+// node_force_default3d.  z is cut into segments (one workgroup each) to fill
+// the chip; a segment starts by forming the springs of the plane below it.
+// ---------------------------------------------------------------------------
+constexpr int kMW = 8, kMRows = kMW - 2, kMCols = 62;
+constexpr int kMThreads = 64 * kMW;
+constexpr int kMPosFloats = 3 * 3 * kMW * 64;   // three planes
+constexpr int kMExBFloats = 9 * kMW * 64;
+constexpr int kMExNFloats = 18 * kMW * 64;
+constexpr size_t kMarchLds = (kMPosFloats + kMExBFloats + kMExNFloats) * sizeof(float);
+
+__global__ void __launch_bounds__(kMThreads)
+integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
+                         float* __restrict__ a, const float* __restrict__ prev, MeshParams p,
+                         const Scalars* __restrict__ scal, float fixed_cap,
+                         float* __restrict__ partials, int nty, int ntx, int nseg,
+                         int seg_planes) {
+  extern __shared__ float march_lds[];
+  float* pos = march_lds;                    // [3][3][kMW][64]
+  float* exB = pos + kMPosFloats;            // [9][kMW][64]
+  float* exN = exB + kMExBFloats;            // [18][kMW][64]
+  constexpr int C = 3;
+  float dt, alpha, cap;
+  if (p.fire) {
+    dt = scal->dt;
+    alpha = scal->alpha;
+    cap = scal->cap;
+  } else {
+    dt = p.vv_dt;
+    alpha = 0.f;
+    cap = fixed_cap;
+  }
+  const float hdtg = (0.5f * dt) * p.gamma;
+  const float fact0 = 1.0f / (1.0f + hdtg);
+  const float fact1 = 1.0f - hdtg;
+  const float hdt = 0.5f * dt;
+
+  int t = blockIdx.x;
+  const int seg = t % nseg;
+  t /= nseg;
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  const long long batch = t / nty;
+  const long long vol = (long long)p.Z * p.Y * p.X;
+  const long long base = batch * vol;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gx = tx * kMCols + lane - 1, gy = ty * kMRows + wave - 1;
+  const int gxc = min(max(gx, 0), p.X - 1), gyc = min(max(gy, 0), p.Y - 1);
+  const bool own_col = lane >= 1 && lane <= kMCols && gx < p.X;
+  const bool own_row = wave >= 1 && wave <= kMRows && gy < p.Y;
+  const int z0 = seg * seg_planes, z1 = min(p.Z, z0 + seg_planes);
+  if (z0 >= p.Z) return;  // whole workgroup
+
+  float l0[13];
+#pragma unroll
+  for (int L = 0; L < 13; ++L) l0[L] = vec_len(p.rest[L], 3);
+
+  auto pos_at = [&](int plane, int c, int w, int l) -> float& {
+    return pos[((plane % 3) * 3 + c) * (kMW * 64) + w * 64 + l];
+  };
+  auto load_plane = [&](int zz, float* out) {
+    const long long n = base + ((long long)min(max(zz, 0), p.Z - 1) * p.Y + gyc) * p.X + gxc;
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = x[c * p.N + n];
+  };
+  const int z_first = z0 > 0 ? z0 - 1 : 0;
+  {
+    float q0[C], q1[C];
+    load_plane(z_first, q0);
+    load_plane(z_first + 1, q1);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      pos_at(z_first, c, wave, lane) = q0[c];
+      pos_at(z_first + 1, c, wave, lane) = q1[c];
+    }
+  }
+  __syncthreads();
+
+  const int wp = min(wave + 1, kMW - 1), wm = max(wave - 1, 0);
+  const int lp = min(lane + 1, 63), lm = max(lane - 1, 0);
+  const bool xm = gx - 1 >= 0, xp = gx + 1 < p.X, ym = gy - 1 >= 0, yp = gy + 1 < p.Y;
+  float c2[C] = {0.f, 0.f, 0.f}, c5[C] = {0.f, 0.f, 0.f}, c6[C] = {0.f, 0.f, 0.f};
+  float part[kNP];
+  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+
+  for (int z = z_first; z < z1; ++z) {
+    const bool pre = z < z0;  // only the springs towards plane z0 are formed
+    // ---- phase 0: loads of this iteration, all issued now
+    float q2[C];
+    load_plane(z + 2, q2);
+    const long long n = base + ((long long)z * p.Y + gyc) * p.X + gxc;
+    float v_old[C], a_old[C], pv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      v_old[c] = v[c * p.N + n];
+      a_old[c] = a[c * p.N + n];
+      pv[c] = p.has_prev ? prev[c * p.N + n] : 0.f;
+    }
+    // ---- phase 1: the springs of this node
+    float self[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) self[c] = pos_at(z, c, wave, lane);
+    float n0[C] = {}, n1[C] = {}, n3[C] = {}, n4[C] = {}, n2[C] = {}, n5[C] = {}, n6[C] = {},
+          n7[C] = {}, n9[C] = {}, n12[C] = {}, n8[C] = {}, n11[C] = {}, f10[C] = {};
+#define SFM_NEAR3(OUT, L, DX, DY, DZ, PL, W, LN)                                          \
+    {                                                                                     \
+      float d_[3];                                                                        \
+      _Pragma("unroll") for (int c = 0; c < 3; ++c)                                       \
+          d_[c] = pos_at(PL, c, W, LN) - self[c] + p.rest[L][c];                          \
+      spring_xyz<DX, DY, DZ>(d_, l0[L], p.neg_k[L], p.prefer, OUT);                       \
+    }
+    const bool rows_all = wave >= 1 && wave <= kMRows;  // owned rows: every spring
+    const bool row_lo = wave == 0, row_hi = wave == kMW - 1;
+    if (rows_all && !pre) SFM_NEAR3(n0, 0, 1, 0, 0, z, wave, lp)
+    if ((rows_all || row_lo) && !pre) {
+      SFM_NEAR3(n1, 1, 0, 1, 0, z, wp, lane)
+      SFM_NEAR3(n3, 3, 1, 1, 0, z, wp, lp)
+      SFM_NEAR3(n4, 4, -1, 1, 0, z, wp, lm)
+    }
+    if (rows_all) {
+      SFM_NEAR3(n2, 2, 0, 0, 1, z + 1, wave, lane)
+      SFM_NEAR3(n5, 5, 1, 0, 1, z + 1, wave, lp)
+      SFM_NEAR3(n6, 6, -1, 0, 1, z + 1, wave, lm)
+    }
+    if (rows_all || row_lo) {
+      SFM_NEAR3(n7, 7, 0, 1, 1, z + 1, wp, lane)
+      SFM_NEAR3(n9, 9, 1, 1, 1, z + 1, wp, lp)
+      SFM_NEAR3(n12, 12, -1, 1, 1, z + 1, wp, lm)
+    }
+    if (rows_all || row_hi) {
+      SFM_NEAR3(n8, 8, 0, -1, 1, z + 1, wm, lane)
+      SFM_NEAR3(n11, 11, 1, -1, 1, z + 1, wm, lp)
+      // link 10 = (1, 1, -1) from its far end b = this node: a = (x-1, y-1, z+1)
+      float d_[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d_[c] = self[c] - pos_at(z + 1, c, wm, lm) + p.rest[10][c];
+      spring_xyz<1, 1, -1>(d_, l0[10], p.neg_k[10], p.prefer, f10);
+    }
+#undef SFM_NEAR3
+    // terms that arrived from the plane below (written one iteration ago)
+    float fd7[C], fd9[C], fd12[C], fe8[C], fe11[C], nf10[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      fd7[c] = exN[((0 * 3 + c) * kMW + wave) * 64 + lane];
+      fd9[c] = exN[((1 * 3 + c) * kMW + wave) * 64 + lm];
+      fd12[c] = exN[((2 * 3 + c) * kMW + wave) * 64 + lp];
+      fe8[c] = exN[((3 * 3 + c) * kMW + wave) * 64 + lane];
+      fe11[c] = exN[((4 * 3 + c) * kMW + wave) * 64 + lm];
+      nf10[c] = exN[((5 * 3 + c) * kMW + wave) * 64 + lp];
+    }
+    __syncthreads();  // A: everyone has read the old exchange slots and plane z
+    // ---- phase 2: publish
+    if (wave + 1 < kMW) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (!pre) {
+          exB[((0 * 3 + c) * kMW + wave + 1) * 64 + lane] = n1[c];
+          exB[((1 * 3 + c) * kMW + wave + 1) * 64 + lane] = n3[c];
+          exB[((2 * 3 + c) * kMW + wave + 1) * 64 + lane] = n4[c];
+        }
+        exN[((0 * 3 + c) * kMW + wave + 1) * 64 + lane] = n7[c];
+        exN[((1 * 3 + c) * kMW + wave + 1) * 64 + lane] = n9[c];
+        exN[((2 * 3 + c) * kMW + wave + 1) * 64 + lane] = n12[c];
+      }
+    }
+    if (wave >= 1) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        exN[((3 * 3 + c) * kMW + wave - 1) * 64 + lane] = n8[c];
+        exN[((4 * 3 + c) * kMW + wave - 1) * 64 + lane] = n11[c];
+        exN[((5 * 3 + c) * kMW + wave - 1) * 64 + lane] = f10[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) pos_at(z + 2, c, wave, lane) = q2[c];
+    // far-side terms that travel along the row: every lane takes part
+    float f0[C], fc5[C], fc6[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      f0[c] = lane_left(n0[c]);
+      fc5[c] = lane_left(c5[c]);
+      fc6[c] = lane_right(c6[c]);
+    }
+    __syncthreads();  // B: exchange slots and plane z + 2 are in place
+    // ---- phase 3: this node's force and velocity
+    if (!pre && own_col && own_row) {
+      float f1[C], f3[C], f4[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        f1[c] = exB[((0 * 3 + c) * kMW + wave) * 64 + lane];
+        f3[c] = exB[((1 * 3 + c) * kMW + wave) * 64 + lm];
+        f4[c] = exB[((2 * 3 + c) * kMW + wave) * 64 + lp];
+      }
+      const bool zm = z - 1 >= 0, zp = z + 1 < p.Z;
+      float f[C] = {0.f, 0.f, 0.f}, vn[C];
+#define SFM_ADD(FAR, OKF, NEAR, OKN)                                           \
+      _Pragma("unroll") for (int c = 0; c < 3; ++c) {                          \
+        f[c] = f[c] + ((OKF) ? FAR[c] : 0.f);                                  \
+        f[c] = f[c] - ((OKN) ? NEAR[c] : 0.f);                                 \
+      }
+      SFM_ADD(f0, xm, n0, xp)                         // 0: ( 1, 0, 0)
+      SFM_ADD(f1, ym, n1, yp)                         // 1: ( 0, 1, 0)
+      SFM_ADD(c2, zm, n2, zp)                         // 2: ( 0, 0, 1)
+      SFM_ADD(f3, xm && ym, n3, xp && yp)             // 3: ( 1, 1, 0)
+      SFM_ADD(f4, xp && ym, n4, xm && yp)             // 4: (-1, 1, 0)
+      SFM_ADD(fc5, xm && zm, n5, xp && zp)            // 5: ( 1, 0, 1)
+      SFM_ADD(fc6, xp && zm, n6, xm && zp)            // 6: (-1, 0, 1)
+      SFM_ADD(fd7, ym && zm, n7, yp && zp)            // 7: ( 0, 1, 1)
+      SFM_ADD(fe8, yp && zm, n8, ym && zp)            // 8: ( 0,-1, 1)
+      SFM_ADD(fd9, xm && ym && zm, n9, xp && yp && zp)      // 9: ( 1, 1, 1)
+      SFM_ADD(f10, xm && ym && zp, nf10, xp && yp && zm)    // 10: ( 1, 1,-1)
+      SFM_ADD(fe11, xm && yp && zm, n11, xp && ym && zp)    // 11: ( 1,-1, 1)
+      SFM_ADD(fd12, xp && ym && zm, n12, xm && yp && zp)    // 12: (-1, 1, 1)
+#undef SFM_ADD
+      const long long nn = base + ((long long)z * p.Y + gy) * p.X + gx;
+      const bool own = gy >= p.own_y0 && gy < p.own_y1;
+      float a2 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float xv = self[c];
+        if (p.has_prev) f[c] = f[c] + prev_pull(xv, pv[c], p.neg_k0, cap);
+        vn[c] = fact0 * (v_old[c] * fact1 + hdt * (a_old[c] + f[c]));
+        a[c * p.N + nn] = f[c];
+        a2 = a2 + f[c] * f[c];
+        v2 = v2 + vn[c] * vn[c];
+        if (p.fire && own) {
+          part[0] = part[0] + f[c] * vn[c];
+          part[1 + c] = part[1 + c] + xv;
+        }
+      }
+      if (p.fire) {
+        const float a_norm = sqrtf(a2) + 1e-6f;
+        const float v_norm = sqrtf(v2);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
+          if (own) part[4 + c] = part[4 + c] + vn[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[c * p.N + nn] = vn[c];
+    }
+    // the springs towards the next plane stay with this thread
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      c2[c] = n2[c];
+      c5[c] = n5[c];
+      c6[c] = n6[c];
+    }
+  }
+  if (!p.fire) return;
+  // fixed-order reduction over the workgroup (scratch: the exchange slots)
+  __syncthreads();
+  float* red = exN;
+  for (int i = 0; i < 7; ++i) red[i * kMThreads + threadIdx.x] = part[i];
+  __syncthreads();
+  for (int st = kMThreads / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int i = 0; i < 7; ++i)
+        red[i * kMThreads + threadIdx.x] =
+            red[i * kMThreads + threadIdx.x] + red[i * kMThreads + threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kNP; ++i) partials[blockIdx.x * kNP + i] = i < 7 ? red[i * kMThreads] : 0.f;
+}
+
+// ---------------------------------------------------------------------------
 // LDS-tiled fused step for volumetric meshes (elastic_mesh_3d with the 13
 // default links).  The multi-launch path re-reads 78 neighbour values per node
 // through L1 / L2 (26 springs x 3 components) and needs two launches per step;
@@ -2677,6 +2963,19 @@ bool shared_enabled() {
   return !(e && e[0] == '0');
 }
 
+// Measured on MI355X: SLOWER than integrate_kernel<3> (394 vs 336 us per step on
+// [3,4,100^3]) although it forms 14.5 instead of 26 springs per node: 193 VGPRs
+// allow one 8-wave workgroup per CU (two waves per SIMD, two barriers per
+// plane), the halo row / column threads carry the per-thread overhead of the
+// exchange (positions, 27 + 27 exchanged floats, 26 guarded adds) without
+// owning nodes, and the tail of a second round of workgroups costs the rest.
+// Opt-in (SFM_MESH_MARCH=1), kept as the measured experiment; its forces are
+// bit-identical (test_volumetric_march_kernel_matches_two_sided_kernel).
+bool march_enabled() {
+  const char* e = getenv("SFM_MESH_MARCH");
+  return e && e[0] == '1';
+}
+
 bool tiled_enabled() {
   const char* e = getenv("SFM_MESH_TILED");
   return !(e && e[0] == '0');
@@ -2989,6 +3288,31 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     SFM_HIP_CHECK(hipMemsetAsync(w.tile_part, 0, (size_t)tiles.tiles * kNP * sizeof(u64), st));
     finish_mode = 2;
   }
+  // Volumetric meshes with the default links: every spring once (z-marching
+  // kernel) instead of integrate_kernel<3>.
+  int march_nty = 0, march_ntx = 0, march_nseg = 0, march_planes = 0, march_grid = 0;
+  if (march_enabled() && p.ncomp == 3 && p.default_links && p.force_kind == SFM_FORCE_SPRINGS &&
+      !tiled && p.N >= 32768 && p.Z >= 2) {
+    march_nty = (p.Y + kMRows - 1) / kMRows;
+    march_ntx = (p.X + kMCols - 1) / kMCols;
+    const long long cols = (long long)p.B * march_nty * march_ntx;
+    if (cols <= kMaxBlocks) {
+      // segments of z: enough workgroups to fill the chip, at least 8 planes each
+      const int want = static_cast<int>((768 + cols - 1) / cols);
+      march_nseg = std::max(1, std::min(std::min(want, p.Z / 8), static_cast<int>(kMaxBlocks / cols)));
+      march_planes = (p.Z + march_nseg - 1) / march_nseg;
+      march_nseg = (p.Z + march_planes - 1) / march_planes;
+      march_grid = static_cast<int>(cols * march_nseg);
+      static bool attr_set = false;
+      if (!attr_set) {
+        SFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_march3d_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          static_cast<int>(kMarchLds)));
+        attr_set = true;
+      }
+    }
+  }
+  const int part_rows = march_grid ? march_grid : grid;
   // One integration step, enqueued on `ls`.  The host-side state it toggles
   // (scalar / buffer ping-pong) has period two, and no launch carries a
   // per-step argument, so two consecutive steps can be replayed from a graph.
@@ -3059,14 +3383,21 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       if (p.fire) cur ^= 1;
     } else {
       SFM_STEP_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
-                        &w.scal[cur ^ 1], w.partials, grid, pending, w.colsum);
+                        &w.scal[cur ^ 1], w.partials, part_rows, pending, w.colsum);
       cur ^= 1;
       if (d->target)
         if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, ls)) return rc;
       if (int rc = external_force()) return rc;
       if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
-      SFM_STEP_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
-                        &w.scal[cur], cap0, w.partials);
+      if (march_grid) {
+        hipLaunchKernelGGL(integrate_march3d_kernel, dim3(march_grid), dim3(kMThreads),
+                           kMarchLds, ls, d->x, d->v, d->a, prev_ptr, p, &w.scal[cur], cap0,
+                           w.partials, march_nty, march_ntx, march_nseg, march_planes);
+        SFM_LAUNCH_CHECK();
+      } else {
+        SFM_STEP_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
+                          &w.scal[cur], cap0, w.partials);
+      }
       if (timing) sfm::prof_end(sfm::kProfMesh, ls);
       if (p.fire && p.drift_cols) {
         hipLaunchKernelGGL(drift_cols_kernel<3>, dim3(p.X, 3), dim3(kBlock), 0, ls, d->x,
@@ -3121,8 +3452,8 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     SFM_HIP_CHECK(hipMemcpyAsync(d->a, w.alt[2], bytes, hipMemcpyDeviceToDevice, st));
   }
   SFM_MESH_DISPATCH(finish_kernel, d->x, d->v, p, &w.scal[cur],
-                    &w.scal[cur ^ 1], w.partials, grid, finish_mode, w.stat_part,
-                    w.colsum);
+                    &w.scal[cur ^ 1], w.partials, finish_mode == 1 ? part_rows : grid,
+                    finish_mode, w.stat_part, w.colsum);
   cur ^= 1;
 #undef SFM_MESH_DISPATCH
   hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(kBlock), 0, st, w.stat_part,

@@ -506,3 +506,40 @@ def test_small_mesh_single_launch_is_bit_identical(gpu, case):
   d = _with_env({'SFM_MESH_SMALL': '0', 'SFM_MESH_PERSISTENT': '0'}, run)
   np.testing.assert_array_equal(np.array(c[0]), np.array(d[0]))
   assert c[1] == d[1] and c[2] == d[2]
+
+
+@pytest.mark.parametrize('shape', [(3, 2, 20, 23, 70), (3, 1, 37, 13, 131)])
+def test_volumetric_march_kernel_matches_two_sided_kernel(gpu, shape):
+  """integrate_march3d_kernel evaluates every spring once and hands the far-side
+  terms over (DPP, LDS, registers along z): same forces bit for bit, so without
+  drift removal (FIRE then depends on the SIGN of the power only) the whole
+  trajectory is bit-identical to integrate_kernel<3>; with drift removal the
+  sums are grouped differently and the states agree to round-off."""
+  from scipy import ndimage
+  from sofima_amd import mesh
+  rng = np.random.default_rng(44)
+  prev = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, 2, 2, 2)) * 60
+  prev = (prev + rng.standard_normal(shape)).astype(np.float32)
+  prev[:, :, :2, :3] = np.nan
+  x0 = (rng.standard_normal(shape) * 0.5).astype(np.float32)
+  for drift in (False, True):
+    cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.05, k=0.1, stride=(40, 40, 40),
+                                 num_iters=60, max_iters=120, stop_v_max=1e-9, dt_max=100,
+                                 start_cap=0.05, final_cap=10, prefer_orig_order=True,
+                                 remove_drift=drift)
+    vv = lambda: mesh.velocity_verlet(x0, np.zeros_like(x0), prev, cfg, cfg.start_cap,
+                                      mesh_force=mesh.elastic_mesh_3d)
+    a = _with_env({'SFM_MESH_MARCH': '1'}, vv)
+    b = _with_env({'SFM_MESH_MARCH': '0'}, vv)
+    assert a[5] == b[5]
+    if not drift:
+      for u, w in zip(a[:3], b[:3]):
+        np.testing.assert_array_equal(np.array(u), np.array(w))
+      assert a[3:] == b[3:]
+    else:
+      for u, w in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(np.array(u), np.array(w), rtol=1e-4,
+                                   atol=1e-5 * np.abs(np.array(w)).max())
+  wx, we, wt = mesh_oracle.relax_mesh(x0[:, :1, :8, :9, :10].copy(), prev[:, :1, :8, :9, :10].copy(),
+                                      cfg, mesh_force=mesh_oracle.elastic_mesh_3d)
+  assert np.isfinite(wx).all()
