@@ -143,11 +143,16 @@ def test_relax_matches_golden(gpu, golden):
   cfg = cfg_from(cfgs['fire'], mesh.IntegrationConfig)
   xs, ek, t = mesh.relax_mesh(g['xr'], np.zeros_like(g['xr']), cfg)
   assert t == int(g['fire_t'])
-  np.testing.assert_allclose(np.array(xs), g['fire_x'], atol=1e-3)
-  np.testing.assert_allclose(ek, g['fire_ekin'], rtol=1e-2, atol=1e-9)
+  # 300 steps; measured on MI355X: max |dx| 1.7e-6 (positions up to 6.5e-4),
+  # kinetic energies within 4.3e-4 relative
+  np.testing.assert_allclose(np.array(xs), g['fire_x'], atol=1e-5)
+  np.testing.assert_allclose(ek, g['fire_ekin'], rtol=2e-3, atol=1e-9)
   cfg = cfg_from(cfgs['em2d'], mesh.IntegrationConfig)
   xs, ek, t = mesh.relax_mesh(g['xe'], g['pe'], cfg)
   assert t == int(g['em2d_t'])
+  # 400 FIRE steps with force capping amplify the round-off of the first steps
+  # (same step count and FIRE branch sequence): measured max |dx| 1.6e-3 on
+  # positions up to 4.2 (3.8e-4 relative), kinetic energies within 2.5 %
   np.testing.assert_allclose(np.array(xs), g['em2d_x'], atol=5e-3)
   np.testing.assert_allclose(ek, g['em2d_ekin'], rtol=5e-2, atol=1e-6)
 
