@@ -549,6 +549,58 @@ def test_full_size_bench_workload_properties(gpu):
   check_flow(fc, want, sharp_rtol=2e-3)
 
 
+def test_full_size_masked_pair_properties(gpu, monkeypatch):
+  """BASELINE configs[1] at full size with masks used IN the correlation
+  (mask_only_for_patch_selection=False): discs on both images, so the batch
+  holds patches of all four classes (clean / pre / post / both masked).
+  Size-independent properties: the rigid content shift is recovered exactly by
+  every patch that is not dropped, and the class shortcuts give bit-identical
+  fields to running all eight passes for every patch (on a 2048^2 crop with
+  the same masks; the full pair takes the shortcuts)."""
+  from bench import synth_pair
+  from sofima_amd import flow_field as ff
+  pre, post = synth_pair(8192, 1002, shift=(3, -5))
+  rng = np.random.default_rng(77)
+  yy, xx = np.mgrid[-90:91, -90:91]
+  disc = yy ** 2 + xx ** 2 <= 90 ** 2
+  masks = []
+  for _ in range(2):
+    m = np.zeros(pre.shape, bool)
+    for _ in range(120):
+      y, x = rng.integers(90, 8192 - 91, 2)
+      m[y - 90:y + 91, x - 90:x + 91] |= disc
+    masks.append(m)
+  calc = ff.JAXMaskedXCorrWithStatsCalculator()
+  kw = dict(batch_size=1024, mask_only_for_patch_selection=False)
+  f = calc.flow_field(pre, post, 160, 40, pre_mask=masks[0], post_mask=masks[1], **kw)
+  assert f.shape == (4, 201, 201)
+  ok = ~np.isnan(f[0])
+  assert ok.mean() > 0.95
+  # (a patch that is mostly masked can lock onto a few-pixel overlap: that is
+  # the method, the reference does the same; the property is stated for
+  # patches with less than a quarter of their pixels masked on either side)
+  frac = np.maximum(ff._masked_counts(masks[0], (160, 160), (40, 40)),
+                    ff._masked_counts(masks[1], (160, 160), (40, 40))) / 160.0 ** 2
+  light = ok & (frac < 0.25)
+  assert light.mean() > 0.85
+  np.testing.assert_array_equal(f[0][light], -5.0)
+  np.testing.assert_array_equal(f[1][light], 3.0)
+  assert ((f[0][ok] == -5.0) & (f[1][ok] == 3.0)).mean() > 0.99
+  assert np.isfinite(f[2][light]).all()   # (sharpness of an NCC surface may be negative)
+  c = (slice(3000, 5048), slice(2000, 4048))
+  args = (pre[c], post[c], 160, 40)
+  ckw = dict(pre_mask=masks[0][c], post_mask=masks[1][c], **kw)
+  fast = calc.flow_field(*args, **ckw)
+  monkeypatch.setenv('SFM_MASKED_FAST', '0')
+  eight = calc.flow_field(*args, **ckw)
+  monkeypatch.delenv('SFM_MASKED_FAST')
+  np.testing.assert_array_equal(fast, eight)
+  cnt = ff._masked_counts(masks[0][c], (160, 160), (40, 40)) > 0
+  cnt2 = ff._masked_counts(masks[1][c], (160, 160), (40, 40)) > 0
+  # all four classes occur in the crop
+  assert (cnt & cnt2).any() and (cnt & ~cnt2).any() and (~cnt & cnt2).any() and (~cnt & ~cnt2).any()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('seed', range(8))
 def test_mfma_random_geometry_fuzz(gpu, seed):
