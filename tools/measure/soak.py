@@ -36,3 +36,16 @@ for i in range(n // 6):
   r = np.array(mesh.relax_mesh(torch.zeros_like(pb), pb, cfg2)[0])
   if not np.array_equal(r, r0): bad += 1
 print('mesh (tiled): %d runs, %d mismatches' % (n // 6, bad))
+# masked correlation (class lists, integral-image tables, two-pass assembly, atomics)
+pm = np.zeros(pre.shape, bool); qm = np.zeros(pre.shape, bool)
+for k in range(40):
+  y, x = rng.integers(100, 3900, 2)
+  (pm if k % 2 else qm)[y - 80:y + 80, x - 80:x + 80] = True
+pmt = torch.from_numpy(pm).cuda(); qmt = torch.from_numpy(qm).cuda()
+run = lambda: calc.flow_field(a, b, 160, 40, pre_mask=pmt, post_mask=qmt, batch_size=1024,
+                              mask_only_for_patch_selection=False)
+ref = run()
+bad = 0
+for i in range(n // 6):
+  if not np.array_equal(run(), ref, equal_nan=True): bad += 1
+print('flow (masked): %d runs, %d mismatches' % (n // 6, bad))
