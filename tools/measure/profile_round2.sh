@@ -25,5 +25,11 @@ PY
 python $R/tools/measure/configs_time.py > $O/configs_time.log 2>&1
 python $R/tools/measure/montage_time.py > $O/montage_time.log 2>&1
 python $R/tools/measure/mesh3d_time.py > $O/mesh3d_time.log 2>&1
+python $R/tools/measure/mesh_big.py > $O/mesh_big.log 2>&1
+python $R/tools/measure/masked_time.py > $O/masked_time.log 2>&1
+python $R/tools/measure/fft_time.py > $O/fft_time.log 2>&1
+python $R/tools/measure/pipeline_time.py > $O/pipeline_time.log 2>&1
+python $R/tools/measure/offset_time.py > $O/offset_time.log 2>&1
+python $R/tools/measure/power_probe.py > $O/power_probe.log 2>&1
 rm -rf $O/trace/*/*.db.tmp; find $O -name '*.db' -size +20M -delete
 cat $O/pytest.log $O/bench.json; tail -3 $O/bench.err
