@@ -89,7 +89,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
       print(' '.join(cmd))
     subprocess.run(cmd, check=True)
+    _stamp()
   return LIB_PATH
+
+
+def _stamp() -> None:
+  """Records the source revision the library was linked from (.build_sha, not
+  tracked): the profile scripts stamp their counter summaries with it.  The
+  snapshot a GPU box receives has no .git, so the file travels with the .so."""
+  root = os.path.join(PKG_DIR, '..')
+  try:
+    sha = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'],
+                         capture_output=True, text=True, check=True).stdout.strip()
+    dirty = subprocess.run(['git', '-C', root, 'status', '--porcelain', '--', 'sofima_amd/csrc',
+                            'include'], capture_output=True, text=True).stdout.strip()
+    with open(os.path.join(root, '.build_sha'), 'w') as f:
+      f.write(sha + ('+' if dirty else '') + '\n')
+  except (OSError, subprocess.CalledProcessError):
+    pass
 
 
 if __name__ == '__main__':

@@ -571,12 +571,27 @@ __device__ bool is_window_max(const float* s, const PeakArgs& p, int z, int y,
   float wm = -INFINITY;
   const bool outside = z - mz < 0 || z + mz >= p.S[0] || y - m < 0 || y + m >= p.S[1] ||
                        x - m < 0 || x + m >= p.S[2];
-  for (int dz = -mz; dz <= mz; ++dz)
-    for (int dy = -m; dy <= m; ++dy)
-      for (int dx = -m; dx <= m; ++dx)
-        wm = fmaxf(wm, surf_at(s, p, min(max(z + dz, 0), p.S[0] - 1),
-                               min(max(y + dy, 0), p.S[1] - 1),
-                               min(max(x + dx, 0), p.S[2] - 1)));
+  if (m == 2) {  // the default min_distance: a plane's 25 loads in flight together
+    for (int dz = -mz; dz <= mz; ++dz) {
+      float w[25];
+      const int zz = min(max(z + dz, 0), p.S[0] - 1);
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx)
+          w[(dy + 2) * 5 + dx + 2] = surf_at(s, p, zz, min(max(y + dy, 0), p.S[1] - 1),
+                                             min(max(x + dx, 0), p.S[2] - 1));
+#pragma unroll
+      for (int k = 0; k < 25; ++k) wm = fmaxf(wm, w[k]);
+    }
+  } else {
+    for (int dz = -mz; dz <= mz; ++dz)
+      for (int dy = -m; dy <= m; ++dy)
+        for (int dx = -m; dx <= m; ++dx)
+          wm = fmaxf(wm, surf_at(s, p, min(max(z + dz, 0), p.S[0] - 1),
+                                 min(max(y + dy, 0), p.S[1] - 1),
+                                 min(max(x + dx, 0), p.S[2] - 1)));
+  }
   if (outside) wm = fmaxf(wm, 0.f);
   return v == wm;
 }

@@ -1386,9 +1386,21 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
     // cannot change the maximum
     float wm = -INFINITY;
     const bool outside = y - m < 0 || y + m >= Sy || x - m < 0 || x + m >= Sx;
-    for (int dy = -m; dy <= m; ++dy) {
-      const float* wrow = surf + (long long)min(max(y + dy, 0), Sy - 1) * pitch;
-      for (int dx = -m; dx <= m; ++dx) wm = fmaxf(wm, wrow[min(max(x + dx, 0), Sx - 1)]);
+    if (m == 2) {  // the default min_distance: 25 loads in flight instead of a loop of waits
+      float w[25];
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx)
+          w[(dy + 2) * 5 + dx + 2] = surf[(long long)min(max(y + dy, 0), Sy - 1) * pitch +
+                                          min(max(x + dx, 0), Sx - 1)];
+#pragma unroll
+      for (int k = 0; k < 25; ++k) wm = fmaxf(wm, w[k]);
+    } else {
+      for (int dy = -m; dy <= m; ++dy) {
+        const float* wrow = surf + (long long)min(max(y + dy, 0), Sy - 1) * pitch;
+        for (int dx = -m; dx <= m; ++dx) wm = fmaxf(wm, wrow[min(max(x + dx, 0), Sx - 1)]);
+      }
     }
     if (outside) wm = fmaxf(wm, 0.f);
     if (v != wm) return;

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2; mkdir -p $O
 cd $R
 SHA=$(cat $R/.build_sha 2>/dev/null || echo unknown)
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest.log
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/pytest.log
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o r2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/trace.log 2>&1
