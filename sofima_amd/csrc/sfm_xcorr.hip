@@ -561,6 +561,9 @@ __device__ __forceinline__ float surf_at(const float* s, const PeakArgs& p, int 
 
 // img == maxfilter(img) (zero 'same' padding) for an element already known to
 // exceed the threshold (flow_field.py:238-254).
+// FAST: the 5 x 5 window of the default min_distance as 25 loads in flight (costs
+// registers: not for kernels where this is the rare path).
+template <bool FAST>
 __device__ bool is_window_max(const float* s, const PeakArgs& p, int z, int y,
                               int x, float v) {
   const int m = p.min_distance;
@@ -571,7 +574,7 @@ __device__ bool is_window_max(const float* s, const PeakArgs& p, int z, int y,
   float wm = -INFINITY;
   const bool outside = z - mz < 0 || z + mz >= p.S[0] || y - m < 0 || y + m >= p.S[1] ||
                        x - m < 0 || x + m >= p.S[2];
-  if (m == 2) {  // the default min_distance: a plane's 25 loads in flight together
+  if (FAST && m == 2) {  // the default min_distance: a plane's 25 loads in flight together
     for (int dz = -mz; dz <= mz; ++dz) {
       float w[25];
       const int zz = min(max(z + dz, 0), p.S[0] - 1);
@@ -624,7 +627,7 @@ __device__ float surface_max(const float* s, const PeakArgs& p, float* lv,
 }
 
 // Calls fn(flat_index, value) for every peak of the surface.
-template <typename F>
+template <bool FAST = true, typename F>
 __device__ void for_each_peak(const float* s, const PeakArgs& p, float thr, F fn,
                               int r0 = 0, int r1 = -1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -640,7 +643,7 @@ __device__ void for_each_peak(const float* s, const PeakArgs& p, float thr, F fn
 #pragma unroll
       for (int k = 0; k < kRowGroups; ++k) {
         const int x = xb + lane + 64 * k;
-        if (x < w && v[k] > thr && is_window_max(s, p, z, y, x, v[k]))
+        if (x < w && v[k] > thr && is_window_max<FAST>(s, p, z, y, x, v[k]))
           fn(r * w + x, v[k]);
       }
     }
@@ -778,7 +781,7 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
   } else {
     // Candidate list overflowed (plateaus): rescan the surface.
     const float mx = surface_max(s, p, lv, li);
-    for_each_peak(s, p, p.threshold_rel * mx, [&](int i, float v) {
+    for_each_peak<false>(s, p, p.threshold_rel * mx, [&](int i, float v) {
       if (((bitmap[i >> 5] >> (i & 31)) & 1u) == 0 && better(v, i, bv, bi)) {
         bv = v;
         bi = i;
