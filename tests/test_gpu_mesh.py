@@ -548,3 +548,37 @@ def test_volumetric_march_kernel_matches_two_sided_kernel(gpu, shape):
   wx, we, wt = mesh_oracle.relax_mesh(x0[:, :1, :8, :9, :10].copy(), prev[:, :1, :8, :9, :10].copy(),
                                       cfg, mesh_force=mesh_oracle.elastic_mesh_3d)
   assert np.isfinite(wx).all()
+
+
+@pytest.mark.parametrize('shape', [(2, 2, 17, 40), (2, 1, 33, 62), (2, 3, 16, 63), (2, 1, 5, 124),
+                                   (2, 2, 31, 125), (2, 1, 100, 311)])
+def test_shared_spring_step_is_bit_identical(gpu, shape):
+  """integrate_shared2d_kernel (every spring once, far-side terms through DPP
+  wave shifts) vs the kernels in which both ends evaluate every spring: the
+  forces are the same bit for bit, so without drift removal (FIRE depends on the
+  SIGN of the power only) the whole chunk is bit-identical for tile widths that
+  are not multiples of 62 / heights that are not multiples of 16; damped Verlet
+  and the in-place (prev_fn-style) form are covered by the montage test."""
+  from scipy import ndimage
+  from sofima_amd import mesh
+  rng = np.random.default_rng(shape[-1])
+  prev = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, 2, 2)) * 50
+  prev = (prev + rng.standard_normal(shape)).astype(np.float32)
+  prev[:, :, :2, :3] = np.nan
+  prev[:, :, -1, -2:] = np.nan
+  x0 = (rng.standard_normal(shape) * 0.5).astype(np.float32)
+  for kw in (dict(), dict(fire=False, gamma=0.5, dt=0.05, start_cap=10.0)):
+    base = dict(dt=0.001, gamma=0.0, k0=0.05, k=0.1, stride=(40, 40), num_iters=50, max_iters=100,
+                stop_v_max=1e-9, dt_max=100, start_cap=0.05, final_cap=10,
+                prefer_orig_order=True)
+    base.update(kw)
+    cfg = mesh.IntegrationConfig(**base)
+    vv = lambda: mesh.velocity_verlet(x0, np.zeros_like(x0), prev, cfg, cfg.start_cap)
+    env = {'SFM_MESH_PERSISTENT': '0'}
+    a = _with_env(dict(env, SFM_MESH_SHARED='1'), vv)
+    b = _with_env(dict(env, SFM_MESH_SHARED='0'), vv)
+    c = _with_env(dict(env, SFM_MESH_TILED='0'), vv)
+    for u, w, m in zip(a[:3], b[:3], c[:3]):
+      np.testing.assert_array_equal(np.array(u), np.array(w))
+      np.testing.assert_array_equal(np.array(u), np.array(m))
+    assert a[3:] == b[3:] == c[3:]
