@@ -599,28 +599,60 @@ __device__ bool is_window_max(const float* s, const PeakArgs& p, int z, int y,
   return v == wm;
 }
 
-// Row sweeps of the peak search: a wave takes whole rows, eight 64-wide column
-// groups at a time, and issues all the loads of such a piece before it looks at
-// the first value (clamped addresses, no load under a per-lane condition:
-// otherwise every load is waited for on its own).
-constexpr int kRowGroups = 8;
+// Row sweeps of the peak search: a wave takes whole rows and issues the loads of
+// a piece -- G 64-wide column groups of R consecutive rows of its share, G R = 8
+// -- before it looks at the first value (clamped addresses, no load under a
+// per-lane condition: otherwise every load is waited for on its own).  G is the
+// smallest of 1, 2, 4, 8 that covers the row, so narrow rows do not pay for
+// column groups that only repeat their last element.
+constexpr int kPiece = 8;
+
+template <int G, typename Body>
+__device__ __forceinline__ void sweep_rows(const float* s, const PeakArgs& p, int r0, int rows,
+                                           Body body) {
+  constexpr int R = kPiece / G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int w = p.S[2];
+  constexpr int kStep = kBlock / 64;  // rows are dealt to the waves round robin
+  for (int rb = r0 + wave; rb < rows; rb += kStep * R) {
+    for (int xb = 0; xb < w; xb += 64 * G) {
+      float v[R][G];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const float* row = s + (long long)min(rb + j * kStep, rows - 1) * p.pitch;
+#pragma unroll
+        for (int k = 0; k < G; ++k) v[j][k] = row[min(xb + lane + 64 * k, w - 1)];
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          const int r = rb + j * kStep, x = xb + lane + 64 * k;
+          if (r < rows && x < w) body(r, x, v[j][k]);
+        }
+    }
+  }
+}
+
+template <typename Body>
+__device__ __forceinline__ void sweep_rows_any(const float* s, const PeakArgs& p, int r0, int rows,
+                                               Body body) {
+  const int w = p.S[2];
+  if (w <= 64)
+    sweep_rows<1>(s, p, r0, rows, body);
+  else if (w <= 128)
+    sweep_rows<2>(s, p, r0, rows, body);
+  else if (w <= 256)
+    sweep_rows<4>(s, p, r0, rows, body);
+  else
+    sweep_rows<8>(s, p, r0, rows, body);
+}
 
 __device__ float surface_max(const float* s, const PeakArgs& p, float* lv,
                              int* li, int r0 = 0, int r1 = -1) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rows = r1 < 0 ? p.S[0] * p.S[1] : r1;
-  const int w = p.S[2];
   float mx = -INFINITY;
-  for (int r = r0 + wave; r < rows; r += kBlock / 64) {
-    const float* row = s + (long long)r * p.pitch;
-    for (int xb = 0; xb < w; xb += 64 * kRowGroups) {
-      float v[kRowGroups];
-#pragma unroll
-      for (int k = 0; k < kRowGroups; ++k) v[k] = row[min(xb + lane + 64 * k, w - 1)];
-#pragma unroll
-      for (int k = 0; k < kRowGroups; ++k) mx = fmaxf(mx, v[k]);  // duplicates are harmless
-    }
-  }
+  sweep_rows_any(s, p, r0, rows, [&](int, int, float v) { mx = fmaxf(mx, v); });
   int dummy = 0;
   block_argmax(&mx, &dummy, lv, li);
   return mx;
@@ -630,24 +662,14 @@ __device__ float surface_max(const float* s, const PeakArgs& p, float* lv,
 template <bool FAST = true, typename F>
 __device__ void for_each_peak(const float* s, const PeakArgs& p, float thr, F fn,
                               int r0 = 0, int r1 = -1) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rows = r1 < 0 ? p.S[0] * p.S[1] : r1;
   const int w = p.S[2];
-  for (int r = r0 + wave; r < rows; r += kBlock / 64) {
-    const int z = r / p.S[1], y = r - z * p.S[1];
-    const float* row = s + (long long)r * p.pitch;
-    for (int xb = 0; xb < w; xb += 64 * kRowGroups) {
-      float v[kRowGroups];
-#pragma unroll
-      for (int k = 0; k < kRowGroups; ++k) v[k] = row[min(xb + lane + 64 * k, w - 1)];
-#pragma unroll
-      for (int k = 0; k < kRowGroups; ++k) {
-        const int x = xb + lane + 64 * k;
-        if (x < w && v[k] > thr && is_window_max<FAST>(s, p, z, y, x, v[k]))
-          fn(r * w + x, v[k]);
-      }
+  sweep_rows_any(s, p, r0, rows, [&](int r, int x, float v) {
+    if (v > thr) {
+      const int z = r / p.S[1], y = r - z * p.S[1];
+      if (is_window_max<FAST>(s, p, z, y, x, v)) fn(r * w + x, v);
     }
-  }
+  });
 }
 
 __global__ void __launch_bounds__(kBlock) peaks_first_kernel(PeakArgs p) {
