@@ -762,21 +762,7 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_masked_kernel(MfmaArgs a) 
   // (byte loads only in the last, partial item of a row)
   const int n_chunks = (px + 15) >> 4;
   const int n_items = py * n_chunks;
-  for (int item = threadIdx.x; item < n_items; item += kThreads) {
-    const int y = item / n_chunks, ch = item - y * n_chunks;
-    const int x = 16 * ch, nx = min(16, px - x);
-    const unsigned char* ip = a.img[s] + (long long)(y0 + y) * W + x0 + x;
-    const unsigned char* mp = mask ? mask + (long long)(my0 + y) * MW + mx0 + x : nullptr;
-    unsigned pw[4] = {0, 0, 0, 0}, mw[4] = {0, 0, 0, 0};
-    if (nx == 16) {
-      __builtin_memcpy(pw, ip, 16);
-      if (mp) __builtin_memcpy(mw, mp, 16);
-    } else {
-      for (int j = 0; j < nx; ++j) {
-        pw[j >> 2] |= static_cast<unsigned>(ip[j]) << (8 * (j & 3));
-        if (mp) mw[j >> 2] |= static_cast<unsigned>(mp[j]) << (8 * (j & 3));
-      }
-    }
+  auto tally = [&](const unsigned* pw, const unsigned* mw, int nx) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int v = static_cast<int>((pw[j >> 2] >> (8 * (j & 3))) & 0xffu);
@@ -785,6 +771,50 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_masked_kernel(MfmaArgs a) 
       mx = ok ? max(mx, v) : mx;
       sum += ok ? v : 0;
       cnt += ok ? 1 : 0;
+    }
+  };
+  if ((px & 15) == 0) {
+    // whole 16-byte items only: four items per round, their eight loads issued
+    // as one straight-line group (items past the end repeat the last one and
+    // are ignored; without a mask the image stands in and its bytes are dropped)
+    const unsigned char* mbase = mask ? mask + (long long)my0 * MW + mx0
+                                      : a.img[s] + (long long)y0 * W + x0;
+    const long long mpitch = mask ? MW : W;
+    const unsigned mkeep = mask ? 0xffffffffu : 0u;
+    constexpr int kRound = 4;
+    for (int item0 = threadIdx.x; item0 < n_items; item0 += kThreads * kRound) {
+      unsigned pw[kRound][4], mw[kRound][4];
+#pragma unroll
+      for (int u = 0; u < kRound; ++u) {
+        const int item = min(item0 + u * kThreads, n_items - 1);
+        const int y = item / n_chunks, x = 16 * (item - y * n_chunks);
+        __builtin_memcpy(pw[u], a.img[s] + (long long)(y0 + y) * W + x0 + x, 16);
+        __builtin_memcpy(mw[u], mbase + y * mpitch + x, 16);
+      }
+#pragma unroll
+      for (int u = 0; u < kRound; ++u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mw[u][k] &= mkeep;
+        tally(pw[u], mw[u], item0 + u * kThreads < n_items ? 16 : 0);
+      }
+    }
+  } else {
+    for (int item = threadIdx.x; item < n_items; item += kThreads) {
+      const int y = item / n_chunks, ch = item - y * n_chunks;
+      const int x = 16 * ch, nx = min(16, px - x);
+      const unsigned char* ip = a.img[s] + (long long)(y0 + y) * W + x0 + x;
+      const unsigned char* mp = mask ? mask + (long long)(my0 + y) * MW + mx0 + x : nullptr;
+      unsigned pw[4] = {0, 0, 0, 0}, mw[4] = {0, 0, 0, 0};
+      if (nx == 16) {
+        __builtin_memcpy(pw, ip, 16);
+        if (mp) __builtin_memcpy(mw, mp, 16);
+      } else {
+        for (int j = 0; j < nx; ++j) {
+          pw[j >> 2] |= static_cast<unsigned>(ip[j]) << (8 * (j & 3));
+          if (mp) mw[j >> 2] |= static_cast<unsigned>(mp[j]) << (8 * (j & 3));
+        }
+      }
+      tally(pw, mw, nx);
     }
   }
   red[0][threadIdx.x] = mn;
