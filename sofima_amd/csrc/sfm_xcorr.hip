@@ -111,35 +111,52 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(GatherArgs g0, GatherArg
     ms[ax] = min(max(v, 0), g.mshape[ax] - g.psz[ax]);
   }
   const T* img = static_cast<const T*>(g.img);
-  const long long py = g.psz[1], px = g.psz[2];
-  auto pix = [&](long long i, float* val, bool* masked) {
-    const int x = static_cast<int>(i % px);
-    const long long r = i / px;
-    const int y = static_cast<int>(r % py);
-    const int z = static_cast<int>(r / py);
-    const long long off =
-        ((long long)(st[0] + z) * g.ishape[1] + (st[1] + y)) * g.ishape[2] +
-        (st[2] + x);
-    *val = static_cast<float>(img[off]);
-    *masked = false;
+  const int py = g.psz[1], px = g.psz[2];
+  const int pn = static_cast<int>(g.pn);  // < 2^16 here (larger patches: gather_big_kernel)
+  // Eight elements per round, their loads issued as one straight-line group
+  // (elements past the end repeat the last one and are ignored; the mask test
+  // is hoisted: a branch between the loads would make each wait on its own).
+  constexpr int kRound = 8;
+  auto offsets = [&](int i, long long* off, long long* mo) {
+    const int x = i % px;
+    const int r = i / px;
+    const int y = r % py;
+    const int z = r / py;
+    *off = ((long long)(st[0] + z) * g.ishape[1] + (st[1] + y)) * g.ishape[2] + (st[2] + x);
+    *mo = ((long long)(ms[0] + z) * g.mshape[1] + (ms[1] + y)) * g.mshape[2] + (ms[2] + x);
+  };
+  auto fetch = [&](int i0, float* val, bool* masked) {
     if (g.mask) {
-      const long long mo =
-          ((long long)(ms[0] + z) * g.mshape[1] + (ms[1] + y)) * g.mshape[2] +
-          (ms[2] + x);
-      *masked = g.mask[mo] != 0;
+#pragma unroll
+      for (int u = 0; u < kRound; ++u) {
+        long long off, mo;
+        offsets(min(i0 + u * kBlock, pn - 1), &off, &mo);
+        val[u] = static_cast<float>(img[off]);
+        masked[u] = g.mask[mo] != 0;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kRound; ++u) {
+        long long off, mo;
+        offsets(min(i0 + u * kBlock, pn - 1), &off, &mo);
+        val[u] = static_cast<float>(img[off]);
+        masked[u] = false;
+      }
     }
   };
   float mu = g.mean;
   if (!g.use_mean) {
     double s = 0.0, c = 0.0;
-    for (long long i = threadIdx.x; i < g.pn; i += kBlock) {
-      float v;
-      bool m;
-      pix(i, &v, &m);
-      if (!m) {
-        s += v;
-        c += 1.0;
-      }
+    for (int i0 = threadIdx.x; i0 < pn; i0 += kBlock * kRound) {
+      float v[kRound];
+      bool m[kRound];
+      fetch(i0, v, m);
+#pragma unroll
+      for (int u = 0; u < kRound; ++u)
+        if (i0 + u * kBlock < pn && !m[u]) {  // same order of additions as element by element
+          s += v[u];
+          c += 1.0;
+        }
     }
     s_sum[threadIdx.x] = s;
     s_cnt[threadIdx.x] = c;
@@ -153,12 +170,18 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(GatherArgs g0, GatherArg
     }
     mu = static_cast<float>(s_sum[0] / s_cnt[0]);  // NaN when all masked
   }
-  for (long long i = threadIdx.x; i < g.pn; i += kBlock) {
-    float v;
-    bool m;
-    pix(i, &v, &m);
-    g.out[b * g.pn + i] = m ? 0.f : v - mu;
-    if (g.valid) g.valid[b * g.pn + i] = m ? 0.f : 1.f;
+  for (int i0 = threadIdx.x; i0 < pn; i0 += kBlock * kRound) {
+    float v[kRound];
+    bool m[kRound];
+    fetch(i0, v, m);
+#pragma unroll
+    for (int u = 0; u < kRound; ++u) {
+      const int i = i0 + u * kBlock;
+      if (i < pn) {
+        g.out[b * g.pn + i] = m[u] ? 0.f : v[u] - mu;
+        if (g.valid) g.valid[b * g.pn + i] = m[u] ? 0.f : 1.f;
+      }
+    }
   }
 }
 
@@ -198,25 +221,57 @@ gather_big_kernel(GatherArgs g0, GatherArgs g1, double* __restrict__ partial) {
     mu = static_cast<float>(s / c);  // NaN when all masked
   }
   double s = 0.0, c = 0.0;
-  for (int r = r0 + wave; r < r1; r += kBlock / 64) {
-    const int z = r / py, y = r - z * py;
-    const long long io =
-        ((long long)(st[0] + z) * g.ishape[1] + (st[1] + y)) * g.ishape[2] + st[2];
-    const long long mo =
-        ((long long)(ms[0] + z) * g.mshape[1] + (ms[1] + y)) * g.mshape[2] + ms[2];
-    for (int x = lane; x < px; x += 64) {
-      const float v = static_cast<float>(img[io + x]);
-      const bool m = g.mask && g.mask[mo + x] != 0;
-      if (PHASE == 0) {
-        if (!m) {
-          s += v;
-          c += 1.0;
-        }
-      } else {
-        const long long o = b * g.pn + (long long)r * px + x;
-        g.out[o] = m ? 0.f : v - mu;
-        if (g.valid) g.valid[o] = m ? 0.f : 1.f;
+  // Four rows x two 64-wide column groups per round, loads issued as one
+  // straight-line group (clamped rows / columns, mask test hoisted); the sums
+  // are still added in (row, column group) order.
+  constexpr int kR = 4, kG = 2, kStep = kBlock / 64;
+  for (int rb = r0 + wave; rb < r1; rb += kStep * kR) {
+    for (int xb = 0; xb < px; xb += 64 * kG) {
+      float v[kR][kG];
+      bool m[kR][kG];
+      long long io[kR], mo[kR];
+#pragma unroll
+      for (int j = 0; j < kR; ++j) {
+        const int r = min(rb + j * kStep, r1 - 1);
+        const int z = r / py, y = r - z * py;
+        io[j] = ((long long)(st[0] + z) * g.ishape[1] + (st[1] + y)) * g.ishape[2] + st[2];
+        mo[j] = ((long long)(ms[0] + z) * g.mshape[1] + (ms[1] + y)) * g.mshape[2] + ms[2];
       }
+      if (g.mask) {
+#pragma unroll
+        for (int j = 0; j < kR; ++j)
+#pragma unroll
+          for (int k = 0; k < kG; ++k) {
+            const int x = min(xb + lane + 64 * k, px - 1);
+            v[j][k] = static_cast<float>(img[io[j] + x]);
+            m[j][k] = g.mask[mo[j] + x] != 0;
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kR; ++j)
+#pragma unroll
+          for (int k = 0; k < kG; ++k) {
+            v[j][k] = static_cast<float>(img[io[j] + min(xb + lane + 64 * k, px - 1)]);
+            m[j][k] = false;
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < kR; ++j)
+#pragma unroll
+        for (int k = 0; k < kG; ++k) {
+          const int r = rb + j * kStep, x = xb + lane + 64 * k;
+          if (r >= r1 || x >= px) continue;
+          if (PHASE == 0) {
+            if (!m[j][k]) {
+              s += v[j][k];
+              c += 1.0;
+            }
+          } else {
+            const long long o = b * g.pn + (long long)r * px + x;
+            g.out[o] = m[j][k] ? 0.f : v[j][k] - mu;
+            if (g.valid) g.valid[o] = m[j][k] ? 0.f : 1.f;
+          }
+        }
     }
   }
   if (PHASE == 0) {
