@@ -18,6 +18,7 @@ SOURCES = {
     'sfm_mesh.hip': ['-ffp-contract=off'] + os.environ.get('SFM_MESH_FLAGS', '').split(),
     'sfm_xcorr.hip': [],
     'sfm_xcorr_fft.hip': [],
+    'sfm_fft_own.hip': [],
     # SFM_MFMA_TIMING / SFM_MFMA_FLAGS: instrumentation and tuning experiments
     'sfm_xcorr_mfma.hip': ((['-DSFM_MFMA_TIMING']
                             if os.environ.get('SFM_MFMA_TIMING') else []) +

@@ -1,0 +1,609 @@
+// Hand-written FFT correlation for volumetric patches (the 3-D configuration:
+// 80^3 patches, F = 160 per axis), replacing the hipFFT plans + pad / product /
+// crop kernels of sfm_xcorr_fft.hip where it applies.
+//
+//   corr[k] = irfft(rfft(a_pad) conj(rfft(b_pad)))[(k - (Q - 1)) mod F]   (flow_field.py:66-89)
+//
+// What a library FFT cannot know is that 7/8 of the padded input is zero and
+// that only the cropped surface is wanted.  The transform is done as three
+// passes of 1-D FFTs that skip the zero parts and fuse their neighbours:
+//
+//   forward  x: rows (z < P0, y < P1) only; reads the un-padded patch, two real
+//               rows per complex FFT (two-for-one), writes F2/2+1 bins per row
+//            y: planes z < P0 only; P1 input samples, zero extended in LDS
+//            z: P0 input samples; for the second operand the product with the
+//               conjugate... (A conj(B)) is formed here
+//   inverse  z, y: full
+//            x: two Hermitian rows per complex FFT; scales, crops with the
+//               wrap-around index and stores the surface row directly; leaves
+//               the surface maximum for the peak search
+//
+// = 9 passes that move about 200 MB per 80^3 patch pair instead of 445 MB in
+// 12 kernels.  One workgroup transforms kT pencils at a time in LDS with a
+// Stockham auto-sort FFT (radices 2, 3, 4, 5; lengths up to 256), pencils laid
+// out [n][t] so that global accesses are contiguous across the pencils of a
+// tile (strided passes) or along the pencil (x passes).
+#include "sfm_common.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace sfm {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kT = 16;        // pencils per workgroup
+constexpr int kTP = kT + 1;   // LDS pitch in complex elements (odd: x passes run along n)
+constexpr int kMaxN = 256;
+constexpr int kMaxStages = 8;
+
+struct Plan {
+  int N;
+  int stages;
+  int radix[kMaxStages];
+};
+
+bool make_plan(int n, Plan* p) {
+  p->N = n;
+  p->stages = 0;
+  if (n < 2 || n > kMaxN) return false;
+  int m = n;
+  for (int r : {4, 2, 3, 5})
+    while (m % r == 0) {
+      if (p->stages == kMaxStages) return false;
+      p->radix[p->stages++] = r;
+      m /= r;
+    }
+  return m == 1;
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 conjf2(float2 a) { return make_float2(a.x, -a.y); }
+// multiplication by -i (forward) / +i (inverse)
+template <bool INV>
+__device__ __forceinline__ float2 rot90(float2 a) {
+  return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+// r-point DFT in place, forward sign exp(-2 pi i / r), inverse: conjugate roots.
+template <bool INV>
+__device__ __forceinline__ void dft2(float2* v) {
+  const float2 a = v[0], b = v[1];
+  v[0] = cadd(a, b);
+  v[1] = csub(a, b);
+}
+template <bool INV>
+__device__ __forceinline__ void dft4(float2* v) {
+  const float2 s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
+  const float2 s13 = cadd(v[1], v[3]), d13 = rot90<INV>(csub(v[1], v[3]));
+  v[0] = cadd(s02, s13);
+  v[2] = csub(s02, s13);
+  v[1] = cadd(d02, d13);
+  v[3] = csub(d02, d13);
+}
+template <bool INV>
+__device__ __forceinline__ void dft3(float2* v) {
+  constexpr float kC = -0.5f, kS = 0.86602540378443864676f;
+  const float2 s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+  const float2 m = make_float2(v[0].x + kC * s.x, v[0].y + kC * s.y);
+  // forward: -i kS d, inverse: +i kS d
+  const float2 r = INV ? make_float2(-kS * d.y, kS * d.x) : make_float2(kS * d.y, -kS * d.x);
+  v[0] = cadd(v[0], s);
+  v[1] = cadd(m, r);
+  v[2] = csub(m, r);
+}
+template <bool INV>
+__device__ __forceinline__ void dft5(float2* v) {
+  constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+  constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+  const float2 a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]);
+  const float2 a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
+  const float2 m1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+  const float2 m2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+  // t1 = s1 b1 + s2 b2, t2 = s2 b1 - s1 b2; forward multiplies them by -i
+  const float2 t1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+  const float2 t2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+  const float2 r1 = rot90<INV>(t1), r2 = rot90<INV>(t2);
+  v[0] = cadd(v[0], cadd(a1, a2));
+  v[1] = cadd(m1, r1);
+  v[4] = csub(m1, r1);
+  v[2] = cadd(m2, r2);
+  v[3] = csub(m2, r2);
+}
+
+// One Stockham stage of radix R over the kT pencils of a tile (compile-time R:
+// the butterfly lives in registers; the sub-transform length ns is a power of
+// two except after an odd radix, so k = j mod ns is a mask almost always).
+template <int R, bool INV>
+__device__ __forceinline__ void lds_stage(const float2* a, float2* b, const float2* tw, int N,
+                                          int ns) {
+  const int nr = N / R;
+  const int twstep = N / (ns * R);
+  const bool pow2 = (ns & (ns - 1)) == 0;
+  for (int it = threadIdx.x; it < nr * kT; it += kThreads) {
+    const int t = it % kT, j = it / kT;
+    const int k = pow2 ? (j & (ns - 1)) : (j % ns);
+    float2 v[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = a[(j + q * nr) * kTP + t];
+    if (k) {  // W^(k q twstep): k q twstep < N
+#pragma unroll
+      for (int q = 1; q < R; ++q) {
+        float2 w = tw[k * q * twstep];
+        if (INV) w.y = -w.y;
+        v[q] = cmul(v[q], w);
+      }
+    }
+    if (R == 4) dft4<INV>(v);
+    else if (R == 2) dft2<INV>(v);
+    else if (R == 5) dft5<INV>(v);
+    else dft3<INV>(v);
+    const int j0 = (j - k) * R + k;
+#pragma unroll
+    for (int q = 0; q < R; ++q) b[(j0 + q * ns) * kTP + t] = v[q];
+  }
+}
+
+// Stockham auto-sort FFT of kT pencils held in LDS as buf[n * kTP + t]; the
+// result is in the returned buffer (one of the two).  tw[k] = exp(-2 pi i k / N).
+template <bool INV>
+__device__ float2* lds_fft(float2* a, float2* b, const float2* tw, const Plan& pl) {
+  const int N = pl.N;
+  int ns = 1;
+  for (int st = 0; st < pl.stages; ++st) {
+    const int r = pl.radix[st];
+    switch (r) {
+      case 4: lds_stage<4, INV>(a, b, tw, N, ns); break;
+      case 2: lds_stage<2, INV>(a, b, tw, N, ns); break;
+      case 5: lds_stage<5, INV>(a, b, tw, N, ns); break;
+      default: lds_stage<3, INV>(a, b, tw, N, ns); break;
+    }
+    __syncthreads();
+    float2* tmp = a;
+    a = b;
+    b = tmp;
+    ns *= r;
+  }
+  return a;
+}
+
+// ---------------------------------------------------------------------------
+// strided pencils (y and z passes)
+// ---------------------------------------------------------------------------
+struct PencilArgs {
+  const float2* in;
+  float2* out;
+  const float2* mul;   // optional: out = FFT(in) * conj(mul) ... see conj_out
+  Plan plan;
+  const float2* tw;
+  int n_in;            // input samples per pencil (the rest is zero)
+  long long stride;    // elements between consecutive samples of a pencil (in and out)
+  int n_inner;         // pencils that are contiguous in memory
+  int n_o0;            // first outer index (e.g. planes z < P0)
+  long long s_o0;
+  int n_o1;            // second outer index (batch)
+  long long s_o1;
+  int product;         // 1: out = mul * conj(FFT(in))   (A conj(B) with mul = A)
+};
+
+template <bool INV>
+__global__ void __launch_bounds__(kThreads) fft_pencil_kernel(PencilArgs g) {
+  extern __shared__ float2 fft_lds[];
+  float2* bufa = fft_lds;
+  float2* bufb = bufa + g.plan.N * kTP;
+  float2* tw = bufb + g.plan.N * kTP;
+  const int N = g.plan.N;
+  for (int k = threadIdx.x; k < N; k += kThreads) tw[k] = g.tw[k];
+  const int tiles_inner = (g.n_inner + kT - 1) / kT;
+  long long tile = blockIdx.x;
+  const int ti = static_cast<int>(tile % tiles_inner);
+  tile /= tiles_inner;
+  const int o0 = static_cast<int>(tile % g.n_o0);
+  const int o1 = static_cast<int>(tile / g.n_o0);
+  const long long base = o1 * g.s_o1 + o0 * g.s_o0 + (long long)ti * kT;
+  const int t = threadIdx.x % kT, n0 = threadIdx.x / kT;
+  constexpr int kRowsPerIt = kThreads / kT;
+  const bool t_ok = ti * kT + t < g.n_inner;
+  // load: rows n of the tile, kT consecutive pencils each; four rows per round,
+  // unconditional loads from clamped addresses (loads under per-lane conditions
+  // would be waited for one by one), zeros for the padding
+  const int tc = min(t, g.n_inner - 1 - ti * kT);
+  for (int nb0 = n0; nb0 < N; nb0 += 4 * kRowsPerIt) {
+    float2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = min(nb0 + u * kRowsPerIt, g.n_in - 1);
+      v[u] = g.in[base + n * g.stride + tc];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = nb0 + u * kRowsPerIt;
+      if (n < N) bufa[n * kTP + t] = (n < g.n_in && t_ok) ? v[u] : make_float2(0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  float2* res = lds_fft<INV>(bufa, bufb, tw, g.plan);
+  if (g.product) {
+    for (int nb0 = n0; nb0 < N; nb0 += 4 * kRowsPerIt) {
+      float2 m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        m[u] = g.mul[base + min(nb0 + u * kRowsPerIt, N - 1) * g.stride + tc];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = nb0 + u * kRowsPerIt;
+        if (n < N && t_ok) g.out[base + n * g.stride + t] = cmul(m[u], conjf2(res[n * kTP + t]));
+      }
+    }
+  } else {
+    for (int n = n0; n < N; n += kRowsPerIt)
+      if (t_ok) g.out[base + n * g.stride + t] = res[n * kTP + t];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// forward x pass: un-padded real rows, two per complex FFT
+// ---------------------------------------------------------------------------
+struct XFwdArgs {
+  const float* src;   // [nb, P0, P1, P2] mean-subtracted patch values
+  float2* out;        // [nb, F0, F1, C] half spectra (rows y < P1 of planes z < P0 written)
+  Plan plan;          // N = F2
+  const float2* tw;
+  int P[3], F[3], C;
+  int nb;
+};
+
+__global__ void __launch_bounds__(kThreads) fft_xfwd_kernel(XFwdArgs g) {
+  extern __shared__ float2 fft_lds[];
+  float2* bufa = fft_lds;
+  float2* bufb = bufa + g.plan.N * kTP;
+  float2* tw = bufb + g.plan.N * kTP;
+  const int N = g.plan.N;
+  for (int k = threadIdx.x; k < N; k += kThreads) tw[k] = g.tw[k];
+  // pencil = (b, z, row pair); a tile = kT consecutive pairs of one (b, z) plane
+  const int pairs = (g.P[1] + 1) / 2;
+  const int tiles = (pairs + kT - 1) / kT;
+  long long tile = blockIdx.x;
+  const int tp = static_cast<int>(tile % tiles);
+  tile /= tiles;
+  const int z = static_cast<int>(tile % g.P[0]);
+  const int b = static_cast<int>(tile / g.P[0]);
+  const float* plane = g.src + ((long long)b * g.P[0] + z) * g.P[1] * g.P[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // load: a wave takes pencils t = wave, wave + 4, ...; lanes run along x
+  for (int t = wave; t < kT; t += kThreads / 64) {
+    const int y = 2 * (tp * kT + t);
+    for (int n = lane; n < N; n += 64) {
+      float2 v = make_float2(0.f, 0.f);
+      if (n < g.P[2]) {
+        if (y < g.P[1]) v.x = plane[(long long)y * g.P[2] + n];
+        if (y + 1 < g.P[1]) v.y = plane[(long long)(y + 1) * g.P[2] + n];
+      }
+      bufa[n * kTP + t] = v;
+    }
+  }
+  __syncthreads();
+  const float2* res = lds_fft<false>(bufa, bufb, tw, g.plan);
+  // split: X1[k] = (Z[k] + conj(Z[N-k])) / 2,  X2[k] = (Z[k] - conj(Z[N-k])) / (2 i)
+  for (int t = wave; t < kT; t += kThreads / 64) {
+    const int y = 2 * (tp * kT + t);
+    if (y >= g.P[1]) continue;
+    float2* row0 = g.out + (((long long)b * g.F[0] + z) * g.F[1] + y) * g.C;
+    float2* row1 = row0 + g.C;
+    for (int k = lane; k < g.C; k += 64) {
+      const float2 zk = res[k * kTP + t];
+      const float2 zn = conjf2(res[((N - k) % N) * kTP + t]);
+      row0[k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
+      if (y + 1 < g.P[1]) {
+        const float2 d = csub(zk, zn);          // 2 i X2
+        row1[k] = make_float2(0.5f * d.y, -0.5f * d.x);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// inverse x pass: two Hermitian rows per complex FFT, scale, crop, maximum
+// ---------------------------------------------------------------------------
+struct XInvArgs {
+  const float2* in;   // [nb, F0, F1, C]
+  float* out;         // [nb, S0, S1, S2] surface
+  unsigned int* smax; // [nb] or NULL
+  Plan plan;
+  const float2* tw;
+  int F[3], S[3], Q[3], C;
+  float scale;
+  int nb;
+};
+
+// surface index of circular index d along an axis, or -1 (the padding gap)
+__device__ __forceinline__ int surf_index(int d, int F, int Q, int S) {
+  // crop: d = (k - (Q - 1)) mod F  <=>  k = d + Q - 1 (d small) or d - F + Q - 1
+  int k = d + Q - 1;
+  if (k >= S) k = d - F + Q - 1;
+  return (k >= 0 && k < S) ? k : -1;
+}
+
+__global__ void __launch_bounds__(kThreads) fft_xinv_kernel(XInvArgs g) {
+  extern __shared__ float2 fft_lds[];
+  float2* bufa = fft_lds;
+  float2* bufb = bufa + g.plan.N * kTP;
+  float2* tw = bufb + g.plan.N * kTP;
+  const int N = g.plan.N;
+  for (int k = threadIdx.x; k < N; k += kThreads) tw[k] = g.tw[k];
+  const int pairs = g.F[1] / 2;  // F is even
+  const int tiles = (pairs + kT - 1) / kT;
+  long long tile = blockIdx.x;
+  const int tp = static_cast<int>(tile % tiles);
+  tile /= tiles;
+  const int dz = static_cast<int>(tile % g.F[0]);
+  const int b = static_cast<int>(tile / g.F[0]);
+  const int kz = surf_index(dz, g.F[0], g.Q[0], g.S[0]);
+  if (kz < 0) return;  // whole workgroup: a plane of the gap
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = wave; t < kT; t += kThreads / 64) {
+    const int dy = 2 * (tp * kT + t);
+    const bool live = dy < g.F[1];
+    const float2* row0 = g.in + (((long long)b * g.F[0] + dz) * g.F[1] + min(dy, g.F[1] - 2)) * g.C;
+    const float2* row1 = row0 + g.C;
+    for (int k = lane; k < N; k += 64) {
+      // Z[k] = S1[k] + i S2[k]; the upper half from the Hermitian symmetry
+      const int kk = k < g.C ? k : N - k;
+      float2 s1 = row0[kk], s2 = row1[kk];
+      if (k >= g.C) {
+        s1 = conjf2(s1);
+        s2 = conjf2(s2);
+      }
+      float2 v = make_float2(s1.x - s2.y, s1.y + s2.x);
+      if (!live) v = make_float2(0.f, 0.f);
+      bufa[k * kTP + t] = v;
+    }
+  }
+  __syncthreads();
+  const float2* res = lds_fft<true>(bufa, bufb, tw, g.plan);
+  float mx = -INFINITY;
+  for (int t = wave; t < kT; t += kThreads / 64) {
+    const int dy = 2 * (tp * kT + t);
+    if (dy >= g.F[1]) continue;
+    const int ky0 = surf_index(dy, g.F[1], g.Q[1], g.S[1]);
+    const int ky1 = surf_index(dy + 1, g.F[1], g.Q[1], g.S[1]);
+    float* o0 = ky0 >= 0 ? g.out + (((long long)b * g.S[0] + kz) * g.S[1] + ky0) * g.S[2] : nullptr;
+    float* o1 = ky1 >= 0 ? g.out + (((long long)b * g.S[0] + kz) * g.S[1] + ky1) * g.S[2] : nullptr;
+    for (int kx = lane; kx < g.S[2]; kx += 64) {
+      int dx = kx - (g.Q[2] - 1);
+      if (dx < 0) dx += g.F[2];
+      const float2 v = res[dx * kTP + t];
+      if (o0) {
+        const float r = v.x * g.scale;
+        o0[kx] = r;
+        mx = fmaxf(mx, r);
+      }
+      if (o1) {
+        const float r = v.y * g.scale;
+        o1[kx] = r;
+        mx = fmaxf(mx, r);
+      }
+    }
+  }
+  if (g.smax) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    if (lane == 0 && mx > -INFINITY) {
+      const unsigned u = __float_as_uint(mx);
+      const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      if (o > __atomic_load_n(&g.smax[b], __ATOMIC_RELAXED)) atomicMax(&g.smax[b], o);
+    }
+  }
+}
+
+// twiddle tables, per device and length
+std::mutex g_tw_mu;
+std::map<std::pair<int, int>, float2*> g_tw;
+
+const float2* twiddles(int n) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_tw_mu);
+  auto it = g_tw.find({dev, n});
+  if (it != g_tw.end()) return it->second;
+  std::vector<float2> h(n);
+  for (int k = 0; k < n; ++k) {
+    const double ang = -2.0 * M_PI * k / n;
+    h[k] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+  }
+  float2* d = nullptr;
+  if (hipMalloc(&d, n * sizeof(float2)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, h.data(), n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  g_tw[{dev, n}] = d;
+  return d;
+}
+
+size_t lds_bytes(int n) { return (size_t)(2 * n * kTP + n) * sizeof(float2); }
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024)
+    SFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(bytes)));
+  return SFM_OK;
+}
+
+bool own_enabled() {
+  const char* e = std::getenv("SFM_FFT_OWN");  // "0": hipFFT plans for every shape
+  return !(e && e[0] == '0');
+}
+
+}  // namespace
+
+// Shapes this path takes: un-masked 3-D patches whose padded lengths factor
+// into 2, 3, 4, 5 and fit the LDS tile.
+bool own_fft_supported(int rank, const int* F) {
+  if (!own_enabled() || rank != 3) return false;
+  Plan p;
+  for (int i = 0; i < 3; ++i)
+    if (!make_plan(F[i], &p) || (F[i] & 1)) return false;
+  return true;
+}
+
+// a0 / b0: [nb, Pn] / [nb, Qn] mean-subtracted patches; sa / sb: two half-spectrum
+// buffers [nb, F0, F1, C]; surface: [nb, Sn]; smax: [nb] or NULL (zeroed).
+int own_fft_correlate(const int* P, const int* Q, const int* S, const int* F, int nb,
+                      const float* a0, const float* b0, float2* sa, float2* sb, float* surface,
+                      unsigned int* smax, hipStream_t st) {
+  Plan px, py, pz;
+  if (!make_plan(F[2], &px) || !make_plan(F[1], &py) || !make_plan(F[0], &pz))
+    return fail(SFM_ERR_INVALID, "own FFT: unsupported length");
+  const float2 *twx = twiddles(F[2]), *twy = twiddles(F[1]), *twz = twiddles(F[0]);
+  if (!twx || !twy || !twz) return fail(SFM_ERR_HIP, "own FFT: twiddle table allocation failed");
+  const int C = F[2] / 2 + 1;
+  const long long plane = (long long)F[1] * C, vol = (long long)F[0] * plane;
+  if (int rc = set_lds(&fft_xfwd_kernel, lds_bytes(F[2]))) return rc;
+  if (int rc = set_lds(&fft_xinv_kernel, lds_bytes(F[2]))) return rc;
+  const size_t lds_yz = lds_bytes(std::max(F[0], F[1]));
+  if (int rc = set_lds(&fft_pencil_kernel<false>, lds_yz)) return rc;
+  if (int rc = set_lds(&fft_pencil_kernel<true>, lds_yz)) return rc;
+
+  for (int side = 0; side < 2; ++side) {
+    const int* R = side ? Q : P;
+    float2* spec = side ? sb : sa;
+    XFwdArgs x;
+    x.src = side ? b0 : a0;
+    x.out = spec;
+    x.plan = px;
+    x.tw = twx;
+    for (int i = 0; i < 3; ++i) {
+      x.P[i] = R[i];
+      x.F[i] = F[i];
+    }
+    x.C = C;
+    x.nb = nb;
+    const int xt = ((R[1] + 1) / 2 + kT - 1) / kT;
+    hipLaunchKernelGGL(fft_xfwd_kernel, dim3((unsigned)((long long)nb * R[0] * xt)), dim3(kThreads),
+                       lds_bytes(F[2]), st, x);
+    PencilArgs y;
+    y.in = spec;
+    y.out = spec;
+    y.mul = nullptr;
+    y.plan = py;
+    y.tw = twy;
+    y.n_in = R[1];
+    y.stride = C;
+    y.n_inner = C;
+    y.n_o0 = R[0];
+    y.s_o0 = plane;
+    y.n_o1 = nb;
+    y.s_o1 = vol;
+    y.product = 0;
+    hipLaunchKernelGGL(fft_pencil_kernel<false>,
+                       dim3((unsigned)((long long)nb * R[0] * ((C + kT - 1) / kT))),
+                       dim3(kThreads), lds_bytes(F[1]), st, y);
+    PencilArgs z = y;
+    z.plan = pz;
+    z.tw = twz;
+    z.n_in = R[0];
+    z.stride = plane;
+    z.n_inner = static_cast<int>(plane);
+    z.n_o0 = 1;
+    z.s_o0 = 0;
+    if (side == 1) {  // product A conj(B) where B is being finished
+      z.mul = sa;
+      z.product = 1;
+    }
+    hipLaunchKernelGGL(fft_pencil_kernel<false>,
+                       dim3((unsigned)((long long)nb * ((plane + kT - 1) / kT))), dim3(kThreads),
+                       lds_bytes(F[0]), st, z);
+  }
+  // inverse of the product (in sb)
+  PencilArgs z;
+  z.in = sb;
+  z.out = sb;
+  z.mul = nullptr;
+  z.plan = pz;
+  z.tw = twz;
+  z.n_in = F[0];
+  z.stride = plane;
+  z.n_inner = static_cast<int>(plane);
+  z.n_o0 = 1;
+  z.s_o0 = 0;
+  z.n_o1 = nb;
+  z.s_o1 = vol;
+  z.product = 0;
+  hipLaunchKernelGGL(fft_pencil_kernel<true>, dim3((unsigned)((long long)nb * ((plane + kT - 1) / kT))),
+                     dim3(kThreads), lds_bytes(F[0]), st, z);
+  PencilArgs y = z;
+  y.plan = py;
+  y.tw = twy;
+  y.n_in = F[1];
+  y.stride = C;
+  y.n_inner = C;
+  y.n_o0 = F[0];
+  y.s_o0 = plane;
+  hipLaunchKernelGGL(fft_pencil_kernel<true>,
+                     dim3((unsigned)((long long)nb * F[0] * ((C + kT - 1) / kT))), dim3(kThreads),
+                     lds_bytes(F[1]), st, y);
+  XInvArgs xi;
+  xi.in = sb;
+  xi.out = surface;
+  xi.smax = smax;
+  xi.plan = px;
+  xi.tw = twx;
+  for (int i = 0; i < 3; ++i) {
+    xi.F[i] = F[i];
+    xi.S[i] = S[i];
+    xi.Q[i] = Q[i];
+  }
+  xi.C = C;
+  xi.scale = 1.0f / (static_cast<float>(F[0]) * F[1] * F[2]);
+  xi.nb = nb;
+  const int it = (F[1] / 2 + kT - 1) / kT;
+  hipLaunchKernelGGL(fft_xinv_kernel, dim3((unsigned)((long long)nb * F[0] * it)), dim3(kThreads),
+                     lds_bytes(F[2]), st, xi);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+}  // namespace sfm
+
+// Test hook (not part of the public header): batched 1-D complex FFT of
+// contiguous pencils through the strided-pencil kernel, pencil p at in + p,
+// samples n at stride n_pencils.
+extern "C" int sfm_debug_fft1d(const void* in, void* out, int n, int n_in, int n_pencils,
+                               int inverse, void* stream) {
+  using namespace sfm;
+  Plan pl;
+  if (!make_plan(n, &pl)) return fail(SFM_ERR_INVALID, "fft1d: unsupported length %d", n);
+  PencilArgs a;
+  a.in = static_cast<const float2*>(in);
+  a.out = static_cast<float2*>(out);
+  a.mul = nullptr;
+  a.plan = pl;
+  a.tw = twiddles(n);
+  a.n_in = n_in;
+  a.stride = n_pencils;
+  a.n_inner = n_pencils;
+  a.n_o0 = 1;
+  a.s_o0 = 0;
+  a.n_o1 = 1;
+  a.s_o1 = 0;
+  a.product = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = (n_pencils + kT - 1) / kT;
+  if (inverse) {
+    if (int rc = set_lds(&fft_pencil_kernel<true>, lds_bytes(n))) return rc;
+    hipLaunchKernelGGL(fft_pencil_kernel<true>, dim3(grid), dim3(kThreads), lds_bytes(n), st, a);
+  } else {
+    if (int rc = set_lds(&fft_pencil_kernel<false>, lds_bytes(n))) return rc;
+    hipLaunchKernelGGL(fft_pencil_kernel<false>, dim3(grid), dim3(kThreads), lds_bytes(n), st, a);
+  }
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}

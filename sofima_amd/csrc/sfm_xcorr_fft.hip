@@ -22,6 +22,12 @@
 
 namespace sfm {
 
+// sfm_fft_own.hip: hand-written transforms for un-masked volumetric patches
+bool own_fft_supported(int rank, const int* F);
+int own_fft_correlate(const int* P, const int* Q, const int* S, const int* F, int nb,
+                      const float* a0, const float* b0, float2* sa, float2* sb, float* surface,
+                      unsigned int* smax, hipStream_t st);
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -333,8 +339,17 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
   if (masked)
     for (int i = 0; i < 6; ++i) real[i] = c.take<float>((size_t)nb_max * g.Fn);
 
+  const bool own = !masked && own_fft_supported(g.rank, g.F);
   for (int lo = 0; lo < d->batch; lo += nb_max) {
     const int nb = d->batch - lo < nb_max ? d->batch - lo : nb_max;
+    if (own) {
+      // zero-skipping transforms with pad / product / crop fused in (no hipFFT)
+      if (int rc = own_fft_correlate(g.P, g.Q, g.S, g.F, nb, a0 + (long long)lo * g.Pn,
+                                     b0 + (long long)lo * g.Qn, spec[0], spec[1],
+                                     surface + (long long)lo * g.Sn, smax ? smax + lo : nullptr, st))
+        return rc;
+      continue;
+    }
     hipfftHandle fwd, inv;
     if (int rc = get_plan(g, nb, HIPFFT_R2C, st, &fwd)) return rc;
     if (int rc = get_plan(g, nb, HIPFFT_C2R, st, &inv)) return rc;

@@ -1,0 +1,95 @@
+"""Hand-written FFT correlation (csrc/sfm_fft_own.hip) vs numpy.fft and vs the
+hipFFT-plan path of the same library (-m gpu)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import flow_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _fft1d(x, n, inverse):
+  """x: [n_in, pencils] complex64 -> [n, pencils] through sfm_debug_fft1d."""
+  import torch
+  from sofima_amd import _abi
+  lib = _abi.load()
+  n_in, pencils = x.shape
+  xin = torch.from_numpy(np.ascontiguousarray(x.astype(np.complex64))).cuda()
+  out = torch.zeros((n, pencils), dtype=torch.complex64, device='cuda')
+  lib.sfm_debug_fft1d.restype = C.c_int
+  lib.sfm_debug_fft1d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p]
+  rc = lib.sfm_debug_fft1d(xin.data_ptr(), out.data_ptr(), n, n_in, pencils, int(inverse),
+                           torch.cuda.current_stream().cuda_stream)
+  assert rc == 0
+  torch.cuda.synchronize()
+  return out.cpu().numpy()
+
+
+@pytest.mark.parametrize('n', [160, 80, 2, 4, 6, 10, 30, 96, 120, 128, 150, 240, 256])
+@pytest.mark.parametrize('inverse', [False, True])
+def test_pencil_fft_matches_numpy(gpu, n, inverse):
+  rng = np.random.default_rng(n)
+  for n_in, pencils in ((n, 37), (max(1, n // 2), 16), (n, 1)):
+    x = (rng.standard_normal((n_in, pencils)) + 1j * rng.standard_normal((n_in, pencils)))
+    got = _fft1d(x, n, inverse)
+    xp = np.zeros((n, pencils), np.complex128)
+    xp[:n_in] = x
+    want = np.fft.ifft(xp, axis=0) * n if inverse else np.fft.fft(xp, axis=0)
+    np.testing.assert_allclose(got, want, atol=2e-5 * np.abs(want).max())
+
+
+def _with_env(env, fn):
+  old = {k: os.environ.get(k) for k in env}
+  os.environ.update(env)
+  try:
+    return fn()
+  finally:
+    for k, v in old.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v
+
+
+@pytest.mark.parametrize('p,q', [((20, 24, 30), (20, 24, 30)), ((16, 40, 25), (9, 33, 25)),
+                                 ((80, 80, 80), (80, 80, 80)), ((5, 7, 12), (5, 6, 11))])
+def test_own_fft_correlation_matches_plans_and_oracle(gpu, p, q):
+  """Full volumetric correlation surfaces: hand-written transforms == hipFFT
+  plans (both float32 FFTs of the same padded size) == float64 oracle."""
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(sum(p))
+  b = 3 if p[0] < 80 else 2
+  a = rng.integers(0, 255, (b,) + p).astype(np.uint8)
+  c = rng.integers(0, 255, (b,) + q).astype(np.uint8)
+  run = lambda: flow_field.masked_xcorr(a, c, dim=3, method=3, mean=None)
+  own = _with_env({'SFM_FFT_OWN': '1'}, run)
+  lib = _with_env({'SFM_FFT_OWN': '0'}, run)
+  scale = np.abs(lib).max()
+  np.testing.assert_allclose(own, lib, atol=2e-6 * scale)
+  if p[0] < 80:
+    a0 = a.astype(np.float64) - a.reshape(b, -1).mean(1)[:, None, None, None]
+    c0 = c.astype(np.float64) - c.reshape(b, -1).mean(1)[:, None, None, None]
+    want = flow_oracle.xcorr_surface(a0, c0, dim=3, dtype=np.float64)
+    np.testing.assert_allclose(own, want, atol=1e-5 * scale)
+
+
+def test_own_fft_flow_3d(gpu):
+  """flow_field on a shifted volume through the hand-written transforms (the
+  default for un-masked volumetric patches) == through the hipFFT plans."""
+  from scipy import ndimage
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(3)
+  vol = ndimage.gaussian_filter(rng.standard_normal((110, 130, 150)), 1.5)
+  vol = ((vol - vol.min()) / (vol.max() - vol.min()) * 255).astype(np.uint8)
+  pre, post = vol[:100, :120, :140], vol[3:103, 2:122, 5:145]
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  run = lambda: calc.flow_field(pre, post, (40, 48, 64), 20, batch_size=8)
+  own = _with_env({'SFM_FFT_OWN': '1'}, run)
+  lib = _with_env({'SFM_FFT_OWN': '0'}, run)
+  np.testing.assert_array_equal(own[:3], lib[:3])
+  assert (own[0] == 5).all() and (own[1] == 2).all() and (own[2] == 3).all()
+  np.testing.assert_allclose(own[3:], lib[3:], rtol=2e-3)
