@@ -212,19 +212,20 @@ __global__ void __launch_bounds__(kThreads) fft_pencil_kernel(PencilArgs g) {
   const int t = threadIdx.x % kT, n0 = threadIdx.x / kT;
   constexpr int kRowsPerIt = kThreads / kT;
   const bool t_ok = ti * kT + t < g.n_inner;
-  // load: rows n of the tile, kT consecutive pencils each; four rows per round,
+  // load: rows n of the tile, kT consecutive pencils each; ten rows per round,
   // unconditional loads from clamped addresses (loads under per-lane conditions
   // would be waited for one by one), zeros for the padding
   const int tc = min(t, g.n_inner - 1 - ti * kT);
-  for (int nb0 = n0; nb0 < N; nb0 += 4 * kRowsPerIt) {
-    float2 v[4];
+  constexpr int kLd = 10;  // N = 160: the whole pencil in one round
+  for (int nb0 = n0; nb0 < N; nb0 += kLd * kRowsPerIt) {
+    float2 v[kLd];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kLd; ++u) {
       const int n = min(nb0 + u * kRowsPerIt, g.n_in - 1);
       v[u] = g.in[base + n * g.stride + tc];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kLd; ++u) {
       const int n = nb0 + u * kRowsPerIt;
       if (n < N) bufa[n * kTP + t] = (n < g.n_in && t_ok) ? v[u] : make_float2(0.f, 0.f);
     }
@@ -232,13 +233,13 @@ __global__ void __launch_bounds__(kThreads) fft_pencil_kernel(PencilArgs g) {
   __syncthreads();
   float2* res = lds_fft<INV>(bufa, bufb, tw, g.plan);
   if (g.product) {
-    for (int nb0 = n0; nb0 < N; nb0 += 4 * kRowsPerIt) {
-      float2 m[4];
+    for (int nb0 = n0; nb0 < N; nb0 += kLd * kRowsPerIt) {
+      float2 m[kLd];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < kLd; ++u)
         m[u] = g.mul[base + min(nb0 + u * kRowsPerIt, N - 1) * g.stride + tc];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kLd; ++u) {
         const int n = nb0 + u * kRowsPerIt;
         if (n < N && t_ok) g.out[base + n * g.stride + t] = cmul(m[u], conjf2(res[n * kTP + t]));
       }
@@ -281,11 +282,22 @@ __global__ void __launch_bounds__(kThreads) fft_xfwd_kernel(XFwdArgs g) {
   // load: a wave takes pencils t = wave, wave + 4, ...; lanes run along x
   for (int t = wave; t < kT; t += kThreads / 64) {
     const int y = 2 * (tp * kT + t);
-    for (int n = lane; n < N; n += 64) {
+    const int y0c = min(y, g.P[1] - 1), y1c = min(y + 1, g.P[1] - 1);
+    float r0[4], r1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // unconditional loads, clamped (four groups: N <= 256)
+      const int n = min(lane + 64 * u, g.P[2] - 1);
+      r0[u] = plane[(long long)y0c * g.P[2] + n];
+      r1[u] = plane[(long long)y1c * g.P[2] + n];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = lane + 64 * u;
+      if (n >= N) continue;
       float2 v = make_float2(0.f, 0.f);
       if (n < g.P[2]) {
-        if (y < g.P[1]) v.x = plane[(long long)y * g.P[2] + n];
-        if (y + 1 < g.P[1]) v.y = plane[(long long)(y + 1) * g.P[2] + n];
+        if (y < g.P[1]) v.x = r0[u];
+        if (y + 1 < g.P[1]) v.y = r1[u];
       }
       bufa[n * kTP + t] = v;
     }
@@ -349,20 +361,36 @@ __global__ void __launch_bounds__(kThreads) fft_xinv_kernel(XInvArgs g) {
   const int kz = surf_index(dz, g.F[0], g.Q[0], g.S[0]);
   if (kz < 0) return;  // whole workgroup: a plane of the gap
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = wave; t < kT; t += kThreads / 64) {
-    const int dy = 2 * (tp * kT + t);
-    const bool live = dy < g.F[1];
+  // all loads of the wave's four pencils (four 64-bin groups each: N <= 256) first
+  constexpr int kPW = kT / (kThreads / 64);  // pencils per wave
+  float2 s1[kPW][4], s2[kPW][4];
+#pragma unroll
+  for (int p = 0; p < kPW; ++p) {
+    const int dy = 2 * (tp * kT + wave + p * (kThreads / 64));
     const float2* row0 = g.in + (((long long)b * g.F[0] + dz) * g.F[1] + min(dy, g.F[1] - 2)) * g.C;
-    const float2* row1 = row0 + g.C;
-    for (int k = lane; k < N; k += 64) {
-      // Z[k] = S1[k] + i S2[k]; the upper half from the Hermitian symmetry
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = min(lane + 64 * u, N - 1);
       const int kk = k < g.C ? k : N - k;
-      float2 s1 = row0[kk], s2 = row1[kk];
+      s1[p][u] = row0[kk];
+      s2[p][u] = row0[g.C + kk];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < kPW; ++p) {
+    const int t = wave + p * (kThreads / 64);
+    const bool live = 2 * (tp * kT + t) < g.F[1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = lane + 64 * u;
+      if (k >= N) continue;
+      // Z[k] = S1[k] + i S2[k]; the upper half from the Hermitian symmetry
+      float2 a1 = s1[p][u], a2 = s2[p][u];
       if (k >= g.C) {
-        s1 = conjf2(s1);
-        s2 = conjf2(s2);
+        a1 = conjf2(a1);
+        a2 = conjf2(a2);
       }
-      float2 v = make_float2(s1.x - s2.y, s1.y + s2.x);
+      float2 v = make_float2(a1.x - a2.y, a1.y + a2.x);
       if (!live) v = make_float2(0.f, 0.f);
       bufa[k * kTP + t] = v;
     }
