@@ -191,7 +191,7 @@ struct PencilArgs {
   long long s_o0;
   int n_o1;            // second outer index (batch)
   long long s_o1;
-  int product;         // 1: out = mul * conj(FFT(in))   (A conj(B) with mul = A)
+  int product;         // 1: out = mul * conj(FFT(in))  (A conj(B), mul = A);  2: FFT(in * conj(mul))
 };
 
 template <bool INV>
@@ -224,6 +224,14 @@ __global__ void __launch_bounds__(kThreads) fft_pencil_kernel(PencilArgs g) {
       const int n = min(nb0 + u * kRowsPerIt, g.n_in - 1);
       v[u] = g.in[base + n * g.stride + tc];
     }
+    if (g.product == 2) {  // (wave-uniform: a second group of loads)
+      float2 m[kLd];
+#pragma unroll
+      for (int u = 0; u < kLd; ++u)
+        m[u] = g.mul[base + min(nb0 + u * kRowsPerIt, g.n_in - 1) * g.stride + tc];
+#pragma unroll
+      for (int u = 0; u < kLd; ++u) v[u] = cmul(v[u], conjf2(m[u]));
+    }
 #pragma unroll
     for (int u = 0; u < kLd; ++u) {
       const int n = nb0 + u * kRowsPerIt;
@@ -232,7 +240,7 @@ __global__ void __launch_bounds__(kThreads) fft_pencil_kernel(PencilArgs g) {
   }
   __syncthreads();
   float2* res = lds_fft<INV>(bufa, bufb, tw, g.plan);
-  if (g.product) {
+  if (g.product == 1) {
     for (int nb0 = n0; nb0 < N; nb0 += kLd * kRowsPerIt) {
       float2 m[kLd];
 #pragma unroll
@@ -260,6 +268,7 @@ struct XFwdArgs {
   const float2* tw;
   int P[3], F[3], C;
   int nb;
+  int square;         // transform the squares of the values (masked terms)
 };
 
 __global__ void __launch_bounds__(kThreads) fft_xfwd_kernel(XFwdArgs g) {
@@ -296,8 +305,8 @@ __global__ void __launch_bounds__(kThreads) fft_xfwd_kernel(XFwdArgs g) {
       if (n >= N) continue;
       float2 v = make_float2(0.f, 0.f);
       if (n < g.P[2]) {
-        if (y < g.P[1]) v.x = r0[u];
-        if (y + 1 < g.P[1]) v.y = r1[u];
+        if (y < g.P[1]) v.x = g.square ? r0[u] * r0[u] : r0[u];
+        if (y + 1 < g.P[1]) v.y = g.square ? r1[u] * r1[u] : r1[u];
       }
       bufa[n * kTP + t] = v;
     }
@@ -334,6 +343,7 @@ struct XInvArgs {
   int F[3], S[3], Q[3], C;
   float scale;
   int nb;
+  int raw;            // 1: out = the un-scaled circular real array [nb, F0, F1, F2]
 };
 
 // surface index of circular index d along an axis, or -1 (the padding gap)
@@ -358,7 +368,7 @@ __global__ void __launch_bounds__(kThreads) fft_xinv_kernel(XInvArgs g) {
   tile /= tiles;
   const int dz = static_cast<int>(tile % g.F[0]);
   const int b = static_cast<int>(tile / g.F[0]);
-  const int kz = surf_index(dz, g.F[0], g.Q[0], g.S[0]);
+  const int kz = g.raw ? dz : surf_index(dz, g.F[0], g.Q[0], g.S[0]);
   if (kz < 0) return;  // whole workgroup: a plane of the gap
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // all loads of the wave's four pencils (four 64-bin groups each: N <= 256) first
@@ -401,6 +411,15 @@ __global__ void __launch_bounds__(kThreads) fft_xinv_kernel(XInvArgs g) {
   for (int t = wave; t < kT; t += kThreads / 64) {
     const int dy = 2 * (tp * kT + t);
     if (dy >= g.F[1]) continue;
+    if (g.raw) {
+      float* o = g.out + (((long long)b * g.F[0] + dz) * g.F[1] + dy) * g.F[2];
+      for (int x = lane; x < N; x += 64) {
+        const float2 v = res[x * kTP + t];
+        o[x] = v.x;
+        o[g.F[2] + x] = v.y;
+      }
+      continue;
+    }
     const int ky0 = surf_index(dy, g.F[1], g.Q[1], g.S[1]);
     const int ky1 = surf_index(dy + 1, g.F[1], g.Q[1], g.S[1]);
     float* o0 = ky0 >= 0 ? g.out + (((long long)b * g.S[0] + kz) * g.S[1] + ky0) * g.S[2] : nullptr;
@@ -482,119 +501,186 @@ bool own_fft_supported(int rank, const int* F) {
   return true;
 }
 
-// a0 / b0: [nb, Pn] / [nb, Qn] mean-subtracted patches; sa / sb: two half-spectrum
-// buffers [nb, F0, F1, C]; surface: [nb, Sn]; smax: [nb] or NULL (zeroed).
-int own_fft_correlate(const int* P, const int* Q, const int* S, const int* F, int nb,
-                      const float* a0, const float* b0, float2* sa, float2* sb, float* surface,
-                      unsigned int* smax, hipStream_t st) {
+namespace {
+
+struct OwnGeo {
   Plan px, py, pz;
-  if (!make_plan(F[2], &px) || !make_plan(F[1], &py) || !make_plan(F[0], &pz))
+  const float2 *twx, *twy, *twz;
+  int C;
+  long long plane, vol;
+};
+
+int own_setup(const int* F, OwnGeo* o) {
+  if (!make_plan(F[2], &o->px) || !make_plan(F[1], &o->py) || !make_plan(F[0], &o->pz))
     return fail(SFM_ERR_INVALID, "own FFT: unsupported length");
-  const float2 *twx = twiddles(F[2]), *twy = twiddles(F[1]), *twz = twiddles(F[0]);
-  if (!twx || !twy || !twz) return fail(SFM_ERR_HIP, "own FFT: twiddle table allocation failed");
-  const int C = F[2] / 2 + 1;
-  const long long plane = (long long)F[1] * C, vol = (long long)F[0] * plane;
+  o->twx = twiddles(F[2]);
+  o->twy = twiddles(F[1]);
+  o->twz = twiddles(F[0]);
+  if (!o->twx || !o->twy || !o->twz)
+    return fail(SFM_ERR_HIP, "own FFT: twiddle table allocation failed");
+  o->C = F[2] / 2 + 1;
+  o->plane = (long long)F[1] * o->C;
+  o->vol = (long long)F[0] * o->plane;
   if (int rc = set_lds(&fft_xfwd_kernel, lds_bytes(F[2]))) return rc;
   if (int rc = set_lds(&fft_xinv_kernel, lds_bytes(F[2]))) return rc;
   const size_t lds_yz = lds_bytes(std::max(F[0], F[1]));
   if (int rc = set_lds(&fft_pencil_kernel<false>, lds_yz)) return rc;
   if (int rc = set_lds(&fft_pencil_kernel<true>, lds_yz)) return rc;
+  return SFM_OK;
+}
 
-  for (int side = 0; side < 2; ++side) {
-    const int* R = side ? Q : P;
-    float2* spec = side ? sb : sa;
-    XFwdArgs x;
-    x.src = side ? b0 : a0;
-    x.out = spec;
-    x.plan = px;
-    x.tw = twx;
-    for (int i = 0; i < 3; ++i) {
-      x.P[i] = R[i];
-      x.F[i] = F[i];
-    }
-    x.C = C;
-    x.nb = nb;
-    const int xt = ((R[1] + 1) / 2 + kT - 1) / kT;
-    hipLaunchKernelGGL(fft_xfwd_kernel, dim3((unsigned)((long long)nb * R[0] * xt)), dim3(kThreads),
-                       lds_bytes(F[2]), st, x);
-    PencilArgs y;
-    y.in = spec;
-    y.out = spec;
-    y.mul = nullptr;
-    y.plan = py;
-    y.tw = twy;
-    y.n_in = R[1];
-    y.stride = C;
-    y.n_inner = C;
-    y.n_o0 = R[0];
-    y.s_o0 = plane;
-    y.n_o1 = nb;
-    y.s_o1 = vol;
-    y.product = 0;
-    hipLaunchKernelGGL(fft_pencil_kernel<false>,
-                       dim3((unsigned)((long long)nb * R[0] * ((C + kT - 1) / kT))),
-                       dim3(kThreads), lds_bytes(F[1]), st, y);
-    PencilArgs z = y;
-    z.plan = pz;
-    z.tw = twz;
-    z.n_in = R[0];
-    z.stride = plane;
-    z.n_inner = static_cast<int>(plane);
-    z.n_o0 = 1;
-    z.s_o0 = 0;
-    if (side == 1) {  // product A conj(B) where B is being finished
-      z.mul = sa;
-      z.product = 1;
-    }
-    hipLaunchKernelGGL(fft_pencil_kernel<false>,
-                       dim3((unsigned)((long long)nb * ((plane + kT - 1) / kT))), dim3(kThreads),
-                       lds_bytes(F[0]), st, z);
+// Half spectrum [nb, F0, F1, C] of the zero-padded patches src [nb, R0, R1, R2];
+// mul != NULL: the product mul * conj(spectrum) instead (formed in the z pass).
+void own_forward(const OwnGeo& o, const int* R, const int* F, int nb, const float* src,
+                 int square, float2* spec, const float2* mul, hipStream_t st) {
+  XFwdArgs x;
+  x.src = src;
+  x.out = spec;
+  x.plan = o.px;
+  x.tw = o.twx;
+  for (int i = 0; i < 3; ++i) {
+    x.P[i] = R[i];
+    x.F[i] = F[i];
   }
-  // inverse of the product (in sb)
+  x.C = o.C;
+  x.nb = nb;
+  x.square = square;
+  const int xt = ((R[1] + 1) / 2 + kT - 1) / kT;
+  hipLaunchKernelGGL(fft_xfwd_kernel, dim3((unsigned)((long long)nb * R[0] * xt)), dim3(kThreads),
+                     lds_bytes(F[2]), st, x);
+  PencilArgs y;
+  y.in = spec;
+  y.out = spec;
+  y.mul = nullptr;
+  y.plan = o.py;
+  y.tw = o.twy;
+  y.n_in = R[1];
+  y.stride = o.C;
+  y.n_inner = o.C;
+  y.n_o0 = R[0];
+  y.s_o0 = o.plane;
+  y.n_o1 = nb;
+  y.s_o1 = o.vol;
+  y.product = 0;
+  hipLaunchKernelGGL(fft_pencil_kernel<false>,
+                     dim3((unsigned)((long long)nb * R[0] * ((o.C + kT - 1) / kT))), dim3(kThreads),
+                     lds_bytes(F[1]), st, y);
+  PencilArgs z = y;
+  z.plan = o.pz;
+  z.tw = o.twz;
+  z.n_in = R[0];
+  z.stride = o.plane;
+  z.n_inner = static_cast<int>(o.plane);
+  z.n_o0 = 1;
+  z.s_o0 = 0;
+  if (mul) {
+    z.mul = mul;
+    z.product = 1;
+  }
+  hipLaunchKernelGGL(fft_pencil_kernel<false>,
+                     dim3((unsigned)((long long)nb * ((o.plane + kT - 1) / kT))), dim3(kThreads),
+                     lds_bytes(F[0]), st, z);
+}
+
+// Inverse of spec (mul != NULL: of spec * conj(mul), formed while loading) through
+// `work` (may be spec itself when mul == NULL); the x pass either crops into the
+// surface or writes the raw circular array.
+void own_inverse(const OwnGeo& o, const int* F, int nb, const float2* spec, const float2* mul,
+                 float2* work, const XInvArgs& xi_in, hipStream_t st) {
   PencilArgs z;
-  z.in = sb;
-  z.out = sb;
-  z.mul = nullptr;
-  z.plan = pz;
-  z.tw = twz;
+  z.in = spec;
+  z.out = work;
+  z.mul = mul;
+  z.plan = o.pz;
+  z.tw = o.twz;
   z.n_in = F[0];
-  z.stride = plane;
-  z.n_inner = static_cast<int>(plane);
+  z.stride = o.plane;
+  z.n_inner = static_cast<int>(o.plane);
   z.n_o0 = 1;
   z.s_o0 = 0;
   z.n_o1 = nb;
-  z.s_o1 = vol;
-  z.product = 0;
-  hipLaunchKernelGGL(fft_pencil_kernel<true>, dim3((unsigned)((long long)nb * ((plane + kT - 1) / kT))),
-                     dim3(kThreads), lds_bytes(F[0]), st, z);
-  PencilArgs y = z;
-  y.plan = py;
-  y.tw = twy;
-  y.n_in = F[1];
-  y.stride = C;
-  y.n_inner = C;
-  y.n_o0 = F[0];
-  y.s_o0 = plane;
+  z.s_o1 = o.vol;
+  z.product = mul ? 2 : 0;
   hipLaunchKernelGGL(fft_pencil_kernel<true>,
-                     dim3((unsigned)((long long)nb * F[0] * ((C + kT - 1) / kT))), dim3(kThreads),
+                     dim3((unsigned)((long long)nb * ((o.plane + kT - 1) / kT))), dim3(kThreads),
+                     lds_bytes(F[0]), st, z);
+  PencilArgs y = z;
+  y.in = work;
+  y.mul = nullptr;
+  y.product = 0;
+  y.plan = o.py;
+  y.tw = o.twy;
+  y.n_in = F[1];
+  y.stride = o.C;
+  y.n_inner = o.C;
+  y.n_o0 = F[0];
+  y.s_o0 = o.plane;
+  hipLaunchKernelGGL(fft_pencil_kernel<true>,
+                     dim3((unsigned)((long long)nb * F[0] * ((o.C + kT - 1) / kT))), dim3(kThreads),
                      lds_bytes(F[1]), st, y);
-  XInvArgs xi;
-  xi.in = sb;
-  xi.out = surface;
-  xi.smax = smax;
-  xi.plan = px;
-  xi.tw = twx;
-  for (int i = 0; i < 3; ++i) {
-    xi.F[i] = F[i];
-    xi.S[i] = S[i];
-    xi.Q[i] = Q[i];
-  }
-  xi.C = C;
-  xi.scale = 1.0f / (static_cast<float>(F[0]) * F[1] * F[2]);
+  XInvArgs xi = xi_in;
+  xi.in = work;
+  xi.plan = o.px;
+  xi.tw = o.twx;
+  for (int i = 0; i < 3; ++i) xi.F[i] = F[i];
+  xi.C = o.C;
   xi.nb = nb;
   const int it = (F[1] / 2 + kT - 1) / kT;
   hipLaunchKernelGGL(fft_xinv_kernel, dim3((unsigned)((long long)nb * F[0] * it)), dim3(kThreads),
                      lds_bytes(F[2]), st, xi);
+}
+
+}  // namespace
+
+// Un-masked correlation.  a0 / b0: [nb, Pn] / [nb, Qn] mean-subtracted patches; sa /
+// sb: two half-spectrum buffers [nb, F0, F1, C]; surface: [nb, Sn]; smax: [nb] or
+// NULL (zeroed).
+int own_fft_correlate(const int* P, const int* Q, const int* S, const int* F, int nb,
+                      const float* a0, const float* b0, float2* sa, float2* sb, float* surface,
+                      unsigned int* smax, hipStream_t st) {
+  OwnGeo o;
+  if (int rc = own_setup(F, &o)) return rc;
+  own_forward(o, P, F, nb, a0, 0, sa, nullptr, st);
+  own_forward(o, Q, F, nb, b0, 0, sb, sa, st);  // sb = A conj(B)
+  XInvArgs xi;
+  xi.out = surface;
+  xi.smax = smax;
+  for (int i = 0; i < 3; ++i) {
+    xi.S[i] = S[i];
+    xi.Q[i] = Q[i];
+  }
+  xi.scale = 1.0f / (static_cast<float>(F[0]) * F[1] * F[2]);
+  xi.raw = 0;
+  own_inverse(o, F, nb, sb, nullptr, sb, xi, st);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+// Building blocks of the masked (six-term) correlation: spectrum of one plane
+// (values or their squares), and the raw circular inverse of lhs * conj(rhs).
+int own_fft_forward(const int* R, const int* F, int nb, const float* src, int square,
+                    float2* spec, hipStream_t st) {
+  OwnGeo o;
+  if (int rc = own_setup(F, &o)) return rc;
+  own_forward(o, R, F, nb, src, square, spec, nullptr, st);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+int own_fft_inverse_product(const int* F, int nb, const float2* lhs, const float2* rhs,
+                            float2* work, float* real_out, hipStream_t st) {
+  OwnGeo o;
+  if (int rc = own_setup(F, &o)) return rc;
+  XInvArgs xi;
+  xi.out = real_out;
+  xi.smax = nullptr;
+  for (int i = 0; i < 3; ++i) {
+    xi.S[i] = F[i];
+    xi.Q[i] = 1;
+  }
+  xi.scale = 1.f;
+  xi.raw = 1;
+  own_inverse(o, F, nb, lhs, rhs, work, xi, st);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }

@@ -27,6 +27,10 @@ bool own_fft_supported(int rank, const int* F);
 int own_fft_correlate(const int* P, const int* Q, const int* S, const int* F, int nb,
                       const float* a0, const float* b0, float2* sa, float2* sb, float* surface,
                       unsigned int* smax, hipStream_t st);
+int own_fft_forward(const int* R, const int* F, int nb, const float* src, int square,
+                    float2* spec, hipStream_t st);
+int own_fft_inverse_product(const int* F, int nb, const float2* lhs, const float2* rhs,
+                            float2* work, float* real_out, hipStream_t st);
 
 namespace {
 
@@ -339,7 +343,8 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
   if (masked)
     for (int i = 0; i < 6; ++i) real[i] = c.take<float>((size_t)nb_max * g.Fn);
 
-  const bool own = !masked && own_fft_supported(g.rank, g.F);
+  const bool own_shape = own_fft_supported(g.rank, g.F);
+  const bool own = !masked && own_shape;
   for (int lo = 0; lo < d->batch; lo += nb_max) {
     const int nb = d->batch - lo < nb_max ? d->batch - lo : nb_max;
     if (own) {
@@ -350,11 +355,16 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
         return rc;
       continue;
     }
-    hipfftHandle fwd, inv;
-    if (int rc = get_plan(g, nb, HIPFFT_R2C, st, &fwd)) return rc;
-    if (int rc = get_plan(g, nb, HIPFFT_C2R, st, &inv)) return rc;
+    hipfftHandle fwd = 0, inv = 0;
+    if (!own_shape) {
+      if (int rc = get_plan(g, nb, HIPFFT_R2C, st, &fwd)) return rc;
+      if (int rc = get_plan(g, nb, HIPFFT_C2R, st, &inv)) return rc;
+    }
 
     auto forward = [&](const float* src, bool pre, int square, float2* out) -> int {
+      if (own_shape)  // masked volumes: zero-skipping hand-written transforms
+        return own_fft_forward(pre ? g.P : g.Q, g.F, nb,
+                               src + (long long)lo * (pre ? g.Pn : g.Qn), square, out, st);
       PadArgs p;
       p.src = src + (long long)lo * (pre ? g.Pn : g.Qn);
       p.dst = pad;
@@ -382,6 +392,7 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
       return SFM_OK;
     };
     auto product = [&](const float2* A, const float2* B, float2* prod, float* out) -> int {
+      if (own_shape) return own_fft_inverse_product(g.F, nb, A, B, prod, out, st);
       const long long n = (long long)nb * g.Cn;
       hipLaunchKernelGGL(cmul_conj_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, A, B,
                          prod, n);

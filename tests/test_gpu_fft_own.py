@@ -93,3 +93,29 @@ def test_own_fft_flow_3d(gpu):
   np.testing.assert_array_equal(own[:3], lib[:3])
   assert (own[0] == 5).all() and (own[1] == 2).all() and (own[2] == 3).all()
   np.testing.assert_allclose(own[3:], lib[3:], rtol=2e-3)
+
+
+@pytest.mark.parametrize('p,q', [((12, 20, 30), (12, 20, 30)), ((16, 24, 25), (9, 20, 25))])
+def test_own_fft_masked_volumes_match_plans_and_oracle(gpu, p, q):
+  """Masked (Padfield) volumetric correlation: six spectra and six inverse
+  transforms of products through the hand-written passes == hipFFT plans ==
+  oracle."""
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(sum(q))
+  b = 3
+  a = rng.integers(0, 255, (b,) + p).astype(np.uint8)
+  c = rng.integers(0, 255, (b,) + q).astype(np.uint8)
+  am = rng.random(a.shape) < 0.2
+  cm = rng.random(c.shape) < 0.1
+  am[0, :3] = True
+  run = lambda: flow_field.masked_xcorr(a, c, am, cm, dim=3, method=3)
+  own = _with_env({'SFM_FFT_OWN': '1'}, run)
+  lib = _with_env({'SFM_FFT_OWN': '0'}, run)
+  flipped = (own == 0) != (lib == 0)       # entries at the tolerance / overlap thresholds
+  assert flipped.mean() < 2e-3
+  np.testing.assert_allclose(own[~flipped], lib[~flipped], atol=2e-5)
+  want = flow_oracle.xcorr_surface(a, c, am, cm, dim=3)
+  flipped = (own == 0) != (want == 0)
+  assert flipped.mean() < 2e-3
+  bad = (np.abs(own - want) > 5e-5) & ~flipped
+  assert bad.mean() < 1e-4
