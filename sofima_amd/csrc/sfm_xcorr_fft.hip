@@ -418,7 +418,9 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
     cr.maxima = maxima;
     // (x: workgroups striding over the rows of one surface, y: surface)
     const int crop_rows = g.S[0] * g.S[1];
-    const dim3 crop_grid(std::max(1, std::min((crop_rows + 3) / 4, 8192 / std::max(nb, 1))), nb);
+    // (about 2048 workgroups in all: thousands of two-row workgroups are bound by
+    // the dispatch rate, not by memory)
+    const dim3 crop_grid(std::max(1, std::min((crop_rows + 3) / 4, 2048 / std::max(nb, 1))), nb);
     cr.smax = smax ? smax + lo : nullptr;
     if (!masked) {
       if (int rc = forward(a0, true, 0, spec[0])) return rc;
