@@ -218,6 +218,16 @@ def main():
       roof['sustained_clock_mhz'] = round(clk, 1)
       roof['peak_at_sustained_clock'] = round(peak * clk / 2400.0, 1)
       roof['frac_at_sustained_clock'] = round(achieved / (peak * clk / 2400.0), 4)
+    drawn = int(prof.tiles_drawn[0])
+    if drawn:
+      # exact pruning: surface row tiles that provably hold no peak, no
+      # candidate and no sharpness-window element are not computed (results
+      # bit-identical; SFM_MFMA_PRUNE=0 computes everything).  `achieved`
+      # counts the ALGORITHMIC 2 P^4 operations per patch either way.
+      roof['row_tiles_skipped_frac'] = round(int(prof.tiles_skipped[0]) / drawn, 4)
+      computed = drawn - int(prof.tiles_skipped[0])
+      if computed:  # of the computed row tiles: outer column tiles left out (of 20 at P=160)
+        roof['col_tiles_skipped_per_row_tile'] = round(int(prof.col_tiles_skipped[0]) / computed, 3)
   mesh_obj = {
       'value': node_updates_s, 'unit': 'node-updates/s',
       'nodes': mesh_nodes, 'iterations_per_step': mesh_steps_done // max(args.steps, 1),

@@ -68,6 +68,10 @@ typedef struct SfmProfile {
   double clock_mhz[2];          /* sustained shader clock inside the kernels of
                                    that kind (s_memtime / s_memrealtime of one
                                    workgroup); 0 when not sampled             */
+  int64_t tiles_skipped[2];     /* kind 0: surface row tiles the exact pruning of
+                                   the fused-peaks kernel skipped / looked at   */
+  int64_t tiles_drawn[2];
+  int64_t col_tiles_skipped[2]; /* column tiles left out of the computed row tiles */
 } SfmProfile;
 int sfm_profile_enable(int on);
 int sfm_profile_read(SfmProfile* out);

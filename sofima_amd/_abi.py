@@ -287,7 +287,9 @@ class SfmFireState(C.Structure):
 
 class SfmProfile(C.Structure):
   _fields_ = [('kernel_ms', C.c_double * 2), ('launches', C.c_int64 * 2),
-              ('clock_mhz', C.c_double * 2)]
+              ('clock_mhz', C.c_double * 2),
+              ('tiles_skipped', C.c_int64 * 2), ('tiles_drawn', C.c_int64 * 2),
+              ('col_tiles_skipped', C.c_int64 * 2)]
 
 
 class SfmChunkStats(C.Structure):

@@ -32,7 +32,7 @@ bool profiling();
 void prof_begin(int kind, hipStream_t st);
 void prof_end(int kind, hipStream_t st);
 // Samples a kernel's shader-clock probe: dev_pair = {core cycles, 10 ns ticks}.
-void prof_clock(int kind, const long long* dev_pair, hipStream_t st);
+void prof_clock(int kind, const long long* dev_pair, hipStream_t st, int n = 2);
 
 // Buffers of the peak search that the MFMA kernel fills itself when the first
 // pass is fused into it (sfm_xcorr_mfma.hip: fused_first_peak).

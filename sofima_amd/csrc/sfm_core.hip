@@ -32,7 +32,7 @@ std::vector<Span> g_spans[2];
 std::vector<Span> g_free;
 Span g_open[2];
 struct ClockSample {
-  long long v[2];
+  long long v[5];  // cycles, 10 ns ticks[, row tiles skipped, drawn, column tiles skipped]
 };
 std::deque<ClockSample> g_clock[2];  // stable addresses: targets of async copies
 }  // namespace
@@ -61,11 +61,11 @@ void prof_end(int kind, hipStream_t st) {
   g_spans[kind].push_back(g_open[kind]);
 }
 
-void prof_clock(int kind, const long long* dev_pair, hipStream_t st) {
+void prof_clock(int kind, const long long* dev_pair, hipStream_t st, int n) {
   if (!profiling() || !dev_pair) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_clock[kind].push_back(ClockSample{{0, 0}});
-  (void)hipMemcpyAsync(g_clock[kind].back().v, dev_pair, sizeof(long long) * 2,
+  g_clock[kind].push_back(ClockSample{{0, 0, 0, 0, 0}});
+  (void)hipMemcpyAsync(g_clock[kind].back().v, dev_pair, sizeof(long long) * (n > 2 && n <= 5 ? n : 2),
                        hipMemcpyDeviceToHost, st);
 }
 
@@ -96,12 +96,18 @@ int sfm_profile_read(SfmProfile* out) {
     out->launches[k] = static_cast<int64_t>(sfm::g_spans[k].size());
     sfm::g_spans[k].clear();
     // the events above are later in stream order than the probe copies
-    long long cyc = 0, ticks = 0;
+    long long cyc = 0, ticks = 0, skipped = 0, drawn = 0, cols = 0;
     for (auto& c : sfm::g_clock[k]) {
       cyc += c.v[0];
       ticks += c.v[1];
+      skipped += c.v[2];
+      drawn += c.v[3];
+      cols += c.v[4];
     }
     out->clock_mhz[k] = ticks > 0 ? static_cast<double>(cyc) * 100.0 / ticks : 0.0;
+    out->tiles_skipped[k] = skipped;
+    out->tiles_drawn[k] = drawn;
+    out->col_tiles_skipped[k] = cols;
     sfm::g_clock[k].clear();
   }
   return SFM_OK;

@@ -101,6 +101,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <cstring>
 #include <vector>
 
@@ -117,6 +118,8 @@ constexpr int kWaves = 4;
 constexpr int kPadTop = 16;     // zero rows above the pre patch in LDS
 constexpr int kPadBottom = 18;  // zero rows below
 constexpr int kMaxTilesPerWave = 24;
+constexpr int kBoundStride = 32;   // dy tiles per patch with a pruning bound
+constexpr int kBoundRows = 256;    // patch rows the prep kernel keeps energies for
 
 struct PatchParams {  // written by the prep kernel, one per patch
   int y0[2], x0[2];   // clamped patch origin in the image (pre, post)
@@ -192,9 +195,18 @@ struct MfmaArgs {
   // dynamic patch queue (NULL: static striding over the workgroups)
   int* work_counter;
   // shader-clock probe: workgroup 0 leaves (core cycles, 10 ns wall ticks) of its
-  // residency here (bench.py reports the sustained clock under this kernel)
+  // residency here (bench.py reports the sustained clock under this kernel);
+  // clk[2], clk[3]: dy tiles skipped by the pruning / drawn, whole launch; clk[4]:
+  // column tiles left out of the computed dy tiles
   long long* clk;
   int prio_mode;      // experiment knob: 0 natural, 1 alternate per tile, 2 static
+  // exact pruning of dy tiles (fused-peaks mode): tbound[b][p] bounds |surface|
+  // over tile p widened by `guard` rows (prep output; see the tile loop)
+  float* tbound;      // [batch, kBoundStride]; the last two entries: outer column tiles
+  int prune;
+  int guard, guard_x;
+  int nq;             // column tiles of the kernel variant
+  int prune_k[2];     // outer column tiles (each side) of the row-loop variants
 };
 
 __device__ __forceinline__ unsigned load_u32_guarded(const unsigned* base,
@@ -344,6 +356,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a) {
   if (a.work_counter && blockIdx.x == 0 && threadIdx.x == 0)
     *a.work_counter = 0;  // the correlation kernel's patch queue
+  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[2] = a.clk[3] = a.clk[4] = 0;  // tile counts
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_c[2];
   __shared__ float s_mu[2];
@@ -351,11 +364,24 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   // reduction scratch of phase 2, aliased onto band_tot (separated by a barrier)
   static_assert(sizeof(band_tot) >= sizeof(int) * 2 * 3 * kPrepThreads, "alias");
   int (*red)[3][kPrepThreads] = reinterpret_cast<int (*)[3][kPrepThreads]>(&band_tot[0][0][0]);
+  // pruning bounds: per-row sum and sum of squares of the raw pixels, later the
+  // prefix sums of the row energies (doubles, aliased)
+  __shared__ int row_sum[2][kBoundRows], row_sq[2][kBoundRows];
+  __shared__ double row_pre[2][kBoundRows + 1];
+  __shared__ int col_sq[2][64 * kPrepCols];  // column sums of squares (post: mirrored)
   const int b = blockIdx.x;
   const int py = a.P[0], px = a.P[1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* pix[2] = {smem, smem + ((py * px + 15) & ~15)};
+  if (a.prune) {
+    for (int i = threadIdx.x; i < 2 * kBoundRows; i += kPrepThreads) {
+      (&row_sum[0][0])[i] = 0;
+      (&row_sq[0][0])[i] = 0;
+    }
+    for (int i = threadIdx.x; i < 2 * 64 * kPrepCols; i += kPrepThreads) (&col_sq[0][0])[i] = 0;
+    __syncthreads();
+  }
 #ifdef SFM_MFMA_TIMING
   long long pt[6]; pt[0] = clock64();
 #define PTICK(i) pt[i] = clock64();
@@ -396,6 +422,7 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
         const int item = item0 + u * kPrepThreads;
         if (item >= n_items) break;
         const int y = item / n_chunks, ch = item - y * n_chunks;
+        int isum = 0, isq = 0;  // this item's share of its row's sums
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const unsigned v = static_cast<unsigned>(w[s][u][k]);
@@ -409,13 +436,19 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
             for (int t = 0; t < keep; ++t) dst[t] = static_cast<unsigned char>(v >> (8 * t));
           }
           const unsigned live = keep == 4 ? 0xffffffffu : (0xffffffffu >> (8 * (4 - keep)));
-          sum[s] = static_cast<int>(__builtin_amdgcn_sad_u8(v & live, 0u, sum[s]));
+          isum = static_cast<int>(__builtin_amdgcn_sad_u8(v & live, 0u, isum));
+          isq = static_cast<int>(__builtin_amdgcn_udot4(v & live, v & live, isq, false));
           const unsigned lo = v | ~live, hi = v & live;  // dead bytes: 255 for min, 0 for max
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             mn[s] = min(mn[s], static_cast<int>((lo >> (8 * t)) & 0xffu));
             mx[s] = max(mx[s], static_cast<int>((hi >> (8 * t)) & 0xffu));
           }
+        }
+        sum[s] += isum;
+        if (a.prune) {
+          atomicAdd(&row_sum[s][y], isum);
+          atomicAdd(&row_sq[s][y], isq);
         }
       }
   }
@@ -469,6 +502,37 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   }
   __syncthreads();  // `red` (aliased with band_tot) fully consumed
   PTICK(2)
+  if (a.prune && wave < 2) {
+    // Row energies e[y] = sum_x (pixel - mean)^2 of side `wave` (exact integers
+    // in, doubles out) and their prefix sums: lane l owns rows 4 l .. 4 l + 3.
+    const int s = wave;
+    const double mu = static_cast<double>(s_c[s]) + static_cast<double>(s_mu[s]);
+    double e[4], tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = 4 * lane + k;
+      e[k] = 0.0;
+      if (y < py)
+        e[k] = fmax(static_cast<double>(row_sq[s][y]) -
+                        2.0 * mu * static_cast<double>(row_sum[s][y]) + mu * mu * px,
+                    0.0);
+      tot += e[k];
+      e[k] = tot;  // inclusive within the lane
+    }
+    double inc = tot;  // inclusive scan of the lane totals
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    const double excl = inc - tot;
+    if (lane == 0) row_pre[s][0] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = 4 * lane + k;
+      if (y < py) row_pre[s][y + 1] = excl + e[k];
+    }
+  }
 
   // Phase 3a: per-band column totals (band w = rows [w R, (w + 1) R)).
   // Lane l owns the kPrepCols consecutive columns kPrepCols * l + k, so one
@@ -479,17 +543,25 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
 #pragma unroll
   for (int k = 0; k < kPrepCols; ++k) {
     const int x = xl + k;
-    int ta = 0, tb = 0;
+    int ta = 0, tb = 0, qa = 0, qb = 0;
     if (x < px) {
       // several rows per trip: the byte loads of a trip are in flight together
 #pragma unroll 5
       for (int y = ra0; y < ra1; ++y) {
-        ta += pix[0][y * px + x];
-        tb += pix[1][y * px + (px - 1 - x)];  // post patch: mirrored columns
+        const int va = pix[0][y * px + x];
+        const int vb = pix[1][y * px + (px - 1 - x)];  // post patch: mirrored columns
+        ta += va;
+        tb += vb;
+        qa += va * va;
+        qb += vb * vb;
       }
     }
     band_tot[0][wave][xl + k] = ta;
     band_tot[1][wave][xl + k] = tb;
+    if (a.prune && x < px) {
+      atomicAdd(&col_sq[0][x], qa);
+      atomicAdd(&col_sq[1][x], qb);
+    }
   }
   __syncthreads();
   const int ca = s_c[0], cb = s_c[1];
@@ -599,6 +671,77 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
     for (int k = 0; k < kPrepCols; ++k) {
       colA[k] += nxt_a[k];
       colB[k] -= nxt_b[k];
+    }
+  }
+  if (a.prune && threadIdx.x < kBoundStride) {
+    // |surface[dy][dx]| = |sum over the overlap of (a - mean_a)(b - mean_b)|
+    //   <= sqrt(E_A(rows of the overlap) E_B(rows of the overlap))     (Cauchy-Schwarz,
+    // the column range only shrinks the sums), and the row sets are nested in
+    // |dy|: the bound of a tile widened by `guard` rows is the one of its row
+    // nearest the centre.  (row_pre was finished before the barrier of phase 3a.)
+    const int p = threadIdx.x;
+    const int lo = 16 * p - (py - 1), hi = min(lo + 15, py - 1);
+    float bound = INFINITY;  // tiles that do not exist are never asked for
+    if (lo <= py - 1) {
+      int d = 0;
+      if (lo > 0) d = max(0, lo - a.guard);
+      if (hi < 0) d = min(0, hi + a.guard);
+      // out[dy] = sum_yb a[yb + dy] b[yb]:  dy >= 0: a rows [dy, py), b rows [0, py - dy)
+      const double ea = d >= 0 ? row_pre[0][py] - row_pre[0][d] : row_pre[0][py + d];
+      const double eb = d >= 0 ? row_pre[1][py - d] : row_pre[1][py] - row_pre[1][-d];
+      // margins: float rounding of the correction terms in the kernel (< 1 abs)
+      bound = static_cast<float>(sqrt(fmax(ea, 0.0) * fmax(eb, 0.0)) * 1.0005 + 4.0);
+    }
+    if (p < kBoundStride - 2) a.tbound[(long long)b * kBoundStride + p] = bound;
+  }
+  if (a.prune && wave == 1) {
+    // The same along x for the outermost prune_k[j] column tiles on either side
+    // (the correlation kernel has row-loop variants without them): column
+    // energies, lane l owns columns 3 l .. 3 l + 2 (post patch: mirrored).
+    const double mua_d = static_cast<double>(s_c[0]) + static_cast<double>(s_mu[0]);
+    const double mub_d = static_cast<double>(s_c[1]) + static_cast<double>(s_mu[1]);
+    double ea[kPrepCols], eb[kPrepCols];
+#pragma unroll
+    for (int k = 0; k < kPrepCols; ++k) {
+      const int x = xl + k;
+      int sa = 0, sb = 0;
+      for (int w2 = 0; w2 < kPrepWaves; ++w2) {
+        sa += band_tot[0][w2][x];
+        sb += band_tot[1][w2][x];
+      }
+      ea[k] = x < px ? fmax(col_sq[0][x] - 2.0 * mua_d * sa + mua_d * mua_d * py, 0.0) : 0.0;
+      eb[k] = x < px ? fmax(col_sq[1][x] - 2.0 * mub_d * sb + mub_d * mub_d * py, 0.0) : 0.0;
+    }
+    auto wave_sum = [&](double v) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+      return v;
+    };
+    // bound of every shift with |dx| >= |d| (d of either sign), all dy:
+    //   out[., dx] = sum a[., xa] b[., xa - dx]:  dx >= 0: a cols [dx, px), b cols [0, px - dx)
+    auto bound_x = [&](int d) {
+      double sa = 0.0, sb = 0.0;
+#pragma unroll
+      for (int k = 0; k < kPrepCols; ++k) {
+        const int xa = xl + k, xb = px - 1 - (xl + k);  // actual columns of the two entries
+        const bool in_a = d >= 0 ? xa >= d : xa < px + d;
+        const bool in_b = d >= 0 ? xb < px - d : xb >= -d;
+        if (xa < px && in_a) sa += ea[k];
+        if (xa < px && in_b) sb += eb[k];
+      }
+      return static_cast<float>(sqrt(wave_sum(sa) * wave_sum(sb)) * 1.0005 + 4.0);
+    };
+    for (int j = 0; j < 2; ++j) {
+      const int ks = a.prune_k[j];
+      float bound = INFINITY;  // no such variant: never taken
+      if (ks > 0) {
+        // nearest-to-centre columns of the outer tiles: kx = 16 ks - 1 (left),
+        // kx = 16 (nq - ks) (right); dx = kx - (px - 1); widened by the guard
+        const int dl = min(0, 16 * ks - px + a.guard_x);
+        const int dr = max(0, 16 * (a.nq - ks) - (px - 1) - a.guard_x);
+        bound = fmaxf(bound_x(dl), bound_x(dr));
+      }
+      if (lane == 0) a.tbound[(long long)b * kBoundStride + kBoundStride - 2 + j] = bound;
     }
   }
 #ifdef SFM_MFMA_TIMING
@@ -1561,6 +1704,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   // 16 bytes behind the aux arrays: running maximum of the current surface.
   int* pmax_lds = reinterpret_cast<int*>(smem + a.a_bytes + a.b_bytes + a.r_bytes);
   int* hot_lds = pmax_lds + 1;  // hot-list fill count of the current patch
+  float* tb_lds = reinterpret_cast<float*>(pmax_lds + 4);  // pruning bounds (a.prune)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -1591,6 +1735,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   // at the same speed (see the priority note below) and finish whole patches
   // at different times.
   int* next_lds = hot_lds + 1;
+  int tiles_drawn = 0, tiles_skipped = 0, cols_skipped = 0;  // (wave-uniform; reported through a.clk)
   if (a.prio_mode == 3) {
     // HW_REG_LDS_ALLOC[7:0] = LDS_BASE: 0 for the first workgroup of the CU.
     const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6) & 0xff;
@@ -1624,7 +1769,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     // take the remainder loops below
     constexpr int kAuxRegs = 3;
     float auxv[kAuxRegs];
-    float const_a = 0.f, const_b = 0.f;
+    float const_a = 0.f, const_b = 0.f, tbv = 0.f;
     if (RAW) {
       stage_plane(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], a.mask[0],
                   (long long)a.mshape[0][0] * a.mshape[0][1], a.mshape[0][1],
@@ -1647,6 +1792,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         }
         const_a = aux[4 * a.aux_n + 0];
         const_b = aux[4 * a.aux_n + 1];
+        // (unconditional: a load under a condition would be waited for on its own)
+        tbv = a.tbound[(long long)b * kBoundStride + (threadIdx.x & (kBoundStride - 1))];
       }
       const StagePlane sa = {a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], Py, Px,
                              pp.c[0], A_lds, a.pa, kPadTop, 0, NCA};
@@ -1666,6 +1813,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         const int i = threadIdx.x + k * kThreads;
         if (i < 4 * a.aux_n) R_lds[i] = auxv[k];
       }
+      if (a.prune && threadIdx.x < kBoundStride) tb_lds[threadIdx.x] = tbv;
       const float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
       for (int i = threadIdx.x + kAuxRegs * kThreads; i < 4 * a.aux_n; i += kThreads)
         R_lds[i] = aux[i];
@@ -1748,6 +1896,35 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         else
           __builtin_amdgcn_s_setprio(0);
       }
+      int col_skip = 0;  // outer column tiles (each side) this tile leaves out
+      if (SAME && a.prune) {
+        // Exact pruning.  Every element of this tile and of the `guard` rows
+        // around it is bounded by tb (prep kernel).  If tb < threshold_rel x (the
+        // running maximum, which never exceeds the final one), none of them is
+        // the maximum, a peak candidate, inside a candidate's max-filter window
+        // or inside the first peak's sharpness window: the tile is never read
+        // for its values.  It is stored as zeros (the fallback sweeps of the peak
+        // kernels read whole surfaces; zeros are below every threshold too).
+        const float mrun = __int_as_float(__builtin_amdgcn_readfirstlane(
+            *const_cast<volatile int*>(pmax_lds)));
+        ++tiles_drawn;
+        if (tb_lds[p] < a.threshold_rel * mrun) {
+          ++tiles_skipped;
+          float* t0 = surf + (long long)16 * p * a.sx_pitch + 4 * lane;
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            __builtin_nontemporal_store(z4, reinterpret_cast<v4f*>(t0 + 256 * q));
+          continue;
+        }
+        // Along x the same argument holds for the outer column tiles (bounds of
+        // the outermost kKs1 / kKs2 tiles on either side, widened by the
+        // guard): the row loop below has variants that leave them out.
+        const float t = a.threshold_rel * mrun;
+        col_skip = tb_lds[kBoundStride - 1] < t ? NQ / 5 : tb_lds[kBoundStride - 2] < t ? NQ / 10 : 0;
+        cols_skipped += 2 * col_skip;
+      }
       const int dy0 = 16 * p - (Qy - 1);
       const int ylo = max(0, -dy0 - 15);
       const int yhi = min(Qy, Py - dy0);
@@ -1809,6 +1986,10 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // with the chunk kW positions ahead (of this row group or the next).
         constexpr int kW = NCA > 6 ? NCA / 2 : NCA;
         static_assert(NCA % kW == 0, "window must divide the chunk count");
+        // The row loop exists in up to three variants: KS outer column tiles on
+        // either side are left out (exact pruning along x, see col_skip below).
+        auto rows = [&](auto ks_const) {
+        constexpr int KS = decltype(ks_const)::value;
         v4i af[kW], bf[NCE];
         unsigned dn[kND];
 #pragma unroll
@@ -1847,8 +2028,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #pragma unroll
             for (int c = 0; c < NCE; ++c) {
               const int q = ca - c + cq0;
-              acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ca % kW], bf[c], acc[q], 0,
-                                                             0, 0);
+              if (q >= KS && q < NQ - KS)
+                acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ca % kW], bf[c], acc[q], 0,
+                                                               0, 0);
               if (ca == NCA - 1) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -1861,12 +2043,30 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
               af[ca % kW] =
                   *reinterpret_cast<const v4i*>(ap + 4 * a.pa + 16 * (ca + kW - NCA));
             if (ca < NCA - 1) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+              // MFMAs of this chunk: columns q = ca - c + cq0 inside [KS, NQ - KS)
+              const int c_lo = ca + cq0 - (NQ - KS - 1) > 0 ? ca + cq0 - (NQ - KS - 1) : 0;
+              const int c_hi = ca + cq0 - KS < NCE - 1 ? ca + cq0 - KS : NCE - 1;
+              const int n_mfma = c_hi - c_lo + 1;
+              // (the builtin wants literal counts; ca is a constant after unrolling)
+#define SFM_PAIR(i)                                                             \
+  if (n_mfma > i) {                                                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */           \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* one LDS read */       \
+  }
+              SFM_PAIR(0) SFM_PAIR(1) SFM_PAIR(2) SFM_PAIR(3)
+#undef SFM_PAIR
+              switch (n_mfma - 4) {
+                case 1: __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); break;
+                case 2: __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); break;
+                case 3: __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); break;
+                case 4: __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); break;
+                case 5: __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); break;
+                case 6: __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); break;
+                case 7: __builtin_amdgcn_sched_group_barrier(0x008, 7, 0); break;
+                case 8: __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); break;
+                default: break;
               }
-              __builtin_amdgcn_sched_group_barrier(0x008, NCE - 4, 0);
+              static_assert(NCE - 4 <= 8, "extend the switch");
             }
 #else
             if (ca + kW < NCA)
@@ -1886,6 +2086,14 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           }
           ap += 4 * a.pa;
         }
+        };
+        constexpr int kKs1 = NQ / 10, kKs2 = NQ / 5;
+        if (kKs2 > 0 && col_skip == kKs2)
+          rows(std::integral_constant<int, kKs2>{});
+        else if (kKs1 > 0 && kKs1 != kKs2 && col_skip == kKs1)
+          rows(std::integral_constant<int, kKs1>{});
+        else
+          rows(std::integral_constant<int, 0>{});
       } else
 #if SFM_AF_PREFETCH
       {
@@ -2028,6 +2236,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             }
           };
           auto store4 = [&](int q, int r, float v) {
+            if (q < col_skip || q >= NQ - col_skip) v = 0.f;  // column tile left out
             __builtin_nontemporal_store(
                 v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
                                             (static_cast<size_t>(rowp[r]) + 64u * q)));
@@ -2113,7 +2322,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             float corr = fmaf(ey[r] * ex, gv[r], sx ? a_pos[r] : a_neg[r]);
             corr += sy[r] ? b_pos : b_neg;
             corr = fmaf(fny[r], fnx, corr);
-            const float v = static_cast<float>(acc[q][r]) + corr;
+            float v = static_cast<float>(acc[q][r]) + corr;
+            if (q < col_skip || q >= NQ - col_skip) v = 0.f;  // column tile left out
             __builtin_nontemporal_store(
                 v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
                                             (static_cast<size_t>(rowp[r]) + 64u * q)));
@@ -2259,6 +2469,14 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     a.clk[0] = clock64() - probe_c0;
     a.clk[1] = wall_clock64() - probe_w0;
   }
+  if (SAME && a.prune && a.clk && lane == 0) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 2),
+              static_cast<unsigned long long>(tiles_skipped));
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 3),
+              static_cast<unsigned long long>(tiles_drawn));
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 4),
+              static_cast<unsigned long long>(cols_skipped));
+  }
 #ifdef SFM_MFMA_TIMING
   if (lane == 0 && wave == 0) {
     // HW_REG_HW_ID (4): [11:8] CU, [12] SH, [15:13] SE; HW_REG_XCC_ID (20): [3:0]
@@ -2285,6 +2503,12 @@ constexpr Variant kVariants[] = {{3, 4}, {4, 5}, {5, 6}, {6, 7}, {8, 9}, {10, 11
 
 bool exact_enabled() {
   const char* e = std::getenv("SFM_MFMA_EXACT");
+  return !(e && e[0] == '0');
+}
+
+// SFM_MFMA_PRUNE=0: every dy tile is computed (tests, measurements).
+bool prune_enabled() {
+  const char* e = std::getenv("SFM_MFMA_PRUNE");
   return !(e && e[0] == '0');
 }
 
@@ -2342,6 +2566,7 @@ struct Ws {
   float* gtab;
   float* aux;
   int aux_n;
+  float* tbound;
   int* counter;
   size_t bytes;
 };
@@ -2357,6 +2582,7 @@ Ws carve_ws(const SfmXcorrDesc* d, void* base) {
     w.aux_n = std::max(d->patch[1], d->patch[2]) + 1;
     w.gtab = c.take<float>(B * d->patch[1] * d->patch[2]);
     w.aux = c.take<float>(B * (4 * w.aux_n + 4));
+    w.tbound = c.take<float>(B * kBoundStride);
   } else {
     w.stride[0] = (long long)(d->patch[1] + 1) * (d->patch[2] + 1);
     w.stride[1] = (long long)(d->post_patch[1] + 1) * (d->post_patch[2] + 1);
@@ -2398,7 +2624,7 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, MODE>), dim3(grid),
                      dim3(kThreads), lds, st, a);
   sfm::prof_end(sfm::kProfXcorr, st);
-  sfm::prof_clock(sfm::kProfXcorr, a.clk, st);
+  sfm::prof_clock(sfm::kProfXcorr, a.clk, st, 5);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }
@@ -2624,7 +2850,18 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     a.hot_count = fp->hot_count;
     a.hot_val = fp->hot_val;
     a.hot_idx = fp->hot_idx;
+    // exact pruning of dy tiles that cannot matter to the peak statistics
+    a.tbound = w.tbound;
+    a.guard = std::max(d->min_distance, 2 * d->peak_radius[1]);
+    a.guard_x = std::max(d->min_distance, 2 * d->peak_radius[2]);
+    a.nq = kVariants[vi].nca + kVariants[vi].nce - 1;
+    a.prune_k[0] = a.nq / 10 != a.nq / 5 ? a.nq / 10 : 0;
+    a.prune_k[1] = a.nq / 5;
+    a.prune = same && prune_enabled() && a.n_order <= kBoundStride - 2 &&
+              a.P[0] <= kBoundRows && d->threshold_rel > 0.f && d->threshold_rel <= 1.f &&
+              a.guard >= 0;
   }
+  if (!a.tbound) a.tbound = w.tbound;  // read (not used) by every same-size launch
   if (same) {
     const size_t prep_lds = 2 * (((size_t)a.P[0] * a.P[1] + 15) & ~(size_t)15);
     static size_t prep_attr = 0;
@@ -2649,7 +2886,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   r_bytes = std::max(r_bytes, (size_t)kThreads * 8);
   r_bytes = (r_bytes + 15) / 16 * 16;
   a.r_bytes = static_cast<int>(r_bytes);
-  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
+  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride;
   const int grid = d->batch;  // capped to the resident workgroups in launch_one
   const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
   if (int rc = launch_mode(vi, a, same ? (exact ? kModeSameExact : kModeSame) : kModeGeneral,

@@ -909,3 +909,62 @@ def test_masked_flow_mostly_clean_vs_oracle(gpu, monkeypatch):
   np.testing.assert_array_equal(got, eight)
   want = flow_oracle.flow_field(pre, post, 160, 40, workers=4, **kw)
   check_flow(got, want, sharp_rtol=5e-3, ratio_rtol=2e-3)
+
+
+def _prune_images(kind, seed, h, w):
+  """Image pairs that stress the tile pruning in different ways."""
+  from scipy import ndimage
+  rng = np.random.default_rng(seed)
+  if kind == 'em':            # high NCC peak near the centre: most pruning
+    return _em_pair(seed, h, w, shift=(3, -5), warp=2.0)
+  if kind == 'far':           # true shift of 100+ px: the peak sits in an outer tile
+    base = ndimage.gaussian_filter(rng.standard_normal((h + 260, w + 260)), 2.0)
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+    return (base[130:130 + h, 130:130 + w].copy(),
+            base[130 + 118:130 + 118 + h, 130 - 97:130 - 97 + w].copy())
+  if kind == 'periodic':      # many peaks of similar height all over the surface
+    yy, xx = np.mgrid[:h, :w]
+    tex = 100 + 60 * np.sin(2 * np.pi * yy / 23.0) * np.cos(2 * np.pi * xx / 31.0)
+    pre = np.clip(tex + rng.normal(0, 6, tex.shape), 0, 255).astype(np.uint8)
+    post = np.clip(np.roll(tex, (4, -7), (0, 1)) + rng.normal(0, 6, tex.shape), 0, 255)
+    return pre, post.astype(np.uint8)
+  if kind == 'noise':         # unrelated images: low, scattered maxima, little pruning
+    return (rng.integers(0, 256, (h, w)).astype(np.uint8),
+            rng.integers(0, 256, (h, w)).astype(np.uint8))
+  # 'edges': half the image flat, features only in a band (energies concentrated
+  # in a few rows, so the bounds fall off abruptly)
+  pre, post = _em_pair(seed, h, w, shift=(-6, 9))
+  pre[: h // 2] = 90
+  post[: h // 2 + 10] = 90
+  pre[:, ::64] = 255
+  return pre, post
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['em', 'far', 'periodic', 'noise', 'edges'])
+def test_pruned_correlation_tiles_are_bit_identical(gpu, monkeypatch, kind):
+  """The fused-peaks kernel skips dy tiles whose Cauchy-Schwarz bound is below
+  threshold_rel x the running maximum: results equal the un-pruned run bit for
+  bit, for every patch size class, peak radius and min_distance."""
+  from sofima_amd import flow_field
+  h, w = 460, 500
+  pre, post = _prune_images(kind, 31, h, w)
+  rng = np.random.default_rng(5)
+  for (py, px), radius, md, thr in [((160, 160), 5, 2, 0.5), ((96, 96), 5, 2, 0.5),
+                                    ((64, 64), 12, 6, 0.5), ((50, 70), 5, 2, 0.3),
+                                    ((160, 160), 30, 2, 0.9), ((128, 112), 3, 1, 0.5)]:
+    b = 24
+    starts = np.stack([rng.integers(-10, h - py + 10, b),
+                       rng.integers(-10, w - px + 10, b)], axis=1)
+    kw = dict(min_distance=md, threshold_rel=thr, peak_radius=radius,
+              post_patch_size=(py, px), post_starts=starts)
+    for mean in (None, 100.0):
+      args = (pre, post, None, None, (py, px), starts, mean)
+      pruned = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+      monkeypatch.setenv('SFM_MFMA_PRUNE', '0')
+      full = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+      monkeypatch.delenv('SFM_MFMA_PRUNE')
+      np.testing.assert_array_equal(pruned, full)
+      if (py, px) == (96, 96):
+        ref = flow_field.batched_xcorr_peaks(*args, method=1, **kw)
+        np.testing.assert_array_equal(pruned[:, :2], ref[:, :2])
