@@ -118,6 +118,11 @@ constexpr int kWaves = 4;
 constexpr int kPadTop = 16;     // zero rows above the pre patch in LDS
 constexpr int kPadBottom = 18;  // zero rows below
 constexpr int kMaxTilesPerWave = 24;
+// Row-loop variants of the correlation kernel: outer column tiles (each side)
+// left out when their bound allows it.  With 20 column tiles (P = 160) and an
+// NCC peak of 0.9+ the outer 4 qualify for most patches, the outer 3 for all.
+__host__ __device__ constexpr int col_skip_hi(int nq) { return nq / 5; }
+__host__ __device__ constexpr int col_skip_lo(int nq) { return 3 * nq / 20; }
 constexpr int kBoundStride = 32;   // dy tiles per patch with a pruning bound
 constexpr int kBoundRows = 256;    // patch rows the prep kernel keeps energies for
 
@@ -1922,7 +1927,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // the outermost kKs1 / kKs2 tiles on either side, widened by the
         // guard): the row loop below has variants that leave them out.
         const float t = a.threshold_rel * mrun;
-        col_skip = tb_lds[kBoundStride - 1] < t ? NQ / 5 : tb_lds[kBoundStride - 2] < t ? NQ / 10 : 0;
+        col_skip = tb_lds[kBoundStride - 1] < t ? col_skip_hi(NQ) : tb_lds[kBoundStride - 2] < t ? col_skip_lo(NQ) : 0;
         cols_skipped += 2 * col_skip;
       }
       const int dy0 = 16 * p - (Qy - 1);
@@ -2087,7 +2092,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           ap += 4 * a.pa;
         }
         };
-        constexpr int kKs1 = NQ / 10, kKs2 = NQ / 5;
+        constexpr int kKs1 = col_skip_lo(NQ), kKs2 = col_skip_hi(NQ);
         if (kKs2 > 0 && col_skip == kKs2)
           rows(std::integral_constant<int, kKs2>{});
         else if (kKs1 > 0 && kKs1 != kKs2 && col_skip == kKs1)
@@ -2855,8 +2860,8 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     a.guard = std::max(d->min_distance, 2 * d->peak_radius[1]);
     a.guard_x = std::max(d->min_distance, 2 * d->peak_radius[2]);
     a.nq = kVariants[vi].nca + kVariants[vi].nce - 1;
-    a.prune_k[0] = a.nq / 10 != a.nq / 5 ? a.nq / 10 : 0;
-    a.prune_k[1] = a.nq / 5;
+    a.prune_k[0] = col_skip_lo(a.nq) != col_skip_hi(a.nq) ? col_skip_lo(a.nq) : 0;
+    a.prune_k[1] = col_skip_hi(a.nq);
     a.prune = same && prune_enabled() && a.n_order <= kBoundStride - 2 &&
               a.P[0] <= kBoundRows && d->threshold_rel > 0.f && d->threshold_rel <= 1.f &&
               a.guard >= 0;

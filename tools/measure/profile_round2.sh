@@ -31,5 +31,7 @@ python $R/tools/measure/fft_time.py > $O/fft_time.log 2>&1
 python $R/tools/measure/pipeline_time.py > $O/pipeline_time.log 2>&1
 python $R/tools/measure/offset_time.py > $O/offset_time.log 2>&1
 python $R/tools/measure/power_probe.py > $O/power_probe.log 2>&1
+python $R/tools/measure/prune_time.py > $O/prune_time.log 2>&1
+SFM_MFMA_PRUNE=0 timeout 600 python $R/bench.py --no-cpu-baseline > $O/bench_noprune.json 2> /dev/null
 rm -rf $O/trace/*/*.db.tmp; find $O -name '*.db' -size +20M -delete
 cat $O/pytest.log $O/bench.json; tail -3 $O/bench.err
