@@ -123,7 +123,14 @@ constexpr int kMaxTilesPerWave = 24;
 // NCC peak of 0.9+ the outer 4 qualify for most patches, the outer 3 for all.
 __host__ __device__ constexpr int col_skip_hi(int nq) { return nq / 5; }
 __host__ __device__ constexpr int col_skip_lo(int nq) { return 3 * nq / 20; }
-constexpr int kBoundStride = 32;   // dy tiles per patch with a pruning bound
+__host__ __device__ constexpr int col_skip_2(int nq) { return nq / 4; }       // per-row-tile
+__host__ __device__ constexpr int col_skip_3(int nq) { return 3 * nq / 10; }  // variants
+// tbound layout per patch: [0, 30) row tiles; [30], [31] outer col_skip_lo / _hi column
+// tiles (any dy); [32 + 3 p + j] row tile p with the outer col_skip_hi / _2 / _3 column
+// tiles (2-D bound from 16 x 16 block energies)
+constexpr int kBoundStride = 128;
+constexpr int kBoundTiles = 30;    // dy tiles per patch with a pruning bound
+constexpr int kBlkRows = 16, kBlkCols = 12;  // 16 x 16 pixel blocks of a patch (<= 256 x 192)
 constexpr int kBoundRows = 256;    // patch rows the prep kernel keeps energies for
 
 struct PatchParams {  // written by the prep kernel, one per patch
@@ -211,7 +218,7 @@ struct MfmaArgs {
   int prune;
   int guard, guard_x;
   int nq;             // column tiles of the kernel variant
-  int prune_k[2];     // outer column tiles (each side) of the row-loop variants
+  int prune_k[4];     // outer column tiles (each side) of the row-loop variants (ascending)
 };
 
 __device__ __forceinline__ unsigned load_u32_guarded(const unsigned* base,
@@ -371,9 +378,12 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   int (*red)[3][kPrepThreads] = reinterpret_cast<int (*)[3][kPrepThreads]>(&band_tot[0][0][0]);
   // pruning bounds: per-row sum and sum of squares of the raw pixels, later the
   // prefix sums of the row energies (doubles, aliased)
-  __shared__ int row_sum[2][kBoundRows], row_sq[2][kBoundRows];
+  // (sum in the low, sum of squares in the high word: one 64-bit LDS atomic per item)
+  __shared__ unsigned long long row_acc[2][kBoundRows];
   __shared__ double row_pre[2][kBoundRows + 1];
   __shared__ int col_sq[2][64 * kPrepCols];  // column sums of squares (post: mirrored)
+  // sums / sums of squares per 16 x 16 block, later their 2-D prefix sums (in place)
+  __shared__ unsigned long long blk_acc[2][kBlkRows][kBlkCols];  // packed like row_acc
   const int b = blockIdx.x;
   const int py = a.P[0], px = a.P[1];
   const int lane = threadIdx.x & 63;
@@ -381,10 +391,12 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   unsigned char* pix[2] = {smem, smem + ((py * px + 15) & ~15)};
   if (a.prune) {
     for (int i = threadIdx.x; i < 2 * kBoundRows; i += kPrepThreads) {
-      (&row_sum[0][0])[i] = 0;
-      (&row_sq[0][0])[i] = 0;
+      (&row_acc[0][0])[i] = 0;
     }
     for (int i = threadIdx.x; i < 2 * 64 * kPrepCols; i += kPrepThreads) (&col_sq[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 2 * kBlkRows * kBlkCols; i += kPrepThreads) {
+      (&blk_acc[0][0][0])[i] = 0;
+    }
     __syncthreads();
   }
 #ifdef SFM_MFMA_TIMING
@@ -452,8 +464,11 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
         }
         sum[s] += isum;
         if (a.prune) {
-          atomicAdd(&row_sum[s][y], isum);
-          atomicAdd(&row_sq[s][y], isq);
+          const unsigned long long both =
+              (static_cast<unsigned long long>(static_cast<unsigned>(isq)) << 32) |
+              static_cast<unsigned>(isum);
+          atomicAdd(&row_acc[s][y], both);
+          atomicAdd(&blk_acc[s][y >> 4][ch], both);
         }
       }
   }
@@ -518,8 +533,8 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
       const int y = 4 * lane + k;
       e[k] = 0.0;
       if (y < py)
-        e[k] = fmax(static_cast<double>(row_sq[s][y]) -
-                        2.0 * mu * static_cast<double>(row_sum[s][y]) + mu * mu * px,
+        e[k] = fmax(static_cast<double>(row_acc[s][y] >> 32) -
+                        2.0 * mu * static_cast<double>(row_acc[s][y] & 0xffffffffull) + mu * mu * px,
                     0.0);
       tot += e[k];
       e[k] = tot;  // inclusive within the lane
@@ -536,6 +551,34 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
     for (int k = 0; k < 4; ++k) {
       const int y = 4 * lane + k;
       if (y < py) row_pre[s][y + 1] = excl + e[k];
+    }
+  }
+  if (a.prune && wave == 2) {
+    // inclusive 2-D prefix sums of the four block tables, in place (exact
+    // integers; one wave: rows first, then columns)
+    // (both fields at once: neither prefix overflows its 32 bits)
+    if (lane < 2 * kBlkRows) {  // a lane reads its whole row (loads in flight together)
+      const int s = lane >> 4, r = lane & 15;
+      unsigned long long v[kBlkCols];
+#pragma unroll
+      for (int c = 0; c < kBlkCols; ++c) v[c] = blk_acc[s][r][c];
+#pragma unroll
+      for (int c = 1; c < kBlkCols; ++c) v[c] += v[c - 1];
+#pragma unroll
+      for (int c = 0; c < kBlkCols; ++c) blk_acc[s][r][c] = v[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 32 && (lane & 15) < kBlkCols) {
+      const int s = lane >> 4, c = lane & 15;
+      unsigned long long v[kBlkRows];
+#pragma unroll
+      for (int r = 0; r < kBlkRows; ++r) v[r] = blk_acc[s][r][c];
+#pragma unroll
+      for (int r = 1; r < kBlkRows; ++r) v[r] += v[r - 1];
+#pragma unroll
+      for (int r = 0; r < kBlkRows; ++r) blk_acc[s][r][c] = v[r];
     }
   }
 
@@ -678,7 +721,7 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
       colB[k] -= nxt_b[k];
     }
   }
-  if (a.prune && threadIdx.x < kBoundStride) {
+  if (a.prune && threadIdx.x < kBoundTiles) {
     // |surface[dy][dx]| = |sum over the overlap of (a - mean_a)(b - mean_b)|
     //   <= sqrt(E_A(rows of the overlap) E_B(rows of the overlap))     (Cauchy-Schwarz,
     // the column range only shrinks the sums), and the row sets are nested in
@@ -697,7 +740,7 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
       // margins: float rounding of the correction terms in the kernel (< 1 abs)
       bound = static_cast<float>(sqrt(fmax(ea, 0.0) * fmax(eb, 0.0)) * 1.0005 + 4.0);
     }
-    if (p < kBoundStride - 2) a.tbound[(long long)b * kBoundStride + p] = bound;
+    a.tbound[(long long)b * kBoundStride + p] = bound;
   }
   if (a.prune && wave == 1) {
     // The same along x for the outermost prune_k[j] column tiles on either side
@@ -736,17 +779,72 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
       }
       return static_cast<float>(sqrt(wave_sum(sa) * wave_sum(sb)) * 1.0005 + 4.0);
     };
-    for (int j = 0; j < 2; ++j) {
+    float c1d[4];  // 1-D bounds of the outer prune_k[j] column tiles (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
       const int ks = a.prune_k[j];
-      float bound = INFINITY;  // no such variant: never taken
-      if (ks > 0) {
+      c1d[j] = INFINITY;  // no such variant: never taken
+      if (ks > 0 && j < 2) {  // (the two widest variants rely on the 2-D bound alone)
         // nearest-to-centre columns of the outer tiles: kx = 16 ks - 1 (left),
         // kx = 16 (nq - ks) (right); dx = kx - (px - 1); widened by the guard
         const int dl = min(0, 16 * ks - px + a.guard_x);
         const int dr = max(0, 16 * (a.nq - ks) - (px - 1) - a.guard_x);
-        bound = fmaxf(bound_x(dl), bound_x(dr));
+        c1d[j] = fmaxf(bound_x(dl), bound_x(dr));
       }
-      if (lane == 0) a.tbound[(long long)b * kBoundStride + kBoundStride - 2 + j] = bound;
+    }
+    if (lane == 0) {
+      a.tbound[(long long)b * kBoundStride + kBoundTiles + 0] = c1d[0];
+      a.tbound[(long long)b * kBoundStride + kBoundTiles + 1] = c1d[1];
+    }
+    // 2-D: row tile p (rows of its guard-widened innermost shift) x the outer column
+    // tiles of prune_k[1..3], from the block energies of the covering block
+    // rectangles (rounded outwards: still an upper bound).  Lane = 2 p + side.
+    // energy about the mean of the block rectangle [r0, r1) x [c0, c1) of side s
+    auto rect_energy = [&](int s, int r0, int r1, int c0, int c1) {
+      auto at = [&](int r, int c) {
+        return (r < 0 || c < 0) ? 0ull : blk_acc[s][r][c];
+      };
+      // inclusion-exclusion, field by field
+      const unsigned long long lo_mask = 0xffffffffull;
+      const unsigned long long a11 = at(r1 - 1, c1 - 1), a01 = at(r0 - 1, c1 - 1);
+      const unsigned long long a10 = at(r1 - 1, c0 - 1), a00 = at(r0 - 1, c0 - 1);
+      const double sq = static_cast<double>(a11 >> 32) - static_cast<double>(a01 >> 32) -
+                        static_cast<double>(a10 >> 32) + static_cast<double>(a00 >> 32);
+      const double sm = static_cast<double>(a11 & lo_mask) - static_cast<double>(a01 & lo_mask) -
+                        static_cast<double>(a10 & lo_mask) + static_cast<double>(a00 & lo_mask);
+      const double cnt = static_cast<double>(min(16 * r1, py) - 16 * r0) *
+                         static_cast<double>(min(16 * c1, px) - 16 * c0);
+      const double mu = s == 0 ? mua_d : mub_d;
+      return fmax(sq - 2.0 * mu * sm + mu * mu * cnt, 0.0);
+    };
+    const int p = lane >> 1, side = lane & 1;
+    const int lo = 16 * p - (py - 1), hi = min(lo + 15, py - 1);
+    int dyy = 0;
+    if (lo > 0) dyy = max(0, lo - a.guard);
+    if (hi < 0) dyy = min(0, hi + a.guard);
+    // out[dy][dx] = sum a[yb + dy][xa] b[yb][xa - dx]
+    const int ra0 = dyy >= 0 ? dyy : 0, ra1 = dyy >= 0 ? py : py + dyy;
+    const int rb0 = dyy >= 0 ? 0 : -dyy, rb1 = dyy >= 0 ? py - dyy : py;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      const int ks = a.prune_k[j];
+      float bound = INFINITY;
+      if (ks > 0 && lo <= py - 1) {
+        const int dxx = side == 0 ? min(0, 16 * ks - px + a.guard_x)
+                                  : max(0, 16 * (a.nq - ks) - (px - 1) - a.guard_x);
+        const int ca0 = dxx >= 0 ? dxx : 0, ca1 = dxx >= 0 ? px : px + dxx;
+        const int cb0 = dxx >= 0 ? 0 : -dxx, cb1 = dxx >= 0 ? px - dxx : px;
+        double ea2 = 0.0, eb2 = 0.0;
+        if (ca1 > ca0 && ra1 > ra0)
+          ea2 = rect_energy(0, ra0 >> 4, (ra1 + 15) >> 4, ca0 >> 4, (ca1 + 15) >> 4);
+        if (cb1 > cb0 && rb1 > rb0)
+          eb2 = rect_energy(1, rb0 >> 4, (rb1 + 15) >> 4, cb0 >> 4, (cb1 + 15) >> 4);
+        bound = static_cast<float>(sqrt(ea2 * eb2) * 1.0005 + 4.0);
+      }
+      bound = fmaxf(bound, __shfl_xor(bound, 1, 64));  // left and right outer tiles
+      bound = fminf(bound, c1d[j]);
+      if (side == 0 && p < kBoundTiles)
+        a.tbound[(long long)b * kBoundStride + 32 + 3 * p + (j - 1)] = bound;
     }
   }
 #ifdef SFM_MFMA_TIMING
@@ -1927,7 +2025,13 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // the outermost kKs1 / kKs2 tiles on either side, widened by the
         // guard): the row loop below has variants that leave them out.
         const float t = a.threshold_rel * mrun;
-        col_skip = tb_lds[kBoundStride - 1] < t ? col_skip_hi(NQ) : tb_lds[kBoundStride - 2] < t ? col_skip_lo(NQ) : 0;
+        if (tb_lds[kBoundTiles + 0] < t) col_skip = col_skip_lo(NQ);
+        if (tb_lds[kBoundTiles + 1] < t) col_skip = col_skip_hi(NQ);
+        // this row tile with fewer columns still (2-D block bounds; each already
+        // capped by the 1-D column bound of its variant)
+        if (tb_lds[32 + 3 * p + 0] < t) col_skip = max(col_skip, col_skip_hi(NQ));
+        if (tb_lds[32 + 3 * p + 1] < t) col_skip = max(col_skip, col_skip_2(NQ));
+        if (tb_lds[32 + 3 * p + 2] < t) col_skip = max(col_skip, col_skip_3(NQ));
         cols_skipped += 2 * col_skip;
       }
       const int dy0 = 16 * p - (Qy - 1);
@@ -2093,9 +2197,15 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         }
         };
         constexpr int kKs1 = col_skip_lo(NQ), kKs2 = col_skip_hi(NQ);
-        if (kKs2 > 0 && col_skip == kKs2)
+        constexpr int kKs3 = col_skip_2(NQ), kKs4 = col_skip_3(NQ);
+        static_assert(kKs1 <= kKs2 && kKs2 <= kKs3 && kKs3 <= kKs4, "ascending");
+        if (kKs4 > kKs3 && col_skip == kKs4)
+          rows(std::integral_constant<int, kKs4>{});
+        else if (kKs3 > kKs2 && col_skip == kKs3)
+          rows(std::integral_constant<int, kKs3>{});
+        else if (kKs2 > kKs1 && col_skip == kKs2)
           rows(std::integral_constant<int, kKs2>{});
-        else if (kKs1 > 0 && kKs1 != kKs2 && col_skip == kKs1)
+        else if (kKs1 > 0 && col_skip == kKs1)
           rows(std::integral_constant<int, kKs1>{});
         else
           rows(std::integral_constant<int, 0>{});
@@ -2860,9 +2970,12 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     a.guard = std::max(d->min_distance, 2 * d->peak_radius[1]);
     a.guard_x = std::max(d->min_distance, 2 * d->peak_radius[2]);
     a.nq = kVariants[vi].nca + kVariants[vi].nce - 1;
-    a.prune_k[0] = col_skip_lo(a.nq) != col_skip_hi(a.nq) ? col_skip_lo(a.nq) : 0;
+    a.prune_k[0] = col_skip_lo(a.nq);
     a.prune_k[1] = col_skip_hi(a.nq);
-    a.prune = same && prune_enabled() && a.n_order <= kBoundStride - 2 &&
+    a.prune_k[2] = col_skip_2(a.nq);
+    a.prune_k[3] = col_skip_3(a.nq);
+    a.prune = same && prune_enabled() && a.n_order <= kBoundTiles &&
+              a.P[0] <= 16 * kBlkRows && a.P[1] <= 16 * kBlkCols &&
               a.P[0] <= kBoundRows && d->threshold_rel > 0.f && d->threshold_rel <= 1.f &&
               a.guard >= 0;
   }
