@@ -51,6 +51,7 @@ struct FusedPeaks {
   int* hot_count;  // zeroed with the rest of the per-batch state
   float* hot_val;
   int* hot_idx;
+  int* skipmask;   // [B] bit t: 16-row surface tile t was pruned (never stored)
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

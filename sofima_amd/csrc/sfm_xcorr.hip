@@ -583,6 +583,7 @@ struct PeakArgs {
   unsigned int* smax;        // [B] ordered bits of the surface maximum (large surfaces)
   unsigned long long* best;  // [B] packed (value, index) arg-max (large surfaces)
   float* out;              // [B, nd + 2]
+  const int* skipmask;     // [B] or NULL: 16-row tiles of the surface that were never stored
 };
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
@@ -856,7 +857,21 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
       }
     }
   } else {
-    // Candidate list overflowed (plateaus): rescan the surface.
+    // Candidate list overflowed (plateaus): rescan the surface.  Row tiles the
+    // correlation kernel pruned were never stored (all their elements are below
+    // the threshold): zeros for the sweep.
+    const int skipped = p.skipmask ? p.skipmask[b] : 0;
+    if (skipped) {
+      float* sw = const_cast<float*>(s);
+      for (int t = 0; t < 32; ++t) {
+        if (!((skipped >> t) & 1)) continue;
+        const int y1 = min(16 * t + 16, p.S[1]);
+        for (int i = threadIdx.x; i < (y1 - 16 * t) * p.S[2]; i += kBlock)
+          sw[(long long)(16 * t + i / p.S[2]) * p.pitch + i % p.S[2]] = 0.f;
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
     const float mx = surface_max(s, p, lv, li);
     for_each_peak<false>(s, p, p.threshold_rel * mx, [&](int i, float v) {
       if (((bitmap[i >> 5] >> (i & 31)) & 1u) == 0 && better(v, i, bv, bi)) {
@@ -939,6 +954,7 @@ struct PeakWs {
   unsigned int* smax;
   unsigned long long* best;
   int* hot_count;      // fused MFMA path only
+  int* skipmask;       // fused MFMA path: pruned row tiles per surface
   float* hot_val;
   int* hot_idx;
   size_t zero_from, zero_bytes;  // region that must be cleared per batch
@@ -960,6 +976,7 @@ PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn, bool hot = false,
   w.zero_is_peak = c.take<int>(batch);
   w.cand_count = c.take<int>(batch);
   w.hot_count = c.take<int>(batch);
+  w.skipmask = c.take<int>(batch);
   w.smax = c.take<unsigned int>(batch);
   w.best = c.take<unsigned long long>(batch);
   w.bitmap = c.take<unsigned int>(
@@ -993,6 +1010,7 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
   p.idx1 = w.idx1;
   p.v1 = w.v1;
   p.zero_is_peak = w.zero_is_peak;
+  p.skipmask = w.skipmask;
   p.cand_count = w.cand_count;
   p.cand_val = w.cand_val;
   p.cand_idx = w.cand_idx;
@@ -1281,6 +1299,7 @@ int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
     fp.bitmap_words = w.peaks.bitmap_words;
     fp.hot_cap = kHotCap;
     fp.hot_count = w.peaks.hot_count;
+    fp.skipmask = w.peaks.skipmask;
     fp.hot_val = w.peaks.hot_val;
     fp.hot_idx = w.peaks.hot_idx;
   }

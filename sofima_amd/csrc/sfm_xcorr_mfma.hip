@@ -130,6 +130,7 @@ __host__ __device__ constexpr int col_skip_3(int nq) { return 3 * nq / 10; }  //
 // tiles (2-D bound from 16 x 16 block energies)
 constexpr int kBoundStride = 128;
 constexpr int kBoundTiles = 30;    // dy tiles per patch with a pruning bound
+constexpr int kBoundCorr = 122;    // tbound slot: bound of the mean-correction terms
 constexpr int kBlkRows = 16, kBlkCols = 12;  // 16 x 16 pixel blocks of a patch (<= 256 x 192)
 constexpr int kBoundRows = 256;    // patch rows the prep kernel keeps energies for
 
@@ -191,6 +192,7 @@ struct MfmaArgs {
   int* hot_count;     // [B]
   float* hot_val;     // [B, hot_cap]
   int* hot_idx;       // [B, hot_cap] flat index ky * Sx + kx
+  int* skipmask;      // [B] bit p: row tile p was pruned, its surface rows are not stored
   int sx_pitch;       // padded surface: row pitch (floats) = 16 * NQ
   // raw-product mode (masked path)
   const unsigned char* mask[2];
@@ -216,6 +218,7 @@ struct MfmaArgs {
   // over tile p widened by `guard` rows (prep output; see the tile loop)
   float* tbound;      // [batch, kBoundStride]; the last two entries: outer column tiles
   int prune;
+  int probe;          // seed the running maximum from a probe block (see the kernel)
   int guard, guard_x;
   int nq;             // column tiles of the kernel variant
   int prune_k[4];     // outer column tiles (each side) of the row-loop variants (ascending)
@@ -795,6 +798,20 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
     if (lane == 0) {
       a.tbound[(long long)b * kBoundStride + kBoundTiles + 0] = c1d[0];
       a.tbound[(long long)b * kBoundStride + kBoundTiles + 1] = c1d[1];
+      // |surface - S| = |mA' SB + mB' SA - mA' mB' N| over any overlap, with
+      // |SA| <= sqrt(N sum a'^2) (a' = pixel - centre; exact integer totals from
+      // the block table): what the seed probe of the correlation kernel subtracts
+      const unsigned long long ta = blk_acc[0][(py - 1) >> 4][(px - 1) >> 4];
+      const unsigned long long tb2 = blk_acc[1][(py - 1) >> 4][(px - 1) >> 4];
+      const double nn = static_cast<double>(py) * px;
+      const double ca_d = s_c[0], cb_d = s_c[1];
+      const double e_a = fmax(static_cast<double>(ta >> 32) -
+                                  2.0 * ca_d * static_cast<double>(ta & 0xffffffffull) + ca_d * ca_d * nn, 0.0);
+      const double e_b = fmax(static_cast<double>(tb2 >> 32) -
+                                  2.0 * cb_d * static_cast<double>(tb2 & 0xffffffffull) + cb_d * cb_d * nn, 0.0);
+      const double ma = fabs(static_cast<double>(s_mu[0])), mb = fabs(static_cast<double>(s_mu[1]));
+      a.tbound[(long long)b * kBoundStride + kBoundCorr] = static_cast<float>(
+          (ma * sqrt(nn * e_b) + mb * sqrt(nn * e_a) + ma * mb * nn) * 1.001 + 8.0);
     }
     // 2-D: row tile p (rows of its guard-widened innermost shift) x the outer column
     // tiles of prune_k[1..3], from the block energies of the covering block
@@ -1708,7 +1725,9 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
     } else {
       // Hot list overflowed (flat surfaces): sweep the stored surface.
       const int n4 = (Sx + 3) >> 2;
+      const int skipped = a.skipmask ? a.skipmask[b] : 0;  // pruned row tiles: not stored
       for (int y = wave; y < Sy; y += kWaves) {
+        if ((skipped >> (y >> 4)) & 1) continue;
         const float* row = surf + (long long)y * pitch;
         for (int c4 = lane; c4 < n4; c4 += 64) {
           const float4 q4 = *reinterpret_cast<const float4*>(row + 4 * c4);
@@ -1801,6 +1820,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   constexpr int NQ = NCA + NCE - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float touch_junk[kThreads];  // sink of the LDS-direct G touches
+  __shared__ int probe_lds[kThreads];     // K-split sums of the seed probe (a.prune)
   unsigned char* A_lds = smem;
   unsigned char* B_lds = smem + a.a_bytes;
   float* R_lds = reinterpret_cast<float*>(smem + a.a_bytes + a.b_bytes);
@@ -1808,6 +1828,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   int* pmax_lds = reinterpret_cast<int*>(smem + a.a_bytes + a.b_bytes + a.r_bytes);
   int* hot_lds = pmax_lds + 1;  // hot-list fill count of the current patch
   float* tb_lds = reinterpret_cast<float*>(pmax_lds + 4);  // pruning bounds (a.prune)
+  // (row tile << 8 | column tile) that held the maximum of the previous patch of
+  // this workgroup: where the next patch is probed first
+  int* best_lds = reinterpret_cast<int*>(tb_lds + kBoundStride);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -1819,6 +1842,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   for (int i = threadIdx.x * 16; i < a.a_bytes + a.b_bytes; i += kThreads * 16)
     *reinterpret_cast<v4i*>(smem + i) = v4i{0, 0, 0, 0};
 
+  if (SAME && a.prune && threadIdx.x == 0)
+    *best_lds = (((a.Q[0] - 1) / 16) << 8) | ((a.Q[1] - 1) / 16);  // the zero shift
   const long long bytes0 = (long long)a.ishape[0][0] * a.ishape[0][1];
   const long long bytes1 = (long long)a.ishape[1][0] * a.ishape[1][1];
   const int cq0 = NCE - 1;
@@ -1909,6 +1934,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       *pmax_lds = 0;  // float bits of max(surface, 0)
       *hot_lds = 0;
       pmax_lds[3] = 0;  // tile counter of this patch
+      if (SAME && a.prune) best_lds[1] = 0;  // row tiles pruned in this patch
     }
     if (SAME) {
 #pragma unroll
@@ -1917,12 +1943,82 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         if (i < 4 * a.aux_n) R_lds[i] = auxv[k];
       }
       if (a.prune && threadIdx.x < kBoundStride) tb_lds[threadIdx.x] = tbv;
+      if (a.prune) probe_lds[threadIdx.x] = 0;
       const float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
       for (int i = threadIdx.x + kAuxRegs * kThreads; i < 4 * a.aux_n; i += kThreads)
         R_lds[i] = aux[i];
     }
     TICK(9)
     __syncthreads();
+
+    if (SAME && a.prune && (a.probe & 1)) {
+      // Seed of the running maximum.  The first tiles are drawn before any tile
+      // has finished, i.e. with nothing to prune against.  So the 16 x 16 block of
+      // shifts that held the previous patch's maximum is evaluated first, its
+      // patch rows split over the four waves (exact integer sums S, the same
+      // fragments the row loop would use), summed through LDS atomics, and
+      //   max(surface) >= max(S over the block) - |correction|max =: m_lo
+      // (tbound[kBoundCorr], prep kernel) goes into the running maximum.  m_lo is
+      // strictly below a real element, so the final maximum is unaffected.
+      const int pq = __builtin_amdgcn_readfirstlane(*best_lds);
+      const int ps = pq >> 8, qs = pq & 255;
+      const int pdy0 = 16 * ps - (Qy - 1);
+      const int pylo = max(0, -pdy0 - 15), pyhi = min(Qy, Py - pdy0);
+      const unsigned char* pap = A_lds + (kPadTop + pylo + g + pdy0 + n) * a.pa;
+      const unsigned char* pbp = B_lds + (pylo + g) * a.pb + (pos0 & ~3);
+      // two row groups per trip: their loads are in flight together and they
+      // accumulate into separate registers (no dependent MFMA chain of 2 NCA)
+      v4i pacc = v4i{0, 0, 0, 0}, pacc2 = v4i{0, 0, 0, 0};
+      const int n_grp = (pyhi - pylo + 3) >> 2;
+      auto load_group = [&](int grp, v4i* paf, unsigned (*pd)[5]) {
+        const int gc = min(grp, n_grp - 1);  // (a group past the end: loaded, then zeroed)
+        const unsigned char* ag = pap + 4 * gc * a.pa;
+        const unsigned char* bg = pbp + 4 * gc * a.pb;
+#pragma unroll
+        for (int ca = 0; ca < NCA; ++ca) {
+          // pair (ca, c) lies on the diagonal of column tile qs iff 0 <= c < NCE;
+          // others read a clamped fragment against a zeroed one (branch-free)
+          const int c = min(max(ca - qs + cq0, 0), NCE - 1);
+          paf[ca] = *reinterpret_cast<const v4i*>(ag + 16 * ca);
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            pd[ca][k] = *reinterpret_cast<const unsigned*>(bg + 16 * c + 4 * k);
+        }
+      };
+      auto mma_group = [&](int grp, const v4i* paf, const unsigned (*pd)[5], v4i& acc_out) {
+#pragma unroll
+        for (int ca = 0; ca < NCA; ++ca) {
+          const int c = ca - qs + cq0;
+          const bool on = c >= 0 && c < NCE && grp < n_grp;
+          v4i af = paf[ca], bf;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            af[k] = on ? af[k] : 0;
+            bf[k] = static_cast<int>(__builtin_amdgcn_alignbyte(pd[ca][k + 1], pd[ca][k], sh));
+          }
+          acc_out = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc_out, 0, 0, 0);
+        }
+      };
+      for (int grp = wave; grp < n_grp; grp += 2 * kWaves) {
+        v4i paf[NCA], paf2[NCA];
+        unsigned pd[NCA][5], pd2[NCA][5];
+        load_group(grp, paf, pd);
+        load_group(grp + kWaves, paf2, pd2);
+        mma_group(grp, paf, pd, pacc);
+        mma_group(grp + kWaves, paf2, pd2, pacc2);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pacc[r] += pacc2[r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&probe_lds[r * 64 + lane], pacc[r]);
+      __syncthreads();
+      int sm = max(max(probe_lds[lane], probe_lds[64 + lane]),
+                   max(probe_lds[128 + lane], probe_lds[192 + lane]));
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) sm = max(sm, __shfl_xor(sm, d, 64));
+      const float m_lo = __int2float_rd(sm) - tb_lds[kBoundCorr];
+      if (lane == 0 && m_lo > 0.f) atomicMax(pmax_lds, __float_as_int(m_lo));
+    }
 
     TICK(1)
     const float mua = pp.mu[0], mub = pp.mu[1];
@@ -2006,19 +2102,15 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // running maximum, which never exceeds the final one), none of them is
         // the maximum, a peak candidate, inside a candidate's max-filter window
         // or inside the first peak's sharpness window: the tile is never read
-        // for its values.  It is stored as zeros (the fallback sweeps of the peak
-        // kernels read whole surfaces; zeros are below every threshold too).
+        // for its values.  It is not stored at all; the overflow fall-backs of the
+        // peak kernels, which sweep whole surfaces, get the set of pruned tiles
+        // (a.skipmask) and skip / zero them.
         const float mrun = __int_as_float(__builtin_amdgcn_readfirstlane(
             *const_cast<volatile int*>(pmax_lds)));
         ++tiles_drawn;
         if (tb_lds[p] < a.threshold_rel * mrun) {
           ++tiles_skipped;
-          float* t0 = surf + (long long)16 * p * a.sx_pitch + 4 * lane;
-          typedef float v4f __attribute__((ext_vector_type(4)));
-          const v4f z4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            __builtin_nontemporal_store(z4, reinterpret_cast<v4f*>(t0 + 256 * q));
+          if (lane == 0) atomicOr(&best_lds[1], 1 << p);
           continue;
         }
         // Along x the same argument holds for the outer column tiles (bounds of
@@ -2540,6 +2632,18 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // nothing that matters is dropped.
         const float mrun = fmaxf(tmax, __int_as_float(prev_bits));
         const float thr_t = a.threshold_rel * mrun;
+        if (SAME && a.prune && tmax > __int_as_float(prev_bits)) {
+          // new running maximum (rare): remember its column tile for the seed
+          // probe of the next patch
+          int qbest = 0;
+#pragma unroll
+          for (int q = NQ - 1; q >= 0; --q) {
+            const float vm = fmaxf(fmaxf(__int_as_float(acc[q][0]), __int_as_float(acc[q][1])),
+                                   fmaxf(__int_as_float(acc[q][2]), __int_as_float(acc[q][3])));
+            if (__any(vm == tmax)) qbest = q;
+          }
+          if (lane == 0) *best_lds = (p << 8) | qbest;
+        }
         float* hv = a.hot_val + (long long)b * a.hot_cap;
         int* hi = a.hot_idx + (long long)b * a.hot_cap;
         // tmax is the wave-wide tile maximum: nothing to do unless it clears
@@ -2576,6 +2680,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       if (threadIdx.x == 0) {
         a.v1[b] = __int_as_float(*pmax_lds);
         a.hot_count[b] = *hot_lds;
+        if (SAME && a.prune) a.skipmask[b] = best_lds[1];
       }
     }
     TICK(6)
@@ -2965,6 +3070,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     a.hot_count = fp->hot_count;
     a.hot_val = fp->hot_val;
     a.hot_idx = fp->hot_idx;
+    a.skipmask = fp->skipmask;
     // exact pruning of dy tiles that cannot matter to the peak statistics
     a.tbound = w.tbound;
     a.guard = std::max(d->min_distance, 2 * d->peak_radius[1]);
@@ -2974,6 +3080,10 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     a.prune_k[1] = col_skip_hi(a.nq);
     a.prune_k[2] = col_skip_2(a.nq);
     a.prune_k[3] = col_skip_3(a.nq);
+    {
+      const char* e = std::getenv("SFM_MFMA_PROBE");  // "0": no seed probe
+      a.probe = !(e && e[0] == '0');
+    }
     a.prune = same && prune_enabled() && a.n_order <= kBoundTiles &&
               a.P[0] <= 16 * kBlkRows && a.P[1] <= 16 * kBlkCols &&
               a.P[0] <= kBoundRows && d->threshold_rel > 0.f && d->threshold_rel <= 1.f &&
@@ -3004,7 +3114,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   r_bytes = std::max(r_bytes, (size_t)kThreads * 8);
   r_bytes = (r_bytes + 15) / 16 * 16;
   a.r_bytes = static_cast<int>(r_bytes);
-  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride;
+  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 16;
   const int grid = d->batch;  // capped to the resident workgroups in launch_one
   const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
   if (int rc = launch_mode(vi, a, same ? (exact ? kModeSameExact : kModeSame) : kModeGeneral,

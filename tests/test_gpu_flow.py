@@ -928,6 +928,16 @@ def _prune_images(kind, seed, h, w):
     pre = np.clip(tex + rng.normal(0, 6, tex.shape), 0, 255).astype(np.uint8)
     post = np.clip(np.roll(tex, (4, -7), (0, 1)) + rng.normal(0, 6, tex.shape), 0, 255)
     return pre, post.astype(np.uint8)
+  if kind == 'smooth':        # broad peak: thousands of elements above half the
+    base = ndimage.gaussian_filter(rng.standard_normal((h + 40, w + 40)), 14.0)  # maximum
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+    return base[20:20 + h, 20:20 + w].copy(), base[24:24 + h, 13:13 + w].copy()
+  if kind == 'fine':          # period-3 lattice: thousands of local maxima above half
+    yy, xx = np.mgrid[:h, :w]
+    tex = 128 + 100 * np.sin(2 * np.pi * yy / 3.0) * np.sin(2 * np.pi * xx / 3.0)
+    pre = np.clip(tex + rng.normal(0, 3, tex.shape), 0, 255).astype(np.uint8)
+    post = np.clip(np.roll(tex, (1, 2), (0, 1)) + rng.normal(0, 3, tex.shape), 0, 255)
+    return pre, post.astype(np.uint8)
   if kind == 'noise':         # unrelated images: low, scattered maxima, little pruning
     return (rng.integers(0, 256, (h, w)).astype(np.uint8),
             rng.integers(0, 256, (h, w)).astype(np.uint8))
@@ -941,7 +951,7 @@ def _prune_images(kind, seed, h, w):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kind', ['em', 'far', 'periodic', 'noise', 'edges'])
+@pytest.mark.parametrize('kind', ['em', 'far', 'periodic', 'noise', 'edges', 'smooth', 'fine'])
 def test_pruned_correlation_tiles_are_bit_identical(gpu, monkeypatch, kind):
   """The fused-peaks kernel skips dy tiles whose Cauchy-Schwarz bound is below
   threshold_rel x the running maximum: results equal the un-pruned run bit for
@@ -965,6 +975,10 @@ def test_pruned_correlation_tiles_are_bit_identical(gpu, monkeypatch, kind):
       full = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
       monkeypatch.delenv('SFM_MFMA_PRUNE')
       np.testing.assert_array_equal(pruned, full)
-      if (py, px) == (96, 96):
+      if (py, px) == (96, 96) or kind in ('smooth', 'fine'):
+        # (the hot-list / candidate overflow fall-backs sweep surfaces with
+        # pruned, never stored tiles: 'smooth' and 'fine' take them)
         ref = flow_field.batched_xcorr_peaks(*args, method=1, **kw)
+        np.testing.assert_array_equal(np.isnan(pruned), np.isnan(ref))
         np.testing.assert_array_equal(pruned[:, :2], ref[:, :2])
+        np.testing.assert_allclose(pruned[:, 3], ref[:, 3], rtol=1e-3, atol=1e-6)
