@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 2
+#define SFM_ABI_VERSION 3   /* 3: SfmProfile carries the pruning tile counts */
 
 #define SFM_OK 0
 #define SFM_ERR_INVALID (-1)     /* bad argument / unsupported combination */
