@@ -1970,42 +1970,44 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       // accumulate into separate registers (no dependent MFMA chain of 2 NCA)
       v4i pacc = v4i{0, 0, 0, 0}, pacc2 = v4i{0, 0, 0, 0};
       const int n_grp = (pyhi - pylo + 3) >> 2;
-      auto load_group = [&](int grp, v4i* paf, unsigned (*pd)[5]) {
-        const int gc = min(grp, n_grp - 1);  // (a group past the end: loaded, then zeroed)
-        const unsigned char* ag = pap + 4 * gc * a.pa;
-        const unsigned char* bg = pbp + 4 * gc * a.pb;
+      // The pairs (ca, c) on the diagonal of column tile qs are ca = ca_lo + i,
+      // c = c_lo + i, i < n_on: contiguous A chunks against a contiguous run of B
+      // dwords (4 n_on + 1, shared between neighbouring fragments like in the row
+      // loop).  Pairs past n_on, and groups past the tile, read A from a zero
+      // padding row instead (branch-free).
+      const int ca_lo = max(0, qs - cq0), c_lo = ca_lo - qs + cq0;
+      const int n_on = min(NCA - ca_lo, NCE - c_lo);
+      const unsigned char* zero_row = A_lds + n * a.pa;  // inside the top padding
+      constexpr int kPD = 4 * NCA + 1;
+      auto load_group = [&](int grp, v4i* paf, unsigned* pd) {
+        const bool live = grp < n_grp;
+        const int gc = min(grp, n_grp - 1);
+        const unsigned char* ag = pap + 4 * gc * a.pa + 16 * ca_lo;
+        const unsigned char* bg = pbp + 4 * gc * a.pb + 16 * c_lo;
 #pragma unroll
-        for (int ca = 0; ca < NCA; ++ca) {
-          // pair (ca, c) lies on the diagonal of column tile qs iff 0 <= c < NCE;
-          // others read a clamped fragment against a zeroed one (branch-free)
-          const int c = min(max(ca - qs + cq0, 0), NCE - 1);
-          paf[ca] = *reinterpret_cast<const v4i*>(ag + 16 * ca);
+        for (int i = 0; i < NCA; ++i)
+          paf[i] = *reinterpret_cast<const v4i*>((live && i < n_on) ? ag + 16 * i : zero_row);
 #pragma unroll
-          for (int k = 0; k < 5; ++k)
-            pd[ca][k] = *reinterpret_cast<const unsigned*>(bg + 16 * c + 4 * k);
-        }
+        for (int j = 0; j < kPD; ++j) pd[j] = *reinterpret_cast<const unsigned*>(bg + 4 * j);
       };
-      auto mma_group = [&](int grp, const v4i* paf, const unsigned (*pd)[5], v4i& acc_out) {
+      auto mma_group = [&](const v4i* paf, const unsigned* pd, v4i& acc_out) {
 #pragma unroll
-        for (int ca = 0; ca < NCA; ++ca) {
-          const int c = ca - qs + cq0;
-          const bool on = c >= 0 && c < NCE && grp < n_grp;
-          v4i af = paf[ca], bf;
+        for (int i = 0; i < NCA; ++i) {
+          v4i bf;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            af[k] = on ? af[k] : 0;
-            bf[k] = static_cast<int>(__builtin_amdgcn_alignbyte(pd[ca][k + 1], pd[ca][k], sh));
-          }
-          acc_out = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc_out, 0, 0, 0);
+          for (int k = 0; k < 4; ++k)
+            bf[k] = static_cast<int>(
+                __builtin_amdgcn_alignbyte(pd[4 * i + k + 1], pd[4 * i + k], sh));
+          acc_out = __builtin_amdgcn_mfma_i32_16x16x64_i8(paf[i], bf, acc_out, 0, 0, 0);
         }
       };
       for (int grp = wave; grp < n_grp; grp += 2 * kWaves) {
         v4i paf[NCA], paf2[NCA];
-        unsigned pd[NCA][5], pd2[NCA][5];
+        unsigned pd[kPD], pd2[kPD];
         load_group(grp, paf, pd);
         load_group(grp + kWaves, paf2, pd2);
-        mma_group(grp, paf, pd, pacc);
-        mma_group(grp + kWaves, paf2, pd2, pacc2);
+        mma_group(paf, pd, pacc);
+        mma_group(paf2, pd2, pacc2);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) pacc[r] += pacc2[r];
