@@ -1842,8 +1842,11 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   for (int i = threadIdx.x * 16; i < a.a_bytes + a.b_bytes; i += kThreads * 16)
     *reinterpret_cast<v4i*>(smem + i) = v4i{0, 0, 0, 0};
 
-  if (SAME && a.prune && threadIdx.x == 0)
+  if (SAME && a.prune && threadIdx.x == 0) {
     *best_lds = (((a.Q[0] - 1) / 16) << 8) | ((a.Q[1] - 1) / 16);  // the zero shift
+    best_lds[2] = 1;  // pruning events of the previous patch (optimistic start)
+    best_lds[3] = 0;  // patches of this workgroup so far
+  }
   const long long bytes0 = (long long)a.ishape[0][0] * a.ishape[0][1];
   const long long bytes1 = (long long)a.ishape[1][0] * a.ishape[1][1];
   const int cq0 = NCE - 1;
@@ -1934,7 +1937,16 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       *pmax_lds = 0;  // float bits of max(surface, 0)
       *hot_lds = 0;
       pmax_lds[3] = 0;  // tile counter of this patch
-      if (SAME && a.prune) best_lds[1] = 0;  // row tiles pruned in this patch
+      if (SAME && a.prune) {
+        best_lds[1] = 0;  // row tiles pruned in this patch
+        // The seed probe pays only where something gets pruned: it runs if the
+        // previous patch of this workgroup pruned anything, and every eighth
+        // patch regardless (to notice when the data improve).
+        const int n_done = best_lds[3];
+        best_lds[3] = n_done + 1;
+        best_lds[4] = (best_lds[2] > 0 || (n_done & 7) == 0) ? 1 : 0;
+        best_lds[2] = 0;
+      }
     }
     if (SAME) {
 #pragma unroll
@@ -1951,7 +1963,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     TICK(9)
     __syncthreads();
 
-    if (SAME && a.prune && (a.probe & 1)) {
+    if (SAME && a.prune && (a.probe & 1) && __builtin_amdgcn_readfirstlane(best_lds[4])) {
       // Seed of the running maximum.  The first tiles are drawn before any tile
       // has finished, i.e. with nothing to prune against.  So the 16 x 16 block of
       // shifts that held the previous patch's maximum is evaluated first, its
@@ -2112,7 +2124,10 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         ++tiles_drawn;
         if (tb_lds[p] < a.threshold_rel * mrun) {
           ++tiles_skipped;
-          if (lane == 0) atomicOr(&best_lds[1], 1 << p);
+          if (lane == 0) {
+            atomicOr(&best_lds[1], 1 << p);
+            best_lds[2] = 1;  // (benign race: any non-zero value)
+          }
           continue;
         }
         // Along x the same argument holds for the outer column tiles (bounds of
@@ -2127,6 +2142,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         if (tb_lds[32 + 3 * p + 1] < t) col_skip = max(col_skip, col_skip_2(NQ));
         if (tb_lds[32 + 3 * p + 2] < t) col_skip = max(col_skip, col_skip_3(NQ));
         cols_skipped += 2 * col_skip;
+        if (col_skip > 0 && lane == 0) best_lds[2] = 1;
       }
       const int dy0 = 16 * p - (Qy - 1);
       const int ylo = max(0, -dy0 - 15);
@@ -3116,7 +3132,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   r_bytes = std::max(r_bytes, (size_t)kThreads * 8);
   r_bytes = (r_bytes + 15) / 16 * 16;
   a.r_bytes = static_cast<int>(r_bytes);
-  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 16;
+  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 32;
   const int grid = d->batch;  // capped to the resident workgroups in launch_one
   const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
   if (int rc = launch_mode(vi, a, same ? (exact ? kModeSameExact : kModeSame) : kModeGeneral,
