@@ -9,8 +9,11 @@
  *
  * Conventions
  *   - plain C types only; every buffer is CALLER-OWNED device memory (HIP
- *     pointers, e.g. torch.Tensor.data_ptr()); the library never allocates or
- *     frees device memory -- scratch space is passed in as `workspace`;
+ *     pointers, e.g. torch.Tensor.data_ptr()); the library never frees or
+ *     keeps caller memory, and scratch space is passed in as `workspace`.  The
+ *     only device memory it owns: hipFFT plan work areas (FFT form of 2-D
+ *     float / wide patches) and the twiddle tables of the hand-written FFT
+ *     (<= 2 KB per transform length and device), cached for the process;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
  *     the default stream).  Entry points do not synchronise unless stated;
  *   - return 0 on success, a negative SFM_ERR_* otherwise; the message is in
