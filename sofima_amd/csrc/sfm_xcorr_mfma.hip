@@ -1828,8 +1828,11 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   int* pmax_lds = reinterpret_cast<int*>(smem + a.a_bytes + a.b_bytes + a.r_bytes);
   int* hot_lds = pmax_lds + 1;  // hot-list fill count of the current patch
   float* tb_lds = reinterpret_cast<float*>(pmax_lds + 4);  // pruning bounds (a.prune)
-  // (row tile << 8 | column tile) that held the maximum of the previous patch of
-  // this workgroup: where the next patch is probed first
+  // Pruning state of the workgroup, behind the bounds:
+  //   [0] (row tile << 8 | column tile) that held the maximum of the previous patch:
+  //       where the next patch is probed first
+  //   [1] bit mask of the row tiles pruned in the current patch
+  //   [2] anything pruned in the current patch?  [3] patches done  [4] probe this patch?
   int* best_lds = reinterpret_cast<int*>(tb_lds + kBoundStride);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1963,7 +1966,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     TICK(9)
     __syncthreads();
 
-    if (SAME && a.prune && (a.probe & 1) && __builtin_amdgcn_readfirstlane(best_lds[4])) {
+    if (SAME && a.prune && a.probe && __builtin_amdgcn_readfirstlane(best_lds[4])) {
       // Seed of the running maximum.  The first tiles are drawn before any tile
       // has finished, i.e. with nothing to prune against.  So the 16 x 16 block of
       // shifts that held the previous patch's maximum is evaluated first, its
