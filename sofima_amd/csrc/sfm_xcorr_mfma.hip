@@ -1375,8 +1375,18 @@ __device__ __forceinline__ void masked_phase_rows(const MaskedFastArgs& g, int b
   // assembled, and the product surfaces of a row are requested together.
   int thi[kTabs ? kTabs : 1][kTabCols], tlo[kTabs ? kTabs : 1][kTabCols];
   const int row_base = (row_block * kWaves + wave) * kAsmRowsPerWave;
+  // FINAL: a surface row whose largest possible overlap, ny * Qx, is below the
+  // overlap threshold (flow_field.py:151-155) is zero whatever its terms are
+  // (overlap <= ny * Qx for every class): nothing is loaded or assembled for it.
+  // With a clean patch in the batch the threshold is 0.3 Py Px: 30 % of the rows.
+  auto dead_row = [&](int ky) {
+    if (!FINAL) return false;
+    const int dy = ky - (Qy - 1);
+    const int ny = min(Py, Qy + dy) - max(0, dy);
+    return static_cast<float>(ny * Qx) < px_thr;
+  };
   auto fetch_tables = [&](int ky) {
-    if (ky >= Sy) return;
+    if (ky >= Sy || dead_row(ky)) return;
     const int dy = ky - (Qy - 1);
     const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
 #pragma unroll
@@ -1399,7 +1409,7 @@ __device__ __forceinline__ void masked_phase_rows(const MaskedFastArgs& g, int b
   // product surfaces: row r of the current surface row, also one row ahead
   int rv[kRaw][kOutCols];
   auto fetch_raw = [&](int ky) {
-    if (ky >= Sy) return;
+    if (ky >= Sy || dead_row(ky)) return;
     const long long row = (long long)ky * g.pitch;
 #pragma unroll
     for (int c = 0; c < kOutCols; ++c) {
@@ -1420,9 +1430,10 @@ __device__ __forceinline__ void masked_phase_rows(const MaskedFastArgs& g, int b
     const int dy = ky - (Qy - 1);
     const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
     const int ny = ya1 - ya0;
+    const bool dead = row_ok && dead_row(ky);
     if (kTabs) {
       __syncthreads();  // previous row's arrays consumed
-      if (row_ok) {
+      if (row_ok && !dead) {
 #pragma unroll
         for (int k = 0; k < kTabCols; ++k) {
           const int x = lane + 64 * k + 1;
@@ -1443,6 +1454,16 @@ __device__ __forceinline__ void masked_phase_rows(const MaskedFastArgs& g, int b
     }
     if (!row_ok) continue;
     const long long row = (long long)ky * g.pitch;
+    if (dead) {  // (FINAL only) the whole row is zero
+      if (i + 1 < kAsmRowsPerWave) fetch_raw(ky + 1);
+#pragma unroll
+      for (int c = 0; c < kOutCols; ++c) {
+        const int kx = lane + 64 * c;
+        if (kx < Sx) g.out[(long long)b * g.elems + row + kx] = 0.f;
+      }
+      po->rmax = fmaxf(po->rmax, 0.f);
+      continue;
+    }
     // this row's products move to `cur`; the next row's loads are issued now
     int cur[kRaw][kOutCols];
 #pragma unroll
@@ -1601,11 +1622,21 @@ __global__ void __launch_bounds__(kThreads) masked_phase3_kernel(MaskedFastArgs 
   float* out = g.out + (long long)b * g.elems + e0;
   PhaseOut po = {0.f, 0.f, -INFINITY};
   v4i nxt[8];
+  // FINAL: rows whose largest possible overlap is below the overlap threshold are
+  // zero (see masked_phase_rows): their eight product rows are not read
+  auto dead_row = [&](int ky) {
+    if (!FINAL) return false;
+    const int dy = ky - (g.Q[0] - 1);
+    const int ny = min(g.P[0], g.Q[0] + dy) - max(0, dy);
+    return static_cast<float>(ny * g.Q[1]) < px_thr;
+  };
   auto fetch = [&](int f) {
+    const int fc = min(f, n4 - 1);
+    if (dead_row(static_cast<int>((e0 + 4LL * fc) / g.pitch))) return;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       if (!FINAL && q == 0) continue;  // the maxima do not involve a' * b'
-      nxt[q] = src[q][min(f, n4 - 1)];
+      nxt[q] = src[q][fc];
     }
   };
   fetch(threadIdx.x);
@@ -1617,6 +1648,11 @@ __global__ void __launch_bounds__(kThreads) masked_phase3_kernel(MaskedFastArgs 
     const long long e = e0 + 4LL * f;
     const int ky = static_cast<int>(e / g.pitch);
     const int kx0 = static_cast<int>(e - (long long)ky * g.pitch);
+    if (dead_row(ky)) {  // (rows past Sy: ny <= 0, dead as well; padding, never read)
+      *reinterpret_cast<float4*>(out + 4 * f) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ky < Sy && kx0 < Sx) po.rmax = fmaxf(po.rmax, 0.f);
+      continue;
+    }
     float v4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
