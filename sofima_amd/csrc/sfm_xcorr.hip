@@ -584,6 +584,11 @@ struct PeakArgs {
   unsigned long long* best;  // [B] packed (value, index) arg-max (large surfaces)
   float* out;              // [B, nd + 2]
   const int* skipmask;     // [B] or NULL: 16-row tiles of the surface that were never stored
+  // masked matrix-core path: rows whose largest possible overlap ny * Qx is below
+  // 0.3 x the batch maximum of the overlap are zero (flow_field.py:151-155); the
+  // large-surface sweeps leave them out
+  const unsigned int* live_ovmax;  // float bits of the batch maximum of the overlap, or NULL
+  int live_py, live_qy, live_qx;
 };
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
@@ -772,10 +777,22 @@ __device__ __forceinline__ float ord_float(unsigned o) {
 }
 
 __device__ __forceinline__ void chunk_rows(const PeakArgs& p, int* r0, int* r1) {
-  const int rows = p.S[0] * p.S[1];
+  int lo = 0, hi = p.S[0] * p.S[1];
+  if (p.live_ovmax && p.S[0] == 1) {
+    // ny(ky) rises to min(Py, Qy) and falls again: the live rows are one range
+    const float thr = 0.3f * __uint_as_float(*p.live_ovmax);
+    auto dead = [&](int ky) {
+      const int dy = ky - (p.live_qy - 1);
+      const int ny = min(p.live_py, p.live_qy + dy) - max(0, dy);
+      return static_cast<float>(ny * p.live_qx) < thr;
+    };
+    while (lo < hi && dead(lo)) ++lo;
+    while (hi > lo && dead(hi - 1)) --hi;
+  }
+  const int rows = hi - lo;
   const int per = (rows + gridDim.x - 1) / gridDim.x;
-  *r0 = min(rows, static_cast<int>(blockIdx.x) * per);
-  *r1 = min(rows, *r0 + per);
+  *r0 = lo + min(rows, static_cast<int>(blockIdx.x) * per);
+  *r1 = lo + min(rows, static_cast<int>(blockIdx.x) * per + per);
 }
 
 __global__ void __launch_bounds__(kBlock) peaks_max_kernel(PeakArgs p) {
@@ -992,8 +1009,13 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
               const float* center,
               int min_distance, float threshold_rel, const int* radius,
               float* out, hipStream_t st, bool first_pass_done = false,
-              bool smax_done = false) {
+              bool smax_done = false, const unsigned int* live_ovmax = nullptr,
+              const int* live_geo = nullptr) {
   PeakArgs p;
+  p.live_ovmax = live_ovmax;
+  p.live_py = live_geo ? live_geo[0] : 0;
+  p.live_qy = live_geo ? live_geo[1] : 0;
+  p.live_qx = live_geo ? live_geo[2] : 0;
   p.surf = surf;
   p.nd = nd;
   for (int i = 0; i < 3; ++i) {
@@ -1270,6 +1292,12 @@ int surface_one(const SfmXcorrDesc* d, const Geo& g, float* surface) {
   return compute_surface(d, g, w, surface);
 }
 
+// SFM_MASKED_DEADROWS=0: the peak sweeps of the masked path read every row.
+bool live_rows_enabled() {
+  const char* e = std::getenv("SFM_MASKED_DEADROWS");
+  return !(e && e[0] == '0');
+}
+
 int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
   XcorrWs w = carve_xcorr(d, g, true, true);
   if (!d->workspace || d->workspace_bytes < w.bytes)
@@ -1309,11 +1337,16 @@ int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
   float center[3];
   for (int i = 0; i < 3; ++i)
     center[i] = static_cast<float>((g.P[i] + g.Q[i]) / 2 - 1);
+  // masked matrix-core surfaces: rows below the overlap threshold are zeros (the
+  // assembly's second maximum, `maxima[1]`, is the batch maximum of the overlap)
+  const bool masked_mfma = use_mfma(d) && is_masked(d);
+  const int live_geo[3] = {g.P[1], g.Q[1], g.Q[2]};
   return run_peaks(w.peaks, static_cast<char*>(d->workspace), w.surface,
                    w.spitch, (long long)w.srows * w.spitch, d->ndim, g.S, g.Sn,
                    d->batch, center, d->min_distance,
                    d->threshold_rel, d->peak_radius, peaks,
-                   static_cast<hipStream_t>(d->stream), fuse, smax_pre);
+                   static_cast<hipStream_t>(d->stream), fuse, smax_pre,
+                   masked_mfma && live_rows_enabled() ? w.maxima + 1 : nullptr, live_geo);
 }
 
 }  // namespace

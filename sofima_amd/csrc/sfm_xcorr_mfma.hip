@@ -1194,6 +1194,7 @@ struct MaskedFastArgs {
   int batch;
   int xcd_map;
   int all_passes;       // test switch: every patch takes the eight passes (class 3)
+  int dead_rows;        // final phase: skip rows below the overlap threshold (SFM_MASKED_DEADROWS=0: off)
   int row_blocks;       // workgroups per surface in the assembly kernels
   unsigned int* maxima;
   float* out;           // [batch, elems] final normalised surface
@@ -1380,7 +1381,7 @@ __device__ __forceinline__ void masked_phase_rows(const MaskedFastArgs& g, int b
   // (overlap <= ny * Qx for every class): nothing is loaded or assembled for it.
   // With a clean patch in the batch the threshold is 0.3 Py Px: 30 % of the rows.
   auto dead_row = [&](int ky) {
-    if (!FINAL) return false;
+    if (!FINAL || !g.dead_rows) return false;
     const int dy = ky - (Qy - 1);
     const int ny = min(Py, Qy + dy) - max(0, dy);
     return static_cast<float>(ny * Qx) < px_thr;
@@ -1625,7 +1626,7 @@ __global__ void __launch_bounds__(kThreads) masked_phase3_kernel(MaskedFastArgs 
   // FINAL: rows whose largest possible overlap is below the overlap threshold are
   // zero (see masked_phase_rows): their eight product rows are not read
   auto dead_row = [&](int ky) {
-    if (!FINAL) return false;
+    if (!FINAL || !g.dead_rows) return false;
     const int dy = ky - (g.Q[0] - 1);
     const int ny = min(g.P[0], g.Q[0] + dy) - max(0, dy);
     return static_cast<float>(ny * g.Q[1]) < px_thr;
@@ -3243,6 +3244,10 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
   }
   g.batch = d->batch;
   g.all_passes = masked_all_passes() ? 1 : 0;
+  {
+    const char* e = std::getenv("SFM_MASKED_DEADROWS");
+    g.dead_rows = !(e && e[0] == '0');
+  }
   {
     const char* e = std::getenv("SFM_PHASE_XCD");
     g.xcd_map = !(e && e[0] == '0');
