@@ -205,6 +205,9 @@ struct MfmaArgs {
   // i < *n_list; its products go to raw_out[i]
   const int* list;
   const int* n_list;
+  // a' * b' pass of the masked path: lower bound of the batch maximum of the overlap
+  // (masked_classify_kernel); row tiles below 0.3 x it are zeroed by the overlap rule
+  const int* ov_lb;
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
   // dynamic patch queue (NULL: static striding over the workgroups)
   int* work_counter;
@@ -1237,6 +1240,23 @@ __global__ void __launch_bounds__(1024) masked_classify_kernel(MaskedFastArgs g)
     __syncthreads();
   }
   if (threadIdx.x == 0) *g.n_items = s_base;
+  // A lower bound of the batch maximum of the overlap, known before any product:
+  // at the zero shift a same-size patch pair overlaps in at least
+  // nvalid_A + nvalid_B - Py Px pixels (= Py Px for a clean pair).  The raw pass of
+  // a' * b' uses it to leave out row tiles that the overlap rule zeroes anyway.
+  int lb = 0;
+  if (g.P[0] == g.Q[0] && g.P[1] == g.Q[1])
+    for (int b = threadIdx.x; b < g.batch; b += 1024)
+      lb = max(lb, g.nvalid[2 * b] + g.nvalid[2 * b + 1] - g.P[0] * g.P[1]);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) lb = max(lb, __shfl_xor(lb, d, 64));
+  __syncthreads();
+  if (lane == 0) wsum[wave] = lb;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) lb = max(lb, wsum[w]);
+    g.n_items[1] = lb;
+  }
 }
 
 // Inclusive integral images T[y][x] = sum over rows <= y, columns <= x of the
@@ -2149,7 +2169,34 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         else
           __builtin_amdgcn_s_setprio(0);
       }
-      int col_skip = 0;  // outer column tiles (each side) this tile leaves out
+      int raw_col_skip = 0;
+      if (RAW && a.ov_lb) {
+        // largest ny = overlap rows of a shift in this tile (ny rises to min(Py, Qy)
+        // at dy in [0, Py - Qy] and falls): at the tile's row nearest that range
+        const int ky0 = 16 * p, ky1 = min(16 * p + 15, Sy - 1);
+        const int dyc = min(max(min(max(0, ky0 - (Qy - 1)), Py - Qy), ky0 - (Qy - 1)), ky1 - (Qy - 1));
+        const int ny_max = min(Py, Qy + dyc) - max(0, dyc);
+        const int lb = __builtin_amdgcn_readfirstlane(*a.ov_lb);
+        const float ov_thr = 0.3f * static_cast<float>(lb);
+        if (static_cast<float>(ny_max * Qx) < ov_thr) continue;
+        // the same along x: outer column tiles whose widest overlap nx, times
+        // ny_max, stays below the threshold are zeroed as well (row-loop variants)
+        auto cols_dead = [&](int ks) {
+          if (ks <= 0) return false;
+          auto nx_at = [&](int kx) {
+            const int dx = kx - (Qx - 1);
+            return kx < Sx ? min(Px, Qx + dx) - max(0, dx) : 0;
+          };
+          const int nx_max = max(nx_at(16 * ks - 1), nx_at(16 * (NQ - ks)));
+          return static_cast<float>(ny_max * nx_max) < ov_thr;
+        };
+        raw_col_skip = cols_dead(col_skip_3(NQ))   ? col_skip_3(NQ)
+                       : cols_dead(col_skip_2(NQ)) ? col_skip_2(NQ)
+                       : cols_dead(col_skip_hi(NQ)) ? col_skip_hi(NQ)
+                       : cols_dead(col_skip_lo(NQ)) ? col_skip_lo(NQ)
+                                                    : 0;
+      }
+      int col_skip = raw_col_skip;  // outer column tiles (each side) this tile leaves out
       if (SAME && a.prune) {
         // Exact pruning.  Every element of this tile and of the `guard` rows
         // around it is bounded by tb (prep kernel).  If tb < threshold_rel x (the
@@ -3264,7 +3311,9 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
   c.plane[0] = kMaskedPasses[0][0];
   c.plane[1] = kMaskedPasses[0][1];
   c.raw_out = w.raw0;
+  c.ov_lb = g.dead_rows ? w.n_items + 1 : nullptr;
   if (int rc = launch_mode(vi, c, kModeRaw, d->batch, lds, st)) return rc;
+  c.ov_lb = nullptr;  // the other products feed the maxima of every element
   c.raw_out = w.rawd;
   c.list = w.items;
   c.n_list = w.n_items;
