@@ -986,3 +986,44 @@ def test_pruned_correlation_tiles_are_bit_identical(gpu, monkeypatch, kind):
         np.testing.assert_array_equal(np.isnan(pruned), np.isnan(ref))
         np.testing.assert_array_equal(pruned[:, :2], ref[:, :2])
         np.testing.assert_allclose(pruned[:, 3], ref[:, 3], rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('py,px,qy,qx', [(160, 160, 160, 160), (96, 96, 96, 96),
+                                         (64, 80, 40, 64), (50, 46, 50, 46)])
+def test_masked_overlap_rule_skips_are_bit_identical(gpu, monkeypatch, py, px, qy, qx):
+  """What the reference zeroes by its overlap rule (flow_field.py:151-155) is not
+  computed: dead rows in the final assembly and in the peak sweeps, dead row /
+  column tiles in the a' * b' pass (bounded through the valid-pixel counts).
+  Surfaces and peak statistics equal the run without the skips, with a clean
+  patch in the batch (threshold 0.3 Py Px), without one, and heavily masked."""
+  from sofima_amd import flow_field
+  prev, curr, pm, cm = _masked_patch_batch(3 * py + qx, 12, py, px, qy, qx)
+  rng = np.random.default_rng(py)
+  heavy_p, heavy_c = pm.copy(), cm.copy()
+  heavy_p[:, : py // 2] = True                      # no clean patch, overlap maximum ~ half a patch
+  heavy_c[rng.random(cm.shape) < 0.3] = True
+  some_p = pm.copy()
+  some_p[::3][:, 5:9, 5:9] = True                   # no clean patch, but nearly clean ones
+  for masks in ((pm, cm), (some_p, cm), (heavy_p, heavy_c), (pm, None)):
+    full_kw = dict(mean=None)
+    fast = flow_field.masked_xcorr(prev, curr, masks[0], masks[1], **full_kw)
+    monkeypatch.setenv('SFM_MASKED_DEADROWS', '0')
+    ref = flow_field.masked_xcorr(prev, curr, masks[0], masks[1], **full_kw)
+    monkeypatch.delenv('SFM_MASKED_DEADROWS')
+    np.testing.assert_array_equal(fast, ref)
+  # whole flow fields (peaks through the live-row sweeps), production patch size
+  if (py, px) == (160, 160):
+    pre, post = _em_pair(11, 420, 470, warp=2.0)
+    m0 = np.zeros(pre.shape, bool)
+    m1 = np.zeros(pre.shape, bool)
+    m0[100:180, 200:330] = True
+    m1[rng.random(pre.shape) < 0.01] = True
+    calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+    kw = dict(batch_size=64, mask_only_for_patch_selection=False)
+    for masks in ((m0, m1), (m0, None)):
+      a = calc.flow_field(pre, post, 160, 40, pre_mask=masks[0], post_mask=masks[1], **kw)
+      monkeypatch.setenv('SFM_MASKED_DEADROWS', '0')
+      b = calc.flow_field(pre, post, 160, 40, pre_mask=masks[0], post_mask=masks[1], **kw)
+      monkeypatch.delenv('SFM_MASKED_DEADROWS')
+      np.testing.assert_array_equal(a, b)
