@@ -32,7 +32,7 @@ std::vector<Span> g_spans[2];
 std::vector<Span> g_free;
 Span g_open[2];
 struct ClockSample {
-  long long v[5];  // cycles, 10 ns ticks[, row tiles skipped, drawn, column tiles skipped]
+  long long v[4];  // cycles, 10 ns ticks[, row tiles drawn << 32 | skipped, column tiles skipped]
 };
 std::deque<ClockSample> g_clock[2];  // stable addresses: targets of async copies
 }  // namespace
@@ -64,8 +64,8 @@ void prof_end(int kind, hipStream_t st) {
 void prof_clock(int kind, const long long* dev_pair, hipStream_t st, int n) {
   if (!profiling() || !dev_pair) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_clock[kind].push_back(ClockSample{{0, 0, 0, 0, 0}});
-  (void)hipMemcpyAsync(g_clock[kind].back().v, dev_pair, sizeof(long long) * (n > 2 && n <= 5 ? n : 2),
+  g_clock[kind].push_back(ClockSample{{0, 0, 0, 0}});
+  (void)hipMemcpyAsync(g_clock[kind].back().v, dev_pair, sizeof(long long) * (n == 4 ? 4 : 2),
                        hipMemcpyDeviceToHost, st);
 }
 
@@ -100,9 +100,9 @@ int sfm_profile_read(SfmProfile* out) {
     for (auto& c : sfm::g_clock[k]) {
       cyc += c.v[0];
       ticks += c.v[1];
-      skipped += c.v[2];
-      drawn += c.v[3];
-      cols += c.v[4];
+      skipped += c.v[2] & 0xffffffffLL;
+      drawn += (c.v[2] >> 32) & 0xffffffffLL;
+      cols += c.v[3];
     }
     out->clock_mhz[k] = ticks > 0 ? static_cast<double>(cyc) * 100.0 / ticks : 0.0;
     out->tiles_skipped[k] = skipped;

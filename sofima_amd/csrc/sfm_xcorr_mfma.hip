@@ -213,14 +213,15 @@ struct MfmaArgs {
   int* work_counter;
   // shader-clock probe: workgroup 0 leaves (core cycles, 10 ns wall ticks) of its
   // residency here (bench.py reports the sustained clock under this kernel);
-  // clk[2], clk[3]: dy tiles skipped by the pruning / drawn, whole launch; clk[4]:
-  // column tiles left out of the computed dy tiles
+  // clk[2]: dy tiles skipped by the pruning (low word) / drawn (high word), whole
+  // launch; clk[3]: column tiles left out of the computed dy tiles (count_tiles)
   long long* clk;
   int prio_mode;      // experiment knob: 0 natural, 1 alternate per tile, 2 static
   // exact pruning of dy tiles (fused-peaks mode): tbound[b][p] bounds |surface|
   // over tile p widened by `guard` rows (prep output; see the tile loop)
   float* tbound;      // [batch, kBoundStride]; the last two entries: outer column tiles
   int prune;
+  int count_tiles;    // report the pruning counts through clk (timing hooks on)
   int probe;          // seed the running maximum from a probe block (see the kernel)
   int guard, guard_x;
   int nq;             // column tiles of the kernel variant
@@ -374,7 +375,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a) {
   if (a.work_counter && blockIdx.x == 0 && threadIdx.x == 0)
     *a.work_counter = 0;  // the correlation kernel's patch queue
-  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[2] = a.clk[3] = a.clk[4] = 0;  // tile counts
+  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[2] = a.clk[3] = 0;  // tile counts
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_c[2];
   __shared__ float s_mu[2];
@@ -2794,12 +2795,13 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     a.clk[0] = clock64() - probe_c0;
     a.clk[1] = wall_clock64() - probe_w0;
   }
-  if (SAME && a.prune && a.clk && lane == 0) {
+  // (only while the timing hooks are on: same-address atomics are serialised in the
+  // L2 -- three per wave cost a launch of one patch per workgroup 100 us at its end)
+  if (SAME && a.prune && a.count_tiles && a.clk && lane == 0) {
     atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 2),
-              static_cast<unsigned long long>(tiles_skipped));
+              (static_cast<unsigned long long>(tiles_drawn) << 32) |
+                  static_cast<unsigned long long>(tiles_skipped));
     atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 3),
-              static_cast<unsigned long long>(tiles_drawn));
-    atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 4),
               static_cast<unsigned long long>(cols_skipped));
   }
 #ifdef SFM_MFMA_TIMING
@@ -2949,7 +2951,7 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, MODE>), dim3(grid),
                      dim3(kThreads), lds, st, a);
   sfm::prof_end(sfm::kProfXcorr, st);
-  sfm::prof_clock(sfm::kProfXcorr, a.clk, st, 5);
+  sfm::prof_clock(sfm::kProfXcorr, a.clk, st, 4);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }
@@ -3189,6 +3191,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
       const char* e = std::getenv("SFM_MFMA_PROBE");  // "0": no seed probe
       a.probe = !(e && e[0] == '0');
     }
+    a.count_tiles = sfm::profiling() ? 1 : 0;
     a.prune = same && prune_enabled() && a.n_order <= kBoundTiles &&
               a.P[0] <= 16 * kBlkRows && a.P[1] <= 16 * kBlkCols &&
               a.P[0] <= kBoundRows && d->threshold_rel > 0.f && d->threshold_rel <= 1.f &&
