@@ -54,6 +54,14 @@ struct FusedPeaks {
   int* skipmask;   // [B] bit t: 16-row surface tile t was pruned (never stored)
 };
 
+#ifdef __HIPCC__
+// Sets bits of a shared word; most callers of a batch set the SAME bit (equal
+// first-peak indices), and same-address atomics are serialised in the L2: look first.
+__device__ __forceinline__ void set_bit_once(unsigned int* word, unsigned int bits) {
+  if ((__atomic_load_n(word, __ATOMIC_RELAXED) & bits) != bits) atomicOr(word, bits);
+}
+#endif
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Carves aligned sub-buffers out of the caller's workspace.

@@ -759,8 +759,8 @@ __global__ void __launch_bounds__(kBlock) peaks_first_kernel(PeakArgs p) {
     const int i1 = bv == -INFINITY ? 0 : bi;  // argmax of an all -inf row is 0
     p.idx1[b] = i1;
     p.v1[b] = bv;
-    atomicOr(&p.bitmap[(long long)(b / p.group) * p.bitmap_words + (i1 >> 5)],
-             1u << (i1 & 31));
+    sfm::set_bit_once(&p.bitmap[(long long)(b / p.group) * p.bitmap_words + (i1 >> 5)],
+                       1u << (i1 & 31));
   }
 }
 
@@ -841,8 +841,8 @@ __global__ void __launch_bounds__(kBlock) peaks_first_finish_kernel(PeakArgs p) 
   const int i1 = k ? static_cast<int>(0xffffffffu - static_cast<unsigned>(k)) : 0;
   p.idx1[b] = i1;
   p.v1[b] = bv;
-  atomicOr(&p.bitmap[(long long)(b / p.group) * p.bitmap_words + (i1 >> 5)],
-           1u << (i1 & 31));
+  sfm::set_bit_once(&p.bitmap[(long long)(b / p.group) * p.bitmap_words + (i1 >> 5)],
+                       1u << (i1 & 31));
 }
 
 __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {

@@ -1816,8 +1816,8 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
     const int i1 = v1 == -INFINITY ? 0 : li[0];  // argmax of an all -inf row is 0
     a.idx1[b] = i1;
     a.v1[b] = v1;
-    atomicOr(&a.bitmap[(long long)(b / a.group) * a.bitmap_words + (i1 >> 5)],
-             1u << (i1 & 31));
+    sfm::set_bit_once(&a.bitmap[(long long)(b / a.group) * a.bitmap_words + (i1 >> 5)],
+                       1u << (i1 & 31));
   }
 }
 
