@@ -6,15 +6,22 @@ pair (BASELINE.json configs[1]):
   1. flow_field(pre, post, patch 160, step 40, batch 1024)  -> [4, 201, 201]
   2. relax_mesh([2, 1, 205, 205], prev from that flow, em_2d FIRE config,
      1000 iterations)
-with the images already resident in HBM.  With --gpus N every rank processes
+with the images already resident in HBM.  The headline pair is SURVEY.md 8d's
+"realistic pair" (content shift + smooth 6 px deformation + noise); --pair
+exact selects the rigid-shift pair.  With --gpus N every rank processes
 its own independent tile pair (weak scaling, no data-path collective); the time
 is the max over ranks.
 
 Prints ONE JSON line (rank 0).  `value` is patch-xcorr Mpix/s = post-image
 pixels / wall time of flow_field(); the mesh figure is in the
 `mesh` object.  `roofline` describes the dominant kernel (the patch-correlation
-kernel), timed with HIP events inside the timed region through the library's
-sfm_profile_* hooks.  `cpu_baseline` times the CPU oracle (a NumPy/SciPy port
+kernel), timed with HIP events through the library's sfm_profile_* hooks:
+`roofline.frac` is the HARDWARE fraction -- the same kernel on the same pair
+with the exact tile pruning switched off (a second leg of the same run), so
+every algorithmic operation is executed; `frac_pruned` is the production launch
+of the timed region (algorithmic operations / time: includes the skipped work);
+`issued_frac` counts the matrix instructions the kernel really issued.  After
+the timed region the step is repeated for >= --sustain seconds (`sustained`).  `cpu_baseline` times the CPU oracle (a NumPy/SciPy port
 of the reference algorithm) on a bounded sample of the same workload.
 """
 import argparse
@@ -38,9 +45,11 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def synth_pair(size, seed, shift=(3, -5)):
-  """EM-like texture pair: low-pass noise, integer content shift + fresh
-  noise in the second image."""
+def synth_pair(size, seed, shift=(3, -5), warp=None):
+  """EM-like texture pair: low-pass noise; the second image is
+  the same content shifted by an integer vector, optionally sampled through the
+  smooth deformation d(x, y) = A sin(2 pi x / L) cos(2 pi y / L) (warp = (A, L),
+  bilinear), plus fresh sensor noise (sigma 4)."""
   from scipy import ndimage
   rng = np.random.default_rng(seed)
   m = 16
@@ -50,9 +59,22 @@ def synth_pair(size, seed, shift=(3, -5)):
   dy, dx = shift
   pre = base[m:m + size, m:m + size]
   post = base[m + dy:m + dy + size, m + dx:m + dx + size]
+  if warp is not None:
+    amp, lam = warp
+    out = np.empty((size, size), np.float32)
+    xx = np.arange(size, dtype=np.float32)[None, :]
+    for y0 in range(0, size, 1024):
+      yy = np.arange(y0, min(y0 + 1024, size), dtype=np.float32)[:, None]
+      d = amp * np.sin(2 * np.pi * xx / lam) * np.cos(2 * np.pi * yy / lam)
+      out[y0:y0 + 1024] = ndimage.map_coordinates(
+          post, [yy + d, xx - d], order=1, mode='nearest', output=np.float32)
+    post = out
   post = post + rng.standard_normal(post.shape, dtype=np.float32) * 4
   return (np.clip(pre, 0, 255).astype(np.uint8),
           np.clip(post, 0, 255).astype(np.uint8))
+
+
+WARP = (6.0, 2048.0)   # SURVEY.md 8d "realistic pair"
 
 
 def mesh_inputs(flow, pad):
@@ -60,6 +82,13 @@ def mesh_inputs(flow, pad):
   f = np.pad(flow[:2], ((0, 0), (pad, pad), (pad, pad)),
              constant_values=np.nan)
   return f[:, None].astype(np.float32)
+
+
+def build_sha():
+  try:
+    return open(os.path.join(ROOT, '.build_sha')).read().strip()
+  except OSError:
+    return None
 
 
 def main():
@@ -75,10 +104,22 @@ def main():
                   help='internal: the CPU leg, run in a child process')
   ap.add_argument('--seed', type=int, default=1002)
   ap.add_argument('--mesh-iters', type=int, default=MESH_ITERS)
+  ap.add_argument('--pair', choices=('warped', 'exact'), default='warped',
+                  help='headline pair: smooth 6 px deformation (SURVEY 8d) or the '
+                       'rigid integer shift')
+  ap.add_argument('--sustain', type=float, default=5.0,
+                  help='seconds of back-to-back steps after the timed region '
+                       '(steady-state power / clocks); 0 = off')
+  ap.add_argument('--no-legs', action='store_true',
+                  help='skip the un-pruned and other-pair roofline legs')
+  ap.add_argument('--mesh-sharded', type=int, default=0, metavar='BANDS',
+                  help='extra leg: one [2,64,204,204] mesh split into BANDS bands '
+                       'per rank, stepped by the C-side banded loop (RCCL halo '
+                       'exchange between ranks)')
   args = ap.parse_args()
 
   if args.cpu_baseline_only:
-    cpu_baseline_child(args.size, args.seed)
+    cpu_baseline_child(args.size, args.seed, args.pair)
     return
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     # `python bench.py --gpus N` without a launcher: start the N ranks here
@@ -117,7 +158,8 @@ def main():
   lib = _abi.load()
 
   size = args.size
-  pre, post = synth_pair(size, 1002 + rank)
+  warp = WARP if args.pair == 'warped' else None
+  pre, post = synth_pair(size, args.seed + rank, warp=warp)
   pre_t = torch.from_numpy(pre).to(dev)
   post_t = torch.from_numpy(post).to(dev)
   calc = flow_field.JAXMaskedXCorrWithStatsCalculator(method=args.method)
@@ -127,8 +169,9 @@ def main():
       dt_max=1000, start_cap=0.01, final_cap=10, prefer_orig_order=True)
   pad = PATCH // 2 // STEP
 
-  def flow_step():
-    return calc.flow_field(pre_t, post_t, PATCH, STEP, batch_size=BATCH)
+  def flow_step(a=None, b=None):
+    return calc.flow_field(pre_t if a is None else a, post_t if b is None else b,
+                           PATCH, STEP, batch_size=BATCH)
 
   def mesh_step(prev):
     x0 = torch.zeros(prev.shape, dtype=torch.float32, device=dev)
@@ -185,49 +228,115 @@ def main():
   mpix_s = world * pix * args.steps / t_flow / 1e6
   node_updates_s = world * mesh_nodes * mesh_steps_done / t_mesh
 
-  # Roofline of the dominant kernel: algorithmic work per launch = 2 P^4 flop
+  # Roofline of the dominant kernel: algorithmic work per launch = 2 P^4 ops
   # per patch (every pixel pair contributes to exactly one shift) x patches
-  # per launch.
+  # per launch, over the HIP-event time of the launches in the timed region.
   flop_per_patch = 2.0 * PATCH ** 4
-  xc_ms, xc_n = prof.kernel_ms[0], prof.launches[0]
-  ms_ms, ms_n = prof.kernel_ms[1], prof.launches[1]
   uses_mfma = args.method != 1 and bool(
       getattr(flow_field, 'MFMA_I8_AVAILABLE', False))
+  peak = PEAK_I8_TOPS if uses_mfma else PEAK_F32_TFLOPS
+
+  def leg_figures(pf, n_pairs):
+    """achieved / issued fractions of one measured leg (SfmProfile, pairs run)."""
+    n = int(pf.launches[0])
+    if not n:
+      return None
+    avg_ms = pf.kernel_ms[0] / n
+    ppl = n_patches * n_pairs / n
+    ach = flop_per_patch * ppl / (avg_ms * 1e-3) / 1e12
+    o = {'avg_launch_ms': round(avg_ms, 4), 'launches': n,
+         'patches_per_launch': round(ppl, 1), 'achieved': round(ach, 2),
+         'frac': round(ach / peak, 4)}
+    issued = int(pf.mfma_issued[0])
+    if issued:
+      # matrix instructions the kernel really issued (16x16x64 int8 = 32768
+      # ops each): tile padding adds to the algorithmic count, pruning removes
+      issued_ops = issued * 32768.0 / n
+      o['issued_frac'] = round(issued_ops / (avg_ms * 1e-3) / 1e12 / peak, 4)
+      o['issued_over_algorithmic'] = round(issued_ops / (flop_per_patch * ppl), 4)
+    clk = float(pf.clock_mhz[0])
+    if clk > 0:
+      o['sustained_clock_mhz'] = round(clk, 1)
+    drawn = int(pf.tiles_drawn[0])
+    if drawn:
+      o['row_tiles_skipped_frac'] = round(int(pf.tiles_skipped[0]) / drawn, 4)
+      computed = drawn - int(pf.tiles_skipped[0])
+      if computed:
+        o['col_tiles_skipped_per_row_tile'] = round(
+            int(pf.col_tiles_skipped[0]) / computed, 3)
+    return o
+
+  def timed_flow_leg(a_t, b_t, prune, n):
+    """n flow passes with the pruning on / off: (SfmProfile, wall ms / pair)."""
+    pf = _abi.SfmProfile()
+    with _abi.option('SFM_MFMA_PRUNE', 1 if prune else 0):
+      flow_step(a_t, b_t)                       # warm-up of this variant
+      torch.cuda.synchronize(dev)
+      lib.sfm_profile_read(C.byref(pf))
+      lib.sfm_profile_enable(1)
+      w0 = time.perf_counter()
+      for _ in range(n):
+        flow_step(a_t, b_t)
+      torch.cuda.synchronize(dev)
+      wall = (time.perf_counter() - w0) / n * 1e3
+      lib.sfm_profile_enable(0)
+      _abi.check(lib.sfm_profile_read(C.byref(pf)))
+    return pf, wall
+
   roof = None
-  if xc_n:
-    avg_ms = xc_ms / xc_n
-    patches_per_launch = n_patches * args.steps / xc_n
-    achieved = flop_per_patch * patches_per_launch / (avg_ms * 1e-3) / 1e12
-    peak = PEAK_I8_TOPS if uses_mfma else PEAK_F32_TFLOPS
+  timed = leg_figures(prof, args.steps)
+  if timed:
     roof = {
-        'kernel': 'xcorr_mfma_i8' if uses_mfma else 'corr_direct_kernel<f32>',
-        'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
+        'kernel': 'xcorr_mfma_kernel<10,11,same-exact>' if uses_mfma
+                  else 'corr_direct_kernel<f32>',
+        'bound': 'mfma', 'peak': peak,
         # int8 multiply-accumulates counted as 2 ops each, against the dense
         # int8 MFMA peak (the contract's unit name for a matrix-core bound)
         'unit': 'TFLOP/s', 'op_dtype': 'int8' if uses_mfma else 'f32',
-        'frac': round(achieved / peak, 4),
-        'avg_launch_ms': round(avg_ms, 4), 'launches': int(xc_n),
-        'patches_per_launch': round(patches_per_launch, 1),
         'flop_per_patch': flop_per_patch, 'traffic': None,
+        'pair': args.pair,
     }
-    clk = float(prof.clock_mhz[0])
-    if clk > 0 and uses_mfma:
-      # DVFS: the chip clocks to its power budget under this kernel; `peak` is the
-      # 2.4 GHz figure.  The matrix pipes' ceiling at the clock the kernel
-      # actually sustained, and the issued (tile-padded) fraction of it:
-      roof['sustained_clock_mhz'] = round(clk, 1)
-      roof['peak_at_sustained_clock'] = round(peak * clk / 2400.0, 1)
-      roof['frac_at_sustained_clock'] = round(achieved / (peak * clk / 2400.0), 4)
-    drawn = int(prof.tiles_drawn[0])
-    if drawn:
-      # exact pruning: surface row tiles that provably hold no peak, no
-      # candidate and no sharpness-window element are not computed (results
-      # bit-identical; SFM_MFMA_PRUNE=0 computes everything).  `achieved`
-      # counts the ALGORITHMIC 2 P^4 operations per patch either way.
-      roof['row_tiles_skipped_frac'] = round(int(prof.tiles_skipped[0]) / drawn, 4)
-      computed = drawn - int(prof.tiles_skipped[0])
-      if computed:  # of the computed row tiles: outer column tiles left out (of 20 at P=160)
-        roof['col_tiles_skipped_per_row_tile'] = round(int(prof.col_tiles_skipped[0]) / computed, 3)
+    # `achieved` / `frac` describe the HARDWARE: the same kernel on the same pair
+    # with the exact pruning switched off, i.e. every algorithmic operation
+    # really executed.  The production (pruned) launch of the timed region is
+    # `frac_pruned`: algorithmic operations over its time, an algorithmic gain.
+    roof['pruned'] = timed
+    roof['frac_pruned'] = timed['frac']
+    legs = uses_mfma and not args.no_legs and world == 1
+    if legs:
+      n_leg = max(args.steps, 3)
+      pf_full, wall_full = timed_flow_leg(pre_t, post_t, False, n_leg)
+      full = leg_figures(pf_full, n_leg)
+      full['flow_ms_per_pair'] = round(wall_full, 3)
+      roof['unpruned'] = full
+      for k in ('achieved', 'frac', 'avg_launch_ms', 'launches', 'patches_per_launch',
+                'issued_frac'):
+        if k in full:
+          roof[k] = full[k]
+      roof['frac_is'] = 'un-pruned leg of the same run (every tile computed)'
+      # the other synthetic pair, both ways
+      other = 'exact' if args.pair == 'warped' else 'warped'
+      o_pre, o_post = synth_pair(size, args.seed + rank,
+                                 warp=WARP if other == 'warped' else None)
+      o_pre_t = torch.from_numpy(o_pre).to(dev)
+      o_post_t = torch.from_numpy(o_post).to(dev)
+      pf_p, wall_p = timed_flow_leg(o_pre_t, o_post_t, True, n_leg)
+      pf_f, wall_f = timed_flow_leg(o_pre_t, o_post_t, False, n_leg)
+      op, of = leg_figures(pf_p, n_leg), leg_figures(pf_f, n_leg)
+      op['flow_ms_per_pair'] = round(wall_p, 3)
+      of['flow_ms_per_pair'] = round(wall_f, 3)
+      roof['other_pair'] = {'pair': other, 'pruned': op, 'unpruned': of}
+      del o_pre_t, o_post_t
+    else:
+      # no un-pruned leg in this run: the line can only state the algorithmic figure
+      for k in ('achieved', 'frac', 'avg_launch_ms', 'launches', 'patches_per_launch',
+                'issued_frac'):
+        if k in timed:
+          roof[k] = timed[k]
+      roof['frac_is'] = ('pruned launch of the timed region (algorithmic; run without '
+                         '--no-legs at --gpus 1 for the un-pruned hardware leg)')
+
+  ms_ms, ms_n = prof.kernel_ms[1], prof.launches[1]
   mesh_obj = {
       'value': node_updates_s, 'unit': 'node-updates/s',
       'nodes': mesh_nodes, 'iterations_per_step': mesh_steps_done // max(args.steps, 1),
@@ -255,28 +364,63 @@ def main():
 
   # HBM traffic of the dominant kernel: PMC counters cannot be read from inside
   # the run, so the figure comes from the separate rocprofv3 --pmc passes of THIS
-  # bench (tools/measure/profile_round2.sh -> profiles/r02_pmc_traffic.json,
-  # stamped with the git revision it was measured on); null when none is on file.
-  if roof and uses_mfma:
+  # bench (tools/measure/profile_round3.sh -> profiles/r03_pmc_traffic.json), and
+  # only when that file was measured on the library that is loaded now
+  # (.build_sha); otherwise null.
+  if roof and uses_mfma and size == 8192:
     try:
-      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
-      for name, v in pmc.items():
-        if 'xcorr_mfma_kernel<10, 11,' in name and size == 8192:
-          # measured per launch of `meta_ppl` patches; scaled to this run's launches
-          meta_ppl = float(pmc.get('_meta', {}).get('patches_per_launch', 4040.1))
-          roof['traffic'] = int(v['hbm_bytes_per_launch'] / meta_ppl * patches_per_launch)
-          alg = (2 * 160 * 160 + 4 * 160 * 160 + 4 * 320 * 320) * patches_per_launch
-          roof['traffic_source'] = {
-              'file': 'profiles/r02_pmc_traffic.json',
-              'measured_on_git_sha': pmc.get('_meta', {}).get('git_sha'),
-              'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of '
-                        'this bench; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per '
-                        'launch of %d patches' % round(patches_per_launch)}
-          roof['traffic_note'] = (
-              'bytes the kernel itself needs per launch: patches 51 KB + G table 102 KB '
-              '+ padded surface 410 KB per patch = %.2f GB' % (alg / 1e9))
+      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')))
+      meta = pmc.get('_meta', {})
+      sha = build_sha()
+      if sha and meta.get('git_sha') == sha and meta.get('pair', 'exact') == args.pair:
+        for name, v in pmc.items():
+          if 'xcorr_mfma_kernel<10, 11,' in name:
+            meta_ppl = float(meta.get('patches_per_launch', n_patches))
+            ppl = roof['pruned']['patches_per_launch']
+            roof['traffic'] = int(v['hbm_bytes_per_launch'] / meta_ppl * ppl)
+            roof['traffic_source'] = {
+                'file': 'profiles/r03_pmc_traffic.json', 'measured_on_git_sha': sha,
+                'launch': 'pruned (production) launch',
+                'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of '
+                          'this bench; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per '
+                          'launch of %d patches' % round(ppl)}
+      else:
+        roof['traffic_note'] = ('null: profiles/r03_pmc_traffic.json was measured on %s / '
+                                'pair %s, this library is %s / pair %s'
+                                % (meta.get('git_sha'), meta.get('pair'), sha, args.pair))
     except (OSError, ValueError):
       pass
+
+  # Steady state: the timed region above is < 1 s on a power-limited kernel, so
+  # the same step is repeated back to back for >= --sustain seconds (all ranks).
+  sustained = None
+  if args.sustain > 0:
+    barrier()
+    s0 = time.perf_counter()
+    n_sus = 0
+    while True:
+      flow_step()
+      mesh_step(prev_t)
+      n_sus += 1
+      if n_sus % 8 == 0 or n_sus < 8:
+        torch.cuda.synchronize(dev)
+        # every rank leaves after the same count: rank 0's clock decides
+        flag = torch.tensor([1.0 if time.perf_counter() - s0 >= args.sustain else 0.0],
+                            device=dev if backend == 'nccl' else 'cpu')
+        if world > 1:
+          dist.broadcast(flag, src=0)
+        if flag.item() > 0:
+          break
+    barrier()
+    s_el = time.perf_counter() - s0
+    sustained = {'seconds': round(s_el, 2), 'steps': n_sus,
+                 'ms_per_step': round(s_el / n_sus * 1e3, 3),
+                 'mpix_s': round(world * pix * n_sus / s_el / 1e6, 1),
+                 'note': 'flow + mesh steps back to back (includes the mesh leg)'}
+
+  sharded = None
+  if args.mesh_sharded > 0:
+    sharded = mesh_sharded_leg(args.mesh_sharded, dev, rank, world)
 
   out = {
       'metric': 'patch-xcorr Mpix/s (+ mesh node-updates/s) on 8192^2 tiles',
@@ -288,23 +432,69 @@ def main():
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'u8' if uses_mfma else 'f32', 'data': 'synthetic',
       'config': {
-          'workload': f'single {size}x{size} EM tile pair per GPU, patch=160 '
-                      f'step=40 batch=1024 flow + {args.mesh_iters}-iter FIRE mesh '
-                      f'relax [2,1,{n_grid + 2 * pad},{n_grid + 2 * pad}] '
+          'workload': f'single {size}x{size} EM tile pair per GPU '
+                      + ('(smooth 6 px / 2048 px deformation + shift + noise, SURVEY 8d '
+                         'realistic pair)' if args.pair == 'warped' else
+                         '(rigid integer shift + noise)')
+                      + f', patch=160 step=40 batch=1024 flow + {args.mesh_iters}-iter FIRE '
+                      f'mesh relax [2,1,{n_grid + 2 * pad},{n_grid + 2 * pad}] '
                       '(BASELINE configs[1])',
+          'pair': args.pair,
           'patches_per_pair': n_patches, 'xcorr_method':
               'int8 MFMA' if uses_mfma else 'direct f32',
       },
       'patches_per_s': world * n_patches * args.steps / t_flow,
       'mesh': mesh_obj, 'roofline': roof,
+      'build_sha': build_sha(),
   }
+  if sustained:
+    out['sustained'] = sustained
+    out['sustained_ms_per_step'] = sustained['ms_per_step']
+  if sharded:
+    out['mesh_sharded'] = sharded
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
-    out['cpu_baseline'] = cpu_baseline(size, 1002 + rank)
+    out['cpu_baseline'] = cpu_baseline(size, args.seed + rank, args.pair)
   if rank == 0:
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
+
+
+def mesh_sharded_leg(bands_per_rank, dev, rank, world):
+  """ONE [2, 64, 204, 204] mesh (the configs[2] montage size) split into
+  world x bands_per_rank bands of rows; the whole chunk of steps runs inside
+  sfm_mesh_relax_banded (halo rows between ranks through sfm_comm_* = RCCL,
+  between local bands by device copies), next to the un-split relaxation."""
+  import torch
+  from sofima_amd import dist as sdist, mesh
+  rng = np.random.default_rng(7)
+  shape = (2, 64, 204, 204)
+  prev = rng.standard_normal(shape).astype(np.float32) * 2
+  iters = 200
+  cfg = mesh.IntegrationConfig(
+      dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(20.0, 20.0), num_iters=iters,
+      max_iters=iters, stop_v_max=1e-9, dt_max=1000, start_cap=0.01, final_cap=10,
+      prefer_orig_order=True)
+  x0 = np.zeros(shape, np.float32)
+  out = {'mesh': list(shape), 'iters': iters, 'bands_per_rank': bands_per_rank,
+         'ranks': world}
+  mesh.relax_mesh(x0, prev, cfg)
+  torch.cuda.synchronize(dev)
+  t0 = time.perf_counter()
+  mesh.relax_mesh(x0, prev, cfg)
+  torch.cuda.synchronize(dev)
+  out['unsplit_us_per_step'] = round((time.perf_counter() - t0) / iters * 1e6, 2)
+  res = sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=bands_per_rank)  # warm-up
+  torch.cuda.synchronize(dev)
+  t0 = time.perf_counter()
+  res = sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=bands_per_rank,
+                                timing=out)
+  torch.cuda.synchronize(dev)
+  out['banded_us_per_step_incl_setup'] = round((time.perf_counter() - t0) / iters * 1e6, 2)
+  out['node_updates_per_s'] = float(np.prod(shape[1:])) * iters / (
+      out.get('banded_chunk_s', time.perf_counter() - t0))
+  return out
 
 
 def spawn_ranks(n):
@@ -323,12 +513,12 @@ def spawn_ranks(n):
   return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(size, seed):
+def cpu_baseline(size, seed, pair='warped'):
   """Runs the CPU leg in a child process (no HIP context there, so it can fork a
   worker pool) and returns its JSON object."""
   import subprocess
   cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only',
-         '--size', str(size), '--seed', str(seed)]
+         '--size', str(size), '--seed', str(seed), '--pair', pair]
   out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
   if out.returncode != 0:
     return {'error': out.stderr[-400:]}
@@ -360,14 +550,14 @@ def _cpu_mesh_replica(seed):
   return time.perf_counter() - t0
 
 
-def cpu_baseline_child(size, seed):
+def cpu_baseline_child(size, seed, pair='warped'):
   """The CPU oracle (a NumPy / SciPy port of the reference algorithm) on ALL host
   cores: one process per core (fork), each correlating whole reference batches
   of the same pair (FFT form + peak statistics, single-threaded FFTs), then one
   independent 205^2 mesh relaxation per core."""
   import multiprocessing as mp
   cores = os.cpu_count() or 1
-  pre, post = synth_pair(size, seed)
+  pre, post = synth_pair(size, seed, warp=WARP if pair == 'warped' else None)
   batch = 256
   n_grid = (size - (PATCH - STEP)) // STEP
   yy, xx = np.mgrid[:n_grid, :n_grid]

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 3   /* 3: SfmProfile carries the pruning tile counts */
+#define SFM_ABI_VERSION 4   /* 4: SfmProfile.mfma_issued; sfm_mesh_relax_banded */
 
 #define SFM_OK 0
 #define SFM_ERR_INVALID (-1)     /* bad argument / unsupported combination */
@@ -59,6 +59,30 @@ const char* sfm_last_error(void);
 /* Number of visible HIP devices (0 and SFM_OK when none). */
 int sfm_device_count(int* count);
 
+/* Behaviour switches.  Every switch selects between kernels / schedules that
+ * return the SAME results (the tests pin the variants against each other);
+ * they exist for A/B measurements and for the tests themselves.  A switch set
+ * here wins over the environment variable of the same name, which is only the
+ * default; value NULL un-sets it (and hides the environment variable).
+ * sfm_get_option copies the value in effect (returns 1 and "" when unset).
+ *   SFM_MFMA_PRUNE=0      correlation kernel computes every surface tile
+ *   SFM_MFMA_PROBE=0      no seed probe in front of the pruning
+ *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry
+ *   SFM_MFMA_QUEUE=0      static instead of dynamic patch queue
+ *   SFM_MFMA_PRIO=n       wave priority experiment (0..3)
+ *   SFM_MFMA_MAX_WG_PER_CU=n   occupancy cap of the correlation kernel
+ *   SFM_MASKED_FAST=0     masked patches always take all eight passes
+ *   SFM_MASKED_DEADROWS=0 no overlap-rule skips in the masked assembly
+ *   SFM_PHASE_XCD=0       masked assembly without the XCD-aware tile order
+ *   SFM_FFT_OWN=0         hipFFT plans instead of the hand-written 3-D passes
+ *   SFM_MESH_PERSISTENT=0 / SFM_MESH_SPECULATE=0 / SFM_MESH_TILED=0 /
+ *   SFM_MESH_SHARED=0 / SFM_MESH_SMALL=0    fall back to the simpler integrator
+ *   SFM_MESH_TILE=16|32   tile edge of the persistent integrator
+ *   SFM_MESH_GRAPH=1 / SFM_MESH_MARCH=1 / SFM_MESH_BRICKS=1   measured-slower
+ *                         experiments (hipGraph replay, z-marching, bricks)   */
+int sfm_set_option(const char* name, const char* value);
+int sfm_get_option(const char* name, char* value, size_t capacity);
+
 /* Kernel timing hooks (used by bench.py for the roofline figures; no
  * reference counterpart).  While enabled, hipEvents on the launch stream
  * bracket every launch of the dominant kernels: the patch-correlation kernel
@@ -75,6 +99,8 @@ typedef struct SfmProfile {
                                    the fused-peaks kernel skipped / looked at   */
   int64_t tiles_drawn[2];
   int64_t col_tiles_skipped[2]; /* column tiles left out of the computed row tiles */
+  int64_t mfma_issued[2];       /* kind 0: matrix instructions (16 x 16 x 64 int8 =
+                                   32768 operations each) the kernel issued      */
 } SfmProfile;
 int sfm_profile_enable(int on);
 int sfm_profile_read(SfmProfile* out);
@@ -499,6 +525,39 @@ int sfm_mesh_shard_integrate(const SfmMeshDesc* desc, SfmMeshShard* shard);
  * the chunk's final scalars, `stats` e_kin and v_max of the OWNED rows. */
 int sfm_mesh_shard_finish(const SfmMeshDesc* desc, SfmMeshShard* shard,
                           SfmFireState* fire, SfmChunkStats* stats);
+
+/* The same split step with the loop INSIDE the library: one call runs
+ * desc.num_iters steps of every local band, moving the edge rows between local
+ * bands by device copies and between ranks through `comm` (grouped RCCL
+ * send / recv), all-gathering the bands' partial sums once per step, with the
+ * exchange of a step's edge rows overlapped with the integration of its
+ * interior rows (second stream).  Band g = rank * n_local + i owns rows
+ * [own_y0, own_y1) of bands[i]'s arrays; shards[i].global_nodes must be set,
+ * sums / my_sums / n_ranks are filled in by the library.  In-plane spring
+ * meshes need SfmMeshDesc.workspace as for sfm_mesh_relax_chunk (it holds the
+ * second state set).  `fire` in/out and `stats` are those of the WHOLE mesh
+ * (e_kin added up in band order, v_max the maximum), identical on every rank.
+ * Synchronises desc.stream once, at the end of the chunk. */
+#define SFM_BANDED_LOOPBACK 1   /* exchanges between LOCAL bands travel through
+                                   comm as self send / recv too (exercises the
+                                   RCCL path on one GPU)                       */
+#define SFM_BANDED_NO_OVERLAP 2 /* one launch per band and step, exchange after it */
+struct SfmComm;
+typedef struct SfmBandedDesc {
+  int32_t n_local;              /* bands of this rank, consecutive, in y order  */
+  const SfmMeshDesc* bands;     /* [n_local]                                   */
+  SfmMeshShard* shards;         /* [n_local]                                   */
+  struct SfmComm* comm;         /* NULL: this process holds the whole mesh      */
+  int32_t rank;
+  int32_t n_ranks;              /* every rank holds n_local bands               */
+  int32_t flags;                /* SFM_BANDED_*                                 */
+  void* comm_stream;            /* exchange stream; NULL: bands[0].stream       */
+  void* scratch;                /* device, sfm_mesh_banded_scratch_bytes        */
+  size_t scratch_bytes;
+} SfmBandedDesc;
+size_t sfm_mesh_banded_scratch_bytes(const SfmBandedDesc* desc);
+int sfm_mesh_relax_banded(const SfmBandedDesc* desc, SfmFireState* fire,
+                          SfmChunkStats* stats);
 
 /* RCCL transport of those exchanges (resolved at run time; SFM_ERR_NO_DEVICE
  * when no librccl can be loaded).  One communicator per process on the

@@ -275,6 +275,23 @@ class SfmMeshShard(C.Structure):
   ]
 
 
+class SfmBandedDesc(C.Structure):
+  _fields_ = [
+      ('n_local', i32),
+      ('bands', C.POINTER(SfmMeshDesc)),
+      ('shards', C.POINTER(SfmMeshShard)),
+      ('comm', C.c_void_p),
+      ('rank', i32),
+      ('n_ranks', i32),
+      ('flags', i32),
+      ('comm_stream', C.c_void_p),
+      ('scratch', C.c_void_p),
+      ('scratch_bytes', C.c_size_t),
+  ]
+
+
+BANDED_LOOPBACK = 1
+BANDED_NO_OVERLAP = 2
 COMM_ID_BYTES = 128
 REDUCE_SUM = 0
 REDUCE_MAX = 1
@@ -289,7 +306,8 @@ class SfmProfile(C.Structure):
   _fields_ = [('kernel_ms', C.c_double * 2), ('launches', C.c_int64 * 2),
               ('clock_mhz', C.c_double * 2),
               ('tiles_skipped', C.c_int64 * 2), ('tiles_drawn', C.c_int64 * 2),
-              ('col_tiles_skipped', C.c_int64 * 2)]
+              ('col_tiles_skipped', C.c_int64 * 2),
+              ('mfma_issued', C.c_int64 * 2)]
 
 
 class SfmChunkStats(C.Structure):
@@ -301,6 +319,8 @@ SIGNATURES = {
     'sfm_version': (C.c_int, []),
     'sfm_last_error': (C.c_char_p, []),
     'sfm_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'sfm_set_option': (C.c_int, [C.c_char_p, C.c_char_p]),
+    'sfm_get_option': (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     'sfm_profile_enable': (C.c_int, [C.c_int]),
     'sfm_profile_read': (C.c_int, [C.POINTER(SfmProfile)]),
     'sfm_xcorr_workspace_bytes': (C.c_size_t, [C.POINTER(SfmXcorrDesc)]),
@@ -334,6 +354,9 @@ SIGNATURES.update({
                                            C.POINTER(SfmMeshShard)]),
     'sfm_mesh_shard_finish': (C.c_int, [C.POINTER(SfmMeshDesc), C.POINTER(SfmMeshShard),
                                         C.POINTER(SfmFireState),
+                                        C.POINTER(SfmChunkStats)]),
+    'sfm_mesh_banded_scratch_bytes': (C.c_size_t, [C.POINTER(SfmBandedDesc)]),
+    'sfm_mesh_relax_banded': (C.c_int, [C.POINTER(SfmBandedDesc), C.POINTER(SfmFireState),
                                         C.POINTER(SfmChunkStats)]),
     'sfm_comm_unique_id': (C.c_int, [C.c_void_p]),
     'sfm_comm_init': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
@@ -380,6 +403,47 @@ def check(rc: int):
   if rc != SFM_OK:
     msg = load().sfm_last_error().decode('utf-8', 'replace')
     raise SofimaAmdError(f'libsofima_amd error {rc}: {msg}')
+
+
+def set_option(name: str, value=None):
+  """Sets a behaviour switch of the library (include/sofima_amd.h lists them);
+  None un-sets it.  Explicit settings win over the environment."""
+  check(load().sfm_set_option(name.encode(), None if value is None else
+                              str(value).encode()))
+
+
+def get_option(name: str):
+  buf = C.create_string_buffer(64)
+  rc = load().sfm_get_option(name.encode(), buf, 64)
+  if rc == 1:
+    return None
+  check(rc)
+  return buf.value.decode()
+
+
+class option:
+  """`with _abi.option('SFM_MFMA_PRUNE', 0): ...` -- a switch for one block
+  (tests, A/B measurements); restores the previous explicit setting."""
+
+  def __init__(self, name, value):
+    self.name, self.value = name, value
+
+  def __enter__(self):
+    self.prev = get_option(self.name)
+    set_option(self.name, self.value)
+    return self
+
+  def __exit__(self, *exc):
+    # back to "not explicitly set" when the previous value came from nowhere or
+    # from the environment (which stays the default)
+    load().sfm_set_option(self.name.encode(), None)
+    env = os.environ.get(self.name)
+    if self.prev is not None and self.prev != env:
+      set_option(self.name, self.prev)
+    elif env is not None:
+      # un-setting hid the environment variable: re-expose it
+      set_option(self.name, env)
+    return False
 
 
 def device_count() -> int:

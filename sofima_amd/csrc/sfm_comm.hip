@@ -102,6 +102,44 @@ int check_comm(const SfmComm* c) {
 
 }  // namespace
 
+// Building blocks for callers inside the library that need more than one
+// neighbour pair per group (sfm_mesh_relax_banded): every send / recv between
+// group_begin and group_end progresses concurrently.
+namespace sfm {
+
+int comm_group_begin(SfmComm* c) {
+  if (int rc = check_comm(c)) return rc;
+  SFM_NCCL_CHECK(g_rccl.group_start());
+  return SFM_OK;
+}
+
+int comm_send(SfmComm* c, const float* buf, size_t count, int peer, hipStream_t st) {
+  ncclResult_t r = g_rccl.send(buf, count, ncclFloat32, peer, c->comm, st);
+  return r == ncclSuccess ? SFM_OK
+                          : fail(SFM_ERR_HIP, "ncclSend failed: %s", g_rccl.error_string(r));
+}
+
+int comm_recv(SfmComm* c, float* buf, size_t count, int peer, hipStream_t st) {
+  ncclResult_t r = g_rccl.recv(buf, count, ncclFloat32, peer, c->comm, st);
+  return r == ncclSuccess ? SFM_OK
+                          : fail(SFM_ERR_HIP, "ncclRecv failed: %s", g_rccl.error_string(r));
+}
+
+// Always call after comm_group_begin succeeded, also when a send / recv failed
+// (`rc` = the first error so far, returned unless closing the group fails too).
+int comm_group_end(SfmComm* c, int rc) {
+  (void)c;
+  ncclResult_t r = g_rccl.group_end();
+  if (rc) return rc;
+  return r == ncclSuccess ? SFM_OK
+                          : fail(SFM_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.error_string(r));
+}
+
+int comm_rank(const SfmComm* c) { return c ? c->rank : 0; }
+int comm_size(const SfmComm* c) { return c ? c->n_ranks : 1; }
+
+}  // namespace sfm
+
 extern "C" {
 
 int sfm_comm_unique_id(void* id128) {
@@ -160,15 +198,23 @@ int sfm_comm_halo_exchange(SfmComm* c, int peer_lo, const float* send_lo, float*
   // one grouped call: both directions progress concurrently on the two xGMI
   // links to the neighbours
   SFM_NCCL_CHECK(g_rccl.group_start());
+  // the group is always closed, also after a failed send / recv: a dangling
+  // group would swallow every later collective of this thread
+  ncclResult_t first = ncclSuccess;
+  auto note = [&](ncclResult_t r) {
+    if (first == ncclSuccess && r != ncclSuccess) first = r;
+  };
   if (peer_lo >= 0) {
-    SFM_NCCL_CHECK(g_rccl.send(send_lo, count, ncclFloat32, peer_lo, c->comm, st));
-    SFM_NCCL_CHECK(g_rccl.recv(recv_lo, count, ncclFloat32, peer_lo, c->comm, st));
+    note(g_rccl.send(send_lo, count, ncclFloat32, peer_lo, c->comm, st));
+    note(g_rccl.recv(recv_lo, count, ncclFloat32, peer_lo, c->comm, st));
   }
   if (peer_hi >= 0) {
-    SFM_NCCL_CHECK(g_rccl.send(send_hi, count, ncclFloat32, peer_hi, c->comm, st));
-    SFM_NCCL_CHECK(g_rccl.recv(recv_hi, count, ncclFloat32, peer_hi, c->comm, st));
+    note(g_rccl.send(send_hi, count, ncclFloat32, peer_hi, c->comm, st));
+    note(g_rccl.recv(recv_hi, count, ncclFloat32, peer_hi, c->comm, st));
   }
-  SFM_NCCL_CHECK(g_rccl.group_end());
+  note(g_rccl.group_end());
+  if (first != ncclSuccess)
+    return sfm::fail(SFM_ERR_HIP, "halo exchange failed: %s", g_rccl.error_string(first));
   return SFM_OK;
 }
 

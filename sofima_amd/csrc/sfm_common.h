@@ -25,6 +25,19 @@ int fail(int code, const char* fmt, ...);
 
 #define SFM_LAUNCH_CHECK() SFM_HIP_CHECK(hipGetLastError())
 
+// Behaviour switches (sfm_set_option; the environment variable of the same name
+// is the default).  Returns the value or nullptr when unset.  The pointer stays
+// valid until the option is set again.
+const char* option(const char* name);
+
+// sfm_comm.hip: grouped point-to-point building blocks (RCCL).
+int comm_group_begin(SfmComm* c);
+int comm_send(SfmComm* c, const float* buf, size_t count, int peer, hipStream_t st);
+int comm_recv(SfmComm* c, float* buf, size_t count, int peer, hipStream_t st);
+int comm_group_end(SfmComm* c, int rc);
+int comm_rank(const SfmComm* c);
+int comm_size(const SfmComm* c);
+
 // bench.py timing hooks (sfm_profile_*): no-ops unless enabled.
 constexpr int kProfXcorr = 0;
 constexpr int kProfMesh = 1;

@@ -2,9 +2,12 @@
 #include "sfm_common.h"
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace sfm {
@@ -23,6 +26,24 @@ int fail(int code, const char* fmt, ...) {
 }
 
 namespace {
+// Option table: explicit settings win over the process environment.  Values
+// are kept in a list of stable strings (callers hold the pointers briefly).
+std::mutex g_opt_mu;
+std::map<std::string, std::string> g_opts;
+std::map<std::string, bool> g_opt_unset;
+}  // namespace
+
+const char* option(const char* name) {
+  {
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    auto it = g_opts.find(name);
+    if (it != g_opts.end()) return it->second.c_str();
+    if (g_opt_unset.count(name)) return nullptr;
+  }
+  return std::getenv(name);
+}
+
+namespace {
 std::mutex g_prof_mu;
 std::atomic<bool> g_prof_on{false};
 struct Span {
@@ -32,7 +53,7 @@ std::vector<Span> g_spans[2];
 std::vector<Span> g_free;
 Span g_open[2];
 struct ClockSample {
-  long long v[4];  // cycles, 10 ns ticks[, row tiles drawn << 32 | skipped, column tiles skipped]
+  long long v[5];  // cycles, 10 ns ticks[, row tiles drawn << 32 | skipped, column tiles skipped, MFMAs issued]
 };
 std::deque<ClockSample> g_clock[2];  // stable addresses: targets of async copies
 }  // namespace
@@ -64,8 +85,8 @@ void prof_end(int kind, hipStream_t st) {
 void prof_clock(int kind, const long long* dev_pair, hipStream_t st, int n) {
   if (!profiling() || !dev_pair) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_clock[kind].push_back(ClockSample{{0, 0, 0, 0}});
-  (void)hipMemcpyAsync(g_clock[kind].back().v, dev_pair, sizeof(long long) * (n == 4 ? 4 : 2),
+  g_clock[kind].push_back(ClockSample{{0, 0, 0, 0, 0}});
+  (void)hipMemcpyAsync(g_clock[kind].back().v, dev_pair, sizeof(long long) * (n >= 2 && n <= 5 ? n : 2),
                        hipMemcpyDeviceToHost, st);
 }
 
@@ -96,20 +117,48 @@ int sfm_profile_read(SfmProfile* out) {
     out->launches[k] = static_cast<int64_t>(sfm::g_spans[k].size());
     sfm::g_spans[k].clear();
     // the events above are later in stream order than the probe copies
-    long long cyc = 0, ticks = 0, skipped = 0, drawn = 0, cols = 0;
+    long long cyc = 0, ticks = 0, skipped = 0, drawn = 0, cols = 0, issued = 0;
     for (auto& c : sfm::g_clock[k]) {
       cyc += c.v[0];
       ticks += c.v[1];
       skipped += c.v[2] & 0xffffffffLL;
       drawn += (c.v[2] >> 32) & 0xffffffffLL;
       cols += c.v[3];
+      issued += c.v[4];
     }
     out->clock_mhz[k] = ticks > 0 ? static_cast<double>(cyc) * 100.0 / ticks : 0.0;
     out->tiles_skipped[k] = skipped;
     out->tiles_drawn[k] = drawn;
     out->col_tiles_skipped[k] = cols;
+    out->mfma_issued[k] = issued;
     sfm::g_clock[k].clear();
   }
+  return SFM_OK;
+}
+
+int sfm_set_option(const char* name, const char* value) {
+  if (!name || std::strncmp(name, "SFM_", 4) != 0)
+    return sfm::fail(SFM_ERR_INVALID, "option names start with SFM_");
+  std::lock_guard<std::mutex> lk(sfm::g_opt_mu);
+  if (value) {
+    sfm::g_opts[name] = value;
+    sfm::g_opt_unset.erase(name);
+  } else {
+    sfm::g_opts.erase(name);
+    sfm::g_opt_unset[name] = true;   // hides the environment variable as well
+  }
+  return SFM_OK;
+}
+
+int sfm_get_option(const char* name, char* value, size_t capacity) {
+  if (!name || !value || capacity == 0) return sfm::fail(SFM_ERR_INVALID, "option: NULL argument");
+  const char* v = sfm::option(name);
+  if (!v) {
+    value[0] = 0;
+    return 1;
+  }
+  std::strncpy(value, v, capacity - 1);
+  value[capacity - 1] = 0;
   return SFM_OK;
 }
 

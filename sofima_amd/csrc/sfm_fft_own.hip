@@ -485,7 +485,7 @@ int set_lds(K kernel, size_t bytes) {
 }
 
 bool own_enabled() {
-  const char* e = std::getenv("SFM_FFT_OWN");  // "0": hipFFT plans for every shape
+  const char* e = sfm::option("SFM_FFT_OWN");  // "0": hipFFT plans for every shape
   return !(e && e[0] == '0');
 }
 

@@ -309,7 +309,9 @@ __global__ void __launch_bounds__(kBlock) flow_starts_kernel(StartsArgs a) {
   int post[3], pre[3], off[3];
   for (int i = 0; i < a.nd; ++i) {
     post[i] = a.pos[b * a.nd + i] * a.step[i];
-    const int p = post[i] - (a.patch[i] - a.post_patch[i]) / 2;
+    // NumPy floor division (flow_field.py:620): -1 // 2 == -1, not 0
+    const int diff = a.patch[i] - a.post_patch[i];
+    const int p = post[i] - (diff >= 0 ? diff / 2 : -((-diff + 1) / 2));
     pre[i] = p < 0 ? 0 : p;
   }
   if (a.tf[0]) {

@@ -1038,6 +1038,47 @@ __device__ __forceinline__ float lane_right(float v) {
       __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));  // wave_shl:1
 }
 
+// Band mode of the tiled step (one mesh split into bands of rows, possibly on
+// several GPUs: sfm_mesh_relax_banded).  `sums` holds the partial sums of ALL
+// bands of the previous step, in band order; every workgroup of every band
+// adds them up in that order (pending == 3), so all bands take the same FIRE
+// branch.  The reducing workgroup leaves this band's sums of the step in
+// `my_sums` instead of advancing the scalars.  A step may be split into two
+// launches -- the tile rows at the band's edges first, so that their rows can
+// travel to the neighbour while the interior is computed: `ty_mode` 1 = only
+// tile rows ty_a / ty_b, 2 = all other tile rows, 0 = all; `total_tiles` counts
+// the tiles of both launches (ticket / partial-sum slots are per tile).
+struct BandArgs {
+  const float* sums;   // [n_bands, kNP] or nullptr: not in band mode
+  float* my_sums;      // [kNP]
+  int n_bands;
+  int total_tiles;     // 0: gridDim.x
+  int ty_mode, ty_a, ty_b;
+};
+
+// Sum of the bands' partial sums in band order + the FIRE update from them
+// (wave-uniform addresses: scalar loads).
+__device__ __forceinline__ void band_scalars(const Scalars& in, const float* sums, int n_bands,
+                                             const MeshParams& p, Scalars* out) {
+  float acc[kNP];
+  for (int i = 0; i < kNP; ++i) acc[i] = 0.f;
+  const int nval = p.remove_drift ? 7 : 1;
+  for (int r = 0; r < n_bands; ++r)
+    for (int i = 0; i < nval; ++i) acc[i] = acc[i] + sums[r * kNP + i];
+  scalars_from_sums(in, acc, p, out);
+}
+
+// The chunk's last pending update in band mode (finish_kernel then runs with
+// pending == 2): same order as the step kernels'.
+__global__ void band_scalars_kernel(const Scalars* __restrict__ scal_in,
+                                    Scalars* __restrict__ scal_out,
+                                    const float* __restrict__ sums, int n_bands, MeshParams p) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Scalars o;
+  band_scalars(*scal_in, sums, n_bands, p, &o);
+  *scal_out = o;
+}
+
 template <bool FUSED>
 __global__ void __launch_bounds__(kBlock, SFM_LBT)
 integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_in,
@@ -1046,7 +1087,7 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
                           const Scalars* __restrict__ scal_in,
                           Scalars* __restrict__ scal_out, float fixed_cap,
                           u64* __restrict__ partials, int* __restrict__ ticket,
-                          int pending, int nty, int ntx) {
+                          int pending, int nty, int ntx, BandArgs bd) {
   constexpr int C = 2;
   constexpr int TW = 64;         // columns -1 .. kSX of the tile
   constexpr int kRows = 4;       // rows per thread
@@ -1055,13 +1096,39 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
   __shared__ int s_last;
   const unsigned epoch = static_cast<unsigned>(ticket[1]) + 1u;
 
+  // tile of this workgroup (a split step enumerates a subset of the tile rows)
+  int tile = blockIdx.x;
+  if (bd.ty_mode) {
+    const int n_edge = bd.ty_a == bd.ty_b ? 1 : 2;
+    const int rows_here = bd.ty_mode == 1 ? n_edge : nty - n_edge;
+    const int txi = blockIdx.x % ntx;
+    const int j = (blockIdx.x / ntx) % rows_here;
+    const int pl = blockIdx.x / (ntx * rows_here);
+    int tyi;
+    if (bd.ty_mode == 1) {
+      tyi = j == 0 ? bd.ty_a : bd.ty_b;
+    } else {
+      tyi = j;
+      if (tyi >= bd.ty_a) ++tyi;
+      if (bd.ty_b != bd.ty_a && tyi >= bd.ty_b) ++tyi;
+    }
+    tile = (pl * nty + tyi) * ntx + txi;
+  }
+  const int total_tiles = bd.total_tiles ? bd.total_tiles : static_cast<int>(gridDim.x);
+
   Scalars s;
   if (p.fire) {
     s = *scal_in;
-    if (!pending) {
+    if (pending == 3) {
+      Scalars o;
+      band_scalars(s, bd.sums, bd.n_bands, p, &o);
+      s = o;
+    } else if (!pending) {
       s.gate = 1.f;
       for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
     }
+    // band mode: the scalars this step runs on are next step's starting point
+    if (bd.sums && blockIdx.x == 0 && threadIdx.x == 0 && bd.ty_mode != 2) *scal_out = s;
   } else {
     s.dt = p.vv_dt;
     s.alpha = 0.f;
@@ -1073,9 +1140,9 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
   const float c2 = 0.5f * (dt * dt);
   const bool fix = p.fire && pending;
 
-  const int tx = blockIdx.x % ntx;
-  const int ty = (blockIdx.x / ntx) % nty;
-  const long long plane = blockIdx.x / (ntx * nty);  // b * Z + z
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const long long plane = tile / (ntx * nty);  // b * Z + z
   const long long base = plane * p.Y * p.X;
   const int gx0 = tx * kSX, gy0 = ty * kSY;
   const int lane = threadIdx.x & 63;
@@ -1183,7 +1250,8 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
       fs[2][c] = lane_left(ns[2][k][c]);       // (x - 1, y - 1)
       fs[3][c] = lane_right(ns[3][k][c]);      // (x + 1, y - 1)
     }
-    const bool own = col_own && gy < p.Y;
+    // (band mode: halo rows belong to the neighbour band -- neither stored nor summed)
+    const bool own = col_own && gy >= p.own_y0 && gy < p.own_y1;
     if (!own) continue;
     const bool xm = gx - 1 >= 0, xp = gx + 1 < p.X, ym = gy - 1 >= 0, yp = gy + 1 < p.Y;
     const bool okf[4] = {xm, ym, xm && ym, xp && ym};
@@ -1232,23 +1300,26 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
   // (hand-off as in integrate_tiled2d_kernel)
   if (threadIdx.x == 0) {
     for (int i = 0; i < 7; ++i)
-      __hip_atomic_store(&partials[blockIdx.x * kNP + i],
+      __hip_atomic_store(&partials[tile * kNP + i],
                          (static_cast<u64>(epoch) << 32) | __float_as_uint(part[i]),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged before the ticket
     s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT) ==
-             static_cast<int>(gridDim.x) - 1;
+                                    __HIP_MEMORY_SCOPE_AGENT) == total_tiles - 1;
   }
   __syncthreads();
   if (!s_last) return;
   float acc[kNP];
-  tile_tail_gather(partials, static_cast<int>(gridDim.x), p.remove_drift ? 7 : 1, epoch, acc);
+  tile_tail_gather(partials, total_tiles, p.remove_drift ? 7 : 1, epoch, acc);
   block_sum(acc, 7, lds);
   if (threadIdx.x == 0) {
-    Scalars in = *scal_in, o;
-    scalars_from_sums(in, acc, p, &o);
-    *scal_out = o;
+    if (bd.sums) {
+      for (int i = 0; i < kNP; ++i) bd.my_sums[i] = i < 7 ? acc[i] : 0.f;
+    } else {
+      Scalars in = *scal_in, o;
+      scalars_from_sums(in, acc, p, &o);
+      *scal_out = o;
+    }
     ticket[1] = static_cast<int>(epoch);
     __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -2905,7 +2976,7 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
 constexpr long long kGraphMaxNodes = 400000;
 
 bool graph_enabled() {
-  const char* e = getenv("SFM_MESH_GRAPH");
+  const char* e = sfm::option("SFM_MESH_GRAPH");
   return e && e[0] == '1';
 }
 
@@ -2919,12 +2990,12 @@ hipStream_t capture_stream() {
 }
 
 bool small_enabled() {
-  const char* e = std::getenv("SFM_MESH_SMALL");  // "0": the launch-per-kernel path
+  const char* e = sfm::option("SFM_MESH_SMALL");  // "0": the launch-per-kernel path
   return !(e && e[0] == '0');
 }
 
 bool persistent_enabled() {
-  const char* e = getenv("SFM_MESH_PERSISTENT");
+  const char* e = sfm::option("SFM_MESH_PERSISTENT");
   return !(e && e[0] == '0');
 }
 
@@ -2959,7 +3030,7 @@ struct TilePlan {
 };
 
 bool shared_enabled() {
-  const char* e = getenv("SFM_MESH_SHARED");  // "0": both ends evaluate every spring
+  const char* e = sfm::option("SFM_MESH_SHARED");  // "0": both ends evaluate every spring
   return !(e && e[0] == '0');
 }
 
@@ -2972,12 +3043,12 @@ bool shared_enabled() {
 // Opt-in (SFM_MESH_MARCH=1), kept as the measured experiment; its forces are
 // bit-identical (test_volumetric_march_kernel_matches_two_sided_kernel).
 bool march_enabled() {
-  const char* e = getenv("SFM_MESH_MARCH");
+  const char* e = sfm::option("SFM_MESH_MARCH");
   return e && e[0] == '1';
 }
 
 bool tiled_enabled() {
-  const char* e = getenv("SFM_MESH_TILED");
+  const char* e = sfm::option("SFM_MESH_TILED");
   return !(e && e[0] == '0');
 }
 
@@ -2990,7 +3061,7 @@ bool tiled_enabled() {
 // bricks remove, and the shell recomputation adds to it.  Opt-in
 // (SFM_MESH_BRICKS=1), kept as the measured experiment.
 bool bricks_enabled() {
-  const char* e = getenv("SFM_MESH_BRICKS");
+  const char* e = sfm::option("SFM_MESH_BRICKS");
   return e && e[0] == '1';
 }
 
@@ -3158,7 +3229,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     // Small tiles spread the (latency bound) step over more CUs; fall back to
     // 32 x 32 tiles when there would be more workgroups than CUs.
     int tile = 0;
-    const char* force_tile = getenv("SFM_MESH_TILE");  // experiment: 16 or 32
+    const char* force_tile = sfm::option("SFM_MESH_TILE");  // experiment: 16 or 32
     for (int t : {16, 32}) {
       if (force_tile && atoi(force_tile) != t) continue;
       const long long nw = (long long)p.B * ((p.Y + t - 1) / t) * ((p.X + t - 1) / t);
@@ -3183,7 +3254,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       q.n_wg = static_cast<int>(n_wg);
       SFM_HIP_CHECK(hipMemsetAsync(w.comm, 0, w.comm_bytes, st));
       sfm::prof_begin(sfm::kProfMesh, st);
-      const char* spec_env = getenv("SFM_MESH_SPECULATE");
+      const char* spec_env = sfm::option("SFM_MESH_SPECULATE");
       const bool spec = p.fire && !p.remove_drift && !(spec_env && spec_env[0] == '0');
       if (spec && tile == 16)
         hipLaunchKernelGGL(mesh_persist2d_spec_kernel<16>, dim3(q.n_wg), dim3(256), 0, st,
@@ -3354,7 +3425,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
         hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(tgrid), dim3(kBlock), 0, ls,
                            bi[0], bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
                            &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.nty,
-                           tiles.ntx);
+                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0});
       else if (tiles.tx == 64)
         SFM_TILED(16, 64, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
       else
@@ -3373,7 +3444,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
         hipLaunchKernelGGL(integrate_shared2d_kernel<false>, dim3(tgrid), dim3(kBlock), 0, ls,
                            d->x, d->v, d->a, prev_ptr, d->x, d->v, d->a, p, &w.scal[cur],
                            &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, 1, tiles.nty,
-                           tiles.ntx);
+                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0});
       else if (tiles.tx == 64)
         SFM_TILED(16, 64, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
       else
@@ -3635,5 +3706,490 @@ int sfm_mesh_shard_finish(const SfmMeshDesc* d, SfmMeshShard* sh, SfmFireState* 
   return SFM_OK;
 }
 #undef SFM_SHARD_DISPATCH
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// sfm_mesh_relax_banded: ONE mesh as bands of rows, the whole chunk of steps in
+// one C call (the step loop of sofima_amd/dist.py moved into the library).
+//
+// Every rank holds `n_local` consecutive bands; band g = rank * n_local + i.  A
+// band's arrays are its owned rows plus one halo row per existing neighbour.
+// Per step (mesh.py:436-499 split at its exchange points):
+//
+//   main stream                           comm stream
+//   edge tile rows of every local band
+//   -- event ---------------------------> rows at the band edges: device copies
+//   interior tile rows (last workgroup       between local bands, pack +
+//     of a band leaves its partial sums)     grouped RCCL send/recv + unpack
+//   -- event --------------------------->    between ranks, into the halo rows
+//                                          all-gather of the partial sums
+//   <------------------------------------ event
+//
+// i.e. the rows a neighbour needs leave while the interior is still being
+// integrated; only the 8-float all-gather (FIRE's `power` decides dt, alpha and
+// the velocity gate of the next step: mesh.py:455-492) is exposed.  In-plane
+// spring meshes run the fused tiled kernel (integrate_shared2d_kernel, state
+// ping-pong); everything else takes the advance / integrate pair on one stream.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int kMaxLocalBands = 16;
+constexpr int kMaxRowJobs = 4 * kMaxLocalBands;
+
+// Copies (x, v, a) of one mesh row between arrays of different row counts (a
+// packed buffer is an array with one row per plane).
+struct RowJob {
+  const float* src[3];
+  float* dst[3];
+  long long src_n, dst_n;      // component stride (floats)
+  long long src_plane, dst_plane;
+  long long src_off, dst_off;  // row * X
+};
+struct RowJobs {
+  int n;
+  int ncomp, planes, X;
+  RowJob job[kMaxRowJobs];
+};
+
+__global__ void __launch_bounds__(kBlock) band_rows_kernel(RowJobs jobs) {
+  const RowJob& j = jobs.job[blockIdx.z];
+  const int arr = blockIdx.y;
+  const long long per = (long long)jobs.planes * jobs.X;
+  for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < per * jobs.ncomp;
+       i += (long long)gridDim.x * kBlock) {
+    const int c = static_cast<int>(i / per);
+    const long long r = i % per;
+    const long long pl = r / jobs.X, xi = r % jobs.X;
+    j.dst[arr][c * j.dst_n + pl * j.dst_plane + j.dst_off + xi] =
+        j.src[arr][c * j.src_n + pl * j.src_plane + j.src_off + xi];
+  }
+}
+
+struct BandState {
+  MeshParams p;
+  MeshWorkspace w;
+  TilePlan tiles;
+  float* set[2][3];     // (x, v, a) ping-pong sets; set[0] = the caller's arrays
+  int grid;             // advance / integrate / finish grid
+  bool has_lo, has_hi;  // neighbours (any rank)
+  float* buf[4];        // packed rows: send lo, send hi, recv lo, recv hi
+};
+
+void launch_rows(const RowJobs& jobs, hipStream_t st) {
+  if (jobs.n == 0) return;
+  const long long per = (long long)jobs.planes * jobs.X * jobs.ncomp;
+  const int gx = static_cast<int>(std::min<long long>((per + kBlock - 1) / kBlock, 64));
+  hipLaunchKernelGGL(band_rows_kernel, dim3(gx, 3, jobs.n), dim3(kBlock), 0, st, jobs);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sfm_mesh_banded_scratch_bytes(const SfmBandedDesc* b) {
+  if (!b || !b->bands || b->n_local < 1) return 0;
+  const SfmMeshDesc& d = b->bands[0];
+  const size_t row = 3 * (size_t)d.ncomp * d.shape[0] * d.shape[1] * d.shape[3];
+  sfm::Carver c(nullptr);
+  const size_t total = (size_t)std::max(b->n_ranks, 1) * b->n_local;
+  c.take<float>(total * kNP);          // sums of all bands
+  c.take<float>(total * 2);            // e_kin, v_max of all bands
+  for (int i = 0; i < b->n_local; ++i)
+    for (int k = 0; k < 4; ++k) c.take<float>(row);
+  return c.total();
+}
+
+int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkStats* stats) {
+  if (!b || !b->bands || !b->shards || !fire || !stats)
+    return sfm::fail(SFM_ERR_INVALID, "banded: NULL argument");
+  const int nl = b->n_local;
+  const int n_ranks = std::max(b->n_ranks, 1);
+  if (nl < 1 || nl > kMaxLocalBands)
+    return sfm::fail(SFM_ERR_INVALID, "banded: 1..%d bands per rank", kMaxLocalBands);
+  if (b->rank < 0 || b->rank >= n_ranks) return sfm::fail(SFM_ERR_INVALID, "banded: rank");
+  if (n_ranks > 1 && !b->comm)
+    return sfm::fail(SFM_ERR_INVALID, "banded: %d ranks need a communicator", n_ranks);
+  const bool loopback = (b->flags & SFM_BANDED_LOOPBACK) != 0;
+  if (loopback && !b->comm)
+    return sfm::fail(SFM_ERR_INVALID, "banded: loop-back needs a communicator");
+  if (b->comm && (sfm::comm_size(b->comm) != n_ranks || sfm::comm_rank(b->comm) != b->rank))
+    return sfm::fail(SFM_ERR_INVALID, "banded: communicator is rank %d of %d, desc says %d of %d",
+                     sfm::comm_rank(b->comm), sfm::comm_size(b->comm), b->rank, n_ranks);
+  const int total = n_ranks * nl;
+  if (total > kMaxBlocks) return sfm::fail(SFM_ERR_INVALID, "banded: too many bands");
+  const SfmMeshDesc& d0 = b->bands[0];
+  hipStream_t st = static_cast<hipStream_t>(d0.stream);
+  hipStream_t xs = b->comm_stream ? static_cast<hipStream_t>(b->comm_stream) : st;
+  const int iters = d0.num_iters;
+  if (iters < 0) return sfm::fail(SFM_ERR_INVALID, "num_iters < 0");
+
+  // scratch
+  const size_t need = sfm_mesh_banded_scratch_bytes(b);
+  if (!b->scratch || b->scratch_bytes < need)
+    return sfm::fail(SFM_ERR_WORKSPACE, "banded scratch needs %zu bytes, got %zu", need,
+                     b->scratch_bytes);
+  sfm::Carver carve_s(b->scratch);
+  float* sums_all = carve_s.take<float>((size_t)total * kNP);
+  float* stats_all = carve_s.take<float>((size_t)total * 2);
+  const size_t row_floats = (size_t)d0.ncomp * d0.shape[0] * d0.shape[1] * d0.shape[3];
+
+  BandState bs[kMaxLocalBands];
+  bool fused = true;
+  for (int i = 0; i < nl; ++i) {
+    const SfmMeshDesc& d = b->bands[i];
+    SfmMeshShard& sh = b->shards[i];
+    if (d.stream != d0.stream || d.num_iters != iters || d.ncomp != d0.ncomp ||
+        d.shape[0] != d0.shape[0] || d.shape[1] != d0.shape[1] || d.shape[3] != d0.shape[3] ||
+        d.fire != d0.fire || d.remove_drift != d0.remove_drift)
+      return sfm::fail(SFM_ERR_INVALID, "banded: the bands of a mesh share shape and config");
+    const int g = b->rank * nl + i;
+    sh.n_ranks = total;
+    sh.sums = sums_all;
+    sh.my_sums = sums_all + (size_t)g * kNP;
+    BandState& s = bs[i];
+    if (int rc = shard_setup(&d, &sh, &s.p, &s.w)) return rc;
+    s.w = carve_for(&d, d.workspace, &s.tiles);
+    s.grid = grid_for(s.p.N);
+    s.has_lo = g > 0;
+    s.has_hi = g < total - 1;
+    if (s.has_lo != (sh.own_y0 > 0) || s.has_hi != (sh.own_y1 < s.p.Y) ||
+        sh.own_y0 > 1 || s.p.Y - sh.own_y1 > 1)
+      return sfm::fail(SFM_ERR_INVALID,
+                       "banded: band %d of %d owns rows [%d, %d) of %d: one halo row per "
+                       "existing neighbour", g, total, sh.own_y0, sh.own_y1, s.p.Y);
+    for (int k = 0; k < 4; ++k) s.buf[k] = carve_s.take<float>(3 * row_floats);
+    s.set[0][0] = d.x;
+    s.set[0][1] = d.v;
+    s.set[0][2] = d.a;
+    for (int k = 0; k < 3; ++k) s.set[1][k] = s.w.alt[k];
+    fused = fused && s.p.ncomp == 2 && s.p.force_kind == SFM_FORCE_SPRINGS &&
+            s.tiles.tx == kSX && s.w.alt[0] != nullptr;
+  }
+  const bool overlap = fused && xs != st && !(b->flags & SFM_BANDED_NO_OVERLAP);
+  const int C = d0.ncomp;
+  const int planes = d0.shape[0] * d0.shape[1], X = d0.shape[3];
+
+  // Row jobs of one exchange on buffer set `q`: `before` runs ahead of the RCCL
+  // group (local copies + packing), `after` behind it (unpacking).
+  auto array_side = [&](RowJob* j, bool src, const BandState& s, int q, int row) {
+    for (int k = 0; k < 3; ++k) {
+      if (src) j->src[k] = s.set[q][k]; else j->dst[k] = s.set[q][k];
+    }
+    const long long n = s.p.N, pl = (long long)s.p.Y * X, off = (long long)row * X;
+    if (src) { j->src_n = n; j->src_plane = pl; j->src_off = off; }
+    else { j->dst_n = n; j->dst_plane = pl; j->dst_off = off; }
+  };
+  auto buffer_side = [&](RowJob* j, bool src, float* buf) {
+    for (int k = 0; k < 3; ++k) {
+      float* base = buf + (size_t)k * row_floats;
+      if (src) j->src[k] = base; else j->dst[k] = base;
+    }
+    const long long n = (long long)planes * X;
+    if (src) { j->src_n = n; j->src_plane = X; j->src_off = 0; }
+    else { j->dst_n = n; j->dst_plane = X; j->dst_off = 0; }
+  };
+  auto build_jobs = [&](int q, RowJobs* before, RowJobs* after) {
+    before->n = after->n = 0;
+    before->ncomp = after->ncomp = C;
+    before->planes = after->planes = planes;
+    before->X = after->X = X;
+    for (int i = 0; i < nl; ++i) {
+      BandState& s = bs[i];
+      const SfmMeshShard& sh = b->shards[i];
+      const bool lo_remote = s.has_lo && (i == 0 || loopback);
+      const bool hi_remote = s.has_hi && (i == nl - 1 || loopback);
+      if (s.has_hi && !hi_remote) {
+        // local pair (i, i + 1): my last owned row -> its low halo row and back
+        BandState& t = bs[i + 1];
+        RowJob* j = &before->job[before->n++];
+        array_side(j, true, s, q, sh.own_y1 - 1);
+        array_side(j, false, t, q, b->shards[i + 1].own_y0 - 1);
+        j = &before->job[before->n++];
+        array_side(j, true, t, q, b->shards[i + 1].own_y0);
+        array_side(j, false, s, q, sh.own_y1);
+      }
+      if (lo_remote) {
+        RowJob* j = &before->job[before->n++];
+        array_side(j, true, s, q, sh.own_y0);
+        buffer_side(j, false, s.buf[0]);
+        j = &after->job[after->n++];
+        buffer_side(j, true, s.buf[2]);
+        array_side(j, false, s, q, sh.own_y0 - 1);
+      }
+      if (hi_remote) {
+        RowJob* j = &before->job[before->n++];
+        array_side(j, true, s, q, sh.own_y1 - 1);
+        buffer_side(j, false, s.buf[1]);
+        j = &after->job[after->n++];
+        buffer_side(j, true, s.buf[3]);
+        array_side(j, false, s, q, sh.own_y1);
+      }
+    }
+  };
+  RowJobs before[2], after[2];
+  build_jobs(0, &before[0], &after[0]);
+  if (fused) build_jobs(1, &before[1], &after[1]);
+
+  // The grouped point-to-point part of one exchange.  Between ranks: the first
+  // band's low edge <-> rank - 1, the last band's high edge <-> rank + 1.  Loop
+  // back (tests on one GPU): every edge between local bands travels through a
+  // self send / recv -- sends and receives to the same peer match in order.
+  const size_t cnt = 3 * row_floats;
+  auto p2p = [&](hipStream_t s_) -> int {
+    if (!b->comm) return SFM_OK;
+    bool any = false;
+    for (int i = 0; i < nl; ++i)
+      any = any || (bs[i].has_lo && (i == 0 || loopback)) || (bs[i].has_hi && (i == nl - 1 || loopback));
+    if (!any) return SFM_OK;
+    if (int rc = sfm::comm_group_begin(b->comm)) return rc;
+    int rc = SFM_OK;
+    auto note = [&](int r) { if (!rc) rc = r; };
+    if (bs[0].has_lo && b->rank > 0) {
+      note(sfm::comm_send(b->comm, bs[0].buf[0], cnt, b->rank - 1, s_));
+      note(sfm::comm_recv(b->comm, bs[0].buf[2], cnt, b->rank - 1, s_));
+    }
+    if (bs[nl - 1].has_hi && b->rank < n_ranks - 1) {
+      note(sfm::comm_send(b->comm, bs[nl - 1].buf[1], cnt, b->rank + 1, s_));
+      note(sfm::comm_recv(b->comm, bs[nl - 1].buf[3], cnt, b->rank + 1, s_));
+    }
+    if (loopback) {
+      for (int i = 0; i + 1 < nl; ++i) {
+        // band i's high edge -> band i + 1's low halo, and the reverse
+        note(sfm::comm_send(b->comm, bs[i].buf[1], cnt, b->rank, s_));
+        note(sfm::comm_recv(b->comm, bs[i + 1].buf[2], cnt, b->rank, s_));
+        note(sfm::comm_send(b->comm, bs[i + 1].buf[0], cnt, b->rank, s_));
+        note(sfm::comm_recv(b->comm, bs[i].buf[3], cnt, b->rank, s_));
+      }
+    }
+    return sfm::comm_group_end(b->comm, rc);
+  };
+  auto exchange = [&](int q, hipStream_t s_) -> int {
+    launch_rows(before[q], s_);
+    SFM_LAUNCH_CHECK();
+    if (int rc = p2p(s_)) return rc;
+    launch_rows(after[q], s_);
+    SFM_LAUNCH_CHECK();
+    return SFM_OK;
+  };
+  auto gather_sums = [&](hipStream_t s_) -> int {
+    if (n_ranks == 1 && !loopback) return SFM_OK;   // my_sums are rows of sums_all already
+    // in place: this rank's rows sit at their final position
+    return sfm_comm_allgather(b->comm, sums_all + (size_t)b->rank * nl * kNP, sums_all,
+                              (size_t)nl * kNP, s_);
+  };
+
+  hipEvent_t ev_edge = nullptr, ev_int = nullptr, ev_x = nullptr;
+  struct EventGuard {
+    hipEvent_t* e[3];
+    ~EventGuard() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); }
+  } guard{{&ev_edge, &ev_int, &ev_x}};
+  if (overlap) {
+    SFM_HIP_CHECK(hipEventCreateWithFlags(&ev_edge, hipEventDisableTiming));
+    SFM_HIP_CHECK(hipEventCreateWithFlags(&ev_int, hipEventDisableTiming));
+    SFM_HIP_CHECK(hipEventCreateWithFlags(&ev_x, hipEventDisableTiming));
+  }
+
+  // -- begin: scalars, a = F(x) + pull on the local rows of every band --------
+  Scalars s0;
+  std::memset(&s0, 0, sizeof(s0));
+  s0.dt = fire->dt;
+  s0.alpha = fire->alpha;
+  s0.n_pos = 0;
+  s0.cap = fire->cap;
+  s0.gate = 1.f;
+  const float cap0 = fire->cap;
+  for (int i = 0; i < nl; ++i) {
+    BandState& s = bs[i];
+    const SfmMeshDesc& d = b->bands[i];
+    SFM_HIP_CHECK(hipMemcpyAsync(&s.w.scal[0], &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+    if (fused) {
+      SFM_HIP_CHECK(hipMemsetAsync(s.w.ticket, 0, 2 * sizeof(int), st));
+      SFM_HIP_CHECK(hipMemsetAsync(s.w.tile_part, 0, (size_t)s.tiles.tiles * kNP * sizeof(u64), st));
+    }
+    if (s.p.ncomp == 2)
+      hipLaunchKernelGGL(force_kernel<2>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.prev, d.a,
+                         s.p, cap0, s.p.has_prev);
+    else
+      hipLaunchKernelGGL(force_kernel<3>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.prev, d.a,
+                         s.p, cap0, s.p.has_prev);
+    SFM_LAUNCH_CHECK();
+  }
+  // Everything that touches the communicator runs on the comm stream when there
+  // is one (fork from / join into the main stream around `fn`).
+  auto on_comm_stream = [&](auto fn) -> int {
+    if (!overlap) return fn(st);
+    SFM_HIP_CHECK(hipEventRecord(ev_int, st));
+    SFM_HIP_CHECK(hipStreamWaitEvent(xs, ev_int, 0));
+    if (int rc = fn(xs)) return rc;
+    SFM_HIP_CHECK(hipEventRecord(ev_x, xs));
+    SFM_HIP_CHECK(hipStreamWaitEvent(st, ev_x, 0));
+    return SFM_OK;
+  };
+  // the halo rows' a (and, from the second chunk on, nothing else) is stale
+  if (int rc = on_comm_stream([&](hipStream_t s_) { return exchange(0, s_); })) return rc;
+
+  int in = 0, cur = 0;
+  for (int k = 0; k < iters; ++k) {
+    const int pending = k > 0 ? 1 : 0;
+    if (fused) {
+      const int out = in ^ 1;
+      auto launch = [&](BandState& s, const SfmMeshDesc& d, int mode, int ty_a, int ty_b,
+                        int rows_here) {
+        const long long pl = (long long)s.p.B * s.p.Z;
+        const int grid = static_cast<int>(pl * rows_here * s.tiles.ntx);
+        BandArgs ba{sums_all, nullptr, total, static_cast<int>(s.tiles.tiles), mode, ty_a, ty_b};
+        ba.my_sums = sums_all + (size_t)(b->rank * nl + (&s - bs)) * kNP;
+        hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(grid), dim3(kBlock), 0, st,
+                           s.set[in][0], s.set[in][1], s.set[in][2], d.prev, s.set[out][0],
+                           s.set[out][1], s.set[out][2], s.p, &s.w.scal[cur], &s.w.scal[cur ^ 1],
+                           cap0, s.w.tile_part, s.w.ticket, pending ? 3 : 0, s.tiles.nty,
+                           s.tiles.ntx, ba);
+      };
+      // edge tile rows of a band: those holding its first / last owned row
+      int ty_a[kMaxLocalBands], ty_b[kMaxLocalBands];
+      bool split[kMaxLocalBands];
+      for (int i = 0; i < nl; ++i) {
+        ty_a[i] = b->shards[i].own_y0 / kSY;
+        ty_b[i] = (b->shards[i].own_y1 - 1) / kSY;
+        const int n_edge = ty_a[i] == ty_b[i] ? 1 : 2;
+        split[i] = overlap && bs[i].tiles.nty > n_edge;
+      }
+      sfm::prof_begin(sfm::kProfMesh, st);
+      for (int i = 0; i < nl; ++i) {
+        if (split[i])
+          launch(bs[i], b->bands[i], 1, ty_a[i], ty_b[i], ty_a[i] == ty_b[i] ? 1 : 2);
+        else
+          launch(bs[i], b->bands[i], 0, 0, 0, bs[i].tiles.nty);
+        SFM_LAUNCH_CHECK();
+      }
+      if (overlap) {
+        SFM_HIP_CHECK(hipEventRecord(ev_edge, st));
+        SFM_HIP_CHECK(hipStreamWaitEvent(xs, ev_edge, 0));
+        if (int rc = exchange(out, xs)) return rc;
+        for (int i = 0; i < nl; ++i)
+          if (split[i]) {
+            const int n_edge = ty_a[i] == ty_b[i] ? 1 : 2;
+            launch(bs[i], b->bands[i], 2, ty_a[i], ty_b[i], bs[i].tiles.nty - n_edge);
+            SFM_LAUNCH_CHECK();
+          }
+        sfm::prof_end(sfm::kProfMesh, st);
+        SFM_HIP_CHECK(hipEventRecord(ev_int, st));
+        SFM_HIP_CHECK(hipStreamWaitEvent(xs, ev_int, 0));
+        if (d0.fire)
+          if (int rc = gather_sums(xs)) return rc;
+        SFM_HIP_CHECK(hipEventRecord(ev_x, xs));
+        SFM_HIP_CHECK(hipStreamWaitEvent(st, ev_x, 0));
+      } else {
+        sfm::prof_end(sfm::kProfMesh, st);
+        if (int rc = exchange(out, st)) return rc;
+        if (d0.fire)
+          if (int rc = gather_sums(st)) return rc;
+      }
+      in = out;
+      if (d0.fire) cur ^= 1;
+    } else {
+      // advance / integrate pair in place; the rows were exchanged after the
+      // previous integrate (or by `begin`)
+      for (int i = 0; i < nl; ++i) {
+        BandState& s = bs[i];
+        const SfmMeshDesc& d = b->bands[i];
+        if (s.p.ncomp == 2)
+          hipLaunchKernelGGL(advance_kernel<2>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, d.a,
+                             s.p, &s.w.scal[cur], &s.w.scal[cur ^ 1], sums_all, total, pending,
+                             s.w.colsum);
+        else
+          hipLaunchKernelGGL(advance_kernel<3>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, d.a,
+                             s.p, &s.w.scal[cur], &s.w.scal[cur ^ 1], sums_all, total, pending,
+                             s.w.colsum);
+        SFM_LAUNCH_CHECK();
+      }
+      cur ^= 1;
+      sfm::prof_begin(sfm::kProfMesh, st);
+      for (int i = 0; i < nl; ++i) {
+        BandState& s = bs[i];
+        const SfmMeshDesc& d = b->bands[i];
+        if (s.p.ncomp == 2)
+          hipLaunchKernelGGL(integrate_kernel<2>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, d.a,
+                             d.prev, s.p, &s.w.scal[cur], cap0, s.w.partials);
+        else
+          hipLaunchKernelGGL(integrate_kernel<3>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, d.a,
+                             d.prev, s.p, &s.w.scal[cur], cap0, s.w.partials);
+        SFM_LAUNCH_CHECK();
+        if (s.p.fire) {
+          hipLaunchKernelGGL(shard_sums_kernel, dim3(1), dim3(kBlock), 0, st, s.w.partials,
+                             s.grid, sums_all + (size_t)(b->rank * nl + i) * kNP);
+          SFM_LAUNCH_CHECK();
+        }
+      }
+      sfm::prof_end(sfm::kProfMesh, st);
+      if (int rc = exchange(0, st)) return rc;
+      if (d0.fire)
+        if (int rc = gather_sums(st)) return rc;
+    }
+  }
+
+  // -- finish: pending gate / drift of the last step, statistics ---------------
+  const Scalars* final_scal = nullptr;
+  for (int i = 0; i < nl; ++i) {
+    BandState& s = bs[i];
+    const SfmMeshDesc& d = b->bands[i];
+    if (in == 1) {
+      const size_t bytes = (size_t)s.p.ncomp * s.p.N * sizeof(float);
+      for (int k = 0; k < 3; ++k)
+        SFM_HIP_CHECK(hipMemcpyAsync(s.set[0][k], s.set[1][k], bytes, hipMemcpyDeviceToDevice, st));
+    }
+    int mode = iters > 0 ? 1 : 0;
+    int c = cur;
+    if (fused && iters > 0 && s.p.fire) {
+      // same (band-order) reduction as the step kernels', then finish with the
+      // scalars as they are
+      hipLaunchKernelGGL(band_scalars_kernel, dim3(1), dim3(64), 0, st, &s.w.scal[c],
+                         &s.w.scal[c ^ 1], sums_all, total, s.p);
+      SFM_LAUNCH_CHECK();
+      c ^= 1;
+      mode = 2;
+    }
+    if (s.p.ncomp == 2)
+      hipLaunchKernelGGL(finish_kernel<2>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, s.p,
+                         &s.w.scal[c], &s.w.scal[c ^ 1], sums_all, total, mode, s.w.stat_part,
+                         s.w.colsum);
+    else
+      hipLaunchKernelGGL(finish_kernel<3>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, s.p,
+                         &s.w.scal[c], &s.w.scal[c ^ 1], sums_all, total, mode, s.w.stat_part,
+                         s.w.colsum);
+    SFM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(kBlock), 0, st, s.w.stat_part, s.grid,
+                       stats_all + (size_t)(b->rank * nl + i) * 2);
+    SFM_LAUNCH_CHECK();
+    // scal[c ^ 1]: the chunk's final scalars (identical in every band)
+    if (i == 0) final_scal = &s.w.scal[c ^ 1];
+  }
+  if (n_ranks > 1)
+    if (int rc = on_comm_stream([&](hipStream_t s_) {
+          return sfm_comm_allgather(b->comm, stats_all + (size_t)b->rank * nl * 2, stats_all,
+                                    (size_t)nl * 2, s_);
+        }))
+      return rc;
+  Scalars s1;
+  float hs[2 * kMaxBlocks];
+  SFM_HIP_CHECK(hipMemcpyAsync(&s1, final_scal, sizeof(s1), hipMemcpyDeviceToHost, st));
+  SFM_HIP_CHECK(hipMemcpyAsync(hs, stats_all, sizeof(float) * 2 * total, hipMemcpyDeviceToHost, st));
+  SFM_HIP_CHECK(hipStreamSynchronize(st));
+  if (d0.fire) {
+    fire->dt = s1.dt;
+    fire->alpha = s1.alpha;
+    fire->n_pos = s1.n_pos;
+    fire->cap = s1.cap;
+  }
+  float ek = 0.f, vm = 0.f;
+  for (int g = 0; g < total; ++g) {   // band order, float32 like the device sums
+    ek = ek + hs[2 * g];
+    vm = std::max(vm, hs[2 * g + 1]);
+  }
+  stats->e_kin = ek;
+  stats->v_max = vm;
+  return SFM_OK;
+}
 
 }  // extern "C"

@@ -1294,7 +1294,7 @@ int surface_one(const SfmXcorrDesc* d, const Geo& g, float* surface) {
 
 // SFM_MASKED_DEADROWS=0: the peak sweeps of the masked path read every row.
 bool live_rows_enabled() {
-  const char* e = std::getenv("SFM_MASKED_DEADROWS");
+  const char* e = sfm::option("SFM_MASKED_DEADROWS");
   return !(e && e[0] == '0');
 }
 

@@ -214,7 +214,8 @@ struct MfmaArgs {
   // shader-clock probe: workgroup 0 leaves (core cycles, 10 ns wall ticks) of its
   // residency here (bench.py reports the sustained clock under this kernel);
   // clk[2]: dy tiles skipped by the pruning (low word) / drawn (high word), whole
-  // launch; clk[3]: column tiles left out of the computed dy tiles (count_tiles)
+  // launch; clk[3]: column tiles left out of the computed dy tiles; clk[4]: matrix
+  // instructions issued by the row loops (count_tiles)
   long long* clk;
   int prio_mode;      // experiment knob: 0 natural, 1 alternate per tile, 2 static
   // exact pruning of dy tiles (fused-peaks mode): tbound[b][p] bounds |surface|
@@ -240,6 +241,8 @@ __device__ __forceinline__ unsigned load_u32_guarded(const unsigned* base,
 __global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
   if (a.work_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     *a.work_counter = 0;  // the correlation kernel's patch queue
+  if (a.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    a.clk[2] = a.clk[3] = a.clk[4] = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int red[3][kThreads];
   const int b = blockIdx.x, s = blockIdx.y;
@@ -375,7 +378,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a) {
   if (a.work_counter && blockIdx.x == 0 && threadIdx.x == 0)
     *a.work_counter = 0;  // the correlation kernel's patch queue
-  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[2] = a.clk[3] = 0;  // tile counts
+  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[2] = a.clk[3] = a.clk[4] = 0;  // tile counts
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_c[2];
   __shared__ float s_mu[2];
@@ -1928,6 +1931,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   // at different times.
   int* next_lds = hot_lds + 1;
   int tiles_drawn = 0, tiles_skipped = 0, cols_skipped = 0;  // (wave-uniform; reported through a.clk)
+  long long mfma_issued = 0;  // matrix instructions this wave issued in the row loops
   if (a.prio_mode == 3) {
     // HW_REG_LDS_ALLOC[7:0] = LDS_BASE: 0 for the first workgroup of the CU.
     const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6) & 0xff;
@@ -2393,6 +2397,17 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           }
           ap += 4 * a.pa;
         }
+        {
+          // instructions of one row group of this variant: (ca, c) pairs whose
+          // column tile q = ca - c + cq0 is kept
+          int per_group = 0;
+#pragma unroll
+          for (int ca = 0; ca < NCA; ++ca)
+#pragma unroll
+            for (int c = 0; c < NCE; ++c)
+              per_group += (ca - c + NCE - 1 >= KS && ca - c + NCE - 1 < NQ - KS) ? 1 : 0;
+          mfma_issued += (long long)((yhi - ylo + 3) / 4) * per_group;
+        }
         };
         constexpr int kKs1 = col_skip_lo(NQ), kKs2 = col_skip_hi(NQ);
         constexpr int kKs3 = col_skip_2(NQ), kKs4 = col_skip_3(NQ);
@@ -2434,6 +2449,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           ap += 4 * a.pa;
           bp += 4 * a.pb;
         }
+        mfma_issued += (long long)((yhi - ylo + 3) / 4) * (NCA * NCE);
       }
 #endif
 
@@ -2804,6 +2820,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 3),
               static_cast<unsigned long long>(cols_skipped));
   }
+  if (a.count_tiles && a.clk && lane == 0)
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 4),
+              static_cast<unsigned long long>(mfma_issued));
 #ifdef SFM_MFMA_TIMING
   if (lane == 0 && wave == 0) {
     // HW_REG_HW_ID (4): [11:8] CU, [12] SH, [15:13] SE; HW_REG_XCC_ID (20): [3:0]
@@ -2829,13 +2848,13 @@ struct Variant {
 constexpr Variant kVariants[] = {{3, 4}, {4, 5}, {5, 6}, {6, 7}, {8, 9}, {10, 11}};
 
 bool exact_enabled() {
-  const char* e = std::getenv("SFM_MFMA_EXACT");
+  const char* e = sfm::option("SFM_MFMA_EXACT");
   return !(e && e[0] == '0');
 }
 
 // SFM_MFMA_PRUNE=0: every dy tile is computed (tests, measurements).
 bool prune_enabled() {
-  const char* e = std::getenv("SFM_MFMA_PRUNE");
+  const char* e = sfm::option("SFM_MFMA_PRUNE");
   return !(e && e[0] == '0');
 }
 
@@ -2941,7 +2960,7 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
             &n, reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE, MODE>), kThreads,
             lds) != hipSuccess || n < 1)
       n = lds * 2 <= 160 * 1024 ? 2 : 1;
-    const char* cap = std::getenv("SFM_MFMA_MAX_WG_PER_CU");
+    const char* cap = sfm::option("SFM_MFMA_MAX_WG_PER_CU");
     if (cap && std::atoi(cap) > 0) n = std::min(n, std::atoi(cap));
     per_cu = n;
     per_cu_lds = lds;
@@ -2951,7 +2970,7 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, MODE>), dim3(grid),
                      dim3(kThreads), lds, st, a);
   sfm::prof_end(sfm::kProfXcorr, st);
-  sfm::prof_clock(sfm::kProfXcorr, a.clk, st, 4);
+  sfm::prof_clock(sfm::kProfXcorr, a.clk, st, 5);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }
@@ -3062,7 +3081,7 @@ const int kMaskedPasses[8][2] = {
 
 // SFM_MASKED_FAST=0 (tests): every patch takes all eight passes.
 bool masked_all_passes() {
-  const char* e = std::getenv("SFM_MASKED_FAST");
+  const char* e = sfm::option("SFM_MASKED_FAST");
   return e && e[0] == '0';
 }
 
@@ -3153,10 +3172,10 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   a.aux_n = w.aux_n;
   a.surface = surface;
   {
-    const char* e = std::getenv("SFM_MFMA_QUEUE");
+    const char* e = sfm::option("SFM_MFMA_QUEUE");
     a.work_counter = (e && e[0] == '0') ? nullptr : w.counter;
     a.clk = reinterpret_cast<long long*>(w.counter + 16);
-    const char* p = std::getenv("SFM_MFMA_PRIO");
+    const char* p = sfm::option("SFM_MFMA_PRIO");
     a.prio_mode = p ? std::atoi(p) : 0;
   }
   if (fp) {
@@ -3188,7 +3207,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     a.prune_k[2] = col_skip_2(a.nq);
     a.prune_k[3] = col_skip_3(a.nq);
     {
-      const char* e = std::getenv("SFM_MFMA_PROBE");  // "0": no seed probe
+      const char* e = sfm::option("SFM_MFMA_PROBE");  // "0": no seed probe
       a.probe = !(e && e[0] == '0');
     }
     a.count_tiles = sfm::profiling() ? 1 : 0;
@@ -3295,11 +3314,11 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
   g.batch = d->batch;
   g.all_passes = masked_all_passes() ? 1 : 0;
   {
-    const char* e = std::getenv("SFM_MASKED_DEADROWS");
+    const char* e = sfm::option("SFM_MASKED_DEADROWS");
     g.dead_rows = !(e && e[0] == '0');
   }
   {
-    const char* e = std::getenv("SFM_PHASE_XCD");
+    const char* e = sfm::option("SFM_PHASE_XCD");
     g.xcd_map = !(e && e[0] == '0');
   }
   g.maxima = maxima;

@@ -408,6 +408,139 @@ def relax_mesh_sharded(x, prev, config, mesh_force=None, group=None,
   return np.concatenate(owned, axis=-2), e_kin, t
 
 
+_COMM_STREAMS = {}
+
+
+def _comm_stream(dev):
+  """One side stream per device for the exchange leg of the banded step."""
+  import torch
+  key = torch.device(dev).index
+  if key not in _COMM_STREAMS:
+    _COMM_STREAMS[key] = torch.cuda.Stream(device=dev)
+  return _COMM_STREAMS[key]
+
+
+def relax_mesh_banded(x, prev, config, mesh_force=None, group=None,
+                      bands_per_rank: int = 1, comm: 'RcclComm | None' = None,
+                      loopback: bool = False, overlap: bool = True, timing=None):
+  """`mesh.relax_mesh(x, prev, config)` for ONE mesh spread over the ranks, with
+  the step loop inside the library (sfm_mesh_relax_banded).
+
+  Same split as `relax_mesh_sharded` -- world_size * bands_per_rank bands of
+  rows, one halo row per neighbour -- but a chunk of `config.num_iters` steps is
+  ONE C call: edge rows move between local bands by device copies and between
+  ranks through the library's RCCL communicator (`comm`, created over the
+  process group when there is more than one rank), the bands' partial sums are
+  all-gathered once per step, and the exchange of a step's edge rows overlaps
+  the integration of its interior rows on a second stream (`overlap`).
+  `loopback=True` sends the edges between LOCAL bands through RCCL self
+  send / recv as well (exercises the transport on one GPU).
+
+  Every rank passes the full arrays and gets the full relaxed mesh back:
+  (x [np.ndarray], e_kin history, steps).  `timing`, a dict, receives
+  `banded_chunk_s`: seconds inside the C calls.
+  """
+  import ctypes as C
+  import time
+  import torch
+  from . import _abi, _dev, mesh
+  rank, ws = world(group)
+  x = np.asarray(x, dtype=np.float32)
+  prev = None if prev is None else np.asarray(prev, dtype=np.float32)
+  if config.start_cap != config.final_cap:
+    if not config.fire:
+      raise NotImplementedError(
+          'Adaptive force capping is only supported with FIRE.')
+    if config.cap_scale <= 1:
+      raise ValueError(
+          'The scaling factor for the force cap has to be larger '
+          'than 1 when the initial and final cap are different.')
+  if config.remove_drift and x.ndim == 5:
+    raise NotImplementedError('per-column drift removal is not sharded')
+  spec = mesh._resolve_force(mesh.inplane_force if mesh_force is None else mesh_force)
+  if spec.kind == _abi.FORCE_EXTERNAL:
+    raise NotImplementedError('banded meshes need a native mesh_force')
+  dev = _dev.device()
+  lib = _abi.load()
+  own_comm = None
+  if comm is None and (ws > 1 or loopback):
+    comm = own_comm = RcclComm(group)
+  n_local = int(bands_per_rank)
+  n_bands = ws * n_local
+  bounds = band_bounds(x.shape[-2], n_bands)
+  global_nodes = int(np.prod(x.shape[1:]))
+
+  descs = (_abi.SfmMeshDesc * n_local)()
+  shards = (_abi.SfmMeshShard * n_local)()
+  keep = []
+  owns = []
+  for i in range(n_local):
+    g = rank * n_local + i
+    y0, y1 = bounds[g]
+    lo = y0 - (1 if g > 0 else 0)
+    hi = y1 + (1 if g < n_bands - 1 else 0)
+    x_t = _dev.as_device_f32(x[..., lo:hi, :], dev, copy=True)
+    v_t = torch.zeros_like(x_t)
+    a_t = torch.empty_like(x_t)
+    p_t = None if prev is None else _dev.as_device_f32(prev[..., lo:hi, :], dev, copy=True)
+    probe = mesh._base_desc(x_t, spec, config.k, config.stride, config.prefer_orig_order)
+    wsp = _dev.workspace(lib.sfm_mesh_workspace_bytes(C.byref(probe)), dev)
+    descs[i] = mesh._chunk_desc(x_t, v_t, a_t, p_t, config, spec, wsp)
+    shards[i].own_y0, shards[i].own_y1 = y0 - lo, y1 - lo
+    shards[i].global_nodes = global_nodes
+    keep.append((x_t, v_t, a_t, p_t, wsp))
+    owns.append((y0 - lo, y1 - lo))
+
+  bd = _abi.SfmBandedDesc()
+  bd.n_local = n_local
+  bd.bands = descs
+  bd.shards = shards
+  bd.comm = comm.handle if comm is not None else None
+  bd.rank, bd.n_ranks = rank, ws
+  bd.flags = (_abi.BANDED_LOOPBACK if loopback else 0) | (
+      0 if overlap else _abi.BANDED_NO_OVERLAP)
+  side = _comm_stream(dev) if overlap else None
+  bd.comm_stream = side.cuda_stream if side is not None else None
+  scratch = _dev.workspace(lib.sfm_mesh_banded_scratch_bytes(C.byref(bd)), dev)
+  bd.scratch = scratch.data_ptr()
+  bd.scratch_bytes = scratch.numel()
+
+  t = 0
+  dt, alpha, cap = config.dt, config.alpha, config.start_cap
+  e_kin = []
+  spent = 0.0
+  try:
+    while t < config.max_iters:
+      fire = _abi.SfmFireState()
+      fire.dt, fire.alpha, fire.n_pos, fire.cap = (
+          np.float32(dt), np.float32(alpha), 0, np.float32(cap))
+      stats = _abi.SfmChunkStats()
+      for i in range(n_local):
+        descs[i].stream = _dev.stream_ptr()
+      t0 = time.perf_counter()
+      _abi.check(lib.sfm_mesh_relax_banded(C.byref(bd), C.byref(fire), C.byref(stats)))
+      spent += time.perf_counter() - t0
+      t += config.num_iters
+      e_kin.append(float(stats.e_kin))
+      v_max = float(stats.v_max)
+      if config.fire:
+        dt, alpha, cap = (np.float32(fire.dt), np.float32(fire.alpha),
+                          np.float32(fire.cap))
+      if v_max < config.stop_v_max:
+        if np.float32(cap) >= np.float32(config.final_cap):
+          break
+        cap = min(cap * config.cap_scale, config.final_cap)
+  finally:
+    if own_comm is not None:
+      torch.cuda.synchronize(dev)
+      own_comm.close()
+  if timing is not None:
+    timing['banded_chunk_s'] = spent
+  local = [k[0][..., o[0]:o[1], :].cpu().numpy() for k, o in zip(keep, owns)]
+  owned = [s for part in gather_objects(local, group) for s in part]
+  return np.concatenate(owned, axis=-2), e_kin, t
+
+
 # ---------------------------------------------------------------------------
 # Section alignment in blocks (BASELINE configs[3]; em_alignment notebook,
 # cells 25 and 38-48): sections depend on the previous solved section, so the

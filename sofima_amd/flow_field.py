@@ -191,6 +191,17 @@ def _side_stream(dev) -> torch.cuda.Stream:
     return _SIDE_STREAMS[key]
 
 
+WORKSPACE_FRACTION = 0.6  # of the HBM that is free when a call is planned
+
+
+def _workspace_budget(dev) -> int:
+  """Bytes one flow_field() call may claim as workspace: a fraction of what
+  the driver reports free plus what torch's caching allocator holds unused."""
+  free, _ = torch.cuda.mem_get_info(dev)
+  cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+  return int(WORKSPACE_FRACTION * (free + max(cached, 0)))
+
+
 def _run_batches_dev(res: _Resident, desc: _abi.SfmXcorrDesc, starts: torch.Tensor,
                      batch_size: int, progress_fn=None) -> torch.Tensor:
   """Enqueues every batch; `starts` is the device tensor [2, n, dim] of pre /
@@ -204,14 +215,24 @@ def _run_batches_dev(res: _Resident, desc: _abi.SfmXcorrDesc, starts: torch.Tens
   # One C call carries several reference batches (`group` rows each keep the
   # batch-coupled behaviours): fewer, larger launches fill the chip even when
   # the reference batch is small.
-  per_call = max(1, LAUNCH_PATCHES // batch_size)
-  desc.batch = min(per_call, n_batches) * batch_size
+  per_call = min(max(1, LAUNCH_PATCHES // batch_size), n_batches)
   desc.group = batch_size
   desc.pre_starts = starts.data_ptr()
   desc.post_starts = starts.data_ptr()
-  need = lib.sfm_xcorr_workspace_bytes(C.byref(desc))
-  if need == 0:
-    _abi.check(-1)
+  n_lanes = 2 if OVERLAP_CALLS else 1
+  # LAUNCH_PATCHES is an upper bound only: the workspace grows with patches x
+  # surface area (26 GB for a whole 8192^2 pair of 160^2 patches), so the call
+  # size is halved until every lane's workspace fits a fraction of the memory
+  # that is free right now (other ranks / threads / jobs may share the GPU).
+  budget = _workspace_budget(res.dev)
+  while True:
+    desc.batch = per_call * batch_size
+    need = lib.sfm_xcorr_workspace_bytes(C.byref(desc))
+    if need == 0:
+      _abi.check(-1)
+    if per_call == 1 or need * n_lanes <= budget:
+      break
+    per_call = max(1, per_call // 2)
   row_bytes = batch_size * nd * 4
   it = iter(range(n_batches) if progress_fn is None else progress_fn)
   # Consecutive calls alternate between the current stream and a side stream
@@ -646,6 +667,11 @@ class JAXMaskedXCorrWithStatsCalculator:
                                ('post', post_targeting_field, post_targeting_step)):
       if field is None or tstep is None:
         continue
+      if isinstance(field, np.ndarray) and field.dtype == np.float64:
+        # the reference truncates the float64 value (.astype(int),
+        # flow_field.py:634): truncate before the float32 rounding can move a
+        # value across an integer (pixel offsets are exact in float32)
+        field = np.trunc(np.nan_to_num(field))
       f = _dev.as_device_f32(field, dev, copy=False)
       offs = torch.empty((total, nd), dtype=torch.int32, device=dev)
       keep += [f, offs]

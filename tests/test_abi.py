@@ -33,7 +33,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_channel(lib):
-  assert lib.sfm_version() == 3
+  assert lib.sfm_version() == 4
   # A NULL descriptor is rejected with a message, not a crash.
   rc = lib.sfm_mesh_force(None, None)
   assert rc == -1
@@ -43,6 +43,22 @@ def test_version_and_error_channel(lib):
   n = ctypes.c_int(-5)
   assert lib.sfm_device_count(ctypes.byref(n)) == 0
   assert n.value >= 0
+
+
+def test_option_table(lib):
+  """Explicit switches win over the environment, NULL hides both."""
+  assert lib.sfm_set_option(b'NOT_OURS', b'1') == -1
+  os.environ['SFM_TEST_SWITCH'] = 'env'
+  try:
+    assert _abi.get_option('SFM_TEST_SWITCH') == 'env'
+    with _abi.option('SFM_TEST_SWITCH', 7):
+      assert _abi.get_option('SFM_TEST_SWITCH') == '7'
+    assert _abi.get_option('SFM_TEST_SWITCH') == 'env'
+    _abi.set_option('SFM_TEST_SWITCH', None)
+    assert _abi.get_option('SFM_TEST_SWITCH') is None
+  finally:
+    del os.environ['SFM_TEST_SWITCH']
+    _abi.set_option('SFM_TEST_SWITCH', None)
 
 
 def test_struct_layouts_match_header():
@@ -64,6 +80,7 @@ def test_struct_layouts_match_header():
                      ('SfmFlowStartsDesc', _abi.SfmFlowStartsDesc),
                      ('SfmFlowScatterDesc', _abi.SfmFlowScatterDesc),
                      ('SfmMeshShard', _abi.SfmMeshShard),
+                     ('SfmBandedDesc', _abi.SfmBandedDesc),
                      ('SfmTargetMeshDesc', _abi.SfmTargetMeshDesc)):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text,
                      re.S).group(1)

@@ -133,3 +133,128 @@ def test_block_chain_on_device_vs_oracle(gpu):
   for b in range(3):
     np.testing.assert_array_equal(np.isnan(blocks[b]), np.isnan(wb[b]))
     np.testing.assert_allclose(np.nan_to_num(blocks[b]), np.nan_to_num(wb[b]), atol=2e-2)
+
+
+# ---------------------------------------------------------------------------
+# The C-side step loop (sfm_mesh_relax_banded)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('drift,fire', [(False, True), (True, True), (False, False)])
+@pytest.mark.parametrize('n_bands,mode', [(1, 'plain'), (2, 'plain'), (4, 'plain'),
+                                          (3, 'serial'), (2, 'loopback'), (4, 'loopback')])
+def test_banded_c_loop_fused_kernel(gpu, n_bands, mode, drift, fire):
+  """One mesh wide enough for the fused tiled kernel (X >= 40), split into
+  bands stepped by ONE C call per chunk: local copies / no-overlap single
+  stream / RCCL self send-recv between the bands all follow the un-split
+  relaxation (2e-4 of the displacement scale) and the oracle."""
+  from sofima_amd import dist as sdist, mesh
+  x0, prev, cfg = _case((2, 3, 75, 70), drift, fire)
+  gx, ge, gt = sdist.relax_mesh_banded(
+      x0, prev, cfg, bands_per_rank=n_bands, loopback=(mode == 'loopback'),
+      overlap=(mode != 'serial'))
+  wx, we, wt = mesh_oracle.relax_mesh(x0, prev, cfg)
+  sx, se, st = mesh.relax_mesh(x0, prev, cfg)
+  assert gt == wt == st
+  scale = np.abs(wx).max()
+  np.testing.assert_allclose(gx, wx, atol=1e-3 * scale)
+  np.testing.assert_allclose(ge, we, rtol=1e-2)
+  np.testing.assert_allclose(gx, np.array(sx), atol=2e-4 * scale)
+  np.testing.assert_allclose(ge, se, rtol=2e-3)
+
+
+def test_banded_c_loop_modes_are_bit_identical(gpu):
+  """Overlapped (edge tiles first, exchange on the second stream), serial and
+  loop-back runs of the same split compute the same numbers."""
+  from sofima_amd import dist as sdist
+  x0, prev, cfg = _case((2, 2, 150, 64), True)
+  a = sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=3)
+  b = sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=3, overlap=False)
+  c = sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=3, loopback=True)
+  np.testing.assert_array_equal(a[0], b[0])
+  np.testing.assert_array_equal(a[0], c[0])
+  assert a[1] == b[1] == c[1] and a[2] == b[2] == c[2]
+
+
+@pytest.mark.parametrize('n_bands', [1, 3])
+def test_banded_c_loop_two_launch_fallback(gpu, n_bands):
+  """Meshes the fused kernel does not take (narrow in-plane mesh, volumetric
+  mesh) run the advance / integrate pair inside the same C loop."""
+  from sofima_amd import dist as sdist, mesh
+  x0, prev, cfg = _case((2, 2, 61, 33), True)
+  gx, ge, gt = sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=n_bands)
+  sx, se, st = mesh.relax_mesh(x0, prev, cfg)
+  assert gt == st
+  scale = np.abs(np.array(sx)).max()
+  np.testing.assert_allclose(gx, np.array(sx), atol=2e-4 * scale)
+  rng = np.random.default_rng(5)
+  x3 = (rng.standard_normal((3, 6, 31, 12)) * 0.5).astype(np.float32)
+  p3 = (rng.standard_normal((3, 6, 31, 12)) * 4).astype(np.float32)
+  cfg3 = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(20, 20, 20),
+                                num_iters=40, max_iters=80, stop_v_max=1e-9, dt_max=1000,
+                                start_cap=0.01, final_cap=10)
+  gx, ge, gt = sdist.relax_mesh_banded(x3, p3, cfg3, mesh_force=mesh.elastic_mesh_3d,
+                                       bands_per_rank=n_bands)
+  sx, se, st = mesh.relax_mesh(x3, p3, cfg3, mesh_force=mesh.elastic_mesh_3d)
+  assert gt == st
+  np.testing.assert_allclose(gx, np.array(sx), atol=2e-4 * np.abs(np.array(sx)).max())
+
+
+def test_banded_c_loop_step_cost(gpu):
+  """[2, 64, 204, 204] (the montage size): the banded step costs at most 1.3x the
+  un-split step on the same GPU (the Python-driven split step was 5.7x)."""
+  import time
+  import torch
+  from sofima_amd import dist as sdist, mesh
+  rng = np.random.default_rng(11)
+  shape = (2, 64, 204, 204)
+  prev = (rng.standard_normal(shape) * 2).astype(np.float32)
+  x0 = np.zeros(shape, np.float32)
+  iters = 300
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(20., 20.),
+                               num_iters=iters, max_iters=iters, stop_v_max=1e-9,
+                               dt_max=1000, start_cap=0.01, final_cap=10,
+                               prefer_orig_order=True)
+  x_d = torch.from_numpy(x0).cuda()
+  p_d = torch.from_numpy(prev).cuda()
+  mesh.relax_mesh(x_d, p_d, cfg)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  sx, _, _ = mesh.relax_mesh(x_d, p_d, cfg)
+  torch.cuda.synchronize()
+  whole = (time.perf_counter() - t0) / iters
+  res = {}
+  for nb in (2, 4):
+    sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=nb)
+    tm = {}
+    gx, _, _ = sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=nb, timing=tm)
+    res[nb] = tm['banded_chunk_s'] / iters
+    np.testing.assert_allclose(gx, np.array(sx), atol=2e-4 * np.abs(gx).max())
+  print('un-split %.1f us/step; banded %s' % (
+      whole * 1e6, {k: round(v * 1e6, 1) for k, v in res.items()}))
+  assert res[2] <= 1.3 * whole and res[4] <= 1.3 * whole, (whole, res)
+
+
+def test_bench_runs_as_two_ranks(gpu):
+  """`bench.py --gpus 2` end to end: spawn_ranks -> torch.distributed.run -> two
+  ranks (gloo, sharing this GPU) -> barrier-bracketed timing, max over ranks,
+  one JSON line from rank 0 with the whole-job aggregate."""
+  import json
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, SFM_BENCH_BACKEND='gloo', SFM_BENCH_ONE_DEVICE='1')
+  cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--size', '1024',
+         '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--mesh-iters', '100',
+         '--sustain', '0.5']
+  out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, out.stdout[-2000:]
+  line = json.loads(lines[0])
+  assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1
+  assert line['scaling'] == 'weak' and line['unit'] == 'Mpix/s'
+  # whole-job aggregate: 2 ranks x 1024^2 pixels x steps / max-over-ranks time
+  want = 2 * 1024 * 1024 * 2 / (line['flow_ms_per_step'] * 2 * 1e-3) / 1e6
+  assert abs(line['value'] - want) <= 1e-6 * want
+  assert line['roofline'] and line['mesh']['value'] > 0
+  assert line['sustained']['steps'] >= 1

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import flow_oracle
-from tests.util import check_flow
+from tests.util import check_flow, em_texture
 
 pytestmark = pytest.mark.gpu
 
@@ -733,6 +733,10 @@ def test_device_plan_equals_host_plan(gpu, nd):
     patch = tuple(int(v) for v in rng.integers(8, 20, nd))
     post_patch = patch if trial % 2 else tuple(max(4, p - int(rng.integers(0, 6)))
                                                for p in patch)
+    if trial == 0:
+      # post patch LARGER than the pre patch by an odd amount: the pre offset is
+      # NumPy's floor division, -1 // 2 == -1 (flow_field.py:620)
+      post_patch = tuple(p + 1 + 2 * int(rng.integers(0, 2)) for p in patch)
     step = tuple(int(v) for v in rng.integers(3, 9, nd))
     pre = rng.integers(0, 256, shape).astype(np.uint8)
     post = rng.integers(0, 256, shape).astype(np.uint8)
@@ -1027,3 +1031,42 @@ def test_masked_overlap_rule_skips_are_bit_identical(gpu, monkeypatch, py, px, q
       b = calc.flow_field(pre, post, 160, 40, pre_mask=masks[0], post_mask=masks[1], **kw)
       monkeypatch.delenv('SFM_MASKED_DEADROWS')
       np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_workspace_budget_only_changes_the_call_size(gpu):
+  """LAUNCH_PATCHES is an upper bound: when the workspace of a whole pair does
+  not fit the free-memory budget the call is cut into smaller ones (whole
+  reference batches), and the field is the same."""
+  from sofima_amd import flow_field as ff
+  rng = np.random.default_rng(77)
+  base = em_texture(rng, (420, 460))
+  pre, post = base[8:400, 10:440].copy(), base[5:397, 14:444].copy()
+  calc = ff.JAXMaskedXCorrWithStatsCalculator()
+  want = calc.flow_field(pre, post, 48, 12, batch_size=32)
+  calls = []
+  orig = ff._abi.load().sfm_xcorr_peaks
+  frac = ff.WORKSPACE_FRACTION
+  try:
+    ff.WORKSPACE_FRACTION = 1e-12          # nothing fits: one batch per call
+    lib = ff._abi.load()
+
+    class Spy:
+      def __getattr__(self, name):
+        if name == 'sfm_xcorr_peaks':
+          def f(desc, out):
+            calls.append(int(desc._obj.batch))
+            return orig(desc, out)
+          return f
+        return getattr(lib, name)
+
+    load = ff._abi.load
+    ff._abi.load = lambda: Spy()
+    try:
+      got = calc.flow_field(pre, post, 48, 12, batch_size=32)
+    finally:
+      ff._abi.load = load
+  finally:
+    ff.WORKSPACE_FRACTION = frac
+  assert len(calls) > 1 and set(calls) == {32}
+  np.testing.assert_array_equal(got, want)
