@@ -1048,12 +1048,39 @@ __device__ __forceinline__ float lane_right(float v) {
 // travel to the neighbour while the interior is computed: `ty_mode` 1 = only
 // tile rows ty_a / ty_b, 2 = all other tile rows, 0 = all; `total_tiles` counts
 // the tiles of both launches (ticket / partial-sum slots are per tile).
+// One band of a multi-band launch (device memory, one entry per local band and
+// state parity): every local band of a mesh is stepped by the SAME launch -- a
+// workgroup finds its band from its block index -- and a band writes the rows
+// at its edges straight into the neighbour's halo rows (or into the packed
+// send buffer of a neighbour on another GPU), so a step of any number of local
+// bands is one launch (two when the edge tile rows go first).
+struct BandDev {
+  const float* in[3];   // x, v, a of the step's input set
+  float* out[3];
+  const float* prev;
+  u64* partials;
+  int* ticket;
+  float* my_sums;
+  const Scalars* scal_in;
+  Scalars* scal_out;
+  float* nb[2][3];      // destination arrays of my first / last owned row (or null)
+  long long nb_n[2];    // their component stride,
+  long long nb_plane[2];  // plane stride
+  long long nb_off[2];  // and row offset (row * X)
+  long long N;
+  int Y, own_y0, own_y1;
+  int nty, tiles, ty_a, ty_b;
+  int base[3];          // first block of this band in a launch of ty_mode 0 / 1 / 2
+};
+
 struct BandArgs {
   const float* sums;   // [n_bands, kNP] or nullptr: not in band mode
   float* my_sums;      // [kNP]
   int n_bands;
   int total_tiles;     // 0: gridDim.x
   int ty_mode, ty_a, ty_b;
+  const BandDev* multi;  // multi-band launch: the per-band fields above and the
+  int n_multi;           // kernel's array / scalar arguments come from here
 };
 
 // Sum of the bands' partial sums in band order + the FIRE update from them
@@ -1082,11 +1109,11 @@ __global__ void band_scalars_kernel(const Scalars* __restrict__ scal_in,
 template <bool FUSED>
 __global__ void __launch_bounds__(kBlock, SFM_LBT)
 integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_in,
-                          const float* __restrict__ prev, float* x_out, float* v_out,
+                          const float* prev, float* x_out, float* v_out,
                           float* a_out, MeshParams p,
-                          const Scalars* __restrict__ scal_in,
-                          Scalars* __restrict__ scal_out, float fixed_cap,
-                          u64* __restrict__ partials, int* __restrict__ ticket,
+                          const Scalars* scal_in,
+                          Scalars* scal_out, float fixed_cap,
+                          u64* partials, int* ticket,
                           int pending, int nty, int ntx, BandArgs bd) {
   constexpr int C = 2;
   constexpr int TW = 64;         // columns -1 .. kSX of the tile
@@ -1094,16 +1121,53 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
   __shared__ float xt[C][(kSY + 2) * TW];
   __shared__ float lds[kNP * kBlock];
   __shared__ int s_last;
+  int block = blockIdx.x;   // block index within the band
+  float* nb_dst[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  long long nb_n[2] = {0, 0}, nb_plane[2] = {0, 0}, nb_off[2] = {0, 0};
+  if (bd.multi) {
+    int bi = 0;
+    while (bi + 1 < bd.n_multi && block >= bd.multi[bi + 1].base[bd.ty_mode]) ++bi;
+    const BandDev& bb = bd.multi[bi];
+    block -= bb.base[bd.ty_mode];
+    x_in = bb.in[0];
+    v_in = bb.in[1];
+    a_in = bb.in[2];
+    x_out = bb.out[0];
+    v_out = bb.out[1];
+    a_out = bb.out[2];
+    prev = bb.prev;
+    partials = bb.partials;
+    ticket = bb.ticket;
+    scal_in = bb.scal_in;
+    scal_out = bb.scal_out;
+    bd.my_sums = bb.my_sums;
+    bd.total_tiles = bb.tiles;
+    bd.ty_a = bb.ty_a;
+    bd.ty_b = bb.ty_b;
+    nty = bb.nty;
+    p.N = bb.N;
+    p.Y = bb.Y;
+    p.own_y0 = bb.own_y0;
+    p.own_y1 = bb.own_y1;
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) nb_dst[sd][k] = bb.nb[sd][k];
+      nb_n[sd] = bb.nb_n[sd];
+      nb_plane[sd] = bb.nb_plane[sd];
+      nb_off[sd] = bb.nb_off[sd];
+    }
+  }
   const unsigned epoch = static_cast<unsigned>(ticket[1]) + 1u;
 
   // tile of this workgroup (a split step enumerates a subset of the tile rows)
-  int tile = blockIdx.x;
+  int tile = block;
   if (bd.ty_mode) {
     const int n_edge = bd.ty_a == bd.ty_b ? 1 : 2;
     const int rows_here = bd.ty_mode == 1 ? n_edge : nty - n_edge;
-    const int txi = blockIdx.x % ntx;
-    const int j = (blockIdx.x / ntx) % rows_here;
-    const int pl = blockIdx.x / (ntx * rows_here);
+    const int txi = block % ntx;
+    const int j = (block / ntx) % rows_here;
+    const int pl = block / (ntx * rows_here);
     int tyi;
     if (bd.ty_mode == 1) {
       tyi = j == 0 ? bd.ty_a : bd.ty_b;
@@ -1128,7 +1192,7 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
       for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
     }
     // band mode: the scalars this step runs on are next step's starting point
-    if (bd.sums && blockIdx.x == 0 && threadIdx.x == 0 && bd.ty_mode != 2) *scal_out = s;
+    if (bd.sums && block == 0 && threadIdx.x == 0 && bd.ty_mode != 2) *scal_out = s;
   } else {
     s.dt = p.vv_dt;
     s.alpha = 0.f;
@@ -1294,6 +1358,21 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) v_out[c * p.N + n] = vn[c];
+    // multi-band launch: my first / last owned row is the neighbour's halo row
+    if (bd.multi) {
+#pragma unroll
+      for (int sd = 0; sd < 2; ++sd) {
+        if (nb_dst[sd][0] && gy == (sd == 0 ? p.own_y0 : p.own_y1 - 1)) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const long long m = c * nb_n[sd] + plane * nb_plane[sd] + nb_off[sd] + gx;
+            nb_dst[sd][0][m] = x_own[k][c];
+            nb_dst[sd][1][m] = vn[c];
+            nb_dst[sd][2][m] = f[c];
+          }
+        }
+      }
+    }
   }
   if (!p.fire) return;
   block_sum(part, 7, lds);
@@ -3425,7 +3504,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
         hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(tgrid), dim3(kBlock), 0, ls,
                            bi[0], bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
                            &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.nty,
-                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0});
+                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0});
       else if (tiles.tx == 64)
         SFM_TILED(16, 64, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
       else
@@ -3444,7 +3523,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
         hipLaunchKernelGGL(integrate_shared2d_kernel<false>, dim3(tgrid), dim3(kBlock), 0, ls,
                            d->x, d->v, d->a, prev_ptr, d->x, d->v, d->a, p, &w.scal[cur],
                            &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, 1, tiles.nty,
-                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0});
+                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0});
       else if (tiles.tx == 64)
         SFM_TILED(16, 64, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
       else
@@ -3793,8 +3872,9 @@ size_t sfm_mesh_banded_scratch_bytes(const SfmBandedDesc* b) {
   const size_t row = 3 * (size_t)d.ncomp * d.shape[0] * d.shape[1] * d.shape[3];
   sfm::Carver c(nullptr);
   const size_t total = (size_t)std::max(b->n_ranks, 1) * b->n_local;
-  c.take<float>(total * kNP);          // sums of all bands
+  c.take<float>(2 * total * kNP);      // sums of all bands, double buffered by step parity
   c.take<float>(total * 2);            // e_kin, v_max of all bands
+  c.take<BandDev>(2 * (size_t)b->n_local);  // multi-band launch tables (two parities)
   for (int i = 0; i < b->n_local; ++i)
     for (int k = 0; k < 4; ++k) c.take<float>(row);
   return c.total();
@@ -3830,8 +3910,14 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
     return sfm::fail(SFM_ERR_WORKSPACE, "banded scratch needs %zu bytes, got %zu", need,
                      b->scratch_bytes);
   sfm::Carver carve_s(b->scratch);
-  float* sums_all = carve_s.take<float>((size_t)total * kNP);
+  // Partial sums of all bands, one buffer per step parity: a band's kernel of
+  // step k leaves its sums while a later band's kernel of the same step still
+  // reads the sums of step k - 1.
+  float* sums_buf = carve_s.take<float>((size_t)2 * total * kNP);
+  auto sums_of = [&](int step) { return sums_buf + (size_t)(step & 1) * total * kNP; };
   float* stats_all = carve_s.take<float>((size_t)total * 2);
+  BandDev* band_dev_all = carve_s.take<BandDev>(2 * (size_t)nl);
+  BandDev* band_dev[2] = {band_dev_all, band_dev_all + nl};
   const size_t row_floats = (size_t)d0.ncomp * d0.shape[0] * d0.shape[1] * d0.shape[3];
 
   BandState bs[kMaxLocalBands];
@@ -3845,8 +3931,8 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
       return sfm::fail(SFM_ERR_INVALID, "banded: the bands of a mesh share shape and config");
     const int g = b->rank * nl + i;
     sh.n_ranks = total;
-    sh.sums = sums_all;
-    sh.my_sums = sums_all + (size_t)g * kNP;
+    sh.sums = sums_buf;
+    sh.my_sums = sums_buf + (size_t)g * kNP;
     BandState& s = bs[i];
     if (int rc = shard_setup(&d, &sh, &s.p, &s.w)) return rc;
     s.w = carve_for(&d, d.workspace, &s.tiles);
@@ -3866,7 +3952,9 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
     fused = fused && s.p.ncomp == 2 && s.p.force_kind == SFM_FORCE_SPRINGS &&
             s.tiles.tx == kSX && s.w.alt[0] != nullptr;
   }
-  const bool overlap = fused && xs != st && !(b->flags & SFM_BANDED_NO_OVERLAP);
+  // The second stream pays for itself only when edge rows really travel (RCCL):
+  // between bands of one process the exchange is one small copy kernel.
+  const bool overlap = fused && xs != st && b->comm && !(b->flags & SFM_BANDED_NO_OVERLAP);
   const int C = d0.ncomp;
   const int planes = d0.shape[0] * d0.shape[1], X = d0.shape[3];
 
@@ -3931,6 +4019,72 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
   build_jobs(0, &before[0], &after[0]);
   if (fused) build_jobs(1, &before[1], &after[1]);
 
+  // Multi-band launch tables of the fused step, one per parity q of the input
+  // set (the scalars and the sums buffers alternate with it).
+  int grid_mode[3] = {0, 0, 0};
+  BandDev host[2][kMaxLocalBands];   // (function scope: source of async copies)
+  if (fused) {
+    std::memset(host, 0, sizeof(host));
+    int base[3] = {0, 0, 0};
+    for (int i = 0; i < nl; ++i) {
+      const BandState& sb = bs[i];
+      const SfmMeshShard& sh = b->shards[i];
+      const int ty_a = sh.own_y0 / kSY, ty_b = (sh.own_y1 - 1) / kSY;
+      const int n_edge = ty_a == ty_b ? 1 : 2;
+      const int count[3] = {static_cast<int>(sb.tiles.tiles),
+                            planes * std::min(n_edge, sb.tiles.nty) * sb.tiles.ntx,
+                            planes * std::max(sb.tiles.nty - n_edge, 0) * sb.tiles.ntx};
+      const int g = b->rank * nl + i;
+      for (int q = 0; q < 2; ++q) {
+        BandDev& h = host[q][i];
+        for (int k = 0; k < 3; ++k) {
+          h.in[k] = sb.set[q][k];
+          h.out[k] = sb.set[q ^ 1][k];
+        }
+        h.prev = b->bands[i].prev;
+        h.partials = sb.w.tile_part;
+        h.ticket = sb.w.ticket;
+        h.my_sums = sums_buf + (size_t)q * total * kNP + (size_t)g * kNP;
+        h.scal_in = &sb.w.scal[q];
+        h.scal_out = &sb.w.scal[q ^ 1];
+        // lo side: my first owned row -> the high halo row of the band below
+        for (int sd = 0; sd < 2; ++sd) {
+          const bool exists = sd == 0 ? sb.has_lo : sb.has_hi;
+          if (!exists) continue;
+          const bool local = !loopback && (sd == 0 ? i > 0 : i < nl - 1);
+          if (local) {
+            const int j = sd == 0 ? i - 1 : i + 1;
+            const int row = sd == 0 ? b->shards[j].own_y1 : b->shards[j].own_y0 - 1;
+            for (int k = 0; k < 3; ++k) h.nb[sd][k] = bs[j].set[q ^ 1][k];
+            h.nb_n[sd] = bs[j].p.N;
+            h.nb_plane[sd] = (long long)bs[j].p.Y * X;
+            h.nb_off[sd] = (long long)row * X;
+          } else {
+            for (int k = 0; k < 3; ++k) h.nb[sd][k] = sb.buf[sd] + (size_t)k * row_floats;
+            h.nb_n[sd] = (long long)planes * X;
+            h.nb_plane[sd] = X;
+            h.nb_off[sd] = 0;
+          }
+        }
+        h.N = sb.p.N;
+        h.Y = sb.p.Y;
+        h.own_y0 = sh.own_y0;
+        h.own_y1 = sh.own_y1;
+        h.nty = sb.tiles.nty;
+        h.tiles = static_cast<int>(sb.tiles.tiles);
+        h.ty_a = ty_a;
+        h.ty_b = ty_b;
+        for (int m = 0; m < 3; ++m) h.base[m] = base[m];
+      }
+      for (int m = 0; m < 3; ++m) base[m] += count[m];
+    }
+    for (int m = 0; m < 3; ++m) grid_mode[m] = base[m];
+    SFM_HIP_CHECK(hipMemcpyAsync(band_dev[0], host[0], sizeof(BandDev) * nl,
+                                 hipMemcpyHostToDevice, st));
+    SFM_HIP_CHECK(hipMemcpyAsync(band_dev[1], host[1], sizeof(BandDev) * nl,
+                                 hipMemcpyHostToDevice, st));
+  }
+
   // The grouped point-to-point part of one exchange.  Between ranks: the first
   // band's low edge <-> rank - 1, the last band's high edge <-> rank + 1.  Loop
   // back (tests on one GPU): every edge between local bands travels through a
@@ -3972,10 +4126,11 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
     SFM_LAUNCH_CHECK();
     return SFM_OK;
   };
-  auto gather_sums = [&](hipStream_t s_) -> int {
-    if (n_ranks == 1 && !loopback) return SFM_OK;   // my_sums are rows of sums_all already
+  auto gather_sums = [&](int step, hipStream_t s_) -> int {
+    if (n_ranks == 1 && !loopback) return SFM_OK;   // my_sums are rows of the buffer already
     // in place: this rank's rows sit at their final position
-    return sfm_comm_allgather(b->comm, sums_all + (size_t)b->rank * nl * kNP, sums_all,
+    float* sums = sums_of(step);
+    return sfm_comm_allgather(b->comm, sums + (size_t)b->rank * nl * kNP, sums,
                               (size_t)nl * kNP, s_);
   };
 
@@ -4034,57 +4189,45 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
     const int pending = k > 0 ? 1 : 0;
     if (fused) {
       const int out = in ^ 1;
-      auto launch = [&](BandState& s, const SfmMeshDesc& d, int mode, int ty_a, int ty_b,
-                        int rows_here) {
-        const long long pl = (long long)s.p.B * s.p.Z;
-        const int grid = static_cast<int>(pl * rows_here * s.tiles.ntx);
-        BandArgs ba{sums_all, nullptr, total, static_cast<int>(s.tiles.tiles), mode, ty_a, ty_b};
-        ba.my_sums = sums_all + (size_t)(b->rank * nl + (&s - bs)) * kNP;
+      // every local band in ONE launch (BandDev table of this parity); the rows at
+      // the band edges land in the neighbours' halo rows / the send buffers
+      auto launch = [&](int mode, int grid) {
+        if (grid <= 0) return;
+        BandArgs ba{sums_of(k - 1), nullptr, total, 0, mode, 0, 0, band_dev[in], nl};
         hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(grid), dim3(kBlock), 0, st,
-                           s.set[in][0], s.set[in][1], s.set[in][2], d.prev, s.set[out][0],
-                           s.set[out][1], s.set[out][2], s.p, &s.w.scal[cur], &s.w.scal[cur ^ 1],
-                           cap0, s.w.tile_part, s.w.ticket, pending ? 3 : 0, s.tiles.nty,
-                           s.tiles.ntx, ba);
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bs[0].p,
+                           nullptr, nullptr, cap0, nullptr, nullptr, pending ? 3 : 0, 0,
+                           bs[0].tiles.ntx, ba);
       };
-      // edge tile rows of a band: those holding its first / last owned row
-      int ty_a[kMaxLocalBands], ty_b[kMaxLocalBands];
-      bool split[kMaxLocalBands];
-      for (int i = 0; i < nl; ++i) {
-        ty_a[i] = b->shards[i].own_y0 / kSY;
-        ty_b[i] = (b->shards[i].own_y1 - 1) / kSY;
-        const int n_edge = ty_a[i] == ty_b[i] ? 1 : 2;
-        split[i] = overlap && bs[i].tiles.nty > n_edge;
-      }
-      sfm::prof_begin(sfm::kProfMesh, st);
-      for (int i = 0; i < nl; ++i) {
-        if (split[i])
-          launch(bs[i], b->bands[i], 1, ty_a[i], ty_b[i], ty_a[i] == ty_b[i] ? 1 : 2);
-        else
-          launch(bs[i], b->bands[i], 0, 0, 0, bs[i].tiles.nty);
+      auto exchange_fused = [&](hipStream_t s_) -> int {
+        if (int rc = p2p(s_)) return rc;
+        launch_rows(after[out], s_);
         SFM_LAUNCH_CHECK();
-      }
+        return SFM_OK;
+      };
+      sfm::prof_begin(sfm::kProfMesh, st);
       if (overlap) {
+        launch(1, grid_mode[1]);
+        SFM_LAUNCH_CHECK();
         SFM_HIP_CHECK(hipEventRecord(ev_edge, st));
         SFM_HIP_CHECK(hipStreamWaitEvent(xs, ev_edge, 0));
-        if (int rc = exchange(out, xs)) return rc;
-        for (int i = 0; i < nl; ++i)
-          if (split[i]) {
-            const int n_edge = ty_a[i] == ty_b[i] ? 1 : 2;
-            launch(bs[i], b->bands[i], 2, ty_a[i], ty_b[i], bs[i].tiles.nty - n_edge);
-            SFM_LAUNCH_CHECK();
-          }
+        if (int rc = exchange_fused(xs)) return rc;
+        launch(2, grid_mode[2]);
+        SFM_LAUNCH_CHECK();
         sfm::prof_end(sfm::kProfMesh, st);
         SFM_HIP_CHECK(hipEventRecord(ev_int, st));
         SFM_HIP_CHECK(hipStreamWaitEvent(xs, ev_int, 0));
         if (d0.fire)
-          if (int rc = gather_sums(xs)) return rc;
+          if (int rc = gather_sums(k, xs)) return rc;
         SFM_HIP_CHECK(hipEventRecord(ev_x, xs));
         SFM_HIP_CHECK(hipStreamWaitEvent(st, ev_x, 0));
       } else {
+        launch(0, grid_mode[0]);
+        SFM_LAUNCH_CHECK();
         sfm::prof_end(sfm::kProfMesh, st);
-        if (int rc = exchange(out, st)) return rc;
+        if (int rc = exchange_fused(st)) return rc;
         if (d0.fire)
-          if (int rc = gather_sums(st)) return rc;
+          if (int rc = gather_sums(k, st)) return rc;
       }
       in = out;
       if (d0.fire) cur ^= 1;
@@ -4096,12 +4239,12 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
         const SfmMeshDesc& d = b->bands[i];
         if (s.p.ncomp == 2)
           hipLaunchKernelGGL(advance_kernel<2>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, d.a,
-                             s.p, &s.w.scal[cur], &s.w.scal[cur ^ 1], sums_all, total, pending,
-                             s.w.colsum);
+                             s.p, &s.w.scal[cur], &s.w.scal[cur ^ 1], sums_of(k - 1), total,
+                             pending, s.w.colsum);
         else
           hipLaunchKernelGGL(advance_kernel<3>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, d.a,
-                             s.p, &s.w.scal[cur], &s.w.scal[cur ^ 1], sums_all, total, pending,
-                             s.w.colsum);
+                             s.p, &s.w.scal[cur], &s.w.scal[cur ^ 1], sums_of(k - 1), total,
+                             pending, s.w.colsum);
         SFM_LAUNCH_CHECK();
       }
       cur ^= 1;
@@ -4118,16 +4261,17 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
         SFM_LAUNCH_CHECK();
         if (s.p.fire) {
           hipLaunchKernelGGL(shard_sums_kernel, dim3(1), dim3(kBlock), 0, st, s.w.partials,
-                             s.grid, sums_all + (size_t)(b->rank * nl + i) * kNP);
+                             s.grid, sums_of(k) + (size_t)(b->rank * nl + i) * kNP);
           SFM_LAUNCH_CHECK();
         }
       }
       sfm::prof_end(sfm::kProfMesh, st);
       if (int rc = exchange(0, st)) return rc;
       if (d0.fire)
-        if (int rc = gather_sums(st)) return rc;
+        if (int rc = gather_sums(k, st)) return rc;
     }
   }
+  const float* sums_last = sums_of(iters - 1);
 
   // -- finish: pending gate / drift of the last step, statistics ---------------
   const Scalars* final_scal = nullptr;
@@ -4145,18 +4289,18 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
       // same (band-order) reduction as the step kernels', then finish with the
       // scalars as they are
       hipLaunchKernelGGL(band_scalars_kernel, dim3(1), dim3(64), 0, st, &s.w.scal[c],
-                         &s.w.scal[c ^ 1], sums_all, total, s.p);
+                         &s.w.scal[c ^ 1], sums_last, total, s.p);
       SFM_LAUNCH_CHECK();
       c ^= 1;
       mode = 2;
     }
     if (s.p.ncomp == 2)
       hipLaunchKernelGGL(finish_kernel<2>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, s.p,
-                         &s.w.scal[c], &s.w.scal[c ^ 1], sums_all, total, mode, s.w.stat_part,
+                         &s.w.scal[c], &s.w.scal[c ^ 1], sums_last, total, mode, s.w.stat_part,
                          s.w.colsum);
     else
       hipLaunchKernelGGL(finish_kernel<3>, dim3(s.grid), dim3(kBlock), 0, st, d.x, d.v, s.p,
-                         &s.w.scal[c], &s.w.scal[c ^ 1], sums_all, total, mode, s.w.stat_part,
+                         &s.w.scal[c], &s.w.scal[c ^ 1], sums_last, total, mode, s.w.stat_part,
                          s.w.colsum);
     SFM_LAUNCH_CHECK();
     hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(kBlock), 0, st, s.w.stat_part, s.grid,

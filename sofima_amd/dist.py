@@ -215,6 +215,10 @@ class BandTransport:
     self.group = group
     self.rank, self.world = world(group)
     self.comm = comm
+    # gloo moves host tensors only: device rows are staged through the host
+    # (several ranks sharing one GPU in the tests; RCCL needs a GPU per rank)
+    self.stage = (comm is None and self.world > 1 and
+                  dist.get_backend(group) == 'gloo')
 
   def exchange(self, bands):
     for lo_band, hi_band in zip(bands[:-1], bands[1:]):
@@ -228,6 +232,11 @@ class BandTransport:
     send_lo = first.boundary('lo') if has_lo else None
     send_hi = last.boundary('hi') if has_hi else None
     import torch
+    dev_of = (send_lo if has_lo else send_hi)
+    dev_of = None if dev_of is None else dev_of.device
+    if self.stage:
+      send_lo = send_lo.cpu() if has_lo else None
+      send_hi = send_hi.cpu() if has_hi else None
     recv_lo = torch.empty_like(send_lo) if has_lo else None
     recv_hi = torch.empty_like(send_hi) if has_hi else None
     if self.comm is not None:
@@ -243,6 +252,9 @@ class BandTransport:
                 dist.P2POp(dist.irecv, recv_hi, self.rank + 1, self.group)]
       for req in dist.batch_isend_irecv(ops):
         req.wait()
+    if self.stage:
+      recv_lo = recv_lo.to(dev_of) if has_lo else None
+      recv_hi = recv_hi.to(dev_of) if has_hi else None
     if has_lo:
       first.set_halo('lo', recv_lo)
     if has_hi:
@@ -257,9 +269,10 @@ class BandTransport:
     elif self.comm is not None:
       full = self.comm.allgather(local)
     else:
-      parts = [torch.empty_like(local) for _ in range(self.world)]
-      dist.all_gather(parts, local, group=self.group)
-      full = torch.cat(parts)
+      src = local.cpu() if self.stage else local
+      parts = [torch.empty_like(src) for _ in range(self.world)]
+      dist.all_gather(parts, src, group=self.group)
+      full = torch.cat(parts).to(local.device)
     for b in bands:
       b.sums.copy_(full)
 
