@@ -85,6 +85,15 @@ def test_cfg1_full_size_warped_pair_first_batch_vs_oracle(gpu):
   assert valid.mean() > 0.99
   assert np.abs(got[0][valid] + 5).max() <= 7 and np.abs(got[1][valid] - 3).max() <= 7
   assert np.ptp(got[0][valid]) >= 8          # the warp is visible in the field
+  # Exact tile pruning at full size: 40401 patches through 512 resident
+  # workgroups whose seed probes carry state from patch to patch -- the field
+  # with every tile computed (SFM_MFMA_PRUNE=0) is the same, bit for bit, and so
+  # is a second pruned run (the decisions depend on wave timing, the result not).
+  from sofima_amd import _abi
+  with _abi.option('SFM_MFMA_PRUNE', 0):
+    full = calc.flow_field(pre, post, 160, 40, batch_size=1024)
+  np.testing.assert_array_equal(got, full)
+  np.testing.assert_array_equal(calc.flow_field(pre, post, 160, 40, batch_size=1024), full)
 
 
 def test_cfg2_montage_strip_vs_oracle(gpu):
