@@ -456,6 +456,14 @@ typedef struct SfmMeshDesc {
   float* ext_force;             /* EXTERNAL: device, same shape as x         */
   SfmForceCallback force_cb;
   void* force_user;
+  /* Generic prev_fn (mesh.py:429-430, any callable): when prev_cb is set, `prev`
+     and `target` must be NULL; the library calls it on the host in front of
+     every force evaluation (initial a = F(x), then after each position update)
+     and it must enqueue, on `stream`, work that leaves prev_fn(x) in ext_prev
+     (device, same shape as x; NaN = no spring).  Non-zero return aborts. */
+  float* ext_prev;
+  SfmForceCallback prev_cb;
+  void* prev_user;
 } SfmMeshDesc;
 
 /* FIRE scalars carried between chunks (mesh.py:449, :513, :589). */

@@ -259,6 +259,9 @@ class SfmMeshDesc(C.Structure):
       ('ext_force', C.c_void_p),
       ('force_cb', SfmForceCallback),
       ('force_user', C.c_void_p),
+      ('ext_prev', C.c_void_p),
+      ('prev_cb', SfmForceCallback),
+      ('prev_user', C.c_void_p),
   ]
 
 

@@ -2968,7 +2968,7 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
   p->N = (long long)p->B * p->Z * p->Y * p->X;
   p->prefer = d->prefer_orig_order;
   p->neg_k0 = static_cast<float>(-d->k0);
-  p->has_prev = d->prev != nullptr || d->target != nullptr;
+  p->has_prev = d->prev != nullptr || d->target != nullptr || d->prev_cb != nullptr;
   p->force_kind = d->force_kind;
   if (d->force_kind < SFM_FORCE_SPRINGS || d->force_kind > SFM_FORCE_EXTERNAL)
     return sfm::fail(SFM_ERR_INVALID, "force_kind %d", d->force_kind);
@@ -3147,7 +3147,7 @@ bool bricks_enabled() {
 TilePlan plan_bricks(const SfmMeshDesc* d) {
   TilePlan t;
   if (!bricks_enabled()) return t;
-  if (d->ncomp != 3 || !tiled_enabled() || d->n_links != 0 || d->target ||
+  if (d->ncomp != 3 || !tiled_enabled() || d->n_links != 0 || d->target || d->prev_cb ||
       d->remove_drift == 2 || d->force_kind != SFM_FORCE_SPRINGS)
     return t;
   const int Z = d->shape[1], Y = d->shape[2], X = d->shape[3];
@@ -3227,7 +3227,8 @@ MeshWorkspace carve_for(const SfmMeshDesc* d, void* ws, TilePlan* plan) {
   // second (x, v, a) set: ping-pong of the fused tiled step, staging of the
   // persistent kernel's result
   return carve(ws, d->target ? cn : 0,
-               ((d->ncomp == 2 && !d->target && d->force_kind == SFM_FORCE_SPRINGS) ||
+               ((d->ncomp == 2 && !d->target && !d->prev_cb &&
+                 d->force_kind == SFM_FORCE_SPRINGS) ||
                 t.ntz > 0) ? cn : 0,
                t.tiles,
                d->shape[3]);
@@ -3272,9 +3273,13 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       (d->remove_drift == 2 && d->ncomp != 3))
     return sfm::fail(SFM_ERR_INVALID,
                      "remove_drift: 0 none, 1 global mean, 2 per x column (3-D only)");
-  if (d->target && d->prev)
+  if ((d->target || d->prev_cb) && d->prev)
     return sfm::fail(SFM_ERR_INVALID,
                      "Only one of: \"prev\" and \"prev_fn\" can be specified.");
+  if (d->target && d->prev_cb)
+    return sfm::fail(SFM_ERR_INVALID, "prev_fn: either the native target mesh or a callback");
+  if (d->prev_cb && !d->ext_prev)
+    return sfm::fail(SFM_ERR_INVALID, "prev_cb needs the ext_prev buffer");
   TilePlan tiles;
   MeshWorkspace w = carve_for(d, d->workspace, &tiles);
   if (!d->workspace || d->workspace_bytes < w.bytes)
@@ -3282,7 +3287,16 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
                      w.bytes, d->workspace_bytes);
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const int grid = grid_for(p.N);
-  const float* prev_ptr = d->target ? w.prev_buf : d->prev;
+  const float* prev_ptr = d->target ? w.prev_buf : d->prev_cb ? d->ext_prev : d->prev;
+  // prev = prev_fn(x) (mesh.py:429-430): the native target mesh, or the caller's
+  // callable through prev_cb, re-evaluated in front of every force evaluation
+  const bool dyn_prev = d->target || d->prev_cb;
+  auto eval_prev = [&](hipStream_t s_) -> int {
+    if (d->target) return sfm::launch_target_mesh(d->target, d->x, w.prev_buf, s_);
+    if (d->prev_cb && d->prev_cb(d->prev_user) != 0)
+      return sfm::fail(SFM_ERR_INVALID, "mesh: the prev_fn callback failed");
+    return SFM_OK;
+  };
 
   Scalars s0;
   std::memset(&s0, 0, sizeof(s0));
@@ -3297,7 +3311,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   const float cap0 = fire->cap;
 
   // Persistent single-launch path for in-plane meshes that fit the chip.
-  if (persistent_enabled() && p.ncomp == 2 && d->num_iters >= 1 && !d->target &&
+  if (persistent_enabled() && p.ncomp == 2 && d->num_iters >= 1 && !dyn_prev &&
       p.force_kind == SFM_FORCE_SPRINGS) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -3404,15 +3418,14 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   };
 
   // a = F(x) + pull(prev, cap)   (mesh.py:501); prev = prev_fn(x) if native
-  if (d->target)
-    if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, st)) return rc;
+  if (int rc = eval_prev(st)) return rc;
   if (int rc = external_force()) return rc;
   SFM_MESH_DISPATCH(force_kernel, d->x, prev_ptr, d->a, p, cap0, p.has_prev);
 
   int cur = 0;
   int finish_mode = d->num_iters > 0 ? 1 : 0;
   // One workgroup's worth of nodes: every step in one launch (mesh_small_kernel).
-  const bool small = small_enabled() && grid == 1 && d->num_iters > 0 && !d->target &&
+  const bool small = small_enabled() && grid == 1 && d->num_iters > 0 && !dyn_prev &&
                      p.force_kind != SFM_FORCE_EXTERNAL && !p.drift_cols &&
                      p.own_y0 <= 0 && p.own_y1 >= p.Y;
   if (small) {
@@ -3429,7 +3442,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   const bool tiled = tiles.tx && d->num_iters > 0;
   float* bufs[2][3] = {{d->x, d->v, d->a}, {w.alt[0], w.alt[1], w.alt[2]}};
   int in = 0;
-  const bool fused = tiled && !d->target;
+  const bool fused = tiled && !dyn_prev;
   const int tgrid = static_cast<int>(tiles.tiles);
   if (tiled) {
     // LDS-tiled integrator (2-D): one launch per step, or advance + prev_fn +
@@ -3517,7 +3530,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       SFM_STEP_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
                         &w.scal[cur ^ 1], w.partials, grid, pending ? 2 : 0, w.colsum);
       cur ^= 1;
-      if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, ls)) return rc;
+      if (int rc = eval_prev(ls)) return rc;
       if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
       if (tiles.tx == kSX)
         hipLaunchKernelGGL(integrate_shared2d_kernel<false>, dim3(tgrid), dim3(kBlock), 0, ls,
@@ -3535,8 +3548,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       SFM_STEP_DISPATCH(advance_kernel, d->x, d->v, d->a, p, &w.scal[cur],
                         &w.scal[cur ^ 1], w.partials, part_rows, pending, w.colsum);
       cur ^= 1;
-      if (d->target)
-        if (int rc = sfm::launch_target_mesh(d->target, d->x, w.prev_buf, ls)) return rc;
+      if (int rc = eval_prev(ls)) return rc;
       if (int rc = external_force()) return rc;
       if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
       if (march_grid) {
@@ -3567,7 +3579,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   // Launch-bound meshes (small, several launches per step): replay pairs of
   // steps from a hipGraph instead of enqueueing every kernel from the host.
   if (graph_enabled() && !sfm::profiling() && p.N <= kGraphMaxNodes &&
-      p.force_kind != SFM_FORCE_EXTERNAL &&
+      p.force_kind != SFM_FORCE_EXTERNAL && !d->prev_cb &&
       d->num_iters - it >= 8) {
     const int pairs = (d->num_iters - it) / 2;
     hipGraph_t graph = nullptr;
@@ -3662,7 +3674,7 @@ int shard_setup(const SfmMeshDesc* d, const SfmMeshShard* sh, MeshParams* p,
   if (!sh) return sfm::fail(SFM_ERR_INVALID, "shard is NULL");
   if (!d->x || !d->v || !d->a)
     return sfm::fail(SFM_ERR_INVALID, "x/v/a must be device pointers");
-  if (d->target || d->force_kind == SFM_FORCE_EXTERNAL)
+  if (d->target || d->prev_cb || d->force_kind == SFM_FORCE_EXTERNAL)
     return sfm::fail(SFM_ERR_INVALID, "band shards: prev_fn / external forces unsupported");
   if (d->remove_drift == 2)
     return sfm::fail(SFM_ERR_INVALID, "band shards: per-column drift removal unsupported");

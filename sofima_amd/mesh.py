@@ -293,14 +293,24 @@ def _resolve_force(mesh_force) -> _ForceSpec:
   raise TypeError('mesh_force must be callable')
 
 
-def _native_prev_fn(prev_fn):
-  """Returns the TargetMeshFn behind `prev_fn`, or raises for JAX closures."""
+def _resolve_prev_fn(prev_fn):
+  """(native TargetMeshFn or None, generic callable or None) for `prev_fn`.
+
+  A `stitch_elastic.TargetMeshFn` (the native form of
+  `jax.vmap(compute_target_mesh)`) runs as a kernel inside the integrator.  Any
+  other callable `f(x) -> prev` (mesh.py:429-430) is evaluated on the live,
+  device-resident positions in front of every force evaluation, like the
+  reference's traced closure: it receives a `DeviceArray` and may return a
+  DeviceArray, a torch tensor or a NumPy array (NaN = no spring).
+  """
+  if prev_fn is None:
+    return None, None
   from . import stitch_elastic
   if isinstance(prev_fn, stitch_elastic.TargetMeshFn):
-    return prev_fn
-  raise NotImplementedError(
-      'prev_fn must be a sofima_amd.stitch_elastic.TargetMeshFn; arbitrary '
-      'Python callables cannot be fused into the HIP integrator (DESIGN.md)')
+    return prev_fn, None
+  if callable(prev_fn):
+    return None, prev_fn
+  raise TypeError('prev_fn must be callable')
 
 
 def _chunk_desc(x_t, v_t, a_t, prev_t, config: IntegrationConfig, spec,
@@ -358,14 +368,36 @@ def _external_force(spec, x_t, config):
   return f_t, _abi.SfmForceCallback(call), errors
 
 
+def _external_prev(prev_call, x_t):
+  """(prev buffer, ctypes callback, error list) for a generic prev_fn."""
+  p_t = torch.empty_like(x_t)
+  errors = []
+  x_view = DeviceArray(x_t)
+
+  def call(_user):
+    try:
+      pv = _dev.as_device_f32(prev_call(x_view), x_t.device, copy=False)
+      if tuple(pv.shape) != tuple(x_t.shape):
+        raise ValueError(f'prev_fn returned shape {tuple(pv.shape)}, '
+                         f'expected {tuple(x_t.shape)}')
+      p_t.copy_(pv)
+      return 0
+    except BaseException as e:  # pylint: disable=broad-except
+      errors.append(e)
+      return 1
+
+  return p_t, _abi.SfmForceCallback(call), errors
+
+
 def _run_chunk(x_t, v_t, prev_t, config, force_cap, fire_dt, fire_alpha, spec,
-               target=None):
+               target=None, prev_call=None):
   """One velocity_verlet call on device tensors (x_t, v_t updated in place)."""
   lib = _abi.load()
   a_t = torch.empty_like(x_t)
   ext = None
   if spec.kind == _abi.FORCE_EXTERNAL:
     ext = _external_force(spec, x_t, config)
+  extp = None if prev_call is None else _external_prev(prev_call, x_t)
   probe = _base_desc(x_t, spec, config.k, config.stride,
                      config.prefer_orig_order)
   tdesc = None
@@ -380,6 +412,9 @@ def _run_chunk(x_t, v_t, prev_t, config, force_cap, fire_dt, fire_alpha, spec,
   if ext is not None:
     d.ext_force = ext[0].data_ptr()
     d.force_cb = ext[1]
+  if extp is not None:
+    d.ext_prev = extp[0].data_ptr()
+    d.prev_cb = extp[1]
   fire = _abi.SfmFireState()
   fire.dt = np.float32(config.dt if fire_dt is None else fire_dt)
   fire.alpha = np.float32(config.alpha if fire_alpha is None else fire_alpha)
@@ -389,6 +424,8 @@ def _run_chunk(x_t, v_t, prev_t, config, force_cap, fire_dt, fire_alpha, spec,
   rc = lib.sfm_mesh_relax_chunk(C.byref(d), C.byref(fire), C.byref(stats))
   if ext is not None and ext[2]:
     raise ext[2][0]  # the caller's mesh_force raised: surface its exception
+  if extp is not None and extp[2]:
+    raise extp[2][0]
   _abi.check(rc)
   return a_t, fire, stats
 
@@ -403,8 +440,8 @@ def velocity_verlet(x, v, prev, config: IntegrationConfig, force_cap: float,
   (x, v, a) or, with FIRE, (x, v, a, dt, alpha, n_pos, cap).  The inputs are
   not modified.
   """
-  target = None if prev_fn is None else _native_prev_fn(prev_fn)
-  if target is not None and prev is not None:
+  target, prev_call = _resolve_prev_fn(prev_fn)
+  if prev_fn is not None and prev is not None:
     raise ValueError('Only one of: "prev" and "prev_fn" can be specified.')
   spec = _resolve_force(mesh_force)
   dev = _dev.device()
@@ -412,7 +449,7 @@ def velocity_verlet(x, v, prev, config: IntegrationConfig, force_cap: float,
   v_t = _dev.as_device_f32(v, dev, copy=True)
   prev_t = None if prev is None else _dev.as_device_f32(prev, dev, copy=False)
   a_t, fire, _ = _run_chunk(x_t, v_t, prev_t, config, force_cap, fire_dt,
-                            fire_alpha, spec, target)
+                            fire_alpha, spec, target, prev_call)
   out = (DeviceArray(x_t), DeviceArray(v_t), DeviceArray(a_t))
   if config.fire:
     out += (np.float32(fire.dt), np.float32(fire.alpha), int(fire.n_pos),
@@ -443,7 +480,7 @@ def relax_mesh(x, prev, config: IntegrationConfig, mesh_force=inplane_force,
 
   if prev is not None and prev_fn is not None:
     raise ValueError('Only one of: "prev" and "prev_fn" can be specified.')
-  target = None if prev_fn is None else _native_prev_fn(prev_fn)
+  target, prev_call = _resolve_prev_fn(prev_fn)
 
   spec = _resolve_force(mesh_force)
   dev = _dev.device()
@@ -453,7 +490,7 @@ def relax_mesh(x, prev, config: IntegrationConfig, mesh_force=inplane_force,
 
   while t < config.max_iters:
     _, fire, stats = _run_chunk(x_t, v_t, prev_t, config, cap, dt, alpha,
-                                spec, target)
+                                spec, target, prev_call)
     t += config.num_iters
     e_kin.append(float(stats.e_kin))
     v_max = float(stats.v_max)

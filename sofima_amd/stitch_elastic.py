@@ -182,3 +182,85 @@ def compute_flow_map(tile_map, offset_map: np.ndarray, axis: int,
       flows[x, y] = np.pad(f, pads, constant_values=np.nan)
       offsets[x, y] = off
   return flows, offsets
+
+
+def _aligned_overlap3d(tile_shape, offset, axis: int, stride):
+  """Overlap region of a 3-d tile pair, aligned to the flow stride
+  (stitch_elastic.py:125-180).
+
+  tile_shape, offset: xyz; stride: zyx.  The neighbour sits at the grid step
+  along `axis` plus `offset`.  Its position is nudged so that, inside the
+  current tile, the overlap starts on a multiple of s = stride[2 - axis] along
+  every axis (the reference aligns ALL axes to the stride of the connection
+  axis).  Returns (start in the current tile, start in the neighbour, size)
+  -- xyz integers -- and the xyz offset recorded for the pair.
+  """
+  shape = np.asarray(tile_shape, dtype=np.float64)
+  pos = np.array([shape[0] * (1 - axis) + offset[0], shape[1] * axis + offset[1],
+                  offset[2]], dtype=np.float64)
+
+  def overlap(nb):
+    lo = np.maximum(0.0, nb)
+    hi = np.minimum(shape, nb + shape)
+    return lo, lo - nb, hi - lo        # start in current, start in neighbour, size
+
+  s = stride[2 - axis]
+  cur0, nb0, size0 = overlap(pos)
+  nudge = np.zeros(3)
+  # along the connection: the strip starts on a multiple of s inside the current
+  # tile (moved towards its origin, i.e. the strip only grows)
+  first = shape[axis] - size0[axis]
+  nudge[axis] = -((shape[axis] - first // s * s) - size0[axis])
+  for ax in range(3):
+    if ax == axis:
+      continue
+    if cur0[ax] > 0:
+      nudge[ax] = s * np.round(cur0[ax] / s) - cur0[ax]
+    elif nb0[ax] > 0:
+      nudge[ax] = -(s * np.round(nb0[ax] / s) - nb0[ax])
+  pos = pos + nudge
+  cur, nb, size = overlap(pos)
+  assert np.all(cur % s == 0) and np.all(nb % s == 0)
+  rec = pos.copy()
+  rec[axis] = -size[axis]
+  return (cur.astype(int), nb.astype(int), size.astype(int),
+          tuple(float(v) for v in rec))
+
+
+def compute_flow_map3d(tile_map, tile_shape, offset_map: np.ndarray, axis: int,
+                       patch_size=(120, 120, 120), stride=(40, 40, 40),
+                       batch_size: int = 16):
+  """Fine flow between horizontally (axis 0) or vertically (axis 1) adjacent
+  3-d tiles (stitch_elastic.py:85-194).
+
+  tile_map: (x, y) -> [1, z, y, x] volume (any indexable); tile_shape: xyz;
+  offset_map: [3, 1, y, x] coarse xyz offsets of the (x+1, y) / (x, y+1) tile;
+  patch_size / stride: zyx.  Returns ({(x, y): flow [5, gz, gy, gx]}, {(x, y):
+  xyz offset at which the neighbour was positioned for the flow}); flows are
+  NaN-padded by patch // 2 // stride nodes like the reference's.  Every pair is
+  one volumetric `flow_field` call (FFT form) on the aligned overlap.
+  """
+  from . import flow_field
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  patch_size = tuple(int(p) for p in patch_size)
+  stride = tuple(int(v) for v in stride)
+  pads = [(0, 0)] + [(p // 2 // v, p // 2 // v - 1) for p, v in zip(patch_size, stride)]
+  grid_y, grid_x = offset_map.shape[-2:]
+  flows, offsets = {}, {}
+  for y in range(grid_y - axis):
+    for x in range(grid_x - (1 - axis)):
+      cur, nb, size, rec = _aligned_overlap3d(tile_shape, offset_map[:, 0, y, x], axis,
+                                              stride)
+
+      def crop(tile, start):          # xyz start / size -> [z, y, x] block
+        sl = tuple(slice(int(a), int(a + n)) for a, n in zip(start[::-1], size[::-1]))
+        return np.asarray(tile[(slice(None),) + sl]).squeeze(axis=0)
+
+      pre = crop(tile_map[x, y], cur)
+      post = crop(tile_map[x + (1 - axis), y + axis], nb)
+      assert pre.shape == post.shape
+      f = calc.flow_field(pre, post, patch_size=patch_size, step=stride,
+                          batch_size=batch_size)
+      flows[x, y] = np.pad(f, pads, constant_values=np.nan)
+      offsets[x, y] = rec
+  return flows, offsets

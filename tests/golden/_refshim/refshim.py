@@ -401,7 +401,29 @@ def install(reference_root='/root/reference'):
       integral_image=_integral_image,
       query_integral_image=_query_integral_image,
   )
-  cc.utils = _mod('connectomics.common.utils', batch=_batch)
+  class NPDataClassJsonMixin:
+    pass
+
+  cc.utils = _mod('connectomics.common.utils', batch=_batch,
+                  NPDataClassJsonMixin=NPDataClassJsonMixin)
+  cc.file = _mod('connectomics.common.file', PathLike=str)
+
+  # connectomics.volume.*: only names that the class bodies / annotations of
+  # processor/mesh.py touch at import time (RelaxMesh.relax_mesh itself uses
+  # none of them: it reads self._config and calls sofima.mesh / map_utils).
+  def _cls(name):
+    return type(name, (), {})
+
+  cv = _mod('connectomics.volume')
+  cv.mask = _mod('connectomics.volume.mask', MaskConfigs=_cls('MaskConfigs'))
+  cv.metadata = _mod('connectomics.volume.metadata',
+                     DecoratedVolume=_cls('DecoratedVolume'))
+  cv.subvolume = _mod('connectomics.volume.subvolume', Subvolume=_cls('Subvolume'))
+  cv.subvolume_processor = _mod(
+      'connectomics.volume.subvolume_processor',
+      SubvolumeProcessor=_cls('SubvolumeProcessor'),
+      SuggestedXyz=_cls('SuggestedXyz'), TupleOrSuggestedXyz=tuple)
+  c.volume = cv
   cc.bounding_box = _mod(
       'connectomics.common.bounding_box',
       BoundingBox=BoundingBox,

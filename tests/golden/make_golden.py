@@ -11,6 +11,7 @@ Every file stores inputs AND expected outputs, so the tests never need the
 reference.  Run:  python tests/golden/make_golden.py
 """
 import dataclasses
+import json
 import os
 import sys
 
@@ -582,8 +583,110 @@ def gen_montage():
   print('target finite fraction', np.isfinite(tg0[0]).mean(axis=(1, 2)))
 
 
+def flow_map3d_tiles():
+  """2 x 2 grid of 3-d uint8 tiles cut from one EM-like volume with jittered
+  positions; returns (tile_map, tile_shape xyz, offsets_x, offsets_y)."""
+  rng = np.random.default_rng(55)
+  tz, ty, tx = 40, 56, 64
+  vol = ndimage.gaussian_filter(rng.standard_normal((tz + 24, 2 * ty + 24, 2 * tx + 24)), 1.5)
+  vol = ((vol - vol.min()) / (vol.max() - vol.min()) * 255).astype(np.uint8)
+  # xyz position of every tile in the volume: grid step (tx - 22, ty - 18) + jitter
+  # (ortho / z jitters of up to 14 px: rounded to the stride on either side of 0)
+  pos = {(0, 0): (8, 9, 8), (1, 0): (8 + tx - 23, 22, 1), (0, 1): (2, 9 + ty - 17, 20),
+         (1, 1): (2 + tx - 25, 9 + ty - 19 - 14, 13)}
+  tiles = {k: vol[None, z:z + tz, y:y + ty, x:x + tx].copy() for k, (x, y, z) in pos.items()}
+  ox = np.full((3, 1, 2, 2), np.nan)
+  oy = np.full((3, 1, 2, 2), np.nan)
+  for (x, y), p in pos.items():
+    if (x + 1, y) in pos:
+      ox[:, 0, y, x] = np.array(pos[x + 1, y]) - np.array(p) - (tx, 0, 0)
+    if (x, y + 1) in pos:
+      oy[:, 0, y, x] = np.array(pos[x, y + 1]) - np.array(p) - (0, ty, 0)
+  return tiles, (tx, ty, tz), ox, oy
+
+
+def gen_flow_map3d():
+  """stitch_elastic.compute_flow_map3d (stitch_elastic.py:85-194) on the tiles
+  above: flow arrays and recorded offsets of every horizontal / vertical pair."""
+  from sofima import stitch_elastic
+  tiles, shape, ox, oy = flow_map3d_tiles()
+  out = dict(tile_keys=np.array(list(tiles)), tiles=np.stack(list(tiles.values())),
+             tile_shape=np.array(shape), ox=ox, oy=oy,
+             patch=np.array((16, 20, 20)), stride=np.array((8, 10, 10)))
+  for name, om, axis in (('fx', ox, 0), ('fy', oy, 1)):
+    flows, offs = stitch_elastic.compute_flow_map3d(
+        tiles, shape, om, axis, patch_size=(16, 20, 20), stride=(8, 10, 10), batch_size=8)
+    keys = list(flows)
+    out[name + '_keys'] = np.array(keys)
+    out[name + '_offsets'] = np.array([offs[k] for k in keys], dtype=np.float64)
+    for i, k in enumerate(keys):
+      out[f'{name}_{i}'] = flows[k].astype(np.float32)
+      print('flow_map3d', name, k, flows[k].shape, 'offset', offs[k],
+            'valid', np.isfinite(flows[k][0]).sum())
+  save('flow_map3d', **out)
+
+
+def relax_passes_cases():
+  """Inputs of the three-pass driver cases (shared with tests/test_gpu_mesh.py)."""
+  cases = {}
+  for case in ('regularized', 'regular', 'prep_failed', 'masked', 'median'):
+    rng = np.random.default_rng(8)
+    shape = (2, 1, 40, 44)
+    prev = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, 4, 4)) * 60
+    if case in ('regularized', 'masked', 'median'):
+      prev[0, 0, 18:22, 20:24] += 60          # a local fold in the flow field
+    if case == 'median':
+      prev[0] += 25.0                         # a global offset: PREV_MEDIAN start state
+    frac = 0.7
+    if case == 'prep_failed':
+      # a 100 px tear: the free band of the soft pass is stretched beyond 1.1
+      prev = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, 4, 4)) * 20
+      prev[0, 0, :, 22:] += 100
+      frac = 0.9
+    mask = None
+    if case == 'masked':
+      mask = np.zeros((1, 40, 44), bool)
+      mask[0, :3, :] = True
+    cases[case] = dict(prev=prev.astype(np.float32), frac=frac, mask=mask,
+                       median=(case == 'median'))
+  kw = dict(dt=0.001, gamma=0.0, k0=0.3, k=0.1, stride=(40, 40), num_iters=100,
+            max_iters=400, stop_v_max=0.005, dt_max=1000, start_cap=1e6,
+            final_cap=1e6, prefer_orig_order=True)
+  return cases, kw
+
+
+def gen_relax_passes():
+  """processor/mesh.py:428-513 RelaxMesh.relax_mesh, the REFERENCE method run on
+  an instance that only carries `_config` (all it touches): relax -> fold test ->
+  soft relaxation -> fold test -> final relaxation."""
+  import types
+  from sofima.processor import mesh as rproc
+  cases, kw = relax_passes_cases()
+  cfg = rmesh.IntegrationConfig(**kw)
+  out = dict(cfg=json.dumps(kw), names=np.array(list(cases)))
+  for name, c in cases.items():
+    proc = rproc.RelaxMesh.__new__(rproc.RelaxMesh)
+    proc._config = types.SimpleNamespace(
+        mesh_min_frac=c['frac'],
+        options=rproc.MeshOptions(
+            init_state=rproc.MeshInitState.PREV_MEDIAN if c['median']
+            else rproc.MeshInitState.ZEROS))
+    x0 = np.zeros_like(c['prev'])
+    x, e_kin, steps, status = proc.relax_mesh(x0, c['prev'].copy(), cfg, c['mask'])
+    print('relax_passes', name, 'status', int(status), 'steps', steps)
+    out[f'{name}_prev'] = c['prev']
+    out[f'{name}_frac'] = np.float64(c['frac'])
+    out[f'{name}_mask'] = (np.zeros((0,), bool) if c['mask'] is None else c['mask'])
+    out[f'{name}_median'] = np.bool_(c['median'])
+    out[f'{name}_x'] = np.asarray(x, dtype=np.float32)
+    out[f'{name}_ekin'] = np.asarray(e_kin, dtype=np.float64)
+    out[f'{name}_steps'] = np.int64(steps)
+    out[f'{name}_status'] = np.int64(int(status))
+  save('relax_passes', **out)
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'irregular', 'montage3d', 'montage', 'stitch']
+  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'irregular', 'montage3d', 'montage', 'stitch', 'passes', 'flowmap3d']
   if 'xcorr' in which:
     gen_xcorr_np()
   if 'peaks' in which:
@@ -604,3 +707,7 @@ if __name__ == '__main__':
     gen_montage()
   if 'stitch' in which:
     gen_stitch()
+  if 'passes' in which:
+    gen_relax_passes()
+  if 'flowmap3d' in which:
+    gen_flow_map3d()

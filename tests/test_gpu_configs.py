@@ -182,3 +182,23 @@ def test_cfg4_3d_montage_mesh_vs_oracle(gpu):
                              [want[3], want[4], want[6]], rtol=1e-6)
   scale = np.abs(want[0]).max()
   np.testing.assert_allclose(np.array(got[0]), want[0], atol=1e-3 * scale)
+
+
+def test_cfg4_flow_map3d_vs_reference_output(gpu, golden):
+  """stitch_elastic.compute_flow_map3d (stitch_elastic.py:85-194) on a 2 x 2 grid
+  of 3-d tiles == the flow arrays and offsets the reference's function produced
+  (flow_map3d.npz): the 3-d flow leg of the volumetric montage, pinned to the
+  reference's own output."""
+  from sofima_amd import stitch_elastic
+  g = golden('flow_map3d')
+  tiles = {tuple(int(v) for v in k): t for k, t in zip(g['tile_keys'], g['tiles'])}
+  shape = tuple(int(v) for v in g['tile_shape'])
+  for name, om, axis in (('fx', g['ox'], 0), ('fy', g['oy'], 1)):
+    flows, offs = stitch_elastic.compute_flow_map3d(
+        tiles, shape, om, axis, patch_size=tuple(g['patch']), stride=tuple(g['stride']),
+        batch_size=8)
+    keys = [tuple(int(v) for v in k) for k in g[name + '_keys']]
+    assert sorted(flows) == sorted(keys)
+    for i, k in enumerate(keys):
+      assert tuple(offs[k]) == tuple(g[name + '_offsets'][i])
+      check_flow(flows[k], g[f'{name}_{i}'], sharp_rtol=2e-3)

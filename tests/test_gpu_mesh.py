@@ -153,8 +153,50 @@ def test_relax_matches_golden(gpu, golden):
   # 400 FIRE steps with force capping amplify the round-off of the first steps
   # (same step count and FIRE branch sequence): measured max |dx| 1.6e-3 on
   # positions up to 4.2 (3.8e-4 relative), kinetic energies within 2.5 %
-  np.testing.assert_allclose(np.array(xs), g['em2d_x'], atol=5e-3)
-  np.testing.assert_allclose(ek, g['em2d_ekin'], rtol=5e-2, atol=1e-6)
+  # (test_em2d_divergence_is_amplified_roundoff follows the two trajectories)
+  np.testing.assert_allclose(np.array(xs), g['em2d_x'], atol=2.5e-3)
+  np.testing.assert_allclose(ek, g['em2d_ekin'], rtol=3e-2, atol=1e-6)
+
+
+def test_em2d_divergence_is_amplified_roundoff(gpu, golden, capsys):
+  """Why `em2d` carries atol 2.5e-3 instead of SURVEY 8c's 1e-3: the HIP and the
+  oracle trajectories of that case are followed chunk by chunk (20 steps each,
+  the FIRE scalars handed over like relax_mesh does).  The FIRE scalars stay
+  IDENTICAL (same branch at every step), the positions agree to 1 ulp-scale
+  after the first chunks and drift apart smoothly: the end-state difference is
+  round-off amplified by the capped-force dynamics, not a different algorithm."""
+  import dataclasses
+  from sofima_amd import mesh
+  g = golden('mesh_relax')
+  cfg = cfg_from(load_cfgs(g)['em2d'], mesh.IntegrationConfig)
+  cfg = dataclasses.replace(cfg, num_iters=20, max_iters=400)
+  ocfg = cfg_from(dataclasses.asdict(cfg))
+  x0, prev = g['xe'], g['pe']
+  gx, gv = x0.copy(), np.zeros_like(x0)
+  wx, wv = x0.copy(), np.zeros_like(x0)
+  dt, alpha, cap = cfg.dt, cfg.alpha, cfg.start_cap
+  scale = float(np.nanmax(np.abs(g['em2d_x'])))
+  curve = []
+  for chunk in range(cfg.max_iters // cfg.num_iters):
+    go = mesh.velocity_verlet(gx, gv, prev, cfg, cap, dt, alpha)
+    wo = mesh_oracle.velocity_verlet(wx, wv, prev, ocfg, cap, dt, alpha)
+    gx, gv = np.array(go[0]), np.array(go[1])
+    wx, wv = wo[0], wo[1]
+    # identical FIRE state: dt, alpha (1 ulp), n_pos, cap
+    np.testing.assert_allclose([go[3], go[4], go[6]], [wo[3], wo[4], wo[6]], rtol=1e-6)
+    assert go[5] == wo[5]
+    dt, alpha, cap = wo[3], wo[4], wo[6]
+    v_max = float(np.sqrt((wv ** 2).sum(axis=0)).max())
+    if v_max < cfg.stop_v_max and cap < cfg.final_cap:
+      cap = min(cap * cfg.cap_scale, cfg.final_cap)
+    curve.append(float(np.nanmax(np.abs(gx - wx))) / scale)
+  with capsys.disabled():
+    print('em2d |dx| / scale per 20-step chunk:', ' '.join('%.1e' % c for c in curve))
+  assert max(curve[:3]) <= 2e-6          # 60 steps: still at round-off level
+  assert curve[-1] <= 6e-4               # 400 steps: 2.5e-3 px on a 4.2 px field
+  # smooth growth, no jump (a wrong branch or a missed cap update would show as one)
+  for a, b in zip(curve[5:-1], curve[6:]):
+    assert b <= 4 * max(a, 1e-7)
 
 
 def test_relaxation_known_answers(gpu):
@@ -379,6 +421,32 @@ def test_three_pass_relaxation_driver_vs_oracle(gpu, case):
   scale = np.nanmax(np.abs(wx))
   np.testing.assert_allclose(np.nan_to_num(gx), np.nan_to_num(wx), atol=2e-3 * scale)
   np.testing.assert_allclose(ge, we, rtol=5e-2, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['regularized', 'regular', 'prep_failed', 'masked', 'median'])
+def test_three_pass_relaxation_driver_vs_reference_output(gpu, golden, case):
+  """processor_mesh.relax_mesh == what RelaxMesh.relax_mesh of the reference
+  returned for the same inputs (relax_passes.npz, generated by running
+  processor/mesh.py:428-513 through the stand-in): status, steps, NaN pattern,
+  mesh, energies."""
+  import json
+  from sofima_amd import mesh, processor_mesh
+  g = golden('relax_passes')
+  cfg = mesh.IntegrationConfig(**json.loads(str(g['cfg'])))
+  prev = g[f'{case}_prev']
+  mask = g[f'{case}_mask']
+  mask = None if mask.size == 0 else mask
+  init = (processor_mesh.MeshInitState.PREV_MEDIAN if bool(g[f'{case}_median'])
+          else processor_mesh.MeshInitState.ZEROS)
+  gx, ge, gs, gstat = processor_mesh.relax_mesh(
+      np.zeros_like(prev), prev.copy(), cfg, mask, float(g[f'{case}_frac']), init)
+  assert int(gstat) == int(g[f'{case}_status']) and gs == int(g[f'{case}_steps'])
+  want = g[f'{case}_x']
+  np.testing.assert_array_equal(np.isnan(gx), np.isnan(want))
+  scale = np.nanmax(np.abs(want))
+  np.testing.assert_allclose(np.nan_to_num(gx), np.nan_to_num(want), atol=2e-3 * scale)
+  np.testing.assert_allclose(ge, g[f'{case}_ekin'], rtol=5e-2, atol=1e-6)
 
 
 @pytest.mark.gpu

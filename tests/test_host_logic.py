@@ -188,3 +188,25 @@ def test_force_spec_resolution():
   assert spec.kind == 2 and spec.ncomp is None
   with pytest.raises(TypeError):
     mesh._resolve_force(3)
+
+
+def test_flow_map3d_overlap_alignment_matches_reference_offsets(golden):
+  """The host arithmetic of compute_flow_map3d (aligned overlap boxes,
+  stitch_elastic.py:125-180): recorded offsets == the reference's, the flow grid
+  sizes follow from the overlap sizes."""
+  from sofima_amd import stitch_elastic
+  g = golden('flow_map3d')
+  shape = tuple(int(v) for v in g['tile_shape'])
+  stride = tuple(int(v) for v in g['stride'])
+  patch = tuple(int(v) for v in g['patch'])
+  for name, om, axis in (('fx', g['ox'], 0), ('fy', g['oy'], 1)):
+    for i, k in enumerate(g[name + '_keys']):
+      x, y = int(k[0]), int(k[1])
+      cur, nb, size, rec = stitch_elastic._aligned_overlap3d(shape, om[:, 0, y, x], axis,
+                                                             stride)
+      assert rec == tuple(g[name + '_offsets'][i])
+      s = stride[2 - axis]
+      assert np.all(cur % s == 0) and np.all(nb % s == 0) and np.all(size > 0)
+      grid = [(n - (p - st)) // st + p // 2 // st * 2 - 1
+              for n, p, st in zip(size[::-1], patch, stride)]
+      assert tuple(g[f'{name}_{i}'].shape[1:]) == tuple(grid)

@@ -280,3 +280,36 @@ def test_flow_map_cfg1_oracle_vs_golden(golden):
     for i, k in enumerate(keys):
       assert tuple(offs[k]) == tuple(g[name + '_offsets'][i])
       check_flow(flows[k], g[f'{name}_{i}'])
+
+
+@pytest.mark.parametrize('case', ['regularized', 'regular', 'prep_failed', 'masked', 'median'])
+def test_three_pass_driver_oracle_vs_reference_output(golden, case):
+  """mesh_oracle.relax_mesh_passes against RelaxMesh.relax_mesh of the reference
+  (processor/mesh.py:428-513, run through the stand-in on an instance carrying
+  only `_config`): status, step count, NaN pattern, mesh, energy trace."""
+  import json
+  import types
+  g = golden('relax_passes')
+  cfg = types.SimpleNamespace(**json.loads(str(g['cfg'])))
+  for k, v in dict(fire=True, f_alpha=0.99, f_inc=1.1, f_dec=0.5, alpha=0.1, n_min=5,
+                   cap_scale=1.1, cap_upscale_every=100, remove_drift=False).items():
+    if not hasattr(cfg, k):
+      setattr(cfg, k, v)
+  cfg.stride = tuple(cfg.stride)
+  prev = g[f'{case}_prev']
+  mask = g[f'{case}_mask']
+  mask = None if mask.size == 0 else mask
+  start_fn = None
+  if bool(g[f'{case}_median']):
+    def start_fn(x, p):      # maybe_update_init_state, PREV_MEDIAN (processor/mesh.py:387-398)
+      x[0, ...] = np.nanmedian(p[0, ...])
+      x[1, ...] = np.nanmedian(p[1, ...])
+      return np.nan_to_num(x)
+  x, ek, steps, status = mo.relax_mesh_passes(np.zeros_like(prev), prev, cfg, mask,
+                                              float(g[f'{case}_frac']), start_fn)
+  assert status == int(g[f'{case}_status']) and steps == int(g[f'{case}_steps'])
+  want = g[f'{case}_x']
+  np.testing.assert_array_equal(np.isnan(x), np.isnan(want))
+  scale = np.nanmax(np.abs(want))
+  np.testing.assert_allclose(np.nan_to_num(x), np.nan_to_num(want), atol=1e-4 * scale)
+  np.testing.assert_allclose(ek, g[f'{case}_ekin'], rtol=1e-3, atol=1e-7)
