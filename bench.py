@@ -558,8 +558,11 @@ def cpu_baseline_child(size, seed, pair='warped'):
   import multiprocessing as mp
   cores = os.cpu_count() or 1
   pre, post = synth_pair(size, seed, warp=WARP if pair == 'warped' else None)
-  batch = 256
   n_grid = (size - (PATCH - STEP)) // STEP
+  # reference batches small enough that every host core gets at least one
+  batch = 256
+  while batch > 32 and (n_grid * n_grid) // batch < cores:
+    batch //= 2
   yy, xx = np.mgrid[:n_grid, :n_grid]
   starts = np.stack([yy.ravel(), xx.ravel()], axis=1).astype(np.int64) * STEP
   n_batches = starts.shape[0] // batch
@@ -575,6 +578,7 @@ def cpu_baseline_child(size, seed, pair='warped'):
   os.environ['OMP_NUM_THREADS'] = '1'
   os.environ['OPENBLAS_NUM_THREADS'] = '1'
   workers = min(cores, n_b)
+  n_b = n_b // workers * workers      # whole rounds: every worker the same load
   with mp.get_context('fork').Pool(workers) as pool:
     pool.map(_cpu_flow_batch, range(workers))          # warm-up (imports, FFT plans)
     t0 = time.perf_counter()
