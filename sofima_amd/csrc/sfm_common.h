@@ -30,6 +30,43 @@ int fail(int code, const char* fmt, ...);
 // valid until the option is set again.
 const char* option(const char* name);
 
+// FIRE scalars as the mesh kernels keep them on the device (sfm_mesh.hip) and
+// the pending per-step corrections derived from the previous step's sums.
+struct MeshScalars {
+  float dt, alpha;
+  int n_pos;
+  float cap;
+  float gate;
+  float mx[3];
+  float mv[3];
+};
+
+// How a kernel outside sfm_mesh.hip reads the position a node has AFTER the
+// position update of the running step, x' = x + dt v + dt^2/2 a (with the pending
+// velocity gate / drift removal of the previous step, mesh.py:439, 492-497),
+// from the state before it -- the same expression, operation for operation, as
+// advance_kernel / the fused integrators evaluate.  v == nullptr: x is final.
+struct AdvanceView {
+  const float* v;
+  const float* a;
+  const MeshScalars* scal;   // FIRE: dt, gate, drift means of the step
+  int fire;
+  int pending;               // the previous step's gate / drift still to apply
+  int remove_drift;
+  float vv_dt;               // damped Verlet: fixed dt
+};
+
+// sfm_maps.hip: prev = target_mesh(x') written to `out`.  strips_only: nodes
+// outside every neighbour's paste region are left untouched (they are NaN after
+// one full evaluation and never change).
+int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
+                       hipStream_t st, const AdvanceView* adv = nullptr,
+                       bool strips_only = false, const int* block_list = nullptr);
+// The node blocks that touch a paste region (in-plane montages), built once per
+// chunk for the strips-only launches: `list` holds target_list_ints(d) ints.
+size_t target_list_ints(const SfmTargetMeshDesc* d);
+int build_target_list(const SfmTargetMeshDesc* d, int* list, hipStream_t st);
+
 // sfm_comm.hip: grouped point-to-point building blocks (RCCL).
 int comm_group_begin(SfmComm* c);
 int comm_send(SfmComm* c, const float* buf, size_t count, int peer, hipStream_t st);

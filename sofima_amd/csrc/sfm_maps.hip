@@ -34,9 +34,33 @@ __device__ __forceinline__ Axis make_axis(float q) {
   return a;
 }
 
+// One component plane of a mesh as the sampler sees it: the stored values, or
+// the positions after the running step's position update (sfm::AdvanceView:
+// the expression of advance_kernel in sfm_mesh.hip, operation for operation).
+struct Plane {
+  const float* x;
+  const float* v;   // ADV only
+  const float* a;
+  float dt, c2, gate, mx, mv;   // no pending gate / drift: gate = 1, mx = mv = 0
+  // Branch free (a load under a condition would be waited for on its own):
+  // v * 1, x - 0 and v - 0 are exact, so one expression serves every case.
+  template <bool ADV>
+  __device__ __forceinline__ float at(long long i) const {
+    if (!ADV) return x[i];
+    const float xv = x[i] - mx;
+    const float vv = v[i] * gate - mv;
+    return xv + (dt * vv + c2 * a[i]);
+  }
+};
+
+__device__ __forceinline__ Plane plain(const float* m) {
+  return Plane{m, nullptr, nullptr, 0.f, 0.f, 1.f, 0.f, 0.f};
+}
+
 // Bilinear sample of plane `m` [ny, nx] + ref (ref = offset + index * step
 // along `ref_axis`) at (qy, qx).
-__device__ float sample2(const float* __restrict__ m, int ny, int nx, float qy,
+template <bool ADV = false>
+__device__ float sample2(const Plane& m, int ny, int nx, float qy,
                          float qx, bool constant, int ref_axis, float ref_off,
                          float ref_step) {
   if (isnan(qy) || isnan(qx)) return NAN;
@@ -52,7 +76,7 @@ __device__ float sample2(const float* __restrict__ m, int ny, int nx, float qy,
       bool valid = iy >= 0 && iy < ny && ix >= 0 && ix < nx;
       iy = min(max(iy, 0), ny - 1);
       ix = min(max(ix, 0), nx - 1);
-      float v = m[(long long)iy * nx + ix] +
+      float v = m.template at<ADV>((long long)iy * nx + ix) +
                 (ref_off + static_cast<float>(ref_axis == 0 ? iy : ix)) * ref_step;
       if (constant && !valid) v = NAN;
       const float t = w * v;
@@ -62,7 +86,8 @@ __device__ float sample2(const float* __restrict__ m, int ny, int nx, float qy,
   return sum;
 }
 
-__device__ float sample3(const float* __restrict__ m, int nz, int ny, int nx,
+template <bool ADV = false>
+__device__ float sample3(const Plane& m, int nz, int ny, int nx,
                          float qz, float qy, float qx, bool constant, int ref_axis,
                          float ref_off, float ref_step) {
   if (isnan(qz) || isnan(qy) || isnan(qx)) return NAN;
@@ -83,7 +108,7 @@ __device__ float sample3(const float* __restrict__ m, int nz, int ny, int nx,
         iy = min(max(iy, 0), ny - 1);
         ix = min(max(ix, 0), nx - 1);
         const int ri = ref_axis == 0 ? iz : (ref_axis == 1 ? iy : ix);
-        float v = m[((long long)iz * ny + iy) * nx + ix] +
+        float v = m.template at<ADV>(((long long)iz * ny + iy) * nx + ix) +
                   (ref_off + static_cast<float>(ri)) * ref_step;
         if (constant && !valid) v = NAN;
         const float t = w * v;
@@ -122,18 +147,18 @@ __global__ void __launch_bounds__(kBlock) compose_kernel(ComposeArgs a) {
       // in map2 cannot occur: the reference indexes map2[:, z] directly.
       const float* p0 = a.m2 + (long long)z * plane2;
       const float* p1 = a.m2 + n2 + (long long)z * plane2;
-      a.out[i] = sample2(p0, a.s2[1], a.s2[2], qy, qx, a.constant, 1, a.off2[2],
+      a.out[i] = sample2(plain(p0), a.s2[1], a.s2[2], qy, qx, a.constant, 1, a.off2[2],
                          a.st2[2]) - ref1x;
-      a.out[n1 + i] = sample2(p1, a.s2[1], a.s2[2], qy, qx, a.constant, 0,
+      a.out[n1 + i] = sample2(plain(p1), a.s2[1], a.s2[2], qy, qx, a.constant, 0,
                               a.off2[1], a.st2[1]) - ref1y;
     } else {
       const float ref1z = (static_cast<float>(z) + a.off1[0]) * a.st1[0];
       const float qz = (ref1z + a.m1[2 * n1 + i]) / a.st2[0];
-      a.out[i] = sample3(a.m2, a.s2[0], a.s2[1], a.s2[2], qz, qy, qx, a.constant,
+      a.out[i] = sample3(plain(a.m2), a.s2[0], a.s2[1], a.s2[2], qz, qy, qx, a.constant,
                          2, a.off2[2], a.st2[2]) - ref1x;
-      a.out[n1 + i] = sample3(a.m2 + n2, a.s2[0], a.s2[1], a.s2[2], qz, qy, qx,
+      a.out[n1 + i] = sample3(plain(a.m2 + n2), a.s2[0], a.s2[1], a.s2[2], qz, qy, qx,
                               a.constant, 1, a.off2[1], a.st2[1]) - ref1y;
-      a.out[2 * n1 + i] = sample3(a.m2 + 2 * n2, a.s2[0], a.s2[1], a.s2[2], qz, qy,
+      a.out[2 * n1 + i] = sample3(plain(a.m2 + 2 * n2), a.s2[0], a.s2[1], a.s2[2], qz, qy,
                                   qx, a.constant, 0, a.off2[0], a.st2[0]) - ref1z;
     }
   }
@@ -147,6 +172,10 @@ struct TargetArgs {
   SfmTargetMeshDesc d;
   const float* x;
   float* out;
+  sfm::AdvanceView adv;   // adv.v == nullptr: x holds the positions to sample
+  int strips_only;        // leave nodes outside every paste region untouched
+  const int* list;        // strips-only: blocks to evaluate (target_list_kernel)
+  const int* count;
 };
 
 // One thread per (tile, node).  The reference pastes the four neighbour
@@ -166,16 +195,11 @@ struct NbEntry {
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
-  const SfmTargetMeshDesc& d = a.d;
+// Everything about neighbour entry j of `tile` that does not depend on the node.
+__device__ NbEntry make_entry(const SfmTargetMeshDesc& d, int tile, int j) {
   const int nc = d.ncomp;
   const int mz = d.mesh_shape[0], my = d.mesh_shape[1], mx = d.mesh_shape[2];
-  const long long mn = (long long)mz * my * mx;
-  const float sz = d.stride[0], sy = d.stride[1], sx = d.stride[2];
-  const int tile = blockIdx.y;
-  __shared__ NbEntry s_e[4];
-  if (threadIdx.x < 4) {
-    const int* nb = d.nbors + ((long long)tile * 4 + threadIdx.x) * d.nbor_fields;
+  const int* nb = d.nbors + ((long long)tile * 4 + j) * d.nbor_fields;
     NbEntry e;
     const int nbor = nb[kNbor];
     e.valid = nbor != -1;
@@ -215,15 +239,90 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
     // jax clamps the dynamic indices; valid data never needs it
     e.fi = min(max(flow_idx, 0), e.n_f - 1);
     e.nb_i = min(max(nbor, 0), d.n_tiles - 1);
+    return e;
+}
+
+// Which 16 x 16 node blocks of which tiles touch a paste region (in-plane
+// montages): built once per chunk, so that the per-step launches of the
+// strips-only evaluation spend their workgroups on the overlap strips only.
+// list[i] = tile * blocks_per_tile + block; *count = entries.
+__global__ void __launch_bounds__(kBlock)
+target_list_kernel(SfmTargetMeshDesc d, int* __restrict__ list, int* __restrict__ count) {
+  const int my = d.mesh_shape[1], mx = d.mesh_shape[2];
+  const int n_bx = (mx + 15) >> 4, n_by = (my + 15) >> 4;
+  const int tile = blockIdx.y;
+  const int blk = blockIdx.x * kBlock + threadIdx.x;
+  if (blk >= n_bx * n_by) return;
+  const int bx = blk % n_bx, by = blk / n_bx;
+  bool any = false;
+  for (int j = 0; j < 4; ++j) {
+    const NbEntry e = make_entry(d, tile, j);
+    if (!e.valid) continue;
+    const int y0 = e.tg[1], x0 = e.tg[2], y1 = y0 + e.fsz[1], x1 = x0 + e.fsz[2];
+    any = any || (by * 16 < y1 && by * 16 + 16 > y0 && bx * 16 < x1 && bx * 16 + 16 > x0);
+  }
+  if (any) list[atomicAdd(count, 1)] = tile * (n_bx * n_by) + blk;
+}
+
+template <bool ADV>
+__global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
+  const SfmTargetMeshDesc& d = a.d;
+  const int nc = d.ncomp;
+  const int mz = d.mesh_shape[0], my = d.mesh_shape[1], mx = d.mesh_shape[2];
+  const long long mn = (long long)mz * my * mx;
+  const float sz = d.stride[0], sy = d.stride[1], sx = d.stride[2];
+  int tile = blockIdx.y, blk = blockIdx.x;
+  if (a.list) {   // strips-only launch over the block list of target_list_kernel
+    if (static_cast<int>(blockIdx.x) >= *a.count) return;
+    const int bpt = ((mx + 15) >> 4) * ((my + 15) >> 4);
+    const int code = a.list[blockIdx.x];
+    tile = code / bpt;
+    blk = code - tile * bpt;
+  }
+  __shared__ NbEntry s_e[4];
+  if (threadIdx.x < 4) {
+    const NbEntry e = make_entry(d, tile, threadIdx.x);
     s_e[threadIdx.x] = e;
   }
   __syncthreads();
+  // the step's position update, if the caller has not applied it yet; the
+  // pending gate / drift of the previous step folded into neutral values
+  float a_dt = 0.f, a_c2 = 0.f, a_gate = 1.f, a_mx[3] = {0.f, 0.f, 0.f},
+        a_mv[3] = {0.f, 0.f, 0.f};
+  if (ADV) {
+    a_dt = a.adv.fire ? a.adv.scal->dt : a.adv.vv_dt;
+    a_c2 = 0.5f * (a_dt * a_dt);
+    if (a.adv.fire && a.adv.pending) {
+      a_gate = a.adv.scal->gate;
+      if (a.adv.remove_drift)
+        for (int c = 0; c < 3; ++c) {
+          a_mx[c] = a.adv.scal->mx[c];
+          a_mv[c] = a.adv.scal->mv[c];
+        }
+    }
+  }
+  auto plane_of = [&](int c, int nb_i) {
+    const long long off = ((long long)c * d.n_tiles + nb_i) * mn;
+    if (!ADV) return plain(a.x + off);
+    return Plane{a.x + off, a.adv.v + off, a.adv.a + off, a_dt, a_c2, a_gate, a_mx[c], a_mv[c]};
+  };
   // A wave covers 16 columns x 4 rows, a workgroup 16 x 16 nodes: waves are
   // either inside an overlap strip or outside (with one row of 64 nodes per
   // wave, every wave crossing a 20-node wide left / right strip ran the
   // sampling path with 10 % of its lanes).
   const int n_bx = (mx + 15) >> 4;
-  const int bx = blockIdx.x % n_bx, by = blockIdx.x / n_bx;
+  const int bx = blk % n_bx, by = blk / n_bx;
+  if (a.strips_only && nc == 2 && !a.list) {
+    // does this 16 x 16 block of nodes touch a paste region at all?
+    bool any = false;
+    for (int j = 0; j < 4; ++j) {
+      if (!uniform(s_e[j].valid)) continue;
+      const int y0 = uniform(s_e[j].tg[1]), x0 = uniform(s_e[j].tg[2]);
+      const int y1 = y0 + uniform(s_e[j].fsz[1]), x1 = x0 + uniform(s_e[j].fsz[2]);
+      any = any || (by * 16 < y1 && by * 16 + 16 > y0 && bx * 16 < x1 && bx * 16 + 16 > x0);
+    }
+    if (!any) return;
+  }
   {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = bx * 16 + (lane & 15);
@@ -233,6 +332,7 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
     const int ty = row - tz * my;
     const int node = row * mx + tx;
     float rx = NAN, ry = NAN, rz = NAN;
+    bool in_region = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (!uniform(s_e[j].valid)) continue;
@@ -242,6 +342,7 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
       const int fz_n = uniform(s_e[j].fsz[0]), fy_n = uniform(s_e[j].fsz[1]),
                 fx_n = uniform(s_e[j].fsz[2]);
       if (uz < 0 || uz >= fz_n || uy < 0 || uy >= fy_n || ux < 0 || ux >= fx_n) continue;
+      in_region = true;
       const int dim = uniform(s_e[j].dim), n_f = uniform(s_e[j].n_f);
       const float* farr = dim == 0 ? d.fx : d.fy;
       const long long fvol = (long long)fz_n * fy_n * fx_n;
@@ -258,21 +359,21 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
       const float qx = (ref1x + m1x) / sx;
       const float qy = (ref1y + m1y) / sy;
       const int nb_i = uniform(s_e[j].nb_i);
-      const float* nx0 = a.x + (long long)nb_i * mn;
-      const float* nx1 = a.x + ((long long)d.n_tiles + nb_i) * mn;
+      const Plane nx0 = plane_of(0, nb_i);
+      const Plane nx1 = plane_of(1, nb_i);
       float ux_v, uy_v, uz_v = NAN;
       if (nc == 2) {
-        ux_v = sample2(nx0, my, mx, qy, qx, true, 1, 0.f, sx) - ref1x;
-        uy_v = sample2(nx1, my, mx, qy, qx, true, 0, 0.f, sy) - ref1y;
+        ux_v = sample2<ADV>(nx0, my, mx, qy, qx, true, 1, 0.f, sx) - ref1x;
+        uy_v = sample2<ADV>(nx1, my, mx, qy, qx, true, 0, 0.f, sy) - ref1y;
       } else {
         const float m1z = fm * farr[2LL * n_f * fvol + fo];
         const float ref1z =
             (static_cast<float>(uz) + static_cast<float>(uniform(s_e[j].st[0]))) * sz;
         const float qz = (ref1z + m1z) / sz;
-        const float* nx2 = a.x + (2LL * d.n_tiles + nb_i) * mn;
-        ux_v = sample3(nx0, mz, my, mx, qz, qy, qx, true, 2, 0.f, sx) - ref1x;
-        uy_v = sample3(nx1, mz, my, mx, qz, qy, qx, true, 1, 0.f, sy) - ref1y;
-        uz_v = sample3(nx2, mz, my, mx, qz, qy, qx, true, 0, 0.f, sz) - ref1z;
+        const Plane nx2 = plane_of(2, nb_i);
+        ux_v = sample3<ADV>(nx0, mz, my, mx, qz, qy, qx, true, 2, 0.f, sx) - ref1x;
+        uy_v = sample3<ADV>(nx1, mz, my, mx, qz, qy, qx, true, 1, 0.f, sy) - ref1y;
+        uz_v = sample3<ADV>(nx2, mz, my, mx, qz, qy, qx, true, 0, 0.f, sz) - ref1z;
         uz_v = uz_v + static_cast<float>(uniform(s_e[j].fine[2]));
       }
       ux_v = ux_v + static_cast<float>(uniform(s_e[j].fine[0]));
@@ -281,6 +382,7 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
       if (!isnan(uy_v)) ry = uy_v;
       if (!isnan(uz_v)) rz = uz_v;
     }
+    if (a.strips_only && !in_region) return;   // NaN since the first full evaluation
     // out holds the evaluated tiles only: [ncomp, n_eval, *mesh]
     const long long n_out = d.n_eval > 0 ? d.n_eval : d.n_tiles;
     a.out[(long long)tile * mn + node] = rx;
@@ -298,8 +400,25 @@ int grid_for(long long n) {
 
 namespace sfm {
 
+size_t target_list_ints(const SfmTargetMeshDesc* d) {
+  if (!d || d->ncomp != 2) return 0;
+  const long long bpt = (long long)((d->mesh_shape[2] + 15) / 16) * ((d->mesh_shape[1] + 15) / 16);
+  return static_cast<size_t>(bpt * d->n_tiles + 4);
+}
+
+int build_target_list(const SfmTargetMeshDesc* d, int* list, hipStream_t st) {
+  if (!d || !list || d->ncomp != 2) return fail(SFM_ERR_INVALID, "target list: in-plane only");
+  const int bpt = ((d->mesh_shape[2] + 15) / 16) * ((d->mesh_shape[1] + 15) / 16);
+  SFM_HIP_CHECK(hipMemsetAsync(list, 0, sizeof(int), st));   // list[0]: the count
+  hipLaunchKernelGGL(target_list_kernel, dim3((bpt + kBlock - 1) / kBlock, d->n_tiles),
+                     dim3(kBlock), 0, st, *d, list + 4, list);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
 int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
-                       hipStream_t st) {
+                       hipStream_t st, const AdvanceView* adv, bool strips_only,
+                       const int* block_list) {
   if (!d || !x || !out) return fail(SFM_ERR_INVALID, "target mesh: NULL argument");
   if (d->ncomp != 2 && d->ncomp != 3)
     return fail(SFM_ERR_INVALID, "target mesh: ncomp must be 2 or 3");
@@ -314,6 +433,10 @@ int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
   a.d = *d;
   a.x = x;
   a.out = out;
+  a.adv = adv ? *adv : AdvanceView{nullptr, nullptr, nullptr, 0, 0, 0, 0.f};
+  a.strips_only = strips_only ? 1 : 0;
+  a.list = strips_only && block_list && d->ncomp == 2 ? block_list + 4 : nullptr;
+  a.count = block_list;
   const long long per_tile =
       (long long)d->mesh_shape[0] * d->mesh_shape[1] * d->mesh_shape[2];
   if (d->nbor_fields > 11)
@@ -321,9 +444,15 @@ int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
   if (per_tile > 0x7fffffffLL) return fail(SFM_ERR_INVALID, "target mesh: tile too large");
   const long long gx = (long long)((d->mesh_shape[2] + 15) / 16) *
                        (((long long)d->mesh_shape[0] * d->mesh_shape[1] + 15) / 16);
-  hipLaunchKernelGGL(target_mesh_kernel,
-                     dim3(static_cast<unsigned>(gx), d->n_eval > 0 ? d->n_eval : d->n_tiles),
-                     dim3(kBlock), 0, st, a);
+  dim3 grid(static_cast<unsigned>(gx), d->n_eval > 0 ? d->n_eval : d->n_tiles);
+  if (a.list) {
+    if (d->n_eval > 0) return fail(SFM_ERR_INVALID, "target mesh: block list with n_eval");
+    grid = dim3(static_cast<unsigned>(gx * d->n_tiles), 1);   // upper bound; extra blocks exit
+  }
+  if (a.adv.v)
+    hipLaunchKernelGGL(target_mesh_kernel<true>, grid, dim3(kBlock), 0, st, a);
+  else
+    hipLaunchKernelGGL(target_mesh_kernel<false>, grid, dim3(kBlock), 0, st, a);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }

@@ -30,11 +30,6 @@
 #include <cstdlib>
 #include <cstring>
 
-namespace sfm {
-// sfm_maps.hip
-int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
-                       hipStream_t st);
-}  // namespace sfm
 
 namespace {
 
@@ -89,14 +84,7 @@ struct MeshParams {
   const float* ext;     // external force, [C, N]
 };
 
-struct Scalars {
-  float dt, alpha;
-  int n_pos;
-  float cap;
-  float gate;
-  float mx[3];
-  float mv[3];
-};
+typedef sfm::MeshScalars Scalars;
 
 // Correctly rounded square root and division without the sub-normal scaling of
 // the compiler's IEEE sequences (15 -> 9 and 11 -> 8 instructions; the spring
@@ -3098,6 +3086,7 @@ struct MeshWorkspace {
   u64* tile_part;      // tiled path: [n_tiles * kNP] {epoch, value} granules
   int* ticket;         // tiled path: last-workgroup counter
   float* colsum;       // per-column drift sums [6][X] (remove_drift == 2)
+  int* target_list;    // native prev_fn, in-plane: node blocks on the overlap strips
   size_t bytes;
 };
 
@@ -3124,6 +3113,11 @@ bool shared_enabled() {
 bool march_enabled() {
   const char* e = sfm::option("SFM_MESH_MARCH");
   return e && e[0] == '1';
+}
+
+bool fuse_target_enabled() {
+  const char* e = sfm::option("SFM_MESH_FUSE_TARGET");  // "0": advance + target + integrate
+  return !(e && e[0] == '0');
 }
 
 bool tiled_enabled() {
@@ -3195,9 +3189,10 @@ TilePlan plan_tiles(int ncomp, long long planes, int Y, int X) {
 }
 
 MeshWorkspace carve(void* ws, size_t prev_floats, size_t alt_floats, long long tiles,
-                    int ncols) {
+                    int ncols, size_t list_ints = 0) {
   sfm::Carver c(ws);
   MeshWorkspace w;
+  w.target_list = list_ints ? c.take<int>(list_ints) : nullptr;
   w.prev_buf = prev_floats ? c.take<float>(prev_floats) : nullptr;
   for (int i = 0; i < 3; ++i) w.alt[i] = alt_floats ? c.take<float>(alt_floats) : nullptr;
   w.tile_part = tiles ? c.take<u64>((size_t)tiles * kNP) : nullptr;
@@ -3227,11 +3222,10 @@ MeshWorkspace carve_for(const SfmMeshDesc* d, void* ws, TilePlan* plan) {
   // second (x, v, a) set: ping-pong of the fused tiled step, staging of the
   // persistent kernel's result
   return carve(ws, d->target ? cn : 0,
-               ((d->ncomp == 2 && !d->target && !d->prev_cb &&
-                 d->force_kind == SFM_FORCE_SPRINGS) ||
+               ((d->ncomp == 2 && !d->prev_cb && d->force_kind == SFM_FORCE_SPRINGS) ||
                 t.ntz > 0) ? cn : 0,
                t.tiles,
-               d->shape[3]);
+               d->shape[3], d->target ? sfm::target_list_ints(d->target) : 0);
 }
 
 }  // namespace
@@ -3442,7 +3436,16 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   const bool tiled = tiles.tx && d->num_iters > 0;
   float* bufs[2][3] = {{d->x, d->v, d->a}, {w.alt[0], w.alt[1], w.alt[2]}};
   int in = 0;
-  const bool fused = tiled && !dyn_prev;
+  // Native prev_fn on a tiled in-plane mesh: the target mesh is sampled from the
+  // positions AFTER the position update, which the target kernel forms itself
+  // from (x, v, a) on the overlap strips (sfm::AdvanceView) -- so the step is
+  // target mesh (strips only) + the fused integrator instead of advance + target
+  // mesh (all nodes) + integrate.  Same float operations: bit-identical.
+  const bool fuse_target = tiled && d->target && tiles.ntz == 0 && w.alt[0] &&
+                           fuse_target_enabled();
+  const bool fused = tiled && (!dyn_prev || fuse_target);
+  if (fuse_target && w.target_list)
+    if (int rc = sfm::build_target_list(d->target, w.target_list, st)) return rc;
   const int tgrid = static_cast<int>(tiles.tiles);
   if (tiled) {
     // LDS-tiled integrator (2-D): one launch per step, or advance + prev_fn +
@@ -3512,6 +3515,13 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     } else if (fused) {
       float** bi = bufs[in];
       float** bo = bufs[in ^ 1];
+      if (fuse_target) {
+        const sfm::AdvanceView av{bi[1], bi[2], &w.scal[cur], p.fire, pending,
+                                  p.remove_drift, p.vv_dt};
+        if (int rc = sfm::launch_target_mesh(d->target, bi[0], w.prev_buf, ls, &av, true,
+                                             w.target_list))
+          return rc;
+      }
       if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
       if (tiles.tx == kSX)
         hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(tgrid), dim3(kBlock), 0, ls,

@@ -247,3 +247,34 @@ def test_target_mesh_3d_golden_and_relax(gpu, golden):
   assert gt == wt == 30
   np.testing.assert_allclose(np.array(gx), wx, atol=2e-3 * np.abs(wx).max())
   np.testing.assert_allclose(ge, we, rtol=2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', ['fire_drift', 'fire', 'verlet'])
+def test_fused_target_step_is_bit_identical(gpu, variant):
+  """Tiled in-plane montage with the native prev_fn: target mesh sampled from the
+  advanced positions on the overlap strips + fused integrator (2 launches per
+  step) == advance + full target mesh + integrate (SFM_MESH_FUSE_TARGET=0), bit
+  for bit, over several chunks; and it follows the oracle."""
+  from oracle import maps_oracle, mesh_oracle
+  from sofima_amd import _abi, mesh, stitch_elastic
+  from tests.util import synth_montage
+  rng = np.random.default_rng(31)
+  nb, fx, fy, x0 = synth_montage(rng, 3, 2, (52, 70), 12)
+  stride = (20.0, 20.0)
+  kw = dict(dt=0.001, gamma=0.0, k0=0.02, k=0.1, stride=stride, num_iters=40,
+            max_iters=120, stop_v_max=1e-9, dt_max=100, prefer_orig_order=True,
+            start_cap=0.1, final_cap=10.0, remove_drift=(variant == 'fire_drift'))
+  if variant == 'verlet':
+    kw.update(fire=False, gamma=0.5, dt=0.05, start_cap=10.0)
+  cfg = mesh.IntegrationConfig(**kw)
+  fn = stitch_elastic.TargetMeshFn(nb, fx, fy, stride)
+  a = mesh.relax_mesh(x0, None, cfg, prev_fn=fn)
+  with _abi.option('SFM_MESH_FUSE_TARGET', 0):
+    b = mesh.relax_mesh(x0, None, cfg, prev_fn=fn)
+  np.testing.assert_array_equal(np.array(a[0]), np.array(b[0]))
+  assert a[1] == b[1] and a[2] == b[2]
+  want = mesh_oracle.relax_mesh(
+      x0, None, cfg, prev_fn=lambda xx: maps_oracle.target_mesh_all(nb, xx, fx, fy, stride))
+  assert a[2] == want[2]
+  np.testing.assert_allclose(np.array(a[0]), want[0], atol=1e-3 * np.abs(want[0]).max())

@@ -36,8 +36,8 @@ x = torch.zeros((2, n, m, m), device='cuda')
 cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(20, 20), num_iters=200, max_iters=200,
                              stop_v_max=1e-9, dt_max=1000, start_cap=0.1, final_cap=10, prefer_orig_order=True,
                              remove_drift=True)
-for env in ({}, {'SFM_MESH_TILED': '0'}):
-  os.environ.pop('SFM_MESH_TILED', None); os.environ.update(env)
+for env in ({}, {'SFM_MESH_FUSE_TARGET': '0'}, {'SFM_MESH_TILED': '0'}):
+  os.environ.pop('SFM_MESH_TILED', None); os.environ.pop('SFM_MESH_FUSE_TARGET', None); os.environ.update(env)
   mesh.relax_mesh(x, None, cfg, prev_fn=fn); torch.cuda.synchronize()
   t = time.perf_counter(); _, ek, it = mesh.relax_mesh(x, None, cfg, prev_fn=fn); torch.cuda.synchronize(); dt = time.perf_counter() - t
   nodes = n * m * m
