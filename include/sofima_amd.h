@@ -69,6 +69,7 @@ int sfm_device_count(int* count);
  *   SFM_MFMA_PROBE=0      no seed probe in front of the pruning
  *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry
  *   SFM_MFMA_QUEUE=0      static instead of dynamic patch queue
+ *   SFM_MFMA_XCD=1        one patch queue per XCD (measured: no gain) instead of a flat one
  *   SFM_MFMA_PRIO=n       wave priority experiment (0..3)
  *   SFM_MFMA_MAX_WG_PER_CU=n   occupancy cap of the correlation kernel
  *   SFM_MASKED_FAST=0     masked patches always take all eight passes

@@ -211,6 +211,13 @@ struct MfmaArgs {
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
   // dynamic patch queue (NULL: static striding over the workgroups)
   int* work_counter;
+  // XCD-sharded form of the queue: the patches are cut into 8 contiguous ranges
+  // (partition k = the blocks b == k mod 8 of the prep kernel, which the
+  // dispatcher places on XCD k), every XCD has its own head word (128 bytes
+  // apart) and a workgroup draws from the range of the XCD it runs on, then
+  // steals from the others.  Neighbouring patches overlap by 75 %: their pixels
+  // are then fetched once per XCD L2 instead of once per L2.
+  int* xcd_heads;
   // shader-clock probe: workgroup 0 leaves (core cycles, 10 ns wall ticks) of its
   // residency here (bench.py reports the sustained clock under this kernel);
   // clk[2]: dy tiles skipped by the pruning (low word) / drawn (high word), whole
@@ -235,6 +242,26 @@ __device__ __forceinline__ unsigned load_u32_guarded(const unsigned* base,
   return (idx >= 0 && idx < n_words) ? base[idx] : 0u;
 }
 
+constexpr int kXcds = 8;
+constexpr int kHeadPitch = 32;   // ints between the per-XCD queue heads
+
+// Range of XCD partition k of n items: as many items as there are indices
+// b == k (mod 8) below n, partitions laid out one after the other.
+__host__ __device__ __forceinline__ int xcd_part_len(int n, int k) { return (n - k + kXcds - 1) / kXcds; }
+__host__ __device__ __forceinline__ int xcd_part_base(int n, int k) {
+  int base = 0;
+  for (int i = 0; i < k; ++i) base += xcd_part_len(n, i);
+  return base;
+}
+
+// Patch of prep block `blk`: block b is dispatched to XCD b mod 8 (observed
+// placement; only speed depends on it), so it prepares an item of partition b mod 8.
+__device__ __forceinline__ int xcd_block_item(const MfmaArgs& a, int blk, int n) {
+  if (!a.xcd_heads) return blk;
+  const int k = blk % kXcds;
+  return xcd_part_base(n, k) + blk / kXcds;
+}
+
 // ---------------------------------------------------------------------------
 // prep: patch statistics, integer centre, integral image
 // ---------------------------------------------------------------------------
@@ -243,9 +270,11 @@ __global__ void __launch_bounds__(kThreads) mfma_prep_kernel(MfmaArgs a) {
     *a.work_counter = 0;  // the correlation kernel's patch queue
   if (a.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     a.clk[2] = a.clk[3] = a.clk[4] = 0;
+  if (a.xcd_heads && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kXcds)
+    a.xcd_heads[kHeadPitch * threadIdx.x] = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int red[3][kThreads];
-  const int b = blockIdx.x, s = blockIdx.y;
+  const int b = xcd_block_item(a, blockIdx.x, a.batch), s = blockIdx.y;
   const int py = s == 0 ? a.P[0] : a.Q[0];
   const int px = s == 0 ? a.P[1] : a.Q[1];
   const int H = a.ishape[s][0], W = a.ishape[s][1];
@@ -379,6 +408,8 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   if (a.work_counter && blockIdx.x == 0 && threadIdx.x == 0)
     *a.work_counter = 0;  // the correlation kernel's patch queue
   if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[2] = a.clk[3] = a.clk[4] = 0;  // tile counts
+  if (a.xcd_heads && blockIdx.x == 0 && threadIdx.x < kXcds)
+    a.xcd_heads[kHeadPitch * threadIdx.x] = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_c[2];
   __shared__ float s_mu[2];
@@ -394,7 +425,7 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   __shared__ int col_sq[2][64 * kPrepCols];  // column sums of squares (post: mirrored)
   // sums / sums of squares per 16 x 16 block, later their 2-D prefix sums (in place)
   __shared__ unsigned long long blk_acc[2][kBlkRows][kBlkCols];  // packed like row_acc
-  const int b = blockIdx.x;
+  const int b = xcd_block_item(a, blockIdx.x, a.batch);
   const int py = a.P[0], px = a.P[1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1017,7 +1048,7 @@ __device__ void stage_plane(const unsigned char* __restrict__ img, long long img
 // Masked path prep: clamped origins in image and mask, masked mean, centre.
 __global__ void __launch_bounds__(kThreads) mfma_prep_masked_kernel(MfmaArgs a) {
   __shared__ int red[4][kThreads];
-  const int b = blockIdx.x, s = blockIdx.y;
+  const int b = xcd_block_item(a, blockIdx.x, a.batch), s = blockIdx.y;
   const int py = s == 0 ? a.P[0] : a.Q[0];
   const int px = s == 0 ? a.P[1] : a.Q[1];
   const int H = a.ishape[s][0], W = a.ishape[s][1];
@@ -1863,6 +1894,33 @@ __global__ void __launch_bounds__(kThreads) mfma_first_peak_kernel(MfmaArgs a) {
                    scratch);
 }
 
+// XCD-sharded queue: next item of this workgroup (n_items: none left).  Called
+// by all threads; `state` (thread 0 only): bits 0..2 the partition drawn from,
+// bits 8..15 the partitions found empty.
+__device__ __forceinline__ int pull_item(const MfmaArgs& a, int n_items, int* state,
+                                         int* next_lds) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int item = n_items, st = *state;
+    for (int tries = 0; tries < kXcds; ++tries) {
+      const int x = st & 7;
+      if (!((st >> (8 + x)) & 1)) {
+        const int p = atomicAdd(&a.xcd_heads[kHeadPitch * x], 1);
+        if (p < xcd_part_len(n_items, x)) {
+          item = xcd_part_base(n_items, x) + p;
+          break;
+        }
+        st |= 1 << (8 + x);
+      }
+      st = (st & ~7) | ((x + 1) & 7);   // steal from the next XCD's range
+    }
+    *state = st;
+    *next_lds = item;
+  }
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(*next_lds);
+}
+
 // Next patch of this workgroup; called by all threads at the end of a patch.
 __device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_lds) {
   if (!a.work_counter) return b + gridDim.x;
@@ -1943,7 +2001,12 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   // Work items: patches, or the extra (patch, operand-plane pair) passes of
   // the masked path (see masked_classify_kernel).
   const int n_items = (RAW && a.list) ? *a.n_list : a.batch;
-  for (int item = blockIdx.x; item < n_items; item = next_patch(a, item, next_lds)) {
+  // HW_REG_XCC_ID (20), bits [3:0]: the XCD this workgroup runs on
+  int q_state = a.xcd_heads ? static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;
+  for (int item = a.xcd_heads ? pull_item(a, n_items, &q_state, next_lds) : blockIdx.x;
+       item < n_items;
+       item = a.xcd_heads ? pull_item(a, n_items, &q_state, next_lds)
+                          : next_patch(a, item, next_lds)) {
     int b = item;
     int plane0 = a.plane[0], plane1 = a.plane[1];
     if (RAW && a.list) {
@@ -2923,7 +2986,7 @@ Ws carve_ws(const SfmXcorrDesc* d, void* base) {
   std::memset(&w, 0, sizeof(w));
   const size_t B = d->batch;
   w.pp = c.take<PatchParams>(B);
-  w.counter = c.take<int>(64);
+  w.counter = c.take<int>(64 + kXcds * kHeadPitch);  // queue head, clk probe, per-XCD heads
   if (same_size(d)) {
     w.aux_n = std::max(d->patch[1], d->patch[2]) + 1;
     w.gtab = c.take<float>(B * d->patch[1] * d->patch[2]);
@@ -3174,6 +3237,12 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   {
     const char* e = sfm::option("SFM_MFMA_QUEUE");
     a.work_counter = (e && e[0] == '0') ? nullptr : w.counter;
+    // Measured on MI355X (8192^2 warped pair, A/B on one box, pruned and not):
+    // 15.48-15.53 / 20.0-20.06 ms either way -- the staging round trip is hidden
+    // behind the other workgroup's matrix phase, the kernel is matrix-pipe / power
+    // bound, so L2 locality of the pixel loads buys nothing.  Opt-in ("1").
+    const char* x = sfm::option("SFM_MFMA_XCD");
+    a.xcd_heads = (a.work_counter && x && x[0] == '1') ? w.counter + 64 : nullptr;
     a.clk = reinterpret_cast<long long*>(w.counter + 16);
     const char* p = sfm::option("SFM_MFMA_PRIO");
     a.prio_mode = p ? std::atoi(p) : 0;

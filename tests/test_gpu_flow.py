@@ -1070,3 +1070,20 @@ def test_workspace_budget_only_changes_the_call_size(gpu):
     ff.WORKSPACE_FRACTION = frac
   assert len(calls) > 1 and set(calls) == {32}
   np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_xcd_sharded_patch_queue_is_bit_identical(gpu):
+  """SFM_MFMA_XCD=1 (one patch queue per XCD, prep blocks mapped to the same
+  partitions; opt-in, measured without gain) only changes the processing order."""
+  from sofima_amd import _abi, flow_field as ff
+  rng = np.random.default_rng(78)
+  base = em_texture(rng, (700, 760))
+  pre, post = base[8:680, 10:740].copy(), base[5:677, 14:744].copy()
+  calc = ff.JAXMaskedXCorrWithStatsCalculator()
+  for kw in (dict(patch_size=96, step=24, batch_size=64),
+             dict(patch_size=64, step=16, batch_size=37, post_patch_size=48)):
+    want = calc.flow_field(pre, post, **kw)
+    with _abi.option('SFM_MFMA_XCD', 1):
+      got = calc.flow_field(pre, post, **kw)
+    np.testing.assert_array_equal(got, want)
