@@ -85,8 +85,10 @@ def mesh_inputs(flow, pad):
 
 
 def build_sha():
+  """Hash of the kernel sources in this tree (sofima_amd._build.source_hash)."""
   try:
-    return open(os.path.join(ROOT, '.build_sha')).read().strip()
+    from sofima_amd import _build
+    return _build.source_hash()
   except OSError:
     return None
 

@@ -94,19 +94,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
   return LIB_PATH
 
 
+def source_hash() -> str:
+  """Hash of the kernel sources (csrc/ + the C header): names the BUILD that
+  measurements belong to.  Unlike a git revision it survives documentation
+  commits and rebuilds of unchanged sources."""
+  import hashlib
+  h = hashlib.sha256()
+  files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                 if f.endswith(('.hip', '.h')))
+  files.append(os.path.join(PKG_DIR, '..', 'include', 'sofima_amd.h'))
+  for path in files:
+    h.update(os.path.basename(path).encode())
+    with open(path, 'rb') as f:
+      h.update(f.read())
+  return h.hexdigest()[:12]
+
+
 def _stamp() -> None:
-  """Records the source revision the library was linked from (.build_sha, not
+  """Records the source hash the library was linked from (.build_sha, not
   tracked): the profile scripts stamp their counter summaries with it.  The
   snapshot a GPU box receives has no .git, so the file travels with the .so."""
-  root = os.path.join(PKG_DIR, '..')
   try:
-    sha = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'],
-                         capture_output=True, text=True, check=True).stdout.strip()
-    dirty = subprocess.run(['git', '-C', root, 'status', '--porcelain', '--', 'sofima_amd/csrc',
-                            'include'], capture_output=True, text=True).stdout.strip()
-    with open(os.path.join(root, '.build_sha'), 'w') as f:
-      f.write(sha + ('+' if dirty else '') + '\n')
-  except (OSError, subprocess.CalledProcessError):
+    with open(os.path.join(PKG_DIR, '..', '.build_sha'), 'w') as f:
+      f.write(source_hash() + '\n')
+  except OSError:
     pass
 
 

@@ -461,7 +461,10 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
     x0[s] = min(max(a.starts[s][b * 2 + 1], 0), W - px);
     img_bytes[s] = (long long)H * W;
   }
-  constexpr int kItems = 4;  // items per thread and plane whose loads are in flight
+#ifndef SFM_PREP_ITEMS
+#define SFM_PREP_ITEMS 4
+#endif
+  constexpr int kItems = SFM_PREP_ITEMS;  // items per thread and plane whose loads are in flight
   for (int item0 = threadIdx.x; item0 < n_items; item0 += kPrepThreads * kItems) {
     v4i w[2][kItems];
 #pragma unroll

@@ -171,7 +171,7 @@ def test_banded_c_loop_fused_kernel(gpu, n_bands, mode, drift, fire):
     # the tile-ordered ones in the last bit (2e-9 after one step), and the
     # relaxation amplifies that: 1.4e-7 of the scale after 50 steps, <= 1.3e-4
     # after 150 on this case (1.2e-3 with the 5x larger target field of the
-    # other cases: e_kin 350 at step 50) -- scratch/band_dbg.py.
+    # other cases: e_kin 350 at step 50) -- tools/measure/banded_c_loop.py.
     np.testing.assert_allclose(gx, np.array(sx), atol=2e-4 * scale)
     np.testing.assert_allclose(ge, se, rtol=2e-3)
     np.testing.assert_allclose(gx, wx, atol=1e-3 * scale)
