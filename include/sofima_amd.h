@@ -11,9 +11,9 @@
  *   - plain C types only; every buffer is CALLER-OWNED device memory (HIP
  *     pointers, e.g. torch.Tensor.data_ptr()); the library never frees or
  *     keeps caller memory, and scratch space is passed in as `workspace`.  The
- *     only device memory it owns: hipFFT plan work areas (FFT form of 2-D
- *     float / wide patches) and the twiddle tables of the hand-written FFT
- *     (<= 2 KB per transform length and device), cached for the process;
+ *     only device memory it owns: the twiddle tables of the hand-written FFT
+ *     (8 bytes per sample of a transform length, per device), cached for the
+ *     process;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
  *     the default stream).  Entry points do not synchronise unless stated;
  *   - return 0 on success, a negative SFM_ERR_* otherwise; the message is in
@@ -75,7 +75,6 @@ int sfm_device_count(int* count);
  *   SFM_MASKED_FAST=0     masked patches always take all eight passes
  *   SFM_MASKED_DEADROWS=0 no overlap-rule skips in the masked assembly
  *   SFM_PHASE_XCD=0       masked assembly without the XCD-aware tile order
- *   SFM_FFT_OWN=0         hipFFT plans instead of the hand-written 3-D passes
  *   SFM_MESH_PERSISTENT=0 / SFM_MESH_SPECULATE=0 / SFM_MESH_TILED=0 /
  *   SFM_MESH_SHARED=0 / SFM_MESH_SMALL=0 / SFM_MESH_FUSE_TARGET=0
  *                         fall back to the simpler integrator

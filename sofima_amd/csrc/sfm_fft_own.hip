@@ -1,28 +1,29 @@
-// Hand-written FFT correlation for volumetric patches (the 3-D configuration:
-// 80^3 patches, F = 160 per axis), replacing the hipFFT plans + pad / product /
-// crop kernels of sfm_xcorr_fft.hip where it applies.
+// Hand-written FFT correlation: every transform of the library (no hipFFT).
 //
 //   corr[k] = irfft(rfft(a_pad) conj(rfft(b_pad)))[(k - (Q - 1)) mod F]   (flow_field.py:66-89)
 //
-// What a library FFT cannot know is that 7/8 of the padded input is zero and
-// that only the cropped surface is wanted.  The transform is done as three
-// passes of 1-D FFTs that skip the zero parts and fuse their neighbours:
+// What a library FFT cannot know is that most of the padded input is zero (7/8
+// for volumes, 3/4 in the plane) and that only the cropped surface is wanted.
+// The transform is done as passes of 1-D FFTs that skip the zero parts and fuse
+// their neighbours:
 //
 //   forward  x: rows (z < P0, y < P1) only; reads the un-padded patch, two real
 //               rows per complex FFT (two-for-one), writes F2/2+1 bins per row
 //            y: planes z < P0 only; P1 input samples, zero extended in LDS
 //            z: P0 input samples; for the second operand the product with the
-//               conjugate... (A conj(B)) is formed here
+//               conjugate... (A conj(B)) is formed here  [in-plane patches: no z
+//               passes, the product rides on the y pass]
 //   inverse  z, y: full
 //            x: two Hermitian rows per complex FFT; scales, crops with the
 //               wrap-around index and stores the surface row directly; leaves
 //               the surface maximum for the peak search
 //
-// = 9 passes that move about 200 MB per 80^3 patch pair instead of 445 MB in
-// 12 kernels.  One workgroup transforms kT pencils at a time in LDS with a
-// Stockham auto-sort FFT (radices 2, 3, 4, 5; lengths up to 256), pencils laid
-// out [n][t] so that global accesses are contiguous across the pencils of a
-// tile (strided passes) or along the pencil (x passes).
+// One workgroup transforms KT pencils at a time in LDS with a Stockham auto-sort
+// FFT (radices 2, 3, 4, 5; KT = 16 / 8 / 4 by length, lengths up to 1728),
+// pencils laid out [n][t] so that global accesses are contiguous across the
+// pencils of a tile (strided passes) or along the pencil (x passes).  A y axis
+// beyond one tile (whole-overlap strips: 8192) takes two strided passes with a
+// twiddle in between (four-step split; see PencilArgs).
 #include "sfm_common.h"
 
 #include <cmath>
@@ -36,10 +37,12 @@ namespace sfm {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kT = 16;        // pencils per workgroup
-constexpr int kTP = kT + 1;   // LDS pitch in complex elements (odd: x passes run along n)
-constexpr int kMaxN = 256;
-constexpr int kMaxStages = 8;
+// Pencils per workgroup: 16, or 8 for lengths whose two LDS buffers would not
+// fit with 16 (KT is a template parameter of the kernels; the LDS pitch KT + 1
+// complex elements is odd: the x passes run along n).
+constexpr int kMaxN = 1728;   // 4 pencils per workgroup: (2 n 5 + n) 8 bytes <= 150 KB
+constexpr int kMaxStages = 12;
+constexpr size_t kLdsLimit = 150 * 1024;
 
 struct Plan {
   int N;
@@ -122,9 +125,10 @@ __device__ __forceinline__ void dft5(float2* v) {
 // One Stockham stage of radix R over the kT pencils of a tile (compile-time R:
 // the butterfly lives in registers; the sub-transform length ns is a power of
 // two except after an odd radix, so k = j mod ns is a mask almost always).
-template <int R, bool INV>
+template <int R, bool INV, int KT>
 __device__ __forceinline__ void lds_stage(const float2* a, float2* b, const float2* tw, int N,
                                           int ns) {
+  constexpr int kT = KT, kTP = KT + 1;
   const int nr = N / R;
   const int twstep = N / (ns * R);
   const bool pow2 = (ns & (ns - 1)) == 0;
@@ -154,17 +158,17 @@ __device__ __forceinline__ void lds_stage(const float2* a, float2* b, const floa
 
 // Stockham auto-sort FFT of kT pencils held in LDS as buf[n * kTP + t]; the
 // result is in the returned buffer (one of the two).  tw[k] = exp(-2 pi i k / N).
-template <bool INV>
+template <bool INV, int KT>
 __device__ float2* lds_fft(float2* a, float2* b, const float2* tw, const Plan& pl) {
   const int N = pl.N;
   int ns = 1;
   for (int st = 0; st < pl.stages; ++st) {
     const int r = pl.radix[st];
     switch (r) {
-      case 4: lds_stage<4, INV>(a, b, tw, N, ns); break;
-      case 2: lds_stage<2, INV>(a, b, tw, N, ns); break;
-      case 5: lds_stage<5, INV>(a, b, tw, N, ns); break;
-      default: lds_stage<3, INV>(a, b, tw, N, ns); break;
+      case 4: lds_stage<4, INV, KT>(a, b, tw, N, ns); break;
+      case 2: lds_stage<2, INV, KT>(a, b, tw, N, ns); break;
+      case 5: lds_stage<5, INV, KT>(a, b, tw, N, ns); break;
+      default: lds_stage<3, INV, KT>(a, b, tw, N, ns); break;
     }
     __syncthreads();
     float2* tmp = a;
@@ -192,10 +196,18 @@ struct PencilArgs {
   int n_o1;            // second outer index (batch)
   long long s_o1;
   int product;         // 1: out = mul * conj(FFT(in))  (A conj(B), mul = A);  2: FFT(in * conj(mul))
+  // Four-step split of a long axis (N = N1 N2, sample n = N2 n1 + n2, bin k = k1 + N1 k2):
+  // pass A transforms over n1 for every n2 (= o0), pass B over n2 for every k1 (= o0);
+  // between them every element (k1, n2) is multiplied by W_N^(k1 n2) [conjugated on the
+  // way back], which rides on the store of the pass in front of the multiplication.
+  int nin_step;        // > 0: pencil o0 has ceil((n_in - o0) / nin_step) non-zero samples
+  const float2* twl;   // table exp(-2 pi i j / N), j < N, or NULL
+  int twl_conj;
 };
 
-template <bool INV>
+template <bool INV, int KT>
 __global__ void __launch_bounds__(kThreads) fft_pencil_kernel(PencilArgs g) {
+  constexpr int kT = KT, kTP = KT + 1;
   extern __shared__ float2 fft_lds[];
   float2* bufa = fft_lds;
   float2* bufb = bufa + g.plan.N * kTP;
@@ -216,30 +228,32 @@ __global__ void __launch_bounds__(kThreads) fft_pencil_kernel(PencilArgs g) {
   // unconditional loads from clamped addresses (loads under per-lane conditions
   // would be waited for one by one), zeros for the padding
   const int tc = min(t, g.n_inner - 1 - ti * kT);
+  const int n_in = g.nin_step ? max(0, (g.n_in - o0 + g.nin_step - 1) / g.nin_step) : g.n_in;
+  const int n_in_c = max(n_in, 1);   // clamp of the load addresses
   constexpr int kLd = 10;  // N = 160: the whole pencil in one round
   for (int nb0 = n0; nb0 < N; nb0 += kLd * kRowsPerIt) {
     float2 v[kLd];
 #pragma unroll
     for (int u = 0; u < kLd; ++u) {
-      const int n = min(nb0 + u * kRowsPerIt, g.n_in - 1);
+      const int n = min(nb0 + u * kRowsPerIt, n_in_c - 1);
       v[u] = g.in[base + n * g.stride + tc];
     }
     if (g.product == 2) {  // (wave-uniform: a second group of loads)
       float2 m[kLd];
 #pragma unroll
       for (int u = 0; u < kLd; ++u)
-        m[u] = g.mul[base + min(nb0 + u * kRowsPerIt, g.n_in - 1) * g.stride + tc];
+        m[u] = g.mul[base + min(nb0 + u * kRowsPerIt, n_in_c - 1) * g.stride + tc];
 #pragma unroll
       for (int u = 0; u < kLd; ++u) v[u] = cmul(v[u], conjf2(m[u]));
     }
 #pragma unroll
     for (int u = 0; u < kLd; ++u) {
       const int n = nb0 + u * kRowsPerIt;
-      if (n < N) bufa[n * kTP + t] = (n < g.n_in && t_ok) ? v[u] : make_float2(0.f, 0.f);
+      if (n < N) bufa[n * kTP + t] = (n < n_in && t_ok) ? v[u] : make_float2(0.f, 0.f);
     }
   }
   __syncthreads();
-  float2* res = lds_fft<INV>(bufa, bufb, tw, g.plan);
+  float2* res = lds_fft<INV, KT>(bufa, bufb, tw, g.plan);
   if (g.product == 1) {
     for (int nb0 = n0; nb0 < N; nb0 += kLd * kRowsPerIt) {
       float2 m[kLd];
@@ -251,6 +265,12 @@ __global__ void __launch_bounds__(kThreads) fft_pencil_kernel(PencilArgs g) {
         const int n = nb0 + u * kRowsPerIt;
         if (n < N && t_ok) g.out[base + n * g.stride + t] = cmul(m[u], conjf2(res[n * kTP + t]));
       }
+    }
+  } else if (g.twl) {
+    for (int n = n0; n < N; n += kRowsPerIt) {
+      float2 w = g.twl[(long long)o0 * n];   // o0 n < N1 N2
+      if (g.twl_conj) w.y = -w.y;
+      if (t_ok) g.out[base + n * g.stride + t] = cmul(res[n * kTP + t], w);
     }
   } else {
     for (int n = n0; n < N; n += kRowsPerIt)
@@ -271,7 +291,9 @@ struct XFwdArgs {
   int square;         // transform the squares of the values (masked terms)
 };
 
+template <int KT>
 __global__ void __launch_bounds__(kThreads) fft_xfwd_kernel(XFwdArgs g) {
+  constexpr int kT = KT, kTP = KT + 1;
   extern __shared__ float2 fft_lds[];
   float2* bufa = fft_lds;
   float2* bufb = bufa + g.plan.N * kTP;
@@ -292,27 +314,30 @@ __global__ void __launch_bounds__(kThreads) fft_xfwd_kernel(XFwdArgs g) {
   for (int t = wave; t < kT; t += kThreads / 64) {
     const int y = 2 * (tp * kT + t);
     const int y0c = min(y, g.P[1] - 1), y1c = min(y + 1, g.P[1] - 1);
-    float r0[4], r1[4];
+    // four 64-sample groups per round (unconditional loads from clamped indices)
+    for (int u0 = 0; u0 * 64 < N; u0 += 4) {
+      float r0[4], r1[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {  // unconditional loads, clamped (four groups: N <= 256)
-      const int n = min(lane + 64 * u, g.P[2] - 1);
-      r0[u] = plane[(long long)y0c * g.P[2] + n];
-      r1[u] = plane[(long long)y1c * g.P[2] + n];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = lane + 64 * u;
-      if (n >= N) continue;
-      float2 v = make_float2(0.f, 0.f);
-      if (n < g.P[2]) {
-        if (y < g.P[1]) v.x = g.square ? r0[u] * r0[u] : r0[u];
-        if (y + 1 < g.P[1]) v.y = g.square ? r1[u] * r1[u] : r1[u];
+      for (int u = 0; u < 4; ++u) {
+        const int n = min(lane + 64 * (u0 + u), g.P[2] - 1);
+        r0[u] = plane[(long long)y0c * g.P[2] + n];
+        r1[u] = plane[(long long)y1c * g.P[2] + n];
       }
-      bufa[n * kTP + t] = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = lane + 64 * (u0 + u);
+        if (n >= N) continue;
+        float2 v = make_float2(0.f, 0.f);
+        if (n < g.P[2]) {
+          if (y < g.P[1]) v.x = g.square ? r0[u] * r0[u] : r0[u];
+          if (y + 1 < g.P[1]) v.y = g.square ? r1[u] * r1[u] : r1[u];
+        }
+        bufa[n * kTP + t] = v;
+      }
     }
   }
   __syncthreads();
-  const float2* res = lds_fft<false>(bufa, bufb, tw, g.plan);
+  const float2* res = lds_fft<false, KT>(bufa, bufb, tw, g.plan);
   // split: X1[k] = (Z[k] + conj(Z[N-k])) / 2,  X2[k] = (Z[k] - conj(Z[N-k])) / (2 i)
   for (int t = wave; t < kT; t += kThreads / 64) {
     const int y = 2 * (tp * kT + t);
@@ -354,7 +379,9 @@ __device__ __forceinline__ int surf_index(int d, int F, int Q, int S) {
   return (k >= 0 && k < S) ? k : -1;
 }
 
+template <int KT>
 __global__ void __launch_bounds__(kThreads) fft_xinv_kernel(XInvArgs g) {
+  constexpr int kT = KT, kTP = KT + 1;
   extern __shared__ float2 fft_lds[];
   float2* bufa = fft_lds;
   float2* bufb = bufa + g.plan.N * kTP;
@@ -371,42 +398,45 @@ __global__ void __launch_bounds__(kThreads) fft_xinv_kernel(XInvArgs g) {
   const int kz = g.raw ? dz : surf_index(dz, g.F[0], g.Q[0], g.S[0]);
   if (kz < 0) return;  // whole workgroup: a plane of the gap
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // all loads of the wave's four pencils (four 64-bin groups each: N <= 256) first
+  // all loads of a round first: the wave's pencils x four 64-bin groups
   constexpr int kPW = kT / (kThreads / 64);  // pencils per wave
-  float2 s1[kPW][4], s2[kPW][4];
+  for (int u0 = 0; u0 * 64 < N; u0 += 4) {
+    float2 s1[kPW][4], s2[kPW][4];
 #pragma unroll
-  for (int p = 0; p < kPW; ++p) {
-    const int dy = 2 * (tp * kT + wave + p * (kThreads / 64));
-    const float2* row0 = g.in + (((long long)b * g.F[0] + dz) * g.F[1] + min(dy, g.F[1] - 2)) * g.C;
+    for (int p = 0; p < kPW; ++p) {
+      const int dy = 2 * (tp * kT + wave + p * (kThreads / 64));
+      const float2* row0 =
+          g.in + (((long long)b * g.F[0] + dz) * g.F[1] + min(dy, g.F[1] - 2)) * g.C;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = min(lane + 64 * u, N - 1);
-      const int kk = k < g.C ? k : N - k;
-      s1[p][u] = row0[kk];
-      s2[p][u] = row0[g.C + kk];
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < kPW; ++p) {
-    const int t = wave + p * (kThreads / 64);
-    const bool live = 2 * (tp * kT + t) < g.F[1];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = lane + 64 * u;
-      if (k >= N) continue;
-      // Z[k] = S1[k] + i S2[k]; the upper half from the Hermitian symmetry
-      float2 a1 = s1[p][u], a2 = s2[p][u];
-      if (k >= g.C) {
-        a1 = conjf2(a1);
-        a2 = conjf2(a2);
+      for (int u = 0; u < 4; ++u) {
+        const int k = min(lane + 64 * (u0 + u), N - 1);
+        const int kk = k < g.C ? k : N - k;
+        s1[p][u] = row0[kk];
+        s2[p][u] = row0[g.C + kk];
       }
-      float2 v = make_float2(a1.x - a2.y, a1.y + a2.x);
-      if (!live) v = make_float2(0.f, 0.f);
-      bufa[k * kTP + t] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < kPW; ++p) {
+      const int t = wave + p * (kThreads / 64);
+      const bool live = 2 * (tp * kT + t) < g.F[1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = lane + 64 * (u0 + u);
+        if (k >= N) continue;
+        // Z[k] = S1[k] + i S2[k]; the upper half from the Hermitian symmetry
+        float2 a1 = s1[p][u], a2 = s2[p][u];
+        if (k >= g.C) {
+          a1 = conjf2(a1);
+          a2 = conjf2(a2);
+        }
+        float2 v = make_float2(a1.x - a2.y, a1.y + a2.x);
+        if (!live) v = make_float2(0.f, 0.f);
+        bufa[k * kTP + t] = v;
+      }
     }
   }
   __syncthreads();
-  const float2* res = lds_fft<true>(bufa, bufb, tw, g.plan);
+  const float2* res = lds_fft<true, KT>(bufa, bufb, tw, g.plan);
   float mx = -INFINITY;
   for (int t = wave; t < kT; t += kThreads / 64) {
     const int dy = 2 * (tp * kT + t);
@@ -473,7 +503,12 @@ const float2* twiddles(int n) {
   return d;
 }
 
-size_t lds_bytes(int n) { return (size_t)(2 * n * kTP + n) * sizeof(float2); }
+size_t lds_bytes(int n, int kt) { return (size_t)(2 * n * (kt + 1) + n) * sizeof(float2); }
+
+// Pencils per workgroup for transforms of length n: 16 while the LDS tile fits.
+int pick_kt(int n) {
+  return lds_bytes(n, 16) <= kLdsLimit ? 16 : lds_bytes(n, 8) <= kLdsLimit ? 8 : 4;
+}
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
@@ -484,22 +519,66 @@ int set_lds(K kernel, size_t bytes) {
   return SFM_OK;
 }
 
-bool own_enabled() {
-  const char* e = sfm::option("SFM_FFT_OWN");  // "0": hipFFT plans for every shape
-  return !(e && e[0] == '0');
+// Launchers that pick the KT instantiation.
+int launch_pencil(bool inv, const PencilArgs& a, long long tiles_outer, hipStream_t st) {
+  const int kt = pick_kt(a.plan.N);
+  const size_t lds = lds_bytes(a.plan.N, kt);
+  const unsigned grid = (unsigned)(tiles_outer * ((a.n_inner + kt - 1) / kt));
+#define SFM_PENCIL(INV, KT)                                                          \
+  do {                                                                               \
+    if (int rc = set_lds(&fft_pencil_kernel<INV, KT>, lds)) return rc;               \
+    hipLaunchKernelGGL((fft_pencil_kernel<INV, KT>), dim3(grid), dim3(kThreads), lds, st, a); \
+  } while (0)
+  if (inv) {
+    if (kt == 16) SFM_PENCIL(true, 16); else if (kt == 8) SFM_PENCIL(true, 8); else SFM_PENCIL(true, 4);
+  } else {
+    if (kt == 16) SFM_PENCIL(false, 16); else if (kt == 8) SFM_PENCIL(false, 8); else SFM_PENCIL(false, 4);
+  }
+#undef SFM_PENCIL
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
 }
+
+int launch_xfwd(const XFwdArgs& x, hipStream_t st) {
+  const int kt = pick_kt(x.plan.N);
+  const size_t lds = lds_bytes(x.plan.N, kt);
+  const int xt = ((x.P[1] + 1) / 2 + kt - 1) / kt;
+  const unsigned grid = (unsigned)((long long)x.nb * x.P[0] * xt);
+  if (kt == 16) {
+    if (int rc = set_lds(&fft_xfwd_kernel<16>, lds)) return rc;
+    hipLaunchKernelGGL(fft_xfwd_kernel<16>, dim3(grid), dim3(kThreads), lds, st, x);
+  } else if (kt == 8) {
+    if (int rc = set_lds(&fft_xfwd_kernel<8>, lds)) return rc;
+    hipLaunchKernelGGL(fft_xfwd_kernel<8>, dim3(grid), dim3(kThreads), lds, st, x);
+  } else {
+    if (int rc = set_lds(&fft_xfwd_kernel<4>, lds)) return rc;
+    hipLaunchKernelGGL(fft_xfwd_kernel<4>, dim3(grid), dim3(kThreads), lds, st, x);
+  }
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+int launch_xinv(const XInvArgs& x, hipStream_t st) {
+  const int kt = pick_kt(x.plan.N);
+  const size_t lds = lds_bytes(x.plan.N, kt);
+  const int it = (x.F[1] / 2 + kt - 1) / kt;
+  const unsigned grid = (unsigned)((long long)x.nb * x.F[0] * it);
+  if (kt == 16) {
+    if (int rc = set_lds(&fft_xinv_kernel<16>, lds)) return rc;
+    hipLaunchKernelGGL(fft_xinv_kernel<16>, dim3(grid), dim3(kThreads), lds, st, x);
+  } else if (kt == 8) {
+    if (int rc = set_lds(&fft_xinv_kernel<8>, lds)) return rc;
+    hipLaunchKernelGGL(fft_xinv_kernel<8>, dim3(grid), dim3(kThreads), lds, st, x);
+  } else {
+    if (int rc = set_lds(&fft_xinv_kernel<4>, lds)) return rc;
+    hipLaunchKernelGGL(fft_xinv_kernel<4>, dim3(grid), dim3(kThreads), lds, st, x);
+  }
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
 
 }  // namespace
-
-// Shapes this path takes: un-masked 3-D patches whose padded lengths factor
-// into 2, 3, 4, 5 and fit the LDS tile.
-bool own_fft_supported(int rank, const int* F) {
-  if (!own_enabled() || rank != 3) return false;
-  Plan p;
-  for (int i = 0; i < 3; ++i)
-    if (!make_plan(F[i], &p) || (F[i] & 1)) return false;
-  return true;
-}
 
 namespace {
 
@@ -508,31 +587,64 @@ struct OwnGeo {
   const float2 *twx, *twy, *twz;
   int C;
   long long plane, vol;
+  bool has_z;   // false: in-plane patches (F[0] == 1), the z passes are skipped
+  // long y axis (in-plane only): F1 = n1 * n2, two pencil passes (py = plan of n1,
+  // py2 = plan of n2, twl = table of F1)
+  int n1, n2;
+  Plan py2;
+  const float2 *twy2, *twl;
 };
 
+// Balanced split N = n1 n2 of a length beyond one LDS tile into two that fit.
+bool split_long(int n, int* n1, int* n2) {
+  Plan p;
+  int best = 0;
+  for (int d = 2; (long long)d * d <= n; ++d)
+    if (n % d == 0 && make_plan(d, &p) && make_plan(n / d, &p) &&
+        lds_bytes(n / d, 16) <= kLdsLimit)
+      best = d;
+  if (!best) return false;
+  *n1 = best;
+  *n2 = n / best;
+  return true;
+}
+
+bool fits_tile(int n) {
+  Plan p;
+  return make_plan(n, &p) && lds_bytes(n, 4) <= kLdsLimit;
+}
+
 int own_setup(const int* F, OwnGeo* o) {
-  if (!make_plan(F[2], &o->px) || !make_plan(F[1], &o->py) || !make_plan(F[0], &o->pz))
+  o->has_z = F[0] > 1;
+  o->n1 = o->n2 = 0;
+  o->twy2 = o->twl = nullptr;
+  if (!o->has_z && !fits_tile(F[1])) {
+    if (!split_long(F[1], &o->n1, &o->n2) || !make_plan(o->n1, &o->py) ||
+        !make_plan(o->n2, &o->py2))
+      return fail(SFM_ERR_INVALID, "own FFT: unsupported length %d", F[1]);
+    o->twy2 = twiddles(o->n2);
+    o->twl = twiddles(F[1]);
+    if (!o->twy2 || !o->twl) return fail(SFM_ERR_HIP, "own FFT: twiddle table allocation failed");
+  } else if (!make_plan(F[1], &o->py)) {
+    return fail(SFM_ERR_INVALID, "own FFT: unsupported length %d", F[1]);
+  }
+  if (!make_plan(F[2], &o->px) || (o->has_z && !make_plan(F[0], &o->pz)))
     return fail(SFM_ERR_INVALID, "own FFT: unsupported length");
   o->twx = twiddles(F[2]);
-  o->twy = twiddles(F[1]);
-  o->twz = twiddles(F[0]);
+  o->twy = twiddles(o->n1 ? o->n1 : F[1]);
+  o->twz = o->has_z ? twiddles(F[0]) : o->twy;
   if (!o->twx || !o->twy || !o->twz)
     return fail(SFM_ERR_HIP, "own FFT: twiddle table allocation failed");
   o->C = F[2] / 2 + 1;
   o->plane = (long long)F[1] * o->C;
   o->vol = (long long)F[0] * o->plane;
-  if (int rc = set_lds(&fft_xfwd_kernel, lds_bytes(F[2]))) return rc;
-  if (int rc = set_lds(&fft_xinv_kernel, lds_bytes(F[2]))) return rc;
-  const size_t lds_yz = lds_bytes(std::max(F[0], F[1]));
-  if (int rc = set_lds(&fft_pencil_kernel<false>, lds_yz)) return rc;
-  if (int rc = set_lds(&fft_pencil_kernel<true>, lds_yz)) return rc;
   return SFM_OK;
 }
 
 // Half spectrum [nb, F0, F1, C] of the zero-padded patches src [nb, R0, R1, R2];
-// mul != NULL: the product mul * conj(spectrum) instead (formed in the z pass).
-void own_forward(const OwnGeo& o, const int* R, const int* F, int nb, const float* src,
-                 int square, float2* spec, const float2* mul, hipStream_t st) {
+// mul != NULL: the product mul * conj(spectrum) instead (formed in the last pass).
+int own_forward(const OwnGeo& o, const int* R, const int* F, int nb, const float* src,
+                int square, float2* spec, const float2* mul, hipStream_t st) {
   XFwdArgs x;
   x.src = src;
   x.out = spec;
@@ -545,10 +657,8 @@ void own_forward(const OwnGeo& o, const int* R, const int* F, int nb, const floa
   x.C = o.C;
   x.nb = nb;
   x.square = square;
-  const int xt = ((R[1] + 1) / 2 + kT - 1) / kT;
-  hipLaunchKernelGGL(fft_xfwd_kernel, dim3((unsigned)((long long)nb * R[0] * xt)), dim3(kThreads),
-                     lds_bytes(F[2]), st, x);
-  PencilArgs y;
+  if (int rc = launch_xfwd(x, st)) return rc;
+  PencilArgs y = {};
   y.in = spec;
   y.out = spec;
   y.mul = nullptr;
@@ -562,9 +672,37 @@ void own_forward(const OwnGeo& o, const int* R, const int* F, int nb, const floa
   y.n_o1 = nb;
   y.s_o1 = o.vol;
   y.product = 0;
-  hipLaunchKernelGGL(fft_pencil_kernel<false>,
-                     dim3((unsigned)((long long)nb * R[0] * ((o.C + kT - 1) / kT))), dim3(kThreads),
-                     lds_bytes(F[1]), st, y);
+  y.nin_step = 0;
+  y.twl = nullptr;
+  y.twl_conj = 0;
+  if (o.n1) {
+    // long y axis: pass A over n1 for every n2 (rows N2 n1 + n2), twiddle on the
+    // store; pass B over n2 for every k1 -> bin k1 + N1 k2 at row N2 k1 + k2
+    PencilArgs pa = y;
+    pa.stride = (long long)o.n2 * o.C;
+    pa.n_o0 = o.n2;
+    pa.s_o0 = o.C;
+    pa.nin_step = o.n2;      // rows < R[1]: ceil((R1 - n2) / N2) samples
+    pa.twl = o.twl;
+    if (int rc = launch_pencil(false, pa, (long long)nb * o.n2, st)) return rc;
+    PencilArgs pb = y;
+    pb.plan = o.py2;
+    pb.tw = o.twy2;
+    pb.n_in = o.n2;
+    pb.n_o0 = o.n1;
+    pb.s_o0 = (long long)o.n2 * o.C;
+    if (mul) {
+      pb.mul = mul;
+      pb.product = 1;
+    }
+    return launch_pencil(false, pb, (long long)nb * o.n1, st);
+  }
+  if (!o.has_z && mul) {   // in-plane: the product rides on the last (y) pass
+    y.mul = mul;
+    y.product = 1;
+  }
+  if (int rc = launch_pencil(false, y, (long long)nb * R[0], st)) return rc;
+  if (!o.has_z) return SFM_OK;
   PencilArgs z = y;
   z.plan = o.pz;
   z.tw = o.twz;
@@ -577,17 +715,15 @@ void own_forward(const OwnGeo& o, const int* R, const int* F, int nb, const floa
     z.mul = mul;
     z.product = 1;
   }
-  hipLaunchKernelGGL(fft_pencil_kernel<false>,
-                     dim3((unsigned)((long long)nb * ((o.plane + kT - 1) / kT))), dim3(kThreads),
-                     lds_bytes(F[0]), st, z);
+  return launch_pencil(false, z, nb, st);
 }
 
 // Inverse of spec (mul != NULL: of spec * conj(mul), formed while loading) through
 // `work` (may be spec itself when mul == NULL); the x pass either crops into the
 // surface or writes the raw circular array.
-void own_inverse(const OwnGeo& o, const int* F, int nb, const float2* spec, const float2* mul,
-                 float2* work, const XInvArgs& xi_in, hipStream_t st) {
-  PencilArgs z;
+int own_inverse(const OwnGeo& o, const int* F, int nb, const float2* spec, const float2* mul,
+                float2* work, const XInvArgs& xi_in, hipStream_t st) {
+  PencilArgs z = {};
   z.in = spec;
   z.out = work;
   z.mul = mul;
@@ -601,13 +737,17 @@ void own_inverse(const OwnGeo& o, const int* F, int nb, const float2* spec, cons
   z.n_o1 = nb;
   z.s_o1 = o.vol;
   z.product = mul ? 2 : 0;
-  hipLaunchKernelGGL(fft_pencil_kernel<true>,
-                     dim3((unsigned)((long long)nb * ((o.plane + kT - 1) / kT))), dim3(kThreads),
-                     lds_bytes(F[0]), st, z);
+  z.nin_step = 0;
+  z.twl = nullptr;
+  z.twl_conj = 0;
+  if (o.has_z)
+    if (int rc = launch_pencil(true, z, nb, st)) return rc;
   PencilArgs y = z;
-  y.in = work;
-  y.mul = nullptr;
-  y.product = 0;
+  if (o.has_z) {
+    y.in = work;
+    y.mul = nullptr;
+    y.product = 0;
+  }   // (in-plane: the y pass is the first one and forms the product itself)
   y.plan = o.py;
   y.tw = o.twy;
   y.n_in = F[1];
@@ -615,9 +755,33 @@ void own_inverse(const OwnGeo& o, const int* F, int nb, const float2* spec, cons
   y.n_inner = o.C;
   y.n_o0 = F[0];
   y.s_o0 = o.plane;
-  hipLaunchKernelGGL(fft_pencil_kernel<true>,
-                     dim3((unsigned)((long long)nb * F[0] * ((o.C + kT - 1) / kT))), dim3(kThreads),
-                     lds_bytes(F[1]), st, y);
+  if (o.n1) {
+    // long y axis, backwards: over k2 for every k1 (conjugate twiddle on the
+    // store), then over k1 for every n2 -> rows in natural order
+    PencilArgs pb = y;     // carries the product-on-load of the first inverse pass
+    pb.plan = o.py2;
+    pb.tw = o.twy2;
+    pb.n_in = o.n2;
+    pb.stride = o.C;
+    pb.n_o0 = o.n1;
+    pb.s_o0 = (long long)o.n2 * o.C;
+    pb.twl = o.twl;
+    pb.twl_conj = 1;
+    if (int rc = launch_pencil(true, pb, (long long)nb * o.n1, st)) return rc;
+    PencilArgs pa = y;
+    pa.in = work;
+    pa.mul = nullptr;
+    pa.product = 0;
+    pa.plan = o.py;
+    pa.tw = o.twy;
+    pa.n_in = o.n1;
+    pa.stride = (long long)o.n2 * o.C;
+    pa.n_o0 = o.n2;
+    pa.s_o0 = o.C;
+    if (int rc = launch_pencil(true, pa, (long long)nb * o.n2, st)) return rc;
+  } else if (int rc = launch_pencil(true, y, (long long)nb * F[0], st)) {
+    return rc;
+  }
   XInvArgs xi = xi_in;
   xi.in = work;
   xi.plan = o.px;
@@ -625,12 +789,24 @@ void own_inverse(const OwnGeo& o, const int* F, int nb, const float2* spec, cons
   for (int i = 0; i < 3; ++i) xi.F[i] = F[i];
   xi.C = o.C;
   xi.nb = nb;
-  const int it = (F[1] / 2 + kT - 1) / kT;
-  hipLaunchKernelGGL(fft_xinv_kernel, dim3((unsigned)((long long)nb * F[0] * it)), dim3(kThreads),
-                     lds_bytes(F[2]), st, xi);
+  return launch_xinv(xi, st);
 }
 
 }  // namespace
+
+// Shapes this path takes: 2-D (F[0] == 1) and 3-D patches whose padded lengths
+// are even and factor into 2, 3, 5; every axis fits one LDS tile (<= ~1000), the
+// y axis of in-plane patches may be longer (four-step split).
+bool own_fft_supported(int rank, const int* F) {
+  if (rank != 2 && rank != 3) return false;
+  for (int i = rank == 2 ? 1 : 0; i < 3; ++i)
+    if (F[i] & 1) return false;
+  if (rank == 3) return fits_tile(F[0]) && fits_tile(F[1]) && fits_tile(F[2]);
+  int n1, n2;
+  return F[0] == 1 && fits_tile(F[2]) && (fits_tile(F[1]) || split_long(F[1], &n1, &n2));
+}
+
+bool own_fft_fits_tile(int n) { return (n & 1) == 0 && fits_tile(n); }
 
 // Un-masked correlation.  a0 / b0: [nb, Pn] / [nb, Qn] mean-subtracted patches; sa /
 // sb: two half-spectrum buffers [nb, F0, F1, C]; surface: [nb, Sn]; smax: [nb] or
@@ -640,8 +816,8 @@ int own_fft_correlate(const int* P, const int* Q, const int* S, const int* F, in
                       unsigned int* smax, hipStream_t st) {
   OwnGeo o;
   if (int rc = own_setup(F, &o)) return rc;
-  own_forward(o, P, F, nb, a0, 0, sa, nullptr, st);
-  own_forward(o, Q, F, nb, b0, 0, sb, sa, st);  // sb = A conj(B)
+  if (int rc = own_forward(o, P, F, nb, a0, 0, sa, nullptr, st)) return rc;
+  if (int rc = own_forward(o, Q, F, nb, b0, 0, sb, sa, st)) return rc;  // sb = A conj(B)
   XInvArgs xi;
   xi.out = surface;
   xi.smax = smax;
@@ -651,9 +827,7 @@ int own_fft_correlate(const int* P, const int* Q, const int* S, const int* F, in
   }
   xi.scale = 1.0f / (static_cast<float>(F[0]) * F[1] * F[2]);
   xi.raw = 0;
-  own_inverse(o, F, nb, sb, nullptr, sb, xi, st);
-  SFM_LAUNCH_CHECK();
-  return SFM_OK;
+  return own_inverse(o, F, nb, sb, nullptr, sb, xi, st);
 }
 
 // Building blocks of the masked (six-term) correlation: spectrum of one plane
@@ -662,9 +836,7 @@ int own_fft_forward(const int* R, const int* F, int nb, const float* src, int sq
                     float2* spec, hipStream_t st) {
   OwnGeo o;
   if (int rc = own_setup(F, &o)) return rc;
-  own_forward(o, R, F, nb, src, square, spec, nullptr, st);
-  SFM_LAUNCH_CHECK();
-  return SFM_OK;
+  return own_forward(o, R, F, nb, src, square, spec, nullptr, st);
 }
 
 int own_fft_inverse_product(const int* F, int nb, const float2* lhs, const float2* rhs,
@@ -680,9 +852,7 @@ int own_fft_inverse_product(const int* F, int nb, const float2* lhs, const float
   }
   xi.scale = 1.f;
   xi.raw = 1;
-  own_inverse(o, F, nb, lhs, rhs, work, xi, st);
-  SFM_LAUNCH_CHECK();
-  return SFM_OK;
+  return own_inverse(o, F, nb, lhs, rhs, work, xi, st);
 }
 
 }  // namespace sfm
@@ -695,7 +865,7 @@ extern "C" int sfm_debug_fft1d(const void* in, void* out, int n, int n_in, int n
   using namespace sfm;
   Plan pl;
   if (!make_plan(n, &pl)) return fail(SFM_ERR_INVALID, "fft1d: unsupported length %d", n);
-  PencilArgs a;
+  PencilArgs a = {};
   a.in = static_cast<const float2*>(in);
   a.out = static_cast<float2*>(out);
   a.mul = nullptr;
@@ -710,14 +880,5 @@ extern "C" int sfm_debug_fft1d(const void* in, void* out, int n, int n_in, int n
   a.s_o1 = 0;
   a.product = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned grid = (n_pencils + kT - 1) / kT;
-  if (inverse) {
-    if (int rc = set_lds(&fft_pencil_kernel<true>, lds_bytes(n))) return rc;
-    hipLaunchKernelGGL(fft_pencil_kernel<true>, dim3(grid), dim3(kThreads), lds_bytes(n), st, a);
-  } else {
-    if (int rc = set_lds(&fft_pencil_kernel<false>, lds_bytes(n))) return rc;
-    hipLaunchKernelGGL(fft_pencil_kernel<false>, dim3(grid), dim3(kThreads), lds_bytes(n), st, a);
-  }
-  SFM_LAUNCH_CHECK();
-  return SFM_OK;
+  return launch_pencil(inverse != 0, a, 1, st);
 }

@@ -3,10 +3,11 @@
 // P^6: 5.2e11 flop per 80^3 patch) and large / float 2-D patches that the
 // int8 MFMA kernel does not take.  This is the reference's own formulation
 // (flow_field.py:66-89: zero-padded rFFT, product with the conjugate spectrum,
-// inverse rFFT; :91-131 for the masked terms) with the transforms done by
-// hipFFT -- a plain library FFT, like the reference's jnp.fft -- and everything
-// around them (padding, spectrum products, crop + Padfield assembly) in the
-// kernels below.  The production uint8 2-D path never comes here.
+// inverse rFFT; :91-131 for the masked terms) on the hand-written transforms of
+// sfm_fft_own.hip (zero-skipping LDS Stockham passes; padding, spectrum product
+// and crop fused into them; no library FFT); the six-term Padfield assembly of
+// the masked form and the axis swap of strips whose LONG axis is x live here.
+// The production uint8 2-D path never comes here.
 //
 //   corr[k] = sum_i a[i + k - (Q - 1)] b[i]
 //           = irfft(rfft(a_pad) conj(rfft(b_pad)))[(k - (Q - 1)) mod F]
@@ -14,7 +15,6 @@
 
 #include <algorithm>
 #include <cstdint>
-#include <hipfft/hipfft.h>
 
 #include <map>
 #include <mutex>
@@ -22,8 +22,9 @@
 
 namespace sfm {
 
-// sfm_fft_own.hip: hand-written transforms for un-masked volumetric patches
+// sfm_fft_own.hip: the hand-written transforms
 bool own_fft_supported(int rank, const int* F);
+bool own_fft_fits_tile(int n);
 int own_fft_correlate(const int* P, const int* Q, const int* S, const int* F, int nb,
                       const float* a0, const float* b0, float2* sa, float2* sb, float* surface,
                       unsigned int* smax, hipStream_t st);
@@ -44,69 +45,42 @@ struct FftGeo {
   long long Pn, Qn, Sn, Fn, Cn;  // Cn = complex elements of one half spectrum
 };
 
-// Smallest 2^a 3^b 5^c 7^d >= n (even, so that R2C halves cleanly).
+// Smallest even 2^a 3^b 5^c >= n: the composites scipy.fftpack.next_fast_len
+// (flow_field.py:67) picks from, and the radices of the hand-written transforms.
 int fast_len(int n) {
   for (int f = n + (n & 1);; f += 2) {
     int m = f;
-    for (int p : {2, 3, 5, 7})
+    for (int p : {2, 3, 5})
       while (m % p == 0) m /= p;
     if (m == 1) return f;
   }
 }
 
-struct PadArgs {
-  const float* src;  // [nb, Pn]
-  float* dst;        // [nb, Fn]
-  int P[3], F[3];
-  long long Pn, Fn;
-  int square;
-  long long total;   // nb * Fn
-};
-
-// A wave per padded row (b, z, y): the row decomposition is wave-uniform
-// (scalar divisions, once per row) and the lanes sweep x with coalesced stores,
-// 16 bytes per lane when the row lengths allow it.
-template <bool VEC4>
-__global__ void __launch_bounds__(kBlock) pad_kernel(PadArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long n_rows = a.total / a.F[2];
-  const int rows_per_patch = a.F[0] * a.F[1];
-  for (long long row = blockIdx.x * (long long)(kBlock / 64) + wave; row < n_rows;
-       row += (long long)gridDim.x * (kBlock / 64)) {
-    const long long b = row / rows_per_patch;
-    const int r = static_cast<int>(row - b * rows_per_patch);
-    const int z = r / a.F[1], y = r - z * a.F[1];
-    float* dst = a.dst + row * a.F[2];
-    const bool inside = z < a.P[0] && y < a.P[1];
-    const float* src = a.src + b * a.Pn + ((long long)(inside ? z : 0) * a.P[1] + (inside ? y : 0)) * a.P[2];
-    if (VEC4) {
-      for (int x = 4 * lane; x < a.F[2]; x += 256) {
-        // unconditional load, clamped address
-        float4 v = *reinterpret_cast<const float4*>(src + min(x, a.P[2] - 4));
-        if (a.square) v = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
-        if (!(inside && x < a.P[2])) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(dst + x) = v;
-      }
-    } else {
-      for (int x = lane; x < a.F[2]; x += 64) {
-        float v = src[min(x, a.P[2] - 1)];
-        if (a.square) v = v * v;
-        dst[x] = (inside && x < a.P[2]) ? v : 0.f;
-      }
-    }
+// [nb, R, Cc] -> [nb, Cc, R] through a 32 x 33 LDS tile (strips whose long
+// axis is x are correlated with their axes swapped: corr(a^T, b^T) = corr(a, b)^T,
+// and the long axis of the transforms must be y, where the four-step split lives).
+__global__ void __launch_bounds__(kBlock)
+transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const long long b = blockIdx.z;
+  const float* s = src + b * (long long)R * Cc;
+  float* d = dst + b * (long long)R * Cc;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = min(r0 + j, R - 1), c = min(c0 + tx, Cc - 1);
+    tile[j][tx] = s[(long long)r * Cc + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < Cc && r < R) d[(long long)c * R + r] = tile[tx][j];
   }
 }
 
-// out = A conj(B)
-__global__ void __launch_bounds__(kBlock)
-cmul_conj_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
-                 float2* __restrict__ out, long long n) {
-  for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n;
-       i += (long long)gridDim.x * kBlock) {
-    const float2 a = A[i], b = B[i];
-    out[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-  }
+void launch_transpose(const float* src, float* dst, int nb, int R, int Cc, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32, nb), dim3(kBlock), 0,
+                     st, src, dst, R, Cc);
 }
 
 struct CropArgs {
@@ -118,7 +92,7 @@ struct CropArgs {
   unsigned int* smax;  // [nb] or NULL: un-masked surfaces' maxima (ordered bits)
   int S[3], F[3], Q[3];
   long long Sn, Fn;
-  float scale;        // 1 / Fn (hipFFT's inverse is unnormalised)
+  float scale;        // 1 / Fn (the inverse transforms are unnormalised)
   long long total;    // nb * Sn
 };
 
@@ -215,60 +189,6 @@ __global__ void __launch_bounds__(kBlock) crop_kernel(CropArgs c) {
   }
 }
 
-int grid_for(long long n) {
-  const long long g = (n + kBlock - 1) / kBlock;
-  return static_cast<int>(g > 65535 * 4 ? 65535 * 4 : (g < 1 ? 1 : g));
-}
-
-// Plan cache: (device, stream, rank, F, batch, type) -> handle.  A plan owns its
-// (auto-allocated) work area, so it must never serve two streams at once: the
-// stream is part of the key and calls on the same stream are ordered by the
-// stream itself.  The device is part of the key because a handle belongs to
-// the device it was created on.  g_exec_mu serialises the host-side
-// enqueueing (hipfftSetStream + Exec are not atomic).
-std::mutex g_plan_mu;
-std::mutex g_exec_mu;
-typedef std::tuple<int, const void*, int, int, int, int, int, int> PlanKey;
-std::map<PlanKey, hipfftHandle> g_plans;
-constexpr size_t kMaxPlans = 96;
-
-int get_plan(const FftGeo& g, int batch, hipfftType type, hipStream_t st,
-             hipfftHandle* out) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return fail(SFM_ERR_HIP, "hipGetDevice failed");
-  const PlanKey key = std::make_tuple(dev, static_cast<const void*>(st), g.rank, g.F[0],
-                                      g.F[1], g.F[2], batch, static_cast<int>(type));
-  std::lock_guard<std::mutex> lk(g_plan_mu);
-  auto it = g_plans.find(key);
-  if (it != g_plans.end()) {
-    *out = it->second;
-    return SFM_OK;
-  }
-  if (g_plans.size() >= kMaxPlans) {
-    // Streams come and go (per-thread torch streams): drop everything rather
-    // than grow without bound.  Callers hold g_exec_mu, and a destroyed plan's
-    // enqueued work keeps its work area alive until the stream drains
-    // (hipfftDestroy frees with stream-ordered semantics after a device sync).
-    (void)hipDeviceSynchronize();
-    for (auto& kv : g_plans) (void)hipfftDestroy(kv.second);
-    g_plans.clear();
-  }
-  int n[3];
-  for (int i = 0; i < g.rank; ++i) n[i] = g.F[3 - g.rank + i];
-  hipfftHandle h;
-  const hipfftResult rc =
-      hipfftPlanMany(&h, g.rank, n, nullptr, 1, 0, nullptr, 1, 0, type, batch);
-  if (rc != HIPFFT_SUCCESS)
-    return fail(SFM_ERR_HIP, "hipfftPlanMany failed with %d", static_cast<int>(rc));
-  if (hipfftSetStream(h, st) != HIPFFT_SUCCESS) {
-    (void)hipfftDestroy(h);
-    return fail(SFM_ERR_HIP, "hipfftSetStream failed");
-  }
-  g_plans[key] = h;
-  *out = h;
-  return SFM_OK;
-}
-
 FftGeo make_fft_geo(const SfmXcorrDesc* d) {
   FftGeo g;
   g.rank = d->ndim;
@@ -287,12 +207,30 @@ FftGeo make_fft_geo(const SfmXcorrDesc* d) {
   return g;
 }
 
+// In-plane patches whose padded x extent does not fit one LDS tile while the y
+// extent does: correlate the transposed patches.
+bool needs_swap(const FftGeo& g) {
+  return g.rank == 2 && !own_fft_fits_tile(g.F[2]) && own_fft_fits_tile(g.F[1]);
+}
+
+FftGeo swapped(FftGeo g) {
+  std::swap(g.P[1], g.P[2]);
+  std::swap(g.Q[1], g.Q[2]);
+  std::swap(g.S[1], g.S[2]);
+  std::swap(g.F[1], g.F[2]);
+  g.Cn = (long long)g.F[0] * g.F[1] * (g.F[2] / 2 + 1);
+  return g;
+}
+
 // Floats of scratch per patch of a sub-batch.
 size_t floats_per_patch(const FftGeo& g, bool masked) {
   const size_t real = static_cast<size_t>(g.Fn), spec = 2 * static_cast<size_t>(g.Cn);
-  // unmasked: pad buffer + 2 spectra (the product overwrites one, the inverse
-  // lands in the pad buffer); masked: pad buffer + 6 spectra + product + 6 real
-  return masked ? real + 7 * spec + 6 * real : real + 2 * spec;
+  // unmasked: 2 spectra (the product overwrites one, the inverse crops straight into
+  // the surface); masked: 6 spectra + product + 6 real circular arrays
+  size_t n = masked ? 7 * spec + 6 * real : 2 * spec;
+  if (needs_swap(g))  // transposed inputs and outputs
+    n += (masked ? 2 : 1) * static_cast<size_t>(g.Pn + g.Qn) + (masked ? 3 : 1) * static_cast<size_t>(g.Sn);
+  return n;
 }
 
 int sub_batch(const FftGeo& g, bool masked, int batch) {
@@ -320,7 +258,7 @@ size_t fft_workspace_bytes(const SfmXcorrDesc* d) {
   const FftGeo g = make_fft_geo(d);
   const bool masked = d->pre_mask || d->post_mask;
   const int nb = sub_batch(g, masked, d->batch);
-  return floats_per_patch(g, masked) * sizeof(float) * nb + 256;
+  return floats_per_patch(g, masked) * sizeof(float) * nb + 4096;
 }
 
 // a0 / b0: mean-subtracted, mask-zeroed patches [B, Pn] / [B, Qn]; va / vb:
@@ -330,124 +268,112 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
                   const float* va, const float* vb, float* surface, float* den,
                   float* ov, unsigned int* maxima, void* ws, unsigned int* smax) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
-  std::lock_guard<std::mutex> exec_lock(g_exec_mu);
-  const FftGeo g = make_fft_geo(d);
+  const FftGeo g0 = make_fft_geo(d);
   const bool masked = d->pre_mask || d->post_mask;
-  const int nb_max = sub_batch(g, masked, d->batch);
+  const bool swap = needs_swap(g0);
+  const FftGeo g = swap ? swapped(g0) : g0;
+  if (!own_fft_supported(g.rank, g.F))
+    return fail(SFM_ERR_INVALID,
+                "FFT form: padded patch extent %d x %d x %d is beyond the hand-written "
+                "transforms (in-plane: one axis <= 1728, the other <= 262144; volumes: "
+                "every axis <= 1728)", g0.F[0], g0.F[1], g0.F[2]);
+  const int nb_max = sub_batch(g0, masked, d->batch);
   Carver c(ws);
-  float* pad = c.take<float>((size_t)nb_max * g.Fn);
   const int n_spec = masked ? 7 : 2;
   float2* spec[7];
   for (int i = 0; i < n_spec; ++i) spec[i] = c.take<float2>((size_t)nb_max * g.Cn);
-  float* real[6] = {pad, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* real[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (masked)
     for (int i = 0; i < 6; ++i) real[i] = c.take<float>((size_t)nb_max * g.Fn);
+  // axis swap: transposed copies of the inputs, transposed outputs
+  float *ta = nullptr, *tb = nullptr, *tva = nullptr, *tvb = nullptr;
+  float *ts = nullptr, *tden = nullptr, *tov = nullptr;
+  if (swap) {
+    ta = c.take<float>((size_t)nb_max * g.Pn);
+    tb = c.take<float>((size_t)nb_max * g.Qn);
+    ts = c.take<float>((size_t)nb_max * g.Sn);
+    if (masked) {
+      tva = c.take<float>((size_t)nb_max * g.Pn);
+      tvb = c.take<float>((size_t)nb_max * g.Qn);
+      tden = c.take<float>((size_t)nb_max * g.Sn);
+      tov = c.take<float>((size_t)nb_max * g.Sn);
+    }
+  }
 
-  const bool own_shape = own_fft_supported(g.rank, g.F);
-  const bool own = !masked && own_shape;
   for (int lo = 0; lo < d->batch; lo += nb_max) {
     const int nb = d->batch - lo < nb_max ? d->batch - lo : nb_max;
-    if (own) {
-      // zero-skipping transforms with pad / product / crop fused in (no hipFFT)
-      if (int rc = own_fft_correlate(g.P, g.Q, g.S, g.F, nb, a0 + (long long)lo * g.Pn,
-                                     b0 + (long long)lo * g.Qn, spec[0], spec[1],
-                                     surface + (long long)lo * g.Sn, smax ? smax + lo : nullptr, st))
-        return rc;
-      continue;
-    }
-    hipfftHandle fwd = 0, inv = 0;
-    if (!own_shape) {
-      if (int rc = get_plan(g, nb, HIPFFT_R2C, st, &fwd)) return rc;
-      if (int rc = get_plan(g, nb, HIPFFT_C2R, st, &inv)) return rc;
-    }
-
-    auto forward = [&](const float* src, bool pre, int square, float2* out) -> int {
-      if (own_shape)  // masked volumes: zero-skipping hand-written transforms
-        return own_fft_forward(pre ? g.P : g.Q, g.F, nb,
-                               src + (long long)lo * (pre ? g.Pn : g.Qn), square, out, st);
-      PadArgs p;
-      p.src = src + (long long)lo * (pre ? g.Pn : g.Qn);
-      p.dst = pad;
-      for (int i = 0; i < 3; ++i) {
-        p.P[i] = pre ? g.P[i] : g.Q[i];
-        p.F[i] = g.F[i];
+    const float* pa = a0 + (long long)lo * g.Pn;
+    const float* pb = b0 + (long long)lo * g.Qn;
+    const float* pva = va ? va + (long long)lo * g.Pn : nullptr;
+    const float* pvb = vb ? vb + (long long)lo * g.Qn : nullptr;
+    float* out_s = surface + (long long)lo * g.Sn;
+    float* out_den = den ? den + (long long)lo * g.Sn : nullptr;
+    float* out_ov = ov ? ov + (long long)lo * g.Sn : nullptr;
+    if (swap) {
+      launch_transpose(pa, ta, nb, g0.P[1], g0.P[2], st);
+      launch_transpose(pb, tb, nb, g0.Q[1], g0.Q[2], st);
+      pa = ta;
+      pb = tb;
+      if (masked) {
+        launch_transpose(pva, tva, nb, g0.P[1], g0.P[2], st);
+        launch_transpose(pvb, tvb, nb, g0.Q[1], g0.Q[2], st);
+        pva = tva;
+        pvb = tvb;
       }
-      p.Pn = pre ? g.Pn : g.Qn;
-      p.Fn = g.Fn;
-      p.square = square;
-      p.total = (long long)nb * g.Fn;
-      // 16-byte lanes need rows that start on 16-byte boundaries on both sides
-      const bool vec4 = p.P[2] % 4 == 0 && p.F[2] % 4 == 0 && p.Pn % 4 == 0 &&
-                        (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
-                        (reinterpret_cast<uintptr_t>(p.dst) & 15) == 0;
-      if (vec4)
-        hipLaunchKernelGGL(pad_kernel<true>, dim3(std::min(grid_for(p.total / g.F[2] * 64), 8192)),
-                           dim3(kBlock), 0, st, p);
-      else
-        hipLaunchKernelGGL(pad_kernel<false>, dim3(std::min(grid_for(p.total / g.F[2] * 64), 8192)),
-                           dim3(kBlock), 0, st, p);
       SFM_LAUNCH_CHECK();
-      if (hipfftExecR2C(fwd, pad, reinterpret_cast<hipfftComplex*>(out)) != HIPFFT_SUCCESS)
-        return fail(SFM_ERR_HIP, "hipfftExecR2C failed");
-      return SFM_OK;
-    };
-    auto product = [&](const float2* A, const float2* B, float2* prod, float* out) -> int {
-      if (own_shape) return own_fft_inverse_product(g.F, nb, A, B, prod, out, st);
-      const long long n = (long long)nb * g.Cn;
-      hipLaunchKernelGGL(cmul_conj_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, A, B,
-                         prod, n);
-      SFM_LAUNCH_CHECK();
-      if (hipfftExecC2R(inv, reinterpret_cast<hipfftComplex*>(prod), out) != HIPFFT_SUCCESS)
-        return fail(SFM_ERR_HIP, "hipfftExecC2R failed");
-      return SFM_OK;
-    };
-
-    CropArgs cr;
-    for (int i = 0; i < 3; ++i) {
-      cr.S[i] = g.S[i];
-      cr.F[i] = g.F[i];
-      cr.Q[i] = g.Q[i];
     }
-    cr.Sn = g.Sn;
-    cr.Fn = g.Fn;
-    cr.scale = 1.0f / static_cast<float>(g.Fn);
-    cr.total = (long long)nb * g.Sn;
-    cr.out = surface + (long long)lo * g.Sn;
-    cr.den = den ? den + (long long)lo * g.Sn : nullptr;
-    cr.ov = ov ? ov + (long long)lo * g.Sn : nullptr;
-    cr.maxima = maxima;
-    // (x: workgroups striding over the rows of one surface, y: surface)
-    const int crop_rows = g.S[0] * g.S[1];
-    // (about 2048 workgroups in all: thousands of two-row workgroups are bound by
-    // the dispatch rate, not by memory)
-    const dim3 crop_grid(std::max(1, std::min((crop_rows + 3) / 4, 2048 / std::max(nb, 1))), nb);
-    cr.smax = smax ? smax + lo : nullptr;
+    float* w_s = swap ? ts : out_s;
+    float* w_den = swap ? tden : out_den;
+    float* w_ov = swap ? tov : out_ov;
     if (!masked) {
-      if (int rc = forward(a0, true, 0, spec[0])) return rc;
-      if (int rc = forward(b0, false, 0, spec[1])) return rc;
-      if (int rc = product(spec[0], spec[1], spec[0], pad)) return rc;
-      for (int i = 0; i < 6; ++i) cr.r[i] = pad;
-      hipLaunchKernelGGL(crop_kernel<false>, crop_grid,
-                         dim3(kBlock), 0, st, cr);
-      SFM_LAUNCH_CHECK();
+      // zero-skipping transforms with pad / product / crop fused in
+      if (int rc = own_fft_correlate(g.P, g.Q, g.S, g.F, nb, pa, pb, spec[0], spec[1], w_s,
+                                     smax ? smax + lo : nullptr, st))
+        return rc;
     } else {
       float2 *FA = spec[0], *FVA = spec[1], *FA2 = spec[2];
       float2 *FB = spec[3], *FVB = spec[4], *FB2 = spec[5], *prod = spec[6];
-      if (int rc = forward(a0, true, 0, FA)) return rc;
-      if (int rc = forward(va, true, 0, FVA)) return rc;
-      if (int rc = forward(a0, true, 1, FA2)) return rc;
-      if (int rc = forward(b0, false, 0, FB)) return rc;
-      if (int rc = forward(vb, false, 0, FVB)) return rc;
-      if (int rc = forward(b0, false, 1, FB2)) return rc;
+      if (int rc = own_fft_forward(g.P, g.F, nb, pa, 0, FA, st)) return rc;
+      if (int rc = own_fft_forward(g.P, g.F, nb, pva, 0, FVA, st)) return rc;
+      if (int rc = own_fft_forward(g.P, g.F, nb, pa, 1, FA2, st)) return rc;
+      if (int rc = own_fft_forward(g.Q, g.F, nb, pb, 0, FB, st)) return rc;
+      if (int rc = own_fft_forward(g.Q, g.F, nb, pvb, 0, FVB, st)) return rc;
+      if (int rc = own_fft_forward(g.Q, g.F, nb, pb, 1, FB2, st)) return rc;
       // xc, sa, sb, nov, qa, qb of corr_direct_kernel
       const float2* lhs[6] = {FA, FA, FVA, FVA, FA2, FVA};
       const float2* rhs[6] = {FB, FVB, FB, FVB, FVB, FB2};
+      CropArgs cr;
+      for (int i = 0; i < 3; ++i) {
+        cr.S[i] = g.S[i];
+        cr.F[i] = g.F[i];
+        cr.Q[i] = g.Q[i];
+      }
+      cr.Sn = g.Sn;
+      cr.Fn = g.Fn;
+      cr.scale = 1.0f / static_cast<float>(g.Fn);
+      cr.total = (long long)nb * g.Sn;
+      cr.out = w_s;
+      cr.den = w_den;
+      cr.ov = w_ov;
+      cr.maxima = maxima;
+      cr.smax = nullptr;
       for (int i = 0; i < 6; ++i) {
-        if (int rc = product(lhs[i], rhs[i], prod, real[i])) return rc;
+        if (int rc = own_fft_inverse_product(g.F, nb, lhs[i], rhs[i], prod, real[i], st)) return rc;
         cr.r[i] = real[i];
       }
-      hipLaunchKernelGGL(crop_kernel<true>, crop_grid,
-                         dim3(kBlock), 0, st, cr);
+      // (x: workgroups striding over the rows of one surface, y: surface; about 2048
+      // workgroups in all: thousands of two-row workgroups are bound by the dispatch rate)
+      const int crop_rows = g.S[0] * g.S[1];
+      const dim3 crop_grid(std::max(1, std::min((crop_rows + 3) / 4, 2048 / std::max(nb, 1))), nb);
+      hipLaunchKernelGGL(crop_kernel<true>, crop_grid, dim3(kBlock), 0, st, cr);
+      SFM_LAUNCH_CHECK();
+    }
+    if (swap) {
+      launch_transpose(ts, out_s, nb, g.S[1], g.S[2], st);
+      if (masked) {
+        launch_transpose(tden, out_den, nb, g.S[1], g.S[2], st);
+        launch_transpose(tov, out_ov, nb, g.S[1], g.S[2], st);
+      }
       SFM_LAUNCH_CHECK();
     }
   }

@@ -1,5 +1,5 @@
-"""Hand-written FFT correlation (csrc/sfm_fft_own.hip) vs numpy.fft and vs the
-hipFFT-plan path of the same library (-m gpu)."""
+"""Hand-written FFT correlation (csrc/sfm_fft_own.hip, the only FFT of the
+library) vs numpy.fft and the float64 oracle (-m gpu)."""
 import ctypes as C
 import os
 
@@ -29,7 +29,8 @@ def _fft1d(x, n, inverse):
   return out.cpu().numpy()
 
 
-@pytest.mark.parametrize('n', [160, 80, 2, 4, 6, 10, 30, 96, 120, 128, 150, 240, 256])
+@pytest.mark.parametrize('n', [160, 80, 2, 4, 6, 10, 30, 96, 120, 128, 150, 240, 256, 320, 400,
+                               512, 600, 750, 960, 1000])
 @pytest.mark.parametrize('inverse', [False, True])
 def test_pencil_fft_matches_numpy(gpu, n, inverse):
   rng = np.random.default_rng(n)
@@ -58,18 +59,16 @@ def _with_env(env, fn):
 @pytest.mark.parametrize('p,q', [((20, 24, 30), (20, 24, 30)), ((16, 40, 25), (9, 33, 25)),
                                  ((80, 80, 80), (80, 80, 80)), ((5, 7, 12), (5, 6, 11))])
 def test_own_fft_correlation_matches_plans_and_oracle(gpu, p, q):
-  """Full volumetric correlation surfaces: hand-written transforms == hipFFT
-  plans (both float32 FFTs of the same padded size) == float64 oracle."""
+  """Full volumetric correlation surfaces: hand-written transforms == float64
+  oracle (the 80^3 case, too slow for the oracle, is covered by the flow test)."""
   from sofima_amd import flow_field
   rng = np.random.default_rng(sum(p))
   b = 3 if p[0] < 80 else 2
   a = rng.integers(0, 255, (b,) + p).astype(np.uint8)
   c = rng.integers(0, 255, (b,) + q).astype(np.uint8)
-  run = lambda: flow_field.masked_xcorr(a, c, dim=3, method=3, mean=None)
-  own = _with_env({'SFM_FFT_OWN': '1'}, run)
-  lib = _with_env({'SFM_FFT_OWN': '0'}, run)
-  scale = np.abs(lib).max()
-  np.testing.assert_allclose(own, lib, atol=2e-6 * scale)
+  own = flow_field.masked_xcorr(a, c, dim=3, method=3, mean=None)
+  scale = np.abs(own).max()
+  assert np.isfinite(own).all() and scale > 0
   if p[0] < 80:
     a0 = a.astype(np.float64) - a.reshape(b, -1).mean(1)[:, None, None, None]
     c0 = c.astype(np.float64) - c.reshape(b, -1).mean(1)[:, None, None, None]
@@ -78,8 +77,8 @@ def test_own_fft_correlation_matches_plans_and_oracle(gpu, p, q):
 
 
 def test_own_fft_flow_3d(gpu):
-  """flow_field on a shifted volume through the hand-written transforms (the
-  default for un-masked volumetric patches) == through the hipFFT plans."""
+  """flow_field on a shifted volume through the hand-written transforms: the
+  exact shift everywhere, the same field twice."""
   from scipy import ndimage
   from sofima_amd import flow_field
   rng = np.random.default_rng(3)
@@ -88,18 +87,15 @@ def test_own_fft_flow_3d(gpu):
   pre, post = vol[:100, :120, :140], vol[3:103, 2:122, 5:145]
   calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
   run = lambda: calc.flow_field(pre, post, (40, 48, 64), 20, batch_size=8)
-  own = _with_env({'SFM_FFT_OWN': '1'}, run)
-  lib = _with_env({'SFM_FFT_OWN': '0'}, run)
-  np.testing.assert_array_equal(own[:3], lib[:3])
+  own = run()
   assert (own[0] == 5).all() and (own[1] == 2).all() and (own[2] == 3).all()
-  np.testing.assert_allclose(own[3:], lib[3:], rtol=2e-3)
+  np.testing.assert_array_equal(own, run())
 
 
 @pytest.mark.parametrize('p,q', [((12, 20, 30), (12, 20, 30)), ((16, 24, 25), (9, 20, 25))])
 def test_own_fft_masked_volumes_match_plans_and_oracle(gpu, p, q):
   """Masked (Padfield) volumetric correlation: six spectra and six inverse
-  transforms of products through the hand-written passes == hipFFT plans ==
-  oracle."""
+  transforms of products through the hand-written passes == oracle."""
   from sofima_amd import flow_field
   rng = np.random.default_rng(sum(q))
   b = 3
@@ -108,13 +104,61 @@ def test_own_fft_masked_volumes_match_plans_and_oracle(gpu, p, q):
   am = rng.random(a.shape) < 0.2
   cm = rng.random(c.shape) < 0.1
   am[0, :3] = True
-  run = lambda: flow_field.masked_xcorr(a, c, am, cm, dim=3, method=3)
-  own = _with_env({'SFM_FFT_OWN': '1'}, run)
-  lib = _with_env({'SFM_FFT_OWN': '0'}, run)
-  flipped = (own == 0) != (lib == 0)       # entries at the tolerance / overlap thresholds
-  assert flipped.mean() < 2e-3
-  np.testing.assert_allclose(own[~flipped], lib[~flipped], atol=2e-5)
+  own = flow_field.masked_xcorr(a, c, am, cm, dim=3, method=3)
   want = flow_oracle.xcorr_surface(a, c, am, cm, dim=3)
+  flipped = (own == 0) != (want == 0)
+  assert flipped.mean() < 2e-3
+  bad = (np.abs(own - want) > 5e-5) & ~flipped
+  assert bad.mean() < 1e-4
+
+
+@pytest.mark.parametrize('p,q,dtype', [((160, 160), (160, 160), np.float32),
+                                        ((200, 180), (200, 180), np.uint8),
+                                        ((256, 256), (256, 256), np.uint8),
+                                        ((300, 90), (300, 90), np.uint8),     # F = 600: 8 pencils
+                                        ((96, 130), (64, 100), np.float32),
+                                        ((700, 40), (700, 40), np.uint8),     # F = 1440: 4 pencils
+                                        ((1200, 64), (1200, 64), np.uint8),   # y 2400 = 48 x 50
+                                        ((4096, 24), (4000, 20), np.uint8),   # y 8100 = 90 x 90
+                                        ((64, 1200), (64, 1200), np.uint8),   # long x: axis swap
+                                        ((30, 2500), (24, 2300), np.float32)])
+def test_own_fft_in_plane_patches_match_plans_and_oracle(gpu, p, q, dtype):
+  """2-D patches that take the FFT form (float images, patches wider than 160):
+  the hand-written passes with the z passes skipped and the product riding on
+  the y pass == float64 oracle (both the 16- and the 8-pencil tiles; a long y
+  axis through the four-step split; a long x axis through the axis swap)."""
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(sum(p))
+  b = 3
+  a = rng.integers(0, 255, (b,) + p).astype(dtype)
+  c = rng.integers(0, 255, (b,) + q).astype(dtype)
+  own = flow_field.masked_xcorr(a, c, dim=2, method=3, mean=None)
+  scale = np.abs(own).max()
+  a0 = a.astype(np.float64) - a.reshape(b, -1).mean(1)[:, None, None]
+  c0 = c.astype(np.float64) - c.reshape(b, -1).mean(1)[:, None, None]
+  want = flow_oracle.xcorr_surface(a0, c0, dim=2, dtype=np.float64)
+  np.testing.assert_allclose(own, want, atol=1e-5 * scale)
+
+
+def test_own_fft_masked_in_plane_patches(gpu):
+  """Masked (Padfield) 2-D float patches through the hand-written passes ==
+  oracle; also a strip with a long axis either way (the `_estimate_offset`
+  regime: four-step split, axis swap)."""
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(9)
+  for b, p, q in ((3, (120, 140), (120, 140)), (1, (1500, 60), (1500, 60)),
+                  (2, (48, 1100), (48, 1100))):
+    _masked_case(flow_field, rng, b, p, q)
+
+
+def _masked_case(flow_field, rng, b, p, q):
+  a = rng.integers(0, 255, (b,) + p).astype(np.float32)
+  c = rng.integers(0, 255, (b,) + q).astype(np.float32)
+  am = rng.random(a.shape) < 0.2
+  cm = rng.random(c.shape) < 0.1
+  am[0, :30, :10] = True
+  own = flow_field.masked_xcorr(a, c, am, cm, dim=2, method=3)
+  want = flow_oracle.xcorr_surface(a, c, am, cm, dim=2)
   flipped = (own == 0) != (want == 0)
   assert flipped.mean() < 2e-3
   bad = (np.abs(own - want) > 5e-5) & ~flipped
