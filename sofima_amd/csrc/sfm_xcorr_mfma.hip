@@ -389,8 +389,6 @@ __device__ __forceinline__ v4i load_16_bytes(const unsigned char* img, long long
 // the centre is folded in afterwards (I'[y][x] = Iraw[y][x] - c y x).
 // ---------------------------------------------------------------------------
 constexpr int kPrepCols = 3;  // columns per lane: Px <= 192
-constexpr int kPrepWaves = 8;  // bands of rows swept concurrently
-constexpr int kPrepThreads = 64 * kPrepWaves;
 
 // Wave-wide inclusive add scan on the DPP network (row shifts inside each
 // 16-lane row, then row broadcasts), ~12 VALU ops instead of 6 LDS permutes.
@@ -404,34 +402,53 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
   return v;
 }
 
-__global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a) {
-  if (a.work_counter && blockIdx.x == 0 && threadIdx.x == 0)
-    *a.work_counter = 0;  // the correlation kernel's patch queue
-  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[2] = a.clk[3] = a.clk[4] = 0;  // tile counts
-  if (a.xcd_heads && blockIdx.x == 0 && threadIdx.x < kXcds)
-    a.xcd_heads[kHeadPitch * threadIdx.x] = 0;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_c[2];
-  __shared__ float s_mu[2];
-  __shared__ int band_tot[2][kPrepWaves][64 * kPrepCols];
-  // reduction scratch of phase 2, aliased onto band_tot (separated by a barrier)
-  static_assert(sizeof(band_tot) >= sizeof(int) * 2 * 3 * kPrepThreads, "alias");
-  int (*red)[3][kPrepThreads] = reinterpret_cast<int (*)[3][kPrepThreads]>(&band_tot[0][0][0]);
+// LDS tables of the prep pass (behind the two raw uint8 patches).
+template <int WAVES, int ROWS>
+struct PrepTables {
+  int s_c[2];
+  float s_mu[2];
+  int band_tot[2][WAVES][64 * kPrepCols];
   // pruning bounds: per-row sum and sum of squares of the raw pixels, later the
-  // prefix sums of the row energies (doubles, aliased)
+  // prefix sums of the row energies (doubles)
   // (sum in the low, sum of squares in the high word: one 64-bit LDS atomic per item)
-  __shared__ unsigned long long row_acc[2][kBoundRows];
-  __shared__ double row_pre[2][kBoundRows + 1];
-  __shared__ int col_sq[2][64 * kPrepCols];  // column sums of squares (post: mirrored)
+  unsigned long long row_acc[2][ROWS];
+  double row_pre[2][ROWS + 1];
+  int col_sq[2][64 * kPrepCols];  // column sums of squares (post: mirrored)
   // sums / sums of squares per 16 x 16 block, later their 2-D prefix sums (in place)
-  __shared__ unsigned long long blk_acc[2][kBlkRows][kBlkCols];  // packed like row_acc
-  const int b = xcd_block_item(a, blockIdx.x, a.batch);
+  unsigned long long blk_acc[2][kBlkRows][kBlkCols];  // packed like row_acc
+};
+
+// The prep pass of patch `b` by a workgroup of WAVES waves: `smem` holds the two
+// raw patches (2 Py Px bytes, 16-byte aligned halves), `tp` the tables.  Used by
+// the stand-alone kernel (8 waves, one block per patch).  Round 3 also ran it with
+// 4 waves at the head of every patch INSIDE the correlation kernel (its LDS patch
+// area as scratch, outputs written to global memory and read back): bit-identical,
+// but the correlation kernel grew from 15.6 to 18.7 ms per pair while the 2.6 ms
+// launch went away -- 19.25 vs 18.9 ms per pair.  The two workgroups of a CU do
+// not stay in anti-phase, so the extra VALU / LDS phase of a patch is not hidden
+// behind the other workgroup's matrix loop; it simply adds.  Removed again.
+template <int WAVES, int ROWS>
+__device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
+                                               unsigned char* smem,
+                                               PrepTables<WAVES, ROWS>* tp) {
+  constexpr int kPrepWaves = WAVES;
+  constexpr int kPrepThreads = 64 * WAVES;
+  int (&s_c)[2] = tp->s_c;
+  float (&s_mu)[2] = tp->s_mu;
+  int (&band_tot)[2][WAVES][64 * kPrepCols] = tp->band_tot;
+  // reduction scratch of phase 2, aliased onto band_tot (separated by a barrier)
+  static_assert(sizeof(tp->band_tot) >= sizeof(int) * 2 * 3 * kPrepThreads, "alias");
+  int (*red)[3][kPrepThreads] = reinterpret_cast<int (*)[3][kPrepThreads]>(&band_tot[0][0][0]);
+  unsigned long long (&row_acc)[2][ROWS] = tp->row_acc;
+  double (&row_pre)[2][ROWS + 1] = tp->row_pre;
+  int (&col_sq)[2][64 * kPrepCols] = tp->col_sq;
+  unsigned long long (&blk_acc)[2][kBlkRows][kBlkCols] = tp->blk_acc;
   const int py = a.P[0], px = a.P[1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* pix[2] = {smem, smem + ((py * px + 15) & ~15)};
   if (a.prune) {
-    for (int i = threadIdx.x; i < 2 * kBoundRows; i += kPrepThreads) {
+    for (int i = threadIdx.x; i < 2 * ROWS; i += kPrepThreads) {
       (&row_acc[0][0])[i] = 0;
     }
     for (int i = threadIdx.x; i < 2 * 64 * kPrepCols; i += kPrepThreads) (&col_sq[0][0])[i] = 0;
@@ -907,10 +924,24 @@ __global__ void __launch_bounds__(kPrepThreads) mfma_prep_same_kernel(MfmaArgs a
   }
 #ifdef SFM_MFMA_TIMING
   PTICK(4)
-  if (blockIdx.x == 100 && lane == 0 && (wave == 0 || wave == 7))
+  if (b == 100 && lane == 0 && (wave == 0 || wave == WAVES - 1))
     printf("PREP wave %d: load %lld reduce %lld bands %lld sweep %lld\n", wave, pt[1] - pt[0],
            pt[2] - pt[1], pt[3] - pt[2], pt[4] - pt[3]);
 #endif
+}
+
+
+constexpr int kPrepWavesAlone = 8;   // bands of rows swept concurrently (stand-alone kernel)
+__global__ void __launch_bounds__(64 * kPrepWavesAlone) mfma_prep_same_kernel(MfmaArgs a) {
+  if (a.work_counter && blockIdx.x == 0 && threadIdx.x == 0)
+    *a.work_counter = 0;  // the correlation kernel's patch queue
+  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[2] = a.clk[3] = a.clk[4] = 0;  // tile counts
+  if (a.xcd_heads && blockIdx.x == 0 && threadIdx.x < kXcds)
+    a.xcd_heads[kHeadPitch * threadIdx.x] = 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ PrepTables<kPrepWavesAlone, kBoundRows> tables;
+  prep_same_body<kPrepWavesAlone, kBoundRows>(a, xcd_block_item(a, blockIdx.x, a.batch), smem,
+                                              &tables);
 }
 
 // ---------------------------------------------------------------------------
@@ -3289,6 +3320,12 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
               a.guard >= 0;
   }
   if (!a.tbound) a.tbound = w.tbound;  // read (not used) by every same-size launch
+  // Region behind the patches: the four 1-D correction arrays, reused as the
+  // arg-max scratch of the fused peak search, then the running-max word.
+  size_t r_bytes = same ? (size_t)4 * w.aux_n * 4 : 0;
+  r_bytes = std::max(r_bytes, (size_t)kThreads * 8);
+  r_bytes = (r_bytes + 15) / 16 * 16;
+  a.r_bytes = static_cast<int>(r_bytes);
   if (same) {
     const size_t prep_lds = 2 * (((size_t)a.P[0] * a.P[1] + 15) & ~(size_t)15);
     static size_t prep_attr = 0;
@@ -3298,7 +3335,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(prep_lds)));
       prep_attr = prep_lds;
     }
-    hipLaunchKernelGGL(mfma_prep_same_kernel, dim3(d->batch), dim3(kPrepThreads),
+    hipLaunchKernelGGL(mfma_prep_same_kernel, dim3(d->batch), dim3(64 * kPrepWavesAlone),
                        prep_lds, st, a);
   } else {
     const size_t prep_lds = (size_t)a.P[0] * a.P[1];
@@ -3306,13 +3343,6 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
                        prep_lds, st, a);
   }
   SFM_LAUNCH_CHECK();
-
-  // Region behind the patches: the four 1-D correction arrays, reused as the
-  // arg-max scratch of the fused peak search, then the running-max word.
-  size_t r_bytes = same ? (size_t)4 * w.aux_n * 4 : 0;
-  r_bytes = std::max(r_bytes, (size_t)kThreads * 8);
-  r_bytes = (r_bytes + 15) / 16 * 16;
-  a.r_bytes = static_cast<int>(r_bytes);
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 32;
   const int grid = d->batch;  // capped to the resident workgroups in launch_one
   const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
