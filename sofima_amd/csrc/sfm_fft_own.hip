@@ -855,6 +855,274 @@ int own_fft_inverse_product(const int* F, int nb, const float2* lhs, const float
   return own_inverse(o, F, nb, lhs, rhs, work, xi, st);
 }
 
+
+// ---------------------------------------------------------------------------
+// In-plane patches whose padded extent exceeds one LDS tile along BOTH axes
+// (patches beyond ~860 px each way).  No half-spectrum tricks: the real patch is
+// expanded to complex and TRANSPOSED, so that its x axis is the row index; the
+// transform along the rows (one pass, or the four-step split) is the x
+// transform; a complex transpose makes y the row index and the same routine
+// transforms y.  The spectrum is [F1][F2] complex with both axes in the order
+// the forward passes leave (element-wise products do not care); the inverse
+// runs the same steps backwards and ends with a transposing real-part crop.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct AxisPlan {
+  int N, n1, n2;          // n1 == 0: one pencil pass
+  Plan p1, p2;
+  const float2 *tw1, *tw2, *twl;
+};
+
+int make_axis(int n, AxisPlan* ax) {
+  ax->N = n;
+  ax->n1 = ax->n2 = 0;
+  ax->tw2 = ax->twl = nullptr;
+  if (fits_tile(n)) {
+    if (!make_plan(n, &ax->p1)) return fail(SFM_ERR_INVALID, "own FFT: unsupported length %d", n);
+    ax->tw1 = twiddles(n);
+  } else {
+    if (!split_long(n, &ax->n1, &ax->n2) || !make_plan(ax->n1, &ax->p1) ||
+        !make_plan(ax->n2, &ax->p2))
+      return fail(SFM_ERR_INVALID, "own FFT: unsupported length %d", n);
+    ax->tw1 = twiddles(ax->n1);
+    ax->tw2 = twiddles(ax->n2);
+    ax->twl = twiddles(n);
+    if (!ax->tw2 || !ax->twl) return fail(SFM_ERR_HIP, "own FFT: twiddle table allocation failed");
+  }
+  if (!ax->tw1) return fail(SFM_ERR_HIP, "own FFT: twiddle table allocation failed");
+  return SFM_OK;
+}
+
+// FFT along the rows of nb arrays [N][C] (C contiguous pencils); forward: rows >=
+// n_in are zero on input; mul / product as in PencilArgs (applied by the last
+// forward pass / the first inverse pass).
+int axis_rows(const AxisPlan& ax, bool inverse, const float2* in, float2* out, const float2* mul,
+              int product, int n_in, int C, int nb, hipStream_t st) {
+  PencilArgs y = {};
+  y.in = in;
+  y.out = out;
+  y.plan = ax.p1;
+  y.tw = ax.tw1;
+  y.n_in = inverse ? ax.N : n_in;
+  y.stride = C;
+  y.n_inner = C;
+  y.n_o0 = 1;
+  y.s_o0 = 0;
+  y.n_o1 = nb;
+  y.s_o1 = (long long)ax.N * C;
+  if (!ax.n1) {
+    y.mul = mul;
+    y.product = product;
+    return launch_pencil(inverse, y, nb, st);
+  }
+  PencilArgs pa = y, pb = y;
+  pa.stride = (long long)ax.n2 * C;    // over n1 for every n2
+  pa.n_o0 = ax.n2;
+  pa.s_o0 = C;
+  pb.plan = ax.p2;                     // over n2 for every k1
+  pb.tw = ax.tw2;
+  pb.n_in = ax.n2;
+  pb.n_o0 = ax.n1;
+  pb.s_o0 = (long long)ax.n2 * C;
+  if (!inverse) {
+    pa.nin_step = ax.n2;
+    pa.twl = ax.twl;
+    if (int rc = launch_pencil(false, pa, (long long)nb * ax.n2, st)) return rc;
+    pb.in = out;
+    pb.mul = mul;
+    pb.product = product;
+    return launch_pencil(false, pb, (long long)nb * ax.n1, st);
+  }
+  pb.mul = mul;
+  pb.product = product;
+  pb.twl = ax.twl;
+  pb.twl_conj = 1;
+  if (int rc = launch_pencil(true, pb, (long long)nb * ax.n1, st)) return rc;
+  pa.in = out;
+  pa.n_in = ax.n1;
+  return launch_pencil(true, pa, (long long)nb * ax.n2, st);
+}
+
+// dst[b][x][y] = (src[b][y][x] (squared), 0) for x < R2, y < R1: [R2][R1] complex
+__global__ void __launch_bounds__(kThreads)
+expand_t_kernel(const float* __restrict__ src, float2* __restrict__ dst, int R1, int R2,
+                long long dst_batch, int square) {
+  __shared__ float tile[32][33];
+  const long long b = blockIdx.z;
+  const float* s = src + b * (long long)R1 * R2;
+  float2* d = dst + b * dst_batch;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8) {
+    const float v = s[(long long)min(y0 + j, R1 - 1) * R2 + min(x0 + tx, R2 - 1)];
+    tile[j][tx] = square ? v * v : v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int x = x0 + j, y = y0 + tx;
+    if (x < R2 && y < R1) d[(long long)x * R1 + y] = make_float2(tile[tx][j], 0.f);
+  }
+}
+
+// dst[b][c][r] = src[b][r][c] for r < R, c < Cc (complex)
+__global__ void __launch_bounds__(kThreads)
+ctranspose_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int R, int Cc,
+                  long long src_batch, long long dst_batch) {
+  __shared__ float2 tile[32][33];
+  const long long b = blockIdx.z;
+  const float2* s = src + b * src_batch;
+  float2* d = dst + b * dst_batch;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8)
+    tile[j][tx] = s[(long long)min(r0 + j, R - 1) * Cc + min(c0 + tx, Cc - 1)];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < Cc && r < R) d[(long long)c * R + r] = tile[tx][j];
+  }
+}
+
+// Real part of w [b][F2][F1] (x-major), transposed: the cropped, scaled surface
+// [S1][S2] (+ its maximum) or the raw circular array [F1][F2].
+struct RealTArgs {
+  const float2* w;
+  float* out;
+  unsigned int* smax;
+  int F1, F2, S1, S2, Q1, Q2;
+  float scale;
+  int raw;
+};
+
+__global__ void __launch_bounds__(kThreads) real_t_kernel(RealTArgs g) {
+  __shared__ float tile[32][33];
+  const long long b = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int O1 = g.raw ? g.F1 : g.S1, O2 = g.raw ? g.F2 : g.S2;
+  const int kx0 = blockIdx.x * 32, ky0 = blockIdx.y * 32;
+  // gather with y fastest (contiguous in w), store with x fastest
+  for (int j = ty; j < 32; j += 8) {
+    const int kx = min(kx0 + j, O2 - 1), ky = min(ky0 + tx, O1 - 1);
+    int dx = kx, dy = ky;
+    if (!g.raw) {
+      dx = kx - (g.Q2 - 1);
+      if (dx < 0) dx += g.F2;
+      dy = ky - (g.Q1 - 1);
+      if (dy < 0) dy += g.F1;
+    }
+    tile[j][tx] = g.w[b * (long long)g.F1 * g.F2 + (long long)dx * g.F1 + dy].x * g.scale;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = ty; j < 32; j += 8) {
+    const int ky = ky0 + j, kx = kx0 + tx;
+    if (ky < O1 && kx < O2) {
+      const float v = tile[tx][j];
+      g.out[b * (long long)O1 * O2 + (long long)ky * O2 + kx] = v;
+      mx = fmaxf(mx, v);
+    }
+  }
+  if (g.smax && !g.raw) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    if ((threadIdx.x & 63) == 0 && mx > -INFINITY) {
+      const unsigned u = __float_as_uint(mx);
+      const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      if (o > __atomic_load_n(&g.smax[b], __ATOMIC_RELAXED)) atomicMax(&g.smax[b], o);
+    }
+  }
+}
+
+dim3 tgrid(int cols, int rows, int nb) { return dim3((cols + 31) / 32, (rows + 31) / 32, nb); }
+
+struct BigGeo {
+  AxisPlan ax, ay;   // transforms of length F2 (x) and F1 (y)
+  long long fn;      // F1 * F2
+};
+
+int big_setup(const int* F, BigGeo* g) {
+  if (int rc = make_axis(F[2], &g->ax)) return rc;
+  if (int rc = make_axis(F[1], &g->ay)) return rc;
+  g->fn = (long long)F[1] * F[2];
+  return SFM_OK;
+}
+
+// spec [nb][F1][F2] = transform of the zero-padded src [nb][R1][R2] (mul: mul * conj of
+// it); tmp: scratch of the same size.
+int big_forward(const BigGeo& g, const int* R, const int* F, int nb, const float* src, int square,
+                float2* spec, float2* tmp, const float2* mul, hipStream_t st) {
+  const int R1 = R[1], R2 = R[2];
+  // tmp as [F2][R1]: x is the row index
+  hipLaunchKernelGGL(expand_t_kernel, tgrid(R2, R1, nb), dim3(kThreads), 0, st, src, tmp, R1, R2,
+                     (long long)F[2] * R1, square);
+  SFM_LAUNCH_CHECK();
+  // (batch stride of the [F2][R1] arrays is F2 * R1: axis_rows assumes N * C)
+  if (int rc = axis_rows(g.ax, false, tmp, tmp, nullptr, 0, R2, R1, nb, st)) return rc;
+  // -> spec as [R1 (of F1)][F2]: y is the row index
+  hipLaunchKernelGGL(ctranspose_kernel, tgrid(R1, F[2], nb), dim3(kThreads), 0, st, tmp, spec, F[2],
+                     R1, (long long)F[2] * R1, g.fn);
+  SFM_LAUNCH_CHECK();
+  return axis_rows(g.ay, false, spec, spec, mul, mul ? 1 : 0, R1, F[2], nb, st);
+}
+
+// tmp [nb][F2][F1] = inverse transform of spec (* conj(mul)), x-major, un-scaled
+int big_inverse(const BigGeo& g, const int* F, int nb, const float2* spec, const float2* mul,
+                float2* work, float2* tmp, hipStream_t st) {
+  if (int rc = axis_rows(g.ay, true, spec, work, mul, mul ? 2 : 0, F[1], F[2], nb, st)) return rc;
+  hipLaunchKernelGGL(ctranspose_kernel, tgrid(F[2], F[1], nb), dim3(kThreads), 0, st, work, tmp, F[1],
+                     F[2], g.fn, g.fn);
+  SFM_LAUNCH_CHECK();
+  return axis_rows(g.ax, true, tmp, tmp, nullptr, 0, F[2], F[1], nb, st);
+}
+
+}  // namespace
+
+bool own_fft_big_supported(int rank, const int* F) {
+  if (rank != 2 || F[0] != 1 || (F[1] & 1) || (F[2] & 1)) return false;
+  AxisPlan a;
+  int n1, n2;
+  for (int i = 1; i < 3; ++i)
+    if (!fits_tile(F[i]) && !split_long(F[i], &n1, &n2)) return false;
+  (void)a;
+  return true;
+}
+
+// The three entry points above for patches that are long along both axes; every
+// spectrum / scratch array holds nb * F1 * F2 complex values.
+int own_fft_big_correlate(const int* P, const int* Q, const int* S, const int* F, int nb,
+                          const float* a0, const float* b0, float2* sa, float2* sb, float2* tmp,
+                          float* surface, unsigned int* smax, hipStream_t st) {
+  BigGeo g;
+  if (int rc = big_setup(F, &g)) return rc;
+  if (int rc = big_forward(g, P, F, nb, a0, 0, sa, tmp, nullptr, st)) return rc;
+  if (int rc = big_forward(g, Q, F, nb, b0, 0, sb, tmp, sa, st)) return rc;   // sb = A conj(B)
+  if (int rc = big_inverse(g, F, nb, sb, nullptr, sb, tmp, st)) return rc;
+  RealTArgs r = {tmp, surface, smax, F[1], F[2], S[1], S[2], Q[1], Q[2],
+                 1.0f / (static_cast<float>(F[1]) * F[2]), 0};
+  hipLaunchKernelGGL(real_t_kernel, tgrid(S[2], S[1], nb), dim3(kThreads), 0, st, r);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+int own_fft_big_forward(const int* R, const int* F, int nb, const float* src, int square,
+                        float2* spec, float2* tmp, hipStream_t st) {
+  BigGeo g;
+  if (int rc = big_setup(F, &g)) return rc;
+  return big_forward(g, R, F, nb, src, square, spec, tmp, nullptr, st);
+}
+
+int own_fft_big_inverse_product(const int* F, int nb, const float2* lhs, const float2* rhs,
+                                float2* work, float2* tmp, float* real_out, hipStream_t st) {
+  BigGeo g;
+  if (int rc = big_setup(F, &g)) return rc;
+  if (int rc = big_inverse(g, F, nb, lhs, rhs, work, tmp, st)) return rc;
+  RealTArgs r = {tmp, real_out, nullptr, F[1], F[2], F[1], F[2], 1, 1, 1.f, 1};
+  hipLaunchKernelGGL(real_t_kernel, tgrid(F[2], F[1], nb), dim3(kThreads), 0, st, r);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
 }  // namespace sfm
 
 // Test hook (not part of the public header): batched 1-D complex FFT of

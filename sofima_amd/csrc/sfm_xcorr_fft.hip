@@ -25,6 +25,15 @@ namespace sfm {
 // sfm_fft_own.hip: the hand-written transforms
 bool own_fft_supported(int rank, const int* F);
 bool own_fft_fits_tile(int n);
+// in-plane patches beyond one tile along both axes (full-complex path)
+bool own_fft_big_supported(int rank, const int* F);
+int own_fft_big_correlate(const int* P, const int* Q, const int* S, const int* F, int nb,
+                          const float* a0, const float* b0, float2* sa, float2* sb, float2* tmp,
+                          float* surface, unsigned int* smax, hipStream_t st);
+int own_fft_big_forward(const int* R, const int* F, int nb, const float* src, int square,
+                        float2* spec, float2* tmp, hipStream_t st);
+int own_fft_big_inverse_product(const int* F, int nb, const float2* lhs, const float2* rhs,
+                                float2* work, float2* tmp, float* real_out, hipStream_t st);
 int own_fft_correlate(const int* P, const int* Q, const int* S, const int* F, int nb,
                       const float* a0, const float* b0, float2* sa, float2* sb, float* surface,
                       unsigned int* smax, hipStream_t st);
@@ -213,6 +222,11 @@ bool needs_swap(const FftGeo& g) {
   return g.rank == 2 && !own_fft_fits_tile(g.F[2]) && own_fft_fits_tile(g.F[1]);
 }
 
+// ... and along both: the full-complex path.
+bool needs_big(const FftGeo& g) {
+  return g.rank == 2 && !own_fft_fits_tile(g.F[2]) && !own_fft_fits_tile(g.F[1]);
+}
+
 FftGeo swapped(FftGeo g) {
   std::swap(g.P[1], g.P[2]);
   std::swap(g.Q[1], g.Q[2]);
@@ -228,6 +242,8 @@ size_t floats_per_patch(const FftGeo& g, bool masked) {
   // unmasked: 2 spectra (the product overwrites one, the inverse crops straight into
   // the surface); masked: 6 spectra + product + 6 real circular arrays
   size_t n = masked ? 7 * spec + 6 * real : 2 * spec;
+  if (needs_big(g))   // full spectra [F1][F2] complex + one transposition buffer
+    n = masked ? (7 + 1) * 2 * real + 6 * real : 3 * 2 * real;
   if (needs_swap(g))  // transposed inputs and outputs
     n += (masked ? 2 : 1) * static_cast<size_t>(g.Pn + g.Qn) + (masked ? 3 : 1) * static_cast<size_t>(g.Sn);
   return n;
@@ -271,17 +287,20 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
   const FftGeo g0 = make_fft_geo(d);
   const bool masked = d->pre_mask || d->post_mask;
   const bool swap = needs_swap(g0);
+  const bool big = needs_big(g0);
   const FftGeo g = swap ? swapped(g0) : g0;
-  if (!own_fft_supported(g.rank, g.F))
+  if (big ? !own_fft_big_supported(g.rank, g.F) : !own_fft_supported(g.rank, g.F))
     return fail(SFM_ERR_INVALID,
                 "FFT form: padded patch extent %d x %d x %d is beyond the hand-written "
-                "transforms (in-plane: one axis <= 1728, the other <= 262144; volumes: "
-                "every axis <= 1728)", g0.F[0], g0.F[1], g0.F[2]);
+                "transforms (in-plane axes <= 262144; volumes: every axis <= 1728)",
+                g0.F[0], g0.F[1], g0.F[2]);
   const int nb_max = sub_batch(g0, masked, d->batch);
   Carver c(ws);
   const int n_spec = masked ? 7 : 2;
   float2* spec[7];
-  for (int i = 0; i < n_spec; ++i) spec[i] = c.take<float2>((size_t)nb_max * g.Cn);
+  const size_t spec_n = big ? (size_t)g.Fn : (size_t)g.Cn;   // complex values per spectrum
+  for (int i = 0; i < n_spec; ++i) spec[i] = c.take<float2>((size_t)nb_max * spec_n);
+  float2* tmp = big ? c.take<float2>((size_t)nb_max * spec_n) : nullptr;
   float* real[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (masked)
     for (int i = 0; i < 6; ++i) real[i] = c.take<float>((size_t)nb_max * g.Fn);
@@ -327,18 +346,27 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
     float* w_ov = swap ? tov : out_ov;
     if (!masked) {
       // zero-skipping transforms with pad / product / crop fused in
-      if (int rc = own_fft_correlate(g.P, g.Q, g.S, g.F, nb, pa, pb, spec[0], spec[1], w_s,
-                                     smax ? smax + lo : nullptr, st))
+      if (big) {
+        if (int rc = own_fft_big_correlate(g.P, g.Q, g.S, g.F, nb, pa, pb, spec[0], spec[1], tmp,
+                                           w_s, smax ? smax + lo : nullptr, st))
+          return rc;
+      } else if (int rc = own_fft_correlate(g.P, g.Q, g.S, g.F, nb, pa, pb, spec[0], spec[1], w_s,
+                                            smax ? smax + lo : nullptr, st)) {
         return rc;
+      }
     } else {
       float2 *FA = spec[0], *FVA = spec[1], *FA2 = spec[2];
       float2 *FB = spec[3], *FVB = spec[4], *FB2 = spec[5], *prod = spec[6];
-      if (int rc = own_fft_forward(g.P, g.F, nb, pa, 0, FA, st)) return rc;
-      if (int rc = own_fft_forward(g.P, g.F, nb, pva, 0, FVA, st)) return rc;
-      if (int rc = own_fft_forward(g.P, g.F, nb, pa, 1, FA2, st)) return rc;
-      if (int rc = own_fft_forward(g.Q, g.F, nb, pb, 0, FB, st)) return rc;
-      if (int rc = own_fft_forward(g.Q, g.F, nb, pvb, 0, FVB, st)) return rc;
-      if (int rc = own_fft_forward(g.Q, g.F, nb, pb, 1, FB2, st)) return rc;
+      auto fwd = [&](const int* R, const float* src, int square, float2* out) -> int {
+        return big ? own_fft_big_forward(R, g.F, nb, src, square, out, tmp, st)
+                   : own_fft_forward(R, g.F, nb, src, square, out, st);
+      };
+      if (int rc = fwd(g.P, pa, 0, FA)) return rc;
+      if (int rc = fwd(g.P, pva, 0, FVA)) return rc;
+      if (int rc = fwd(g.P, pa, 1, FA2)) return rc;
+      if (int rc = fwd(g.Q, pb, 0, FB)) return rc;
+      if (int rc = fwd(g.Q, pvb, 0, FVB)) return rc;
+      if (int rc = fwd(g.Q, pb, 1, FB2)) return rc;
       // xc, sa, sb, nov, qa, qb of corr_direct_kernel
       const float2* lhs[6] = {FA, FA, FVA, FVA, FA2, FVA};
       const float2* rhs[6] = {FB, FVB, FB, FVB, FVB, FB2};
@@ -358,7 +386,9 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
       cr.maxima = maxima;
       cr.smax = nullptr;
       for (int i = 0; i < 6; ++i) {
-        if (int rc = own_fft_inverse_product(g.F, nb, lhs[i], rhs[i], prod, real[i], st)) return rc;
+        if (int rc = big ? own_fft_big_inverse_product(g.F, nb, lhs[i], rhs[i], prod, tmp, real[i], st)
+                         : own_fft_inverse_product(g.F, nb, lhs[i], rhs[i], prod, real[i], st))
+          return rc;
         cr.r[i] = real[i];
       }
       // (x: workgroups striding over the rows of one surface, y: surface; about 2048
