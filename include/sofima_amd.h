@@ -63,7 +63,7 @@ int sfm_device_count(int* count);
  * return the SAME results (the tests pin the variants against each other);
  * they exist for A/B measurements and for the tests themselves.  A switch set
  * here wins over the environment variable of the same name, which is only the
- * default; value NULL un-sets it (and hides the environment variable).
+ * default; value NULL removes the explicit setting again.
  * sfm_get_option copies the value in effect (returns 1 and "" when unset).
  *   SFM_MFMA_PRUNE=0      correlation kernel computes every surface tile
  *   SFM_MFMA_PROBE=0      no seed probe in front of the pruning

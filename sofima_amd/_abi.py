@@ -408,14 +408,23 @@ def check(rc: int):
     raise SofimaAmdError(f'libsofima_amd error {rc}: {msg}')
 
 
+_explicit = {}   # switches set through set_option (name -> str), for option()
+
+
 def set_option(name: str, value=None):
   """Sets a behaviour switch of the library (include/sofima_amd.h lists them);
-  None un-sets it.  Explicit settings win over the environment."""
+  None removes the explicit setting.  Explicit settings win over the
+  environment variable of the same name, which is only the default."""
   check(load().sfm_set_option(name.encode(), None if value is None else
                               str(value).encode()))
+  if value is None:
+    _explicit.pop(name, None)
+  else:
+    _explicit[name] = str(value)
 
 
 def get_option(name: str):
+  """The value in effect (explicit setting, else environment), or None."""
   buf = C.create_string_buffer(64)
   rc = load().sfm_get_option(name.encode(), buf, 64)
   if rc == 1:
@@ -426,26 +435,19 @@ def get_option(name: str):
 
 class option:
   """`with _abi.option('SFM_MFMA_PRUNE', 0): ...` -- a switch for one block
-  (tests, A/B measurements); restores the previous explicit setting."""
+  (tests, A/B measurements); restores the previous explicit setting, or the
+  environment default when there was none."""
 
   def __init__(self, name, value):
     self.name, self.value = name, value
 
   def __enter__(self):
-    self.prev = get_option(self.name)
+    self.prev = _explicit.get(self.name)
     set_option(self.name, self.value)
     return self
 
   def __exit__(self, *exc):
-    # back to "not explicitly set" when the previous value came from nowhere or
-    # from the environment (which stays the default)
-    load().sfm_set_option(self.name.encode(), None)
-    env = os.environ.get(self.name)
-    if self.prev is not None and self.prev != env:
-      set_option(self.name, self.prev)
-    elif env is not None:
-      # un-setting hid the environment variable: re-expose it
-      set_option(self.name, env)
+    set_option(self.name, self.prev)
     return False
 
 

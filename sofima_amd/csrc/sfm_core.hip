@@ -30,7 +30,6 @@ namespace {
 // are kept in a list of stable strings (callers hold the pointers briefly).
 std::mutex g_opt_mu;
 std::map<std::string, std::string> g_opts;
-std::map<std::string, bool> g_opt_unset;
 }  // namespace
 
 const char* option(const char* name) {
@@ -38,7 +37,6 @@ const char* option(const char* name) {
     std::lock_guard<std::mutex> lk(g_opt_mu);
     auto it = g_opts.find(name);
     if (it != g_opts.end()) return it->second.c_str();
-    if (g_opt_unset.count(name)) return nullptr;
   }
   return std::getenv(name);
 }
@@ -140,13 +138,10 @@ int sfm_set_option(const char* name, const char* value) {
   if (!name || std::strncmp(name, "SFM_", 4) != 0)
     return sfm::fail(SFM_ERR_INVALID, "option names start with SFM_");
   std::lock_guard<std::mutex> lk(sfm::g_opt_mu);
-  if (value) {
+  if (value)
     sfm::g_opts[name] = value;
-    sfm::g_opt_unset.erase(name);
-  } else {
-    sfm::g_opts.erase(name);
-    sfm::g_opt_unset[name] = true;   // hides the environment variable as well
-  }
+  else
+    sfm::g_opts.erase(name);   // back to the default: the environment variable, if any
   return SFM_OK;
 }
 

@@ -46,19 +46,27 @@ def test_version_and_error_channel(lib):
 
 
 def test_option_table(lib):
-  """Explicit switches win over the environment, NULL hides both."""
+  """Explicit switches win over the environment, which stays the default."""
   assert lib.sfm_set_option(b'NOT_OURS', b'1') == -1
   os.environ['SFM_TEST_SWITCH'] = 'env'
   try:
     assert _abi.get_option('SFM_TEST_SWITCH') == 'env'
     with _abi.option('SFM_TEST_SWITCH', 7):
       assert _abi.get_option('SFM_TEST_SWITCH') == '7'
+      with _abi.option('SFM_TEST_SWITCH', 8):
+        assert _abi.get_option('SFM_TEST_SWITCH') == '8'
+      assert _abi.get_option('SFM_TEST_SWITCH') == '7'
     assert _abi.get_option('SFM_TEST_SWITCH') == 'env'
+    os.environ['SFM_TEST_SWITCH'] = 'env2'          # still just the default
+    assert _abi.get_option('SFM_TEST_SWITCH') == 'env2'
+    _abi.set_option('SFM_TEST_SWITCH', 'x')
+    assert _abi.get_option('SFM_TEST_SWITCH') == 'x'
     _abi.set_option('SFM_TEST_SWITCH', None)
-    assert _abi.get_option('SFM_TEST_SWITCH') is None
+    assert _abi.get_option('SFM_TEST_SWITCH') == 'env2'
   finally:
     del os.environ['SFM_TEST_SWITCH']
     _abi.set_option('SFM_TEST_SWITCH', None)
+  assert _abi.get_option('SFM_TEST_SWITCH') is None
 
 
 def test_struct_layouts_match_header():
