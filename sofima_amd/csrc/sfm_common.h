@@ -54,6 +54,7 @@ struct AdvanceView {
   int pending;               // the previous step's gate / drift still to apply
   int remove_drift;
   float vv_dt;               // damped Verlet: fixed dt
+  const float* colmean;      // pending per-x-column drift means [6][X] (5-D states) or nullptr
 };
 
 // sfm_maps.hip: prev = target_mesh(x') written to `out`.  strips_only: nodes

@@ -543,8 +543,8 @@ advance_kernel(float* __restrict__ x, float* __restrict__ v,
         vv = vv * s.gate;
         if (p.drift_cols) {
           const int xi = static_cast<int>(n % p.X);
-          xv = xv - colsum[c * p.X + xi] / p.n_col;
-          vv = vv - (colsum[(3 + c) * p.X + xi] / p.n_col) * s.gate;
+          xv = xv - colsum[c * p.X + xi];
+          vv = vv - colsum[(3 + c) * p.X + xi] * s.gate;
         } else if (p.remove_drift) {
           xv = xv - s.mx[c];
           vv = vv - s.mv[c];
@@ -1697,7 +1697,7 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
                          float* a_out, MeshParams p, const Scalars* __restrict__ scal_in,
                          Scalars* __restrict__ scal_out, float fixed_cap,
                          u64* __restrict__ partials, int* __restrict__ ticket, int pending,
-                         int ntz, int nty, int ntx) {
+                         int ntz, int nty, int ntx, const float* __restrict__ colmean) {
   constexpr int C = 3;
   constexpr int PZ = kTZ3 + 2, PY = kTY3 + 2, PX = kTX3 + 2;
   constexpr int kCells = PZ * PY * PX;
@@ -1725,6 +1725,9 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
   const float dt = s.dt, alpha = s.alpha, cap = s.cap;
   const float c2 = 0.5f * (dt * dt);
   const bool fix = p.fire && pending;
+  // pending per-x-column drift means (5-D states): colsum[c][xi] = mean of x,
+  // colsum[3 + c][xi] = mean of v over the column, left by drift_cols_kernel
+  const bool fix_cols = fix && p.drift_cols;
 
   int t = blockIdx.x;
   const int tx = t % ntx;
@@ -1737,13 +1740,16 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
   const long long base = batch * vol;
   const int gx0 = tx * kTX3, gy0 = ty * kTY3, gz0 = tz * kTZ3;
 
-  auto advanced = [&](long long n, int c, float* v_keep, float* a_keep) -> float {
+  auto advanced = [&](long long n, int xi, int c, float* v_keep, float* a_keep) -> float {
     float xv = x_in[c * p.N + n];
     float vv = v_in[c * p.N + n];
     const float aa = a_in[c * p.N + n];
     if (fix) {
       vv = vv * s.gate;
-      if (p.remove_drift) {
+      if (fix_cols) {
+        xv = xv - colmean[c * p.X + xi];
+        vv = vv - colmean[(3 + c) * p.X + xi] * s.gate;
+      } else if (p.remove_drift) {
         xv = xv - s.mx[c];
         vv = vv - s.mv[c];
       }
@@ -1771,7 +1777,7 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
     const long long nc = base + ((long long)min(gz, p.Z - 1) * p.Y + min(gy, p.Y - 1)) * p.X +
                          min(gx, p.X - 1);
 #pragma unroll
-    for (int c = 0; c < C; ++c) x_own[k][c] = advanced(nc, c, &v_own[k][c], &a_own[k][c]);
+    for (int c = 0; c < C; ++c) x_own[k][c] = advanced(nc, min(gx, p.X - 1), c, &v_own[k][c], &a_own[k][c]);
   }
   // shell cells (the six faces of the padded brick), enumerated directly
   constexpr int kFaceZ = PY * PX, kFaceY = (PZ - 2) * PX, kFaceX = (PZ - 2) * (PY - 2);
@@ -1806,7 +1812,7 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
     const long long n = base + ((long long)min(max(gz, 0), p.Z - 1) * p.Y +
                                 min(max(gy, 0), p.Y - 1)) * p.X + min(max(gx, 0), p.X - 1);
 #pragma unroll
-    for (int c = 0; c < C; ++c) sh[it][c] = advanced(n, c, nullptr, nullptr);
+    for (int c = 0; c < C; ++c) sh[it][c] = advanced(n, min(max(gx, 0), p.X - 1), c, nullptr, nullptr);
   }
   // the remaining per-node input
   float pv_own[kOwn][C];
@@ -1936,25 +1942,92 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
 
 // Reference quirk Q3 (mesh.py:496-497): the drift means are taken over axes
 // (1, 2, 3); for a 5-D state [3, N, z, y, x] that is a mean per x COLUMN.
-// colsum[c][xi] = sum of x, colsum[3 + c][xi] = sum of v over the column, in a
-// fixed order (one workgroup per column and component).
+// colsum[c][xi] = mean of x, colsum[3 + c][xi] = mean of v over the column, summed
+// in a fixed order: thread (g, xi) of chunk k adds rows k * rows_per + g, + G, ...
+// (consecutive threads read consecutive addresses), the G row groups of a chunk
+// are added in order, and the last workgroup of a component (ticket) adds the
+// chunks in order and divides.  (One workgroup per column striding through the
+// rows took 14.7 us on [3,64,12,12,12]; this takes ~4.)
+constexpr int kColChunksMax = 64;
+constexpr int kColBatch = 16;
+
 template <int C>
 __global__ void __launch_bounds__(kBlock)
 drift_cols_kernel(const float* __restrict__ x, const float* __restrict__ v,
-                  MeshParams p, float* __restrict__ colsum) {
-  __shared__ float lds[kNP * kBlock];
-  const int xi = blockIdx.x, c = blockIdx.y;
+                  MeshParams p, float* __restrict__ colsum, float* __restrict__ col_part,
+                  int* __restrict__ col_ticket, int rows_per) {
+  __shared__ float lds[2][kBlock];
+  __shared__ int s_last;
+  const int c = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x;
   const long long rows = p.N / p.X;
-  float acc[2] = {0.f, 0.f};
-  for (long long r = threadIdx.x; r < rows; r += kBlock) {
-    acc[0] = acc[0] + x[c * p.N + r * p.X + xi];
-    acc[1] = acc[1] + v[c * p.N + r * p.X + xi];
+  const int G = p.X <= kBlock ? kBlock / p.X : 1;
+  const long long r0 = (long long)chunk * rows_per;
+  const long long r1 = min(rows, r0 + rows_per);
+  // columns beyond the workgroup width are walked in passes (X > 256: G == 1)
+  for (int x0 = 0; x0 < p.X; x0 += kBlock) {
+    const int g = threadIdx.x / p.X, xi = x0 + (G > 1 ? threadIdx.x % p.X : threadIdx.x);
+    float acc[2] = {0.f, 0.f};
+    if (g < G && xi < p.X)
+      // batches of independent loads (the adds stay in row order): a rolled loop
+      // waits for every row's pair of loads in turn
+      for (long long rb = r0 + g; rb < r1; rb += (long long)G * kColBatch) {
+        float bx[kColBatch], bv[kColBatch];
+#pragma unroll
+        for (int k = 0; k < kColBatch; ++k) {
+          const long long r = min(rb + (long long)k * G, rows - 1);
+          bx[k] = x[c * p.N + r * p.X + xi];
+          bv[k] = v[c * p.N + r * p.X + xi];
+        }
+#pragma unroll
+        for (int k = 0; k < kColBatch; ++k)
+          if (rb + (long long)k * G < r1) {
+            acc[0] = acc[0] + bx[k];
+            acc[1] = acc[1] + bv[k];
+          }
+      }
+    lds[0][threadIdx.x] = acc[0];
+    lds[1][threadIdx.x] = acc[1];
+    __syncthreads();
+    if (threadIdx.x < min(p.X - x0, kBlock)) {
+      float s0 = lds[0][threadIdx.x], s1 = lds[1][threadIdx.x];
+      for (int k = 1; k < G; ++k) {
+        s0 = s0 + lds[0][threadIdx.x + k * p.X];
+        s1 = s1 + lds[1][threadIdx.x + k * p.X];
+      }
+      float* dst = col_part + (((long long)c * n_chunks + chunk) * 2) * p.X + x0 + threadIdx.x;
+      __builtin_nontemporal_store(s0, dst);
+      __builtin_nontemporal_store(s1, dst + p.X);
+    }
+    __syncthreads();
   }
-  block_sum(acc, 2, lds);
-  if (threadIdx.x == 0) {
-    colsum[c * p.X + xi] = acc[0];
-    colsum[(3 + c) * p.X + xi] = acc[1];
+  __threadfence();
+  if (threadIdx.x == 0)
+    s_last = atomicAdd(&col_ticket[c], 1) == n_chunks - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (int xi = threadIdx.x; xi < p.X; xi += kBlock) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int kb = 0; kb < n_chunks; kb += kColBatch) {
+      float b0[kColBatch], b1[kColBatch];
+#pragma unroll
+      for (int k = 0; k < kColBatch; ++k) {
+        const float* src =
+            col_part + (((long long)c * n_chunks + min(kb + k, n_chunks - 1)) * 2) * p.X + xi;
+        b0[k] = __builtin_nontemporal_load(src);
+        b1[k] = __builtin_nontemporal_load(src + p.X);
+      }
+#pragma unroll
+      for (int k = 0; k < kColBatch; ++k)
+        if (kb + k < n_chunks) {
+          s0 = s0 + b0[k];
+          s1 = s1 + b1[k];
+        }
+    }
+    colsum[c * p.X + xi] = s0 / p.n_col;
+    colsum[(3 + c) * p.X + xi] = s1 / p.n_col;
   }
+  if (threadIdx.x == 0) col_ticket[c] = 0;   // ready for the next step's launch
 }
 
 // Applies the pending gate / drift of the last step and emits the per-block
@@ -1992,8 +2065,8 @@ finish_kernel(float* __restrict__ x, float* __restrict__ v, MeshParams p,
         vv = vv * s.gate;
         if (p.drift_cols) {
           const int xi = static_cast<int>(n % p.X);
-          x[c * p.N + n] = x[c * p.N + n] - colsum[c * p.X + xi] / p.n_col;
-          vv = vv - (colsum[(3 + c) * p.X + xi] / p.n_col) * s.gate;
+          x[c * p.N + n] = x[c * p.N + n] - colsum[c * p.X + xi];
+          vv = vv - colsum[(3 + c) * p.X + xi] * s.gate;
         } else if (p.remove_drift) {
           x[c * p.N + n] = x[c * p.N + n] - s.mx[c];
           vv = vv - s.mv[c];
@@ -3085,7 +3158,9 @@ struct MeshWorkspace {
   float* alt[3];       // tiled path: second (x, v, a) set, [ncomp * N] each
   u64* tile_part;      // tiled path: [n_tiles * kNP] {epoch, value} granules
   int* ticket;         // tiled path: last-workgroup counter
-  float* colsum;       // per-column drift sums [6][X] (remove_drift == 2)
+  float* colsum;       // per-column drift means [6][X] (remove_drift == 2)
+  float* col_part;     // drift_cols_kernel: [3][kColChunksMax][2][X] chunk sums
+  int* col_ticket;     // [3], zero between launches
   int* target_list;    // native prev_fn, in-plane: node blocks on the overlap strips
   size_t bytes;
 };
@@ -3140,12 +3215,24 @@ bool bricks_enabled() {
 
 TilePlan plan_bricks(const SfmMeshDesc* d) {
   TilePlan t;
+  // Volumetric montage with the native prev_fn (12^3-node tiles: launch and
+  // latency bound).  Measured per step on [3,64,12,12,12], FIRE, column drift:
+  //   advance 8 + target mesh 12 + integrate_kernel<3> 17 + column means   52 us
+  //   target mesh of the advanced positions 33 + brick kernel 42 + means   99 us
+  //   target mesh INSIDE the brick kernel (one launch + means)            137 us
+  // Every "fused" variant loses: a thread of the brick kernel owns four nodes
+  // and runs load -> LDS -> barrier -> springs -> tile sums -> ticket in series,
+  // the per-node kernels have a thread per node and nothing to wait for.  With
+  // SFM_MESH_BRICKS=1 the second variant runs (tested, not the default).
+  const bool montage = d->target != nullptr;
   if (!bricks_enabled()) return t;
-  if (d->ncomp != 3 || !tiled_enabled() || d->n_links != 0 || d->target || d->prev_cb ||
-      d->remove_drift == 2 || d->force_kind != SFM_FORCE_SPRINGS)
+  if (d->ncomp != 3 || !tiled_enabled() || d->n_links != 0 || d->prev_cb ||
+      d->force_kind != SFM_FORCE_SPRINGS)
     return t;
+  if (!montage && d->remove_drift == 2) return t;
+  if (montage && !fuse_target_enabled()) return t;
   const int Z = d->shape[1], Y = d->shape[2], X = d->shape[3];
-  if ((long long)Z * Y * X < 4096) return t;  // tiny volumes stay launch bound either way
+  if (!montage && (long long)Z * Y * X < 4096) return t;  // tiny volumes stay launch bound either way
   t.tx = kTX3;
   t.ty = kTY3;
   t.ntz = (Z + kTZ3 - 1) / kTZ3;
@@ -3198,6 +3285,8 @@ MeshWorkspace carve(void* ws, size_t prev_floats, size_t alt_floats, long long t
   w.tile_part = tiles ? c.take<u64>((size_t)tiles * kNP) : nullptr;
   w.ticket = c.take<int>(4);
   w.colsum = c.take<float>(6 * (size_t)(ncols > 0 ? ncols : 1));
+  w.col_part = c.take<float>(ncols > 0 ? (size_t)3 * kColChunksMax * 2 * ncols : 1);
+  w.col_ticket = c.take<int>(4);
   w.scal = c.take<Scalars>(2);
   w.partials = c.take<float>(kMaxBlocks * kNP);
   w.stat_part = c.take<float>(kMaxBlocks * 2);
@@ -3441,8 +3530,9 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   // from (x, v, a) on the overlap strips (sfm::AdvanceView) -- so the step is
   // target mesh (strips only) + the fused integrator instead of advance + target
   // mesh (all nodes) + integrate.  Same float operations: bit-identical.
-  const bool fuse_target = tiled && d->target && tiles.ntz == 0 && w.alt[0] &&
-                           fuse_target_enabled();
+  // Volumetric montages the same way in front of the brick kernel (all nodes of
+  // the 16-node blocks that touch a region; no block list).
+  const bool fuse_target = tiled && d->target && w.alt[0] && fuse_target_enabled();
   const bool fused = tiled && (!dyn_prev || fuse_target);
   if (fuse_target && w.target_list)
     if (int rc = sfm::build_target_list(d->target, w.target_list, st)) return rc;
@@ -3499,17 +3589,38 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
                          __VA_ARGS__);                                       \
     SFM_LAUNCH_CHECK();                                                      \
   } while (0)
+  // column means of the state in (xs, vs): ~16 rows per thread and chunk
+  const long long col_rows = p.N / p.X;
+  const int col_groups = p.X <= kBlock ? kBlock / p.X : 1;
+  const int col_chunks = static_cast<int>(std::max<long long>(
+      1, std::min<long long>(kColChunksMax, (col_rows + col_groups * 16LL - 1) / (col_groups * 16LL))));
+  const int col_rows_per = static_cast<int>((col_rows + col_chunks - 1) / col_chunks);
+  if (p.fire && p.drift_cols) SFM_HIP_CHECK(hipMemsetAsync(w.col_ticket, 0, 4 * sizeof(int), st));
+  auto column_means = [&](const float* xs, const float* vs) {
+    hipLaunchKernelGGL(drift_cols_kernel<3>, dim3(col_chunks, 3), dim3(kBlock), 0, ls, xs, vs, p,
+                       w.colsum, w.col_part, w.col_ticket, col_rows_per);
+  };
   auto step = [&](int pending) -> int {
     if (fused && tiles.ntz > 0) {
       float** bi = bufs[in];
       float** bo = bufs[in ^ 1];
+      if (fuse_target) {
+        const sfm::AdvanceView av{bi[1], bi[2], &w.scal[cur], p.fire, pending, p.remove_drift,
+                                  p.vv_dt, p.drift_cols ? w.colsum : nullptr};
+        if (int rc = sfm::launch_target_mesh(d->target, bi[0], w.prev_buf, ls, &av, true))
+          return rc;
+      }
       if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
       hipLaunchKernelGGL(integrate_tiled3d_kernel, dim3(tgrid), dim3(kBlock), 0, ls, bi[0],
                          bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
                          &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.ntz,
-                         tiles.nty, tiles.ntx);
+                         tiles.nty, tiles.ntx, w.colsum);
       if (timing) sfm::prof_end(sfm::kProfMesh, ls);
       SFM_LAUNCH_CHECK();
+      if (p.fire && p.drift_cols) {   // column sums of what this step stored
+        column_means(bo[0], bo[1]);
+        SFM_LAUNCH_CHECK();
+      }
       in ^= 1;
       if (p.fire) cur ^= 1;
     } else if (fused) {
@@ -3517,7 +3628,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       float** bo = bufs[in ^ 1];
       if (fuse_target) {
         const sfm::AdvanceView av{bi[1], bi[2], &w.scal[cur], p.fire, pending,
-                                  p.remove_drift, p.vv_dt};
+                                  p.remove_drift, p.vv_dt, nullptr};
         if (int rc = sfm::launch_target_mesh(d->target, bi[0], w.prev_buf, ls, &av, true,
                                              w.target_list))
           return rc;
@@ -3572,8 +3683,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       }
       if (timing) sfm::prof_end(sfm::kProfMesh, ls);
       if (p.fire && p.drift_cols) {
-        hipLaunchKernelGGL(drift_cols_kernel<3>, dim3(p.X, 3), dim3(kBlock), 0, ls, d->x,
-                           d->v, p, w.colsum);
+        column_means(d->x, d->v);
         SFM_LAUNCH_CHECK();
       }
     }
