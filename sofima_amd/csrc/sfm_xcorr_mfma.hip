@@ -63,7 +63,7 @@
 // 176 / 208 keep the b128 / b32 fragment reads bank-conflict free.
 //
 // Build switches (experiments): SFM_MFMA_TIMING
-// (in-kernel phase ticks), SFM_ABLATE_EPILOGUE, SFM_NO_TOUCH, SFM_AF_PREFETCH,
+// (in-kernel phase ticks), SFM_ABLATE_EPILOGUE, SFM_ABLATE_STORE, SFM_NO_TOUCH, SFM_AF_PREFETCH,
 // SFM_EPI_QG / SFM_EPI_DEPTH.
 #include "sfm_common.h"
 
@@ -2663,9 +2663,11 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           };
           auto store4 = [&](int q, int r, float v) {
             if (q < col_skip || q >= NQ - col_skip) v = 0.f;  // column tile left out
+#ifndef SFM_ABLATE_STORE  // timing experiment: the kernel without its surface writes
             __builtin_nontemporal_store(
                 v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
                                             (static_cast<size_t>(rowp[r]) + 64u * q)));
+#endif
             tmax = fmaxf(tmax, v);
             acc[q][r] = __float_as_int(v);
           };
@@ -2750,9 +2752,11 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             corr = fmaf(fny[r], fnx, corr);
             float v = static_cast<float>(acc[q][r]) + corr;
             if (q < col_skip || q >= NQ - col_skip) v = 0.f;  // column tile left out
+#ifndef SFM_ABLATE_STORE  // timing experiment: the kernel without its surface writes
             __builtin_nontemporal_store(
                 v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
                                             (static_cast<size_t>(rowp[r]) + 64u * q)));
+#endif
             tmax = fmaxf(tmax, v);
             acc[q][r] = __float_as_int(v);
           }
