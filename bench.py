@@ -21,7 +21,9 @@ with the exact tile pruning switched off (a second leg of the same run), so
 every algorithmic operation is executed; `frac_pruned` is the production launch
 of the timed region (algorithmic operations / time: includes the skipped work);
 `issued_frac` counts the matrix instructions the kernel really issued.  After
-the timed region the step is repeated for >= --sustain seconds (`sustained`).  `cpu_baseline` times the CPU oracle (a NumPy/SciPy port
+the timed region the step is repeated for >= --sustain seconds (`sustained`).
+`aux_rooflines` carries HBM roofline lines for the FFT form of the correlation
+and the volumetric / large in-plane mesh steps.  `cpu_baseline` times the CPU oracle (a NumPy/SciPy port
 of the reference algorithm) on a bounded sample of the same workload.
 """
 import argparse
@@ -420,6 +422,10 @@ def main():
                  'mpix_s': round(world * pix * n_sus / s_el / 1e6, 1),
                  'note': 'flow + mesh steps back to back (includes the mesh leg)'}
 
+  aux = None
+  if world == 1 and not args.no_legs:
+    aux = aux_legs(dev, args.seed)
+
   sharded = None
   if args.mesh_sharded > 0:
     sharded = mesh_sharded_leg(args.mesh_sharded, dev, rank, world)
@@ -454,6 +460,8 @@ def main():
     out['sustained_ms_per_step'] = sustained['ms_per_step']
   if sharded:
     out['mesh_sharded'] = sharded
+  if aux:
+    out['aux_rooflines'] = aux
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline(size, args.seed + rank, args.pair)
@@ -461,6 +469,75 @@ def main():
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
+
+
+def aux_legs(dev, seed):
+  """HBM roofline lines of the other kernels of the path, wall-clock timed with
+  the inputs resident (a few hundred ms each): the FFT form of the correlation
+  (float images: flow_field.py:374-441 with method 3; 3-D patches) and the
+  volumetric / large in-plane mesh steps (mesh.py:192-279, 383-513).
+  `achieved` = ALGORITHMIC bytes / time: each input patch pixel read once and
+  the peak statistics written (FFT form); x, v, a read and written and prev
+  read once per node update (mesh: 14 floats in-plane, 21 volumetric)."""
+  import torch
+  from sofima_amd import _abi, flow_field, mesh
+  out = []
+
+  def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    for _ in range(reps):
+      fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t) / reps
+
+  def line(name, kernel, nbytes, sec, **extra):
+    gbs = nbytes / sec / 1e9
+    o = {'leg': name, 'kernel': kernel, 'bound': 'hbm', 'achieved': round(gbs, 1),
+         'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+         'ms': round(sec * 1e3, 3), 'traffic': None}
+    o.update(extra)
+    out.append(o)
+
+  rng = np.random.default_rng(seed)
+  # FFT form, in-plane: float32 2048^2 pair, patch 160 step 40 -> 48 x 48 patches
+  n2 = 2048
+  a = torch.from_numpy(rng.random((n2, n2), dtype=np.float32)).to(dev)
+  b = torch.roll(a, (2, -3), (0, 1)).contiguous()
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator(method=_abi.XCORR_FFT)
+  sec = timed(lambda: calc.flow_field(a, b, PATCH, STEP, batch_size=BATCH), 3)
+  np2 = ((n2 - PATCH) // STEP + 1) ** 2
+  line('xcorr_fft_2d', 'fft_pencil / fft_xfwd / fft_xinv (sfm_fft_own.hip)',
+       np2 * (2 * PATCH * PATCH * 4 + 16), sec, patches=np2,
+       workload='float32 2048^2 pair, patch 160 step 40, FFT form')
+  # FFT form, volumetric: 160^3 pair, patch 80 step 40 -> 3^3 patches
+  v = torch.from_numpy(rng.random((160, 160, 160), dtype=np.float32)).to(dev)
+  w = torch.roll(v, (1, -2, 2), (0, 1, 2)).contiguous()
+  calc3 = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  sec = timed(lambda: calc3.flow_field(v, w, (80, 80, 80), (40, 40, 40), batch_size=64), 3)
+  line('xcorr_fft_3d', 'fft3 kernels (sfm_fft_own.hip)', 27 * (2 * 80 ** 3 * 4 + 20), sec,
+       patches=27, workload='float32 160^3 pair, patch 80^3 step 40 (BASELINE configs[4] patch size)')
+  # mesh steps: FIRE, 200 iterations of one chunk
+  iters = 200
+  for name, shape, force, stride, fl in (
+      ('mesh_3d', (3, 4, 100, 100, 100), mesh.elastic_mesh_3d, (40, 40, 40), 21),
+      ('mesh_2d_large', (2, 4, 2048, 2048), None, (40, 40), 14),
+      ('mesh_2d_montage_size', (2, 64, 204, 204), None, (40, 40), 14)):
+    prev = torch.from_numpy((rng.standard_normal(shape) * 3).astype(np.float32)).to(dev)
+    x0 = torch.zeros_like(prev)
+    cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=stride,
+                                 num_iters=iters, max_iters=iters, stop_v_max=1e-9,
+                                 dt_max=1000, start_cap=0.1, final_cap=10)
+    kw = {'mesh_force': force} if force is not None else {}
+    sec = timed(lambda: mesh.relax_mesh(x0, prev, cfg, **kw), 2)
+    nodes = int(np.prod(shape[1:]))
+    line(name, 'integrate_kernel<3>' if force is not None else 'integrate_shared2d_kernel',
+         nodes * iters * fl * 4, sec, nodes=nodes, us_per_step=round(sec / iters * 1e6, 2),
+         node_updates_per_s=round(nodes * iters / sec, 0), state=list(shape),
+         bytes_per_node_update=fl * 4)
+    del prev, x0
+  return out
 
 
 def mesh_sharded_leg(bands_per_rank, dev, rank, world):

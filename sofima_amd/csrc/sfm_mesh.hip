@@ -46,6 +46,9 @@ constexpr int kMaxBlocks = 1024;
 #ifndef SFM_LB3
 #define SFM_LB3 3
 #endif
+#ifndef SFM_LB_SHARED
+#define SFM_LB_SHARED 1
+#endif
 #ifndef SFM_LBT
 #define SFM_LBT 1
 #endif
@@ -1069,6 +1072,7 @@ struct BandArgs {
   int ty_mode, ty_a, ty_b;
   const BandDev* multi;  // multi-band launch: the per-band fields above and the
   int n_multi;           // kernel's array / scalar arguments come from here
+  int xcd_map;           // blocks of one XCD (block % 8) take a contiguous run of tiles
 };
 
 // Sum of the bands' partial sums in band order + the FIRE update from them
@@ -1095,7 +1099,7 @@ __global__ void band_scalars_kernel(const Scalars* __restrict__ scal_in,
 }
 
 template <bool FUSED>
-__global__ void __launch_bounds__(kBlock, SFM_LBT)
+__global__ void __launch_bounds__(kBlock, SFM_LB_SHARED)
 integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_in,
                           const float* prev, float* x_out, float* v_out,
                           float* a_out, MeshParams p,
@@ -1110,6 +1114,14 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
   __shared__ float lds[kNP * kBlock];
   __shared__ int s_last;
   int block = blockIdx.x;   // block index within the band
+  if (bd.xcd_map) {
+    // consecutive workgroups go to different XCDs (own L2 each), neighbouring
+    // tiles share halo rows / the cache lines at their column seams: give every
+    // XCD one contiguous run of tiles
+    const int nb = static_cast<int>(gridDim.x), per = nb >> 3, rem = nb & 7;
+    const int xcd = block & 7, idx = block >> 3;
+    block = xcd * per + min(xcd, rem) + idx;
+  }
   float* nb_dst[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   long long nb_n[2] = {0, 0}, nb_plane[2] = {0, 0}, nb_off[2] = {0, 0};
   if (bd.multi) {
@@ -3537,6 +3549,8 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   if (fuse_target && w.target_list)
     if (int rc = sfm::build_target_list(d->target, w.target_list, st)) return rc;
   const int tgrid = static_cast<int>(tiles.tiles);
+  const char* xcd_opt = sfm::option("SFM_MESH_XCD");
+  const int xcd_map = (xcd_opt && xcd_opt[0] == '1' && tgrid >= 64) ? 1 : 0;
   if (tiled) {
     // LDS-tiled integrator (2-D): one launch per step, or advance + prev_fn +
     // integrate when the spring targets depend on the advanced positions.
@@ -3638,7 +3652,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
         hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(tgrid), dim3(kBlock), 0, ls,
                            bi[0], bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
                            &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.nty,
-                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0});
+                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, xcd_map});
       else if (tiles.tx == 64)
         SFM_TILED(16, 64, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
       else
@@ -3657,7 +3671,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
         hipLaunchKernelGGL(integrate_shared2d_kernel<false>, dim3(tgrid), dim3(kBlock), 0, ls,
                            d->x, d->v, d->a, prev_ptr, d->x, d->v, d->a, p, &w.scal[cur],
                            &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, 1, tiles.nty,
-                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0});
+                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, xcd_map});
       else if (tiles.tx == 64)
         SFM_TILED(16, 64, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
       else
