@@ -353,8 +353,12 @@ def flow_field(pre_image, post_image, patch_size, step, pre_mask=None,
                post_patch_size=None, pre_targeting_field=None,
                pre_targeting_step=None, post_targeting_field=None,
                post_targeting_step=None, mean=None, min_distance=2,
-               peak_radius=5, workers=1, max_batches=None):
-  """[dim+2, *grid] float32 flow (x, y[, z], sharpness, ratio); NaN = none."""
+               peak_radius=5, workers=1, max_batches=None, only_batches=None):
+  """[dim+2, *grid] float32 flow (x, y[, z], sharpness, ratio); NaN = none.
+
+  max_batches / only_batches (test infrastructure, not in the reference): stop
+  after the first n batches / evaluate only the batches with these indices;
+  the rest of the field stays NaN."""
   nd = pre_image.ndim
   patch_size = _seq(patch_size, nd)
   post_patch_size = patch_size if post_patch_size is None else _seq(
@@ -377,6 +381,8 @@ def flow_field(pre_image, post_image, patch_size, step, pre_mask=None,
   for lo in range(0, len(grid), batch_size):
     if max_batches is not None and n_done >= max_batches:
       break
+    if only_batches is not None and lo // batch_size not in only_batches:
+      continue
     n_done += 1
     pos = grid[lo:lo + batch_size]
     real = len(pos)

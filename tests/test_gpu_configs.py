@@ -3,9 +3,9 @@
 configs[0]  2 x 2 grid of 512^2 tiles, patch 64 step 32: flow leg vs the
             reference's own output (stitch_cfg1.npz), mesh leg in
             test_gpu_maps.py (montage.npz)
-configs[1]  8192^2 pair, patch 160 step 40 batch 1024: warped pair, one full
-            reference batch of 1024 patches vs the oracle (the rigid-shift
-            properties are in test_gpu_flow.py)
+configs[1]  8192^2 pair, patch 160 step 40 batch 1024: warped pair, three full
+            reference batches (first, middle, ragged last: 2513 patches) vs the
+            oracle (the rigid-shift properties are in test_gpu_flow.py)
 configs[2]  8 x 8 montage of 4096^2 tiles: a 4096 x 400 overlap strip, patch 120
             step 20 batch 256, and the [2, 64, 204, 204] mesh with the native
             target-mesh prev_fn + remove_drift, 100 FIRE steps, vs the oracle
@@ -56,10 +56,12 @@ def _warp(img, amp, lam):
   return out
 
 
-def test_cfg1_full_size_warped_pair_first_batch_vs_oracle(gpu):
+def test_cfg1_full_size_warped_pair_batches_vs_oracle(gpu):
   """8192^2 pair whose second image is sampled through a smooth 6 px warp:
-  the first reference batch (1024 patches, same batch membership) agrees with
-  the oracle vector for vector; the rest of the field follows the warp."""
+  three whole reference batches -- the first, one from the middle and the
+  ragged last one (465 of 1024 patches; 2513 patches in all, same batch
+  membership as the reference) -- agree with the oracle vector for vector; the
+  rest of the field follows the warp."""
   from sofima_amd import flow_field as ff
   rng = np.random.default_rng(1002)
   size = 8192
@@ -69,11 +71,15 @@ def test_cfg1_full_size_warped_pair_first_batch_vs_oracle(gpu):
   calc = ff.JAXMaskedXCorrWithStatsCalculator()
   got = calc.flow_field(pre, post, 160, 40, batch_size=1024)
   assert got.shape == (4, 201, 201)
+  batches = (0, 19, 39)
   want = flow_oracle.flow_field(pre, post, 160, 40, batch_size=1024, workers=16,
-                                max_batches=1)
-  n = 1024
-  g = got.reshape(4, -1)[:, :n]
-  w = want.reshape(4, -1)[:, :n]
+                                only_batches=batches)
+  sel = np.zeros(201 * 201, bool)
+  for b in batches:
+    sel[b * 1024:(b + 1) * 1024] = True
+  assert sel.sum() == 2 * 1024 + 465
+  g = got.reshape(4, -1)[:, sel]
+  w = want.reshape(4, -1)[:, sel]
   assert np.isfinite(w[:2]).all()
   np.testing.assert_array_equal(g[:2], w[:2])
   np.testing.assert_array_equal(np.isnan(g), np.isnan(w))

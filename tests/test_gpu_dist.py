@@ -111,26 +111,32 @@ def test_rccl_entry_points_world_size_one(gpu):
     comm.close()
 
 
-def test_block_chain_on_device_vs_oracle(gpu):
-  """configs[3] block chain with the HIP relax / compose ops vs the oracle."""
+@pytest.mark.parametrize('shape,n_blocks,max_iters', [((2, 6, 30, 34), 3, 1000),
+                                                      ((2, 8, 201, 201), 4, 300)])
+def test_block_chain_on_device_vs_oracle(gpu, shape, n_blocks, max_iters):
+  """configs[3] block chain with the HIP relax / compose ops vs the oracle: a
+  small chain, and eight sections of the configs[1] field size (201 x 201
+  vectors) in four blocks."""
   from oracle import maps_oracle
   from scipy import ndimage
   from sofima_amd import dist as sdist, mesh
   rng = np.random.default_rng(6)
-  flow = ndimage.gaussian_filter(rng.standard_normal((2, 6, 30, 34)), (0, 0, 3, 3)) * 12
-  flow = flow.astype(np.float32)
+  big = shape[-1] > 100
+  sigma = 12 if big else 3
+  flow = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, sigma, sigma))
+  flow = (flow / np.abs(flow).max() * 4.0).astype(np.float32)
   flow[:, 2, :2, :3] = np.nan
   cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.05, k=0.1, stride=(40, 40),
-                               num_iters=100, max_iters=1000, stop_v_max=0.005,
+                               num_iters=100, max_iters=max_iters, stop_v_max=0.005,
                                dt_max=1000, start_cap=0.1, final_cap=10,
                                prefer_orig_order=True)
-  blocks, last, xblk = sdist.align_sections_blocked(flow, cfg, 40.0, n_blocks=3)
+  blocks, last, xblk = sdist.align_sections_blocked(flow, cfg, 40.0, n_blocks=n_blocks)
   wb, wl, wx = sdist.align_sections_blocked(
-      flow, cfg, 40.0, n_blocks=3, relax_fn=mesh_oracle.relax_mesh,
+      flow, cfg, 40.0, n_blocks=n_blocks, relax_fn=mesh_oracle.relax_mesh,
       compose_fn=maps_oracle.compose_maps_fast)
   np.testing.assert_allclose(last, wl, atol=2e-2)
   np.testing.assert_allclose(xblk, wx, atol=2e-2)
-  for b in range(3):
+  for b in range(n_blocks):
     np.testing.assert_array_equal(np.isnan(blocks[b]), np.isnan(wb[b]))
     np.testing.assert_allclose(np.nan_to_num(blocks[b]), np.nan_to_num(wb[b]), atol=2e-2)
 
