@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 4   /* 4: SfmProfile.mfma_issued; sfm_mesh_relax_banded */
+#define SFM_ABI_VERSION 5   /* 4: SfmProfile.mfma_issued; sfm_mesh_relax_banded; 5: SfmWarpDesc.coord_map_f64 */
 
 #define SFM_OK 0
 #define SFM_ERR_INVALID (-1)     /* bad argument / unsupported combination */
@@ -328,13 +328,17 @@ typedef struct SfmWarpDesc {
   double map_origin[2];         /* y, x of map node (0, 0) in output pixels  */
   double stride;                /* output pixels per map node                */
   const void* image;            /* device [y, x]                             */
-  const float* coord_map;       /* device [2, y, x]: ABSOLUTE source (x, y)
-                                   coordinates in image pixels               */
+  const void* coord_map;        /* device [2, y, x]: ABSOLUTE source (x, y)
+                                   coordinates in image pixels, float32 (or
+                                   float64 when coord_map_f64 is set: the
+                                   reference interpolates in the map's dtype,
+                                   warp.py:125-150)                          */
   const void* weights;          /* device [32 * 32, ksize * ksize]: int16 with
                                    15 fractional bits for u8 images, float
                                    otherwise; phase = 32 * fy + fx            */
   void* out;                    /* device [y, x]                             */
   void* stream;
+  int32_t coord_map_f64;        /* 1: coord_map holds doubles                */
 } SfmWarpDesc;
 
 int sfm_warp_section(const SfmWarpDesc* desc);

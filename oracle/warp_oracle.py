@@ -56,25 +56,48 @@ def _taps(kind, x):
 
 
 def weight_table(kind, fixed):
-  """[32, 32, ks, ks] weights; int32 with unit sum 2^15 when `fixed`."""
+  """[32, 32, ks, ks] weights; int32 holding OpenCV's int16 table when `fixed`.
+
+  imgwarp.cpp, initInterTab2D: every product is saturate_cast<short>(v * 2^15);
+  when the taps of a phase do not sum to 2^15 the difference goes to the
+  largest / smallest of itab[k1 * ks + k2], k1, k2 in {ks/2, ks/2 + 1}, strict
+  compares in scan order starting from (ks/2, ks/2), result cast to short.  The
+  phases are consecutive in one static array that is filled in order, so for
+  ks = 2 the scan reads taps of the next phases (zero at that time) and a
+  correction stored there is lost when that phase is written."""
   one = [_taps(kind, i / TAB) for i in range(TAB)]
   ks = len(one[0])
-  out = np.zeros((TAB, TAB, ks, ks), np.int32 if fixed else np.float32)
+  if not fixed:
+    out = np.zeros((TAB, TAB, ks, ks), np.float32)
+    for i in range(TAB):
+      for j in range(TAB):
+        out[i, j] = np.outer(one[i], one[j]).astype(np.float32)
+    return out
+  mem = [0] * ((TAB * TAB + 4) * ks * ks)
+  half = ks // 2
   for i in range(TAB):
     for j in range(TAB):
-      w = np.outer(one[i], one[j]).astype(np.float32)
-      if not fixed:
-        out[i, j] = w
-        continue
-      iw = np.clip(np.rint(w * np.float32(SCALE)), -32768, 32767).astype(np.int32)
-      diff = int(iw.sum()) - SCALE
-      if diff:
-        lo = ks // 2 - 1
-        cen = iw[lo:lo + 2, lo:lo + 2]
-        k = np.unravel_index(np.argmax(cen) if diff < 0 else np.argmin(cen), (2, 2))
-        iw[lo + k[0], lo + k[1]] = min(iw[lo + k[0], lo + k[1]] - diff, 32767)
-      out[i, j] = iw
-  return out
+      at = (i * TAB + j) * ks * ks
+      total = 0
+      for k1 in range(ks):
+        for k2 in range(ks):
+          v = np.float32(one[i][k1] * one[j][k2]) * np.float32(SCALE)
+          q = int(min(max(np.rint(v), -32768), 32767))
+          mem[at + k1 * ks + k2] = q
+          total += q
+      if total != SCALE:
+        diff = total - SCALE
+        hi = lo = at + half * ks + half
+        for k1 in range(half, half + 2):
+          for k2 in range(half, half + 2):
+            cur = at + k1 * ks + k2
+            if mem[cur] < mem[lo]:
+              lo = cur
+            elif mem[cur] > mem[hi]:
+              hi = cur
+        dst = hi if diff < 0 else lo
+        mem[dst] = (mem[dst] - diff + 32768) % 65536 - 32768
+  return np.array(mem[:TAB * TAB * ks * ks], np.int32).reshape(TAB, TAB, ks, ks)
 
 
 def _cv_round(v):
@@ -138,20 +161,23 @@ def warp_subvolume(image, image_box, coord_map, map_box, stride, out_box,
   skipped = np.all(np.isnan(coord_map), axis=(0, 2, 3))
   my, mx = coord_map.shape[2:]
   hy, hx = np.mgrid[:my, :mx]
-  abs_map = np.array(coord_map, np.float64)
+  # warp.py:125-128 / map_utils.py:169-186: both additions are made in place,
+  # i.e. in the dtype of the map
+  abs_map = np.array(coord_map, copy=True)
+  if abs_map.dtype not in (np.float32, np.float64):
+    abs_map = abs_map.astype(np.float32)
   abs_map[0] += hx[None] * stride
   abs_map[1] += hy[None] * stride
   abs_map += (map_start[:2] * stride - img_start[:2] + offset).reshape(2, 1, 1, 1)
   map_y = (np.arange(my) + map_start[1]) * stride - out_start[1] + offset
   map_x = (np.arange(mx) + map_start[0]) * stride - out_start[0] + offset
   out_y, out_x = np.mgrid[:out_size[1], :out_size[0]]
-  warped = np.zeros((image.shape[0], image.shape[1], out_size[1], out_size[0]),
+  warped = np.zeros((image.shape[0], out_size[2], out_size[1], out_size[0]),
                     image.dtype)
   for z in range(image.shape[1]):
     if skipped[z]:
       continue
-    # the kernel receives the node coordinates as float32
-    nodes = abs_map[:, z].astype(np.float32).astype(np.float64)
+    nodes = abs_map[:, z]
     dense = [interpolate.RegularGridInterpolator(
         (map_y, map_x), nodes[c], bounds_error=False, fill_value=None)(
             (out_y, out_x)).astype(np.float32) for c in (0, 1)]

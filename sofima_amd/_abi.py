@@ -182,6 +182,7 @@ class SfmWarpDesc(C.Structure):
       ('weights', C.c_void_p),
       ('out', C.c_void_p),
       ('stream', C.c_void_p),
+      ('coord_map_f64', i32),
   ]
 
 

@@ -22,7 +22,8 @@ constexpr int kTabBits = 5, kTabSize = 1 << kTabBits;
 
 struct WarpArgs {
   const void* image;
-  const float* map;     // [2, my, mx] absolute source coordinates (x, y)
+  const void* map;      // [2, my, mx] absolute source coordinates (x, y), float or double
+  int map_f64;
   void* out;
   const void* tab;      // [32 * 32, ks * ks] short (u8 images) or float
   int dtype, nearest, ks;
@@ -44,7 +45,8 @@ __device__ __forceinline__ long long cv_round(double v) {
 // Linear interpolation (with extrapolation) of one map component at grid
 // position (gy, gx) in node units (RegularGridInterpolator, method "linear",
 // fill_value None).
-__device__ __forceinline__ double map_at(const float* m, int my, int mx, double gy,
+template <typename M>
+__device__ __forceinline__ double map_at(const M* m, int my, int mx, double gy,
                                          double gx) {
   int i = static_cast<int>(floor(gy)), j = static_cast<int>(floor(gx));
   i = i < 0 ? 0 : (i > my - 2 ? my - 2 : i);
@@ -69,8 +71,16 @@ __global__ void __launch_bounds__(kBlock) warp_kernel(WarpArgs a) {
   const int py = static_cast<int>(idx / a.ox), px = static_cast<int>(idx % a.ox);
   const double gy = (py - a.org_y) / a.stride, gx = (px - a.org_x) / a.stride;
   const long long plane = (long long)a.my * a.mx;
-  const float sx = static_cast<float>(map_at(a.map, a.my, a.mx, gy, gx));
-  const float sy = static_cast<float>(map_at(a.map + plane, a.my, a.mx, gy, gx));
+  float sx, sy;   // dense coordinates: interpolated in the map's dtype, cast to float32
+  if (a.map_f64) {
+    const double* m = static_cast<const double*>(a.map);
+    sx = static_cast<float>(map_at(m, a.my, a.mx, gy, gx));
+    sy = static_cast<float>(map_at(m + plane, a.my, a.mx, gy, gx));
+  } else {
+    const float* m = static_cast<const float*>(a.map);
+    sx = static_cast<float>(map_at(m, a.my, a.mx, gy, gx));
+    sy = static_cast<float>(map_at(m + plane, a.my, a.mx, gy, gx));
+  }
   const T* img = static_cast<const T*>(a.image);
   T* out = static_cast<T*>(a.out);
   if (a.nearest) {
@@ -128,6 +138,7 @@ extern "C" int sfm_warp_section(const SfmWarpDesc* d) {
   WarpArgs a;
   a.image = d->image;
   a.map = d->coord_map;
+  a.map_f64 = d->coord_map_f64 ? 1 : 0;
   a.out = d->out;
   a.tab = d->weights;
   a.dtype = d->dtype;

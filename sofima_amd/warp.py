@@ -63,7 +63,8 @@ def _coeffs_1d(kind: int) -> np.ndarray:
 @functools.lru_cache(maxsize=None)
 def _inter_tab(kind: int, fixed: bool) -> np.ndarray:
   """[32 * 32, ksize * ksize] 2-d weights (phase = 32 * fy + fx); int16 with 15
-  fractional bits and an exact unit sum when `fixed` (8-bit images)."""
+  fractional bits when `fixed` (8-bit images), rounding error folded into one
+  tap the way OpenCV does it."""
   c = _coeffs_1d(kind)
   ks = c.shape[1]
   tab = (c[:, None, :, None] * c[None, :, None, :]).reshape(_TAB * _TAB, ks * ks)
@@ -71,16 +72,33 @@ def _inter_tab(kind: int, fixed: bool) -> np.ndarray:
   if not fixed:
     return np.ascontiguousarray(tab)
   it = np.clip(np.rint(tab * np.float32(_COEF_SCALE)), -32768, 32767).astype(np.int32)
-  # the rounding error of every phase goes to the largest (deficit) or the
-  # smallest (excess) of the four central taps
-  lo = ks // 2 - 1
-  central = [(lo + a) * ks + lo + b for a in (0, 1) for b in (0, 1)]
-  for row in it:
-    diff = int(row.sum()) - _COEF_SCALE
+  # OpenCV's initInterTab2D, statement for statement: the rounding error of a
+  # phase goes to the largest (deficit) / smallest (excess) of the taps
+  # (k1, k2) in [ks/2, ks/2 + 2)^2, found with strict compares starting from
+  # (ks/2, ks/2), and the corrected tap is cast to short.  The tables of all
+  # phases are one array filled phase by phase, and for the 2 x 2 bilinear
+  # kernel that index range runs past the phase's own taps into the (still
+  # zero) taps of the following phases: the scan sees those zeros, and a
+  # correction written there is overwritten when that phase is filled.
+  kk = ks * ks
+  flat = np.zeros((_TAB * _TAB + 4) * kk, np.int64)
+  h = ks // 2
+  scan = [k1 * ks + k2 for k1 in (h, h + 1) for k2 in (h, h + 1)]
+  for e in range(_TAB * _TAB):
+    base = e * kk
+    flat[base:base + kk] = it[e]
+    diff = int(it[e].sum()) - _COEF_SCALE
     if diff:
-      vals = row[central]
-      k = central[int(np.argmax(vals))] if diff < 0 else central[int(np.argmin(vals))]
-      row[k] = min(row[k] - diff, 32767)   # a unit weight stays 32767 (int16)
+      big = small = base + scan[0]
+      for off in scan:
+        v = flat[base + off]
+        if v < flat[small]:
+          small = base + off
+        elif v > flat[big]:
+          big = base + off
+      k = big if diff < 0 else small
+      flat[k] = ((int(flat[k]) - diff + 32768) & 0xffff) - 32768   # (short)
+  it = flat[:_TAB * _TAB * kk].reshape(_TAB * _TAB, kk)
   return np.ascontiguousarray(it.astype(np.int16))
 
 
@@ -144,20 +162,29 @@ def warp_subvolume(image: np.ndarray, image_box, coord_map: np.ndarray, map_box,
   coord_map = np.asarray(coord_map)
   skipped = np.all(np.isnan(coord_map), axis=(0, 2, 3))
 
+  if coord_map.shape[1] < image.shape[1] or int(out_size[2]) < image.shape[1]:
+    # the reference indexes abs_map[:, z] and warped[:, z] for every z of image
+    raise ValueError(
+        f'z extents disagree: image {image.shape[1]}, coord_map {coord_map.shape[1]}, '
+        f'out_box {int(out_size[2])}')
+
   # absolute source coordinates in the local frame of `image`
-  # (map_utils.to_absolute + the box shift, warp.py:128-133), in float64 like
-  # the reference, handed to the kernel as float32 node values
+  # (map_utils.to_absolute + the box shift, warp.py:125-128): the reference
+  # adds both in place, i.e. rounds twice to the MAP's dtype, and interpolates
+  # the dense coordinates from those values -- same here, float32 or float64
   my, mx = coord_map.shape[2:]
   hy, hx = np.mgrid[:my, :mx]
   shift = map_start[:2] * stride - img_start[:2] + offset
-  abs_map = np.empty(coord_map.shape, np.float64)
-  abs_map[0] = coord_map[0] + hx * stride + shift[0]
-  abs_map[1] = coord_map[1] + hy * stride + shift[1]
-  map_t = torch.from_numpy(abs_map.astype(np.float32)).to(dev)
+  map_dtype = np.float64 if coord_map.dtype == np.float64 else np.float32
+  abs_map = coord_map.astype(map_dtype, copy=True)
+  abs_map[0] += hx * stride
+  abs_map[1] += hy * stride
+  abs_map += np.asarray(shift, np.float64).reshape(2, 1, 1)[:, None]
+  map_t = torch.from_numpy(abs_map).to(dev)
 
   img_t = torch.from_numpy(np.ascontiguousarray(image).view(
       np.int16 if image.dtype == np.uint16 else image.dtype)).to(dev)
-  out_t = torch.zeros((image.shape[0], image.shape[1], int(out_size[1]),
+  out_t = torch.zeros((image.shape[0], int(out_size[2]), int(out_size[1]),
                        int(out_size[0])), dtype=img_t.dtype, device=dev)
   d = _abi.SfmWarpDesc()
   d.dtype = dtype
@@ -175,6 +202,7 @@ def warp_subvolume(image: np.ndarray, image_box, coord_map: np.ndarray, map_box,
       float(map_start[1] * stride - out_start[1] + offset),
       float(map_start[0] * stride - out_start[0] + offset))
   d.stride = float(stride)
+  d.coord_map_f64 = 1 if map_dtype == np.float64 else 0
   d.stream = _dev.stream_ptr()
   lib = _abi.load()
   for z in range(image.shape[1]):

@@ -55,11 +55,14 @@ def test_kat_rotate(gpu):
   assert np.all(warped[~mask] < 64)
 
 
+@pytest.mark.parametrize('map_dtype', [np.float64, np.float32])
 @pytest.mark.parametrize('dtype', [np.uint8, np.uint16, np.float32])
 @pytest.mark.parametrize('interp', ['nearest', 'linear', 'cubic', None])
-def test_warp_vs_oracle(gpu, dtype, interp):
+def test_warp_vs_oracle(gpu, dtype, interp, map_dtype):
   """Smooth map with extrapolated borders, a NaN section, an output box that
-  hangs over the image: identical to the oracle (integer types exactly)."""
+  hangs over the image: identical to the oracle (integer types exactly), for
+  float32 and float64 maps (the dense coordinates are interpolated in the
+  map's dtype, warp.py:125-150)."""
   from sofima_amd import warp
   from tests.util import em_texture
   rng = np.random.default_rng(5)
@@ -71,6 +74,7 @@ def test_warp_vs_oracle(gpu, dtype, interp):
   cm[0] = 4 * np.sin(yy / 3.0) + 0.3 * xx + rng.standard_normal((3, 9, 11))
   cm[1] = 3 * np.cos(xx / 4.0) - 0.2 * yy
   cm[:, 1] = np.nan                               # skipped section
+  cm = cm.astype(map_dtype)
   boxes = dict(image_box=((5, 8, 0), (150, 120, 3)), map_box=((0, 0, 0), (11, 9, 3)),
                out_box=((-3, 2, 0), (140, 110, 3)))
   want = warp_oracle.warp_subvolume(img, boxes['image_box'], cm, boxes['map_box'], 16.0,
@@ -84,3 +88,23 @@ def test_warp_vs_oracle(gpu, dtype, interp):
   else:
     np.testing.assert_array_equal(got, want)
   assert got[:, 0].std() > 1
+
+
+def test_warp_z_extents_must_agree(gpu):
+  """The reference indexes the map and the output with every z of the image
+  (warp.py:141-176): a shorter map or output box is an error, not a silently
+  unwarped section."""
+  from sofima_amd import warp
+  img = np.zeros((1, 3, 20, 20), np.uint8)
+  cm = np.zeros((2, 2, 3, 3), np.float32)
+  with pytest.raises(ValueError):
+    warp.warp_subvolume(img, _box((0, 0, 0), (20, 20, 3)), cm, _box((0, 0, 0), (3, 3, 2)), 10.0,
+                        _box((0, 0, 0), (20, 20, 3)))
+  cm = np.zeros((2, 3, 3, 3), np.float32)
+  with pytest.raises(ValueError):
+    warp.warp_subvolume(img, _box((0, 0, 0), (20, 20, 3)), cm, _box((0, 0, 0), (3, 3, 3)), 10.0,
+                        _box((0, 0, 0), (20, 20, 2)))
+  # an output box with more sections than the image: the extra ones stay zero
+  out = warp.warp_subvolume(img + 7, _box((0, 0, 0), (20, 20, 3)), cm, _box((0, 0, 0), (3, 3, 3)),
+                            10.0, _box((0, 0, 0), (20, 20, 4)))
+  assert out.shape == (1, 4, 20, 20) and not out[:, 3].any() and out[:, :3].any()
