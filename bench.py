@@ -29,6 +29,7 @@ of the reference algorithm) on a bounded sample of the same workload.
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -306,6 +307,17 @@ def main():
     # `frac_pruned`: algorithmic operations over its time, an algorithmic gain.
     roof['pruned'] = timed
     roof['frac_pruned'] = timed['frac']
+    # the reference's FFT formulation needs ~3 transforms x 2.5 N log2 N
+    # flop per patch (N = 320^2): ~100x less arithmetic than the direct sum.  The
+    # same patch rate priced at that count, so the direct form is not flattered
+    # (the FFT form itself is timed in aux_rooflines.xcorr_fft_2d).
+    n_fft = float((2 * PATCH) ** 2)
+    fft_flop = 3 * 2.5 * n_fft * math.log2(n_fft)
+    roof['fft_equivalent'] = {
+        'flop_per_patch': round(fft_flop),
+        'tflops_at_this_patch_rate': round(
+            fft_flop * world * n_patches * args.steps / t_flow / 1e12, 3),
+        'direct_over_fft_flop': round(flop_per_patch / fft_flop, 1)}
     legs = uses_mfma and not args.no_legs and world == 1
     if legs:
       n_leg = max(args.steps, 3)

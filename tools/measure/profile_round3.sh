@@ -14,6 +14,9 @@ cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-legs --sustain 0"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o r3 -- $B --steps 3 --warmup 1 > $O/trace.log 2>&1
 python $R/tools/rocpd_summary.py $(find $O/trace -name '*.db' | head -1) > $O/trace_summary.md 2>&1
+# the same with the roofline legs on (un-pruned pair, other pair, aux_rooflines: FFT form, volumetric / large meshes)
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_aux -o r3 -- python $R/bench.py --no-cpu-baseline --sustain 0 --steps 1 --warmup 1 > $O/trace_aux.log 2>&1
+python $R/tools/rocpd_summary.py $(find $O/trace_aux -name '*.db' | head -1) > $O/trace_aux_summary.md 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- $B --steps 1 --warmup 1 > $O/pmc_f.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o w -- $B --steps 1 --warmup 1 > $O/pmc_w.log 2>&1
 python $R/tools/pmc_summary.py $(find $O/pmc_f -name '*counter_collection.csv' | head -1) $(find $O/pmc_w -name '*counter_collection.csv' | head -1) $O/pmc_traffic.json $SHA 40401 > $O/pmc_summary.log 2>&1
@@ -49,5 +52,8 @@ python $R/tools/measure/mesh_big.py > $O/mesh_big.log 2>&1
 python $R/tools/measure/masked_time.py > $O/masked_time.log 2>&1
 python $R/tools/measure/configs_time.py > $O/configs_time.log 2>&1
 python $R/tools/measure/banded_c_loop.py > $O/banded.log 2>&1
+python $R/tools/measure/patch_size_rates.py 2>&1 | grep -v amdgpu > $O/patch_size_rates.log
+python $R/tools/measure/montage3d_time.py 2>&1 | grep volumetric > $O/montage3d_time.log
+DRIFT=0 python $R/tools/measure/montage3d_time.py 2>&1 | grep volumetric >> $O/montage3d_time.log
 rm -rf $O/trace/*/*.db.tmp; find $O -name '*.db' -size +20M -delete; find $O -name '*.csv' -size +5M -delete
 cat $O/pytest.log $O/bench.json; tail -3 $O/bench.err
