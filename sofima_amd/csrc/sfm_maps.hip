@@ -97,8 +97,11 @@ target_list_kernel(SfmTargetMeshDesc d, int* __restrict__ list, int* __restrict_
   if (any) list[atomicAdd(count, 1)] = tile * (n_bx * n_by) + blk;
 }
 
-template <bool ADV>
+// MODE: sfm_target::Plane::at (0 stored positions, 1 advanced, 2 advanced with
+// per-column drift means pending)
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
+  constexpr bool ADV = MODE != 0;
   const SfmTargetMeshDesc& d = a.d;
   const int nc = d.ncomp;
   const int mz = d.mesh_shape[0], my = d.mesh_shape[1], mx = d.mesh_shape[2];
@@ -121,13 +124,12 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
   // pending gate / drift of the previous step folded into neutral values
   float a_dt = 0.f, a_c2 = 0.f, a_gate = 1.f, a_mx[3] = {0.f, 0.f, 0.f},
         a_mv[3] = {0.f, 0.f, 0.f};
-  bool cols = false;   // per-column drift means pending instead of the global ones
+  constexpr bool cols = MODE == 2;   // per-column drift means pending instead of the global ones
   if (ADV) {
     a_dt = a.adv.fire ? a.adv.scal->dt : a.adv.vv_dt;
     a_c2 = 0.5f * (a_dt * a_dt);
     if (a.adv.fire && a.adv.pending) {
       a_gate = a.adv.scal->gate;
-      cols = a.adv.colmean != nullptr;
       if (a.adv.remove_drift && !cols)
         for (int c = 0; c < 3; ++c) {
           a_mx[c] = a.adv.scal->mx[c];
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(kBlock) target_mesh_kernel(TargetArgs a) {
     const int ty = row - tz * my;
     const int node = row * mx + tx;
     float rx, ry, rz;
-    const bool in_region = target_node<ADV>(d, s_e, tz, ty, tx, plane_of, &rx, &ry, &rz);
+    const bool in_region = target_node<MODE>(d, s_e, tz, ty, tx, plane_of, &rx, &ry, &rz);
     if (a.strips_only && !in_region) return;   // NaN since the first full evaluation
     // out holds the evaluated tiles only: [ncomp, n_eval, *mesh]
     const long long n_out = d.n_eval > 0 ? d.n_eval : d.n_tiles;
@@ -240,10 +242,12 @@ int launch_target_mesh(const SfmTargetMeshDesc* d, const float* x, float* out,
     if (d->n_eval > 0) return fail(SFM_ERR_INVALID, "target mesh: block list with n_eval");
     grid = dim3(static_cast<unsigned>(gx * d->n_tiles), 1);   // upper bound; extra blocks exit
   }
-  if (a.adv.v)
-    hipLaunchKernelGGL(target_mesh_kernel<true>, grid, dim3(kBlock), 0, st, a);
+  if (a.adv.v && a.adv.colmean && a.adv.fire && a.adv.pending)
+    hipLaunchKernelGGL(target_mesh_kernel<2>, grid, dim3(kBlock), 0, st, a);
+  else if (a.adv.v)
+    hipLaunchKernelGGL(target_mesh_kernel<1>, grid, dim3(kBlock), 0, st, a);
   else
-    hipLaunchKernelGGL(target_mesh_kernel<false>, grid, dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(target_mesh_kernel<0>, grid, dim3(kBlock), 0, st, a);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }

@@ -40,13 +40,15 @@ struct Plane {
   // of x / v of this component, or nullptr
   const float* cs_x;
   const float* cs_v;
-  // Branch free unless column means are pending (a load under a condition would
-  // be waited for on its own): v * 1, x - 0 and v - 0 are exact, so one
-  // expression serves every other case.
-  template <bool ADV>
+  // MODE 0: stored values; 1: advanced positions; 2: advanced, per-column drift
+  // means pending.  A compile-time choice: a load under a run-time condition is
+  // waited for on its own (the in-plane montage step lost 11 us to one such
+  // branch).  Within a mode the expression is branch free: v * 1, x - 0 and
+  // v - 0 are exact, so one form serves "nothing pending" too.
+  template <int MODE>
   __device__ __forceinline__ float at(long long i, int xi) const {
-    if (!ADV) return x[i];
-    if (cs_x) {   // advance_kernel with drift_cols, operation for operation
+    if (MODE == 0) return x[i];
+    if (MODE == 2) {   // advance_kernel with drift_cols, operation for operation
       const float vv = v[i] * gate;
       const float xv = x[i] - cs_x[xi];
       const float vw = vv - cs_v[xi] * gate;
@@ -64,7 +66,7 @@ __device__ __forceinline__ Plane plain(const float* m) {
 
 // Bilinear sample of plane `m` [ny, nx] + ref (ref = offset + index * step
 // along `ref_axis`) at (qy, qx).
-template <bool ADV = false>
+template <int MODE = 0>
 __device__ inline float sample2(const Plane& m, int ny, int nx, float qy,
                          float qx, bool constant, int ref_axis, float ref_off,
                          float ref_step) {
@@ -81,7 +83,7 @@ __device__ inline float sample2(const Plane& m, int ny, int nx, float qy,
       bool valid = iy >= 0 && iy < ny && ix >= 0 && ix < nx;
       iy = min(max(iy, 0), ny - 1);
       ix = min(max(ix, 0), nx - 1);
-      float v = m.template at<ADV>((long long)iy * nx + ix, ix) +
+      float v = m.template at<MODE>((long long)iy * nx + ix, ix) +
                 (ref_off + static_cast<float>(ref_axis == 0 ? iy : ix)) * ref_step;
       if (constant && !valid) v = NAN;
       const float t = w * v;
@@ -91,7 +93,7 @@ __device__ inline float sample2(const Plane& m, int ny, int nx, float qy,
   return sum;
 }
 
-template <bool ADV = false>
+template <int MODE = 0>
 __device__ inline float sample3(const Plane& m, int nz, int ny, int nx,
                          float qz, float qy, float qx, bool constant, int ref_axis,
                          float ref_off, float ref_step) {
@@ -113,7 +115,7 @@ __device__ inline float sample3(const Plane& m, int nz, int ny, int nx,
         iy = min(max(iy, 0), ny - 1);
         ix = min(max(ix, 0), nx - 1);
         const int ri = ref_axis == 0 ? iz : (ref_axis == 1 ? iy : ix);
-        float v = m.template at<ADV>(((long long)iz * ny + iy) * nx + ix, ix) +
+        float v = m.template at<MODE>(((long long)iz * ny + iy) * nx + ix, ix) +
                   (ref_off + static_cast<float>(ri)) * ref_step;
         if (constant && !valid) v = NAN;
         const float t = w * v;
@@ -196,7 +198,7 @@ __device__ inline NbEntry make_entry(const SfmTargetMeshDesc& d, int tile, int j
 // uniform: a workgroup works on ONE tile): the four neighbour updates pasted in
 // order, the last non-NaN one wins per component.  Returns whether the node lies
 // in any paste region; *r stay NaN outside.
-template <bool ADV, int UNROLL_J = 4, typename PlaneOf>
+template <int MODE, int UNROLL_J = 4, typename PlaneOf>
 __device__ __forceinline__ bool target_node(const SfmTargetMeshDesc& d, const NbEntry* s_e, int tz,
                                             int ty, int tx, PlaneOf plane_of, float* rx_out,
                                             float* ry_out, float* rz_out) {
@@ -236,17 +238,17 @@ __device__ __forceinline__ bool target_node(const SfmTargetMeshDesc& d, const Nb
     const Plane nx1 = plane_of(1, nb_i);
     float ux_v, uy_v, uz_v = NAN;
     if (nc == 2) {
-      ux_v = sample2<ADV>(nx0, my, mx, qy, qx, true, 1, 0.f, sx) - ref1x;
-      uy_v = sample2<ADV>(nx1, my, mx, qy, qx, true, 0, 0.f, sy) - ref1y;
+      ux_v = sample2<MODE>(nx0, my, mx, qy, qx, true, 1, 0.f, sx) - ref1x;
+      uy_v = sample2<MODE>(nx1, my, mx, qy, qx, true, 0, 0.f, sy) - ref1y;
     } else {
       const float m1z = fm * farr[2LL * n_f * fvol + fo];
       const float ref1z =
           (static_cast<float>(uz) + static_cast<float>(uniform(s_e[j].st[0]))) * sz;
       const float qz = (ref1z + m1z) / sz;
       const Plane nx2 = plane_of(2, nb_i);
-      ux_v = sample3<ADV>(nx0, mz, my, mx, qz, qy, qx, true, 2, 0.f, sx) - ref1x;
-      uy_v = sample3<ADV>(nx1, mz, my, mx, qz, qy, qx, true, 1, 0.f, sy) - ref1y;
-      uz_v = sample3<ADV>(nx2, mz, my, mx, qz, qy, qx, true, 0, 0.f, sz) - ref1z;
+      ux_v = sample3<MODE>(nx0, mz, my, mx, qz, qy, qx, true, 2, 0.f, sx) - ref1x;
+      uy_v = sample3<MODE>(nx1, mz, my, mx, qz, qy, qx, true, 1, 0.f, sy) - ref1y;
+      uz_v = sample3<MODE>(nx2, mz, my, mx, qz, qy, qx, true, 0, 0.f, sz) - ref1z;
       uz_v = uz_v + static_cast<float>(uniform(s_e[j].fine[2]));
     }
     ux_v = ux_v + static_cast<float>(uniform(s_e[j].fine[0]));

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3; mkdir -p $O
 cd $R
 SHA=$(python -c "from sofima_amd import _build; print(_build.source_hash())")
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/pytest.log
+timeout 2400 python -m pytest tests -m gpu -q -rf --tb=line 2>&1 | grep -E "^FAILED|passed|failed|error" | tail -12 > $O/pytest.log
 timeout 900 python bench.py --steps 20 --warmup 2 > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --steps 5 --warmup 1 --pair exact --no-cpu-baseline > $O/bench_exact.json 2> /dev/null
 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-legs --sustain 1 --mesh-sharded 2 > $O/bench_sharded2.json 2> /dev/null
