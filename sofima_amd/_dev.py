@@ -90,9 +90,32 @@ def as_device_image(img, dev):
         _abi.DTYPE_U8 if t.dtype == torch.uint8 else _abi.DTYPE_F32)
   arr = np.asarray(img)
   if arr.dtype == np.uint8:
-    return torch.from_numpy(np.ascontiguousarray(arr)).to(dev), _abi.DTYPE_U8
+    return upload(np.ascontiguousarray(arr), dev), _abi.DTYPE_U8
   arr = np.ascontiguousarray(arr, dtype=np.float32)
-  return torch.from_numpy(arr).to(dev), _abi.DTYPE_F32
+  return upload(arr, dev), _abi.DTYPE_F32
+
+
+_upload_streams = {}
+
+
+def upload(arr: np.ndarray, dev) -> torch.Tensor:
+  """Host array -> device tensor on a side stream.  A copy from pageable memory
+  makes the host wait for the stream it is enqueued on; on the compute stream
+  that is everything launched so far, and a loop of flow_field() calls on NumPy
+  strips (stitch_elastic.compute_flow_map) could never run ahead of the GPU.
+  On its own stream the host waits for the copy alone."""
+  dev = torch.device(dev)
+  if dev.type != 'cuda':
+    return torch.from_numpy(arr).to(dev)
+  key = (dev.index if dev.index is not None else torch.cuda.current_device())
+  side = _upload_streams.get(key)
+  if side is None:
+    side = _upload_streams[key] = torch.cuda.Stream(device=dev)
+  cur = torch.cuda.current_stream(dev)
+  with torch.cuda.stream(side):
+    t = torch.from_numpy(arr).to(dev)      # returns when the copy has finished
+  t.record_stream(cur)                     # allocated on `side`, used on `cur`
+  return t
 
 
 def as_device_mask(mask, dev):

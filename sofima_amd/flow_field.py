@@ -192,6 +192,7 @@ def _side_stream(dev) -> torch.cuda.Stream:
 
 
 WORKSPACE_FRACTION = 0.6  # of the HBM that is free when a call is planned
+SMALL_WORKSPACE = 1 << 30  # calls below this are not checked against the budget
 
 
 def _workspace_budget(dev) -> int:
@@ -224,13 +225,19 @@ def _run_batches_dev(res: _Resident, desc: _abi.SfmXcorrDesc, starts: torch.Tens
   # surface area (26 GB for a whole 8192^2 pair of 160^2 patches), so the call
   # size is halved until every lane's workspace fits a fraction of the memory
   # that is free right now (other ranks / threads / jobs may share the GPU).
-  budget = _workspace_budget(res.dev)
+  budget = None
   while True:
     desc.batch = per_call * batch_size
     need = lib.sfm_xcorr_workspace_bytes(C.byref(desc))
     if need == 0:
       _abi.check(-1)
-    if per_call == 1 or need * n_lanes <= budget:
+    # (the allocator statistics behind the budget cost 0.2 ms: asked for only
+    # when a call wants more than SMALL_WORKSPACE)
+    if per_call == 1 or need * n_lanes <= SMALL_WORKSPACE:
+      break
+    if budget is None:
+      budget = _workspace_budget(res.dev)
+    if need * n_lanes <= budget:
       break
     per_call = max(1, per_call // 2)
   row_bytes = batch_size * nd * 4

@@ -1046,9 +1046,10 @@ def test_workspace_budget_only_changes_the_call_size(gpu):
   want = calc.flow_field(pre, post, 48, 12, batch_size=32)
   calls = []
   orig = ff._abi.load().sfm_xcorr_peaks
-  frac = ff.WORKSPACE_FRACTION
+  frac, small = ff.WORKSPACE_FRACTION, ff.SMALL_WORKSPACE
   try:
     ff.WORKSPACE_FRACTION = 1e-12          # nothing fits: one batch per call
+    ff.SMALL_WORKSPACE = 0                 # (small calls are not exempt here)
     lib = ff._abi.load()
 
     class Spy:
@@ -1067,7 +1068,7 @@ def test_workspace_budget_only_changes_the_call_size(gpu):
     finally:
       ff._abi.load = load
   finally:
-    ff.WORKSPACE_FRACTION = frac
+    ff.WORKSPACE_FRACTION, ff.SMALL_WORKSPACE = frac, small
   assert len(calls) > 1 and set(calls) == {32}
   np.testing.assert_array_equal(got, want)
 
