@@ -46,8 +46,11 @@ constexpr int kMaxBlocks = 1024;
 #ifndef SFM_LB3
 #define SFM_LB3 3
 #endif
+// integrate_shared2d_kernel outside band mode: four workgroups per CU (128
+// VGPRs; 130 without the bound).  Measured: 1-3 % over three once the SGPR
+// spills were gone; with them (and 20 bytes of scratch) it had been 7 % slower.
 #ifndef SFM_LB_SHARED
-#define SFM_LB_SHARED 1
+#define SFM_LB_SHARED 4
 #endif
 #ifndef SFM_LBT
 #define SFM_LBT 1
@@ -319,9 +322,34 @@ __device__ __forceinline__ void node_force_default3d(const float* __restrict__ x
                                                      const float* self, float* out) {
   float acc[3] = {0.f, 0.f, 0.f};
   const long long sy = p.X, sz = (long long)p.X * p.Y;
+  // The 13 default links have rest = dir * stride (exactly: dir is -1, 0 or 1) and
+  // fall into seven classes by which axes they span -- x, y, z, xy, xz, yz, xyz --
+  // with one rest length and one spring constant per class.  Reading rest[13][3]
+  // and neg_k[13] as 52 separate wave-uniform values had the 3-D kernels spill
+  // 196-239 SGPRs (one v_readlane in eight VALU instructions of integrate_kernel<3>);
+  // three strides and seven constants are the same numbers (spills 233 -> 119,
+  // [3,4,100^3] 334 -> 309 us per step).  A further instantiation without the
+  // other force kinds got the spills to 75 but 108 bytes of scratch: 390 us.
+  const float st[3] = {p.rest[0][0], p.rest[1][1], p.rest[2][2]};
+  auto rest_of = [&](int d, int c) { return d == 0 ? 0.f : (d > 0 ? st[c] : -st[c]); };
+  auto len_of = [&](int dx, int dy, int dz) {
+    const float r[3] = {rest_of(dx, 0), rest_of(dy, 1), rest_of(dz, 2)};
+    return vec_len(r, 3);
+  };
+  // representative link of a class: the first one with that |dir| pattern
+  const float l0c[7] = {len_of(1, 0, 0), len_of(0, 1, 0), len_of(0, 0, 1), len_of(1, 1, 0),
+                        len_of(1, 0, 1), len_of(0, 1, 1), len_of(1, 1, 1)};
+  const float nkc[7] = {p.neg_k[0], p.neg_k[1], p.neg_k[2], p.neg_k[3],
+                        p.neg_k[5], p.neg_k[7], p.neg_k[9]};
+#define SFM_CLASS(DX, DY, DZ)                                                         \
+  ((DX) != 0 && (DY) != 0 && (DZ) != 0 ? 6                                           \
+   : (DY) != 0 && (DZ) != 0 ? 5 : (DX) != 0 && (DZ) != 0 ? 4 : (DX) != 0 && (DY) != 0 ? 3 \
+   : (DZ) != 0 ? 2 : (DY) != 0 ? 1 : 0)
 #define SFM_LINK(L, DX, DY, DZ)                                                      \
   {                                                                                  \
-    const float l0 = vec_len(p.rest[L], 3);                                          \
+    constexpr int kc = SFM_CLASS(DX, DY, DZ);                                        \
+    const float l0 = l0c[kc];                                                        \
+    const float rest[3] = {rest_of(DX, 0), rest_of(DY, 1), rest_of(DZ, 2)};          \
     const bool okf = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&          \
                      yi - (DY) < p.Y && zi - (DZ) >= 0 && zi - (DZ) < p.Z;            \
     const bool okn = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&          \
@@ -330,11 +358,11 @@ __device__ __forceinline__ void node_force_default3d(const float* __restrict__ x
     const long long mf = okf ? n - off : n, mn = okn ? n + off : n;                  \
     float df[3], dn[3], ff[3], fn[3];                                                \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                  \
-      df[c] = self[c] - x[c * p.N + mf] + p.rest[L][c];                              \
-      dn[c] = x[c * p.N + mn] - self[c] + p.rest[L][c];                              \
+      df[c] = self[c] - x[c * p.N + mf] + rest[c];                                   \
+      dn[c] = x[c * p.N + mn] - self[c] + rest[c];                                   \
     }                                                                                \
-    spring_xyz<DX, DY, DZ>(df, l0, p.neg_k[L], p.prefer, ff);                        \
-    spring_xyz<DX, DY, DZ>(dn, l0, p.neg_k[L], p.prefer, fn);                        \
+    spring_xyz<DX, DY, DZ>(df, l0, nkc[kc], p.prefer, ff);                           \
+    spring_xyz<DX, DY, DZ>(dn, l0, nkc[kc], p.prefer, fn);                           \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                  \
       acc[c] = acc[c] + (okf ? ff[c] : 0.f);                                         \
       acc[c] = acc[c] - (okn ? fn[c] : 0.f);                                         \
@@ -345,6 +373,7 @@ __device__ __forceinline__ void node_force_default3d(const float* __restrict__ x
   SFM_LINK(8, 0, -1, 1) SFM_LINK(9, 1, 1, 1) SFM_LINK(10, 1, 1, -1) SFM_LINK(11, 1, -1, 1)
   SFM_LINK(12, -1, 1, 1)
 #undef SFM_LINK
+#undef SFM_CLASS
   out[0] = acc[0];
   out[1] = acc[1];
   out[2] = acc[2];
@@ -1098,8 +1127,12 @@ __global__ void band_scalars_kernel(const Scalars* __restrict__ scal_in,
   *scal_out = o;
 }
 
-template <bool FUSED>
-__global__ void __launch_bounds__(kBlock, SFM_LB_SHARED)
+// BAND: band mode (sfm_mesh_relax_banded).  Its own instantiation: the band
+// tables, neighbour-row pointers and strides are wave-uniform values that stay
+// live through the whole kernel, and the plain kernel was spilling 111 SGPRs
+// (475 v_readlane / v_writelane in a VALU-bound kernel) with them.
+template <bool FUSED, bool BAND = false>
+__global__ void __launch_bounds__(kBlock, (FUSED && !BAND) ? SFM_LB_SHARED : 1)
 integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_in,
                           const float* prev, float* x_out, float* v_out,
                           float* a_out, MeshParams p,
@@ -1107,6 +1140,15 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
                           Scalars* scal_out, float fixed_cap,
                           u64* partials, int* ticket,
                           int pending, int nty, int ntx, BandArgs bd) {
+  if (!BAND) {   // constants: everything that depends on them folds away
+    bd.sums = nullptr;
+    bd.my_sums = nullptr;
+    bd.n_bands = 0;
+    bd.total_tiles = 0;
+    bd.ty_mode = 0;
+    bd.multi = nullptr;
+    bd.n_multi = 0;
+  }
   constexpr int C = 2;
   constexpr int TW = 64;         // columns -1 .. kSX of the tile
   constexpr int kRows = 4;       // rows per thread
@@ -1122,8 +1164,7 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
     const int xcd = block & 7, idx = block >> 3;
     block = xcd * per + min(xcd, rem) + idx;
   }
-  float* nb_dst[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  long long nb_n[2] = {0, 0}, nb_plane[2] = {0, 0}, nb_off[2] = {0, 0};
+  const BandDev* band = nullptr;   // multi-band launch: this workgroup's band
   if (bd.multi) {
     int bi = 0;
     while (bi + 1 < bd.n_multi && block >= bd.multi[bi + 1].base[bd.ty_mode]) ++bi;
@@ -1149,14 +1190,8 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
     p.Y = bb.Y;
     p.own_y0 = bb.own_y0;
     p.own_y1 = bb.own_y1;
-#pragma unroll
-    for (int sd = 0; sd < 2; ++sd) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) nb_dst[sd][k] = bb.nb[sd][k];
-      nb_n[sd] = bb.nb_n[sd];
-      nb_plane[sd] = bb.nb_plane[sd];
-      nb_off[sd] = bb.nb_off[sd];
-    }
+    band = &bb;   // (the neighbour-row fields are read where they are used: held
+                  // in registers through the kernel they cost 24 more SGPRs)
   }
   const unsigned epoch = static_cast<unsigned>(ticket[1]) + 1u;
 
@@ -1362,13 +1397,18 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
     if (bd.multi) {
 #pragma unroll
       for (int sd = 0; sd < 2; ++sd) {
-        if (nb_dst[sd][0] && gy == (sd == 0 ? p.own_y0 : p.own_y1 - 1)) {
+        if (gy == (sd == 0 ? p.own_y0 : p.own_y1 - 1) && band->nb[sd][0]) {
+          float* const dx = band->nb[sd][0];
+          float* const dv = band->nb[sd][1];
+          float* const da = band->nb[sd][2];
+          const long long nn = band->nb_n[sd];
+          const long long m0 = plane * band->nb_plane[sd] + band->nb_off[sd] + gx;
 #pragma unroll
           for (int c = 0; c < C; ++c) {
-            const long long m = c * nb_n[sd] + plane * nb_plane[sd] + nb_off[sd] + gx;
-            nb_dst[sd][0][m] = x_own[k][c];
-            nb_dst[sd][1][m] = vn[c];
-            nb_dst[sd][2][m] = f[c];
+            const long long m = c * nn + m0;
+            dx[m] = x_own[k][c];
+            dv[m] = vn[c];
+            da[m] = f[c];
           }
         }
       }
@@ -4340,7 +4380,7 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
       auto launch = [&](int mode, int grid) {
         if (grid <= 0) return;
         BandArgs ba{sums_of(k - 1), nullptr, total, 0, mode, 0, 0, band_dev[in], nl};
-        hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(grid), dim3(kBlock), 0, st,
+        hipLaunchKernelGGL((integrate_shared2d_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st,
                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bs[0].p,
                            nullptr, nullptr, cap0, nullptr, nullptr, pending ? 3 : 0, 0,
                            bs[0].tiles.ntx, ba);
