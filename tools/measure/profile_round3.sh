@@ -52,6 +52,8 @@ python $R/tools/measure/mesh_big.py > $O/mesh_big.log 2>&1
 python $R/tools/measure/masked_time.py > $O/masked_time.log 2>&1
 python $R/tools/measure/configs_time.py > $O/configs_time.log 2>&1
 python $R/tools/measure/banded_c_loop.py > $O/banded.log 2>&1
+bash $R/tools/measure/pmc_mesh2d.sh > $O/pmc_mesh2d.txt 2>&1
+python $R/tools/measure/mesh2d_xcd.py 2>&1 | grep -v amdgpu > $O/mesh2d_xcd.log
 python $R/tools/measure/patch_size_rates.py 2>&1 | grep -v amdgpu > $O/patch_size_rates.log
 python $R/tools/measure/montage3d_time.py 2>&1 | grep volumetric > $O/montage3d_time.log
 DRIFT=0 python $R/tools/measure/montage3d_time.py 2>&1 | grep volumetric >> $O/montage3d_time.log
