@@ -81,8 +81,8 @@ int sfm_device_count(int* count);
  *   SFM_MESH_TILE=16|32   tile edge of the persistent integrator
  *   SFM_MESH_GRAPH=1 / SFM_MESH_MARCH=1 / SFM_MESH_BRICKS=1   measured-slower
  *                         experiments (hipGraph replay, z-marching, bricks)
- *   SFM_MESH_XCD=1        tiled in-plane step: one contiguous run of tiles per
- *                         XCD (measured: no gain)                             */
+ *   SFM_MESH_XCD=0|1      tiled in-plane step: one contiguous run of tiles per
+ *                         XCD never / always (default: from 2048 tiles on)   */
 int sfm_set_option(const char* name, const char* value);
 int sfm_get_option(const char* name, char* value, size_t capacity);
 

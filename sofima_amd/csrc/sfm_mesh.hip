@@ -3589,8 +3589,14 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   if (fuse_target && w.target_list)
     if (int rc = sfm::build_target_list(d->target, w.target_list, st)) return rc;
   const int tgrid = static_cast<int>(tiles.tiles);
+  // XCD-contiguous tile order: on once there are several rounds of workgroups
+  // (measured after the SGPR spills were gone: [2,4,2048^2] 270 -> 261 us,
+  // [2,64,204^2] 62.2 -> 58.6; [2,1,1000^2], one round of 1071 tiles: 31.1 -> 31.5).
+  // SFM_MESH_XCD=0 / 1: off / on for any grid of at least 64 tiles.
   const char* xcd_opt = sfm::option("SFM_MESH_XCD");
-  const int xcd_map = (xcd_opt && xcd_opt[0] == '1' && tgrid >= 64) ? 1 : 0;
+  const int xcd_map = xcd_opt && xcd_opt[0] == '0'   ? 0
+                      : xcd_opt && xcd_opt[0] == '1' ? (tgrid >= 64 ? 1 : 0)
+                                                     : (tgrid >= 2048 ? 1 : 0);
   if (tiled) {
     // LDS-tiled integrator (2-D): one launch per step, or advance + prev_fn +
     // integrate when the spring targets depend on the advanced positions.

@@ -653,3 +653,27 @@ def test_shared_spring_step_is_bit_identical(gpu, shape):
       np.testing.assert_array_equal(np.array(u), np.array(w))
       np.testing.assert_array_equal(np.array(u), np.array(m))
     assert a[3:] == b[3:] == c[3:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('drift', [False, True])
+def test_xcd_tile_order_is_bit_identical(gpu, drift):
+  """SFM_MESH_XCD (every XCD takes one contiguous run of tiles of the fused
+  in-plane step; default from 2048 tiles on) only changes which workgroup owns
+  which tile: the per-tile partial sums are reduced in tile order either way."""
+  from sofima_amd import _abi, mesh
+  rng = np.random.default_rng(41)
+  shape = (2, 3, 150, 333)     # 3 x 10 x 6 = 180 tiles, ragged right / bottom edges
+  prev = (rng.standard_normal(shape) * 2).astype(np.float32)
+  x0 = np.zeros(shape, np.float32)
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(20., 20.),
+                               num_iters=60, max_iters=120, stop_v_max=1e-9, dt_max=1000,
+                               start_cap=0.01, final_cap=10, prefer_orig_order=True,
+                               remove_drift=drift)
+  out = []
+  for opt in (0, 1):
+    with _abi.option('SFM_MESH_XCD', opt):
+      x, e, t = mesh.relax_mesh(x0, prev, cfg)
+    out.append((np.array(x), list(e), t))
+  np.testing.assert_array_equal(out[0][0], out[1][0])
+  assert out[0][1] == out[1][1] and out[0][2] == out[1][2]

@@ -14,7 +14,7 @@ for shape in shapes:
                                max_iters=iters, stop_v_max=1e-9, dt_max=1000, start_cap=0.1, final_cap=10)
   nodes = int(np.prod(shape[1:]))
   ref = None
-  for opt in (0, 1, 0, 1):
+  for opt in (0, 1, 0, 1):   # explicit off / on (the default switches at 2048 tiles)
     with _abi.option('SFM_MESH_XCD', opt):
       r = mesh.relax_mesh(x0, prev, cfg); torch.cuda.synchronize()
       t = time.perf_counter(); r = mesh.relax_mesh(x0, prev, cfg); torch.cuda.synchronize()
