@@ -1132,7 +1132,7 @@ __global__ void band_scalars_kernel(const Scalars* __restrict__ scal_in,
 // live through the whole kernel, and the plain kernel was spilling 111 SGPRs
 // (475 v_readlane / v_writelane in a VALU-bound kernel) with them.
 template <bool FUSED, bool BAND = false>
-__global__ void __launch_bounds__(kBlock, (FUSED && !BAND) ? SFM_LB_SHARED : 1)
+__global__ void __launch_bounds__(kBlock, FUSED ? SFM_LB_SHARED : 1)
 integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_in,
                           const float* prev, float* x_out, float* v_out,
                           float* a_out, MeshParams p,
@@ -4385,7 +4385,11 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
       // the band edges land in the neighbours' halo rows / the send buffers
       auto launch = [&](int mode, int grid) {
         if (grid <= 0) return;
-        BandArgs ba{sums_of(k - 1), nullptr, total, 0, mode, 0, 0, band_dev[in], nl};
+        // (XCD-contiguous tile order like the un-split step: the band of a block is
+        // looked up after the remap, so a run may span bands)
+        const char* xo = sfm::option("SFM_MESH_XCD");
+        const int xcd = xo && xo[0] == '0' ? 0 : (xo && xo[0] == '1' ? grid >= 64 : grid >= 2048);
+        BandArgs ba{sums_of(k - 1), nullptr, total, 0, mode, 0, 0, band_dev[in], nl, xcd};
         hipLaunchKernelGGL((integrate_shared2d_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st,
                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bs[0].p,
                            nullptr, nullptr, cap0, nullptr, nullptr, pending ? 3 : 0, 0,
