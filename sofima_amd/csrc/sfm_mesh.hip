@@ -309,6 +309,43 @@ __device__ __forceinline__ void spring_xyz(const float* d, float l0, float neg_k
   }
 }
 
+// The 13 default links of a volumetric mesh have rest = dir * stride (exactly: dir
+// is -1, 0 or 1) and fall into seven classes by the axes they span -- x, y, z, xy,
+// xz, yz, xyz -- with one rest length and one spring constant per class.  Reading
+// rest[13][3] and neg_k[13] as 52 separate wave-uniform values had the 3-D kernels
+// spill 75-239 SGPRs (one v_readlane in eight VALU instructions of
+// integrate_kernel<3>); three strides and seven constants are the same numbers.
+#define SFM_CLASS3(DX, DY, DZ)                                                        \
+  ((DX) != 0 && (DY) != 0 && (DZ) != 0 ? 6                                           \
+   : (DY) != 0 && (DZ) != 0 ? 5 : (DX) != 0 && (DZ) != 0 ? 4 : (DX) != 0 && (DY) != 0 ? 3 \
+   : (DZ) != 0 ? 2 : (DY) != 0 ? 1 : 0)
+struct DefLinks3 {
+  float st[3];    // +stride per axis = the rest vectors of links 0, 1, 2
+  float l0c[7];   // rest length per class (same device function as the live lengths)
+  float nkc[7];   // -k_eff per class (representative links 0, 1, 2, 3, 5, 7, 9)
+  __device__ __forceinline__ explicit DefLinks3(const MeshParams& p) {
+    st[0] = p.rest[0][0];
+    st[1] = p.rest[1][1];
+    st[2] = p.rest[2][2];
+    const int cls[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const float r[3] = {rest(cls[k][0], 0), rest(cls[k][1], 1), rest(cls[k][2], 2)};
+      l0c[k] = vec_len(r, 3);
+    }
+    nkc[0] = p.neg_k[0];
+    nkc[1] = p.neg_k[1];
+    nkc[2] = p.neg_k[2];
+    nkc[3] = p.neg_k[3];
+    nkc[4] = p.neg_k[5];
+    nkc[5] = p.neg_k[7];
+    nkc[6] = p.neg_k[9];
+  }
+  __device__ __forceinline__ float rest(int d, int c) const {
+    return d == 0 ? 0.f : (d > 0 ? st[c] : -st[c]);
+  }
+};
+
 // elastic_mesh_3d with the 13 default links (MESH_LINK_DIRECTIONS), unrolled
 // with compile-time directions and branch free: a spring whose other end lies
 // outside the mesh is evaluated against the node itself, which gives d = rest,
@@ -322,34 +359,15 @@ __device__ __forceinline__ void node_force_default3d(const float* __restrict__ x
                                                      const float* self, float* out) {
   float acc[3] = {0.f, 0.f, 0.f};
   const long long sy = p.X, sz = (long long)p.X * p.Y;
-  // The 13 default links have rest = dir * stride (exactly: dir is -1, 0 or 1) and
-  // fall into seven classes by which axes they span -- x, y, z, xy, xz, yz, xyz --
-  // with one rest length and one spring constant per class.  Reading rest[13][3]
-  // and neg_k[13] as 52 separate wave-uniform values had the 3-D kernels spill
-  // 196-239 SGPRs (one v_readlane in eight VALU instructions of integrate_kernel<3>);
-  // three strides and seven constants are the same numbers (spills 233 -> 119,
-  // [3,4,100^3] 334 -> 309 us per step).  A further instantiation without the
-  // other force kinds got the spills to 75 but 108 bytes of scratch: 390 us.
-  const float st[3] = {p.rest[0][0], p.rest[1][1], p.rest[2][2]};
-  auto rest_of = [&](int d, int c) { return d == 0 ? 0.f : (d > 0 ? st[c] : -st[c]); };
-  auto len_of = [&](int dx, int dy, int dz) {
-    const float r[3] = {rest_of(dx, 0), rest_of(dy, 1), rest_of(dz, 2)};
-    return vec_len(r, 3);
-  };
-  // representative link of a class: the first one with that |dir| pattern
-  const float l0c[7] = {len_of(1, 0, 0), len_of(0, 1, 0), len_of(0, 0, 1), len_of(1, 1, 0),
-                        len_of(1, 0, 1), len_of(0, 1, 1), len_of(1, 1, 1)};
-  const float nkc[7] = {p.neg_k[0], p.neg_k[1], p.neg_k[2], p.neg_k[3],
-                        p.neg_k[5], p.neg_k[7], p.neg_k[9]};
-#define SFM_CLASS(DX, DY, DZ)                                                         \
-  ((DX) != 0 && (DY) != 0 && (DZ) != 0 ? 6                                           \
-   : (DY) != 0 && (DZ) != 0 ? 5 : (DX) != 0 && (DZ) != 0 ? 4 : (DX) != 0 && (DY) != 0 ? 3 \
-   : (DZ) != 0 ? 2 : (DY) != 0 ? 1 : 0)
+  // (spills 233 -> 119, [3,4,100^3] 334 -> 309 us per step.  A further
+  // instantiation without the other force kinds got the spills to 75 but 108
+  // bytes of scratch: 390 us.)
+  const DefLinks3 dl(p);
 #define SFM_LINK(L, DX, DY, DZ)                                                      \
   {                                                                                  \
-    constexpr int kc = SFM_CLASS(DX, DY, DZ);                                        \
-    const float l0 = l0c[kc];                                                        \
-    const float rest[3] = {rest_of(DX, 0), rest_of(DY, 1), rest_of(DZ, 2)};          \
+    constexpr int kc = SFM_CLASS3(DX, DY, DZ);                                       \
+    const float l0 = dl.l0c[kc];                                                     \
+    const float rest[3] = {dl.rest(DX, 0), dl.rest(DY, 1), dl.rest(DZ, 2)};          \
     const bool okf = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&          \
                      yi - (DY) < p.Y && zi - (DZ) >= 0 && zi - (DZ) < p.Z;            \
     const bool okn = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&          \
@@ -361,8 +379,8 @@ __device__ __forceinline__ void node_force_default3d(const float* __restrict__ x
       df[c] = self[c] - x[c * p.N + mf] + rest[c];                                   \
       dn[c] = x[c * p.N + mn] - self[c] + rest[c];                                   \
     }                                                                                \
-    spring_xyz<DX, DY, DZ>(df, l0, nkc[kc], p.prefer, ff);                           \
-    spring_xyz<DX, DY, DZ>(dn, l0, nkc[kc], p.prefer, fn);                           \
+    spring_xyz<DX, DY, DZ>(df, l0, dl.nkc[kc], p.prefer, ff);                        \
+    spring_xyz<DX, DY, DZ>(dn, l0, dl.nkc[kc], p.prefer, fn);                        \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                  \
       acc[c] = acc[c] + (okf ? ff[c] : 0.f);                                         \
       acc[c] = acc[c] - (okn ? fn[c] : 0.f);                                         \
@@ -373,7 +391,6 @@ __device__ __forceinline__ void node_force_default3d(const float* __restrict__ x
   SFM_LINK(8, 0, -1, 1) SFM_LINK(9, 1, 1, 1) SFM_LINK(10, 1, 1, -1) SFM_LINK(11, 1, -1, 1)
   SFM_LINK(12, -1, 1, 1)
 #undef SFM_LINK
-#undef SFM_CLASS
   out[0] = acc[0];
   out[1] = acc[1];
   out[2] = acc[2];
@@ -1516,9 +1533,7 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
   const int z0 = seg * seg_planes, z1 = min(p.Z, z0 + seg_planes);
   if (z0 >= p.Z) return;  // whole workgroup
 
-  float l0[13];
-#pragma unroll
-  for (int L = 0; L < 13; ++L) l0[L] = vec_len(p.rest[L], 3);
+  const DefLinks3 dl(p);
 
   auto pos_at = [&](int plane, int c, int w, int l) -> float& {
     return pos[((plane % 3) * 3 + c) * (kMW * 64) + w * 64 + l];
@@ -1570,9 +1585,11 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
 #define SFM_NEAR3(OUT, L, DX, DY, DZ, PL, W, LN)                                          \
     {                                                                                     \
       float d_[3];                                                                        \
+      constexpr int dd_[3] = {DX, DY, DZ};                                                \
       _Pragma("unroll") for (int c = 0; c < 3; ++c)                                       \
-          d_[c] = pos_at(PL, c, W, LN) - self[c] + p.rest[L][c];                          \
-      spring_xyz<DX, DY, DZ>(d_, l0[L], p.neg_k[L], p.prefer, OUT);                       \
+          d_[c] = pos_at(PL, c, W, LN) - self[c] + dl.rest(dd_[c], c);                    \
+      spring_xyz<DX, DY, DZ>(d_, dl.l0c[SFM_CLASS3(DX, DY, DZ)],                          \
+                             dl.nkc[SFM_CLASS3(DX, DY, DZ)], p.prefer, OUT);              \
     }
     const bool rows_all = wave >= 1 && wave <= kMRows;  // owned rows: every spring
     const bool row_lo = wave == 0, row_hi = wave == kMW - 1;
@@ -1597,9 +1614,10 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
       SFM_NEAR3(n11, 11, 1, -1, 1, z + 1, wm, lp)
       // link 10 = (1, 1, -1) from its far end b = this node: a = (x-1, y-1, z+1)
       float d_[3];
+      constexpr int d10[3] = {1, 1, -1};
 #pragma unroll
-      for (int c = 0; c < 3; ++c) d_[c] = self[c] - pos_at(z + 1, c, wm, lm) + p.rest[10][c];
-      spring_xyz<1, 1, -1>(d_, l0[10], p.neg_k[10], p.prefer, f10);
+      for (int c = 0; c < 3; ++c) d_[c] = self[c] - pos_at(z + 1, c, wm, lm) + dl.rest(d10[c], c);
+      spring_xyz<1, 1, -1>(d_, dl.l0c[6], dl.nkc[6], p.prefer, f10);
     }
 #undef SFM_NEAR3
     // terms that arrived from the plane below (written one iteration ago)
@@ -1897,6 +1915,7 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
   const float hdt = 0.5f * dt;
   float part[kNP];
   for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+  const DefLinks3 dl(p);
 #pragma unroll
   for (int k = 0; k < kOwn; ++k) {
     if (!live[k]) continue;
@@ -1910,7 +1929,9 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
     // node itself (d = rest: force exactly +-0)
 #define SFM_LINK(L, DX, DY, DZ)                                                      \
     {                                                                                \
-      const float l0 = vec_len(p.rest[L], 3);                                        \
+      constexpr int kc = SFM_CLASS3(DX, DY, DZ);                                     \
+      const float l0 = dl.l0c[kc];                                                   \
+      const float rest[3] = {dl.rest(DX, 0), dl.rest(DY, 1), dl.rest(DZ, 2)};        \
       const bool okf = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&        \
                        yi - (DY) < p.Y && zi - (DZ) >= 0 && zi - (DZ) < p.Z;          \
       const bool okn = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&        \
@@ -1919,11 +1940,11 @@ integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in
       const int mf = okf ? ctr[k] - off : ctr[k], mn = okn ? ctr[k] + off : ctr[k];  \
       float df[3], dn[3], ff[3], fn[3];                                              \
       _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                \
-        df[c] = self[c] - xt[c][mf] + p.rest[L][c];                                  \
-        dn[c] = xt[c][mn] - self[c] + p.rest[L][c];                                  \
+        df[c] = self[c] - xt[c][mf] + rest[c];                                       \
+        dn[c] = xt[c][mn] - self[c] + rest[c];                                       \
       }                                                                              \
-      spring_xyz<DX, DY, DZ>(df, l0, p.neg_k[L], p.prefer, ff);                      \
-      spring_xyz<DX, DY, DZ>(dn, l0, p.neg_k[L], p.prefer, fn);                      \
+      spring_xyz<DX, DY, DZ>(df, l0, dl.nkc[kc], p.prefer, ff);                      \
+      spring_xyz<DX, DY, DZ>(dn, l0, dl.nkc[kc], p.prefer, fn);                      \
       _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                \
         acc[c] = acc[c] + (okf ? ff[c] : 0.f);                                       \
         acc[c] = acc[c] - (okn ? fn[c] : 0.f);                                       \
@@ -3235,7 +3256,8 @@ bool shared_enabled() {
 // plane), the halo row / column threads carry the per-thread overhead of the
 // exchange (positions, 27 + 27 exchanged floats, 26 guarded adds) without
 // owning nodes, and the tail of a second round of workgroups costs the rest.
-// Opt-in (SFM_MESH_MARCH=1), kept as the measured experiment; its forces are
+// (Round 3, after the link constants stopped spilling in all three kernels: 379
+// vs 308 us.)  Opt-in (SFM_MESH_MARCH=1), kept as the measured experiment; its forces are
 // bit-identical (test_volumetric_march_kernel_matches_two_sided_kernel).
 bool march_enabled() {
   const char* e = sfm::option("SFM_MESH_MARCH");
@@ -3258,7 +3280,8 @@ bool tiled_enabled() {
 // on [3,4,100^3], 408 vs 375 on [3,1,64,256,256]): the volumetric step is bound
 // by the ~3000 IEEE-exact VALU operations per node (26 spring evaluations with
 // correctly rounded sqrt and division each), not by the neighbour re-reads the
-// bricks remove, and the shell recomputation adds to it.  Opt-in
+// bricks remove, and the shell recomputation adds to it.  (Round 3, link constants
+// without spills everywhere: 380 vs 308 and 354 vs 324 us.)  Opt-in
 // (SFM_MESH_BRICKS=1), kept as the measured experiment.
 bool bricks_enabled() {
   const char* e = sfm::option("SFM_MESH_BRICKS");
