@@ -737,8 +737,11 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
     const int ta = __builtin_amdgcn_readlane(inc_a, 63);  // IrawA[yv][px]
     const int tb = __builtin_amdgcn_readlane(inc_b, 63);  // IrawB[py - yv][px]
     // centred integral images: I'[y][x] = Iraw[y][x] - c y x
-    auto ia = [&](int raw, int x) { return static_cast<float>(raw - ca * yv * x); };
-    auto ib = [&](int raw, int x) { return static_cast<float>(raw - cb * yw * x); };
+    // (c y x < 255 * 256 * 192 < 2^24: 24-bit multiplies, full rate; the 32-bit
+    // v_mul_lo_u32 is a quarter-rate instruction and a row had twelve of them)
+    const int cay = ca * yv, cby = cb * yw;
+    auto ia = [&](int raw, int x) { return static_cast<float>(raw - __mul24(cay, x)); };
+    auto ib = [&](int raw, int x) { return static_cast<float>(raw - __mul24(cby, x)); };
     const float ia_px = ia(ta, px), ib_px = ib(tb, px);
     if (yv < py) {
 #pragma unroll
