@@ -117,6 +117,10 @@ def main():
                        '(steady-state power / clocks); 0 = off')
   ap.add_argument('--no-legs', action='store_true',
                   help='skip the un-pruned and other-pair roofline legs')
+  ap.add_argument('--no-multi-gpu-legs', action='store_true',
+                  help='N > 1: skip the communicating legs (configs[3] section '
+                       'chain with the boundary hand-off, one mesh in bands '
+                       'across the ranks)')
   ap.add_argument('--mesh-sharded', type=int, default=0, metavar='BANDS',
                   help='extra leg: one [2,64,204,204] mesh split into BANDS bands '
                        'per rank, stepped by the C-side banded loop (RCCL halo '
@@ -152,12 +156,16 @@ def main():
       dist.init_process_group(backend, rank=rank, world_size=world)
   if world != args.gpus:
     raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
-  if world > 1 and backend == 'nccl':
-    # every rank must sit on its own GPU and RCCL must see all of them
-    assert torch.cuda.device_count() >= world, (torch.cuda.device_count(), world)
-    probe = torch.ones(1, device=torch.device('cuda', local_rank))
+  ranks_seen = 1
+  if world > 1:
+    if backend == 'nccl':
+      # every rank must sit on its own GPU and RCCL must see all of them
+      assert torch.cuda.device_count() >= world, (torch.cuda.device_count(), world)
+    probe = torch.ones(1, device=torch.device('cuda', local_rank) if backend == 'nccl'
+                       else 'cpu')
     dist.all_reduce(probe)
-    assert int(probe.item()) == world, (probe.item(), world)
+    ranks_seen = int(probe.item())
+    assert ranks_seen == world, (ranks_seen, world)
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
   lib = _abi.load()
@@ -442,6 +450,22 @@ def main():
   if args.mesh_sharded > 0:
     sharded = mesh_sharded_leg(args.mesh_sharded, dev, rank, world)
 
+  # N > 1: the legs that really communicate (the timed default workload above
+  # is N independent tile pairs, no data-path collective)
+  multi = None
+  if world > 1 and not args.no_multi_gpu_legs:
+    multi = {
+        'backend': 'rccl' if backend == 'nccl' else backend,
+        # the value of an all-reduce of ones over the process group
+        'rccl_ranks' if backend == 'nccl' else 'ranks_seen': ranks_seen,
+        'devices': 'one GPU per rank' if not os.environ.get('SFM_BENCH_ONE_DEVICE')
+                   else 'all ranks share cuda:0 (smoke test)',
+        'section_chain': section_chain_leg(dev, rank, world, backend, args.seed,
+                                           args.mesh_iters),
+        'mesh_sharded': mesh_sharded_leg(1, dev, rank, world,
+                                         iters=min(200, max(args.mesh_iters, 20))),
+    }
+
   out = {
       'metric': 'patch-xcorr Mpix/s (+ mesh node-updates/s) on 8192^2 tiles',
       'value': mpix_s, 'unit': 'Mpix/s', 'n_gpus': world,
@@ -472,6 +496,8 @@ def main():
     out['sustained_ms_per_step'] = sustained['ms_per_step']
   if sharded:
     out['mesh_sharded'] = sharded
+  if multi:
+    out['multi_gpu'] = multi
   if aux:
     out['aux_rooflines'] = aux
 
@@ -552,7 +578,82 @@ def aux_legs(dev, seed):
   return out
 
 
-def mesh_sharded_leg(bands_per_rank, dev, rank, world):
+def section_chain_leg(dev, rank, world, backend, seed, iters, sections_per_rank=8):
+  """BASELINE configs[3], mesh side: a z-stack of 8 x world sections of 8192^2
+  (mesh [2, 1, 205, 205] each, stride 40) aligned section by section in blocks
+  of 8, one block per rank (em_alignment notebook cells 25, 38-48): every rank
+  solves its block device resident (compose_maps_fast -> relax_mesh), the last
+  solved mesh of every block (336 KB) crosses ranks in ONE all-gather (RCCL,
+  GPU to GPU, on an nccl group) and the small cross-block relaxation runs on
+  every rank.  Times are the max over ranks; the hand-off includes waiting for
+  the slowest rank, `handoff_only_us` is the collective alone."""
+  import torch
+  import torch.distributed as dist
+  from scipy import ndimage
+  from sofima_amd import dist as sdist, mesh
+  n_grid, pad = 201, PATCH // 2 // STEP
+  n = sections_per_rank * world
+  flow = np.full((2, n, n_grid + 2 * pad, n_grid + 2 * pad), np.nan, np.float32)
+  drift = np.zeros((2, n_grid, n_grid), np.float32)
+  for z in range(n):
+    rng = np.random.default_rng(seed + 2 + z)          # SURVEY 8d: seeds 1004 + z
+    # smooth in-plane field + a drift that varies slowly with z
+    drift += ndimage.gaussian_filter(rng.standard_normal(drift.shape), (0, 30, 30)) * 8
+    local = ndimage.gaussian_filter(rng.standard_normal(drift.shape), (0, 12, 12)) * 25
+    flow[:, z, pad:-pad, pad:-pad] = 0.25 * drift + local
+  cfg = mesh.IntegrationConfig(
+      dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(STEP, STEP), num_iters=iters,
+      max_iters=iters, stop_v_max=0.005, dt_max=1000, start_cap=0.01, final_cap=10,
+      prefer_orig_order=True)
+
+  def barrier():
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+
+  sdist.align_sections_blocked(flow, cfg, float(STEP), n_blocks=world)   # warm-up
+  reps = 2
+  tot = np.zeros(4)
+  for _ in range(reps):
+    tm = {}
+    barrier()
+    t0 = time.perf_counter()
+    blocks, last, xblk = sdist.align_sections_blocked(flow, cfg, float(STEP),
+                                                      n_blocks=world, timing=tm)
+    torch.cuda.synchronize(dev)
+    tot += [time.perf_counter() - t0, tm['solve_s'], tm['handoff_s'], tm['xblk_s']]
+  tot /= reps
+  # the collective alone, data ready on every rank
+  mine = [torch.from_numpy(last[:, b:b + 1].copy()).to(dev)
+          for b in sdist.shard_units(world, rank, world)]
+  sdist.gather_boundaries(mine, world)
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(20):
+    sdist.gather_boundaries(mine, world)
+  torch.cuda.synchronize(dev)
+  only = (time.perf_counter() - t0) / 20
+  t = torch.tensor(list(tot) + [only], dtype=torch.float64,
+                   device=dev if backend == 'nccl' else 'cpu')
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  total, solve, hand, xb, only = [float(v) for v in t.cpu()]
+  nodes = (n_grid + 2 * pad) ** 2
+  return {
+      'workload': f'{n} sections of 8192^2 (mesh [2,1,{n_grid + 2 * pad},{n_grid + 2 * pad}]), '
+                  f'{sections_per_rank} per rank, {iters} FIRE iterations per section, '
+                  'blocks chained by the last-section mesh (BASELINE configs[3], mesh side)',
+      'sections': n, 'blocks': world, 'ms_total': round(total * 1e3, 3),
+      'ms_block_solve': round(solve * 1e3, 3), 'ms_handoff': round(hand * 1e3, 3),
+      'ms_cross_block': round(xb * 1e3, 3), 'handoff_only_us': round(only * 1e6, 1),
+      'handoff_bytes_per_block': int(2 * nodes * 4),
+      'handoff': 'one all-gather of the blocks\' last meshes '
+                 + ('(RCCL, device tensors)' if backend == 'nccl' else f'({backend}, host tensors)'),
+      'sections_per_s': n / total,
+      'node_updates_per_s': (n + world) * nodes * iters / total,
+      'finite_fraction': float(np.isfinite(xblk).mean()),
+  }
+
+
+def mesh_sharded_leg(bands_per_rank, dev, rank, world, iters=200):
   """ONE [2, 64, 204, 204] mesh (the configs[2] montage size) split into
   world x bands_per_rank bands of rows; the whole chunk of steps runs inside
   sfm_mesh_relax_banded (halo rows between ranks through sfm_comm_* = RCCL,
@@ -562,7 +663,6 @@ def mesh_sharded_leg(bands_per_rank, dev, rank, world):
   rng = np.random.default_rng(7)
   shape = (2, 64, 204, 204)
   prev = rng.standard_normal(shape).astype(np.float32) * 2
-  iters = 200
   cfg = mesh.IntegrationConfig(
       dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(20.0, 20.0), num_iters=iters,
       max_iters=iters, stop_v_max=1e-9, dt_max=1000, start_cap=0.01, final_cap=10,
@@ -570,6 +670,11 @@ def mesh_sharded_leg(bands_per_rank, dev, rank, world):
   x0 = np.zeros(shape, np.float32)
   out = {'mesh': list(shape), 'iters': iters, 'bands_per_rank': bands_per_rank,
          'ranks': world}
+  import torch.distributed as dist
+  if world > 1:
+    out['transport'] = ('RCCL send / recv + all-gather (sfm_comm_*)'
+                        if dist.get_backend() == 'nccl' else
+                        'host-staged callbacks over ' + dist.get_backend())
   mesh.relax_mesh(x0, prev, cfg)
   torch.cuda.synchronize(dev)
   t0 = time.perf_counter()
@@ -580,6 +685,12 @@ def mesh_sharded_leg(bands_per_rank, dev, rank, world):
   torch.cuda.synchronize(dev)
   tm = {}
   sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=bands_per_rank, timing=tm)
+  spent = tm['banded_chunk_s']
+  if world > 1:                      # max over ranks, like every other time here
+    t = torch.tensor([spent], dtype=torch.float64,
+                     device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    spent = tm['banded_chunk_s'] = float(t.item())
   out['banded_us_per_step'] = round(tm['banded_chunk_s'] / iters * 1e6, 2)
   out['banded_over_unsplit'] = round(out['banded_us_per_step'] / out['unsplit_us_per_step'], 3)
   out['node_updates_per_s'] = float(np.prod(shape[1:])) * iters / tm['banded_chunk_s']

@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 5   /* 4: SfmProfile.mfma_issued; sfm_mesh_relax_banded; 5: SfmWarpDesc.coord_map_f64 */
+#define SFM_ABI_VERSION 6   /* 4: SfmProfile.mfma_issued; sfm_mesh_relax_banded; 5: SfmWarpDesc.coord_map_f64;
+                                6: SfmBandedDesc.host_halo / host_allgather / host_user */
 
 #define SFM_OK 0
 #define SFM_ERR_INVALID (-1)     /* bad argument / unsupported combination */
@@ -557,6 +558,21 @@ int sfm_mesh_shard_finish(const SfmMeshDesc* desc, SfmMeshShard* shard,
                                    comm as self send / recv too (exercises the
                                    RCCL path on one GPU)                       */
 #define SFM_BANDED_NO_OVERLAP 2 /* one launch per band and step, exchange after it */
+/* Host-staged transport (twin of force_cb / prev_cb): used between ranks when
+ * `comm` is NULL and n_ranks > 1, so that the inter-rank branch of the loop --
+ * peer indexing, packed edge rows, the in-place all-gather layout with several
+ * bands per rank, the edge-first split on the second stream -- also runs where
+ * RCCL cannot connect the ranks (several processes sharing one GPU, CPU-side
+ * process groups).  The library synchronises the exchange stream, copies the
+ * packed rows to host memory, calls back, and copies the received rows to the
+ * device; every pointer the callbacks see is HOST memory.  Argument meaning as
+ * sfm_comm_halo_exchange / sfm_comm_allgather below (peer = -1: no neighbour on
+ * that side; `recv` of the all-gather holds n_ranks * count floats, rank r's
+ * part at r * count, and the callee fills every part).  Return 0, or non-zero
+ * to abort the chunk (SFM_ERR_INVALID, like force_cb). */
+typedef int (*SfmHostHaloFn)(void* user, int peer_lo, const float* send_lo, float* recv_lo,
+                             int peer_hi, const float* send_hi, float* recv_hi, size_t count);
+typedef int (*SfmHostAllgatherFn)(void* user, const float* send, float* recv, size_t count);
 struct SfmComm;
 typedef struct SfmBandedDesc {
   int32_t n_local;              /* bands of this rank, consecutive, in y order  */
@@ -569,6 +585,9 @@ typedef struct SfmBandedDesc {
   void* comm_stream;            /* exchange stream; NULL: bands[0].stream       */
   void* scratch;                /* device, sfm_mesh_banded_scratch_bytes        */
   size_t scratch_bytes;
+  SfmHostHaloFn host_halo;      /* both or neither; ignored when comm is given   */
+  SfmHostAllgatherFn host_allgather;
+  void* host_user;
 } SfmBandedDesc;
 size_t sfm_mesh_banded_scratch_bytes(const SfmBandedDesc* desc);
 int sfm_mesh_relax_banded(const SfmBandedDesc* desc, SfmFireState* fire,

@@ -279,6 +279,13 @@ class SfmMeshShard(C.Structure):
   ]
 
 
+_fp = C.POINTER(C.c_float)
+# host-staged transport of the banded loop (SfmHostHaloFn / SfmHostAllgatherFn)
+HOST_HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _fp, _fp, C.c_int, _fp, _fp,
+                           C.c_size_t)
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, _fp, C.c_size_t)
+
+
 class SfmBandedDesc(C.Structure):
   _fields_ = [
       ('n_local', i32),
@@ -291,6 +298,9 @@ class SfmBandedDesc(C.Structure):
       ('comm_stream', C.c_void_p),
       ('scratch', C.c_void_p),
       ('scratch_bytes', C.c_size_t),
+      ('host_halo', HOST_HALO_FN),
+      ('host_allgather', HOST_ALLGATHER_FN),
+      ('host_user', C.c_void_p),
   ]
 
 

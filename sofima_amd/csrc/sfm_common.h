@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include <cstdarg>
 #include <cstdio>
 
@@ -27,8 +29,10 @@ int fail(int code, const char* fmt, ...);
 
 // Behaviour switches (sfm_set_option; the environment variable of the same name
 // is the default).  Returns the value or nullptr when unset.  The pointer stays
-// valid until the option is set again.
+// valid for the life of the process (values are interned, never freed).  Entry
+// points resolve their switches once, outside their launch loops.
 const char* option(const char* name);
+std::string option_str(const char* name);   // copy; empty when unset
 
 // FIRE scalars as the mesh kernels keep them on the device (sfm_mesh.hip) and
 // the pending per-step corrections derived from the previous step's sums.

@@ -26,19 +26,31 @@ int fail(int code, const char* fmt, ...) {
 }
 
 namespace {
-// Option table: explicit settings win over the process environment.  Values
-// are kept in a list of stable strings (callers hold the pointers briefly).
+// Option table: explicit settings win over the process environment.  A value
+// string is interned once and never freed or modified afterwards (the set of
+// distinct values a process ever uses is tiny), so a pointer handed out by
+// option() stays valid while another thread sets the option again.
 std::mutex g_opt_mu;
-std::map<std::string, std::string> g_opts;
+std::map<std::string, const std::string*> g_opts;
+std::map<std::string, std::string> g_opt_values;   // node addresses are stable
+
+const std::string* intern(const char* value) {
+  return &g_opt_values.emplace(value, value).first->second;
+}
 }  // namespace
 
 const char* option(const char* name) {
   {
     std::lock_guard<std::mutex> lk(g_opt_mu);
     auto it = g_opts.find(name);
-    if (it != g_opts.end()) return it->second.c_str();
+    if (it != g_opts.end()) return it->second->c_str();
   }
   return std::getenv(name);
+}
+
+std::string option_str(const char* name) {
+  const char* v = option(name);
+  return v ? std::string(v) : std::string();
 }
 
 namespace {
@@ -139,7 +151,7 @@ int sfm_set_option(const char* name, const char* value) {
     return sfm::fail(SFM_ERR_INVALID, "option names start with SFM_");
   std::lock_guard<std::mutex> lk(sfm::g_opt_mu);
   if (value)
-    sfm::g_opts[name] = value;
+    sfm::g_opts[name] = sfm::intern(value);
   else
     sfm::g_opts.erase(name);   // back to the default: the environment variable, if any
   return SFM_OK;

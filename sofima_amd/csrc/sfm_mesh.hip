@@ -4103,8 +4103,13 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
   if (nl < 1 || nl > kMaxLocalBands)
     return sfm::fail(SFM_ERR_INVALID, "banded: 1..%d bands per rank", kMaxLocalBands);
   if (b->rank < 0 || b->rank >= n_ranks) return sfm::fail(SFM_ERR_INVALID, "banded: rank");
-  if (n_ranks > 1 && !b->comm)
-    return sfm::fail(SFM_ERR_INVALID, "banded: %d ranks need a communicator", n_ranks);
+  // host-staged transport: the inter-rank branch without RCCL peers
+  const bool host_x = !b->comm && n_ranks > 1 && b->host_halo && b->host_allgather;
+  if (n_ranks > 1 && !b->comm && !host_x)
+    return sfm::fail(SFM_ERR_INVALID,
+                     "banded: %d ranks need a communicator or the host_halo / host_allgather pair",
+                     n_ranks);
+  const bool transport = b->comm != nullptr || host_x;
   const bool loopback = (b->flags & SFM_BANDED_LOOPBACK) != 0;
   if (loopback && !b->comm)
     return sfm::fail(SFM_ERR_INVALID, "banded: loop-back needs a communicator");
@@ -4169,7 +4174,7 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
   }
   // The second stream pays for itself only when edge rows really travel (RCCL):
   // between bands of one process the exchange is one small copy kernel.
-  const bool overlap = fused && xs != st && b->comm && !(b->flags & SFM_BANDED_NO_OVERLAP);
+  const bool overlap = fused && xs != st && transport && !(b->flags & SFM_BANDED_NO_OVERLAP);
   const int C = d0.ncomp;
   const int planes = d0.shape[0] * d0.shape[1], X = d0.shape[3];
 
@@ -4305,7 +4310,44 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
   // back (tests on one GPU): every edge between local bands travels through a
   // self send / recv -- sends and receives to the same peer match in order.
   const size_t cnt = 3 * row_floats;
+  // Host staging of the transport callbacks (pageable memory: the copies return
+  // when they are done).  Parts: send lo, send hi, recv lo, recv hi.
+  std::vector<float> stage_rows, stage_gather;
+  if (host_x) {
+    stage_rows.resize(4 * cnt);
+    stage_gather.resize((size_t)total * std::max<size_t>(kNP, 2));
+  }
+  auto host_p2p = [&](hipStream_t s_) -> int {
+    const bool lo = bs[0].has_lo && b->rank > 0;
+    const bool hi = bs[nl - 1].has_hi && b->rank < n_ranks - 1;
+    if (!lo && !hi) return SFM_OK;
+    float* h = stage_rows.data();
+    if (lo) SFM_HIP_CHECK(hipMemcpyAsync(h, bs[0].buf[0], cnt * sizeof(float), hipMemcpyDeviceToHost, s_));
+    if (hi) SFM_HIP_CHECK(hipMemcpyAsync(h + cnt, bs[nl - 1].buf[1], cnt * sizeof(float), hipMemcpyDeviceToHost, s_));
+    SFM_HIP_CHECK(hipStreamSynchronize(s_));
+    if (b->host_halo(b->host_user, lo ? b->rank - 1 : -1, lo ? h : nullptr, lo ? h + 2 * cnt : nullptr,
+                     hi ? b->rank + 1 : -1, hi ? h + cnt : nullptr, hi ? h + 3 * cnt : nullptr, cnt) != 0)
+      return sfm::fail(SFM_ERR_INVALID, "banded: host_halo callback failed");
+    if (lo) SFM_HIP_CHECK(hipMemcpyAsync(bs[0].buf[2], h + 2 * cnt, cnt * sizeof(float), hipMemcpyHostToDevice, s_));
+    if (hi) SFM_HIP_CHECK(hipMemcpyAsync(bs[nl - 1].buf[3], h + 3 * cnt, cnt * sizeof(float), hipMemcpyHostToDevice, s_));
+    SFM_HIP_CHECK(hipStreamSynchronize(s_));   // the staging area is reused
+    return SFM_OK;
+  };
+  // recv[r * count ..) = the `count` floats at recv + rank * count of rank r (in place)
+  auto allgather = [&](float* recv, size_t count, hipStream_t s_) -> int {
+    if (b->comm) return sfm_comm_allgather(b->comm, recv + (size_t)b->rank * count, recv, count, s_);
+    float* h = stage_gather.data();
+    SFM_HIP_CHECK(hipMemcpyAsync(h + (size_t)b->rank * count, recv + (size_t)b->rank * count,
+                                 count * sizeof(float), hipMemcpyDeviceToHost, s_));
+    SFM_HIP_CHECK(hipStreamSynchronize(s_));
+    if (b->host_allgather(b->host_user, h + (size_t)b->rank * count, h, count) != 0)
+      return sfm::fail(SFM_ERR_INVALID, "banded: host_allgather callback failed");
+    SFM_HIP_CHECK(hipMemcpyAsync(recv, h, (size_t)n_ranks * count * sizeof(float), hipMemcpyHostToDevice, s_));
+    SFM_HIP_CHECK(hipStreamSynchronize(s_));
+    return SFM_OK;
+  };
   auto p2p = [&](hipStream_t s_) -> int {
+    if (host_x) return host_p2p(s_);
     if (!b->comm) return SFM_OK;
     bool any = false;
     for (int i = 0; i < nl; ++i)
@@ -4344,9 +4386,7 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
   auto gather_sums = [&](int step, hipStream_t s_) -> int {
     if (n_ranks == 1 && !loopback) return SFM_OK;   // my_sums are rows of the buffer already
     // in place: this rank's rows sit at their final position
-    float* sums = sums_of(step);
-    return sfm_comm_allgather(b->comm, sums + (size_t)b->rank * nl * kNP, sums,
-                              (size_t)nl * kNP, s_);
+    return allgather(sums_of(step), (size_t)nl * kNP, s_);
   };
 
   hipEvent_t ev_edge = nullptr, ev_int = nullptr, ev_x = nullptr;
@@ -4359,6 +4399,17 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
     SFM_HIP_CHECK(hipEventCreateWithFlags(&ev_int, hipEventDisableTiming));
     SFM_HIP_CHECK(hipEventCreateWithFlags(&ev_x, hipEventDisableTiming));
   }
+  // An error return between a fork (the exchange stream waits for the main
+  // stream) and its join must not leave the exchange stream running behind the
+  // caller's back: the guard joins it into the main stream on the way out.
+  struct JoinGuard {
+    hipStream_t st, xs;
+    hipEvent_t* ev;
+    bool forked;
+    ~JoinGuard() {
+      if (forked && *ev && hipEventRecord(*ev, xs) == hipSuccess) (void)hipStreamWaitEvent(st, *ev, 0);
+    }
+  } join{st, xs, &ev_x, false};
 
   // -- begin: scalars, a = F(x) + pull on the local rows of every band --------
   Scalars s0;
@@ -4391,14 +4442,21 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
     if (!overlap) return fn(st);
     SFM_HIP_CHECK(hipEventRecord(ev_int, st));
     SFM_HIP_CHECK(hipStreamWaitEvent(xs, ev_int, 0));
+    join.forked = true;
     if (int rc = fn(xs)) return rc;
     SFM_HIP_CHECK(hipEventRecord(ev_x, xs));
     SFM_HIP_CHECK(hipStreamWaitEvent(st, ev_x, 0));
+    join.forked = false;
     return SFM_OK;
   };
   // the halo rows' a (and, from the second chunk on, nothing else) is stale
   if (int rc = on_comm_stream([&](hipStream_t s_) { return exchange(0, s_); })) return rc;
 
+  int xcd_opt = -1;   // SFM_MESH_XCD: 0 off, 1 from 64 tiles on, default from 2048 on
+  {
+    const std::string xo = sfm::option_str("SFM_MESH_XCD");
+    if (!xo.empty() && (xo[0] == '0' || xo[0] == '1')) xcd_opt = xo[0] - '0';
+  }
   int in = 0, cur = 0;
   for (int k = 0; k < iters; ++k) {
     const int pending = k > 0 ? 1 : 0;
@@ -4410,8 +4468,7 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
         if (grid <= 0) return;
         // (XCD-contiguous tile order like the un-split step: the band of a block is
         // looked up after the remap, so a run may span bands)
-        const char* xo = sfm::option("SFM_MESH_XCD");
-        const int xcd = xo && xo[0] == '0' ? 0 : (xo && xo[0] == '1' ? grid >= 64 : grid >= 2048);
+        const int xcd = xcd_opt == 0 ? 0 : (xcd_opt == 1 ? grid >= 64 : grid >= 2048);
         BandArgs ba{sums_of(k - 1), nullptr, total, 0, mode, 0, 0, band_dev[in], nl, xcd};
         hipLaunchKernelGGL((integrate_shared2d_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st,
                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bs[0].p,
@@ -4430,6 +4487,7 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
         SFM_LAUNCH_CHECK();
         SFM_HIP_CHECK(hipEventRecord(ev_edge, st));
         SFM_HIP_CHECK(hipStreamWaitEvent(xs, ev_edge, 0));
+        join.forked = true;
         if (int rc = exchange_fused(xs)) return rc;
         launch(2, grid_mode[2]);
         SFM_LAUNCH_CHECK();
@@ -4440,6 +4498,7 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
           if (int rc = gather_sums(k, xs)) return rc;
         SFM_HIP_CHECK(hipEventRecord(ev_x, xs));
         SFM_HIP_CHECK(hipStreamWaitEvent(st, ev_x, 0));
+        join.forked = false;
       } else {
         launch(0, grid_mode[0]);
         SFM_LAUNCH_CHECK();
@@ -4530,8 +4589,7 @@ int sfm_mesh_relax_banded(const SfmBandedDesc* b, SfmFireState* fire, SfmChunkSt
   }
   if (n_ranks > 1)
     if (int rc = on_comm_stream([&](hipStream_t s_) {
-          return sfm_comm_allgather(b->comm, stats_all + (size_t)b->rank * nl * 2, stats_all,
-                                    (size_t)nl * 2, s_);
+          return allgather(stats_all, (size_t)nl * 2, s_);
         }))
       return rc;
   Scalars s1;

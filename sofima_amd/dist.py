@@ -339,6 +339,55 @@ class RcclComm:
     return t
 
 
+class HostStagedTransport:
+  """The host_halo / host_allgather pair of `SfmBandedDesc` over a
+  torch.distributed group that moves HOST tensors (gloo): the library stages
+  the packed edge rows and the bands' partial sums through host memory and
+  calls back here, so the inter-rank branch of `sfm_mesh_relax_banded` runs
+  where RCCL cannot connect the ranks (two processes sharing one GPU)."""
+
+  def __init__(self, group=None):
+    from . import _abi
+    self.group = group
+    self.rank, self.world = world(group)
+    self.error = None
+    self.calls = {'halo': 0, 'allgather': 0}
+    self.halo = _abi.HOST_HALO_FN(self._halo)
+    self.allgather = _abi.HOST_ALLGATHER_FN(self._allgather)
+
+  @staticmethod
+  def _tensor(ptr, n):
+    import torch
+    return torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(int(n),)))
+
+  def _halo(self, user, peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi, count):
+    try:
+      ops = []
+      for peer, snd, rcv in ((peer_lo, send_lo, recv_lo), (peer_hi, send_hi, recv_hi)):
+        if peer < 0:
+          continue
+        ops += [dist.P2POp(dist.isend, self._tensor(snd, count), peer, self.group),
+                dist.P2POp(dist.irecv, self._tensor(rcv, count), peer, self.group)]
+      for req in dist.batch_isend_irecv(ops):
+        req.wait()
+      self.calls['halo'] += 1
+      return 0
+    except BaseException as e:      # never unwind through the C frames
+      self.error = e
+      return 1
+
+  def _allgather(self, user, send, recv, count):
+    try:
+      src = self._tensor(send, count).clone()     # `send` lies inside `recv`
+      parts = list(self._tensor(recv, count * self.world).split(int(count)))
+      dist.all_gather(parts, src, group=self.group)
+      self.calls['allgather'] += 1
+      return 0
+    except BaseException as e:
+      self.error = e
+      return 1
+
+
 def relax_mesh_sharded(x, prev, config, mesh_force=None, group=None,
                        bands_per_rank: int = 1, band_factory=None,
                        transport: BandTransport | None = None):
@@ -435,7 +484,8 @@ def _comm_stream(dev):
 
 def relax_mesh_banded(x, prev, config, mesh_force=None, group=None,
                       bands_per_rank: int = 1, comm: 'RcclComm | None' = None,
-                      loopback: bool = False, overlap: bool = True, timing=None):
+                      loopback: bool = False, overlap: bool = True, timing=None,
+                      transport: str = 'auto'):
   """`mesh.relax_mesh(x, prev, config)` for ONE mesh spread over the ranks, with
   the step loop inside the library (sfm_mesh_relax_banded).
 
@@ -447,7 +497,16 @@ def relax_mesh_banded(x, prev, config, mesh_force=None, group=None,
   all-gathered once per step, and the exchange of a step's edge rows overlaps
   the integration of its interior rows on a second stream (`overlap`).
   `loopback=True` sends the edges between LOCAL bands through RCCL self
-  send / recv as well (exercises the transport on one GPU).
+  send / recv as well (exercises the transport on one GPU).  `transport`:
+  'rccl' (one GPU per rank), 'host' (the library stages rows and sums through
+  host memory and `HostStagedTransport` moves them over the process group --
+  ranks that share a GPU, gloo groups) or 'auto' = 'rccl' on an nccl group,
+  'host' otherwise.
+
+  Scope: meshes with a fixed `prev`.  A montage (`prev_fn`: the target of a
+  tile depends on its neighbour TILES, stitch_elastic.py:624-676) does not
+  split into bands of rows; montages and volumetric 5-D states with per-column
+  drift removal scale as replicas.
 
   Every rank passes the full arrays and gets the full relaxed mesh back:
   (x [np.ndarray], e_kin history, steps).  `timing`, a dict, receives
@@ -476,7 +535,18 @@ def relax_mesh_banded(x, prev, config, mesh_force=None, group=None,
   dev = _dev.device()
   lib = _abi.load()
   own_comm = None
-  if comm is None and (ws > 1 or loopback):
+  host = None
+  if transport not in ('auto', 'rccl', 'host'):
+    raise ValueError(f'unknown transport {transport!r}')
+  if transport == 'auto':
+    transport = 'rccl' if (comm is not None or ws == 1 or
+                           dist.get_backend(group) == 'nccl') else 'host'
+  if transport == 'host':
+    if comm is not None or loopback:
+      raise ValueError('the host-staged transport takes no RCCL communicator')
+    if ws > 1:
+      host = HostStagedTransport(group)
+  elif comm is None and (ws > 1 or loopback):
     comm = own_comm = RcclComm(group)
   n_local = int(bands_per_rank)
   n_bands = ws * n_local
@@ -514,6 +584,8 @@ def relax_mesh_banded(x, prev, config, mesh_force=None, group=None,
       0 if overlap else _abi.BANDED_NO_OVERLAP)
   side = _comm_stream(dev) if overlap else None
   bd.comm_stream = side.cuda_stream if side is not None else None
+  if host is not None:
+    bd.host_halo, bd.host_allgather = host.halo, host.allgather
   scratch = _dev.workspace(lib.sfm_mesh_banded_scratch_bytes(C.byref(bd)), dev)
   bd.scratch = scratch.data_ptr()
   bd.scratch_bytes = scratch.numel()
@@ -531,7 +603,10 @@ def relax_mesh_banded(x, prev, config, mesh_force=None, group=None,
       for i in range(n_local):
         descs[i].stream = _dev.stream_ptr()
       t0 = time.perf_counter()
-      _abi.check(lib.sfm_mesh_relax_banded(C.byref(bd), C.byref(fire), C.byref(stats)))
+      rc = lib.sfm_mesh_relax_banded(C.byref(bd), C.byref(fire), C.byref(stats))
+      if host is not None and host.error is not None:
+        raise host.error
+      _abi.check(rc)
       spent += time.perf_counter() - t0
       t += config.num_iters
       e_kin.append(float(stats.e_kin))
@@ -549,6 +624,8 @@ def relax_mesh_banded(x, prev, config, mesh_force=None, group=None,
       own_comm.close()
   if timing is not None:
     timing['banded_chunk_s'] = spent
+    if host is not None:
+      timing['host_calls'] = dict(host.calls)
   local = [k[0][..., o[0]:o[1], :].cpu().numpy() for k, o in zip(keep, owns)]
   owned = [s for part in gather_objects(local, group) for s in part]
   return np.concatenate(owned, axis=-2), e_kin, t
@@ -571,13 +648,16 @@ def block_ranges(n_sections: int, n_blocks: int) -> list[tuple[int, int]]:
   return list(zip(edges[:-1], edges[1:]))
 
 
-def solve_section_block(flow, config, stride, relax_fn=None, compose_fn=None):
+def solve_section_block(flow, config, stride, relax_fn=None, compose_fn=None,
+                        with_last=False):
   """Sequential section-by-section relaxation of one block (notebook cell 25):
   prev = compose_maps_fast(flow[z], solved[-1]); x = relax_mesh(0, prev).
 
   flow: [2, n, y, x] cleaned flow of the block's sections.  Returns the solved
   meshes [2, n + 1, y, x] (entry 0 is the zero mesh of the block's first
-  section).  The state stays on the device between the two ops.
+  section).  The state stays on the device between the two ops.  `with_last`:
+  also returns the last solved mesh as `relax_fn` produced it (a DeviceArray on
+  the HIP path), for a hand-off that never leaves the device.
   """
   if relax_fn is None or compose_fn is None:
     from . import map_utils, mesh
@@ -593,35 +673,92 @@ def solve_section_block(flow, config, stride, relax_fn=None, compose_fn=None):
     prev = compose_fn(flow[:, z:z + 1], origin, stride, solved[-1], origin, stride)
     x, _, _ = relax_fn(zero, prev, config)
     solved.append(x)
-  return np.concatenate([np.asarray(s, dtype=np.float32) for s in solved], axis=1)
+  out = np.concatenate([np.asarray(s, dtype=np.float32) for s in solved], axis=1)
+  return (out, solved[-1]) if with_last else out
+
+
+def gather_boundaries(last_local: list, n_blocks: int, group=None) -> np.ndarray:
+  """The mesh-boundary hand-off of the block chain as ONE tensor all-gather.
+
+  last_local: the last solved mesh [2, 1, y, x] of each of THIS rank's blocks
+  (round-robin deal), DeviceArrays / device tensors on the HIP path.  On an nccl
+  (= RCCL) group the meshes travel GPU to GPU over xGMI without touching the
+  host; on a gloo group as host tensors.  Returns [2, n_blocks, y, x] (host),
+  identical on every rank.
+  """
+  import torch
+  rank, ws = world(group)
+  tensors = []
+  for obj in last_local:
+    t = getattr(obj, 'tensor', obj)
+    if not isinstance(t, torch.Tensor):
+      t = torch.from_numpy(np.ascontiguousarray(np.asarray(t, dtype=np.float32)))
+    tensors.append(t.to(torch.float32))
+  if ws == 1:
+    return np.concatenate([t.cpu().numpy() for t in tensors], axis=1)
+  on_gpu = dist.get_backend(group) == 'nccl'
+  per = -(-n_blocks // ws)                      # blocks per rank, padded
+  ref = tensors[0]
+  if on_gpu and not ref.is_cuda:
+    ref = ref.cuda()
+  send = torch.zeros((per,) + tuple(ref.shape), dtype=torch.float32,
+                     device=ref.device if on_gpu else 'cpu')
+  for k, t in enumerate(tensors):
+    send[k].copy_(t)                            # device to device on the HIP path
+  parts = [torch.empty_like(send) for _ in range(ws)]
+  dist.all_gather(parts, send, group=group)
+  last = [None] * n_blocks
+  for r in range(ws):
+    host = parts[r].cpu().numpy()
+    for k, b in enumerate(shard_units(n_blocks, r, ws)):
+      last[b] = host[k]
+  return np.concatenate(last, axis=1)
 
 
 def align_sections_blocked(flow, config, stride, n_blocks=None, group=None,
-                           xblk_config=None, relax_fn=None, compose_fn=None):
+                           xblk_config=None, relax_fn=None, compose_fn=None,
+                           timing=None):
   """Block-parallel section alignment.
 
   flow: [2, n_sections, y, x] (every rank passes the same array, or at least
   its own blocks' sections).  Blocks are dealt round-robin to the ranks and
   solved independently; the last-section mesh of every block ([2, 1, y, x],
   336 KB for an 8192^2 section at stride 40) is the only data that crosses
-  ranks.  Returns (blocks: {block index: [2, n_b + 1, y, x]} of THIS rank,
+  ranks (`gather_boundaries`: one all-gather, device resident on RCCL).
+  Returns (blocks: {block index: [2, n_b + 1, y, x]} of THIS rank,
   last: [2, n_blocks, y, x] boundary meshes of all blocks, xblk: the solved
-  cross-block mesh [2, n_blocks, y, x], identical on every rank).
+  cross-block mesh [2, n_blocks, y, x], identical on every rank).  `timing`, a
+  dict, receives the seconds of the three phases (`solve_s`, `handoff_s`,
+  `xblk_s`; the hand-off includes waiting for the slowest rank).
   """
+  import time
   rank, ws = world(group)
   flow = np.asarray(flow, dtype=np.float32)
   n_blocks = ws if n_blocks is None else n_blocks
   ranges = block_ranges(flow.shape[1], n_blocks)
   mine = shard_units(n_blocks, rank, ws)
-  blocks = {b: solve_section_block(flow[:, ranges[b][0]:ranges[b][1]], config, stride,
-                                   relax_fn, compose_fn) for b in mine}
+
+  def sync():
+    try:
+      import torch
+      if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    except ImportError:
+      pass
+
+  t0 = time.perf_counter()
+  blocks, last_local = {}, []
+  for b in mine:
+    blocks[b], last_obj = solve_section_block(
+        flow[:, ranges[b][0]:ranges[b][1]], config, stride, relax_fn, compose_fn,
+        with_last=True)
+    last_local.append(last_obj)
+  if timing is not None:
+    sync()
+  t1 = time.perf_counter()
   # mesh-boundary exchange: last solved section of every block, to every rank
-  last_local = [blocks[b][:, -1] for b in mine]
-  last = [None] * n_blocks
-  for r, part in enumerate(gather_objects(last_local, group)):
-    for k, b in enumerate(shard_units(n_blocks, r, ws)):
-      last[b] = part[k]
-  last = np.stack(last, axis=1)
+  last = gather_boundaries(last_local, n_blocks, group)
+  t2 = time.perf_counter()
   # cross-block mesh: every block is a virtual section (notebook cell 47); it
   # is tiny, so every rank solves it redundantly instead of broadcasting it
   xcfg = xblk_config or config
@@ -638,4 +775,7 @@ def align_sections_blocked(flow, config, stride, n_blocks=None, group=None,
       prev = compose_fn(last[:, z:z + 1], origin, stride, xblk[-1], origin, stride)
     x, _, _ = relax_fn(np.zeros_like(last[:, 0:1]), prev, xcfg)
     xblk.append(np.array(x, dtype=np.float32))
+  if timing is not None:
+    sync()
+    timing.update(solve_s=t1 - t0, handoff_s=t2 - t1, xblk_s=time.perf_counter() - t2)
   return blocks, last, np.concatenate(xblk, axis=1)

@@ -288,6 +288,16 @@ def test_bench_runs_as_two_ranks(gpu):
   assert abs(line['value'] - want) <= 1e-6 * want
   assert line['roofline'] and line['mesh']['value'] > 0
   assert line['sustained']['steps'] >= 1
+  # the communicating legs are part of the default N > 1 line
+  mg = line['multi_gpu']
+  assert mg['ranks_seen'] == 2 and mg['backend'] == 'gloo'
+  chain = mg['section_chain']
+  assert chain['sections'] == 16 and chain['blocks'] == 2
+  assert chain['sections_per_s'] > 0 and chain['handoff_only_us'] > 0
+  assert chain['finite_fraction'] > 0.9
+  band = mg['mesh_sharded']
+  assert band['ranks'] == 2 and band['banded_us_per_step'] > 0
+  assert 'host-staged' in band['transport']
 
 
 def _two_rank_band_worker(rank, world_size, port, out_dir):
@@ -324,3 +334,81 @@ def test_two_ranks_with_hip_bands_share_one_gpu(gpu, tmp_path):
   for r in range(2):
     np.testing.assert_array_equal(np.load(tmp_path / f'x_{r}.npy'), wx)
     np.testing.assert_array_equal(np.load(tmp_path / f'e_{r}.npy'), np.array(we + [wt]))
+
+
+def _two_rank_c_loop_worker(rank, world_size, port, out_dir):
+  import os
+  import torch
+  import torch.distributed as dist
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world_size)
+  torch.cuda.set_device(0)
+  from sofima_amd import dist as sdist, mesh
+  rng = np.random.default_rng(5)
+  x3 = (rng.standard_normal((3, 6, 31, 12)) * 0.5).astype(np.float32)
+  p3 = (rng.standard_normal((3, 6, 31, 12)) * 4).astype(np.float32)
+  cfg3 = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(20, 20, 20),
+                                num_iters=40, max_iters=80, stop_v_max=1e-9, dt_max=1000,
+                                start_cap=0.01, final_cap=10)
+  cases = {
+      # fused tiled kernel in band mode, edge-first split on the second stream
+      'fused': (_case((2, 3, 75, 70), False), {}),
+      'fused_drift': (_case((2, 3, 75, 70), True, amp=6.0), {}),
+      'fused_serial': (_case((2, 2, 150, 64), True), {'overlap': False}),
+      'verlet': (_case((2, 2, 61, 47), False, fire=False), {}),
+      # advance / integrate pair inside the loop (narrow mesh, volumetric mesh)
+      'narrow': (_case((2, 2, 61, 33), True), {}),
+      'vol': ((x3, p3, cfg3), {'mesh_force': mesh.elastic_mesh_3d}),
+  }
+  for name, ((x0, prev, cfg), kw) in cases.items():
+    timing = {}
+    gx, ge, gt = sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=2, transport='host',
+                                         timing=timing, **kw)
+    np.save(os.path.join(out_dir, f'{name}_x_{rank}.npy'), gx)
+    np.save(os.path.join(out_dir, f'{name}_e_{rank}.npy'), np.array(ge + [gt]))
+    calls = timing['host_calls']
+    # one exchange at the head of every chunk + one per step; one all-gather of
+    # the sums per step (FIRE only) + one of the chunk statistics
+    chunks = gt // cfg.num_iters
+    assert calls['halo'] == chunks * (cfg.num_iters + 1), calls
+    assert calls['allgather'] == chunks * ((cfg.num_iters if cfg.fire else 0) + 1), calls
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_ranks_drive_the_c_banded_loop_on_one_gpu(gpu, tmp_path):
+  """The INTER-RANK branch of sfm_mesh_relax_banded (peer indexing, packed edge
+  rows, in-place all-gather with two bands per rank, edge-first split on the
+  second stream) with a transport that works between two processes sharing
+  this GPU: the library stages rows and sums through the host, gloo moves them
+  (SfmBandedDesc.host_halo / host_allgather).  2 ranks x 2 bands == 1 process x
+  4 bands through the same C loop, bit for bit, on both ranks."""
+  import socket
+  import torch.multiprocessing as mp
+  from sofima_amd import dist as sdist, mesh
+  sock = socket.socket()
+  sock.bind(('127.0.0.1', 0))
+  port = sock.getsockname()[1]
+  sock.close()
+  mp.spawn(_two_rank_c_loop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  rng = np.random.default_rng(5)
+  x3 = (rng.standard_normal((3, 6, 31, 12)) * 0.5).astype(np.float32)
+  p3 = (rng.standard_normal((3, 6, 31, 12)) * 4).astype(np.float32)
+  cfg3 = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(20, 20, 20),
+                                num_iters=40, max_iters=80, stop_v_max=1e-9, dt_max=1000,
+                                start_cap=0.01, final_cap=10)
+  cases = {
+      'fused': (_case((2, 3, 75, 70), False), {}),
+      'fused_drift': (_case((2, 3, 75, 70), True, amp=6.0), {}),
+      'fused_serial': (_case((2, 2, 150, 64), True), {'overlap': False}),
+      'verlet': (_case((2, 2, 61, 47), False, fire=False), {}),
+      'narrow': (_case((2, 2, 61, 33), True), {}),
+      'vol': ((x3, p3, cfg3), {'mesh_force': mesh.elastic_mesh_3d}),
+  }
+  for name, ((x0, prev, cfg), kw) in cases.items():
+    wx, we, wt = sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=4, **kw)
+    for r in range(2):
+      np.testing.assert_array_equal(np.load(tmp_path / f'{name}_x_{r}.npy'), wx, err_msg=name)
+      np.testing.assert_array_equal(np.load(tmp_path / f'{name}_e_{r}.npy'),
+                                    np.array(we + [wt]), err_msg=name)

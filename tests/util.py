@@ -91,3 +91,56 @@ def synth_montage(rng, gx, gy, mesh_shape, overlap, amp=4.0):
     if ty < gy - 1:
       nb[t, k] = entry(t + gx, t, 1, fy, *offs_y[t]); k += 1
   return nb, fx, fy, x0
+
+
+# ---------------------------------------------------------------------------
+# The CPU oracle on many reference batches at once: one SPAWNED process per
+# batch (no HIP context is inherited), images handed over as memory-mapped .npy
+# files.  Test infrastructure only.
+# ---------------------------------------------------------------------------
+_ORACLE_ARGS = {}
+
+
+def _oracle_init(paths, kwargs):
+  _ORACLE_ARGS['arrays'] = {k: (None if p is None else np.load(p, mmap_mode='r'))
+                            for k, p in paths.items()}
+  _ORACLE_ARGS['kwargs'] = kwargs
+
+
+def _oracle_batch(b):
+  from oracle import flow_oracle
+  a = _ORACLE_ARGS['arrays']
+  kw = dict(_ORACLE_ARGS['kwargs'])
+  out = flow_oracle.flow_field(np.asarray(a['pre']), np.asarray(a['post']),
+                               pre_mask=None if a['pre_mask'] is None else np.asarray(a['pre_mask']),
+                               post_mask=None if a['post_mask'] is None else np.asarray(a['post_mask']),
+                               only_batches=(b,), **kw)
+  flat = out.reshape(out.shape[0], -1)
+  bs = kw['batch_size']
+  return b, flat[:, b * bs:(b + 1) * bs].copy()
+
+
+def oracle_flow_batches(tmp_dir, pre, post, patch_size, step, batch_size, batches,
+                        pre_mask=None, post_mask=None, procs=None, fft_workers=None,
+                        **kwargs):
+  """flow_oracle.flow_field on the reference batches `batches` (indices into
+  the row-major list of grid positions -- valid when no patch is dropped by a
+  mask, which the callers assert), in parallel.  Returns {batch: [dim + 2, n]}."""
+  import multiprocessing as mp
+  import os
+  cores = os.cpu_count() or 1
+  procs = procs or max(1, min(len(batches), cores // 4, 24))
+  fft_workers = fft_workers or max(1, min(16, cores // procs))
+  paths = {}
+  for name, arr in (('pre', pre), ('post', post), ('pre_mask', pre_mask),
+                    ('post_mask', post_mask)):
+    if arr is None:
+      paths[name] = None
+    else:
+      paths[name] = os.path.join(str(tmp_dir), name + '.npy')
+      np.save(paths[name], arr)
+  kw = dict(patch_size=patch_size, step=step, batch_size=batch_size,
+            workers=fft_workers, **kwargs)
+  with mp.get_context('spawn').Pool(procs, initializer=_oracle_init,
+                                    initargs=(paths, kw)) as pool:
+    return dict(pool.imap_unordered(_oracle_batch, list(batches)))
