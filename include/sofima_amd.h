@@ -77,11 +77,9 @@ int sfm_device_count(int* count);
  *   SFM_MASKED_DEADROWS=0 no overlap-rule skips in the masked assembly
  *   SFM_PHASE_XCD=0       masked assembly without the XCD-aware tile order
  *   SFM_MESH_PERSISTENT=0 / SFM_MESH_SPECULATE=0 / SFM_MESH_TILED=0 /
- *   SFM_MESH_SHARED=0 / SFM_MESH_SMALL=0 / SFM_MESH_FUSE_TARGET=0
+ *   SFM_MESH_SMALL=0 / SFM_MESH_FUSE_TARGET=0
  *                         fall back to the simpler integrator
  *   SFM_MESH_TILE=16|32   tile edge of the persistent integrator
- *   SFM_MESH_GRAPH=1 / SFM_MESH_MARCH=1 / SFM_MESH_BRICKS=1   measured-slower
- *                         experiments (hipGraph replay, z-marching, bricks)
  *   SFM_MESH_XCD=0|1      tiled in-plane step: one contiguous run of tiles per
  *                         XCD never / always (default: from 2048 tiles on)   */
 int sfm_set_option(const char* name, const char* value);

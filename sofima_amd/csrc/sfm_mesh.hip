@@ -52,9 +52,6 @@ constexpr int kMaxBlocks = 1024;
 #ifndef SFM_LB_SHARED
 #define SFM_LB_SHARED 4
 #endif
-#ifndef SFM_LBT
-#define SFM_LBT 1
-#endif
 constexpr int kNP = 8;  // partials per block: power, sx[3], sv[3], pad
 
 struct MeshParams {
@@ -823,237 +820,27 @@ __device__ __forceinline__ void tile_tail_gather(const u64* __restrict__ partial
 }
 
 // ---------------------------------------------------------------------------
-// LDS-tiled step for large in-plane meshes (state far beyond the caches).
+// Tiled step for large in-plane meshes (state far beyond the caches), every
+// spring evaluated ONCE.
 //
-// One workgroup owns a TY x TX tile of one section.  It loads x (FUSED: and
-// v, a) of the tile plus a one-node halo with coalesced loads that are all in
-// flight together, keeps the positions in LDS for the 8-neighbour stencil and
-// writes x, v, a of its own nodes once: ~59 bytes per node update against the
-// algorithmic 56 (the multi-launch pair moves 88 and waits for every
-// neighbour load separately).
-//
-// FUSED = true is the whole FIRE / Verlet step in one launch: the position
-// update x += dt v + dt^2/2 a of the halo nodes is recomputed from the
-// neighbours' (x, v, a), so the state ping-pongs between two buffer sets.
-// FUSED = false integrates positions that advance_kernel (and the native
-// prev_fn) already produced, in place.
-//
-// The per-tile partial sums are reduced by the LAST workgroup to finish (ticket
-// counter), in row order, so the result does not depend on which one is last;
+// One workgroup owns a 16 x 62 tile of one section.  It loads x (FUSED: and v,
+// a) of the tile plus a one-node halo with coalesced loads that are all in
+// flight together and writes x, v, a of its own nodes once: ~59 bytes per node
+// update against the algorithmic 56 (the advance / integrate pair moves 88 and
+// waits for every neighbour load separately).  FUSED = true is the whole FIRE /
+// Verlet step in one launch: the position update x += dt v + dt^2/2 a of the
+// halo nodes is recomputed from the neighbours' (x, v, a), so the state
+// ping-pongs between two buffer sets.  FUSED = false integrates positions that
+// advance_kernel (and the native prev_fn) already produced, in place.  The
+// per-tile partial sums are reduced by the LAST workgroup to finish (ticket
+// counter), in tile order, so the result does not depend on which one is last;
 // it leaves the updated FIRE scalars for the next launch.
-// ---------------------------------------------------------------------------
-template <int TY, int TX, bool FUSED>
-__global__ void __launch_bounds__(kBlock, SFM_LBT)
-integrate_tiled2d_kernel(const float* x_in, const float* v_in, const float* a_in,
-                         const float* __restrict__ prev, float* x_out, float* v_out,
-                         float* a_out, MeshParams p,
-                         const Scalars* __restrict__ scal_in,
-                         Scalars* __restrict__ scal_out, float fixed_cap,
-                         u64* __restrict__ partials, int* __restrict__ ticket,
-                         int pending, int nty, int ntx) {
-  constexpr int C = 2;
-  constexpr int TW = TX + 2;
-  constexpr int kRows = TY * TX / kBlock;  // nodes per thread
-  constexpr int kRowStep = kBlock / TX;
-  static_assert(TY * TX % kBlock == 0 && kBlock % TX == 0, "tile shape");
-  __shared__ float xt[C][(TY + 2) * TW];
-  __shared__ float lds[kNP * kBlock];
-  __shared__ int s_last;
-  // step counter in device memory (advanced by the reducing workgroup), so
-  // that a launch has no per-step argument and steps can be replayed from a
-  // hipGraph
-  const unsigned epoch = static_cast<unsigned>(ticket[1]) + 1u;
-
-  Scalars s;
-  if (p.fire) {
-    s = *scal_in;
-    if (!pending) {
-      s.gate = 1.f;
-      for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
-    }
-  } else {
-    s.dt = p.vv_dt;
-    s.alpha = 0.f;
-    s.cap = fixed_cap;
-    s.gate = 1.f;
-    for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
-  }
-  const float dt = s.dt, alpha = s.alpha, cap = s.cap;
-  const float c2 = 0.5f * (dt * dt);
-  const bool fix = p.fire && pending;
-
-  const int tx = blockIdx.x % ntx;
-  const int ty = (blockIdx.x / ntx) % nty;
-  const long long plane = blockIdx.x / (ntx * nty);  // b * Z + z
-  const long long base = plane * p.Y * p.X;
-  const int gx0 = tx * TX, gy0 = ty * TY;
-
-  // Position of one node after the position update (FUSED) / as stored.
-  auto advanced = [&](long long n, int c, float* v_keep, float* a_keep) -> float {
-    float xv = x_in[c * p.N + n];
-    if (!FUSED) return xv;
-    float vv = v_in[c * p.N + n];
-    const float aa = a_in[c * p.N + n];
-    if (fix) {
-      vv = vv * s.gate;
-      if (p.remove_drift) {
-        xv = xv - s.mx[c];
-        vv = vv - s.mv[c];
-      }
-    }
-    if (v_keep) *v_keep = vv;
-    if (a_keep) *a_keep = aa;
-    return xv + (dt * vv + c2 * aa);
-  };
-
-  const int lx = threadIdx.x % TX, ly0 = threadIdx.x / TX;
-  float v_own[kRows][C], a_own[kRows][C], x_own[kRows][C];
-  // Loads from clamped coordinates, unconditional: a load under a per-lane
-  // condition gets its own block and the rows would be fetched one after the
-  // other (nodes beyond the mesh read a neighbour's state; never stored).
-#pragma unroll
-  for (int k = 0; k < kRows; ++k) {
-    const int ly = ly0 + k * kRowStep;
-    const int gy = min(gy0 + ly, p.Y - 1), gx = min(gx0 + lx, p.X - 1);
-    const long long n = base + (long long)gy * p.X + gx;
-#pragma unroll
-    for (int c = 0; c < C; ++c) x_own[k][c] = advanced(n, c, &v_own[k][c], &a_own[k][c]);
-  }
-#pragma unroll
-  for (int k = 0; k < kRows; ++k) {
-    const int ly = ly0 + k * kRowStep;
-    if (gy0 + ly < p.Y && gx0 + lx < p.X) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) xt[c][(ly + 1) * TW + lx + 1] = x_own[k][c];
-    }
-  }
-  constexpr int kHalo = 2 * TW + 2 * TY;
-  for (int h = threadIdx.x; h < kHalo; h += kBlock) {
-    int hy, hx;  // tile coordinates in [-1, TY] x [-1, TX]
-    if (h < TW) {
-      hy = -1;
-      hx = h - 1;
-    } else if (h < 2 * TW) {
-      hy = TY;
-      hx = h - TW - 1;
-    } else {
-      const int r = h - 2 * TW;
-      hy = r >> 1;
-      hx = (r & 1) ? TX : -1;
-    }
-    const int gy = gy0 + hy, gx = gx0 + hx;
-    const bool inside = gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X;
-    const long long n = base + (long long)min(max(gy, 0), p.Y - 1) * p.X + min(max(gx, 0), p.X - 1);
-    float hv[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) hv[c] = advanced(n, c, nullptr, nullptr);
-    if (inside) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) xt[c][(hy + 1) * TW + hx + 1] = hv[c];
-    }
-  }
-  __syncthreads();
-
-  const float hdtg = (0.5f * dt) * p.gamma;
-  const float fact0 = 1.0f / (1.0f + hdtg);
-  const float fact1 = 1.0f - hdtg;
-  const float hdt = 0.5f * dt;
-  float l0[4];
-#pragma unroll
-  for (int L = 0; L < 4; ++L) l0[L] = vec_len(p.rest[L], 2);
-  float part[kNP];
-  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
-  // the remaining per-node inputs, again all requested up front
-  float pv_own[kRows][C];
-#pragma unroll
-  for (int k = 0; k < kRows; ++k) {
-    const int gy = min(gy0 + ly0 + k * kRowStep, p.Y - 1), gx = min(gx0 + lx, p.X - 1);
-    const long long n = base + (long long)gy * p.X + gx;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      pv_own[k][c] = p.has_prev ? prev[c * p.N + n] : 0.f;
-      if (!FUSED) {
-        a_own[k][c] = a_in[c * p.N + n];
-        v_own[k][c] = v_in[c * p.N + n];
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < kRows; ++k) {
-    const int ly = ly0 + k * kRowStep;
-    const int gy = gy0 + ly, gx = gx0 + lx;
-    if (gy >= p.Y || gx >= p.X) continue;
-    const long long n = base + (long long)gy * p.X + gx;
-    const int ctr = (ly + 1) * TW + lx + 1;
-    float f[C], vn[C];
-    node_force_tile2d<TW>(xt[0], xt[1], ctr, p, gx, gy, x_own[k][0], x_own[k][1], l0, f);
-    float a2 = 0.f, v2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float xv = x_own[k][c];
-      if (p.has_prev) f[c] = f[c] + prev_pull(xv, pv_own[k][c], p.neg_k0, cap);
-      const float a_old = a_own[k][c];
-      const float v_old = v_own[k][c];
-      vn[c] = fact0 * (v_old * fact1 + hdt * (a_old + f[c]));
-      a_out[c * p.N + n] = f[c];
-      if (FUSED) x_out[c * p.N + n] = xv;
-      a2 = a2 + f[c] * f[c];
-      v2 = v2 + vn[c] * vn[c];
-      if (p.fire) {
-        part[0] = part[0] + f[c] * vn[c];
-        part[1 + c] = part[1 + c] + xv;
-      }
-    }
-    if (p.fire) {
-      const float a_norm = sqrtf(a2) + 1e-6f;
-      const float v_norm = sqrtf(v2);
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
-        part[4 + c] = part[4 + c] + vn[c];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) v_out[c * p.N + n] = vn[c];
-  }
-  if (!p.fire) return;
-  block_sum(part, 7, lds);
-  // Hand-off without cache fences (a release fence would write back the whole
-  // L2 of this XCD, once per workgroup): every partial is an 8-byte
-  // {epoch, value} granule stored write-through at agent scope, so the datum
-  // is its own flag; the ticket only elects the reducing workgroup.
-  if (threadIdx.x == 0) {
-    for (int i = 0; i < 7; ++i)
-      __hip_atomic_store(&partials[blockIdx.x * kNP + i],
-                         (static_cast<u64>(epoch) << 32) | __float_as_uint(part[i]),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged before the ticket
-    s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT) ==
-             static_cast<int>(gridDim.x) - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  float acc[kNP];
-  tile_tail_gather(partials, static_cast<int>(gridDim.x), p.remove_drift ? 7 : 1, epoch, acc);
-  block_sum(acc, 7, lds);
-  if (threadIdx.x == 0) {
-    Scalars in = *scal_in, o;
-    scalars_from_sums(in, acc, p, &o);
-    *scal_out = o;
-    ticket[1] = static_cast<int>(epoch);
-    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// In-plane step with every spring evaluated ONCE.
 //
 // A spring between node n and n + dir is the "near side" term of n and the "far
 // side" term of n + dir: the same d = x[n + dir] - x[n] + rest, the same force,
 // bit for bit (mesh.py:107-169 adds it to one end and subtracts it from the
-// other).  integrate_tiled2d_kernel evaluates it at both ends: 8 evaluations
-// of ~54 VALU slots per node, which is what bounds that kernel.  Here a lane
+// other).  Evaluating it at both ends costs 8 evaluations of ~54 VALU slots per
+// node (the first tiled kernel of this file, rounds 1-2, did).  Here a lane
 // owns one COLUMN of a 16-row tile (a wave = 4 consecutive rows x 64 columns:
 // 62 owned + the two halo columns), evaluates only the four near-side springs
 // of its nodes (and three of the row above its rows), and receives the
@@ -1433,7 +1220,7 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
   }
   if (!p.fire) return;
   block_sum(part, 7, lds);
-  // (hand-off as in integrate_tiled2d_kernel)
+  // (hand-off to the last workgroup: see the header)
   if (threadIdx.x == 0) {
     for (int i = 0; i < 7; ++i)
       __hip_atomic_store(&partials[tile * kNP + i],
@@ -1456,558 +1243,6 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
       scalars_from_sums(in, acc, p, &o);
       *scal_out = o;
     }
-    ticket[1] = static_cast<int>(epoch);
-    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Volumetric force + velocity update with every spring evaluated ONCE
-// (replaces integrate_kernel<3> for the 13 default links).
-//
-// As in integrate_shared2d_kernel a spring is the near-side term of one end
-// and the far-side term of the other, bit for bit.  A workgroup of 8 waves owns
-// a 6 x 62 patch of (y, x) columns -- wave = row -1 .. 6, lane = column -1 ..
-// 62, the outer ones are halo rows / columns that only evaluate the springs
-// their neighbours need -- and MARCHES along z.  At plane z a thread evaluates
-// the 13 springs from its node towards +dir (link 10 = (1,1,-1) from its far
-// end, so that every spring of the plane pair (z, z+1) is formed at plane z):
-//   same row, same plane (link 0)          -> neighbour lane, DPP wave shift
-//   row + 1, same plane (links 1, 3, 4)    -> LDS, read after a barrier
-//   same row, next plane (links 2, 5, 6)   -> kept in registers (+ wave shift)
-//   row +- 1, next plane (7, 9, 12 / 8, 11, 10) -> LDS, read one plane later
-// 13 evaluations per node (+ the halo rows: 14.5) instead of 26.  Positions of
-// three planes rotate through LDS.  The sums follow the reference's order
-// (per link: += far side, -= near side), so the forces are bit-identical to
-// node_force_default3d.  z is cut into segments (one workgroup each) to fill
-// the chip; a segment starts by forming the springs of the plane below it.
-// ---------------------------------------------------------------------------
-constexpr int kMW = 8, kMRows = kMW - 2, kMCols = 62;
-constexpr int kMThreads = 64 * kMW;
-constexpr int kMPosFloats = 3 * 3 * kMW * 64;   // three planes
-constexpr int kMExBFloats = 9 * kMW * 64;
-constexpr int kMExNFloats = 18 * kMW * 64;
-constexpr size_t kMarchLds = (kMPosFloats + kMExBFloats + kMExNFloats) * sizeof(float);
-
-__global__ void __launch_bounds__(kMThreads)
-integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
-                         float* __restrict__ a, const float* __restrict__ prev, MeshParams p,
-                         const Scalars* __restrict__ scal, float fixed_cap,
-                         float* __restrict__ partials, int nty, int ntx, int nseg,
-                         int seg_planes) {
-  extern __shared__ float march_lds[];
-  float* pos = march_lds;                    // [3][3][kMW][64]
-  float* exB = pos + kMPosFloats;            // [9][kMW][64]
-  float* exN = exB + kMExBFloats;            // [18][kMW][64]
-  constexpr int C = 3;
-  float dt, alpha, cap;
-  if (p.fire) {
-    dt = scal->dt;
-    alpha = scal->alpha;
-    cap = scal->cap;
-  } else {
-    dt = p.vv_dt;
-    alpha = 0.f;
-    cap = fixed_cap;
-  }
-  const float hdtg = (0.5f * dt) * p.gamma;
-  const float fact0 = 1.0f / (1.0f + hdtg);
-  const float fact1 = 1.0f - hdtg;
-  const float hdt = 0.5f * dt;
-
-  int t = blockIdx.x;
-  const int seg = t % nseg;
-  t /= nseg;
-  const int tx = t % ntx;
-  t /= ntx;
-  const int ty = t % nty;
-  const long long batch = t / nty;
-  const long long vol = (long long)p.Z * p.Y * p.X;
-  const long long base = batch * vol;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gx = tx * kMCols + lane - 1, gy = ty * kMRows + wave - 1;
-  const int gxc = min(max(gx, 0), p.X - 1), gyc = min(max(gy, 0), p.Y - 1);
-  const bool own_col = lane >= 1 && lane <= kMCols && gx < p.X;
-  const bool own_row = wave >= 1 && wave <= kMRows && gy < p.Y;
-  const int z0 = seg * seg_planes, z1 = min(p.Z, z0 + seg_planes);
-  if (z0 >= p.Z) return;  // whole workgroup
-
-  const DefLinks3 dl(p);
-
-  auto pos_at = [&](int plane, int c, int w, int l) -> float& {
-    return pos[((plane % 3) * 3 + c) * (kMW * 64) + w * 64 + l];
-  };
-  auto load_plane = [&](int zz, float* out) {
-    const long long n = base + ((long long)min(max(zz, 0), p.Z - 1) * p.Y + gyc) * p.X + gxc;
-#pragma unroll
-    for (int c = 0; c < C; ++c) out[c] = x[c * p.N + n];
-  };
-  const int z_first = z0 > 0 ? z0 - 1 : 0;
-  {
-    float q0[C], q1[C];
-    load_plane(z_first, q0);
-    load_plane(z_first + 1, q1);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      pos_at(z_first, c, wave, lane) = q0[c];
-      pos_at(z_first + 1, c, wave, lane) = q1[c];
-    }
-  }
-  __syncthreads();
-
-  const int wp = min(wave + 1, kMW - 1), wm = max(wave - 1, 0);
-  const int lp = min(lane + 1, 63), lm = max(lane - 1, 0);
-  const bool xm = gx - 1 >= 0, xp = gx + 1 < p.X, ym = gy - 1 >= 0, yp = gy + 1 < p.Y;
-  float c2[C] = {0.f, 0.f, 0.f}, c5[C] = {0.f, 0.f, 0.f}, c6[C] = {0.f, 0.f, 0.f};
-  float part[kNP];
-  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
-
-  for (int z = z_first; z < z1; ++z) {
-    const bool pre = z < z0;  // only the springs towards plane z0 are formed
-    // ---- phase 0: loads of this iteration, all issued now
-    float q2[C];
-    load_plane(z + 2, q2);
-    const long long n = base + ((long long)z * p.Y + gyc) * p.X + gxc;
-    float v_old[C], a_old[C], pv[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      v_old[c] = v[c * p.N + n];
-      a_old[c] = a[c * p.N + n];
-      pv[c] = p.has_prev ? prev[c * p.N + n] : 0.f;
-    }
-    // ---- phase 1: the springs of this node
-    float self[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) self[c] = pos_at(z, c, wave, lane);
-    float n0[C] = {}, n1[C] = {}, n3[C] = {}, n4[C] = {}, n2[C] = {}, n5[C] = {}, n6[C] = {},
-          n7[C] = {}, n9[C] = {}, n12[C] = {}, n8[C] = {}, n11[C] = {}, f10[C] = {};
-#define SFM_NEAR3(OUT, L, DX, DY, DZ, PL, W, LN)                                          \
-    {                                                                                     \
-      float d_[3];                                                                        \
-      constexpr int dd_[3] = {DX, DY, DZ};                                                \
-      _Pragma("unroll") for (int c = 0; c < 3; ++c)                                       \
-          d_[c] = pos_at(PL, c, W, LN) - self[c] + dl.rest(dd_[c], c);                    \
-      spring_xyz<DX, DY, DZ>(d_, dl.l0c[SFM_CLASS3(DX, DY, DZ)],                          \
-                             dl.nkc[SFM_CLASS3(DX, DY, DZ)], p.prefer, OUT);              \
-    }
-    const bool rows_all = wave >= 1 && wave <= kMRows;  // owned rows: every spring
-    const bool row_lo = wave == 0, row_hi = wave == kMW - 1;
-    if (rows_all && !pre) SFM_NEAR3(n0, 0, 1, 0, 0, z, wave, lp)
-    if ((rows_all || row_lo) && !pre) {
-      SFM_NEAR3(n1, 1, 0, 1, 0, z, wp, lane)
-      SFM_NEAR3(n3, 3, 1, 1, 0, z, wp, lp)
-      SFM_NEAR3(n4, 4, -1, 1, 0, z, wp, lm)
-    }
-    if (rows_all) {
-      SFM_NEAR3(n2, 2, 0, 0, 1, z + 1, wave, lane)
-      SFM_NEAR3(n5, 5, 1, 0, 1, z + 1, wave, lp)
-      SFM_NEAR3(n6, 6, -1, 0, 1, z + 1, wave, lm)
-    }
-    if (rows_all || row_lo) {
-      SFM_NEAR3(n7, 7, 0, 1, 1, z + 1, wp, lane)
-      SFM_NEAR3(n9, 9, 1, 1, 1, z + 1, wp, lp)
-      SFM_NEAR3(n12, 12, -1, 1, 1, z + 1, wp, lm)
-    }
-    if (rows_all || row_hi) {
-      SFM_NEAR3(n8, 8, 0, -1, 1, z + 1, wm, lane)
-      SFM_NEAR3(n11, 11, 1, -1, 1, z + 1, wm, lp)
-      // link 10 = (1, 1, -1) from its far end b = this node: a = (x-1, y-1, z+1)
-      float d_[3];
-      constexpr int d10[3] = {1, 1, -1};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) d_[c] = self[c] - pos_at(z + 1, c, wm, lm) + dl.rest(d10[c], c);
-      spring_xyz<1, 1, -1>(d_, dl.l0c[6], dl.nkc[6], p.prefer, f10);
-    }
-#undef SFM_NEAR3
-    // terms that arrived from the plane below (written one iteration ago)
-    float fd7[C], fd9[C], fd12[C], fe8[C], fe11[C], nf10[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      fd7[c] = exN[((0 * 3 + c) * kMW + wave) * 64 + lane];
-      fd9[c] = exN[((1 * 3 + c) * kMW + wave) * 64 + lm];
-      fd12[c] = exN[((2 * 3 + c) * kMW + wave) * 64 + lp];
-      fe8[c] = exN[((3 * 3 + c) * kMW + wave) * 64 + lane];
-      fe11[c] = exN[((4 * 3 + c) * kMW + wave) * 64 + lm];
-      nf10[c] = exN[((5 * 3 + c) * kMW + wave) * 64 + lp];
-    }
-    __syncthreads();  // A: everyone has read the old exchange slots and plane z
-    // ---- phase 2: publish
-    if (wave + 1 < kMW) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        if (!pre) {
-          exB[((0 * 3 + c) * kMW + wave + 1) * 64 + lane] = n1[c];
-          exB[((1 * 3 + c) * kMW + wave + 1) * 64 + lane] = n3[c];
-          exB[((2 * 3 + c) * kMW + wave + 1) * 64 + lane] = n4[c];
-        }
-        exN[((0 * 3 + c) * kMW + wave + 1) * 64 + lane] = n7[c];
-        exN[((1 * 3 + c) * kMW + wave + 1) * 64 + lane] = n9[c];
-        exN[((2 * 3 + c) * kMW + wave + 1) * 64 + lane] = n12[c];
-      }
-    }
-    if (wave >= 1) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        exN[((3 * 3 + c) * kMW + wave - 1) * 64 + lane] = n8[c];
-        exN[((4 * 3 + c) * kMW + wave - 1) * 64 + lane] = n11[c];
-        exN[((5 * 3 + c) * kMW + wave - 1) * 64 + lane] = f10[c];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) pos_at(z + 2, c, wave, lane) = q2[c];
-    // far-side terms that travel along the row: every lane takes part
-    float f0[C], fc5[C], fc6[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      f0[c] = lane_left(n0[c]);
-      fc5[c] = lane_left(c5[c]);
-      fc6[c] = lane_right(c6[c]);
-    }
-    __syncthreads();  // B: exchange slots and plane z + 2 are in place
-    // ---- phase 3: this node's force and velocity
-    if (!pre && own_col && own_row) {
-      float f1[C], f3[C], f4[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        f1[c] = exB[((0 * 3 + c) * kMW + wave) * 64 + lane];
-        f3[c] = exB[((1 * 3 + c) * kMW + wave) * 64 + lm];
-        f4[c] = exB[((2 * 3 + c) * kMW + wave) * 64 + lp];
-      }
-      const bool zm = z - 1 >= 0, zp = z + 1 < p.Z;
-      float f[C] = {0.f, 0.f, 0.f}, vn[C];
-#define SFM_ADD(FAR, OKF, NEAR, OKN)                                           \
-      _Pragma("unroll") for (int c = 0; c < 3; ++c) {                          \
-        f[c] = f[c] + ((OKF) ? FAR[c] : 0.f);                                  \
-        f[c] = f[c] - ((OKN) ? NEAR[c] : 0.f);                                 \
-      }
-      SFM_ADD(f0, xm, n0, xp)                         // 0: ( 1, 0, 0)
-      SFM_ADD(f1, ym, n1, yp)                         // 1: ( 0, 1, 0)
-      SFM_ADD(c2, zm, n2, zp)                         // 2: ( 0, 0, 1)
-      SFM_ADD(f3, xm && ym, n3, xp && yp)             // 3: ( 1, 1, 0)
-      SFM_ADD(f4, xp && ym, n4, xm && yp)             // 4: (-1, 1, 0)
-      SFM_ADD(fc5, xm && zm, n5, xp && zp)            // 5: ( 1, 0, 1)
-      SFM_ADD(fc6, xp && zm, n6, xm && zp)            // 6: (-1, 0, 1)
-      SFM_ADD(fd7, ym && zm, n7, yp && zp)            // 7: ( 0, 1, 1)
-      SFM_ADD(fe8, yp && zm, n8, ym && zp)            // 8: ( 0,-1, 1)
-      SFM_ADD(fd9, xm && ym && zm, n9, xp && yp && zp)      // 9: ( 1, 1, 1)
-      SFM_ADD(f10, xm && ym && zp, nf10, xp && yp && zm)    // 10: ( 1, 1,-1)
-      SFM_ADD(fe11, xm && yp && zm, n11, xp && ym && zp)    // 11: ( 1,-1, 1)
-      SFM_ADD(fd12, xp && ym && zm, n12, xm && yp && zp)    // 12: (-1, 1, 1)
-#undef SFM_ADD
-      const long long nn = base + ((long long)z * p.Y + gy) * p.X + gx;
-      const bool own = gy >= p.own_y0 && gy < p.own_y1;
-      float a2 = 0.f, v2 = 0.f;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float xv = self[c];
-        if (p.has_prev) f[c] = f[c] + prev_pull(xv, pv[c], p.neg_k0, cap);
-        vn[c] = fact0 * (v_old[c] * fact1 + hdt * (a_old[c] + f[c]));
-        a[c * p.N + nn] = f[c];
-        a2 = a2 + f[c] * f[c];
-        v2 = v2 + vn[c] * vn[c];
-        if (p.fire && own) {
-          part[0] = part[0] + f[c] * vn[c];
-          part[1 + c] = part[1 + c] + xv;
-        }
-      }
-      if (p.fire) {
-        const float a_norm = sqrtf(a2) + 1e-6f;
-        const float v_norm = sqrtf(v2);
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
-          if (own) part[4 + c] = part[4 + c] + vn[c];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < C; ++c) v[c * p.N + nn] = vn[c];
-    }
-    // the springs towards the next plane stay with this thread
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      c2[c] = n2[c];
-      c5[c] = n5[c];
-      c6[c] = n6[c];
-    }
-  }
-  if (!p.fire) return;
-  // fixed-order reduction over the workgroup (scratch: the exchange slots)
-  __syncthreads();
-  float* red = exN;
-  for (int i = 0; i < 7; ++i) red[i * kMThreads + threadIdx.x] = part[i];
-  __syncthreads();
-  for (int st = kMThreads / 2; st > 0; st >>= 1) {
-    if (threadIdx.x < st)
-      for (int i = 0; i < 7; ++i)
-        red[i * kMThreads + threadIdx.x] =
-            red[i * kMThreads + threadIdx.x] + red[i * kMThreads + threadIdx.x + st];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0)
-    for (int i = 0; i < kNP; ++i) partials[blockIdx.x * kNP + i] = i < 7 ? red[i * kMThreads] : 0.f;
-}
-
-// ---------------------------------------------------------------------------
-// LDS-tiled fused step for volumetric meshes (elastic_mesh_3d with the 13
-// default links).  The multi-launch path re-reads 78 neighbour values per node
-// through L1 / L2 (26 springs x 3 components) and needs two launches per step;
-// here one workgroup owns a TZ x TY x TX brick, loads (x, v, a) of the brick
-// and of its one-node shell once, applies the position update to all of them
-// (the shell's update is recomputed from the neighbours' state, like
-// integrate_tiled2d_kernel<.., FUSED>), keeps the advanced positions in LDS for
-// the 26-neighbour stencil and writes x, v, a of its own nodes to the second
-// buffer set: the whole FIRE / Verlet step is ONE launch.
-// ---------------------------------------------------------------------------
-constexpr int kTZ3 = 8, kTY3 = 8, kTX3 = 16;
-
-__global__ void __launch_bounds__(kBlock)
-integrate_tiled3d_kernel(const float* x_in, const float* v_in, const float* a_in,
-                         const float* __restrict__ prev, float* x_out, float* v_out,
-                         float* a_out, MeshParams p, const Scalars* __restrict__ scal_in,
-                         Scalars* __restrict__ scal_out, float fixed_cap,
-                         u64* __restrict__ partials, int* __restrict__ ticket, int pending,
-                         int ntz, int nty, int ntx, const float* __restrict__ colmean) {
-  constexpr int C = 3;
-  constexpr int PZ = kTZ3 + 2, PY = kTY3 + 2, PX = kTX3 + 2;
-  constexpr int kCells = PZ * PY * PX;
-  constexpr int kOwn = kTZ3 * kTY3 * kTX3 / kBlock;  // nodes per thread
-  static_assert(kTZ3 * kTY3 * kTX3 % kBlock == 0, "brick shape");
-  __shared__ float xt[C][kCells];
-  __shared__ float lds[kNP * kBlock];
-  __shared__ int s_last;
-  const unsigned epoch = static_cast<unsigned>(ticket[1]) + 1u;
-
-  Scalars s;
-  if (p.fire) {
-    s = *scal_in;
-    if (!pending) {
-      s.gate = 1.f;
-      for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
-    }
-  } else {
-    s.dt = p.vv_dt;
-    s.alpha = 0.f;
-    s.cap = fixed_cap;
-    s.gate = 1.f;
-    for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
-  }
-  const float dt = s.dt, alpha = s.alpha, cap = s.cap;
-  const float c2 = 0.5f * (dt * dt);
-  const bool fix = p.fire && pending;
-  // pending per-x-column drift means (5-D states): colsum[c][xi] = mean of x,
-  // colsum[3 + c][xi] = mean of v over the column, left by drift_cols_kernel
-  const bool fix_cols = fix && p.drift_cols;
-
-  int t = blockIdx.x;
-  const int tx = t % ntx;
-  t /= ntx;
-  const int ty = t % nty;
-  t /= nty;
-  const int tz = t % ntz;
-  const long long batch = t / ntz;
-  const long long vol = (long long)p.Z * p.Y * p.X;
-  const long long base = batch * vol;
-  const int gx0 = tx * kTX3, gy0 = ty * kTY3, gz0 = tz * kTZ3;
-
-  auto advanced = [&](long long n, int xi, int c, float* v_keep, float* a_keep) -> float {
-    float xv = x_in[c * p.N + n];
-    float vv = v_in[c * p.N + n];
-    const float aa = a_in[c * p.N + n];
-    if (fix) {
-      vv = vv * s.gate;
-      if (fix_cols) {
-        xv = xv - colmean[c * p.X + xi];
-        vv = vv - colmean[(3 + c) * p.X + xi] * s.gate;
-      } else if (p.remove_drift) {
-        xv = xv - s.mx[c];
-        vv = vv - s.mv[c];
-      }
-    }
-    if (v_keep) *v_keep = vv;
-    if (a_keep) *a_keep = aa;
-    return xv + (dt * vv + c2 * aa);
-  };
-
-  // own nodes: thread t owns brick cells t, t + 256, ... (x fastest)
-  float x_own[kOwn][C], v_own[kOwn][C], a_own[kOwn][C];
-  bool live[kOwn];
-  long long n_own[kOwn];
-  int ctr[kOwn];
-#pragma unroll
-  for (int k = 0; k < kOwn; ++k) {
-    const int cell = threadIdx.x + k * kBlock;
-    const int lx = cell % kTX3, ly = (cell / kTX3) % kTY3, lz = cell / (kTX3 * kTY3);
-    const int gx = gx0 + lx, gy = gy0 + ly, gz = gz0 + lz;
-    live[k] = gx < p.X && gy < p.Y && gz < p.Z;
-    ctr[k] = ((lz + 1) * PY + ly + 1) * PX + lx + 1;
-    n_own[k] = base + ((long long)gz * p.Y + gy) * p.X + gx;
-    // loads from clamped coordinates, unconditional (a load under a per-lane
-    // condition gets its own block: the groups would be fetched one by one)
-    const long long nc = base + ((long long)min(gz, p.Z - 1) * p.Y + min(gy, p.Y - 1)) * p.X +
-                         min(gx, p.X - 1);
-#pragma unroll
-    for (int c = 0; c < C; ++c) x_own[k][c] = advanced(nc, min(gx, p.X - 1), c, &v_own[k][c], &a_own[k][c]);
-  }
-  // shell cells (the six faces of the padded brick), enumerated directly
-  constexpr int kFaceZ = PY * PX, kFaceY = (PZ - 2) * PX, kFaceX = (PZ - 2) * (PY - 2);
-  constexpr int kShell = 2 * (kFaceZ + kFaceY + kFaceX);
-  constexpr int kShellIt = (kShell + kBlock - 1) / kBlock;
-  float sh[kShellIt][C];
-  int sh_cell[kShellIt];
-#pragma unroll
-  for (int it = 0; it < kShellIt; ++it) {
-    const int sidx = min(threadIdx.x + it * kBlock, kShell - 1);
-    int hx, hy, hz;
-    if (sidx < 2 * kFaceZ) {
-      const int r = sidx % kFaceZ;
-      hz = sidx < kFaceZ ? 0 : PZ - 1;
-      hy = r / PX;
-      hx = r % PX;
-    } else if (sidx < 2 * (kFaceZ + kFaceY)) {
-      const int t2 = sidx - 2 * kFaceZ, r = t2 % kFaceY;
-      hy = t2 < kFaceY ? 0 : PY - 1;
-      hz = 1 + r / PX;
-      hx = r % PX;
-    } else {
-      const int t2 = sidx - 2 * (kFaceZ + kFaceY), r = t2 % kFaceX;
-      hx = t2 < kFaceX ? 0 : PX - 1;
-      hz = 1 + r / (PY - 2);
-      hy = 1 + r % (PY - 2);
-    }
-    const int gx = gx0 + hx - 1, gy = gy0 + hy - 1, gz = gz0 + hz - 1;
-    const bool inside = threadIdx.x + it * kBlock < kShell && gx >= 0 && gx < p.X &&
-                        gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z;
-    sh_cell[it] = inside ? (hz * PY + hy) * PX + hx : -1;
-    const long long n = base + ((long long)min(max(gz, 0), p.Z - 1) * p.Y +
-                                min(max(gy, 0), p.Y - 1)) * p.X + min(max(gx, 0), p.X - 1);
-#pragma unroll
-    for (int c = 0; c < C; ++c) sh[it][c] = advanced(n, min(max(gx, 0), p.X - 1), c, nullptr, nullptr);
-  }
-  // the remaining per-node input
-  float pv_own[kOwn][C];
-#pragma unroll
-  for (int k = 0; k < kOwn; ++k) {
-    const int cell = threadIdx.x + k * kBlock;
-    const int lx = cell % kTX3, ly = (cell / kTX3) % kTY3, lz = cell / (kTX3 * kTY3);
-    const long long nc = base + ((long long)min(gz0 + lz, p.Z - 1) * p.Y + min(gy0 + ly, p.Y - 1)) * p.X +
-                         min(gx0 + lx, p.X - 1);
-#pragma unroll
-    for (int c = 0; c < C; ++c) pv_own[k][c] = p.has_prev ? prev[c * p.N + nc] : 0.f;
-  }
-#pragma unroll
-  for (int k = 0; k < kOwn; ++k)
-    if (live[k]) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) xt[c][ctr[k]] = x_own[k][c];
-    }
-#pragma unroll
-  for (int it = 0; it < kShellIt; ++it)
-    if (sh_cell[it] >= 0) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) xt[c][sh_cell[it]] = sh[it][c];
-    }
-  __syncthreads();
-
-  const float hdtg = (0.5f * dt) * p.gamma;
-  const float fact0 = 1.0f / (1.0f + hdtg);
-  const float fact1 = 1.0f - hdtg;
-  const float hdt = 0.5f * dt;
-  float part[kNP];
-  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
-  const DefLinks3 dl(p);
-#pragma unroll
-  for (int k = 0; k < kOwn; ++k) {
-    if (!live[k]) continue;
-    const int cell = threadIdx.x + k * kBlock;
-    const int lx = cell % kTX3, ly = (cell / kTX3) % kTY3, lz = cell / (kTX3 * kTY3);
-    const int xi = gx0 + lx, yi = gy0 + ly, zi = gz0 + lz;
-    const float* self = x_own[k];
-    float acc[3] = {0.f, 0.f, 0.f};
-    // same per-link order and branch-free form as node_force_default3d: a
-    // spring whose other end is outside the mesh is evaluated against the
-    // node itself (d = rest: force exactly +-0)
-#define SFM_LINK(L, DX, DY, DZ)                                                      \
-    {                                                                                \
-      constexpr int kc = SFM_CLASS3(DX, DY, DZ);                                     \
-      const float l0 = dl.l0c[kc];                                                   \
-      const float rest[3] = {dl.rest(DX, 0), dl.rest(DY, 1), dl.rest(DZ, 2)};        \
-      const bool okf = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&        \
-                       yi - (DY) < p.Y && zi - (DZ) >= 0 && zi - (DZ) < p.Z;          \
-      const bool okn = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&        \
-                       yi + (DY) < p.Y && zi + (DZ) >= 0 && zi + (DZ) < p.Z;          \
-      constexpr int off = (DX) + (DY) * PX + (DZ) * PX * PY;                         \
-      const int mf = okf ? ctr[k] - off : ctr[k], mn = okn ? ctr[k] + off : ctr[k];  \
-      float df[3], dn[3], ff[3], fn[3];                                              \
-      _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                \
-        df[c] = self[c] - xt[c][mf] + rest[c];                                       \
-        dn[c] = xt[c][mn] - self[c] + rest[c];                                       \
-      }                                                                              \
-      spring_xyz<DX, DY, DZ>(df, l0, dl.nkc[kc], p.prefer, ff);                      \
-      spring_xyz<DX, DY, DZ>(dn, l0, dl.nkc[kc], p.prefer, fn);                      \
-      _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                \
-        acc[c] = acc[c] + (okf ? ff[c] : 0.f);                                       \
-        acc[c] = acc[c] - (okn ? fn[c] : 0.f);                                       \
-      }                                                                              \
-    }
-    SFM_LINK(0, 1, 0, 0) SFM_LINK(1, 0, 1, 0) SFM_LINK(2, 0, 0, 1) SFM_LINK(3, 1, 1, 0)
-    SFM_LINK(4, -1, 1, 0) SFM_LINK(5, 1, 0, 1) SFM_LINK(6, -1, 0, 1) SFM_LINK(7, 0, 1, 1)
-    SFM_LINK(8, 0, -1, 1) SFM_LINK(9, 1, 1, 1) SFM_LINK(10, 1, 1, -1)
-    SFM_LINK(11, 1, -1, 1) SFM_LINK(12, -1, 1, 1)
-#undef SFM_LINK
-    const long long n = n_own[k];
-    float f[C], vn[C];
-    float a2 = 0.f, v2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float xv = self[c];
-      f[c] = acc[c];
-      if (p.has_prev) f[c] = f[c] + prev_pull(xv, pv_own[k][c], p.neg_k0, cap);
-      vn[c] = fact0 * (v_own[k][c] * fact1 + hdt * (a_own[k][c] + f[c]));
-      a_out[c * p.N + n] = f[c];
-      x_out[c * p.N + n] = xv;
-      a2 = a2 + f[c] * f[c];
-      v2 = v2 + vn[c] * vn[c];
-      if (p.fire) {
-        part[0] = part[0] + f[c] * vn[c];
-        part[1 + c] = part[1 + c] + xv;
-      }
-    }
-    if (p.fire) {
-      const float a_norm = sqrtf(a2) + 1e-6f;
-      const float v_norm = sqrtf(v2);
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
-        part[4 + c] = part[4 + c] + vn[c];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) v_out[c * p.N + n] = vn[c];
-  }
-  if (!p.fire) return;
-  // per-brick partial sums -> {epoch, value} granules; the last workgroup to
-  // arrive reduces them in brick order (see integrate_tiled2d_kernel)
-  block_sum(part, 7, lds);
-  if (threadIdx.x == 0) {
-    for (int i = 0; i < 7; ++i)
-      __hip_atomic_store(&partials[blockIdx.x * kNP + i],
-                         (static_cast<u64>(epoch) << 32) | __float_as_uint(part[i]),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);
-    s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT) ==
-             static_cast<int>(gridDim.x) - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  float acc[kNP];
-  tile_tail_gather(partials, static_cast<int>(gridDim.x), p.remove_drift ? 7 : 1, epoch, acc);
-  block_sum(acc, 7, lds);
-  if (threadIdx.x == 0) {
-    Scalars in = *scal_in, o;
-    scalars_from_sums(in, acc, p, &o);
-    *scal_out = o;
     ticket[1] = static_cast<int>(epoch);
     __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -3181,27 +2416,6 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
   return SFM_OK;
 }
 
-// hipGraph replay of the step loop.  Measured on MI355X / ROCm 7.2 it is 10-17 %
-// SLOWER than enqueueing the kernels (28.0 -> 30.7 us/step on [3,16,12,12,12],
-// 14.5 -> 16.9 on [2,4,17,17]): the step loop is bound by the device-side
-// launch latency of dependent kernels, not by host enqueue cost, and a graph
-// node costs more than an async launch.  Opt-in with SFM_MESH_GRAPH=1.
-constexpr long long kGraphMaxNodes = 400000;
-
-bool graph_enabled() {
-  const char* e = sfm::option("SFM_MESH_GRAPH");
-  return e && e[0] == '1';
-}
-
-// Stream capture is not allowed on the legacy default stream the caller may
-// hand us, so the two-step graph is captured on a private stream (nothing
-// executes during capture) and launched on the caller's stream.
-hipStream_t capture_stream() {
-  static thread_local hipStream_t cs = nullptr;
-  if (!cs && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) cs = nullptr;
-  return cs;
-}
-
 bool small_enabled() {
   const char* e = sfm::option("SFM_MESH_SMALL");  // "0": the launch-per-kernel path
   return !(e && e[0] == '0');
@@ -3238,31 +2452,12 @@ struct MeshWorkspace {
   size_t bytes;
 };
 
-// Tile shape of the LDS-tiled 2-D integrator: 0 = not applicable, else TX.
+// Tile shape of the tiled in-plane integrator (integrate_shared2d_kernel):
+// tx = 0: not applicable.
 struct TilePlan {
   int tx = 0, ty = 0, nty = 0, ntx = 0;
-  int ntz = 0;  // > 0: the volumetric brick kernel (kTZ3 x kTY3 x kTX3)
   long long tiles = 0;
 };
-
-bool shared_enabled() {
-  const char* e = sfm::option("SFM_MESH_SHARED");  // "0": both ends evaluate every spring
-  return !(e && e[0] == '0');
-}
-
-// Measured on MI355X: SLOWER than integrate_kernel<3> (394 vs 336 us per step on
-// [3,4,100^3]) although it forms 14.5 instead of 26 springs per node: 193 VGPRs
-// allow one 8-wave workgroup per CU (two waves per SIMD, two barriers per
-// plane), the halo row / column threads carry the per-thread overhead of the
-// exchange (positions, 27 + 27 exchanged floats, 26 guarded adds) without
-// owning nodes, and the tail of a second round of workgroups costs the rest.
-// (Round 3, after the link constants stopped spilling in all three kernels: 379
-// vs 308 us.)  Opt-in (SFM_MESH_MARCH=1), kept as the measured experiment; its forces are
-// bit-identical (test_volumetric_march_kernel_matches_two_sided_kernel).
-bool march_enabled() {
-  const char* e = sfm::option("SFM_MESH_MARCH");
-  return e && e[0] == '1';
-}
 
 bool fuse_target_enabled() {
   const char* e = sfm::option("SFM_MESH_FUSE_TARGET");  // "0": advance + target + integrate
@@ -3274,78 +2469,17 @@ bool tiled_enabled() {
   return !(e && e[0] == '0');
 }
 
-// Bricks of the volumetric fused step: default links, prev given or absent (no
-// prev_fn), global or no drift removal.
-// Measured on MI355X: SLOWER than the multi-launch pair (446 vs 357 us per step
-// on [3,4,100^3], 408 vs 375 on [3,1,64,256,256]): the volumetric step is bound
-// by the ~3000 IEEE-exact VALU operations per node (26 spring evaluations with
-// correctly rounded sqrt and division each), not by the neighbour re-reads the
-// bricks remove, and the shell recomputation adds to it.  (Round 3, link constants
-// without spills everywhere: 380 vs 308 and 354 vs 324 us.)  Opt-in
-// (SFM_MESH_BRICKS=1), kept as the measured experiment.
-bool bricks_enabled() {
-  const char* e = sfm::option("SFM_MESH_BRICKS");
-  return e && e[0] == '1';
-}
-
-TilePlan plan_bricks(const SfmMeshDesc* d) {
-  TilePlan t;
-  // Volumetric montage with the native prev_fn (12^3-node tiles: launch and
-  // latency bound).  Measured per step on [3,64,12,12,12], FIRE, column drift:
-  //   advance 8 + target mesh 12 + integrate_kernel<3> 17 + column means   52 us
-  //   target mesh of the advanced positions 33 + brick kernel 42 + means   99 us
-  //   target mesh INSIDE the brick kernel (one launch + means)            137 us
-  // Every "fused" variant loses: a thread of the brick kernel owns four nodes
-  // and runs load -> LDS -> barrier -> springs -> tile sums -> ticket in series,
-  // the per-node kernels have a thread per node and nothing to wait for.  With
-  // SFM_MESH_BRICKS=1 the second variant runs (tested, not the default).
-  const bool montage = d->target != nullptr;
-  if (!bricks_enabled()) return t;
-  if (d->ncomp != 3 || !tiled_enabled() || d->n_links != 0 || d->prev_cb ||
-      d->force_kind != SFM_FORCE_SPRINGS)
-    return t;
-  if (!montage && d->remove_drift == 2) return t;
-  if (montage && !fuse_target_enabled()) return t;
-  const int Z = d->shape[1], Y = d->shape[2], X = d->shape[3];
-  if (!montage && (long long)Z * Y * X < 4096) return t;  // tiny volumes stay launch bound either way
-  t.tx = kTX3;
-  t.ty = kTY3;
-  t.ntz = (Z + kTZ3 - 1) / kTZ3;
-  t.nty = (Y + kTY3 - 1) / kTY3;
-  t.ntx = (X + kTX3 - 1) / kTX3;
-  t.tiles = (long long)d->shape[0] * t.ntz * t.nty * t.ntx;
-  if (t.tiles > 0x7fffffffLL / kNP) t = TilePlan();
-  return t;
-}
-
 TilePlan plan_tiles(int ncomp, long long planes, int Y, int X) {
   TilePlan best;
-  if (ncomp != 2 || !tiled_enabled() || X < 16 || Y < 4) return best;
   // every spring once (integrate_shared2d_kernel): 16 x 62 tiles, a lane per
   // column; pays off unless most of a 64-lane row would hang over the mesh
-  if (shared_enabled() && X >= 40) {
-    best.ty = kSY;
-    best.tx = kSX;
-    best.nty = (Y + kSY - 1) / kSY;
-    best.ntx = (X + kSX - 1) / kSX;
-    best.tiles = planes * best.nty * best.ntx;
-    if (best.tiles > 0x7fffffffLL / kNP) best = TilePlan();
-    return best;
-  }
-  const int shapes[2][2] = {{16, 64}, {32, 32}};
-  long long best_cells = 0;
-  for (const auto& sh : shapes) {
-    const int nty = (Y + sh[0] - 1) / sh[0], ntx = (X + sh[1] - 1) / sh[1];
-    const long long cells = (long long)nty * sh[0] * ntx * sh[1];
-    if (best.tx == 0 || cells < best_cells) {
-      best.ty = sh[0];
-      best.tx = sh[1];
-      best.nty = nty;
-      best.ntx = ntx;
-      best.tiles = planes * nty * ntx;
-      best_cells = cells;
-    }
-  }
+  // (narrower meshes take the advance / integrate pair)
+  if (ncomp != 2 || !tiled_enabled() || X < 40 || Y < 4) return best;
+  best.ty = kSY;
+  best.tx = kSX;
+  best.nty = (Y + kSY - 1) / kSY;
+  best.ntx = (X + kSX - 1) / kSX;
+  best.tiles = planes * best.nty * best.ntx;
   if (best.tiles > 0x7fffffffLL / kNP) best = TilePlan();
   return best;
 }
@@ -3380,14 +2514,12 @@ MeshWorkspace carve_for(const SfmMeshDesc* d, void* ws, TilePlan* plan) {
                    ? plan_tiles(d->ncomp, (long long)d->shape[0] * d->shape[1],
                                 d->shape[2], d->shape[3])
                    : TilePlan();
-  if (d->ncomp == 3) t = plan_bricks(d);
   if (plan) *plan = t;
   const size_t cn = (size_t)d->ncomp * n;
   // second (x, v, a) set: ping-pong of the fused tiled step, staging of the
   // persistent kernel's result
   return carve(ws, d->target ? cn : 0,
-               ((d->ncomp == 2 && !d->prev_cb && d->force_kind == SFM_FORCE_SPRINGS) ||
-                t.ntz > 0) ? cn : 0,
+               (d->ncomp == 2 && !d->prev_cb && d->force_kind == SFM_FORCE_SPRINGS) ? cn : 0,
                t.tiles,
                d->shape[3], d->target ? sfm::target_list_ints(d->target) : 0);
 }
@@ -3605,8 +2737,6 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   // from (x, v, a) on the overlap strips (sfm::AdvanceView) -- so the step is
   // target mesh (strips only) + the fused integrator instead of advance + target
   // mesh (all nodes) + integrate.  Same float operations: bit-identical.
-  // Volumetric montages the same way in front of the brick kernel (all nodes of
-  // the 16-node blocks that touch a region; no block list).
   const bool fuse_target = tiled && d->target && w.alt[0] && fuse_target_enabled();
   const bool fused = tiled && (!dyn_prev || fuse_target);
   if (fuse_target && w.target_list)
@@ -3627,41 +2757,9 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     SFM_HIP_CHECK(hipMemsetAsync(w.tile_part, 0, (size_t)tiles.tiles * kNP * sizeof(u64), st));
     finish_mode = 2;
   }
-  // Volumetric meshes with the default links: every spring once (z-marching
-  // kernel) instead of integrate_kernel<3>.
-  int march_nty = 0, march_ntx = 0, march_nseg = 0, march_planes = 0, march_grid = 0;
-  if (march_enabled() && p.ncomp == 3 && p.default_links && p.force_kind == SFM_FORCE_SPRINGS &&
-      !tiled && p.N >= 32768 && p.Z >= 2) {
-    march_nty = (p.Y + kMRows - 1) / kMRows;
-    march_ntx = (p.X + kMCols - 1) / kMCols;
-    const long long cols = (long long)p.B * march_nty * march_ntx;
-    if (cols <= kMaxBlocks) {
-      // segments of z: enough workgroups to fill the chip, at least 8 planes each
-      const int want = static_cast<int>((768 + cols - 1) / cols);
-      march_nseg = std::max(1, std::min(std::min(want, p.Z / 8), static_cast<int>(kMaxBlocks / cols)));
-      march_planes = (p.Z + march_nseg - 1) / march_nseg;
-      march_nseg = (p.Z + march_planes - 1) / march_planes;
-      march_grid = static_cast<int>(cols * march_nseg);
-      static bool attr_set = false;
-      if (!attr_set) {
-        SFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_march3d_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          static_cast<int>(kMarchLds)));
-        attr_set = true;
-      }
-    }
-  }
-  const int part_rows = march_grid ? march_grid : grid;
-  // One integration step, enqueued on `ls`.  The host-side state it toggles
-  // (scalar / buffer ping-pong) has period two, and no launch carries a
-  // per-step argument, so two consecutive steps can be replayed from a graph.
+  const int part_rows = grid;
+  // One integration step, enqueued on `ls`.
   hipStream_t ls = st;
-  bool timing = true;
-#define SFM_TILED(TY, TX, FUSED, XI, VI, AI, XO, VO, AO, PEND)                      \
-  hipLaunchKernelGGL((integrate_tiled2d_kernel<TY, TX, FUSED>), dim3(tgrid),        \
-                     dim3(kBlock), 0, ls, XI, VI, AI, prev_ptr, XO, VO, AO, p,      \
-                     &w.scal[cur], &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket,   \
-                     PEND, tiles.nty, tiles.ntx)
 #define SFM_STEP_DISPATCH(KERNEL, ...)                                       \
   do {                                                                       \
     if (p.ncomp == 2)                                                        \
@@ -3684,29 +2782,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
                        w.colsum, w.col_part, w.col_ticket, col_rows_per);
   };
   auto step = [&](int pending) -> int {
-    if (fused && tiles.ntz > 0) {
-      float** bi = bufs[in];
-      float** bo = bufs[in ^ 1];
-      if (fuse_target) {
-        const sfm::AdvanceView av{bi[1], bi[2], &w.scal[cur], p.fire, pending, p.remove_drift,
-                                  p.vv_dt, p.drift_cols ? w.colsum : nullptr};
-        if (int rc = sfm::launch_target_mesh(d->target, bi[0], w.prev_buf, ls, &av, true))
-          return rc;
-      }
-      if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
-      hipLaunchKernelGGL(integrate_tiled3d_kernel, dim3(tgrid), dim3(kBlock), 0, ls, bi[0],
-                         bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
-                         &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.ntz,
-                         tiles.nty, tiles.ntx, w.colsum);
-      if (timing) sfm::prof_end(sfm::kProfMesh, ls);
-      SFM_LAUNCH_CHECK();
-      if (p.fire && p.drift_cols) {   // column sums of what this step stored
-        column_means(bo[0], bo[1]);
-        SFM_LAUNCH_CHECK();
-      }
-      in ^= 1;
-      if (p.fire) cur ^= 1;
-    } else if (fused) {
+    if (fused) {
       float** bi = bufs[in];
       float** bo = bufs[in ^ 1];
       if (fuse_target) {
@@ -3716,17 +2792,12 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
                                              w.target_list))
           return rc;
       }
-      if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
-      if (tiles.tx == kSX)
-        hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(tgrid), dim3(kBlock), 0, ls,
-                           bi[0], bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
-                           &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.nty,
-                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, xcd_map});
-      else if (tiles.tx == 64)
-        SFM_TILED(16, 64, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
-      else
-        SFM_TILED(32, 32, true, bi[0], bi[1], bi[2], bo[0], bo[1], bo[2], pending);
-      if (timing) sfm::prof_end(sfm::kProfMesh, ls);
+      sfm::prof_begin(sfm::kProfMesh, ls);
+      hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(tgrid), dim3(kBlock), 0, ls,
+                         bi[0], bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
+                         &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.nty,
+                         tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, xcd_map});
+      sfm::prof_end(sfm::kProfMesh, ls);
       SFM_LAUNCH_CHECK();
       in ^= 1;
       if (p.fire) cur ^= 1;
@@ -3735,17 +2806,12 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
                         &w.scal[cur ^ 1], w.partials, grid, pending ? 2 : 0, w.colsum);
       cur ^= 1;
       if (int rc = eval_prev(ls)) return rc;
-      if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
-      if (tiles.tx == kSX)
-        hipLaunchKernelGGL(integrate_shared2d_kernel<false>, dim3(tgrid), dim3(kBlock), 0, ls,
-                           d->x, d->v, d->a, prev_ptr, d->x, d->v, d->a, p, &w.scal[cur],
-                           &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, 1, tiles.nty,
-                           tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, xcd_map});
-      else if (tiles.tx == 64)
-        SFM_TILED(16, 64, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
-      else
-        SFM_TILED(32, 32, false, d->x, d->v, d->a, d->x, d->v, d->a, 1);
-      if (timing) sfm::prof_end(sfm::kProfMesh, ls);
+      sfm::prof_begin(sfm::kProfMesh, ls);
+      hipLaunchKernelGGL(integrate_shared2d_kernel<false>, dim3(tgrid), dim3(kBlock), 0, ls,
+                         d->x, d->v, d->a, prev_ptr, d->x, d->v, d->a, p, &w.scal[cur],
+                         &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, 1, tiles.nty,
+                         tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, xcd_map});
+      sfm::prof_end(sfm::kProfMesh, ls);
       SFM_LAUNCH_CHECK();
       if (p.fire) cur ^= 1;
     } else {
@@ -3754,17 +2820,10 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       cur ^= 1;
       if (int rc = eval_prev(ls)) return rc;
       if (int rc = external_force()) return rc;
-      if (timing) sfm::prof_begin(sfm::kProfMesh, ls);
-      if (march_grid) {
-        hipLaunchKernelGGL(integrate_march3d_kernel, dim3(march_grid), dim3(kMThreads),
-                           kMarchLds, ls, d->x, d->v, d->a, prev_ptr, p, &w.scal[cur], cap0,
-                           w.partials, march_nty, march_ntx, march_nseg, march_planes);
-        SFM_LAUNCH_CHECK();
-      } else {
-        SFM_STEP_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
-                          &w.scal[cur], cap0, w.partials);
-      }
-      if (timing) sfm::prof_end(sfm::kProfMesh, ls);
+      sfm::prof_begin(sfm::kProfMesh, ls);
+      SFM_STEP_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
+                        &w.scal[cur], cap0, w.partials);
+      sfm::prof_end(sfm::kProfMesh, ls);
       if (p.fire && p.drift_cols) {
         column_means(d->x, d->v);
         SFM_LAUNCH_CHECK();
@@ -3779,37 +2838,8 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     if (int rc = step(0)) return rc;
     it = 1;
   }
-  // Launch-bound meshes (small, several launches per step): replay pairs of
-  // steps from a hipGraph instead of enqueueing every kernel from the host.
-  if (graph_enabled() && !sfm::profiling() && p.N <= kGraphMaxNodes &&
-      p.force_kind != SFM_FORCE_EXTERNAL && !d->prev_cb &&
-      d->num_iters - it >= 8) {
-    const int pairs = (d->num_iters - it) / 2;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipStream_t cs = capture_stream();
-    bool ok = cs != nullptr &&
-              hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
-    if (ok) {
-      ls = cs;
-      timing = false;
-      const int rc0 = step(1);
-      const int rc1 = rc0 ? rc0 : step(1);
-      ls = st;
-      timing = true;
-      ok = hipStreamEndCapture(cs, &graph) == hipSuccess && graph && !rc1;
-      ok = ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-      for (int k = 0; ok && k < pairs; ++k) ok = hipGraphLaunch(exec, st) == hipSuccess;
-      if (exec) (void)hipGraphExecDestroy(exec);
-      if (graph) (void)hipGraphDestroy(graph);
-      if (!ok) return sfm::fail(SFM_ERR_HIP, "mesh: hipGraph capture / replay failed");
-      it += 2 * pairs;
-    }
-    (void)hipGetLastError();
-  }
   for (; it < d->num_iters; ++it)
     if (int rc = step(1)) return rc;
-#undef SFM_TILED
   if (in == 1) {
     const size_t bytes = (size_t)p.ncomp * p.N * sizeof(float);
     SFM_HIP_CHECK(hipMemcpyAsync(d->x, w.alt[0], bytes, hipMemcpyDeviceToDevice, st));

@@ -3,9 +3,10 @@
 configs[0]  2 x 2 grid of 512^2 tiles, patch 64 step 32: flow leg vs the
             reference's own output (stitch_cfg1.npz), mesh leg in
             test_gpu_maps.py (montage.npz)
-configs[1]  8192^2 pair, patch 160 step 40 batch 1024: warped pair, three full
-            reference batches (first, middle, ragged last: 2513 patches) vs the
-            oracle (the rigid-shift properties are in test_gpu_flow.py)
+configs[1]  8192^2 pair, patch 160 step 40 batch 1024: warped pair, the WHOLE
+            field (all 40 reference batches, 40401 patches) vs the oracle; the
+            masked pair on four whole batches (the rigid-shift properties are
+            in test_gpu_flow.py)
 configs[2]  8 x 8 montage of 4096^2 tiles: a 4096 x 400 overlap strip, patch 120
             step 20 batch 256, and the [2, 64, 204, 204] mesh with the native
             target-mesh prev_fn + remove_drift, 100 FIRE steps, vs the oracle
@@ -56,13 +57,14 @@ def _warp(img, amp, lam):
   return out
 
 
-def test_cfg1_full_size_warped_pair_batches_vs_oracle(gpu):
-  """8192^2 pair whose second image is sampled through a smooth 6 px warp:
-  three whole reference batches -- the first, one from the middle and the
-  ragged last one (465 of 1024 patches; 2513 patches in all, same batch
-  membership as the reference) -- agree with the oracle vector for vector; the
-  rest of the field follows the warp."""
+def test_cfg1_full_size_warped_pair_whole_field_vs_oracle(gpu, tmp_path):
+  """8192^2 pair whose second image is sampled through a smooth 6 px warp: the
+  WHOLE [4, 201, 201] field -- all 40 reference batches of 1024 (the last one
+  ragged: 465 patches), 40401 patches, same batch membership as the reference
+  -- agrees with the oracle vector for vector (the oracle runs one process per
+  batch on the host cores)."""
   from sofima_amd import flow_field as ff
+  from tests.util import oracle_flow_batches
   rng = np.random.default_rng(1002)
   size = 8192
   base = em_texture(rng, (size + 32, size + 32))
@@ -71,22 +73,21 @@ def test_cfg1_full_size_warped_pair_batches_vs_oracle(gpu):
   calc = ff.JAXMaskedXCorrWithStatsCalculator()
   got = calc.flow_field(pre, post, 160, 40, batch_size=1024)
   assert got.shape == (4, 201, 201)
-  batches = (0, 19, 39)
-  want = flow_oracle.flow_field(pre, post, 160, 40, batch_size=1024, workers=16,
-                                only_batches=batches)
-  sel = np.zeros(201 * 201, bool)
-  for b in batches:
-    sel[b * 1024:(b + 1) * 1024] = True
-  assert sel.sum() == 2 * 1024 + 465
-  g = got.reshape(4, -1)[:, sel]
-  w = want.reshape(4, -1)[:, sel]
-  assert np.isfinite(w[:2]).all()
-  np.testing.assert_array_equal(g[:2], w[:2])
-  np.testing.assert_array_equal(np.isnan(g), np.isnan(w))
-  np.testing.assert_allclose(g[3], w[3], rtol=1e-4, atol=1e-6)
-  ok = np.isfinite(w[2])
-  np.testing.assert_allclose(g[2][ok], w[2][ok], rtol=2e-3)
-  # whole field: content shift (-5, 3) plus the warp, |d| <= 6 px
+  parts = oracle_flow_batches(tmp_path, pre, post, 160, 40, 1024, range(40))
+  assert sorted(parts) == list(range(40))
+  want = np.concatenate([parts[b] for b in range(40)], axis=1)
+  assert want.shape == (4, 201 * 201)
+  want = want.reshape(4, 201, 201)
+  assert np.isfinite(want[:2]).all()
+  np.testing.assert_array_equal(got[:2], want[:2])
+  np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+  np.testing.assert_allclose(got[3], want[3], rtol=1e-4, atol=1e-6)
+  # sharpness = peak / min(11 x 11 window) of a RAW surface: the quotient is ill
+  # conditioned where the window minimum is close to 0; numerator and minimum are
+  # pinned separately (test_gpu_flow.py), here the quotient to 2e-3
+  ok = np.isfinite(want[2])
+  np.testing.assert_allclose(got[2][ok], want[2][ok], rtol=2e-3)
+  # content shift (-5, 3) plus the warp, |d| <= 6 px
   valid = np.isfinite(got[0])
   assert valid.mean() > 0.99
   assert np.abs(got[0][valid] + 5).max() <= 7 and np.abs(got[1][valid] - 3).max() <= 7
@@ -100,6 +101,54 @@ def test_cfg1_full_size_warped_pair_batches_vs_oracle(gpu):
     full = calc.flow_field(pre, post, 160, 40, batch_size=1024)
   np.testing.assert_array_equal(got, full)
   np.testing.assert_array_equal(calc.flow_field(pre, post, 160, 40, batch_size=1024), full)
+
+
+def test_cfg1_full_size_masked_pair_batches_vs_oracle(gpu, tmp_path):
+  """The same geometry with masks used IN the correlation
+  (mask_only_for_patch_selection=False, discs on both images, max_masked > 1 so
+  that no patch is dropped and batch membership is the plain row-major one):
+  four whole reference batches -- first, two from the middle, the ragged last --
+  hold patches of all four mask classes and agree with the oracle's Padfield
+  surface statistics (batch-global tolerances included)."""
+  from bench import synth_pair
+  from sofima_amd import flow_field as ff
+  from tests.util import oracle_flow_batches
+  pre, post = synth_pair(8192, 1002, shift=(3, -5))
+  rng = np.random.default_rng(77)
+  yy, xx = np.mgrid[-90:91, -90:91]
+  disc = yy ** 2 + xx ** 2 <= 90 ** 2
+  masks = []
+  for _ in range(2):
+    m = np.zeros(pre.shape, bool)
+    for _ in range(120):
+      y, x = rng.integers(90, 8192 - 91, 2)
+      m[y - 90:y + 91, x - 90:x + 91] |= disc
+    masks.append(m)
+  calc = ff.JAXMaskedXCorrWithStatsCalculator()
+  kw = dict(batch_size=1024, mask_only_for_patch_selection=False, max_masked=1.01)
+  got = calc.flow_field(pre, post, 160, 40, pre_mask=masks[0], post_mask=masks[1], **kw)
+  batches = (0, 13, 26, 39)
+  parts = oracle_flow_batches(tmp_path, pre, post, 160, 40, 1024, batches,
+                              pre_mask=masks[0], post_mask=masks[1],
+                              mask_only_for_patch_selection=False, max_masked=1.01)
+  g = got.reshape(4, -1)
+  cnt_a = (ff._masked_counts(masks[0], (160, 160), (40, 40)) > 0).ravel()
+  cnt_b = (ff._masked_counts(masks[1], (160, 160), (40, 40)) > 0).ravel()
+  seen = set()
+  n = 0
+  for b in batches:
+    w = parts[b]
+    sl = slice(b * 1024, b * 1024 + w.shape[1])
+    n += w.shape[1]
+    seen |= set(zip(cnt_a[sl].tolist(), cnt_b[sl].tolist()))
+    np.testing.assert_array_equal(np.isnan(g[:, sl]), np.isnan(w), err_msg=str(b))
+    np.testing.assert_array_equal(g[:2, sl], w[:2], err_msg=str(b))
+    np.testing.assert_allclose(g[3, sl], w[3], rtol=1e-4, atol=1e-6, err_msg=str(b))
+    ok = np.isfinite(w[2])
+    # normalised surface: |values| <= 1, the sharpness quotient to 1e-3
+    np.testing.assert_allclose(g[2, sl][ok], w[2][ok], rtol=1e-3, atol=1e-4, err_msg=str(b))
+  assert n == 3 * 1024 + 465
+  assert len(seen) == 4, seen          # clean / pre only / post only / both masked
 
 
 def test_cfg2_montage_strip_vs_oracle(gpu):

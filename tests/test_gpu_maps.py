@@ -280,46 +280,3 @@ def test_fused_target_step_is_bit_identical(gpu, variant):
   np.testing.assert_allclose(np.array(a[0]), want[0], atol=1e-3 * np.abs(want[0]).max())
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('variant', ['fire_drift', 'fire', 'verlet'])
-def test_volumetric_montage_brick_step(gpu, variant):
-  """Volumetric montage with the native prev_fn, SFM_MESH_BRICKS=1: target mesh
-  of the advanced positions (AdvanceView with the per-column drift means) + the
-  brick kernel == advance + target mesh + integrate (the default) to round-off
-  (the partial sums are reduced in a different order), with the same FIRE
-  branch sequence, and both follow the oracle."""
-  from oracle import maps_oracle, mesh_oracle
-  from sofima_amd import _abi, mesh, stitch_elastic
-  from tests.util import synth_montage
-  rng = np.random.default_rng(33)
-  nb, fx, fy, x0 = synth_montage(rng, 3, 2, (10, 12, 14), 3, amp=4.0)
-  stride = (20.0, 20.0, 20.0)
-  kw = dict(dt=0.001, gamma=0.0, k0=0.02, k=0.1, stride=stride, num_iters=30,
-            max_iters=90, stop_v_max=1e-9, dt_max=100, start_cap=0.1, final_cap=10.0,
-            remove_drift=(variant == 'fire_drift'))
-  if variant == 'verlet':
-    kw.update(fire=False, gamma=0.5, dt=0.05, start_cap=10.0)
-  cfg = mesh.IntegrationConfig(**kw)
-  fn = stitch_elastic.TargetMeshFn(nb, fx, fy, stride)
-  force = mesh.elastic_mesh_3d
-  with _abi.option('SFM_MESH_BRICKS', 1):
-    a = mesh.relax_mesh(x0, None, cfg, mesh_force=force, prev_fn=fn)
-  b = mesh.relax_mesh(x0, None, cfg, mesh_force=force, prev_fn=fn)
-  assert a[2] == b[2]
-  scale = np.abs(np.array(b[0])).max()
-  np.testing.assert_allclose(np.array(a[0]), np.array(b[0]), atol=2e-4 * scale)
-  np.testing.assert_allclose(a[1], b[1], rtol=2e-3)
-  # the same chunk as velocity_verlet: identical FIRE scalars
-  with _abi.option('SFM_MESH_BRICKS', 1):
-    va = mesh.velocity_verlet(x0, np.zeros_like(x0), None, cfg, cfg.start_cap,
-                              mesh_force=force, prev_fn=fn)
-  vb = mesh.velocity_verlet(x0, np.zeros_like(x0), None, cfg, cfg.start_cap,
-                            mesh_force=force, prev_fn=fn)
-  if cfg.fire:
-    assert va[5] == vb[5]
-    np.testing.assert_allclose([va[3], va[4], va[6]], [vb[3], vb[4], vb[6]], rtol=1e-6)
-  want = mesh_oracle.relax_mesh(
-      x0, None, cfg, mesh_force=mesh_oracle.elastic_mesh_3d,
-      prev_fn=lambda xx: maps_oracle.target_mesh_all(nb, xx, fx, fy, stride))
-  assert a[2] == want[2]
-  np.testing.assert_allclose(np.array(a[0]), want[0], atol=1e-3 * np.abs(want[0]).max())

@@ -1,4 +1,4 @@
-"""Step time of a volumetric montage [3,64,12,12,12]: default multi-launch step vs SFM_MESH_BRICKS=1."""
+"""Step time of a volumetric montage [3,64,12,12,12]: the multi-launch step."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -12,9 +12,7 @@ cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=stride,
                              stop_v_max=1e-9, dt_max=100, start_cap=0.1, final_cap=10.0, remove_drift=drift)
 fn = stitch_elastic.TargetMeshFn(nb, fx, fy, stride)
 x = torch.from_numpy(x0).cuda()
-for opt in (1, 0):
-  with _abi.option('SFM_MESH_BRICKS', opt):
-    mesh.relax_mesh(x, None, cfg, mesh_force=mesh.elastic_mesh_3d, prev_fn=fn); torch.cuda.synchronize()
-    t = time.perf_counter(); _, ek, it = mesh.relax_mesh(x, None, cfg, mesh_force=mesh.elastic_mesh_3d, prev_fn=fn); torch.cuda.synchronize()
-    dt = time.perf_counter() - t
-    print('volumetric montage [3,64,12,12,12] drift=%d bricks=%d: %.1f us/step' % (drift, opt, dt / it * 1e6), flush=True)
+mesh.relax_mesh(x, None, cfg, mesh_force=mesh.elastic_mesh_3d, prev_fn=fn); torch.cuda.synchronize()
+t = time.perf_counter(); _, ek, it = mesh.relax_mesh(x, None, cfg, mesh_force=mesh.elastic_mesh_3d, prev_fn=fn); torch.cuda.synchronize()
+dt = time.perf_counter() - t
+print('volumetric montage [3,64,12,12,12] drift=%d: %.1f us/step' % (drift, dt / it * 1e6), flush=True)
