@@ -2395,7 +2395,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // A fragments live in a rotating window of kW register sets: chunk ca
         // uses set ca % kW and, once its MFMAs are issued, the set is reloaded
         // with the chunk kW positions ahead (of this row group or the next).
-        constexpr int kW = NCA > 6 ? NCA / 2 : NCA;
+        constexpr int kW = (NCA > 6 && NCA % 2 == 0) ? NCA / 2 : NCA;
         static_assert(NCA % kW == 0, "window must divide the chunk count");
         // The row loop exists in up to three variants: KS outer column tiles on
         // either side are left out (exact pruning along x, see col_skip below).
@@ -2949,7 +2949,7 @@ struct Variant {
   int nca, nce;
 };
 // Instantiated chunk geometries: NCA >= ceil(Px / 16), NCE >= floor((Qx + 14) / 16) + 1.
-constexpr Variant kVariants[] = {{3, 4}, {4, 5}, {5, 6}, {6, 7}, {8, 9}, {10, 11}};
+constexpr Variant kVariants[] = {{3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {10, 11}};
 
 bool exact_enabled() {
   const char* e = sfm::option("SFM_MFMA_EXACT");
@@ -3097,8 +3097,9 @@ int launch_mode(int vi, const MfmaArgs& a, int mode, int grid, size_t lds,
     case 1: return launch_variant<4, 5>(a, mode, grid, lds, st);
     case 2: return launch_variant<5, 6>(a, mode, grid, lds, st);
     case 3: return launch_variant<6, 7>(a, mode, grid, lds, st);
-    case 4: return launch_variant<8, 9>(a, mode, grid, lds, st);
-    case 5: return launch_variant<10, 11>(a, mode, grid, lds, st);
+    case 4: return launch_variant<7, 8>(a, mode, grid, lds, st);
+    case 5: return launch_variant<8, 9>(a, mode, grid, lds, st);
+    case 6: return launch_variant<10, 11>(a, mode, grid, lds, st);
   }
   return sfm::fail(SFM_ERR_INVALID, "no MFMA variant");
 }

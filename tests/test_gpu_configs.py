@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 
 from oracle import flow_oracle, maps_oracle, mesh_oracle
-from tests.util import check_flow, em_texture, synth_montage
+from tests.util import check_flow, check_sharpness, em_texture, synth_montage
 
 pytestmark = pytest.mark.gpu
 
@@ -82,11 +82,11 @@ def test_cfg1_full_size_warped_pair_whole_field_vs_oracle(gpu, tmp_path):
   np.testing.assert_array_equal(got[:2], want[:2])
   np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
   np.testing.assert_allclose(got[3], want[3], rtol=1e-4, atol=1e-6)
-  # sharpness = peak / min(11 x 11 window) of a RAW surface: the quotient is ill
-  # conditioned where the window minimum is close to 0; numerator and minimum are
-  # pinned separately (test_gpu_flow.py), here the quotient to 2e-3
+  # sharpness = peak / min(11 x 11 window) of a RAW surface: ill conditioned where
+  # the window minimum is close to 0 (3 of the 40401 patches differ by up to 8 %
+  # in the quotient): value to 2e-4 or window minimum to 2e-5 x |peak|
   ok = np.isfinite(want[2])
-  np.testing.assert_allclose(got[2][ok], want[2][ok], rtol=2e-3)
+  check_sharpness(got[2][ok], want[2][ok])
   # content shift (-5, 3) plus the warp, |d| <= 6 px
   valid = np.isfinite(got[0])
   assert valid.mean() > 0.99
@@ -145,8 +145,7 @@ def test_cfg1_full_size_masked_pair_batches_vs_oracle(gpu, tmp_path):
     np.testing.assert_array_equal(g[:2, sl], w[:2], err_msg=str(b))
     np.testing.assert_allclose(g[3, sl], w[3], rtol=1e-4, atol=1e-6, err_msg=str(b))
     ok = np.isfinite(w[2])
-    # normalised surface: |values| <= 1, the sharpness quotient to 1e-3
-    np.testing.assert_allclose(g[2, sl][ok], w[2][ok], rtol=1e-3, atol=1e-4, err_msg=str(b))
+    check_sharpness(g[2, sl][ok], w[2][ok])
   assert n == 3 * 1024 + 465
   assert len(seen) == 4, seen          # clean / pre only / post only / both masked
 
@@ -164,7 +163,7 @@ def test_cfg2_montage_strip_vs_oracle(gpu):
   assert got.shape == (4, 199, 15)
   want = flow_oracle.flow_field(pre, post, (120, 120), (20, 20), batch_size=256,
                                 workers=16)
-  check_flow(got, want, sharp_rtol=2e-3)
+  check_flow(got, want)
 
 
 def test_cfg2_montage_mesh_vs_oracle(gpu):
@@ -211,7 +210,7 @@ def test_cfg4_3d_overlap_strip_flow_vs_oracle(gpu):
   np.testing.assert_array_equal(got[2], 2)
   want = flow_oracle.flow_field(pre, post, (80, 80, 80), 40, batch_size=16,
                                 workers=16)
-  check_flow(got, want, sharp_rtol=1e-3)
+  check_flow(got, want)
 
 
 def test_cfg4_3d_montage_mesh_vs_oracle(gpu):
@@ -256,4 +255,4 @@ def test_cfg4_flow_map3d_vs_reference_output(gpu, golden):
     assert sorted(flows) == sorted(keys)
     for i, k in enumerate(keys):
       assert tuple(offs[k]) == tuple(g[name + '_offsets'][i])
-      check_flow(flows[k], g[f'{name}_{i}'], sharp_rtol=2e-3)
+      check_flow(flows[k], g[f'{name}_{i}'])
