@@ -184,3 +184,57 @@ def warp_subvolume(image, image_box, coord_map, map_box, stride, out_box,
     for c in range(image.shape[0]):
       warped[c, z] = remap(image[c, z], dense[0], dense[1], kind)
   return ids[warped] if ids is not None else warped
+
+
+# ---------------------------------------------------------------------------
+# warp.ndimage_warp (/root/reference/warp.py:189-335).  PINNED: the reference
+# function itself runs through the stand-ins of tests/golden/_refshim (it needs
+# only SciPy besides the stubbed imports) and its outputs are the fixtures of
+# tests/golden/ndimage_warp.npz; this restatement is checked against them bit
+# for bit (tests/test_oracle_golden.py).  scipy.ndimage.map_coordinates is the
+# reference's own third-party call, used here as well.
+# ---------------------------------------------------------------------------
+def ndimage_abs_map(coord_map, stride, out_scale, map_start=None, image_start=None):
+  """The float64 absolute source map of warp.py:250-265: map_utils.to_absolute
+  (in-place float32 adds of float64 terms, map_utils.py:169-187), the optional
+  box shift (float32 in place again) and the float64 product with out_scale."""
+  dim = coord_map.shape[0]
+  m = np.array(coord_map, dtype=np.float32)
+  idx = np.mgrid[tuple(slice(0, s) for s in m.shape[1:])]
+  off_zyx = [h * st for h, st in zip(idx, stride)]
+  for i in range(dim):
+    m[i, ...] += off_zyx[-(i + 1)]
+  if map_start is not None:
+    shift = (np.asarray(map_start)[:dim] * np.asarray(stride)[::-1] -
+             np.asarray(image_start)[:dim] / np.asarray(out_scale)[:dim])
+    m += shift.reshape((dim,) + (1,) * dim)
+  reshaper = (slice(None),) + (np.newaxis,) * dim
+  return m.copy() * np.array(out_scale[:dim])[reshaper]
+
+
+def ndimage_warp(image, coord_map, stride, order=1, image_start=None, map_start=None,
+                 out_start=None, out_size=None, out_scale=(1.0, 1.0, 1.0)):
+  """One work box covering the whole output (the result does not depend on the
+  work-box decomposition for order <= 1).  Boxes are xyz `start` / `size`
+  vectors.  uint64 label volumes are not covered."""
+  from scipy import ndimage
+  dim = coord_map.shape[0]
+  if dim != image.ndim:
+    raise ValueError(f'Dimension mismatch: image: {image.ndim} vs coord map: {dim}')
+  if map_start is not None and image_start is None:
+    raise ValueError('image_box has to be specified when map_box is used.')
+  src_map = ndimage_abs_map(coord_map, stride, out_scale, map_start, image_start)
+  if out_size is not None:
+    out_shape = tuple(int(v) for v in np.asarray(out_size)[::-1][-dim:])
+    out_start = np.asarray(out_start)
+  else:
+    out_shape = image.shape
+    out_start = np.zeros(3, np.int64)
+  if map_start is not None:
+    offset = (np.asarray(map_start) * np.asarray(stride)[::-1] - out_start)[::-1]
+  else:
+    offset = (0, 0, 0)
+  src_coords = np.mgrid[tuple(slice(0, s) for s in out_shape)]
+  src_coords = [(c - o) / s for c, s, o in zip(src_coords, stride, offset)]
+  dense = [ndimage.map_coordinates(ev, src_coords, order=1) for ev in src_map[::-1]]
+  return ndimage.map_coordinates(image, dense, order=order).astype(image.dtype)

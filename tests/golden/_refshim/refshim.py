@@ -370,6 +370,58 @@ class BoundingBox:
     return f'BB(start={self.start}, size={self.size})'
 
 
+class BoxGenerator:
+  """Stand-in for connectomics.common.box_generator.BoxGenerator with the three
+  members warp.ndimage_warp touches (warp.py:279-321): an outer box cut into
+  overlapping work boxes of `box_size` (stride box_size - overlap; boxes that
+  would stick out are shifted back inside, `back_shift_small_boxes`), and for
+  every work box the part of it that is written to the output -- here: half the
+  overlap is given to either neighbour, so the cropped boxes tile the outer box
+  exactly once.  For interpolation orders <= 1 (no spline prefilter over the
+  work box) the warped output does not depend on how the work boxes are cut, so
+  any exact tiling gives the reference's result; this is NOT a restatement of
+  the connectomics class."""
+
+  def __init__(self, outer_box, box_size, box_overlap=None, back_shift_small_boxes=False):
+    self.outer = outer_box
+    size = np.array(box_size)
+    ov = np.zeros_like(size) if box_overlap is None else np.array(box_overlap)
+    outer = np.array(outer_box.size)
+    size = np.minimum(size, outer)
+    self._starts, self._crops = [], []
+    for d in range(len(size)):
+      step = max(int(size[d] - ov[d]), 1)
+      st = list(range(0, max(int(outer[d] - ov[d]), 1), step))
+      st = sorted(set(min(s, int(outer[d] - size[d])) for s in st))
+      cuts = [0] + [st[i] + int(ov[d]) // 2 for i in range(1, len(st))] + [int(outer[d])]
+      self._starts.append([(s, int(size[d])) for s in st])
+      self._crops.append([(cuts[i], cuts[i + 1]) for i in range(len(st))])
+    self._shape = [len(s) for s in self._starts]
+
+  @property
+  def num_boxes(self):
+    return int(np.prod(self._shape))
+
+  def _coords(self, i):
+    out = []
+    for n in self._shape:
+      out.append(i % n)
+      i //= n
+    return out
+
+  def generate(self, i):
+    c = self._coords(i)
+    start = [self._starts[d][c[d]][0] for d in range(len(c))]
+    size = [self._starts[d][c[d]][1] for d in range(len(c))]
+    return tuple(c), BoundingBox(start=np.array(start) + self.outer.start, size=size)
+
+  def index_to_cropped_box(self, i):
+    c = self._coords(i)
+    start = [self._crops[d][c[d]][0] for d in range(len(c))]
+    end = [self._crops[d][c[d]][1] for d in range(len(c))]
+    return BoundingBox(start=np.array(start) + self.outer.start, end=np.array(end) + self.outer.start)
+
+
 def install(reference_root='/root/reference'):
   """Installs the stand-ins and makes `import sofima` resolve to the reference."""
   global _INSTALLED
@@ -429,7 +481,18 @@ def install(reference_root='/root/reference'):
       BoundingBox=BoundingBox,
       BoundingBoxBase=BoundingBox,
   )
+  cc.box_generator = _mod('connectomics.common.box_generator', BoxGenerator=BoxGenerator)
   c.common = cc
+  # warp.py imports these at module level; ndimage_warp (the only function the
+  # goldens run) touches none of them for non-uint64 images
+  cs = _mod('connectomics.segmentation')
+  cs.labels = _mod('connectomics.segmentation.labels')
+  c.segmentation = cs
+  if 'cv2' not in sys.modules:
+    _mod('cv2', INTER_NEAREST=0, INTER_LINEAR=1, INTER_CUBIC=2, INTER_LANCZOS4=4)
+  if 'skimage' not in sys.modules:
+    sk = _mod('skimage')
+    sk.exposure = _mod('skimage.exposure')
   _build_jax()
 
   link_dir = tempfile.mkdtemp(prefix='sofima_ref_')

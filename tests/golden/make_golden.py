@@ -685,8 +685,72 @@ def gen_relax_passes():
   save('relax_passes', **out)
 
 
+def ndimage_warp_cases():
+  """Inputs of the ndimage_warp fixtures (shared with nothing: stored in the
+  .npz).  Boxes are xyz (start, size) pairs; None = not given."""
+  rng = np.random.default_rng(4242)
+
+  def field(shape, amp, sig):
+    f = ndimage.gaussian_filter(rng.standard_normal(shape), (0,) + (sig,) * (len(shape) - 1))
+    return (f / np.abs(f).max() * amp).astype(np.float32)
+
+  img2 = em_like(rng, (96, 120))
+  map2 = field((2, 9, 11), 5.0, 1.5)
+  img3 = em_like(rng, (14, 44, 52), 1.5)
+  map3 = field((3, 6, 9, 10), 2.5, 1.0)
+  cases = {
+      # name: image, map, stride zyx, work xyz, overlap xyz, order, boxes, out_scale
+      'u8_2d': (img2, map2, (12, 12), (40, 32), (8, 8), 1, None, None),
+      'u8_2d_nearest': (img2, map2, (12.0, 12.0), (64, 64), (0, 0), 0, None, None),
+      'f32_2d': (img2.astype(np.float32) / 3, map2 * 2, (12, 12), (50, 50), (10, 4), 1, None,
+                 (1.0, 1.0)),
+      'u16_2d': (img2.astype(np.uint16) * 200, map2, (12, 12), (128, 128), (0, 0), 1, None, None),
+      'u8_3d': (img3, map3, (3, 6, 6), (20, 20, 6), (4, 4, 2), 1, None, None),
+      # map with context around the output box, output box inside the image box
+      'u8_3d_boxes': (img3, map3, (3, 6, 6), (24, 16, 5), (6, 4, 1), 1,
+                      dict(image=((100, 200, 10), (52, 44, 14)), map=((16, 33, 3), (10, 9, 6)),
+                           out=((104, 203, 11), (40, 36, 10))), (1.0, 1.0, 1.0)),
+      # output voxels twice the size of the image voxels in x and y
+      'f32_3d_scale': (img3.astype(np.float32), map3 * 0.5, (3, 6, 6), (32, 32, 8), (0, 0, 0), 1,
+                       dict(image=((0, 0, 0), (52, 44, 14)), map=((0, 0, 0), (10, 9, 6)),
+                            out=((1, 2, 1), (22, 18, 12))), (2.0, 2.0, 1.0)),
+  }
+  return cases
+
+
+def gen_ndimage_warp():
+  """warp.ndimage_warp (warp.py:189-335), the SciPy-only rendering path: the
+  reference function itself on small 2-d / 3-d images (uint8, uint16, float32;
+  linear and nearest; work boxes with overlap; map / image / output boxes;
+  out_scale)."""
+  from sofima import warp as rwarp
+  out = {'names': np.array(list(ndimage_warp_cases()))}
+  for name, (img, cmap, stride, work, ov, order, boxes, scale) in ndimage_warp_cases().items():
+    kw = {}
+    if boxes is not None:
+      for k in ('image', 'map', 'out'):
+        kw[k + '_box'] = refshim.BoundingBox(start=boxes[k][0], size=boxes[k][1])
+        out[f'{name}_{k}_box'] = np.array(boxes[k], np.int64)
+    if scale is not None:
+      kw['out_scale'] = scale
+      out[f'{name}_out_scale'] = np.array(scale, np.float64)
+    got = rwarp.ndimage_warp(img, cmap, stride, work, ov, order=order, parallelism=2, **kw)
+    print('ndimage_warp', name, got.shape, got.dtype, 'non-zero %.3f' % (got != 0).mean())
+    out[f'{name}_image'] = img
+    out[f'{name}_map'] = cmap
+    out[f'{name}_stride'] = np.array(stride, np.float64)
+    out[f'{name}_stride_is_int'] = np.bool_(all(isinstance(v, int) for v in stride))
+    out[f'{name}_work'] = np.array(work, np.int64)
+    out[f'{name}_overlap'] = np.array(ov, np.int64)
+    out[f'{name}_order'] = np.int64(order)
+    out[f'{name}_warped'] = got
+  save('ndimage_warp', **out)
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'irregular', 'montage3d', 'montage', 'stitch', 'passes', 'flowmap3d']
+  which = sys.argv[1:] or ['xcorr', 'peaks', 'flow', 'mesh', 'maps', 'clean', 'irregular', 'montage3d', 'montage', 'stitch', 'passes', 'flowmap3d', 'ndwarp']
+  if 'ndwarp' in which:
+    gen_ndimage_warp()
   if 'xcorr' in which:
     gen_xcorr_np()
   if 'peaks' in which:
