@@ -446,6 +446,10 @@ def main():
   if world == 1 and not args.no_legs:
     aux = aux_legs(dev, args.seed)
 
+  cfg_legs = None
+  if world == 1 and not args.no_legs:
+    cfg_legs = config_legs(dev, pre, args.seed)
+
   sharded = None
   if args.mesh_sharded > 0:
     sharded = mesh_sharded_leg(args.mesh_sharded, dev, rank, world)
@@ -500,6 +504,8 @@ def main():
     out['multi_gpu'] = multi
   if aux:
     out['aux_rooflines'] = aux
+  if cfg_legs:
+    out['configs_legs'] = cfg_legs
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline(size, args.seed + rank, args.pair)
@@ -575,6 +581,98 @@ def aux_legs(dev, seed):
          node_updates_per_s=round(nodes * iters / sec, 0), state=list(shape),
          bytes_per_node_update=fl * 4)
     del prev, x0
+  return out
+
+
+def config_legs(dev, canvas, seed):
+  """Driver-timed legs of BASELINE configs[2] and configs[4] at their workload
+  shapes (bounded samples; wall clock with the inputs resident or uploaded as
+  the drop-in functions do it):
+    configs[2]  8 x 8 montage of 4096^2 tiles: stitch_elastic.compute_flow_map
+                (patch 120, step 20, batch 256) on the 4 strip pairs of a 2 x 2
+                grid of 4096^2 tiles cut from the headline canvas, and 200 FIRE
+                steps of the [2, 64, 204, 204] montage mesh with the native
+                target-mesh prev_fn and drift removal;
+    configs[4]  volumetric: flow_field with 80^3 patches, step 40 on the overlap
+                strip of two 512^3 tiles (512 x 512 x 120 voxels) and 200 FIRE
+                steps of the [3, 64, 12, 12, 12] montage mesh (elastic_mesh_3d,
+                volumetric target mesh, per-column drift removal)."""
+  import torch
+  from scipy import ndimage
+  from sofima_amd import flow_field, mesh, stitch_elastic
+  from tests.util import synth_montage
+  out = []
+
+  def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    for _ in range(reps):
+      r = fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t) / reps, r
+
+  # -- configs[2]: flow leg ------------------------------------------------------
+  T, OV = 4096, 400
+  if canvas.shape[0] >= 2 * T - OV:
+    tiles = {(x, y): np.ascontiguousarray(canvas[y * (T - OV):y * (T - OV) + T,
+                                                 x * (T - OV):x * (T - OV) + T])
+             for y in range(2) for x in range(2)}
+    cx = np.zeros((2, 2, 2)); cx[0] = -OV          # coarse offsets of the (x+1, y) tiles
+    cy = np.zeros((2, 2, 2)); cy[1] = -OV
+    sec, (fl, _) = timed(lambda: stitch_elastic.compute_flow_map(tiles, cx, 0), 3)
+    sec_y, (fl_y, _) = timed(lambda: stitch_elastic.compute_flow_map(tiles, cy, 1), 3)
+    n_pairs = len(fl) + len(fl_y)
+    per_pair = (sec + sec_y) / n_pairs
+    shp = next(iter(fl.values())).shape
+    patches = int((shp[1] - 5) * (shp[2] - 5))
+    out.append({
+        'config': 'configs[2] flow', 'workload':
+            f'compute_flow_map on {n_pairs} overlap strips ({T} x {OV}) of a 2 x 2 grid of '
+            f'{T}^2 tiles, patch 120 step 20 batch 256 (host tiles: uploads included)',
+        'ms_per_strip_pair': round(per_pair * 1e3, 3), 'patches_per_pair': patches,
+        'mpix_s': round(T * OV / per_pair / 1e6, 1),
+        'montage_8x8_estimate_ms': round(per_pair * 112 * 1e3, 1),
+        'tops_algorithmic': round(2.0 * 120 ** 4 * patches / per_pair / 1e12, 1)})
+  # -- configs[2]: mesh leg ------------------------------------------------------
+  rng = np.random.default_rng(seed + 2)
+  iters = 200
+  for name, ms_shape, ov, stride, force, label in (
+      ('configs[2] mesh', (204, 204), 20, (20.0, 20.0), None, '[2, 64, 204, 204]'),
+      ('configs[4] mesh', (12, 12, 12), 3, (40.0, 40.0, 40.0), mesh.elastic_mesh_3d,
+       '[3, 64, 12, 12, 12]')):
+    nb, fx, fy, x0 = synth_montage(rng, 8, 8, ms_shape, ov, amp=4.0)
+    cfg = mesh.IntegrationConfig(
+        dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=stride, num_iters=iters, max_iters=iters,
+        stop_v_max=1e-9, dt_max=100, prefer_orig_order=force is None, start_cap=0.1,
+        final_cap=10.0, remove_drift=True)
+    fn = stitch_elastic.TargetMeshFn(nb, fx, fy, stride)
+    x_t = torch.from_numpy(x0).to(dev)
+    kw = {'mesh_force': force} if force is not None else {}
+    sec, _ = timed(lambda: mesh.relax_mesh(x_t, None, cfg, prev_fn=fn, **kw), 2)
+    nodes = int(np.prod(x0.shape[1:]))
+    out.append({
+        'config': name, 'workload':
+            f'{label} montage mesh (8 x 8 tiles), native target-mesh prev_fn, remove_drift, '
+            f'{iters} FIRE steps',
+        'us_per_step': round(sec / iters * 1e6, 2),
+        'node_updates_per_s': round(nodes * iters / sec, 0), 'nodes': nodes})
+  # -- configs[4]: flow leg ------------------------------------------------------
+  vol = ndimage.gaussian_filter(
+      rng.standard_normal((512 + 8, 512 + 8, 120 + 8), dtype=np.float32), 1.5)
+  vol = ((vol - vol.min()) / (vol.max() - vol.min()) * 255).astype(np.uint8)
+  a = torch.from_numpy(np.ascontiguousarray(vol[4:516, 4:516, 4:124])).to(dev)
+  b = torch.from_numpy(np.ascontiguousarray(vol[6:518, 1:513, 7:127])).to(dev)
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  sec, f = timed(lambda: calc.flow_field(a, b, (80, 80, 80), 40, batch_size=64), 2)
+  patches = int(np.prod(f.shape[1:]))
+  out.append({
+      'config': 'configs[4] flow', 'workload':
+          '512 x 512 x 120 overlap strip of two 512^3 tiles, 80^3 patches step 40 batch 64 '
+          '(FFT form, resident volumes)',
+      'ms_per_strip_pair': round(sec * 1e3, 3), 'patches_per_pair': patches,
+      'ms_per_patch': round(sec / patches * 1e3, 4),
+      'mvox_s': round(512 * 512 * 120 / sec / 1e6, 1)})
   return out
 
 

@@ -33,8 +33,9 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 6   /* 4: SfmProfile.mfma_issued; sfm_mesh_relax_banded; 5: SfmWarpDesc.coord_map_f64;
-                                6: SfmBandedDesc.host_halo / host_allgather / host_user */
+#define SFM_ABI_VERSION 7   /* 4: SfmProfile.mfma_issued; sfm_mesh_relax_banded; 5: SfmWarpDesc.coord_map_f64;
+                                6: SfmBandedDesc.host_halo / host_allgather / host_user;
+                                7: sfm_ndimage_warp */
 
 #define SFM_OK 0
 #define SFM_ERR_INVALID (-1)     /* bad argument / unsupported combination */
@@ -343,6 +344,39 @@ typedef struct SfmWarpDesc {
 } SfmWarpDesc;
 
 int sfm_warp_section(const SfmWarpDesc* desc);
+
+/* ------------------------------------------------------------------------
+ * warp.ndimage_warp (warp.py:189-335), the SciPy rendering path, 2-D and 3-D,
+ * as ONE kernel: per output voxel the node-space position (c - offset) / stride,
+ * the order-1 interpolation of the absolute source map (scipy.ndimage.
+ * map_coordinates, mode "constant", cval 0: a position outside the node grid
+ * gives the dense coordinate 0, like the reference), and the order-0 / order-1
+ * sampling of the image at the dense coordinates, all in double like SciPy and
+ * in SciPy's operation order (weights 1 - t and 1 - (1 - t), value x weights in
+ * axis order, taps added in row-major order), so integer images come out bit
+ * for bit and float images to the last bit.  The work-box decomposition of the
+ * reference (work_size / overlap) does not change the result for these orders
+ * and has no counterpart here.  Axes are z, y, x; 2-D inputs use y, x of the
+ * last two entries with shape[0] = 1.
+ * ---------------------------------------------------------------------- */
+typedef struct SfmNdWarpDesc {
+  int32_t ndim;                 /* 2 or 3                                      */
+  int32_t dtype;                /* SFM_DTYPE_U8 | U16 | F32 of image and out   */
+  int32_t order;                /* 0 nearest, 1 linear                         */
+  int32_t image_shape[3];       /* z, y, x                                     */
+  int32_t map_shape[3];         /* z, y, x nodes                               */
+  int32_t out_shape[3];         /* z, y, x                                     */
+  double stride[3];             /* z, y, x output voxels per map node          */
+  double offset[3];             /* z, y, x of map node 0 relative to out voxel 0 */
+  const void* image;            /* device [z, y, x]                            */
+  const double* src_map;        /* device [ndim, z, y, x] float64, channels x,
+                                   y[, z]: absolute source coordinates in image
+                                   voxels (warp.py:250-265)                    */
+  void* out;                    /* device [z, y, x]                            */
+  void* stream;
+} SfmNdWarpDesc;
+
+int sfm_ndimage_warp(const SfmNdWarpDesc* desc);
 
 /* ------------------------------------------------------------------------
  * Dynamic-range mask of an overlap strip, the step in front of the

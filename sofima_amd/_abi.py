@@ -186,6 +186,23 @@ class SfmWarpDesc(C.Structure):
   ]
 
 
+class SfmNdWarpDesc(C.Structure):
+  _fields_ = [
+      ('ndim', i32),
+      ('dtype', i32),
+      ('order', i32),
+      ('image_shape', i32 * 3),
+      ('map_shape', i32 * 3),
+      ('out_shape', i32 * 3),
+      ('stride', C.c_double * 3),
+      ('offset', C.c_double * 3),
+      ('image', C.c_void_p),
+      ('src_map', C.c_void_p),
+      ('out', C.c_void_p),
+      ('stream', C.c_void_p),
+  ]
+
+
 class SfmRangeMaskDesc(C.Structure):
   _fields_ = [
       ('dtype', i32),
@@ -350,6 +367,7 @@ SIGNATURES = {
     'sfm_flow_starts': (C.c_int, [C.POINTER(SfmFlowStartsDesc)]),
     'sfm_flow_scatter': (C.c_int, [C.POINTER(SfmFlowScatterDesc)]),
     'sfm_warp_section': (C.c_int, [C.POINTER(SfmWarpDesc)]),
+    'sfm_ndimage_warp': (C.c_int, [C.POINTER(SfmNdWarpDesc)]),
     'sfm_range_mask': (C.c_int, [C.POINTER(SfmRangeMaskDesc), C.c_void_p]),
     'sfm_target_mesh': (C.c_int, [C.POINTER(SfmTargetMeshDesc), C.c_void_p,
                                   C.c_void_p, C.c_void_p]),

@@ -178,3 +178,175 @@ extern "C" int sfm_warp_section(const SfmWarpDesc* d) {
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }
+
+// ---------------------------------------------------------------------------
+// warp.ndimage_warp (warp.py:189-335): scipy.ndimage.map_coordinates twice --
+// order 1 on the float64 source map at the node-space position of the output
+// voxel, then order 0 / 1 on the image at the resulting coordinates.  Double
+// arithmetic in SciPy's order (this file is built with -ffp-contract=off).
+// ---------------------------------------------------------------------------
+namespace {
+
+struct NdWarpArgs {
+  const void* image;
+  const double* map;
+  void* out;
+  int order;
+  int ishape[3], mshape[3], oshape[3];
+  double stride[3], offset[3];
+};
+
+// scipy NI_GeometricTransform, order 1, mode "constant", cval 0: outside
+// [0, len - 1] on any axis -> 0; taps beyond the last sample carry weight 0 and
+// are read from the last sample.
+template <int DIM, typename T>
+__device__ __forceinline__ double linear_sample(const T* __restrict__ a, const int* shape,
+                                                const double* c) {
+  long long base[DIM];
+  double w[DIM][2];
+  long long pitch = 1;
+  long long step[DIM];
+#pragma unroll
+  for (int d = DIM - 1; d >= 0; --d) {
+    step[d] = pitch;
+    pitch *= shape[3 - DIM + d];
+  }
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    const int len = shape[3 - DIM + d];
+    if (c[d] < 0.0 || c[d] > static_cast<double>(len - 1)) return 0.0;
+    const double fl = floor(c[d]);
+    const double t = c[d] - fl;
+    w[d][0] = 1.0 - t;
+    w[d][1] = 1.0 - w[d][0];
+    base[d] = static_cast<long long>(fl);
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int tap = 0; tap < (1 << DIM); ++tap) {
+    long long idx = 0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      const int bit = (tap >> (DIM - 1 - d)) & 1;
+      const int len = shape[3 - DIM + d];
+      long long i = base[d] + bit;
+      i = i > len - 1 ? len - 1 : i;
+      idx += i * step[d];
+    }
+    double coeff = static_cast<double>(a[idx]);
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) coeff = coeff * w[d][(tap >> (DIM - 1 - d)) & 1];
+    acc = acc + coeff;
+  }
+  return acc;
+}
+
+template <int DIM, typename T>
+__device__ __forceinline__ double nearest_sample(const T* __restrict__ a, const int* shape,
+                                                 const double* c) {
+  long long idx = 0, pitch = 1;
+#pragma unroll
+  for (int d = DIM - 1; d >= 0; --d) {
+    const int len = shape[3 - DIM + d];
+    if (c[d] < 0.0 || c[d] > static_cast<double>(len - 1)) return 0.0;
+    long long i = static_cast<long long>(floor(c[d] + 0.5));
+    i = i > len - 1 ? len - 1 : i;
+    idx += i * pitch;
+    pitch *= len;
+  }
+  return static_cast<double>(a[idx]);
+}
+
+// double -> output type like NI's CASE_INTERP_OUT_*: unsigned types add 0.5 to
+// positive values, clip and truncate; floats are narrowed.
+template <typename T>
+__device__ __forceinline__ T nd_convert(double v, double vmax) {
+  v = v > 0.0 ? v + 0.5 : 0.0;
+  v = v > vmax ? vmax : v;
+  return static_cast<T>(v);
+}
+template <>
+__device__ __forceinline__ float nd_convert<float>(double v, double) {
+  return static_cast<float>(v);
+}
+
+template <int DIM, typename T>
+__global__ void __launch_bounds__(kBlock) ndimage_warp_kernel(NdWarpArgs a) {
+  const long long n = (long long)a.oshape[0] * a.oshape[1] * a.oshape[2];
+  const long long i = blockIdx.x * (long long)kBlock + threadIdx.x;
+  if (i >= n) return;
+  int o[3];
+  o[2] = static_cast<int>(i % a.oshape[2]);
+  o[1] = static_cast<int>((i / a.oshape[2]) % a.oshape[1]);
+  o[0] = static_cast<int>(i / ((long long)a.oshape[2] * a.oshape[1]));
+  // node-space position (warp.py:300-301)
+  double pos[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    const int ax = 3 - DIM + d;
+    pos[d] = (static_cast<double>(o[ax]) - a.offset[ax]) / a.stride[ax];
+  }
+  // dense coordinates z, y, x = channels DIM - 1 ... 0 of the map (warp.py:304-307)
+  const long long nodes = (long long)a.mshape[0] * a.mshape[1] * a.mshape[2];
+  double dense[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d)
+    dense[d] = linear_sample<DIM, double>(a.map + (long long)(DIM - 1 - d) * nodes, a.mshape, pos);
+  const T* img = static_cast<const T*>(a.image);
+  const double v = a.order == 0 ? nearest_sample<DIM, T>(img, a.ishape, dense)
+                                : linear_sample<DIM, T>(img, a.ishape, dense);
+  constexpr double vmax = sizeof(T) == 1 ? 255.0 : 65535.0;
+  static_cast<T*>(a.out)[i] = nd_convert<T>(v, vmax);
+}
+
+}  // namespace
+
+extern "C" int sfm_ndimage_warp(const SfmNdWarpDesc* d) {
+  if (!d || !d->image || !d->src_map || !d->out)
+    return sfm::fail(SFM_ERR_INVALID, "ndimage_warp: NULL argument");
+  if (d->ndim != 2 && d->ndim != 3) return sfm::fail(SFM_ERR_INVALID, "ndimage_warp: ndim %d", d->ndim);
+  if (d->order != 0 && d->order != 1)
+    return sfm::fail(SFM_ERR_INVALID, "ndimage_warp: interpolation order %d (0 and 1 are built)",
+                     d->order);
+  NdWarpArgs a;
+  a.image = d->image;
+  a.map = d->src_map;
+  a.out = d->out;
+  a.order = d->order;
+  long long n = 1;
+  for (int k = 0; k < 3; ++k) {
+    if (d->image_shape[k] < 1 || d->map_shape[k] < 1 || d->out_shape[k] < 1)
+      return sfm::fail(SFM_ERR_INVALID, "ndimage_warp: bad shape");
+    if (d->ndim == 2 && k == 0 &&
+        (d->image_shape[0] != 1 || d->map_shape[0] != 1 || d->out_shape[0] != 1))
+      return sfm::fail(SFM_ERR_INVALID, "ndimage_warp: 2-d arrays have shape[0] = 1");
+    if (k >= 3 - d->ndim && !(d->stride[k] != 0.0))
+      return sfm::fail(SFM_ERR_INVALID, "ndimage_warp: stride");
+    a.ishape[k] = d->image_shape[k];
+    a.mshape[k] = d->map_shape[k];
+    a.oshape[k] = d->out_shape[k];
+    a.stride[k] = d->stride[k];
+    a.offset[k] = d->offset[k];
+    n *= d->out_shape[k];
+  }
+  const long long grid = (n + kBlock - 1) / kBlock;
+  if (grid > 0x7fffffffLL) return sfm::fail(SFM_ERR_INVALID, "ndimage_warp: too large");
+  hipStream_t st = static_cast<hipStream_t>(d->stream);
+  const dim3 g(static_cast<unsigned>(grid)), b(kBlock);
+#define SFM_NDW(T)                                                                 \
+  do {                                                                             \
+    if (d->ndim == 2)                                                              \
+      hipLaunchKernelGGL((ndimage_warp_kernel<2, T>), g, b, 0, st, a);             \
+    else                                                                           \
+      hipLaunchKernelGGL((ndimage_warp_kernel<3, T>), g, b, 0, st, a);             \
+  } while (0)
+  switch (d->dtype) {
+    case SFM_DTYPE_U8: SFM_NDW(unsigned char); break;
+    case SFM_DTYPE_U16: SFM_NDW(unsigned short); break;
+    case SFM_DTYPE_F32: SFM_NDW(float); break;
+    default: return sfm::fail(SFM_ERR_INVALID, "ndimage_warp: dtype %d", d->dtype);
+  }
+#undef SFM_NDW
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}

@@ -148,6 +148,12 @@ def _overlap_strips(pre, post, off_xy, axis: int, stride):
   return pre[tuple(pre_sl)], post[tuple(post_sl)], off
 
 
+# Tile pairs whose flow_field() call may be enqueued before the oldest result is
+# fetched (compute_flow_map, compute_flow_map3d): enough for the host to stay
+# ahead of the GPU, small enough to bound the device memory held by queued pairs.
+MAX_PAIRS_IN_FLIGHT = 8
+
+
 def compute_flow_map(tile_map, offset_map: np.ndarray, axis: int,
                      patch_size=(120, 120), stride=(20, 20),
                      batch_size: int = 256):
@@ -185,6 +191,11 @@ def compute_flow_map(tile_map, offset_map: np.ndarray, axis: int,
           pre, post, patch_size=patch_size, step=stride, batch_size=batch_size,
           device_output=True)))
       offsets[x, y] = off
+      # bounded run-ahead: strips and workspaces of the queued pairs stay
+      # allocated until the compute stream has passed them
+      if len(pending) >= MAX_PAIRS_IN_FLIGHT:
+        key, f = pending.pop(0)
+        flows[key] = np.pad(np.asarray(f), pads, constant_values=np.nan)
   for key, f in pending:
     flows[key] = np.pad(np.asarray(f), pads, constant_values=np.nan)
   return flows, offsets
@@ -202,8 +213,13 @@ def _aligned_overlap3d(tile_shape, offset, axis: int, stride):
   -- xyz integers -- and the xyz offset recorded for the pair.
   """
   shape = np.asarray(tile_shape, dtype=np.float64)
+  # (the reference keeps the neighbour position in a connectomics BoundingBox,
+  # whose corners are integers: a fractional coarse offset is truncated there --
+  # third-party semantics, absent from /root/reference, pinned for integer
+  # offsets only -- and the recorded offsets are ints)
   pos = np.array([shape[0] * (1 - axis) + offset[0], shape[1] * axis + offset[1],
                   offset[2]], dtype=np.float64)
+  pos = np.trunc(pos)
 
   def overlap(nb):
     lo = np.maximum(0.0, nb)
@@ -230,7 +246,7 @@ def _aligned_overlap3d(tile_shape, offset, axis: int, stride):
   rec = pos.copy()
   rec[axis] = -size[axis]
   return (cur.astype(int), nb.astype(int), size.astype(int),
-          tuple(float(v) for v in rec))
+          tuple(int(v) for v in rec))
 
 
 def compute_flow_map3d(tile_map, tile_shape, offset_map: np.ndarray, axis: int,
@@ -270,6 +286,9 @@ def compute_flow_map3d(tile_map, tile_shape, offset_map: np.ndarray, axis: int,
           pre, post, patch_size=patch_size, step=stride, batch_size=batch_size,
           device_output=True)))
       offsets[x, y] = rec
+      if len(pending) >= MAX_PAIRS_IN_FLIGHT:   # two overlap volumes + FFT workspace each
+        key, f = pending.pop(0)
+        flows[key] = np.pad(np.asarray(f), pads, constant_values=np.nan)
   for key, f in pending:   # fetched after the last pair is enqueued (compute_flow_map)
     flows[key] = np.pad(np.asarray(f), pads, constant_values=np.nan)
   return flows, offsets

@@ -12,8 +12,10 @@ resampling semantics (convertMaps rounding, the 32 x 32-phase weight tables of
 initInterTab2D with 15-bit fixed point for 8-bit images, constant zero border)
 are restated from OpenCV's published algorithm and pinned by the reference's
 own tests (tests/warp_test.py:27-82) only: "parity unpinned" beyond those.
-The other functions of the reference's warp.py (ndimage_warp, render_tiles,
-warp_points) are host-side rendering utilities and out of scope.
+`ndimage_warp` (warp.py:189-335), the SciPy-only rendering path, is built as
+well and IS pinned: the reference function runs through the golden shim and
+the kernel reproduces its output bit for bit (tests/golden/ndimage_warp.npz).
+render_tiles and warp_points are host-side utilities and out of scope.
 """
 from __future__ import annotations
 
@@ -220,3 +222,105 @@ def warp_subvolume(image: np.ndarray, image_box, coord_map: np.ndarray, map_box,
   if orig_dtype == np.uint16 or image.dtype == np.uint16:
     warped = warped.view(np.uint16)
   return warped.astype(orig_dtype)
+
+
+def ndimage_warp(image: np.ndarray, coord_map: np.ndarray, stride, work_size, overlap,
+                 order=1, map_coordinates=None, image_box=None, map_box=None, out_box=None,
+                 parallelism: int = 1, out_scale=(1.0, 1.0, 1.0)) -> np.ndarray:
+  """Warps a subvolume of data using map_coordinates semantics (warp.py:189-335).
+
+  image: [z, ] y, x data (uint8 / uint16 / float32); coord_map: [N, [z,] y, x]
+  relative coordinate map; stride: [z,] y, x image voxels per map node;
+  image_box / map_box / out_box: objects with `.start` / `.size` in xyz (or
+  (start, size) pairs); out_scale: xy[z] out_voxel / source_voxel.
+
+  One kernel computes, per output voxel, what the reference computes with two
+  rounds of scipy.ndimage.map_coordinates per work box (dense coordinates by
+  order-1 interpolation of the absolute map, then order-`order` sampling of the
+  image), in double and in SciPy's operation order -- bit for bit the
+  reference's output (tests/golden/ndimage_warp.npz).  `work_size`, `overlap`
+  and `parallelism` only shape the reference's host loop and do not change the
+  result for orders 0 and 1; they are validated and otherwise unused.  Built:
+  order 0 and 1 with the default `map_coordinates`; higher spline orders,
+  custom samplers and uint64 label volumes raise NotImplementedError (use
+  `warp_subvolume` for label volumes).
+  """
+  del parallelism
+  image = np.asarray(image)
+  coord_map = np.asarray(coord_map)
+  shape = coord_map.shape[1:]
+  dim = len(shape)
+  assert dim == len(stride)
+  assert dim == len(overlap)
+  assert dim == len(work_size)
+  if dim != image.ndim:
+    raise ValueError(f'Dimension mismatch: image: {image.ndim} vs coord map: {dim}')
+  if map_coordinates is not None:
+    raise NotImplementedError('ndimage_warp: custom map_coordinates callables run on the host only')
+  if image.dtype == np.uint64:
+    raise NotImplementedError('ndimage_warp: uint64 label volumes (use warp_subvolume)')
+  if order not in (0, 1):
+    raise NotImplementedError(f'ndimage_warp: interpolation order {order} (0 and 1 are built)')
+  if dim not in (2, 3):
+    raise ValueError(f'ndimage_warp: {dim}-d data')
+  if map_box is not None and image_box is None:
+    raise ValueError('image_box has to be specified when map_box is used.')
+
+  # absolute source map, operation for operation (map_utils.to_absolute adds in
+  # place in the map's dtype; the out_scale product is float64): warp.py:250-265
+  src = np.array(coord_map, copy=True)
+  idx = np.mgrid[tuple(slice(0, s) for s in shape)]
+  off_zyx = [h * st for h, st in zip(idx, stride)]
+  for i in range(dim):
+    src[i, ...] += off_zyx[-(i + 1)]
+  if map_box is not None:
+    map_start, _ = _box(map_box)
+    img_start, _ = _box(image_box)
+    src += (map_start[:dim] * np.asarray(stride)[::-1] -
+            img_start[:dim] / np.asarray(out_scale)[:dim]).reshape((dim,) + (1,) * dim)
+  reshaper = (slice(None),) + (np.newaxis,) * dim
+  src = np.ascontiguousarray(src.copy() * np.array(out_scale[:dim])[reshaper], dtype=np.float64)
+
+  if out_box is not None:
+    out_start, out_size = _box(out_box)
+    out_shape = tuple(int(v) for v in np.asarray(out_size)[::-1][-dim:])
+  else:
+    out_start = np.zeros(3, np.int64)
+    out_shape = image.shape
+  if map_box is not None:
+    map_start, _ = _box(map_box)
+    offset = (map_start * np.asarray(stride)[::-1] - out_start)[::-1]
+  else:
+    offset = (0,) * dim
+
+  if image.dtype == np.uint8:
+    dtype, view = _abi.DTYPE_U8, np.uint8
+  elif image.dtype == np.uint16:
+    dtype, view = _abi.DTYPE_U16, np.int16
+  elif image.dtype == np.float32:
+    dtype, view = _abi.DTYPE_F32, np.float32
+  else:
+    raise NotImplementedError(f'ndimage_warp: {image.dtype} images (uint8, uint16, float32)')
+  dev = _dev.device()
+  img_t = torch.from_numpy(np.ascontiguousarray(image).view(view)).to(dev)
+  map_t = torch.from_numpy(src).to(dev)
+  out_t = torch.empty(out_shape, dtype=img_t.dtype, device=dev)
+  pad = (1,) * (3 - dim)
+  d = _abi.SfmNdWarpDesc()
+  d.ndim = dim
+  d.dtype = dtype
+  d.order = int(order)
+  d.image_shape = (C.c_int32 * 3)(*(pad + tuple(image.shape)))
+  d.map_shape = (C.c_int32 * 3)(*(pad + tuple(shape)))
+  d.out_shape = (C.c_int32 * 3)(*(pad + tuple(out_shape)))
+  d.stride = (C.c_double * 3)(*((1.0,) * (3 - dim) + tuple(float(v) for v in stride)))
+  d.offset = (C.c_double * 3)(*((0.0,) * (3 - dim) + tuple(float(v) for v in offset[-dim:])))
+  d.image = img_t.data_ptr()
+  d.src_map = map_t.data_ptr()
+  d.out = out_t.data_ptr()
+  d.stream = _dev.stream_ptr()
+  _abi.check(_abi.load().sfm_ndimage_warp(C.byref(d)))
+  warped = out_t.cpu().numpy()
+  if image.dtype == np.uint16:
+    warped = warped.view(np.uint16)
+  return warped.astype(image.dtype)

@@ -33,7 +33,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_channel(lib):
-  assert lib.sfm_version() == 6
+  assert lib.sfm_version() == 7
   # A NULL descriptor is rejected with a message, not a crash.
   rc = lib.sfm_mesh_force(None, None)
   assert rc == -1
@@ -85,6 +85,7 @@ def test_struct_layouts_match_header():
                      ('SfmMaskIrregularDesc', _abi.SfmMaskIrregularDesc),
                      ('SfmRangeMaskDesc', _abi.SfmRangeMaskDesc),
                      ('SfmWarpDesc', _abi.SfmWarpDesc),
+                     ('SfmNdWarpDesc', _abi.SfmNdWarpDesc),
                      ('SfmFlowStartsDesc', _abi.SfmFlowStartsDesc),
                      ('SfmFlowScatterDesc', _abi.SfmFlowScatterDesc),
                      ('SfmMeshShard', _abi.SfmMeshShard),

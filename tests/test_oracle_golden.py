@@ -313,3 +313,23 @@ def test_three_pass_driver_oracle_vs_reference_output(golden, case):
   scale = np.nanmax(np.abs(want))
   np.testing.assert_allclose(np.nan_to_num(x), np.nan_to_num(want), atol=1e-4 * scale)
   np.testing.assert_allclose(ek, g[f'{case}_ekin'], rtol=1e-3, atol=1e-7)
+
+
+def test_ndimage_warp_oracle_vs_reference_output(golden):
+  """oracle.warp_oracle.ndimage_warp == the arrays the reference's
+  warp.ndimage_warp produced (work boxes with overlap, boxes, out_scale,
+  uint8 / uint16 / float32, linear and nearest), bit for bit."""
+  from oracle import warp_oracle
+  from tests.util import ndimage_warp_case
+  g = golden('ndimage_warp')
+  for name in g['names']:
+    img, cmap, stride, _, _, order, boxes, scale, want = ndimage_warp_case(g, str(name))
+    kw = {}
+    if boxes is not None:
+      kw = dict(image_start=boxes['image'][0], map_start=boxes['map'][0],
+                out_start=boxes['out'][0], out_size=boxes['out'][1])
+    if scale is not None:
+      kw['out_scale'] = scale
+    got = warp_oracle.ndimage_warp(img, cmap, stride, order=order, **kw)
+    assert got.dtype == want.dtype and got.shape == want.shape, name
+    np.testing.assert_array_equal(got, want, err_msg=str(name))

@@ -165,3 +165,20 @@ def oracle_flow_batches(tmp_dir, pre, post, patch_size, step, batch_size, batche
   with mp.get_context('spawn').Pool(procs, initializer=_oracle_init,
                                     initargs=(paths, kw)) as pool:
     return dict(pool.imap_unordered(_oracle_batch, list(batches)))
+
+
+def ndimage_warp_case(g, name):
+  """Arguments of one ndimage_warp fixture: (image, map, stride, work, overlap,
+  order, boxes or None ({image, map, out}: (start xyz, size xyz)), out_scale or
+  None, expected)."""
+  stride = g[f'{name}_stride']
+  stride = tuple(int(v) for v in stride) if bool(g[f'{name}_stride_is_int']) else tuple(
+      float(v) for v in stride)
+  boxes = None
+  if f'{name}_image_box' in g.files:
+    boxes = {k: (g[f'{name}_{k}_box'][0], g[f'{name}_{k}_box'][1])
+             for k in ('image', 'map', 'out')}
+  scale = tuple(g[f'{name}_out_scale']) if f'{name}_out_scale' in g.files else None
+  return (g[f'{name}_image'], g[f'{name}_map'], stride, tuple(g[f'{name}_work']),
+          tuple(g[f'{name}_overlap']), int(g[f'{name}_order']), boxes, scale,
+          g[f'{name}_warped'])
