@@ -177,6 +177,30 @@ __device__ __forceinline__ void spring_xy(float d0, float d1, float l0, float ne
   f[1] = v1;
 }
 
+// The same spring with a run-time link direction (dx, dy in {-1, 0, 1}): the
+// operations and their order are those of spring_xy<DX, DY>, so the result is
+// bit-identical (used where the link differs from lane to lane).
+__device__ __forceinline__ void spring_xy_rt(float d0, float d1, float l0, float neg_k,
+                                             int prefer, int dx, int dy, float* f) {
+  const float l = sfm_sqrt(d0 * d0 + d1 * d1);
+  const float r = sfm_div(l0, l);
+  float t0 = r, t1 = r;
+  if (prefer) {
+    const float sg0 = d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f);
+    const float sg1 = d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f);
+    const float m0 = r * (static_cast<float>(dx) * sg0);
+    const float m1 = r * (static_cast<float>(dy) * sg1);
+    t0 = dx != 0 ? m0 : r;
+    t1 = dy != 0 ? m1 : r;
+  }
+  float v0 = (neg_k * (1.0f - t0)) * d0;
+  float v1 = (neg_k * (1.0f - t1)) * d1;
+  if (!isfinite(v0)) v0 = 0.f;
+  if (!isfinite(v1)) v1 = 0.f;
+  f[0] = v0;
+  f[1] = v1;
+}
+
 // inplane_force at one node from an LDS tile: the four link families of
 // build_params (ncomp 2) unrolled, same operation order as node_force_at with
 // order2d.  `ctr` indexes the node inside a tile of row pitch TW.
@@ -1939,17 +1963,37 @@ mesh_persist2d_kernel(MeshParams p, const float* __restrict__ xg,
 //      the step and redoes it with the uphill scalars (dt *= f_dec, v = 0).
 // Every workgroup sees the same sums, takes the same decision and redoes the
 // same steps: the trajectory is bit-identical to the non-speculative kernel.
+//
+// T = 16 (r4): every spring ONCE.  The step is a chain of dependent latencies on
+// one wave per SIMD (2.0 of the 4.6 us of a step are the force evaluation), and
+// a node evaluated each of its eight springs itself although the far-side term
+// of node n for link L is the near-side term of node n - dir(L), bit for bit
+// (see integrate_shared2d_kernel).  Now a node evaluates its four near-side
+// springs only and leaves them in LDS; the 94 near-side springs of HALO nodes
+// that tile nodes need (left column for links 0 and 2, top row for 1, 2, 3,
+// right column for 3) are evaluated by two extra waves, one spring per lane,
+// with the run-time-direction form of the same spring; after a barrier every
+// node adds far sides (from LDS) and near sides (its registers) in the order it
+// always did.  Same floats in the same order: bit-identical trajectories.
 // ---------------------------------------------------------------------------
 template <int T>
-__global__ void __launch_bounds__(T * T)
+constexpr int spec_threads() { return T == 16 ? T * T + 128 : T * T; }
+
+template <int T>
+__global__ void __launch_bounds__(spec_threads<T>())
 mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
                            const float* __restrict__ vg, float* __restrict__ xo,
                            float* __restrict__ vo, float* __restrict__ ao,
                            const float* __restrict__ prevg, PersistArgs q) {
   using TL = Tile<T>;
-  constexpr int NT = TL::kThreads;
+  constexpr bool SH = T == 16;            // every spring once, two halo waves
+  constexpr int NM = TL::kThreads;        // threads that own a node
+  constexpr int NT = spec_threads<T>();   // all threads (polls, reductions)
+  constexpr int kHaloPollsS = (TL::kHalo * kNodeGran + NT - 1) / NT;
   constexpr int kPartPolls1 = (kMaxWg + NT - 1) / NT;  // one value per workgroup
   __shared__ float xt[2][T + 2][T + 3];
+  // near-side spring forces of every frame node, by link and component (SH)
+  __shared__ float nf[SH ? 4 : 1][2][SH ? T + 2 : 1][SH ? T + 3 : 1];
   __shared__ float hval[TL::kHalo][kNodeGran];
   __shared__ float part_all[kMaxWg];
   __shared__ float wred[TL::kWavesT];
@@ -1957,16 +2001,17 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int ly = tid / T, lx = tid % T;
+  const bool owner = tid < NM;            // (the halo waves own no node)
+  const int ly = owner ? tid / T : 0, lx = owner ? tid % T : 0;
   const int wg = blockIdx.x;
   const int tx_i = wg % q.ntx;
   const int ty_i = (wg / q.ntx) % q.nty;
   const int slice = wg / (q.ntx * q.nty);
   const int yi = ty_i * T + ly, xi = tx_i * T + lx;
-  const bool active = yi < p.Y && xi < p.X;
+  const bool active = owner && yi < p.Y && xi < p.X;
   const long long plane = (long long)p.Y * p.X;
   const long long n = slice * plane + (long long)yi * p.X + xi;
-  const int pidx = perim_index<T>(ly, lx);
+  const int pidx = owner ? perim_index<T>(ly, lx) : -1;
 
   int hy = 0, hx = 0;
   long long h_n = -1;
@@ -1976,10 +2021,10 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X)
       h_n = slice * plane + (long long)gy * p.X + gx;
   }
-  long long h_off[TL::kHaloPolls];
-  float* h_dst[TL::kHaloPolls];
+  long long h_off[kHaloPollsS];
+  float* h_dst[kHaloPollsS];
 #pragma unroll
-  for (int u = 0; u < TL::kHaloPolls; ++u) {
+  for (int u = 0; u < kHaloPollsS; ++u) {
     h_off[u] = -1;
     h_dst[u] = nullptr;
     const int t = tid + u * NT;
@@ -2016,9 +2061,77 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
 #pragma unroll
   for (int L = 0; L < 4; ++L) l0[L] = vec_len(p.rest[L], 2);
 
+  // Halo waves (SH): lane -> (frame node, link) of one near-side spring that a
+  // tile node needs as its far side.  Frame coordinates: tile nodes at 1 .. T.
+  //   link 0 (1, 0):  (1..T, 0)                              T springs
+  //   link 1 (0, 1):  (0, 1..T)                              T
+  //   link 2 (1, 1):  (0, 0..T-1), (1..T-1, 0)               2 T - 1
+  //   link 3 (-1, 1): (0, 2..T+1), (1..T-1, T+1)             2 T - 1
+  int hs_y = 0, hs_x = 0, hs_L = -1, hs_dx = 0, hs_dy = 0;
+  if (SH && !owner) {
+    const int i = tid - NM;
+    if (i < T) { hs_L = 0; hs_y = 1 + i; hs_x = 0; }
+    else if (i < 2 * T) { hs_L = 1; hs_y = 0; hs_x = 1 + (i - T); }
+    else if (i < 3 * T) { hs_L = 2; hs_y = 0; hs_x = i - 2 * T; }
+    else if (i < 4 * T - 1) { hs_L = 2; hs_y = 1 + (i - 3 * T); hs_x = 0; }
+    else if (i < 5 * T - 1) { hs_L = 3; hs_y = 0; hs_x = 2 + (i - (4 * T - 1)); }
+    else if (i < 6 * T - 2) { hs_L = 3; hs_y = 1 + (i - (5 * T - 1)); hs_x = T + 1; }
+    if (hs_L >= 0) {
+      hs_dx = p.dir[hs_L][0];
+      hs_dy = p.dir[hs_L][1];
+    }
+  }
+  static_assert(!SH || 6 * T - 2 <= NT - NM, "one halo spring per halo-wave lane");
+
+  // Net spring force on this thread's node from the positions in xt.  Contains
+  // a barrier when SH: called by ALL threads.
   auto tile_force = [&](float* out) {
     const float s0 = xt[0][ly + 1][lx + 1], s1 = xt[1][ly + 1][lx + 1];
     float acc0 = 0.f, acc1 = 0.f;
+    if constexpr (SH) {
+      float nr[4][2];
+      if (owner) {
+#define SFM_NEAR_EVAL(L, DX, DY)                                                    \
+        spring_xy<DX, DY>(xt[0][ly + 1 + (DY)][lx + 1 + (DX)] - s0 + p.rest[L][0],   \
+                          xt[1][ly + 1 + (DY)][lx + 1 + (DX)] - s1 + p.rest[L][1],   \
+                          l0[L], p.neg_k[L], p.prefer, nr[L]);                      \
+        nf[L][0][ly + 1][lx + 1] = nr[L][0];                                        \
+        nf[L][1][ly + 1][lx + 1] = nr[L][1];
+        SFM_NEAR_EVAL(0, 1, 0) SFM_NEAR_EVAL(1, 0, 1) SFM_NEAR_EVAL(2, 1, 1)
+        SFM_NEAR_EVAL(3, -1, 1)
+#undef SFM_NEAR_EVAL
+      } else if (hs_L >= 0) {
+        float f[2];
+        spring_xy_rt(xt[0][hs_y + hs_dy][hs_x + hs_dx] - xt[0][hs_y][hs_x] + p.rest[hs_L][0],
+                     xt[1][hs_y + hs_dy][hs_x + hs_dx] - xt[1][hs_y][hs_x] + p.rest[hs_L][1],
+                     l0[hs_L], p.neg_k[hs_L], p.prefer, hs_dx, hs_dy, f);
+        nf[hs_L][0][hs_y][hs_x] = f[0];
+        nf[hs_L][1][hs_y][hs_x] = f[1];
+      }
+      __syncthreads();
+#define SFM_FAR_ADD(L, DX, DY)                                                      \
+      {                                                                             \
+        const bool ok = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&      \
+                        yi - (DY) < p.Y;                                            \
+        const float f0 = nf[L][0][ly + 1 - (DY)][lx + 1 - (DX)];                    \
+        const float f1 = nf[L][1][ly + 1 - (DY)][lx + 1 - (DX)];                    \
+        acc0 = acc0 + (ok ? f0 : 0.f);                                              \
+        acc1 = acc1 + (ok ? f1 : 0.f);                                              \
+      }
+#define SFM_NEAR_SUB(L, DX, DY)                                                     \
+      {                                                                             \
+        const bool ok = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&      \
+                        yi + (DY) < p.Y;                                            \
+        acc0 = acc0 - (ok ? nr[L][0] : 0.f);                                        \
+        acc1 = acc1 - (ok ? nr[L][1] : 0.f);                                        \
+      }
+      if (owner) {
+        SFM_FAR_ADD(0, 1, 0) SFM_FAR_ADD(1, 0, 1) SFM_FAR_ADD(2, 1, 1) SFM_FAR_ADD(3, -1, 1)
+        SFM_NEAR_SUB(0, 1, 0) SFM_NEAR_SUB(1, 0, 1) SFM_NEAR_SUB(2, 1, 1) SFM_NEAR_SUB(3, -1, 1)
+      }
+#undef SFM_FAR_ADD
+#undef SFM_NEAR_SUB
+    } else {
 #define SFM_FAR(L, DX, DY)                                                          \
     {                                                                               \
       const bool ok = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&        \
@@ -2045,6 +2158,7 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     SFM_NEAR(0, 1, 0) SFM_NEAR(1, 0, 1) SFM_NEAR(2, 1, 1) SFM_NEAR(3, -1, 1)
 #undef SFM_FAR
 #undef SFM_NEAR
+    }
     out[0] = acc0;
     out[1] = acc1;
   };
@@ -2069,22 +2183,26 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
   };
 
   // a = F(x) + pull at the initial positions
-  xt[0][ly + 1][lx + 1] = x0;
-  xt[1][ly + 1][lx + 1] = x1;
+  if (owner) {
+    xt[0][ly + 1][lx + 1] = x0;
+    xt[1][ly + 1][lx + 1] = x1;
+  }
   if (h_n >= 0) {
     xt[0][hy][hx] = xg[h_n];
     xt[1][hy][hx] = xg[p.N + h_n];
   }
   __syncthreads();
-  if (active) {
-    float f[2];
-    tile_force(f);
+  {
+    float f[2] = {0.f, 0.f};
+    if (SH || active) tile_force(f);
+    if (active) {
     if (p.has_prev) {
       f[0] = f[0] + prev_pull(x0, pr0, p.neg_k0, s.cap);
       f[1] = f[1] + prev_pull(x1, pr1, p.neg_k0, s.cap);
     }
     a0 = f[0];
     a1 = f[1];
+    }
   }
   float my_part = 0.f;  // thread 0: this workgroup's partial power of the last step
 
@@ -2097,8 +2215,10 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     const float c2 = 0.5f * (dt * dt);
     x0 = x0 + (dt * v0 + c2 * a0);
     x1 = x1 + (dt * v1 + c2 * a1);
-    xt[0][ly + 1][lx + 1] = x0;
-    xt[1][ly + 1][lx + 1] = x1;
+    if (owner) {
+      xt[0][ly + 1][lx + 1] = x0;
+      xt[1][ly + 1][lx + 1] = x1;
+    }
     if (h_n >= 0) {
       const float hv0 = hval[tid][2] * gate, hv1 = hval[tid][3] * gate;
       xt[0][hy][hx] = hval[tid][0] + (dt * hv0 + c2 * hval[tid][4]);
@@ -2106,13 +2226,13 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     }
     __syncthreads();
     float pw = 0.f;
+    float f[2] = {0.f, 0.f};
+    if (SH || active) tile_force(f);
     if (active) {
       const float hdtg = (0.5f * dt) * p.gamma;
       const float fact0 = 1.0f / (1.0f + hdtg);
       const float fact1 = 1.0f - hdtg;
       const float hdt = 0.5f * dt;
-      float f[2];
-      tile_force(f);
       if (p.has_prev) {
         f[0] = f[0] + prev_pull(x0, pr0, p.neg_k0, sk.cap);
         f[1] = f[1] + prev_pull(x1, pr1, p.neg_k0, sk.cap);
@@ -2136,8 +2256,8 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       v1 = n1;
     }
     const float t = wave_sum63(pw);
-    if (lane == 63) wred[wave] = t;
-    __syncthreads();  // also: everyone is done with xt / hval
+    if (lane == 63 && wave < TL::kWavesT) wred[wave] = t;
+    __syncthreads();  // also: everyone is done with xt / hval / nf
     if (tid == 0) {
       float acc = 0.f;
       for (int w2 = 0; w2 < TL::kWavesT; ++w2) acc = acc + wred[w2];
@@ -2172,14 +2292,14 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     STICK(0)
     // ---- the halo of the 8 neighbours: the only wait in front of the step --------
     if (!last) {
-      const u64* g[TL::kHaloPolls];
-      float* d[TL::kHaloPolls];
+      const u64* g[kHaloPollsS];
+      float* d[kHaloPollsS];
 #pragma unroll
-      for (int u = 0; u < TL::kHaloPolls; ++u) {
+      for (int u = 0; u < kHaloPollsS; ++u) {
         g[u] = h_off[u] >= 0 ? q.comm + h_off[u] + slot_off : nullptr;
         d[u] = h_dst[u];
       }
-      const bool mine_ok = poll_granules<TL::kHaloPolls>(g, d, epoch, q.abort);
+      const bool mine_ok = poll_granules<kHaloPollsS>(g, d, epoch, q.abort);
       if (!__syncthreads_and(mine_ok ? 1 : 0)) {
         ok = false;
         break;
@@ -2284,7 +2404,7 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
   }
   __shared__ float fin[TL::kWavesT][2];
   __syncthreads();
-  if (lane == 0) {
+  if (lane == 0 && wave < TL::kWavesT) {
     fin[wave][0] = ek;
     fin[wave][1] = vm2;
   }
@@ -2640,7 +2760,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       const char* spec_env = sfm::option("SFM_MESH_SPECULATE");
       const bool spec = p.fire && !p.remove_drift && !(spec_env && spec_env[0] == '0');
       if (spec && tile == 16)
-        hipLaunchKernelGGL(mesh_persist2d_spec_kernel<16>, dim3(q.n_wg), dim3(256), 0, st,
+        hipLaunchKernelGGL(mesh_persist2d_spec_kernel<16>, dim3(q.n_wg), dim3(spec_threads<16>()), 0, st,
                            p, d->x, d->v, w.alt[0], w.alt[1], w.alt[2], d->prev, q);
       else if (spec)
         hipLaunchKernelGGL(mesh_persist2d_spec_kernel<32>, dim3(q.n_wg), dim3(1024), 0, st,
