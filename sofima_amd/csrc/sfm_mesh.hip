@@ -1484,6 +1484,13 @@ constexpr int kNodeGran = 6;   // x0 x1 v0 v1 a0 a1
 constexpr int kPartGran = 8;   // power, sum x[3], sum v[3], pad
 constexpr int kMaxWg = 256;
 constexpr int kSpinLimit = 1 << 21;
+// Replicas of a workgroup's partial power (speculative kernel).  EVERY workgroup
+// reads every partial every step; readers of one cache line are served one
+// after the other on the memory side (~12 ns each): 168 readers of one granule
+// took ~2 us, the longest wait of the step.  A workgroup writes its partial
+// kPartRep times, 128 bytes apart, and reader w takes replica w % kPartRep.
+constexpr int kPartRep = 8;
+constexpr int kPartPitch = 16;   // u64 per (replica, workgroup): 8 step places + padding
 
 
 template <int T>
@@ -1500,6 +1507,7 @@ struct Tile {
 
 struct PersistArgs {
   u64* comm;            // [nWG][2][slot] granules, zeroed before launch
+  u64* part;            // [kPartRep][kMaxWg][kPartPitch] partial-power replicas
   int* abort;           // set on timeout
   const Scalars* scal_in;
   Scalars* scal_out;
@@ -1508,6 +1516,15 @@ struct PersistArgs {
   float cap0;
   int nty, ntx, n_wg;
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits
+// for every outstanding global access of the wave (s_waitcnt vmcnt(0)): in the
+// persistent kernels that put the round trip of the write-through granule
+// stores and of loads issued ahead of their use (the partial powers) inside the
+// step -- about half of what the step phase cost.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ void put_granule(u64* g, unsigned epoch, float v) {
   __hip_atomic_store(g, (static_cast<u64>(epoch) << 32) | __float_as_uint(v),
@@ -1998,9 +2015,18 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
   __shared__ float part_all[kMaxWg];
   __shared__ float wred[TL::kWavesT];
   __shared__ float s_power;
+  __shared__ int s_fail;   // a poll of this workgroup timed out (wg_and)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_fail = 0;
+  // "did every thread's poll succeed?" through LDS: __syncthreads_and() would
+  // also wait for the global loads that are in flight on purpose
+  auto wg_and = [&](bool mine) {
+    if (!mine) s_fail = 1;
+    lds_barrier();
+    return s_fail == 0;
+  };
   const bool owner = tid < NM;            // (the halo waves own no node)
   const int ly = owner ? tid / T : 0, lx = owner ? tid % T : 0;
   const int wg = blockIdx.x;
@@ -2076,12 +2102,66 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     else if (i < 4 * T - 1) { hs_L = 2; hs_y = 1 + (i - 3 * T); hs_x = 0; }
     else if (i < 5 * T - 1) { hs_L = 3; hs_y = 0; hs_x = 2 + (i - (4 * T - 1)); }
     else if (i < 6 * T - 2) { hs_L = 3; hs_y = 1 + (i - (5 * T - 1)); hs_x = T + 1; }
-    if (hs_L >= 0) {
-      hs_dx = p.dir[hs_L][0];
-      hs_dy = p.dir[hs_L][1];
-    }
   }
+  // the lane's link constants in registers (a run-time index into the kernel
+  // argument would be a global load inside every step)
+  float hs_r0 = 0.f, hs_r1 = 0.f, hs_l0 = 0.f, hs_k = 0.f;
+#pragma unroll
+  for (int L = 0; L < 4; ++L)
+    if (hs_L == L) {
+      hs_dx = p.dir[L][0];
+      hs_dy = p.dir[L][1];
+      hs_r0 = p.rest[L][0];
+      hs_r1 = p.rest[L][1];
+      hs_l0 = l0[L];
+      hs_k = p.neg_k[L];
+    }
   static_assert(!SH || 6 * T - 2 <= NT - NM, "one halo spring per halo-wave lane");
+
+  // The partial powers of the previous step, one per workgroup: requested at the
+  // head of a step (`issue_early`; they left their workgroups most of an
+  // iteration ago) and taken in at its end (`take_early`), BEFORE the next
+  // halo is requested: the verification then touches LDS only and no wait of
+  // this iteration covers more than one round trip.  Stragglers are polled for
+  // in the verification.
+  const u64* pg[kPartPolls1];
+  float* pd[kPartPolls1];
+  u64 early[kPartPolls1];
+  bool early_pending = false;
+  unsigned early_tag = 0;
+  // The neighbours' state after this step, requested right behind this
+  // workgroup's own publication (they publish at about the same time, and a
+  // request needs half a round trip to get there): the other half of the round
+  // trip hides behind the verification instead of opening the next step.
+  u64 hearly[kHaloPollsS], hearly2[kHaloPollsS];   // two requests, ~1500 cycles apart
+#pragma unroll
+  for (int u = 0; u < kHaloPollsS; ++u) hearly[u] = hearly2[u] = 0;
+  auto request_halo = [&](int step, u64* dst) {
+    const long long next_off = (long long)((step + 1) & 1) * TL::kSlot;
+#pragma unroll
+    for (int u = 0; u < kHaloPollsS; ++u)
+      dst[u] = __hip_atomic_load(q.comm + (h_off[u] >= 0 ? h_off[u] + next_off : 0),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto issue_early = [&]() {
+    if (!early_pending) return;
+    early_pending = false;
+    // (unconditional loads: a load under a per-lane condition gets its own basic
+    // block and is waited for on the spot; lanes without a granule read the
+    // first word of the exchange area and ignore it)
+#pragma unroll
+    for (int u = 0; u < kPartPolls1; ++u)
+      early[u] = __hip_atomic_load(pg[u] ? pg[u] : q.comm, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto take_early = [&]() {
+#pragma unroll
+    for (int u = 0; u < kPartPolls1; ++u)
+      if (pg[u] && static_cast<unsigned>(early[u] >> 32) == early_tag) {
+        *pd[u] = __uint_as_float(static_cast<unsigned>(early[u]));
+        pg[u] = nullptr;  // arrived: nothing left to poll
+      }
+  };
 
   // Net spring force on this thread's node from the positions in xt.  Contains
   // a barrier when SH: called by ALL threads.
@@ -2102,13 +2182,13 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
 #undef SFM_NEAR_EVAL
       } else if (hs_L >= 0) {
         float f[2];
-        spring_xy_rt(xt[0][hs_y + hs_dy][hs_x + hs_dx] - xt[0][hs_y][hs_x] + p.rest[hs_L][0],
-                     xt[1][hs_y + hs_dy][hs_x + hs_dx] - xt[1][hs_y][hs_x] + p.rest[hs_L][1],
-                     l0[hs_L], p.neg_k[hs_L], p.prefer, hs_dx, hs_dy, f);
+        spring_xy_rt(xt[0][hs_y + hs_dy][hs_x + hs_dx] - xt[0][hs_y][hs_x] + hs_r0,
+                     xt[1][hs_y + hs_dy][hs_x + hs_dx] - xt[1][hs_y][hs_x] + hs_r1,
+                     hs_l0, hs_k, p.prefer, hs_dx, hs_dy, f);
         nf[hs_L][0][hs_y][hs_x] = f[0];
         nf[hs_L][1][hs_y][hs_x] = f[1];
       }
-      __syncthreads();
+      lds_barrier();
 #define SFM_FAR_ADD(L, DX, DY)                                                      \
       {                                                                             \
         const bool ok = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&      \
@@ -2206,9 +2286,43 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
   }
   float my_part = 0.f;  // thread 0: this workgroup's partial power of the last step
 
+  // Where and how the state after `step` steps and that step's partial power are
+  // published.  Node granules: slot of parity (step + 1) & 1 (its previous
+  // content, the state after step - 2 steps, was consumed by every neighbour
+  // before it published the state this workgroup needed for step `step`).  The
+  // partial: eight places (parity x four) -- it is read a whole iteration later,
+  // by workgroups that no hand-off orders against this one.  tag = step + 1,
+  // bit 24 set when the step was redone on the uphill branch: readers know
+  // which of the two they need, because everyone takes the same decisions.
+  auto publish = [&](int step, unsigned tag) {
+    u64* slot = q.comm + (long long)wg * 2 * TL::kSlot + (long long)((step + 1) & 1) * TL::kSlot;
+    if (active && pidx >= 0) {
+      u64* g = slot + pidx * kNodeGran;
+      put_granule(g + 0, tag, x0);
+      put_granule(g + 1, tag, x1);
+      put_granule(g + 2, tag, v0);
+      put_granule(g + 3, tag, v1);
+      put_granule(g + 4, tag, a0);
+      put_granule(g + 5, tag, a1);
+    }
+  };
+  // replica `rep` of workgroup w2's partial of step `step` (eight step places)
+  auto part_place = [&](int w2, int step, int rep) {
+    return q.part + ((long long)rep * kMaxWg + w2) * kPartPitch + ((step + 1) & 7);
+  };
+
+#ifdef SFM_MESH_TIMING
+  long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stc = clock64();
+#define STICK(i) { const long long tn = clock64(); st[i] += tn - stc; stc = tn; }
+#else
+#define STICK(i)
+#endif
   // One step with scalars `sk`; `gate` (0 / 1) is the pending velocity gate of
-  // the previous step, applied to the node's own and the halo velocities.
-  auto do_step = [&](const Scalars& sk, float gate) {
+  // the previous step, applied to the node's own and the halo velocities.  The
+  // new state and the step's partial power are published right away (`tag`):
+  // the neighbours' next step and everyone's verification do not wait for this
+  // workgroup's own verification.
+  auto do_step = [&](const Scalars& sk, float gate, int step, unsigned tag) {
     v0 = v0 * gate;
     v1 = v1 * gate;
     const float dt = sk.dt;
@@ -2224,10 +2338,13 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       xt[0][hy][hx] = hval[tid][0] + (dt * hv0 + c2 * hval[tid][4]);
       xt[1][hy][hx] = hval[tid][1] + (dt * hv1 + c2 * hval[tid][5]);
     }
-    __syncthreads();
+    lds_barrier();
+    issue_early();
+    STICK(5)
     float pw = 0.f;
     float f[2] = {0.f, 0.f};
     if (SH || active) tile_force(f);
+    STICK(6)
     if (active) {
       const float hdtg = (0.5f * dt) * p.gamma;
       const float fact0 = 1.0f / (1.0f + hdtg);
@@ -2255,40 +2372,36 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       v0 = n0;
       v1 = n1;
     }
+    STICK(7)
+    publish(step, tag);   // the state is final: out before the power reduction
+    STICK(8)
     const float t = wave_sum63(pw);
     if (lane == 63 && wave < TL::kWavesT) wred[wave] = t;
-    __syncthreads();  // also: everyone is done with xt / hval / nf
-    if (tid == 0) {
+    lds_barrier();  // also: everyone is done with xt / hval / nf
+    STICK(9)
+    if (tid < kPartRep) {   // (every writer lane forms the same sum)
       float acc = 0.f;
       for (int w2 = 0; w2 < TL::kWavesT; ++w2) acc = acc + wred[w2];
       my_part = acc;
+      put_granule(part_place(wg, step, tid), tag, acc);
     }
+    // (after the last step: nobody's halo).  Two requests: behind the wait for
+    // the partials and behind the verification's polls (a third one right after
+    // the publication never found the neighbours' state: measured, removed).
+    take_early();
+    if (step < q.num_iters) request_halo(step, hearly);
   };
 
-#ifdef SFM_MESH_TIMING
-  long long st[5] = {0, 0, 0, 0, 0}, stc = clock64();
-#define STICK(i) { const long long tn = clock64(); st[i] += tn - stc; stc = tn; }
-#else
-#define STICK(i)
-#endif
   bool ok = true;
+  constexpr unsigned kRedoBit = 1u << 24;
+  publish(0, 1u);          // the initial state, for everyone's first step
+  unsigned redo_prev = 0;  // kRedoBit if the previous iteration redid its step
   for (int k = 1; k <= q.num_iters + 1; ++k) {
     STICK(4)
-    const unsigned epoch = static_cast<unsigned>(k);
     const bool last = k == q.num_iters + 1;
+    // the state after k - 1 steps / the partial power of step k - 1 carry this tag
+    const unsigned want_tag = static_cast<unsigned>(k) | redo_prev;
     const long long slot_off = (long long)(k & 1) * TL::kSlot;
-    u64* my_slot = q.comm + (long long)wg * 2 * TL::kSlot + slot_off;
-    // ---- publish the (verified) state after k - 1 steps -------------------------
-    if (!last && active && pidx >= 0) {
-      u64* g = my_slot + pidx * kNodeGran;
-      put_granule(g + 0, epoch, x0);
-      put_granule(g + 1, epoch, x1);
-      put_granule(g + 2, epoch, v0);
-      put_granule(g + 3, epoch, v1);
-      put_granule(g + 4, epoch, a0);
-      put_granule(g + 5, epoch, a1);
-    }
-    if (k > 1 && tid == 0) put_granule(my_slot + TL::kPerim * kNodeGran, epoch, my_part);
     STICK(0)
     // ---- the halo of the 8 neighbours: the only wait in front of the step --------
     if (!last) {
@@ -2298,9 +2411,16 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       for (int u = 0; u < kHaloPollsS; ++u) {
         g[u] = h_off[u] >= 0 ? q.comm + h_off[u] + slot_off : nullptr;
         d[u] = h_dst[u];
+        if (g[u] && static_cast<unsigned>(hearly[u] >> 32) == want_tag) {
+          *d[u] = __uint_as_float(static_cast<unsigned>(hearly[u]));
+          g[u] = nullptr;   // requested at the end of the previous step, arrived since
+        } else if (g[u] && static_cast<unsigned>(hearly2[u] >> 32) == want_tag) {
+          *d[u] = __uint_as_float(static_cast<unsigned>(hearly2[u]));
+          g[u] = nullptr;
+        }
       }
-      const bool mine_ok = poll_granules<kHaloPollsS>(g, d, epoch, q.abort);
-      if (!__syncthreads_and(mine_ok ? 1 : 0)) {
+      const bool mine_ok = poll_granules<kHaloPollsS>(g, d, want_tag, q.abort);
+      if (!wg_and(mine_ok)) {
         ok = false;
         break;
       }
@@ -2310,41 +2430,34 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     const Scalars s_before = s;  // scalars of step k - 1 (verified)
     const float bx0 = x0, bx1 = x1, bv0 = v0, bv1 = v1, ba0 = a0, ba1 = a1;
     const float part_before = my_part;
-    // The partial powers of step k - 1 were published at the top of this
-    // iteration by everyone: request them now, look at them after the step
-    // (the round trip hides behind the force evaluation).
-    const u64* pg[kPartPolls1];
-    float* pd[kPartPolls1];
-    u64 early[kPartPolls1];
+    // The partial powers of step k - 1 were published at the end of that step by
+    // everyone: requested in the middle of this step, looked at after it.
 #pragma unroll
     for (int u = 0; u < kPartPolls1; ++u) {
       const int w2 = tid + u * NT;
       const bool want = k > 1 && w2 < q.n_wg && w2 != wg;
-      pg[u] = want ? q.comm + (long long)w2 * 2 * TL::kSlot + slot_off +
-                         TL::kPerim * kNodeGran
-                   : nullptr;
+      pg[u] = want ? part_place(w2, k - 1, wg % kPartRep) : nullptr;
       pd[u] = want ? &part_all[w2] : nullptr;
-      early[u] = want ? __hip_atomic_load(pg[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                      : 0;
+      early[u] = 0;
     }
+    early_pending = k > 1;
+    early_tag = want_tag;
     Scalars s_try = s;
     if (!last) {
       if (k > 1) s_try = next_scalars(s_before, true);
-      do_step(s_try, 1.f);
+      do_step(s_try, 1.f, k, static_cast<unsigned>(k + 1));
     }
+    issue_early();   // (last iteration: there was no step)
+    take_early();
     STICK(2)
+    redo_prev = 0;
     if (k == 1) continue;  // no power yet: nothing to verify
     // ---- the partial powers of step k - 1: verify the speculation -------------------
     {
-#pragma unroll
-      for (int u = 0; u < kPartPolls1; ++u)
-        if (pg[u] && static_cast<unsigned>(early[u] >> 32) == epoch) {
-          *pd[u] = __uint_as_float(static_cast<unsigned>(early[u]));
-          pg[u] = nullptr;  // arrived: nothing left to poll
-        }
       if (tid == 0) part_all[wg] = part_before;  // own: no round trip
-      const bool mine_ok = poll_granules<kPartPolls1>(pg, pd, epoch, q.abort);
-      if (!__syncthreads_and(mine_ok ? 1 : 0)) {
+      const bool mine_ok = poll_granules<kPartPolls1>(pg, pd, want_tag, q.abort);
+      if (!last && k < q.num_iters) request_halo(k, hearly2);
+      if (!wg_and(mine_ok)) {
         ok = false;
         break;
       }
@@ -2354,7 +2467,7 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
         t = wave_sum63(t);
         if (lane == 63) s_power = t;
       }
-      __syncthreads();
+      lds_barrier();
     }
     STICK(3)
     const bool downhill = s_power >= 0.f;
@@ -2367,7 +2480,8 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     if (downhill) {
       s = s_try;
     } else {
-      // misprediction: back to the state before the step, uphill scalars, v = 0
+      // misprediction: back to the state before the step, uphill scalars, v = 0;
+      // the redone step replaces what the speculative one published
       x0 = bx0;
       x1 = bx1;
       v0 = bv0;
@@ -2375,15 +2489,18 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       a0 = ba0;
       a1 = ba1;
       s = next_scalars(s_before, false);
-      do_step(s, 0.f);
+      do_step(s, 0.f, k, static_cast<unsigned>(k + 1) | kRedoBit);
+      redo_prev = kRedoBit;
     }
   }
 
 #ifdef SFM_MESH_TIMING
   if ((wg == 0 || wg == q.n_wg / 2) && tid == 0)
-    printf("SPEC wg %d per step: publish %lld halo-wait %lld step %lld verify %lld other %lld\n", wg,
+    printf("SPEC wg %d per step: publish %lld halo-wait %lld step-tail %lld verify %lld other %lld | in step: "
+           "advance+S1 %lld force(S2) %lld mix %lld publish %lld reduce+S3 %lld\n", wg,
            st[0] / q.num_iters, st[1] / q.num_iters, st[2] / q.num_iters, st[3] / q.num_iters,
-           st[4] / q.num_iters);
+           st[4] / q.num_iters, st[5] / q.num_iters, st[6] / q.num_iters, st[7] / q.num_iters,
+           st[8] / q.num_iters, st[9] / q.num_iters);
 #endif
   if (!ok) return;  // timed out (the abort flag is set)
   float ek = 0.f, vm2 = 0.f;
@@ -2621,9 +2738,10 @@ MeshWorkspace carve(void* ws, size_t prev_floats, size_t alt_floats, long long t
   w.stat_part = c.take<float>(kMaxBlocks * 2);
   w.stats = c.take<float>(2);
   const size_t slot_max = Tile<32>::kSlot;
-  w.comm = c.take<u64>((size_t)kMaxWg * 2 * slot_max + 8);
+  const size_t part_u64 = (size_t)kPartRep * kMaxWg * kPartPitch;
+  w.comm = c.take<u64>((size_t)kMaxWg * 2 * slot_max + 8 + part_u64);
   w.abort = reinterpret_cast<int*>(w.comm + (size_t)kMaxWg * 2 * slot_max);
-  w.comm_bytes = ((size_t)kMaxWg * 2 * slot_max + 8) * sizeof(u64);
+  w.comm_bytes = ((size_t)kMaxWg * 2 * slot_max + 8 + part_u64) * sizeof(u64);
   w.bytes = c.total();
   return w;
 }
@@ -2746,6 +2864,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       const long long n_wg = (long long)p.B * nty * ntx;
       PersistArgs q;
       q.comm = w.comm;
+      q.part = w.comm + (size_t)kMaxWg * 2 * Tile<32>::kSlot + 8;
       q.abort = w.abort;
       q.scal_in = &w.scal[0];
       q.scal_out = &w.scal[1];
