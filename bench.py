@@ -117,6 +117,9 @@ def main():
                        '(steady-state power / clocks); 0 = off')
   ap.add_argument('--no-legs', action='store_true',
                   help='skip the un-pruned and other-pair roofline legs')
+  ap.add_argument('--multi-gpu-timeout', type=float, default=240.0,
+                  help='N > 1: seconds a communicating leg may take before it is '
+                       'abandoned (the line is printed without it)')
   ap.add_argument('--no-multi-gpu-legs', action='store_true',
                   help='N > 1: skip the communicating legs (configs[3] section '
                        'chain with the boundary hand-off, one mesh in bands '
@@ -388,12 +391,12 @@ def main():
 
   # HBM traffic of the dominant kernel: PMC counters cannot be read from inside
   # the run, so the figure comes from the separate rocprofv3 --pmc passes of THIS
-  # bench (tools/measure/profile_round3.sh -> profiles/r03_pmc_traffic.json), and
+  # bench (tools/measure/profile_round4.sh -> profiles/r04_pmc_traffic.json), and
   # only when that file was measured on the library that is loaded now
   # (.build_sha); otherwise null.
   if roof and uses_mfma and size == 8192:
     try:
-      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')))
+      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')))
       meta = pmc.get('_meta', {})
       sha = build_sha()
       if sha and meta.get('git_sha') == sha and meta.get('pair', 'exact') == args.pair:
@@ -403,13 +406,13 @@ def main():
             ppl = roof['pruned']['patches_per_launch']
             roof['traffic'] = int(v['hbm_bytes_per_launch'] / meta_ppl * ppl)
             roof['traffic_source'] = {
-                'file': 'profiles/r03_pmc_traffic.json', 'measured_on_git_sha': sha,
+                'file': 'profiles/r04_pmc_traffic.json', 'measured_on_git_sha': sha,
                 'launch': 'pruned (production) launch',
                 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of '
                           'this bench; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per '
                           'launch of %d patches' % round(ppl)}
       else:
-        roof['traffic_note'] = ('null: profiles/r03_pmc_traffic.json was measured on %s / '
+        roof['traffic_note'] = ('null: profiles/r04_pmc_traffic.json was measured on %s / '
                                 'pair %s, this library is %s / pair %s'
                                 % (meta.get('git_sha'), meta.get('pair'), sha, args.pair))
     except (OSError, ValueError):
@@ -454,22 +457,6 @@ def main():
   if args.mesh_sharded > 0:
     sharded = mesh_sharded_leg(args.mesh_sharded, dev, rank, world)
 
-  # N > 1: the legs that really communicate (the timed default workload above
-  # is N independent tile pairs, no data-path collective)
-  multi = None
-  if world > 1 and not args.no_multi_gpu_legs:
-    multi = {
-        'backend': 'rccl' if backend == 'nccl' else backend,
-        # the value of an all-reduce of ones over the process group
-        'rccl_ranks' if backend == 'nccl' else 'ranks_seen': ranks_seen,
-        'devices': 'one GPU per rank' if not os.environ.get('SFM_BENCH_ONE_DEVICE')
-                   else 'all ranks share cuda:0 (smoke test)',
-        'section_chain': section_chain_leg(dev, rank, world, backend, args.seed,
-                                           args.mesh_iters),
-        'mesh_sharded': mesh_sharded_leg(1, dev, rank, world,
-                                         iters=min(200, max(args.mesh_iters, 20))),
-    }
-
   out = {
       'metric': 'patch-xcorr Mpix/s (+ mesh node-updates/s) on 8192^2 tiles',
       'value': mpix_s, 'unit': 'Mpix/s', 'n_gpus': world,
@@ -500,8 +487,6 @@ def main():
     out['sustained_ms_per_step'] = sustained['ms_per_step']
   if sharded:
     out['mesh_sharded'] = sharded
-  if multi:
-    out['multi_gpu'] = multi
   if aux:
     out['aux_rooflines'] = aux
   if cfg_legs:
@@ -509,10 +494,65 @@ def main():
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline(size, args.seed + rank, args.pair)
+
+  # N > 1: the legs that really communicate (the timed default workload above
+  # is N independent tile pairs, no data-path collective).  They run LAST and
+  # under a watchdog: the headline numbers above are complete, and a leg that
+  # fails or hangs (they are the least-exercised code: single-GPU boxes cannot
+  # run them over RCCL) costs its own entry, never the line.
+  if world > 1 and not args.no_multi_gpu_legs:
+    import threading
+    multi = {
+        'backend': 'rccl' if backend == 'nccl' else backend,
+        # the value of an all-reduce of ones over the process group
+        'rccl_ranks' if backend == 'nccl' else 'ranks_seen': ranks_seen,
+        'devices': 'one GPU per rank' if not os.environ.get('SFM_BENCH_ONE_DEVICE')
+                   else 'all ranks share cuda:0 (smoke test)',
+    }
+    out['multi_gpu'] = multi
+    state = {'leg': None}
+
+    def bail():
+      multi[state['leg'] or 'legs'] = {
+          'error': f'no result within {args.multi_gpu_timeout:.0f} s (leg abandoned)'}
+      if rank == 0:
+        print(json.dumps(out), flush=True)
+      os._exit(0)
+
+    for name, fn in (
+        ('section_chain', lambda: section_chain_leg(dev, rank, world, backend, args.seed,
+                                                    args.mesh_iters)),
+        ('mesh_sharded', lambda: mesh_sharded_leg(
+            1, dev, rank, world, iters=min(200, max(args.mesh_iters, 20))))):
+      state['leg'] = name
+      dog = threading.Timer(args.multi_gpu_timeout, bail)
+      dog.daemon = True
+      dog.start()
+      try:
+        multi[name] = fn()
+      except Exception as e:   # pylint: disable=broad-except
+        multi[name] = {'error': f'{type(e).__name__}: {e}'[:400]}
+      finally:
+        dog.cancel()
+      # a rank that failed must not leave the others inside a collective of the
+      # NEXT leg: agree on going on (an all-reduce with its own watchdog)
+      dog = threading.Timer(args.multi_gpu_timeout, bail)
+      dog.daemon = True
+      dog.start()
+      flag = torch.tensor([0.0 if 'error' in multi[name] else 1.0],
+                          device=dev if backend == 'nccl' else 'cpu')
+      dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+      dog.cancel()
+      if flag.item() < 1.0:
+        multi[name].setdefault('error', 'failed on another rank')
+        break
   if rank == 0:
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
   if world > 1:
-    dist.destroy_process_group()
+    try:
+      dist.destroy_process_group()
+    except Exception:   # pylint: disable=broad-except
+      pass
 
 
 def aux_legs(dev, seed):
