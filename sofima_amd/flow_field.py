@@ -635,6 +635,26 @@ class JAXMaskedXCorrWithStatsCalculator:
     out_shape = [int(v) for v in
                  (np.array(post_shape) - (np.array(post_patch_size) - step)) // step]
     out_sel = tuple(slice(0, s) for s in out_shape)
+    if (int(np.prod(out_shape)) == 1 and selection_mask is None and
+        pre_targeting_field is None and post_targeting_field is None):
+      # ONE patch (whole-overlap correlations: stitch_rigid._estimate_offset).
+      # The general plan below costs a dozen small launches and two host
+      # round trips (~0.5 ms) to find out what one masked-pixel count per side
+      # says: the patch at grid position 0 covers [0, patch) of its mask
+      # (flow_field.py:570-589), starts are 0 on both sides.
+      keep = True
+      for mask, psz in ((res.pre_mask, patch_size), (res.post_mask, post_patch_size)):
+        if mask is None:
+          continue
+        region = mask[tuple(slice(0, int(v)) for v in psz)]
+        count = int(torch.count_nonzero(region).item())
+        keep = keep and not (np.float64(count) / float(np.prod(psz)) >= max_masked)
+      n = 1 if keep else 0
+      total = int(batch_size) if keep else 0
+      return dict(out_shape=out_shape, n=n, n_batches=n,
+                  positions=torch.zeros((total, nd), dtype=torch.int32, device=dev),
+                  starts=(torch.zeros((2, total, nd), dtype=torch.int32, device=dev)
+                          if keep else None), tg=None, po=None)
     if selection_mask is None:
       sel = torch.ones(out_shape, dtype=torch.bool, device=dev)
     else:
