@@ -653,22 +653,29 @@ def config_legs(dev, canvas, seed):
     return (time.perf_counter() - t) / reps, r
 
   # -- configs[2]: flow leg ------------------------------------------------------
-  T, OV = 4096, 400
+  T, OV, G = 4096, 400, 3
   if canvas.shape[0] >= 2 * T - OV:
-    tiles = {(x, y): np.ascontiguousarray(canvas[y * (T - OV):y * (T - OV) + T,
-                                                 x * (T - OV):x * (T - OV) + T])
-             for y in range(2) for x in range(2)}
-    cx = np.zeros((2, 2, 2)); cx[0] = -OV          # coarse offsets of the (x+1, y) tiles
-    cy = np.zeros((2, 2, 2)); cy[1] = -OV
-    sec, (fl, _) = timed(lambda: stitch_elastic.compute_flow_map(tiles, cx, 0), 3)
-    sec_y, (fl_y, _) = timed(lambda: stitch_elastic.compute_flow_map(tiles, cy, 1), 3)
+    # a G x G grid of tiles from the headline canvas continued by reflection
+    # (continuous content in every overlap; 12 strip pairs keep the loop's
+    # run-ahead of MAX_PAIRS_IN_FLIGHT busy like a real montage does)
+    side = G * T - (G - 1) * OV
+    big = np.pad(canvas, ((0, max(0, side - canvas.shape[0])), (0, max(0, side - canvas.shape[1]))),
+                 mode='reflect')
+    tiles = {(x, y): np.ascontiguousarray(big[y * (T - OV):y * (T - OV) + T,
+                                              x * (T - OV):x * (T - OV) + T])
+             for y in range(G) for x in range(G)}
+    del big
+    cx = np.zeros((2, G, G)); cx[0] = -OV          # coarse offsets of the (x+1, y) tiles
+    cy = np.zeros((2, G, G)); cy[1] = -OV
+    sec, (fl, _) = timed(lambda: stitch_elastic.compute_flow_map(tiles, cx, 0), 2)
+    sec_y, (fl_y, _) = timed(lambda: stitch_elastic.compute_flow_map(tiles, cy, 1), 2)
     n_pairs = len(fl) + len(fl_y)
     per_pair = (sec + sec_y) / n_pairs
     shp = next(iter(fl.values())).shape
     patches = int((shp[1] - 5) * (shp[2] - 5))
     out.append({
         'config': 'configs[2] flow', 'workload':
-            f'compute_flow_map on {n_pairs} overlap strips ({T} x {OV}) of a 2 x 2 grid of '
+            f'compute_flow_map on {n_pairs} overlap strips ({T} x {OV}) of a {G} x {G} grid of '
             f'{T}^2 tiles, patch 120 step 20 batch 256 (host tiles: uploads included)',
         'ms_per_strip_pair': round(per_pair * 1e3, 3), 'patches_per_pair': patches,
         'mpix_s': round(T * OV / per_pair / 1e6, 1),
