@@ -33,6 +33,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws, float* surface,
 void mfma_i8_padded_dims(const SfmXcorrDesc* d, int* rows, int* pitch);
 // sfm_xcorr_fft.hip
 bool fft_preferred(const SfmXcorrDesc* d);
+int fft_check(const SfmXcorrDesc* d);
 size_t fft_workspace_bytes(const SfmXcorrDesc* d);
 int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
                   const float* va, const float* vb, float* surface, float* den,
@@ -1357,6 +1358,7 @@ size_t sfm_xcorr_workspace_bytes(const SfmXcorrDesc* d) {
   if (check_desc(d) != SFM_OK) return 0;
   Geo g;
   if (make_geo(d, &g) != SFM_OK) return 0;
+  if (use_fft(d) && sfm::fft_check(d) != SFM_OK) return 0;   // message in sfm_last_error
   SfmXcorrDesc tmp = *d;
   tmp.workspace = nullptr;
   if (!one_launch(d)) {  // run group by group: scratch for one group

@@ -280,6 +280,22 @@ size_t fft_workspace_bytes(const SfmXcorrDesc* d) {
 // a0 / b0: mean-subtracted, mask-zeroed patches [B, Pn] / [B, Qn]; va / vb:
 // validity planes (masked only).  Outputs as corr_direct_kernel: `surface`
 // (raw correlation, or the Padfield numerator), den, ov, maxima.
+// Can the hand-written transforms take this descriptor's padded patch?  Called
+// when the workspace is sized, so that an unsupported shape is an error with a
+// message BEFORE anything is allocated (the library has no general FFT behind
+// its own: INTEGRATION.md, limits).
+int fft_check(const SfmXcorrDesc* d) {
+  const FftGeo g0 = make_fft_geo(d);
+  const FftGeo g = needs_swap(g0) ? swapped(g0) : g0;
+  const bool big = needs_big(g0);
+  if (big ? !own_fft_big_supported(g.rank, g.F) : !own_fft_supported(g.rank, g.F))
+    return fail(SFM_ERR_INVALID,
+                "FFT form: padded patch extent %d x %d x %d is beyond the hand-written "
+                "transforms (in-plane axes <= 262144; volumes: every axis <= 1728)",
+                g0.F[0], g0.F[1], g0.F[2]);
+  return SFM_OK;
+}
+
 int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
                   const float* va, const float* vb, float* surface, float* den,
                   float* ov, unsigned int* maxima, void* ws, unsigned int* smax) {

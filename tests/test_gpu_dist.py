@@ -412,3 +412,71 @@ def test_two_ranks_drive_the_c_banded_loop_on_one_gpu(gpu, tmp_path):
       np.testing.assert_array_equal(np.load(tmp_path / f'{name}_x_{r}.npy'), wx, err_msg=name)
       np.testing.assert_array_equal(np.load(tmp_path / f'{name}_e_{r}.npy'),
                                     np.array(we + [wt]), err_msg=name)
+
+
+def test_banded_host_transport_failure_is_an_error_not_a_hang(gpu):
+  """A host-staged transport callback that fails aborts the chunk with an error
+  code and message (like force_cb / prev_cb), with the exchange stream joined
+  back: the next call on the same streams works."""
+  import ctypes as C
+  import torch
+  from sofima_amd import _abi, _dev, dist as sdist, mesh
+  x0, prev, cfg = _case((2, 2, 61, 47), False)
+  lib = _abi.load()
+  dev = _dev.device()
+  # rank 0 of 2, one band: rows [0, 30) + one halo row
+  bounds = sdist.band_bounds(x0.shape[-2], 2)
+  y0, y1 = bounds[0]
+  x_t = _dev.as_device_f32(x0[..., :y1 + 1, :], dev)
+  v_t = torch.zeros_like(x_t)
+  a_t = torch.empty_like(x_t)
+  p_t = _dev.as_device_f32(prev[..., :y1 + 1, :], dev)
+  spec = mesh._resolve_force(mesh.inplane_force)
+  probe = mesh._base_desc(x_t, spec, cfg.k, cfg.stride, cfg.prefer_orig_order)
+  wsp = _dev.workspace(lib.sfm_mesh_workspace_bytes(C.byref(probe)), dev)
+  descs = (_abi.SfmMeshDesc * 1)()
+  descs[0] = mesh._chunk_desc(x_t, v_t, a_t, p_t, cfg, spec, wsp)
+  descs[0].stream = _dev.stream_ptr()
+  shards = (_abi.SfmMeshShard * 1)()
+  shards[0].own_y0, shards[0].own_y1 = 0, y1
+  shards[0].global_nodes = int(np.prod(x0.shape[1:]))
+  calls = {'n': 0}
+
+  def halo(user, plo, slo, rlo, phi, shi, rhi, count):
+    calls['n'] += 1
+    assert plo == -1 and phi == 1          # rank 0 only has an upper neighbour
+    if calls['n'] >= 3:
+      return 1
+    np.ctypeslib.as_array(rhi, shape=(count,))[:] = np.ctypeslib.as_array(shi, shape=(count,))
+    return 0
+
+  def gather(user, send, recv, count):
+    src = np.ctypeslib.as_array(send, shape=(count,)).copy()
+    out = np.ctypeslib.as_array(recv, shape=(2 * count,))
+    out[:count] = src
+    out[count:] = src
+    return 0
+
+  bd = _abi.SfmBandedDesc()
+  bd.n_local, bd.bands, bd.shards = 1, descs, shards
+  bd.rank, bd.n_ranks = 0, 2
+  side = torch.cuda.Stream(device=dev)
+  bd.comm_stream = side.cuda_stream
+  halo_c, gather_c = _abi.HOST_HALO_FN(halo), _abi.HOST_ALLGATHER_FN(gather)
+  bd.host_halo, bd.host_allgather = halo_c, gather_c
+  scratch = _dev.workspace(lib.sfm_mesh_banded_scratch_bytes(C.byref(bd)), dev)
+  bd.scratch, bd.scratch_bytes = scratch.data_ptr(), scratch.numel()
+  fire = _abi.SfmFireState()
+  fire.dt, fire.alpha, fire.n_pos, fire.cap = cfg.dt, cfg.alpha, 0, cfg.start_cap
+  stats = _abi.SfmChunkStats()
+  rc = lib.sfm_mesh_relax_banded(C.byref(bd), C.byref(fire), C.byref(stats))
+  assert rc == -1 and b'host_halo callback failed' in lib.sfm_last_error()
+  assert calls['n'] == 3
+  torch.cuda.synchronize(dev)               # nothing left dangling on either stream
+  # without a transport at all the same descriptor is refused up front
+  bd.host_halo = _abi.HOST_HALO_FN()
+  rc = lib.sfm_mesh_relax_banded(C.byref(bd), C.byref(fire), C.byref(stats))
+  assert rc == -1 and b'communicator or the host_halo' in lib.sfm_last_error()
+  # and the streams still work
+  gx, _, gt = mesh.relax_mesh(x0, prev, cfg)
+  assert gt == cfg.max_iters and np.isfinite(np.array(gx)).all()

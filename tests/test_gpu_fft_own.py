@@ -165,3 +165,39 @@ def _masked_case(flow_field, rng, b, p, q):
   assert flipped.mean() < 2e-3
   bad = (np.abs(own - want) > 5e-5) & ~flipped
   assert bad.mean() < 1e-4
+
+
+def test_oversize_volume_is_refused_before_any_allocation(gpu):
+  """A volumetric patch whose padded extent is beyond the hand-written transforms
+  (an axis > 1728) is an error with a message when the workspace is sized:
+  nothing is allocated or launched."""
+  import ctypes as C
+  import torch
+  from sofima_amd import _abi, flow_field as ff
+  lib = _abi.load()
+  d = _abi.SfmXcorrDesc()
+  d.ndim = 3
+  d.dtype = _abi.DTYPE_F32
+  shape = (1000, 8, 8)
+  d.pre_shape = (C.c_int32 * 3)(*shape)
+  d.post_shape = (C.c_int32 * 3)(*shape)
+  d.patch = (C.c_int32 * 3)(*shape)          # padded z extent: 2000 > 1728
+  d.post_patch = (C.c_int32 * 3)(*shape)
+  d.batch = 1
+  d.group = 1
+  d.use_mean = 0
+  d.min_distance = 2
+  d.threshold_rel = 0.5
+  d.peak_radius = (C.c_int32 * 3)(5, 5, 5)
+  d.method = _abi.XCORR_FFT
+  img = torch.zeros(shape, dtype=torch.float32, device=gpu)
+  st = torch.zeros((2, 1, 3), dtype=torch.int32, device=gpu)
+  d.pre_image = d.post_image = img.data_ptr()
+  d.pre_starts = d.post_starts = st.data_ptr()
+  before = torch.cuda.memory_allocated(gpu)
+  assert lib.sfm_xcorr_workspace_bytes(C.byref(d)) == 0
+  assert b'beyond the hand-written' in lib.sfm_last_error()
+  with pytest.raises(_abi.SofimaAmdError, match='hand-written'):
+    ff.JAXMaskedXCorrWithStatsCalculator(method=_abi.XCORR_FFT).flow_field(
+        img, img, shape, 1, batch_size=1)
+  assert torch.cuda.memory_allocated(gpu) <= before + (1 << 20)
