@@ -138,6 +138,9 @@ def main():
     # (one process per GPU, RCCL), exactly as the driver's torchrun line does.
     sys.exit(spawn_ranks(args.gpus))
 
+  # (multi-process GPU work on this driver stack needs dmabuf IPC: harmless when
+  # already exported, decisive when a launcher forgot it)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
   import torch
   import torch.distributed as dist
   from sofima_amd import _abi, flow_field, mesh
