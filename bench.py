@@ -524,7 +524,7 @@ def main():
 
     for name, fn in (
         ('section_chain', lambda: section_chain_leg(dev, rank, world, backend, args.seed,
-                                                    args.mesh_iters)),
+                                                    args.mesh_iters, pre_t, post_t)),
         ('mesh_sharded', lambda: mesh_sharded_leg(
             1, dev, rank, world, iters=min(200, max(args.mesh_iters, 20))))):
       state['leg'] = name
@@ -726,49 +726,93 @@ def config_legs(dev, canvas, seed):
   return out
 
 
-def section_chain_leg(dev, rank, world, backend, seed, iters, sections_per_rank=8):
-  """BASELINE configs[3], mesh side: a z-stack of 8 x world sections of 8192^2
-  (mesh [2, 1, 205, 205] each, stride 40) aligned section by section in blocks
-  of 8, one block per rank (em_alignment notebook cells 25, 38-48): every rank
-  solves its block device resident (compose_maps_fast -> relax_mesh), the last
-  solved mesh of every block (336 KB) crosses ranks in ONE all-gather (RCCL,
-  GPU to GPU, on an nccl group) and the small cross-block relaxation runs on
-  every rank.  Times are the max over ranks; the hand-off includes waiting for
-  the slowest rank, `handoff_only_us` is the collective alone."""
+def section_chain_leg(dev, rank, world, backend, seed, iters, pre_t=None, post_t=None,
+                      sections_per_rank=8):
+  """BASELINE configs[3] end to end: a z-stack of 8 x world sections of 8192^2,
+  one block of 8 consecutive sections per rank (em_alignment notebook cells 11-26,
+  38-48).  Per section on its rank: flow_field against the previous section
+  (patch 160, step 40, batch 1024; the field stays in HBM) -> clean_flow ->
+  [2, 1, 205, 205] mesh target -> compose_maps_fast with the previous solved
+  section -> relax_mesh (FIRE, `iters` iterations).  Then the last solved mesh
+  of every block (336 KB) crosses ranks in ONE all-gather (RCCL, GPU to GPU, on
+  an nccl group) and the small cross-block relaxation runs on every rank.
+  Sections are synthetic: the headline pair's second image rolled by a
+  section-dependent integer shift against the first (every section pair has the
+  statistics of the headline pair; nine resident images per rank).  Times are
+  the max over ranks; the hand-off includes waiting for the slowest rank,
+  `handoff_only_us` is the collective alone."""
   import torch
   import torch.distributed as dist
-  from scipy import ndimage
-  from sofima_amd import dist as sdist, mesh
-  n_grid, pad = 201, PATCH // 2 // STEP
+  from sofima_amd import dist as sdist, flow_field, flow_utils, mesh
+  with_flow = pre_t is not None
+  size = int(pre_t.shape[0]) if with_flow else 8192
+  n_grid, pad = (size - (PATCH - STEP)) // STEP, PATCH // 2 // STEP
   n = sections_per_rank * world
-  flow = np.full((2, n, n_grid + 2 * pad, n_grid + 2 * pad), np.nan, np.float32)
-  drift = np.zeros((2, n_grid, n_grid), np.float32)
-  for z in range(n):
-    rng = np.random.default_rng(seed + 2 + z)          # SURVEY 8d: seeds 1004 + z
-    # smooth in-plane field + a drift that varies slowly with z
-    drift += ndimage.gaussian_filter(rng.standard_normal(drift.shape), (0, 30, 30)) * 8
-    local = ndimage.gaussian_filter(rng.standard_normal(drift.shape), (0, 12, 12)) * 25
-    flow[:, z, pad:-pad, pad:-pad] = 0.25 * drift + local
+  first = rank * sections_per_rank
   cfg = mesh.IntegrationConfig(
       dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(STEP, STEP), num_iters=iters,
       max_iters=iters, stop_v_max=0.005, dt_max=1000, start_cap=0.01, final_cap=10,
       prefer_orig_order=True)
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  full = n_grid + 2 * pad
+
+  def section_images():
+    """The rank's 9 sections: image z = post rolled by (z, -z) pixels for odd z,
+    pre rolled likewise for even z (adjacent sections differ like pre / post)."""
+    imgs = []
+    for z in range(first, first + sections_per_rank + 1):
+      base = post_t if z & 1 else pre_t
+      imgs.append(torch.roll(base, shifts=(z % 5, -(z % 3)), dims=(0, 1)).contiguous())
+    return imgs
+
+  def block_flows(imgs):
+    """Cleaned, NaN-padded flow of the rank's block: [2, n, 205, 205] with the
+    other ranks' sections left NaN (align_sections_blocked only reads its own)."""
+    flow = np.full((2, n, full, full), np.nan, np.float32)
+    for i in range(sections_per_rank):
+      f = calc.flow_field(imgs[i], imgs[i + 1], PATCH, STEP, batch_size=BATCH,
+                          device_output=True)
+      clean = flow_utils.clean_flow(f.tensor[:, None], min_peak_ratio=1.4,
+                                    min_peak_sharpness=1.4, max_magnitude=80,
+                                    max_deviation=20)
+      flow[:, first + i, pad:-pad, pad:-pad] = np.asarray(clean)[:, 0]
+    return flow
+
+  def synthetic_flows():
+    from scipy import ndimage
+    flow = np.full((2, n, full, full), np.nan, np.float32)
+    drift = np.zeros((2, n_grid, n_grid), np.float32)
+    for z in range(n):
+      rng = np.random.default_rng(seed + 2 + z)          # SURVEY 8d: seeds 1004 + z
+      drift += ndimage.gaussian_filter(rng.standard_normal(drift.shape), (0, 30, 30)) * 8
+      local = ndimage.gaussian_filter(rng.standard_normal(drift.shape), (0, 12, 12)) * 25
+      flow[:, z, pad:-pad, pad:-pad] = 0.25 * drift + local
+    return flow
 
   def barrier():
     torch.cuda.synchronize(dev)
     dist.barrier()
 
-  sdist.align_sections_blocked(flow, cfg, float(STEP), n_blocks=world)   # warm-up
+  imgs = section_images() if with_flow else None
+
+  def run(tm):
+    t0 = time.perf_counter()
+    flow = block_flows(imgs) if with_flow else synthetic_flows()
+    torch.cuda.synchronize(dev)
+    t_flow = time.perf_counter() - t0
+    blocks, last, xblk = sdist.align_sections_blocked(flow, cfg, float(STEP), n_blocks=world,
+                                                      timing=tm)
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0, t_flow, last, xblk
+
+  run({})                                              # warm-up
   reps = 2
-  tot = np.zeros(4)
+  tot = np.zeros(5)
   for _ in range(reps):
     tm = {}
     barrier()
-    t0 = time.perf_counter()
-    blocks, last, xblk = sdist.align_sections_blocked(flow, cfg, float(STEP),
-                                                      n_blocks=world, timing=tm)
-    torch.cuda.synchronize(dev)
-    tot += [time.perf_counter() - t0, tm['solve_s'], tm['handoff_s'], tm['xblk_s']]
+    total, t_flow, last, xblk = run(tm)
+    tot += [total, t_flow if with_flow else 0.0, tm['solve_s'], tm['handoff_s'], tm['xblk_s']]
   tot /= reps
   # the collective alone, data ready on every rank
   mine = [torch.from_numpy(last[:, b:b + 1].copy()).to(dev)
@@ -783,13 +827,17 @@ def section_chain_leg(dev, rank, world, backend, seed, iters, sections_per_rank=
   t = torch.tensor(list(tot) + [only], dtype=torch.float64,
                    device=dev if backend == 'nccl' else 'cpu')
   dist.all_reduce(t, op=dist.ReduceOp.MAX)
-  total, solve, hand, xb, only = [float(v) for v in t.cpu()]
-  nodes = (n_grid + 2 * pad) ** 2
-  return {
-      'workload': f'{n} sections of 8192^2 (mesh [2,1,{n_grid + 2 * pad},{n_grid + 2 * pad}]), '
-                  f'{sections_per_rank} per rank, {iters} FIRE iterations per section, '
-                  'blocks chained by the last-section mesh (BASELINE configs[3], mesh side)',
+  total, t_flow, solve, hand, xb, only = [float(v) for v in t.cpu()]
+  nodes = full ** 2
+  out = {
+      'workload': f'{n} sections of {size}^2, {sections_per_rank} per rank: '
+                  + ('flow_field (patch 160 step 40) + clean_flow + ' if with_flow else
+                     '(synthetic flow fields) ')
+                  + f'compose_maps_fast + {iters}-iteration FIRE relaxation of the '
+                  f'[2,1,{full},{full}] mesh per section, blocks chained by the last-section mesh '
+                  '(BASELINE configs[3])',
       'sections': n, 'blocks': world, 'ms_total': round(total * 1e3, 3),
+      'ms_flow': round(t_flow * 1e3, 3),
       'ms_block_solve': round(solve * 1e3, 3), 'ms_handoff': round(hand * 1e3, 3),
       'ms_cross_block': round(xb * 1e3, 3), 'handoff_only_us': round(only * 1e6, 1),
       'handoff_bytes_per_block': int(2 * nodes * 4),
@@ -799,6 +847,9 @@ def section_chain_leg(dev, rank, world, backend, seed, iters, sections_per_rank=
       'node_updates_per_s': (n + world) * nodes * iters / total,
       'finite_fraction': float(np.isfinite(xblk).mean()),
   }
+  if with_flow:
+    out['mpix_s'] = round(n * float(size) * size / total / 1e6, 1)
+  return out
 
 
 def mesh_sharded_leg(bands_per_rank, dev, rank, world, iters=200):

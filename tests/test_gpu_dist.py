@@ -295,6 +295,7 @@ def test_bench_runs_as_two_ranks(gpu):
   assert chain['sections'] == 16 and chain['blocks'] == 2
   assert chain['sections_per_s'] > 0 and chain['handoff_only_us'] > 0
   assert chain['finite_fraction'] > 0.9
+  assert chain['ms_flow'] > 0 and chain['mpix_s'] > 0     # flow_field + clean_flow per section
   band = mg['mesh_sharded']
   assert band['ranks'] == 2 and band['banded_us_per_step'] > 0
   assert 'host-staged' in band['transport']
