@@ -525,6 +525,7 @@ def main():
     for name, fn in (
         ('section_chain', lambda: section_chain_leg(dev, rank, world, backend, args.seed,
                                                     args.mesh_iters, pre_t, post_t)),
+        ('volumetric_chunks', lambda: volumetric_leg(dev, rank, world, backend, args.seed)),
         ('mesh_sharded', lambda: mesh_sharded_leg(
             1, dev, rank, world, iters=min(200, max(args.mesh_iters, 20))))):
       state['leg'] = name
@@ -850,6 +851,77 @@ def section_chain_leg(dev, rank, world, backend, seed, iters, pre_t=None, post_t
   if with_flow:
     out['mpix_s'] = round(n * float(size) * size / total / 1e6, 1)
   return out
+
+
+def volumetric_leg(dev, rank, world, backend, seed, chunks_per_rank=1):
+  """BASELINE configs[4] across the ranks: the 2 x 2 x 16 grid of 512^3 tiles is
+  16 z chunks of one 2 x 2 montage each, and the chunks are independent units
+  (no data-path collective: `dist.map_units` semantics, weak scaling).  Per
+  chunk on its rank: the four tile pairs' volumetric flow (80^3 patches, step
+  40, on a 512 x 512 x 120 overlap strip; FFT form) and 200 FIRE steps of the
+  chunk's [3, 4, 12, 12, 12] montage mesh (elastic_mesh_3d, volumetric target
+  mesh, per-column drift removal); the small flow fields are gathered to every
+  rank at the end (one all-gather).  Times are the max over ranks."""
+  import torch
+  import torch.distributed as dist
+  from scipy import ndimage
+  from sofima_amd import flow_field, mesh, stitch_elastic
+  from tests.util import synth_montage
+  rng = np.random.default_rng(seed + 40 + rank)
+  vol = ndimage.gaussian_filter(
+      rng.standard_normal((512 + 8, 512 + 8, 120 + 8), dtype=np.float32), 1.5)
+  vol = ((vol - vol.min()) / (vol.max() - vol.min()) * 255).astype(np.uint8)
+  a = torch.from_numpy(np.ascontiguousarray(vol[4:516, 4:516, 4:124])).to(dev)
+  b = torch.from_numpy(np.ascontiguousarray(vol[6:518, 1:513, 7:127])).to(dev)
+  del vol
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  iters = 200
+  nb, fx, fy, x0 = synth_montage(rng, 2, 2, (12, 12, 12), 3, amp=4.0)
+  stride = (40.0, 40.0, 40.0)
+  cfg = mesh.IntegrationConfig(
+      dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=stride, num_iters=iters, max_iters=iters,
+      stop_v_max=1e-9, dt_max=100, start_cap=0.1, final_cap=10.0, remove_drift=True)
+  fn = stitch_elastic.TargetMeshFn(nb, fx, fy, stride)
+  x_t = torch.from_numpy(x0).to(dev)
+
+  def chunk():
+    flows = [calc.flow_field(a, b, (80, 80, 80), 40, batch_size=64, device_output=True)
+             for _ in range(4)]
+    mesh.relax_mesh(x_t, None, cfg, mesh_force=mesh.elastic_mesh_3d, prev_fn=fn)
+    return torch.stack([f.tensor for f in flows])
+
+  chunk()
+  torch.cuda.synchronize(dev)
+  dist.barrier()
+  t0 = time.perf_counter()
+  mine = [chunk() for _ in range(chunks_per_rank)]
+  torch.cuda.synchronize(dev)
+  t_work = time.perf_counter() - t0
+  send = torch.stack(mine)
+  if backend != 'nccl':
+    send = send.cpu()
+  parts = [torch.empty_like(send) for _ in range(world)]
+  dist.all_gather(parts, send)
+  torch.cuda.synchronize(dev)
+  total = time.perf_counter() - t0
+  t = torch.tensor([total, t_work], dtype=torch.float64,
+                   device=dev if backend == 'nccl' else 'cpu')
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  total, t_work = [float(v) for v in t.cpu()]
+  pairs = 4 * chunks_per_rank * world
+  patches = int(np.prod(mine[0].shape[2:]))
+  return {
+      'workload': f'{chunks_per_rank * world} z chunks (2 x 2 tiles of 512^3 each), '
+                  f'{chunks_per_rank} per rank: 4 volumetric tile-pair flows (80^3 patches, step 40, '
+                  f'512 x 512 x 120 overlap) + {iters} FIRE steps of the [3,4,12,12,12] montage mesh '
+                  'per chunk; flow fields gathered at the end (BASELINE configs[4])',
+      'tile_pairs': pairs, 'patches_per_pair': patches,
+      'ms_total': round(total * 1e3, 3), 'ms_work': round(t_work * 1e3, 3),
+      'tile_pairs_per_s': pairs / total,
+      'mvox_s': round(pairs * 512.0 * 512 * 120 / total / 1e6, 1),
+      'gathered_bytes_per_rank': int(send.numel() * 4),
+      'finite_fraction': float(torch.isfinite(torch.stack(parts)[..., :3, :, :, :]).float().mean()),
+  }
 
 
 def mesh_sharded_leg(bands_per_rank, dev, rank, world, iters=200):

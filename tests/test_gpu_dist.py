@@ -296,6 +296,8 @@ def test_bench_runs_as_two_ranks(gpu):
   assert chain['sections_per_s'] > 0 and chain['handoff_only_us'] > 0
   assert chain['finite_fraction'] > 0.9
   assert chain['ms_flow'] > 0 and chain['mpix_s'] > 0     # flow_field + clean_flow per section
+  vol = mg['volumetric_chunks']
+  assert vol['tile_pairs'] == 8 and vol['tile_pairs_per_s'] > 0 and vol['finite_fraction'] > 0.9
   band = mg['mesh_sharded']
   assert band['ranks'] == 2 and band['banded_us_per_step'] > 0
   assert 'host-staged' in band['transport']
