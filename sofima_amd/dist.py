@@ -696,6 +696,9 @@ def gather_boundaries(last_local: list, n_blocks: int, group=None) -> np.ndarray
     tensors.append(t.to(torch.float32))
   if ws == 1:
     return np.concatenate([t.cpu().numpy() for t in tensors], axis=1)
+  if not tensors:
+    raise ValueError(f'rank {rank} holds no block: {n_blocks} blocks for {ws} ranks '
+                     '(every rank needs at least one)')
   on_gpu = dist.get_backend(group) == 'nccl'
   per = -(-n_blocks // ws)                      # blocks per rank, padded
   ref = tensors[0]
