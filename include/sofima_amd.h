@@ -69,6 +69,8 @@ int sfm_device_count(int* count);
  * sfm_get_option copies the value in effect (returns 1 and "" when unset).
  *   SFM_MFMA_PRUNE=0      correlation kernel computes every surface tile
  *   SFM_MFMA_PROBE=0      no seed probe in front of the pruning
+ *   SFM_MFMA_LAZY=0       flow path stores every computed surface tile (default:
+ *                         only the tiles the peak kernels can read)
  *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry
  *   SFM_MFMA_QUEUE=0      static instead of dynamic patch queue
  *   SFM_MFMA_XCD=1        one patch queue per XCD (measured: no gain) instead of a flat one

@@ -1895,6 +1895,22 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
 // kModeSameExact: P == Q and Px == 16 NCA (production 160, 128, 96, 64, 48): the
 // per-column sign / index arithmetic of the epilogue becomes compile-time.
 constexpr int kModeGeneral = 0, kModeSame = 1, kModeRaw = 2, kModeSameExact = 3;
+// Lazy surface stores (r4), the flow path's form of kModeSame / kModeSameExact.
+// The flow path never returns the surface, and the peak kernels read a few
+// hundred of its 102 400 values: the 5 x 5 window of every hot element, the
+// 11 x 11 sharpness window of the first peak, the hot elements themselves.  A
+// row tile is therefore stored only if it may hold a hot element (its maximum
+// exceeds threshold_rel x the running maximum, the test that also feeds the hot
+// list) or lies within the guard band (max(min_distance, 2 peak_radius) rows) of
+// a tile that may.  A tile learns that it is needed from a request mask in LDS
+// if the hot neighbour finished first; if it had already finished without
+// storing, it is recomputed at the end of the patch (redo mask; rare, because
+// tiles are drawn innermost first and the peak sits there).  What is left
+// un-stored has the property of a pruned tile -- every element of the tile and
+// of its guard band is below threshold_rel x the final maximum -- and goes into
+// the same skip mask for the overflow sweeps of the peak kernels.  Values and
+// decisions that reach the output are unchanged: bit-identical results.
+constexpr int kModeSameLazy = 4, kModeSameExactLazy = 5;
 
 // Wave-wide maximum of non-negative values on the DPP network (no LDS round
 // trips): row shifts inside each 16-lane row, then row broadcasts; the result
@@ -1970,8 +1986,10 @@ __device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_ld
 
 template <int NCA, int NCE, int MODE>
 __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
-  constexpr bool SAME = MODE == kModeSame || MODE == kModeSameExact;
-  constexpr bool EXACT = MODE == kModeSameExact;
+  constexpr bool SAME = MODE == kModeSame || MODE == kModeSameExact || MODE == kModeSameLazy ||
+                        MODE == kModeSameExactLazy;
+  constexpr bool EXACT = MODE == kModeSameExact || MODE == kModeSameExactLazy;
+  constexpr bool LAZY = MODE == kModeSameLazy || MODE == kModeSameExactLazy;
   constexpr bool RAW = MODE == kModeRaw;
   constexpr int NQ = NCA + NCE - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1990,6 +2008,12 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   //   [1] bit mask of the row tiles pruned in the current patch
   //   [2] anything pruned in the current patch?  [3] patches done  [4] probe this patch?
   int* best_lds = reinterpret_cast<int*>(tb_lds + kBoundStride);
+  // Lazy stores, per patch: [0] row tiles that should be stored (requests of
+  // tiles that may be hot), [1] tiles finished, [2] tiles stored, [3] tiles
+  // claimed for recomputation; lz_tmax[p]: maximum of finished tile p
+  int* lz = best_lds + 8;
+  float* lz_tmax = reinterpret_cast<float*>(lz + 4);
+  int* lz_prev = reinterpret_cast<int*>(lz_tmax + 31);   // (tiles 0 .. 30) what the previous patch needed
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -2001,10 +2025,11 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   for (int i = threadIdx.x * 16; i < a.a_bytes + a.b_bytes; i += kThreads * 16)
     *reinterpret_cast<v4i*>(smem + i) = v4i{0, 0, 0, 0};
 
-  if (SAME && a.prune && threadIdx.x == 0) {
+  if (SAME && (a.prune || LAZY) && threadIdx.x == 0) {
     *best_lds = (((a.Q[0] - 1) / 16) << 8) | ((a.Q[1] - 1) / 16);  // the zero shift
     best_lds[2] = 1;  // pruning events of the previous patch (optimistic start)
     best_lds[3] = 0;  // patches of this workgroup so far
+    if (LAZY) *lz_prev = 0;
   }
   const long long bytes0 = (long long)a.ishape[0][0] * a.ishape[0][1];
   const long long bytes1 = (long long)a.ishape[1][0] * a.ishape[1][1];
@@ -2102,6 +2127,21 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       *pmax_lds = 0;  // float bits of max(surface, 0)
       *hot_lds = 0;
       pmax_lds[3] = 0;  // tile counter of this patch
+      if (LAZY) {
+        // requested from the start: what the previous patch of this workgroup
+        // turned out to need, and the tiles around the row tile that held its
+        // maximum (flow fields are coherent; the tiles next to the peak tile are
+        // drawn together with it and would otherwise finish un-stored and be
+        // recomputed: measured 2.4 redone tiles per patch without any request,
+        // 0.75 with the peak tile's band alone -- the peak's blob often straddles
+        // two tiles, whose bands are four tiles)
+        const int pt = *best_lds >> 8, gt = (a.guard + 15) >> 4;
+        const int lo_t = max(pt - gt, 0), hi_t = min(pt + gt, a.n_order - 1);
+        const int pv = *lz_prev;   // (widened by a tile: a store costs less than a recomputation)
+        lz[0] = static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u)) | pv | (pv << 1) |
+                (pv >> 1);
+        lz[1] = lz[2] = lz[3] = 0;
+      }
       if (SAME && a.prune) {
         best_lds[1] = 0;  // row tiles pruned in this patch
         // The seed probe pays only where something gets pruned: it runs if the
@@ -2247,16 +2287,54 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     float* surf = a.surface + b * a.s_stride;
 
 #if SFM_DYNAMIC_TILES
+    bool redo_phase = false;   // LAZY: the patch's tiles are finished, recompute what was missed
     for (;;) {
-      int ti = 0;
-      if (lane == 0) ti = atomicAdd(pmax_lds + 3, 1);
-      ti = __builtin_amdgcn_readfirstlane(ti);
-      if (ti >= a.n_order) break;
-      const int p = __builtin_amdgcn_readfirstlane(a.order[ti]);
+      int ti = 0, p = 0;
+      bool forced = false;
+      if (!redo_phase) {
+        if (lane == 0) ti = atomicAdd(pmax_lds + 3, 1);
+        ti = __builtin_amdgcn_readfirstlane(ti);
+        if (ti >= a.n_order) {
+          if (!LAZY) break;
+          __syncthreads();   // (once per wave and patch) every tile is finished: the redo set is final
+          redo_phase = true;
+        } else {
+          p = __builtin_amdgcn_readfirstlane(a.order[ti]);
+        }
+      }
+      if (LAZY && redo_phase) {
+        // What has to be in memory, now that the maximum is final: the tiles that
+        // hold an element above threshold_rel x the maximum and their guard bands.
+        // The former stored themselves (the running maximum they were judged by
+        // was not larger); of the latter, those that finished before anybody asked
+        // are recomputed -- every wave forms the same set and claims its share.
+        const float thr_f = a.threshold_rel * __int_as_float(*const_cast<volatile int*>(pmax_lds));
+        const int done = *const_cast<volatile int*>(&lz[1]);
+        const int gt = (a.guard + 15) >> 4;
+        int need = 0;
+        for (int t = 0; t < a.n_order; ++t)
+          if (((done >> t) & 1) && lz_tmax[t] > thr_f) {
+            const int lo_t = max(t - gt, 0), hi_t = min(t + gt, a.n_order - 1);
+            need |= static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u));
+          }
+        if (lane == 0) *lz_prev = need;   // (every wave writes the same value)
+        int todo = need & done & ~*const_cast<volatile int*>(&lz[2]) &
+                   ~*const_cast<volatile int*>(&lz[3]);
+        todo = __builtin_amdgcn_readfirstlane(todo);
+        if (todo == 0) break;
+        p = __builtin_ctz(todo);
+        int old = 0;
+        if (lane == 0) old = atomicOr(&lz[3], 1 << p);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if ((old >> p) & 1) continue;   // another wave took it
+        forced = true;
+      }
 #else
     const int n_my_tiles = __builtin_amdgcn_readfirstlane(a.n_tiles[wave]);
     for (int ti = 0; ti < n_my_tiles; ++ti) {
       const int p = __builtin_amdgcn_readfirstlane(a.tiles[wave][ti]);
+      constexpr bool forced = false;
+      static_assert(!LAZY, "lazy stores need the dynamic tile queue");
 #endif
       // The two workgroups of a CU share each SIMD's MFMA pipe, and the issue
       // arbiter always favours the older wave: the younger workgroup would
@@ -2302,7 +2380,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                                                     : 0;
       }
       int col_skip = raw_col_skip;  // outer column tiles (each side) this tile leaves out
-      if (SAME && a.prune) {
+      if (SAME && a.prune && !forced) {
         // Exact pruning.  Every element of this tile and of the `guard` rows
         // around it is bounded by tb (prep kernel).  If tb < threshold_rel x (the
         // running maximum, which never exceeds the final one), none of them is
@@ -2667,9 +2745,10 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           auto store4 = [&](int q, int r, float v) {
             if (q < col_skip || q >= NQ - col_skip) v = 0.f;  // column tile left out
 #ifndef SFM_ABLATE_STORE  // timing experiment: the kernel without its surface writes
-            __builtin_nontemporal_store(
-                v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
-                                            (static_cast<size_t>(rowp[r]) + 64u * q)));
+            if constexpr (!LAZY)
+              __builtin_nontemporal_store(
+                  v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
+                                              (static_cast<size_t>(rowp[r]) + 64u * q)));
 #endif
             tmax = fmaxf(tmax, v);
             acc[q][r] = __float_as_int(v);
@@ -2756,9 +2835,10 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             float v = static_cast<float>(acc[q][r]) + corr;
             if (q < col_skip || q >= NQ - col_skip) v = 0.f;  // column tile left out
 #ifndef SFM_ABLATE_STORE  // timing experiment: the kernel without its surface writes
-            __builtin_nontemporal_store(
-                v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
-                                            (static_cast<size_t>(rowp[r]) + 64u * q)));
+            if constexpr (!LAZY)
+              __builtin_nontemporal_store(
+                  v, reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
+                                              (static_cast<size_t>(rowp[r]) + 64u * q)));
 #endif
             tmax = fmaxf(tmax, v);
             acc[q][r] = __float_as_int(v);
@@ -2845,7 +2925,21 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         }
       }
       TICK(3)
-      if (a.do_peaks) {
+      if (a.do_peaks && forced) {
+        // LAZY, recomputed tile: it is cold (nothing for the running maximum or
+        // the hot list), it only has to reach memory
+        if constexpr (LAZY) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              __builtin_nontemporal_store(
+                  __int_as_float(acc[q][r]),
+                  reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
+                                           (4 * static_cast<size_t>(srow[r]) + 64u * q)));
+          if (lane == 0) atomicOr(&lz[2], 1 << p);
+        }
+      } else if (a.do_peaks) {
         tmax = wave_max_nonneg(tmax);
         // non-negative floats order like their bit patterns; the atomic hands
         // back the running maximum of the tiles finished so far
@@ -2858,7 +2952,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // nothing that matters is dropped.
         const float mrun = fmaxf(tmax, __int_as_float(prev_bits));
         const float thr_t = a.threshold_rel * mrun;
-        if (SAME && a.prune && tmax > __int_as_float(prev_bits)) {
+        if (SAME && (a.prune || LAZY) && tmax > __int_as_float(prev_bits)) {
           // new running maximum (rare): remember its column tile for the seed
           // probe of the next patch
           int qbest = 0;
@@ -2869,6 +2963,39 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             if (__any(vm == tmax)) qbest = q;
           }
           if (lane == 0) *best_lds = (p << 8) | qbest;
+        }
+        if constexpr (LAZY) {
+          // Store this tile?  `hot`: it may hold an element above threshold_rel x
+          // the final maximum (the running maximum only grows, so this errs on the
+          // side of storing).  A hot tile asks for the tiles of its guard band; a
+          // tile of the band that had finished before is dealt with at the end of
+          // the patch, against the FINAL maximum (redo phase above).
+          const bool hot = tmax > thr_t;
+          const int gt = (a.guard + 15) >> 4;
+          const int lo_t = max(p - gt, 0), hi_t = min(p + gt, a.n_order - 1);
+          const int nbmask = static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u));
+          int req = 0;
+          if (lane == 0) {
+            if (hot) atomicOr(&lz[0], nbmask);   // later tiles of the band store right away
+            req = *const_cast<volatile int*>(&lz[0]);
+          }
+          req = __builtin_amdgcn_readfirstlane(req);
+          const bool need = hot || ((req >> p) & 1);
+          if (need) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                __builtin_nontemporal_store(
+                    __int_as_float(acc[q][r]),
+                    reinterpret_cast<float*>(reinterpret_cast<char*>(surf) +
+                                             (4 * static_cast<size_t>(srow[r]) + 64u * q)));
+          }
+          if (lane == 0) {
+            lz_tmax[p] = tmax;
+            if (need) atomicOr(&lz[2], 1 << p);
+            atomicOr(&lz[1], 1 << p);
+          }
         }
         float* hv = a.hot_val + (long long)b * a.hot_cap;
         int* hi = a.hot_idx + (long long)b * a.hot_cap;
@@ -2907,6 +3034,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         a.v1[b] = __int_as_float(*pmax_lds);
         a.hot_count[b] = *hot_lds;
         if (SAME && a.prune) a.skipmask[b] = best_lds[1];
+        // un-stored tiles (pruned ones included) are what the sweeps must leave out
+        if (LAZY) a.skipmask[b] = ~lz[2] & static_cast<int>((2u << (a.n_order - 1)) - 1u);
       }
     }
     TICK(6)
@@ -3085,6 +3214,8 @@ int launch_variant(const MfmaArgs& a, int mode, int grid, size_t lds,
   switch (mode) {
     case kModeSame: return launch_one<NCA, NCE, kModeSame>(a, grid, lds, st);
     case kModeSameExact: return launch_one<NCA, NCE, kModeSameExact>(a, grid, lds, st);
+    case kModeSameLazy: return launch_one<NCA, NCE, kModeSameLazy>(a, grid, lds, st);
+    case kModeSameExactLazy: return launch_one<NCA, NCE, kModeSameExactLazy>(a, grid, lds, st);
     case kModeRaw: return launch_one<NCA, NCE, kModeRaw>(a, grid, lds, st);
     default: return launch_one<NCA, NCE, kModeGeneral>(a, grid, lds, st);
   }
@@ -3351,12 +3482,20 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
                        prep_lds, st, a);
   }
   SFM_LAUNCH_CHECK();
-  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 32;
+  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 48 + 128;
   const int grid = d->batch;  // capped to the resident workgroups in launch_one
   const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
-  if (int rc = launch_mode(vi, a, same ? (exact ? kModeSameExact : kModeSame) : kModeGeneral,
-                           grid, lds, st))
-    return rc;
+  // lazy surface stores: the flow path only (fused peak search: nobody else
+  // reads the surface), tile masks of 31 bits, SFM_MFMA_LAZY=0 switches it off
+  bool lazy = same && fp != nullptr && a.n_order <= 31 && a.skipmask != nullptr;
+  {
+    const char* e = sfm::option("SFM_MFMA_LAZY");
+    if (e && e[0] == '0') lazy = false;
+  }
+  const int mode = !same ? kModeGeneral
+                   : exact ? (lazy ? kModeSameExactLazy : kModeSameExact)
+                           : (lazy ? kModeSameLazy : kModeSame);
+  if (int rc = launch_mode(vi, a, mode, grid, lds, st)) return rc;
   if (fp) {
     hipLaunchKernelGGL(mfma_first_peak_kernel, dim3(d->batch), dim3(kThreads), 0, st, a);
     SFM_LAUNCH_CHECK();

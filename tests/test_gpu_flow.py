@@ -980,6 +980,17 @@ def test_pruned_correlation_tiles_are_bit_identical(gpu, monkeypatch, kind):
       full = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
       monkeypatch.delenv('SFM_MFMA_PRUNE')
       np.testing.assert_array_equal(pruned, full)
+      # lazy surface stores (only tiles that may hold hot elements, and their guard
+      # bands, reach memory) against the kernel that stores every computed tile,
+      # with and without the pruning
+      monkeypatch.setenv('SFM_MFMA_LAZY', '0')
+      eager = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+      monkeypatch.setenv('SFM_MFMA_PRUNE', '0')
+      eager_full = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+      monkeypatch.delenv('SFM_MFMA_PRUNE')
+      monkeypatch.delenv('SFM_MFMA_LAZY')
+      np.testing.assert_array_equal(pruned, eager)
+      np.testing.assert_array_equal(pruned, eager_full)
       # (the hot-list / candidate overflow fall-backs sweep surfaces with pruned,
       # never stored tiles: 'smooth' and 'fine' take them at threshold 0.2.  The
       # lattice of 'fine' has many peaks of nearly equal height, which the float
