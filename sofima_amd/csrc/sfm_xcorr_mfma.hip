@@ -2632,6 +2632,36 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #endif
 
       TICK(2)
+      if constexpr (LAZY) {
+        // Cold tile, known before its epilogue: every output is S + correction, the
+        // integer sums S are in the accumulators and |correction| has the patch-wide
+        // bound of the seed probe (tbound[kBoundCorr]).  If max S + that bound stays
+        // below threshold_rel x the running maximum, no element of the tile is hot,
+        // none raises the maximum, and -- unless a hot tile asked for it -- nothing
+        // of it is stored: the epilogue (40 table gathers and ~400 VALU operations
+        // per lane) has nothing to deliver.  Asked for later after all, it is
+        // recomputed like any band tile that finished un-stored.
+        if (a.prune && !forced) {
+          int ms = acc[0][0];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ms = max(ms, acc[q][r]);
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) ms = max(ms, __shfl_xor(ms, d, 64));
+          const float ub = __int2float_ru(ms) + tb_lds[kBoundCorr];
+          const float mrun = __int_as_float(__builtin_amdgcn_readfirstlane(
+              *const_cast<volatile int*>(pmax_lds)));
+          const int req = __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&lz[0]));
+          if (ub < a.threshold_rel * mrun && !((req >> p) & 1)) {
+            if (lane == 0) {
+              lz_tmax[p] = ub;
+              atomicOr(&lz[1], 1 << p);
+            }
+            continue;
+          }
+        }
+      }
       // The epilogue's table addresses do not depend on the MFMA loop; without
       // this opaque zero the compiler hoists its ~100 gathers above the loop
       // and spills the accumulators.  After the loop there are >140 free VGPRs,
