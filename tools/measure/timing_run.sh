@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 SFM_MFMA_TIMING=1 python -c "
 from sofima_amd import _build; _build.build(force=True)"
-python - <<PY 2>&1 | grep -v amdgpu.ids | tail -30
+python - <<PY 2>&1 | grep -v amdgpu.ids | tail -600
 import sys, time, os; sys.path.insert(0, os.environ['GRAFT_REPO_ROOT'])
 import numpy as np, torch
 from sofima_amd import flow_field
