@@ -280,6 +280,9 @@ def main():
     if drawn:
       o['row_tiles_skipped_frac'] = round(int(pf.tiles_skipped[0]) / drawn, 4)
       computed = drawn - int(pf.tiles_skipped[0])
+      # (of the drawn row tiles) given up inside their row loop: proved cold by the
+      # energy of the rows still to come, the rest of their matrix loop unissued
+      o['row_tiles_abandoned_frac'] = round(int(pf.tiles_abandoned[0]) / drawn, 4)
       if computed:
         o['col_tiles_skipped_per_row_tile'] = round(
             int(pf.col_tiles_skipped[0]) / computed, 3)

@@ -33,9 +33,9 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 7   /* 4: SfmProfile.mfma_issued; sfm_mesh_relax_banded; 5: SfmWarpDesc.coord_map_f64;
+#define SFM_ABI_VERSION 8   /* 4: SfmProfile.mfma_issued; sfm_mesh_relax_banded; 5: SfmWarpDesc.coord_map_f64;
                                 6: SfmBandedDesc.host_halo / host_allgather / host_user;
-                                7: sfm_ndimage_warp */
+                                7: sfm_ndimage_warp; 8: SfmProfile.tiles_abandoned */
 
 #define SFM_OK 0
 #define SFM_ERR_INVALID (-1)     /* bad argument / unsupported combination */
@@ -71,6 +71,10 @@ int sfm_device_count(int* count);
  *   SFM_MFMA_PROBE=0      no seed probe in front of the pruning
  *   SFM_MFMA_LAZY=0       flow path stores every computed surface tile (default:
  *                         only the tiles the peak kernels can read)
+ *   SFM_MFMA_EARLY=n      lazy path: row groups between two tests that abandon a
+ *                         provably cold tile inside its row loop (default 4; 0: none)
+ *   SFM_MFMA_WIDEN=1      lazy path: the store requests a patch starts with are widened
+ *                         by one row tile (fewer recomputed tiles, more finished ones)
  *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry
  *   SFM_MFMA_QUEUE=0      static instead of dynamic patch queue
  *   SFM_MFMA_XCD=1        one patch queue per XCD (measured: no gain) instead of a flat one
@@ -106,6 +110,8 @@ typedef struct SfmProfile {
   int64_t col_tiles_skipped[2]; /* column tiles left out of the computed row tiles */
   int64_t mfma_issued[2];       /* kind 0: matrix instructions (16 x 16 x 64 int8 =
                                    32768 operations each) the kernel issued      */
+  int64_t tiles_abandoned[2];   /* kind 0: row tiles given up inside their row loop
+                                   (proved cold by the rows still to come)       */
 } SfmProfile;
 int sfm_profile_enable(int on);
 int sfm_profile_read(SfmProfile* out);

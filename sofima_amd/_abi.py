@@ -338,7 +338,8 @@ class SfmProfile(C.Structure):
               ('clock_mhz', C.c_double * 2),
               ('tiles_skipped', C.c_int64 * 2), ('tiles_drawn', C.c_int64 * 2),
               ('col_tiles_skipped', C.c_int64 * 2),
-              ('mfma_issued', C.c_int64 * 2)]
+              ('mfma_issued', C.c_int64 * 2),
+              ('tiles_abandoned', C.c_int64 * 2)]
 
 
 class SfmChunkStats(C.Structure):

@@ -127,13 +127,14 @@ int sfm_profile_read(SfmProfile* out) {
     out->launches[k] = static_cast<int64_t>(sfm::g_spans[k].size());
     sfm::g_spans[k].clear();
     // the events above are later in stream order than the probe copies
-    long long cyc = 0, ticks = 0, skipped = 0, drawn = 0, cols = 0, issued = 0;
+    long long cyc = 0, ticks = 0, skipped = 0, drawn = 0, cols = 0, issued = 0, early = 0;
     for (auto& c : sfm::g_clock[k]) {
       cyc += c.v[0];
       ticks += c.v[1];
       skipped += c.v[2] & 0xffffffffLL;
       drawn += (c.v[2] >> 32) & 0xffffffffLL;
-      cols += c.v[3];
+      cols += c.v[3] & 0xffffffffLL;
+      early += (c.v[3] >> 32) & 0xffffffffLL;
       issued += c.v[4];
     }
     out->clock_mhz[k] = ticks > 0 ? static_cast<double>(cyc) * 100.0 / ticks : 0.0;
@@ -141,6 +142,7 @@ int sfm_profile_read(SfmProfile* out) {
     out->tiles_drawn[k] = drawn;
     out->col_tiles_skipped[k] = cols;
     out->mfma_issued[k] = issued;
+    out->tiles_abandoned[k] = early;
     sfm::g_clock[k].clear();
   }
   return SFM_OK;

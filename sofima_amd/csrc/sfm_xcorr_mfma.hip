@@ -128,11 +128,16 @@ __host__ __device__ constexpr int col_skip_3(int nq) { return 3 * nq / 10; }  //
 // tbound layout per patch: [0, 30) row tiles; [30], [31] outer col_skip_lo / _hi column
 // tiles (any dy); [32 + 3 p + j] row tile p with the outer col_skip_hi / _2 / _3 column
 // tiles (2-D bound from 16 x 16 block energies)
-constexpr int kBoundStride = 128;
+constexpr int kBoundStride = 256;   // floats per patch: bounds, then the row-energy prefixes
 constexpr int kBoundTiles = 30;    // dy tiles per patch with a pruning bound
 constexpr int kBoundCorr = 122;    // tbound slot: bound of the mean-correction terms
 constexpr int kBlkRows = 16, kBlkCols = 12;  // 16 x 16 pixel blocks of a patch (<= 256 x 192)
 constexpr int kBoundRows = 256;    // patch rows the prep kernel keeps energies for
+// tbound[kRowPre + 64 s + k] (uint bits): sum over rows < min(4 k, rows) of side s of
+// sum_x (pixel - centre)^2 -- the energies of the int8 operands, exact integers
+// (< 2^31 for every patch the matrix path takes); k <= 63, i.e. rows <= kEarlyRows
+constexpr int kRowPre = 128;
+constexpr int kEarlyRows = 252;
 
 struct PatchParams {  // written by the prep kernel, one per patch
   int y0[2], x0[2];   // clamped patch origin in the image (pre, post)
@@ -221,7 +226,8 @@ struct MfmaArgs {
   // shader-clock probe: workgroup 0 leaves (core cycles, 10 ns wall ticks) of its
   // residency here (bench.py reports the sustained clock under this kernel);
   // clk[2]: dy tiles skipped by the pruning (low word) / drawn (high word), whole
-  // launch; clk[3]: column tiles left out of the computed dy tiles; clk[4]: matrix
+  // launch; clk[3]: column tiles left out of the computed dy tiles (low word) / dy tiles
+  // abandoned inside their row loop (high word); clk[4]: matrix
   // instructions issued by the row loops (count_tiles)
   long long* clk;
   int prio_mode;      // experiment knob: 0 natural, 1 alternate per tile, 2 static
@@ -229,6 +235,8 @@ struct MfmaArgs {
   // over tile p widened by `guard` rows (prep output; see the tile loop)
   float* tbound;      // [batch, kBoundStride]; the last two entries: outer column tiles
   int prune;
+  int widen;          // initial store requests: the previous need mask, widened by a tile (SFM_MFMA_WIDEN=1)
+  int early;          // lazy modes: abandon provably cold tiles inside the row loop (check period, row groups; 0 = off)
   int count_tiles;    // report the pruning counts through clk (timing hooks on)
   int probe;          // seed the running maximum from a probe block (see the kernel)
   int guard, guard_x;
@@ -608,6 +616,29 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
     }
     const double excl = inc - tot;
     if (lane == 0) row_pre[s][0] = 0.0;
+    {
+      // the same about the integer centre c (what the matrix operands hold), every
+      // fourth row: the correlation kernel bounds the rows a tile has not visited yet
+      const long long c = s_c[s];
+      unsigned tot_c = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int y = 4 * lane + k;
+        if (y < py) {
+          const long long sq = static_cast<long long>(row_acc[s][y] >> 32);
+          const long long sm = static_cast<long long>(row_acc[s][y] & 0xffffffffull);
+          tot_c += static_cast<unsigned>(sq - 2 * c * sm + c * c * px);
+        }
+      }
+      unsigned inc_c = tot_c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(inc_c, d, 64);
+        if (lane >= d) inc_c += o;
+      }
+      a.tbound[(long long)b * kBoundStride + kRowPre + 64 * s + lane] =
+          __uint_as_float(inc_c - tot_c);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int y = 4 * lane + k;
@@ -2050,7 +2081,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   // at the same speed (see the priority note below) and finish whole patches
   // at different times.
   int* next_lds = hot_lds + 1;
-  int tiles_drawn = 0, tiles_skipped = 0, cols_skipped = 0;  // (wave-uniform; reported through a.clk)
+  int tiles_drawn = 0, tiles_skipped = 0, cols_skipped = 0, tiles_early = 0;  // (wave-uniform; reported through a.clk)
   long long mfma_issued = 0;  // matrix instructions this wave issued in the row loops
   if (a.prio_mode == 3) {
     // HW_REG_LDS_ALLOC[7:0] = LDS_BASE: 0 for the first workgroup of the CU.
@@ -2138,8 +2169,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         const int pt = *best_lds >> 8, gt = (a.guard + 15) >> 4;
         const int lo_t = max(pt - gt, 0), hi_t = min(pt + gt, a.n_order - 1);
         const int pv = *lz_prev;   // (widened by a tile: a store costs less than a recomputation)
-        lz[0] = static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u)) | pv | (pv << 1) |
-                (pv >> 1);
+        lz[0] = static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u)) | pv |
+                (a.widen ? (pv << 1) | (pv >> 1) : 0);
         lz[1] = lz[2] = lz[3] = 0;
       }
       if (SAME && a.prune) {
@@ -2420,6 +2451,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       v4i acc[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) acc[q] = v4i{0, 0, 0, 0};
+      const bool chk_early = LAZY && a.early > 0 && a.prune && !forced;
+      bool abandoned = false;   // (lazy modes) given up inside the row loop: see cold_after
 
       const unsigned char* ap =
           A_lds + (kPadTop + ylo + g + dy0 + n) * a.pa;
@@ -2477,6 +2510,48 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         static_assert(NCA % kW == 0, "window must divide the chunk count");
         // The row loop exists in up to three variants: KS outer column tiles on
         // either side are left out (exact pruning along x, see col_skip below).
+        // Cold before it is finished (lazy modes).  After the patch rows yb < y the
+        // accumulators hold exact partial sums; what the rows y .. yhi - 1 can still
+        // add to any element of the tile is at most
+        //   sqrt(E_A(rows y + dy0 .. yhi + dy0 + 14) E_B(rows y .. yhi - 1))
+        // (Cauchy-Schwarz over the remaining operand bytes, whole rows: shifts and
+        // the column window only shrink the sums; rows outside a patch are zero
+        // padding) -- integer row energies about the operand centres from the prep
+        // kernel (tb_lds[kRowPre ...], every fourth row, rounded outwards).  With the
+        // bound of the mean correction added, a tile whose every element stays below
+        // threshold_rel x the running maximum is exactly what the test behind the
+        // loop calls cold: not hot, not a maximum, and -- unless requested -- never
+        // read.  It is abandoned here, with the rest of its row loop unissued (before
+        // the first row group this is the tile's own bound, without the guard band
+        // the a-priori test has to include); requested later, it is recomputed like
+        // any tile that finished un-stored.
+        auto cold_after = [&](int y) {
+          int ms = 0;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ms = max(ms, acc[q][r]);
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) ms = max(ms, __shfl_xor(ms, d, 64));
+          const unsigned* rp = reinterpret_cast<const unsigned*>(tb_lds + kRowPre);
+          const int a_lo = max(0, y + dy0), a_hi = min(Py, yhi + dy0 + 15);
+          const unsigned ea = rp[(a_hi + 3) >> 2] - rp[a_lo >> 2];
+          const unsigned eb = rp[64 + ((yhi + 3) >> 2)] - rp[64 + (y >> 2)];
+          // (margins: a few ulp of the product, the root and the two sums)
+          const float rest = sqrtf(__uint2float_ru(ea) * __uint2float_ru(eb)) * 1.000002f + 2.f;
+          const float ub = (__int2float_ru(ms) + rest + tb_lds[kBoundCorr]) * 1.000002f + 2.f;
+          const float mrun = __int_as_float(__builtin_amdgcn_readfirstlane(
+              *const_cast<volatile int*>(pmax_lds)));
+          const int req = __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&lz[0]));
+          if (ub < a.threshold_rel * mrun && !((req >> p) & 1)) {
+            if (lane == 0) {
+              lz_tmax[p] = ub;
+              atomicOr(&lz[1], 1 << p);
+            }
+            return true;
+          }
+          return false;
+        };
         auto rows = [&](auto ks_const) {
         constexpr int KS = decltype(ks_const)::value;
         v4i af[kW], bf[NCE];
@@ -2492,7 +2567,19 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           for (int k = 0; k < 4; ++k)
             bf[c][k] = static_cast<int>(
                 __builtin_amdgcn_alignbyte(dn[4 * c + k + 1], dn[4 * c + k], sh));
-        for (int yb0 = ylo; yb0 < yhi; yb0 += 4) {
+        // Lazy modes: every a.early row groups (and before the first) the tile is
+        // tested for being provably cold already -- see cold_after below.
+        int yb0 = ylo;
+        for (;;) {
+        int yseg = yhi;
+        if (LAZY && chk_early) {
+          if (yhi - yb0 > 8 && cold_after(yb0)) {
+            abandoned = true;
+            break;
+          }
+          yseg = min(yhi, yb0 + 4 * a.early);
+        }
+        for (; yb0 < yseg; yb0 += 4) {
           bp += 4 * a.pb;
 #pragma unroll
           for (int ca = 0; ca < NCA; ++ca) {
@@ -2575,6 +2662,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           }
           ap += 4 * a.pa;
         }
+        if (yb0 >= yhi) break;
+        }
         {
           // instructions of one row group of this variant: (ca, c) pairs whose
           // column tile q = ca - c + cq0 is kept
@@ -2584,7 +2673,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #pragma unroll
             for (int c = 0; c < NCE; ++c)
               per_group += (ca - c + NCE - 1 >= KS && ca - c + NCE - 1 < NQ - KS) ? 1 : 0;
-          mfma_issued += (long long)((yhi - ylo + 3) / 4) * per_group;
+          mfma_issued += (long long)((yb0 - ylo) / 4) * per_group;  // (groups issued)
         }
         };
         constexpr int kKs1 = col_skip_lo(NQ), kKs2 = col_skip_hi(NQ);
@@ -2632,6 +2721,10 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #endif
 
       TICK(2)
+      if (LAZY && abandoned) {
+        ++tiles_early;
+        continue;
+      }
       if constexpr (LAZY) {
         // Cold tile, known before its epilogue: every output is S + correction, the
         // integer sums S are in the accumulators and |correction| has the patch-wide
@@ -3081,7 +3174,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
               (static_cast<unsigned long long>(tiles_drawn) << 32) |
                   static_cast<unsigned long long>(tiles_skipped));
     atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 3),
-              static_cast<unsigned long long>(cols_skipped));
+              (static_cast<unsigned long long>(tiles_early) << 32) |
+                  static_cast<unsigned long long>(cols_skipped));
   }
   if (a.count_tiles && a.clk && lane == 0)
     atomicAdd(reinterpret_cast<unsigned long long*>(a.clk + 4),
@@ -3483,6 +3577,21 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
       a.probe = !(e && e[0] == '0');
     }
     a.count_tiles = sfm::profiling() ? 1 : 0;
+    {
+      // row groups between two cold tests inside the row loop of the lazy modes
+      // ("0": none); see cold_after in the kernel
+      const char* e = sfm::option("SFM_MFMA_EARLY");
+      a.early = e ? std::atoi(e) : 4;
+      // initial store requests of a patch: what the previous patch of the workgroup
+      // needed, "1": widened by a row tile on either side.  (Before the in-loop test
+      // a spare request cost a store and saved a recomputation when the peak moved
+      // to the next tile; now a requested tile also runs its whole row loop where
+      // an unrequested one is abandoned after ~3/4 of it.  Measured on the 8192^2
+      // warped pair: 12.29 ms per launch without, 12.54 ms with the widening.)
+      const char* wd = sfm::option("SFM_MFMA_WIDEN");
+      a.widen = wd ? std::atoi(wd) : 0;
+      if (a.early < 0 || a.P[0] > kEarlyRows) a.early = 0;
+    }
     a.prune = same && prune_enabled() && a.n_order <= kBoundTiles &&
               a.P[0] <= 16 * kBlkRows && a.P[1] <= 16 * kBlkCols &&
               a.P[0] <= kBoundRows && d->threshold_rel > 0.f && d->threshold_rel <= 1.f &&

@@ -33,7 +33,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_channel(lib):
-  assert lib.sfm_version() == 7
+  assert lib.sfm_version() == 8
   # A NULL descriptor is rejected with a message, not a crash.
   rc = lib.sfm_mesh_force(None, None)
   assert rc == -1

@@ -991,6 +991,17 @@ def test_pruned_correlation_tiles_are_bit_identical(gpu, monkeypatch, kind):
       monkeypatch.delenv('SFM_MFMA_LAZY')
       np.testing.assert_array_equal(pruned, eager)
       np.testing.assert_array_equal(pruned, eager_full)
+      # tiles abandoned inside their row loop (proved cold by the energy of the rows
+      # still to come): tested after every row group, and never
+      for period in ('1', '0'):
+        monkeypatch.setenv('SFM_MFMA_EARLY', period)
+        np.testing.assert_array_equal(
+            pruned, flow_field.batched_xcorr_peaks(*args, method=2, **kw))
+      monkeypatch.delenv('SFM_MFMA_EARLY')
+      monkeypatch.setenv('SFM_MFMA_WIDEN', '1')   # wider initial store requests
+      np.testing.assert_array_equal(
+          pruned, flow_field.batched_xcorr_peaks(*args, method=2, **kw))
+      monkeypatch.delenv('SFM_MFMA_WIDEN')
       # (the hot-list / candidate overflow fall-backs sweep surfaces with pruned,
       # never stored tiles: 'smooth' and 'fine' take them at threshold 0.2.  The
       # lattice of 'fine' has many peaks of nearly equal height, which the float
@@ -1001,6 +1012,41 @@ def test_pruned_correlation_tiles_are_bit_identical(gpu, monkeypatch, kind):
         np.testing.assert_array_equal(np.isnan(pruned), np.isnan(ref))
         np.testing.assert_array_equal(pruned[:, :2], ref[:, :2])
         np.testing.assert_allclose(pruned[:, 3], ref[:, 3], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_abandoned_tiles_are_counted_and_save_matrix_instructions(gpu, monkeypatch):
+  """SfmProfile.tiles_abandoned / mfma_issued: on an EM-like pair the in-loop cold
+  test gives up row tiles and the kernel issues fewer matrix instructions than
+  with SFM_MFMA_EARLY=0, for identical peak statistics."""
+  import ctypes as C
+  from sofima_amd import flow_field, _abi
+  lib = _abi.load()
+  pre, post = _prune_images('em', 7, 460, 500)
+  rng = np.random.default_rng(2)
+  starts = np.stack([rng.integers(0, 300, 64), rng.integers(0, 340, 64)], axis=1)
+  kw = dict(min_distance=2, threshold_rel=0.5, peak_radius=5,
+            post_patch_size=(160, 160), post_starts=starts)
+  args = (pre, post, None, None, (160, 160), starts, None)
+
+  def run():
+    pf = _abi.SfmProfile()
+    lib.sfm_profile_read(C.byref(pf))
+    lib.sfm_profile_enable(1)
+    try:
+      out = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+      lib.sfm_profile_read(C.byref(pf))
+    finally:
+      lib.sfm_profile_enable(0)
+    return out, int(pf.tiles_abandoned[0]), int(pf.mfma_issued[0]), int(pf.tiles_drawn[0])
+
+  out_e, abandoned_e, issued_e, drawn_e = run()
+  monkeypatch.setenv('SFM_MFMA_EARLY', '0')
+  out_0, abandoned_0, issued_0, drawn_0 = run()
+  np.testing.assert_array_equal(out_e, out_0)
+  assert drawn_e == drawn_0 > 0
+  assert abandoned_0 == 0 and abandoned_e > 0
+  assert issued_e < issued_0
 
 
 @pytest.mark.gpu

@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/early
+for e in 1 0; do
+  SFM_MFMA_WIDEN=$e timeout 600 python bench.py --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/early/bench_w$e.json 2> gpurun_out/early/bench_w$e.err
+  python - <<PY
+import json
+j = json.loads(open('gpurun_out/early/bench_w$e.json').read().strip().splitlines()[-1])
+r = j['roofline']['pruned']
+print('WIDEN=$e value', round(j['value'], 1), 'ms/step', round(j['ms_per_step'], 3), 'kernel ms', r['avg_launch_ms'],
+      'issued/alg', r['issued_over_algorithmic'], 'abandoned', r.get('row_tiles_abandoned_frac'),
+      'skipped', r['row_tiles_skipped_frac'], 'MHz', r['sustained_clock_mhz'])
+PY
+done
