@@ -71,8 +71,12 @@ int sfm_device_count(int* count);
  *   SFM_MFMA_PROBE=0      no seed probe in front of the pruning
  *   SFM_MFMA_LAZY=0       flow path stores every computed surface tile (default:
  *                         only the tiles the peak kernels can read)
- *   SFM_MFMA_EARLY=n      lazy path: row groups between two tests that abandon a
- *                         provably cold tile inside its row loop (default 4; 0: none)
+ *   SFM_MFMA_EARLY=n      lazy path: least number of row groups between two tests that
+ *                         abandon a provably cold tile inside its row loop, or narrow
+ *                         it (default 2; each test schedules the next; 0: no tests)
+ *   SFM_MFMA_NARROW=n     lazy path: widest in-flight narrowing of a row loop (outer column
+ *                         tiles dropped once proved cold; default: down to the four
+ *                         central tiles; 0: never)
  *   SFM_MFMA_WIDEN=1      lazy path: the store requests a patch starts with are widened
  *                         by one row tile (fewer recomputed tiles, more finished ones)
  *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry

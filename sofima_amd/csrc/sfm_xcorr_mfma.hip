@@ -125,6 +125,9 @@ __host__ __device__ constexpr int col_skip_hi(int nq) { return nq / 5; }
 __host__ __device__ constexpr int col_skip_lo(int nq) { return 3 * nq / 20; }
 __host__ __device__ constexpr int col_skip_2(int nq) { return nq / 4; }       // per-row-tile
 __host__ __device__ constexpr int col_skip_3(int nq) { return 3 * nq / 10; }  // variants
+// the narrowest row loop: the four central column tiles (entered only in flight, see
+// narrow_after in the kernel)
+__host__ __device__ constexpr int col_skip_c(int nq) { return (nq - 4) / 2; }
 // tbound layout per patch: [0, 30) row tiles; [30], [31] outer col_skip_lo / _hi column
 // tiles (any dy); [32 + 3 p + j] row tile p with the outer col_skip_hi / _2 / _3 column
 // tiles (2-D bound from 16 x 16 block energies)
@@ -235,8 +238,9 @@ struct MfmaArgs {
   // over tile p widened by `guard` rows (prep output; see the tile loop)
   float* tbound;      // [batch, kBoundStride]; the last two entries: outer column tiles
   int prune;
+  int narrow;         // lazy modes: row loops drop provably cold outer column tiles in flight (SFM_MFMA_NARROW=0: off)
   int widen;          // initial store requests: the previous need mask, widened by a tile (SFM_MFMA_WIDEN=1)
-  int early;          // lazy modes: abandon provably cold tiles inside the row loop (check period, row groups; 0 = off)
+  int early;          // lazy modes: abandon provably cold tiles inside the row loop (least distance of two tests, row groups; 0 = off)
   int count_tiles;    // report the pruning counts through clk (timing hooks on)
   int probe;          // seed the running maximum from a probe block (see the kernel)
   int guard, guard_x;
@@ -2045,6 +2049,12 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   int* lz = best_lds + 8;
   float* lz_tmax = reinterpret_cast<float*>(lz + 4);
   int* lz_prev = reinterpret_cast<int*>(lz_tmax + 31);   // (tiles 0 .. 30) what the previous patch needed
+  // Column side of the lazy stores: lz_cq[0], [1] lowest / highest column tile that
+  // held a possibly hot element in this patch, [2], [3] the same of the previous
+  // patch of the workgroup; lz_ks[p]: outer column tiles row tile p dropped inside its
+  // row loop (0: none beyond the a-priori ones)
+  int* lz_cq = lz_prev + 1;
+  int* lz_ks = lz_cq + 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -2060,7 +2070,12 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     *best_lds = (((a.Q[0] - 1) / 16) << 8) | ((a.Q[1] - 1) / 16);  // the zero shift
     best_lds[2] = 1;  // pruning events of the previous patch (optimistic start)
     best_lds[3] = 0;  // patches of this workgroup so far
-    if (LAZY) *lz_prev = 0;
+    if (LAZY) {
+      *lz_prev = 0;
+      lz_cq[0] = NQ;
+      lz_cq[1] = -1;
+      lz_cq[2] = lz_cq[3] = (a.Q[1] - 1) / 16;   // the zero shift
+    }
   }
   const long long bytes0 = (long long)a.ishape[0][0] * a.ishape[0][1];
   const long long bytes1 = (long long)a.ishape[1][0] * a.ishape[1][1];
@@ -2072,7 +2087,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #ifdef SFM_MFMA_TIMING
   const long long wstart = wall_clock64();
   const long long cstart = clock64();
-  long long tph[10] = {0,0,0,0,0,0,0,0,0,0}; long long tc = clock64(); int npat = 0;
+  long long tph[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0}; long long tc = clock64(); int npat = 0;
 #define TICK(i) { long long tn = clock64(); tph[i] += tn - tc; tc = tn; }
 #else
 #define TICK(i)
@@ -2172,6 +2187,12 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         lz[0] = static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u)) | pv |
                 (a.widen ? (pv << 1) | (pv >> 1) : 0);
         lz[1] = lz[2] = lz[3] = 0;
+        if (lz_cq[1] >= lz_cq[0]) {   // (the previous patch had hot elements)
+          lz_cq[2] = lz_cq[0];
+          lz_cq[3] = lz_cq[1];
+        }
+        lz_cq[0] = NQ;
+        lz_cq[1] = -1;
       }
       if (SAME && a.prune) {
         best_lds[1] = 0;  // row tiles pruned in this patch
@@ -2192,6 +2213,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       }
       if (a.prune && threadIdx.x < kBoundStride) tb_lds[threadIdx.x] = tbv;
       if (a.prune) probe_lds[threadIdx.x] = 0;
+      if (LAZY && threadIdx.x < 32) lz_ks[threadIdx.x] = 0;
       const float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
       for (int i = threadIdx.x + kAuxRegs * kThreads; i < 4 * a.aux_n; i += kThreads)
         R_lds[i] = aux[i];
@@ -2349,7 +2371,21 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             need |= static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u));
           }
         if (lane == 0) *lz_prev = need;   // (every wave writes the same value)
-        int todo = need & done & ~*const_cast<volatile int*>(&lz[2]) &
+        // stored tiles that dropped column tiles in flight and turn out to have a
+        // possibly hot column (of any row tile) within a tile of what they dropped:
+        // recomputed in full like the band tiles that finished un-stored
+        int bad = 0;
+        {
+          const int hq_lo = *const_cast<volatile int*>(&lz_cq[0]);
+          const int hq_hi = *const_cast<volatile int*>(&lz_cq[1]);
+          if (hq_hi >= hq_lo)
+            for (int t = 0; t < a.n_order; ++t) {
+              const int ks = lz_ks[t];
+              if (((done >> t) & 1) && ks > 0 && (hq_lo < ks + 1 || hq_hi > NQ - 2 - ks))
+                bad |= 1 << t;
+            }
+        }
+        int todo = need & done & (~*const_cast<volatile int*>(&lz[2]) | bad) &
                    ~*const_cast<volatile int*>(&lz[3]);
         todo = __builtin_amdgcn_readfirstlane(todo);
         if (todo == 0) break;
@@ -2452,7 +2488,14 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) acc[q] = v4i{0, 0, 0, 0};
       const bool chk_early = LAZY && a.early > 0 && a.prune && !forced;
-      bool abandoned = false;   // (lazy modes) given up inside the row loop: see cold_after
+      bool abandoned = false;   // (lazy modes) given up inside the row loop: see check_after
+      bool narrowed = false;    // (lazy modes) column tiles dropped inside the row loop
+      int yb0 = ylo, y_checked = -1;   // row-loop position (shared by the loop variants)
+      int y_next = ylo;                // row of the next in-loop test (see check_after)
+      // widest narrowing the previous patch's hot column tiles allow (one tile of margin)
+      int kmax_pred = 0;
+      if (LAZY && chk_early && a.narrow && a.guard_x <= 16)
+        kmax_pred = min(__builtin_amdgcn_readfirstlane(min(lz_cq[2], NQ - 1 - lz_cq[3])) - 1, a.narrow);
 
       const unsigned char* ap =
           A_lds + (kPadTop + ylo + g + dy0 + n) * a.pa;
@@ -2525,12 +2568,46 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // the first row group this is the tile's own bound, without the guard band
         // the a-priori test has to include); requested later, it is recomputed like
         // any tile that finished un-stored.
-        auto cold_after = [&](int y) {
-          int ms = 0;
+        // (returns -1: abandoned; otherwise the number of outer column tiles the rest
+        // of the row loop may leave out, >= ks_now)
+        // Narrower in flight.  The same bound column by column: if every shift of the
+        // outer K + 1 column tiles on either side (one tile of margin: guard_x <= 16)
+        // already satisfies partial sum + rest + |correction|max < threshold_rel x the
+        // running maximum, the K outer tiles are cold whatever the remaining rows hold,
+        // and the loop continues in the variant without them; the epilogue zeroes them
+        // like tiles left out a priori.  Zeros stand in for cold values wherever a cold
+        // value may be read (a max-filter window); the windows that need true values
+        // belong to hot elements, which this tile does not have within a tile of the
+        // columns it dropped -- but another row tile of the band might.  So every tile
+        // that may be hot records its hot column tiles (lz_cq), a stored tile records
+        // how far it was narrowed (lz_ks), and the end-of-patch pass recomputes in full
+        // what turns out to lie within a tile of a hot column (rare: the loop only
+        // narrows to what the previous patch's hot columns leave, kmax_pred).
+        // The tests are not free (80 integer maxima, wave reductions, a square root:
+        // measured 2 300 cycles each next to the other workgroup's matrix loop, 23 %
+        // of a wave's time in the tile loop when run every four row groups), so each
+        // one schedules the next: the rest bound falls about linearly with the rows
+        // that are left, which puts the earliest row at which the tile (or its outer
+        // column tiles) can pass at  yhi - (rows left) x gap / rest  for the current
+        // gap = threshold - partial maximum - |correction|max.
+        auto check_after = [&](int y, int ks_now) {
+          int run = 0, m_k[5] = {0, 0, 0, 0, 0};
+          constexpr int kCand[5] = {col_skip_lo(NQ), col_skip_hi(NQ), col_skip_2(NQ),
+                                    col_skip_3(NQ), col_skip_c(NQ)};
+          if (y > ylo) {   // (before the first row group every sum is zero)
 #pragma unroll
-          for (int q = 0; q < NQ; ++q)
+            for (int j = 0; j < (NQ + 1) / 2; ++j) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ms = max(ms, acc[q][r]);
+              for (int r = 0; r < 4; ++r) {
+                run = max(run, acc[j][r]);
+                run = max(run, acc[NQ - 1 - j][r]);
+              }
+#pragma unroll
+              for (int i = 0; i < 5; ++i)
+                if (kCand[i] == j) m_k[i] = run;   // tiles q <= K and q >= NQ - 1 - K
+            }
+          }
+          int ms = run;
 #pragma unroll
           for (int d = 32; d > 0; d >>= 1) ms = max(ms, __shfl_xor(ms, d, 64));
           const unsigned* rp = reinterpret_cast<const unsigned*>(tb_lds + kRowPre);
@@ -2539,18 +2616,48 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           const unsigned eb = rp[64 + ((yhi + 3) >> 2)] - rp[64 + (y >> 2)];
           // (margins: a few ulp of the product, the root and the two sums)
           const float rest = sqrtf(__uint2float_ru(ea) * __uint2float_ru(eb)) * 1.000002f + 2.f;
-          const float ub = (__int2float_ru(ms) + rest + tb_lds[kBoundCorr]) * 1.000002f + 2.f;
-          const float mrun = __int_as_float(__builtin_amdgcn_readfirstlane(
-              *const_cast<volatile int*>(pmax_lds)));
+          const float corr = tb_lds[kBoundCorr];
+          const float ub = (__int2float_ru(ms) + rest + corr) * 1.000002f + 2.f;
+          const float thr_now = a.threshold_rel * __int_as_float(__builtin_amdgcn_readfirstlane(
+                                                      *const_cast<volatile int*>(pmax_lds)));
           const int req = __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&lz[0]));
-          if (ub < a.threshold_rel * mrun && !((req >> p) & 1)) {
+          const bool requested = (req >> p) & 1;
+          if (ub < thr_now && !requested) {
             if (lane == 0) {
               lz_tmax[p] = ub;
               atomicOr(&lz[1], 1 << p);
             }
-            return true;
+            return -1;
           }
-          return false;
+          // earliest row at which a set of columns with partial maximum m can pass
+          const float left = static_cast<float>(yhi - y);
+          auto passes_at = [&](int m) {
+            const float gap = thr_now - (__int2float_ru(m) + corr);
+            return gap > 0.f ? yhi - static_cast<int>(left * (gap / rest)) : yhi;
+          };
+          int y_at = requested ? yhi : passes_at(ms);
+          int ks_new = ks_now;
+          if (y > ylo && kmax_pred > ks_now) {
+            bool open = true;   // widest first: the sets are nested
+#pragma unroll
+            for (int i = 4; i >= 0; --i) {
+              if (i < 4 && kCand[i] == kCand[i + 1]) continue;
+              if (kCand[i] <= 0 || 2 * kCand[i] + 2 > NQ) continue;
+              if (!open || kCand[i] <= ks_now || kCand[i] > kmax_pred) continue;   // (wave-uniform)
+              int mo = m_k[i];
+#pragma unroll
+              for (int d = 32; d > 0; d >>= 1) mo = max(mo, __shfl_xor(mo, d, 64));
+              const float ubk = (__int2float_ru(mo) + rest + corr) * 1.000002f + 2.f;
+              if (ubk < thr_now) {
+                ks_new = kCand[i];
+                open = false;
+              } else {
+                y_at = min(y_at, passes_at(mo));
+              }
+            }
+          }
+          y_next = max(y + 4 * a.early, ylo + ((y_at - ylo + 3) & ~3));
+          return ks_new;
         };
         auto rows = [&](auto ks_const) {
         constexpr int KS = decltype(ks_const)::value;
@@ -2568,16 +2675,28 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             bf[c][k] = static_cast<int>(
                 __builtin_amdgcn_alignbyte(dn[4 * c + k + 1], dn[4 * c + k], sh));
         // Lazy modes: every a.early row groups (and before the first) the tile is
-        // tested for being provably cold already -- see cold_after below.
-        int yb0 = ylo;
+        // tested for being provably cold already, as a whole or in its outer column
+        // tiles -- see check_after above.
+        const int y_enter = yb0;
         for (;;) {
         int yseg = yhi;
         if (LAZY && chk_early) {
-          if (yhi - yb0 > 8 && cold_after(yb0)) {
-            abandoned = true;
-            break;
+          if (yhi - yb0 > 8 && yb0 >= y_next && yb0 != y_checked) {
+            y_checked = yb0;
+            TICK(12)   // (timing build) row groups (and the loop prologue)
+            const int ks_new = check_after(yb0, KS);
+            TICK(11)   // (timing build) the in-loop tests
+            if (ks_new < 0) {
+              abandoned = true;
+              break;
+            }
+            if (ks_new > KS) {   // the rest of the tile runs in a narrower variant
+              col_skip = ks_new;
+              narrowed = true;
+              break;
+            }
           }
-          yseg = min(yhi, yb0 + 4 * a.early);
+          yseg = min(yhi, max(y_next, yb0 + 4));
         }
         for (; yb0 < yseg; yb0 += 4) {
           bp += 4 * a.pb;
@@ -2673,22 +2792,29 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #pragma unroll
             for (int c = 0; c < NCE; ++c)
               per_group += (ca - c + NCE - 1 >= KS && ca - c + NCE - 1 < NQ - KS) ? 1 : 0;
-          mfma_issued += (long long)((yb0 - ylo) / 4) * per_group;  // (groups issued)
+          mfma_issued += (long long)((yb0 - y_enter) / 4) * per_group;  // (groups issued)
         }
         };
         constexpr int kKs1 = col_skip_lo(NQ), kKs2 = col_skip_hi(NQ);
         constexpr int kKs3 = col_skip_2(NQ), kKs4 = col_skip_3(NQ);
+        constexpr int kKs5 = (LAZY && 2 * col_skip_c(NQ) + 2 <= NQ) ? col_skip_c(NQ) : 0;
         static_assert(kKs1 <= kKs2 && kKs2 <= kKs3 && kKs3 <= kKs4, "ascending");
-        if (kKs4 > kKs3 && col_skip == kKs4)
-          rows(std::integral_constant<int, kKs4>{});
-        else if (kKs3 > kKs2 && col_skip == kKs3)
-          rows(std::integral_constant<int, kKs3>{});
-        else if (kKs2 > kKs1 && col_skip == kKs2)
-          rows(std::integral_constant<int, kKs2>{});
-        else if (kKs1 > 0 && col_skip == kKs1)
+        // (a variant returns when the tile is finished, abandoned or to be continued
+        // in a narrower variant)
+        TICK(10)   // (timing build) tile draw, pruning tests, setup
+        // ascending and straight-line: a tile only ever moves to a narrower variant
+        // (a loop around one dispatch made the register allocator spill 255 VGPRs)
+        if (col_skip == 0 || (kKs1 == 0 && col_skip == kKs1)) rows(std::integral_constant<int, 0>{});
+        if (kKs1 > 0 && col_skip == kKs1 && !abandoned && yb0 < yhi)
           rows(std::integral_constant<int, kKs1>{});
-        else
-          rows(std::integral_constant<int, 0>{});
+        if (kKs2 > kKs1 && col_skip == kKs2 && !abandoned && yb0 < yhi)
+          rows(std::integral_constant<int, kKs2>{});
+        if (kKs3 > kKs2 && col_skip == kKs3 && !abandoned && yb0 < yhi)
+          rows(std::integral_constant<int, kKs3>{});
+        if (kKs4 > kKs3 && col_skip == kKs4 && !abandoned && yb0 < yhi)
+          rows(std::integral_constant<int, kKs4>{});
+        if (kKs5 > kKs4 && col_skip == kKs5 && !abandoned && yb0 < yhi)
+          rows(std::integral_constant<int, kKs5>{});
       } else
 #if SFM_AF_PREFETCH
       {
@@ -3116,6 +3242,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           }
           if (lane == 0) {
             lz_tmax[p] = tmax;
+            lz_ks[p] = narrowed ? col_skip : 0;
             if (need) atomicOr(&lz[2], 1 << p);
             atomicOr(&lz[1], 1 << p);
           }
@@ -3124,13 +3251,16 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         int* hi = a.hot_idx + (long long)b * a.hot_cap;
         // tmax is the wave-wide tile maximum: nothing to do unless it clears
         // the running threshold (the common case away from the peak).
-        if (tmax > thr_t)
+        if (tmax > thr_t) {
+        int hq_lo = NQ, hq_hi = -1;   // column tiles with elements that may be hot
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const float v0 = __int_as_float(acc[q][0]), v1 = __int_as_float(acc[q][1]);
           const float v2 = __int_as_float(acc[q][2]), v3 = __int_as_float(acc[q][3]);
           const float vm = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
           if (__any(vm > thr_t)) {  // wave-uniform, rarely taken
+            hq_lo = min(hq_lo, q);
+            hq_hi = q;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float v = __int_as_float(acc[q][r]);
@@ -3143,6 +3273,11 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
               }
             }
           }
+        }
+        if (LAZY && lane == 0 && hq_hi >= 0) {
+          atomicMin(&lz_cq[0], hq_lo);
+          atomicMax(&lz_cq[1], hq_hi);
+        }
         }
       }
       TICK(4)
@@ -3192,8 +3327,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
            tph[3] / (npat ? npat : 1));
   }
   if (blockIdx.x == 7 && lane == 0)
-    printf("wave %d patches %d: next %lld sync %lld pix %lld aux+touch %lld stagesync %lld mfma %lld epi %lld hot %lld tail %lld peaks %lld\n",
-           wave, npat, tph[7] / npat, tph[0] / npat, tph[8] / npat, tph[9] / npat, tph[1] / npat, tph[2] / npat, tph[3] / npat,
+    printf("wave %d patches %d: next %lld sync %lld pix %lld aux+touch %lld stagesync %lld mfma %lld (+ setup %lld tests %lld groups %lld) epi %lld hot %lld tail %lld peaks %lld\n",
+           wave, npat, tph[7] / npat, tph[0] / npat, tph[8] / npat, tph[9] / npat, tph[1] / npat, tph[2] / npat,
+           tph[10] / npat, tph[11] / npat, tph[12] / npat, tph[3] / npat,
            tph[4] / npat, tph[5] / npat, tph[6] / npat);
 #endif
 }
@@ -3578,10 +3714,10 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     }
     a.count_tiles = sfm::profiling() ? 1 : 0;
     {
-      // row groups between two cold tests inside the row loop of the lazy modes
-      // ("0": none); see cold_after in the kernel
+      // least number of row groups between two tests inside the row loop of the
+      // lazy modes ("0": no tests); each test schedules the next, see check_after
       const char* e = sfm::option("SFM_MFMA_EARLY");
-      a.early = e ? std::atoi(e) : 4;
+      a.early = e ? std::atoi(e) : 2;
       // initial store requests of a patch: what the previous patch of the workgroup
       // needed, "1": widened by a row tile on either side.  (Before the in-loop test
       // a spare request cost a store and saved a recomputation when the peak moved
@@ -3590,6 +3726,8 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
       // warped pair: 12.29 ms per launch without, 12.54 ms with the widening.)
       const char* wd = sfm::option("SFM_MFMA_WIDEN");
       a.widen = wd ? std::atoi(wd) : 0;
+      const char* nw = sfm::option("SFM_MFMA_NARROW");
+      a.narrow = nw ? std::atoi(nw) : 64;   // widest narrowing allowed (0: off)
       if (a.early < 0 || a.P[0] > kEarlyRows) a.early = 0;
     }
     a.prune = same && prune_enabled() && a.n_order <= kBoundTiles &&
@@ -3621,7 +3759,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
                        prep_lds, st, a);
   }
   SFM_LAUNCH_CHECK();
-  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 48 + 128;
+  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 48 + 128 + 160;
   const int grid = d->batch;  // capped to the resident workgroups in launch_one
   const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
   // lazy surface stores: the flow path only (fused peak search: nobody else

@@ -1002,6 +1002,14 @@ def test_pruned_correlation_tiles_are_bit_identical(gpu, monkeypatch, kind):
       np.testing.assert_array_equal(
           pruned, flow_field.batched_xcorr_peaks(*args, method=2, **kw))
       monkeypatch.delenv('SFM_MFMA_WIDEN')
+      # row loops that drop provably cold outer column tiles in flight (default: down
+      # to the four central tiles; 'far' and 'periodic' have their hot columns where
+      # the previous patch does not predict them): never, and to the a-priori widths
+      for widest in ('0', '4'):
+        monkeypatch.setenv('SFM_MFMA_NARROW', widest)
+        np.testing.assert_array_equal(
+            pruned, flow_field.batched_xcorr_peaks(*args, method=2, **kw))
+      monkeypatch.delenv('SFM_MFMA_NARROW')
       # (the hot-list / candidate overflow fall-backs sweep surfaces with pruned,
       # never stored tiles: 'smooth' and 'fine' take them at threshold 0.2.  The
       # lattice of 'fine' has many peaks of nearly equal height, which the float
