@@ -77,6 +77,8 @@ int sfm_device_count(int* count);
  *   SFM_MFMA_NARROW=n     lazy path: widest in-flight narrowing of a row loop (outer column
  *                         tiles dropped once proved cold; default: down to the four
  *                         central tiles; 0: never)
+ *   SFM_MFMA_TOUCH_ALL=1  lazy path: pull a patch's whole correction table into L2 ahead of
+ *                         the epilogues (default: the rows of the requested tiles only)
  *   SFM_MFMA_WIDEN=1      lazy path: the store requests a patch starts with are widened
  *                         by one row tile (fewer recomputed tiles, more finished ones)
  *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry

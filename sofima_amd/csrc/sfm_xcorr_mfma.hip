@@ -238,6 +238,7 @@ struct MfmaArgs {
   // over tile p widened by `guard` rows (prep output; see the tile loop)
   float* tbound;      // [batch, kBoundStride]; the last two entries: outer column tiles
   int prune;
+  int touch_all;      // lazy modes: pull the whole correction table into L2, not only the requested tiles' rows (SFM_MFMA_TOUCH_ALL=1)
   int narrow;         // lazy modes: row loops drop provably cold outer column tiles in flight (SFM_MFMA_NARROW=0: off)
   int widen;          // initial store requests: the previous need mask, widened by a tile (SFM_MFMA_WIDEN=1)
   int early;          // lazy modes: abandon provably cold tiles inside the row loop (least distance of two tests, row groups; 0 = off)
@@ -2318,10 +2319,22 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       // the patch loop as 16 VGPRs and spilled
       unsigned lane_off;
       asm volatile("v_lshlrev_b32 %0, 6, %1" : "=v"(lane_off) : "v"(threadIdx.x));
+      // Lazy modes: the epilogue runs on the few tiles that may be hot or are asked
+      // for, so only the table rows of the tiles requested at this point are pulled
+      // (row yv serves the shifts dy = yv and dy = yv - Py: two row tiles); a tile
+      // that turns out hot without having been predicted takes its L2 misses.
+      const int req_now = LAZY ? *const_cast<volatile int*>(&lz[0]) : -1;
 #pragma unroll
       for (int k = 0; k < kTouches; ++k) {
         const int i = (threadIdx.x + k * kThreads) * 16;
-        if (i < Py * Px) {
+        bool wanted = i < Py * Px;
+        if (LAZY && a.prune && !a.touch_all) {
+          const int yv = min(i / Px, Py - 1), yv2 = min((i + 15) / Px, Py - 1);   // (a line may straddle two rows)
+          const unsigned t_mask = (1u << ((yv + Py - 1) >> 4)) | (1u << (max(yv - 1, 0) >> 4)) |
+                                  (1u << ((yv2 + Py - 1) >> 4)) | (1u << (max(yv2 - 1, 0) >> 4));
+          wanted = wanted && (t_mask & static_cast<unsigned>(req_now)) != 0;
+        }
+        if (wanted) {
           const char* src = gt + (size_t)k * kThreads * 64 + lane_off;
           unsigned saved_m0;  // M0 is the LDS base of the load; put it back
           asm volatile(
@@ -3726,6 +3739,8 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
       // warped pair: 12.29 ms per launch without, 12.54 ms with the widening.)
       const char* wd = sfm::option("SFM_MFMA_WIDEN");
       a.widen = wd ? std::atoi(wd) : 0;
+      const char* ta = sfm::option("SFM_MFMA_TOUCH_ALL");
+      a.touch_all = ta && ta[0] == '1';
       const char* nw = sfm::option("SFM_MFMA_NARROW");
       a.narrow = nw ? std::atoi(nw) : 64;   // widest narrowing allowed (0: off)
       if (a.early < 0 || a.P[0] > kEarlyRows) a.early = 0;
