@@ -2056,6 +2056,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   // row loop (0: none beyond the a-priori ones)
   int* lz_cq = lz_prev + 1;
   int* lz_ks = lz_cq + 4;
+  // lz_rows[p]: first | last << 8 row (0 .. 15) of tile p with a possibly hot element
+  int* lz_rows = lz_ks + 32;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -2185,8 +2187,10 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         const int pt = *best_lds >> 8, gt = (a.guard + 15) >> 4;
         const int lo_t = max(pt - gt, 0), hi_t = min(pt + gt, a.n_order - 1);
         const int pv = *lz_prev;   // (widened by a tile: a store costs less than a recomputation)
-        lz[0] = static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u)) | pv |
-                (a.widen ? (pv << 1) | (pv >> 1) : 0);
+        // (the band of the peak tile only while there is no previous need mask: the
+        // mask counts the guard band in rows and is usually a tile narrower)
+        lz[0] = (pv && !a.widen ? 0 : static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u))) |
+                pv | (a.widen ? (pv << 1) | (pv >> 1) : 0);
         lz[1] = lz[2] = lz[3] = 0;
         if (lz_cq[1] >= lz_cq[0]) {   // (the previous patch had hot elements)
           lz_cq[2] = lz_cq[0];
@@ -2376,11 +2380,14 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // are recomputed -- every wave forms the same set and claims its share.
         const float thr_f = a.threshold_rel * __int_as_float(*const_cast<volatile int*>(pmax_lds));
         const int done = *const_cast<volatile int*>(&lz[1]);
-        const int gt = (a.guard + 15) >> 4;
         int need = 0;
         for (int t = 0; t < a.n_order; ++t)
           if (((done >> t) & 1) && lz_tmax[t] > thr_f) {
-            const int lo_t = max(t - gt, 0), hi_t = min(t + gt, a.n_order - 1);
+            // (the guard band is counted in rows from the tile's hot rows: 10 rows
+            // reach both neighbouring tiles from a quarter of the positions only)
+            const int rr = lz_rows[t];
+            const int lo_t = max(16 * t + (rr & 255) - a.guard, 0) >> 4;
+            const int hi_t = min((16 * t + (rr >> 8) + a.guard) >> 4, a.n_order - 1);
             need |= static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u));
           }
         if (lane == 0) *lz_prev = need;   // (every wave writes the same value)
@@ -3233,9 +3240,28 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           // tile of the band that had finished before is dealt with at the end of
           // the patch, against the FINAL maximum (redo phase above).
           const bool hot = tmax > thr_t;
-          const int gt = (a.guard + 15) >> 4;
-          const int lo_t = max(p - gt, 0), hi_t = min(p + gt, a.n_order - 1);
-          const int nbmask = static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u));
+          int nbmask = 0;
+          if (hot) {
+            // rows of the tile that hold a possibly hot element -> the tiles within
+            // `guard` rows of them
+            unsigned rowmask = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float vm = __int_as_float(acc[0][r]);
+#pragma unroll
+              for (int q = 1; q < NQ; ++q) vm = fmaxf(vm, __int_as_float(acc[q][r]));
+              const unsigned long long bal = __ballot(vm > thr_t);
+#pragma unroll
+              for (int gg = 0; gg < 4; ++gg)
+                if ((bal >> (16 * gg)) & 0xffffull) rowmask |= 1u << (4 * gg + r);
+            }
+            const int r_lo = __builtin_ctz(rowmask | 0x10000u);
+            const int r_hi = 31 - __builtin_clz(rowmask | 1u);
+            const int lo_t = max(16 * p + r_lo - a.guard, 0) >> 4;
+            const int hi_t = min((16 * p + r_hi + a.guard) >> 4, a.n_order - 1);
+            nbmask = static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u)) | (1 << p);
+            if (lane == 0) lz_rows[p] = r_lo | (r_hi << 8);
+          }
           int req = 0;
           if (lane == 0) {
             if (hot) atomicOr(&lz[0], nbmask);   // later tiles of the band store right away
@@ -3774,7 +3800,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
                        prep_lds, st, a);
   }
   SFM_LAUNCH_CHECK();
-  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 48 + 128 + 160;
+  const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 48 + 128 + 160 + 128;
   const int grid = d->batch;  // capped to the resident workgroups in launch_one
   const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
   // lazy surface stores: the flow path only (fused peak search: nobody else
