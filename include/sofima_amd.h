@@ -73,7 +73,7 @@ int sfm_device_count(int* count);
  *                         only the tiles the peak kernels can read)
  *   SFM_MFMA_EARLY=n      lazy path: least number of row groups between two tests that
  *                         abandon a provably cold tile inside its row loop, or narrow
- *                         it (default 2; each test schedules the next; 0: no tests)
+ *                         it (default 1; each test schedules the next; 0: no tests)
  *   SFM_MFMA_NARROW=n     lazy path: widest in-flight narrowing of a row loop (outer column
  *                         tiles dropped once proved cold; default: down to the four
  *                         central tiles; 0: never)

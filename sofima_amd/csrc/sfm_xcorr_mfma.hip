@@ -1964,6 +1964,21 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// The same for non-negative integers (six DPP steps on the VALU; the shuffle
+// form of the reduction is six dependent LDS round trips, next to the matrix
+// loops' fragment reads).
+#define SFM_DPP_MAXI(x, ctrl, rmask, bc) \
+  max(x, __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, bc))
+__device__ __forceinline__ int wave_max_nonneg_i(int v) {
+  v = SFM_DPP_MAXI(v, 0x111, 0xf, true);   // row_shr:1
+  v = SFM_DPP_MAXI(v, 0x112, 0xf, true);   // row_shr:2
+  v = SFM_DPP_MAXI(v, 0x114, 0xf, true);   // row_shr:4
+  v = SFM_DPP_MAXI(v, 0x118, 0xf, true);   // row_shr:8
+  v = SFM_DPP_MAXI(v, 0x142, 0xa, false);  // row_bcast:15
+  v = SFM_DPP_MAXI(v, 0x143, 0xc, false);  // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // base[byte_off]: a 32-bit byte offset on a wave-uniform base selects the
 // scalar-base + VGPR-offset addressing mode (no 64-bit VALU address math).
 __device__ __forceinline__ float at_byte(const float* base, unsigned byte_off) {
@@ -2627,9 +2642,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                 if (kCand[i] == j) m_k[i] = run;   // tiles q <= K and q >= NQ - 1 - K
             }
           }
-          int ms = run;
-#pragma unroll
-          for (int d = 32; d > 0; d >>= 1) ms = max(ms, __shfl_xor(ms, d, 64));
+          const int ms = wave_max_nonneg_i(run);
           const unsigned* rp = reinterpret_cast<const unsigned*>(tb_lds + kRowPre);
           const int a_lo = max(0, y + dy0), a_hi = min(Py, yhi + dy0 + 15);
           const unsigned ea = rp[(a_hi + 3) >> 2] - rp[a_lo >> 2];
@@ -2664,9 +2677,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
               if (i < 4 && kCand[i] == kCand[i + 1]) continue;
               if (kCand[i] <= 0 || 2 * kCand[i] + 2 > NQ) continue;
               if (!open || kCand[i] <= ks_now || kCand[i] > kmax_pred) continue;   // (wave-uniform)
-              int mo = m_k[i];
-#pragma unroll
-              for (int d = 32; d > 0; d >>= 1) mo = max(mo, __shfl_xor(mo, d, 64));
+              const int mo = wave_max_nonneg_i(m_k[i]);
               const float ubk = (__int2float_ru(mo) + rest + corr) * 1.000002f + 2.f;
               if (ubk < thr_now) {
                 ks_new = kCand[i];
@@ -2881,13 +2892,12 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // per lane) has nothing to deliver.  Asked for later after all, it is
         // recomputed like any band tile that finished un-stored.
         if (a.prune && !forced) {
-          int ms = acc[0][0];
+          int ms = 0;   // (max(S, 0): a bound of max S all the same)
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ms = max(ms, acc[q][r]);
-#pragma unroll
-          for (int d = 32; d > 0; d >>= 1) ms = max(ms, __shfl_xor(ms, d, 64));
+          ms = wave_max_nonneg_i(ms);
           const float ub = __int2float_ru(ms) + tb_lds[kBoundCorr];
           const float mrun = __int_as_float(__builtin_amdgcn_readfirstlane(
               *const_cast<volatile int*>(pmax_lds)));
@@ -3756,7 +3766,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
       // least number of row groups between two tests inside the row loop of the
       // lazy modes ("0": no tests); each test schedules the next, see check_after
       const char* e = sfm::option("SFM_MFMA_EARLY");
-      a.early = e ? std::atoi(e) : 2;
+      a.early = e ? std::atoi(e) : 1;
       // initial store requests of a patch: what the previous patch of the workgroup
       // needed, "1": widened by a row tile on either side.  (Before the in-loop test
       // a spare request cost a store and saved a recomputation when the peak moved
