@@ -2835,7 +2835,14 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         TICK(10)   // (timing build) tile draw, pruning tests, setup
         // ascending and straight-line: a tile only ever moves to a narrower variant
         // (a loop around one dispatch made the register allocator spill 255 VGPRs)
-        if (col_skip == 0 || (kKs1 == 0 && col_skip == kKs1)) rows(std::integral_constant<int, 0>{});
+        // (the test before the first row group runs here: a tile it abandons never
+        // loads the loop's first fragments)
+        if (LAZY && chk_early && yhi - ylo > 8) {
+          y_checked = ylo;
+          if (check_after(ylo, col_skip) < 0) abandoned = true;
+        }
+        if (!abandoned && (col_skip == 0 || (kKs1 == 0 && col_skip == kKs1)))
+          rows(std::integral_constant<int, 0>{});
         if (kKs1 > 0 && col_skip == kKs1 && !abandoned && yb0 < yhi)
           rows(std::integral_constant<int, kKs1>{});
         if (kKs2 > kKs1 && col_skip == kKs2 && !abandoned && yb0 < yhi)
