@@ -1979,6 +1979,19 @@ __device__ __forceinline__ int wave_max_nonneg_i(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Bitwise OR over the wave, the same way.
+#define SFM_DPP_OR(x, ctrl, rmask, bc) \
+  ((x) | __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, bc))
+__device__ __forceinline__ int wave_or(int v) {
+  v = SFM_DPP_OR(v, 0x111, 0xf, true);   // row_shr:1
+  v = SFM_DPP_OR(v, 0x112, 0xf, true);   // row_shr:2
+  v = SFM_DPP_OR(v, 0x114, 0xf, true);   // row_shr:4
+  v = SFM_DPP_OR(v, 0x118, 0xf, true);   // row_shr:8
+  v = SFM_DPP_OR(v, 0x142, 0xa, false);  // row_bcast:15
+  v = SFM_DPP_OR(v, 0x143, 0xc, false);  // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // base[byte_off]: a 32-bit byte offset on a wave-uniform base selects the
 // scalar-base + VGPR-offset addressing mode (no 64-bit VALU address math).
 __device__ __forceinline__ float at_byte(const float* base, unsigned byte_off) {
@@ -2395,31 +2408,30 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // are recomputed -- every wave forms the same set and claims its share.
         const float thr_f = a.threshold_rel * __int_as_float(*const_cast<volatile int*>(pmax_lds));
         const int done = *const_cast<volatile int*>(&lz[1]);
-        int need = 0;
-        for (int t = 0; t < a.n_order; ++t)
-          if (((done >> t) & 1) && lz_tmax[t] > thr_f) {
-            // (the guard band is counted in rows from the tile's hot rows: 10 rows
-            // reach both neighbouring tiles from a quarter of the positions only)
-            const int rr = lz_rows[t];
-            const int lo_t = max(16 * t + (rr & 255) - a.guard, 0) >> 4;
-            const int hi_t = min((16 * t + (rr >> 8) + a.guard) >> 4, a.n_order - 1);
-            need |= static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u));
-          }
+        // (one tile per lane: as loops over the tiles these were forty dependent LDS
+        // round trips per wave and patch, under the fragment traffic of the other
+        // workgroup's matrix loops)
+        const int t_l = min(lane, 30);
+        const bool mine = lane < a.n_order && ((done >> lane) & 1);
+        const float tm_l = lz_tmax[t_l];
+        const int rr_l = lz_rows[t_l], ks_l = lz_ks[t_l];
+        const int hq_lo = *const_cast<volatile int*>(&lz_cq[0]);
+        const int hq_hi = *const_cast<volatile int*>(&lz_cq[1]);
+        int mask_l = 0;
+        if (mine && tm_l > thr_f) {
+          // (the guard band is counted in rows from the tile's hot rows: 10 rows
+          // reach both neighbouring tiles from a quarter of the positions only)
+          const int lo_t = max(16 * t_l + (rr_l & 255) - a.guard, 0) >> 4;
+          const int hi_t = min((16 * t_l + (rr_l >> 8) + a.guard) >> 4, a.n_order - 1);
+          mask_l = static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u));
+        }
+        const int need = wave_or(mask_l);
         if (lane == 0) *lz_prev = need;   // (every wave writes the same value)
         // stored tiles that dropped column tiles in flight and turn out to have a
         // possibly hot column (of any row tile) within a tile of what they dropped:
         // recomputed in full like the band tiles that finished un-stored
-        int bad = 0;
-        {
-          const int hq_lo = *const_cast<volatile int*>(&lz_cq[0]);
-          const int hq_hi = *const_cast<volatile int*>(&lz_cq[1]);
-          if (hq_hi >= hq_lo)
-            for (int t = 0; t < a.n_order; ++t) {
-              const int ks = lz_ks[t];
-              if (((done >> t) & 1) && ks > 0 && (hq_lo < ks + 1 || hq_hi > NQ - 2 - ks))
-                bad |= 1 << t;
-            }
-        }
+        const int bad = static_cast<int>(__ballot(mine && hq_hi >= hq_lo && ks_l > 0 &&
+                                                  (hq_lo < ks_l + 1 || hq_hi > NQ - 2 - ks_l)));
         int todo = need & done & (~*const_cast<volatile int*>(&lz[2]) | bad) &
                    ~*const_cast<volatile int*>(&lz[3]);
         todo = __builtin_amdgcn_readfirstlane(todo);
