@@ -2681,6 +2681,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
             return gap > 0.f ? yhi - static_cast<int>(left * (gap / rest)) : yhi;
           };
           int y_at = requested ? yhi : passes_at(ms);
+          // (before the first row group nothing is known about the columns: the first
+          // row at which anything can pass -- requested tiles are tested for narrowing only)
+          if (y == ylo && kmax_pred > ks_now) y_at = min(y_at, passes_at(0));
           int ks_new = ks_now;
           if (y > ylo && kmax_pred > ks_now) {
             bool open = true;   // widest first: the sets are nested
