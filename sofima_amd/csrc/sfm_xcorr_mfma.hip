@@ -2494,6 +2494,10 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                                                     : 0;
       }
       int col_skip = raw_col_skip;  // outer column tiles (each side) this tile leaves out
+      // (lazy modes) read with the pruning bounds, used by the test in front of the row loop
+      unsigned hd_ea = 0, hd_eb = 0;
+      float hd_corr = 0.f, hd_thr = 0.f;
+      int hd_req = 0, hd_cq = 0;
       if (SAME && a.prune && !forced) {
         // Exact pruning.  Every element of this tile and of the `guard` rows
         // around it is bounded by tb (prep kernel).  If tb < threshold_rel x (the
@@ -2503,10 +2507,28 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // for its values.  It is not stored at all; the overflow fall-backs of the
         // peak kernels, which sweep whole surfaces, get the set of pruned tiles
         // (a.skipmask) and skip / zero them.
-        const float mrun = __int_as_float(__builtin_amdgcn_readfirstlane(
-            *const_cast<volatile int*>(pmax_lds)));
+        // (everything the decisions of this tile read from LDS is requested here, in
+        // one round: under the fragment traffic of eight waves a dependent LDS read
+        // costs several hundred cycles, and the tests below were six of them in a row)
+        const int mrun_bits = *const_cast<volatile int*>(pmax_lds);
+        const float tb_p = tb_lds[p], tb_c0 = tb_lds[kBoundTiles + 0], tb_c1 = tb_lds[kBoundTiles + 1];
+        const float tb_2a = tb_lds[32 + 3 * p + 0], tb_2b = tb_lds[32 + 3 * p + 1];
+        const float tb_2c = tb_lds[32 + 3 * p + 2];
+        if (LAZY) {
+          const int dy0h = 16 * p - (Qy - 1);
+          const int yloh = max(0, -dy0h - 15), yhih = min(Qy, Py - dy0h);
+          const unsigned* rp = reinterpret_cast<const unsigned*>(tb_lds + kRowPre);
+          const int a_lo = max(0, yloh + dy0h), a_hi = min(Py, yhih + dy0h + 15);
+          hd_ea = rp[(a_hi + 3) >> 2] - rp[a_lo >> 2];
+          hd_eb = rp[64 + ((yhih + 3) >> 2)] - rp[64 + (yloh >> 2)];
+          hd_corr = tb_lds[kBoundCorr];
+          hd_req = *const_cast<volatile int*>(&lz[0]);
+          hd_cq = min(lz_cq[2], NQ - 1 - lz_cq[3]);
+        }
+        const float mrun = __int_as_float(__builtin_amdgcn_readfirstlane(mrun_bits));
+        hd_thr = a.threshold_rel * mrun;
         ++tiles_drawn;
-        if (tb_lds[p] < a.threshold_rel * mrun) {
+        if (tb_p < a.threshold_rel * mrun) {
           ++tiles_skipped;
           if (lane == 0) {
             atomicOr(&best_lds[1], 1 << p);
@@ -2518,13 +2540,13 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // the outermost kKs1 / kKs2 tiles on either side, widened by the
         // guard): the row loop below has variants that leave them out.
         const float t = a.threshold_rel * mrun;
-        if (tb_lds[kBoundTiles + 0] < t) col_skip = col_skip_lo(NQ);
-        if (tb_lds[kBoundTiles + 1] < t) col_skip = col_skip_hi(NQ);
+        if (tb_c0 < t) col_skip = col_skip_lo(NQ);
+        if (tb_c1 < t) col_skip = col_skip_hi(NQ);
         // this row tile with fewer columns still (2-D block bounds; each already
         // capped by the 1-D column bound of its variant)
-        if (tb_lds[32 + 3 * p + 0] < t) col_skip = max(col_skip, col_skip_hi(NQ));
-        if (tb_lds[32 + 3 * p + 1] < t) col_skip = max(col_skip, col_skip_2(NQ));
-        if (tb_lds[32 + 3 * p + 2] < t) col_skip = max(col_skip, col_skip_3(NQ));
+        if (tb_2a < t) col_skip = max(col_skip, col_skip_hi(NQ));
+        if (tb_2b < t) col_skip = max(col_skip, col_skip_2(NQ));
+        if (tb_2c < t) col_skip = max(col_skip, col_skip_3(NQ));
         cols_skipped += 2 * col_skip;
         if (col_skip > 0 && lane == 0) best_lds[2] = 1;
       }
@@ -2542,7 +2564,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       // widest narrowing the previous patch's hot column tiles allow (one tile of margin)
       int kmax_pred = 0;
       if (LAZY && chk_early && a.narrow && a.guard_x <= 16)
-        kmax_pred = min(__builtin_amdgcn_readfirstlane(min(lz_cq[2], NQ - 1 - lz_cq[3])) - 1, a.narrow);
+        kmax_pred = min(__builtin_amdgcn_readfirstlane(hd_cq) - 1, a.narrow);
 
       const unsigned char* ap =
           A_lds + (kPadTop + ylo + g + dy0 + n) * a.pa;
@@ -2853,8 +2875,24 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         // (the test before the first row group runs here: a tile it abandons never
         // loads the loop's first fragments)
         if (LAZY && chk_early && yhi - ylo > 8) {
+          // check_after(ylo) on the values read with the pruning bounds: every partial
+          // sum is zero, the bound is the tile's own a-priori bound
           y_checked = ylo;
-          if (check_after(ylo, col_skip) < 0) abandoned = true;
+          const float rest = sqrtf(__uint2float_ru(hd_ea) * __uint2float_ru(hd_eb)) * 1.000002f + 2.f;
+          const float ub = (rest + hd_corr) * 1.000002f + 2.f;
+          const bool requested = (__builtin_amdgcn_readfirstlane(hd_req) >> p) & 1;
+          if (ub < hd_thr && !requested) {
+            if (lane == 0) {
+              lz_tmax[p] = ub;
+              atomicOr(&lz[1], 1 << p);
+            }
+            abandoned = true;
+          } else {
+            const float gap = hd_thr - hd_corr;
+            const int y0_at = gap > 0.f ? yhi - static_cast<int>(static_cast<float>(yhi - ylo) * (gap / rest)) : yhi;
+            const int y_at = (requested && kmax_pred <= col_skip) ? yhi : y0_at;
+            y_next = max(ylo + 4 * a.early, ylo + ((y_at - ylo + 3) & ~3));
+          }
         }
         if (!abandoned && (col_skip == 0 || (kKs1 == 0 && col_skip == kKs1)))
           rows(std::integral_constant<int, 0>{});
