@@ -3370,16 +3370,31 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           if (__any(vm > thr_t)) {  // wave-uniform, rarely taken
             hq_lo = min(hq_lo, q);
             hq_hi = q;
+            // one list reservation per column tile (ballots + one LDS atomic): an
+            // atomic per lane and row was four dependent LDS round trips here
+            unsigned long long bal[4];
+            int total = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              bal[r] = __ballot(__int_as_float(acc[q][r]) > thr_t);
+              total += __builtin_popcountll(bal[r]);
+            }
+            int base = 0;
+            if (lane == 0) base = atomicAdd(hot_lds, total);
+            base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float v = __int_as_float(acc[q][r]);
               if (v > thr_t) {
-                const int slot = atomicAdd(hot_lds, 1);
+                const int slot = base + static_cast<int>(__builtin_amdgcn_mbcnt_hi(
+                                            static_cast<unsigned>(bal[r] >> 32),
+                                            __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(bal[r]), 0u)));
                 if (slot < a.hot_cap) {
                   hv[slot] = v;
                   hi[slot] = (16 * p + 4 * g + r) * Sx + 16 * q + n;
                 }
               }
+              base += __builtin_popcountll(bal[r]);
             }
           }
         }
