@@ -191,6 +191,7 @@ def _side_stream(dev) -> torch.cuda.Stream:
     return _SIDE_STREAMS[key]
 
 
+_FITTED = {}              # (device index, fraction) -> largest workspace that passed the budget check
 WORKSPACE_FRACTION = 0.6  # of the HBM that is free when a call is planned
 SMALL_WORKSPACE = 1 << 30  # calls below this are not checked against the budget
 
@@ -235,9 +236,16 @@ def _run_batches_dev(res: _Resident, desc: _abi.SfmXcorrDesc, starts: torch.Tens
     # when a call wants more than SMALL_WORKSPACE)
     if per_call == 1 or need * n_lanes <= SMALL_WORKSPACE:
       break
+    # (nor when a workspace of at least this size passed the check on this device
+    # before: the production loop asks for the same bytes section after section,
+    # and torch's caching allocator still holds the block)
+    dev_key = (torch.device(res.dev).index, WORKSPACE_FRACTION)
+    if need * n_lanes <= _FITTED.get(dev_key, 0):
+      break
     if budget is None:
       budget = _workspace_budget(res.dev)
     if need * n_lanes <= budget:
+      _FITTED[dev_key] = max(_FITTED.get(dev_key, 0), need * n_lanes)
       break
     per_call = max(1, per_call // 2)
   row_bytes = batch_size * nd * 4
