@@ -124,6 +124,13 @@ def main():
                   help='N > 1: skip the communicating legs (configs[3] section '
                        'chain with the boundary hand-off, one mesh in bands '
                        'across the ranks)')
+  ap.add_argument('--force-multi-gpu-legs', action='store_true',
+                  help='N = 1: run the communicating legs anyway, over an nccl (RCCL) '
+                       'process group of ONE rank, so that the nccl-only branches '
+                       '(device all-gather of the boundary meshes, the library '
+                       'communicator from a broadcast id, the watchdog) execute on a '
+                       'single-GPU box; the banded mesh runs 2 local bands through '
+                       'RCCL self send / recv')
   ap.add_argument('--mesh-sharded', type=int, default=0, metavar='BANDS',
                   help='extra leg: one [2,64,204,204] mesh split into BANDS bands '
                        'per rank, stepped by the C-side banded loop (RCCL halo '
@@ -153,7 +160,17 @@ def main():
   backend = os.environ.get('SFM_BENCH_BACKEND', 'nccl')
   if os.environ.get('SFM_BENCH_ONE_DEVICE'):
     local_rank = 0
-  if world > 1:
+  forced = bool(args.force_multi_gpu_legs) and world == 1
+  if forced:
+    import socket
+    from sofima_amd import dist as _sdist
+    _sdist.FORCE_COLLECTIVES = True
+    if 'MASTER_PORT' not in os.environ:
+      sock = socket.socket()
+      sock.bind(('127.0.0.1', 0))
+      os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
+      sock.close()
+  if world > 1 or forced:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if backend == 'nccl':
       dist.init_process_group('nccl', rank=rank, world_size=world,
@@ -163,7 +180,7 @@ def main():
   if world != args.gpus:
     raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
   ranks_seen = 1
-  if world > 1:
+  if world > 1 or forced:
     if backend == 'nccl':
       # every rank must sit on its own GPU and RCCL must see all of them
       assert torch.cuda.device_count() >= world, (torch.cuda.device_count(), world)
@@ -506,7 +523,7 @@ def main():
   # under a watchdog: the headline numbers above are complete, and a leg that
   # fails or hangs (they are the least-exercised code: single-GPU boxes cannot
   # run them over RCCL) costs its own entry, never the line.
-  if world > 1 and not args.no_multi_gpu_legs:
+  if (world > 1 or forced) and not args.no_multi_gpu_legs:
     import threading
     multi = {
         'backend': 'rccl' if backend == 'nccl' else backend,
@@ -530,7 +547,8 @@ def main():
                                                     args.mesh_iters, pre_t, post_t)),
         ('volumetric_chunks', lambda: volumetric_leg(dev, rank, world, backend, args.seed)),
         ('mesh_sharded', lambda: mesh_sharded_leg(
-            1, dev, rank, world, iters=min(200, max(args.mesh_iters, 20))))):
+            2 if forced else 1, dev, rank, world,
+            iters=min(200, max(args.mesh_iters, 20)), loopback=forced))):
       state['leg'] = name
       dog = threading.Timer(args.multi_gpu_timeout, bail)
       dog.daemon = True
@@ -555,7 +573,7 @@ def main():
         break
   if rank == 0:
     print(json.dumps(out), flush=True)
-  if world > 1:
+  if world > 1 or forced:
     try:
       dist.destroy_process_group()
     except Exception:   # pylint: disable=broad-except
@@ -927,7 +945,7 @@ def volumetric_leg(dev, rank, world, backend, seed, chunks_per_rank=1):
   }
 
 
-def mesh_sharded_leg(bands_per_rank, dev, rank, world, iters=200):
+def mesh_sharded_leg(bands_per_rank, dev, rank, world, iters=200, loopback=False):
   """ONE [2, 64, 204, 204] mesh (the configs[2] montage size) split into
   world x bands_per_rank bands of rows; the whole chunk of steps runs inside
   sfm_mesh_relax_banded (halo rows between ranks through sfm_comm_* = RCCL,
@@ -955,10 +973,14 @@ def mesh_sharded_leg(bands_per_rank, dev, rank, world, iters=200):
   mesh.relax_mesh(x0, prev, cfg)
   torch.cuda.synchronize(dev)
   out['unsplit_us_per_step'] = round((time.perf_counter() - t0) / iters * 1e6, 2)
-  sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=bands_per_rank)  # warm-up
+  sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=bands_per_rank,
+                          loopback=loopback)  # warm-up
   torch.cuda.synchronize(dev)
   tm = {}
-  sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=bands_per_rank, timing=tm)
+  sdist.relax_mesh_banded(x0, prev, cfg, bands_per_rank=bands_per_rank, timing=tm,
+                          loopback=loopback)
+  if loopback:
+    out['transport'] = 'RCCL self send / recv between the local bands (loop-back)'
   spent = tm['banded_chunk_s']
   if world > 1:                      # max over ranks, like every other time here
     t = torch.tensor([spent], dtype=torch.float64,

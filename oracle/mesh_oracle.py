@@ -128,10 +128,15 @@ def _total_force(x, prev, cap, cfg, mesh_force, prev_fn):
 
 
 def velocity_verlet(x, v, prev, cfg, force_cap, fire_dt=None, fire_alpha=None,
-                    mesh_force=inplane_force, prev_fn=None):
+                    mesh_force=inplane_force, prev_fn=None, snapshots=None,
+                    snapshot_every=0):
   """cfg.num_iters damped-VV or FIRE steps.
 
   Returns (x, v, a) or, with FIRE, (x, v, a, dt, alpha, n_pos, cap).
+  `snapshots` (a list, FIRE only; test instrumentation, not in the reference):
+  receives (step, x, dt, alpha, n_pos, cap) after every `snapshot_every` steps,
+  so that a test can follow ONE long chunk without cutting it (a cut would
+  restart n_pos, mesh.py:448).
   """
   x = np.array(x, f32)
   v = np.array(v, f32)
@@ -155,7 +160,9 @@ def velocity_verlet(x, v, prev, cfg, force_cap, fire_dt=None, fire_alpha=None,
   alpha = f32(cfg.alpha if fire_alpha is None else fire_alpha)
   n_pos = 0
   dt_cap = f32(float(cfg.dt_max) * float(cfg.dt))
-  for _ in range(cfg.num_iters):
+  for step in range(cfg.num_iters):
+    if snapshots is not None and step and step % snapshot_every == 0:
+      snapshots.append((step, x.copy(), f32(dt), f32(alpha), n_pos, f32(cap)))
     x, v, a = vv(x, v, a, dt, cap)
     a_n = np.sqrt(np.sum(np.square(a), axis=0, keepdims=True)) + f32(1e-6)
     v_n = np.sqrt(np.sum(np.square(v), axis=0, keepdims=True))

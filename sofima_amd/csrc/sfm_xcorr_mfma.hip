@@ -3577,12 +3577,24 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
             &n, reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE, MODE>), kThreads,
             lds) != hipSuccess || n < 1)
       n = lds * 2 <= 160 * 1024 ? 2 : 1;
-    const char* cap = sfm::option("SFM_MFMA_MAX_WG_PER_CU");
-    if (cap && std::atoi(cap) > 0) n = std::min(n, std::atoi(cap));
     per_cu = n;
     per_cu_lds = lds;
   }
-  grid = std::min(grid, device_cus() * per_cu);
+  int wg_per_cu = per_cu;
+  {
+    // (a measurement switch; read per call so that a test can flip it)
+    const char* cap = sfm::option("SFM_MFMA_MAX_WG_PER_CU");
+    if (cap && std::atoi(cap) > 0) wg_per_cu = std::min(wg_per_cu, std::atoi(cap));
+  }
+  grid = std::min(grid, device_cus() * wg_per_cu);
+  {
+    // SFM_MFMA_GRID=n (tests): at most n workgroups, so that a small batch runs
+    // MANY patches through one workgroup -- the state a workgroup carries from
+    // patch to patch (previous need mask / hot columns / seed block, the probe's
+    // self-switch-off) is otherwise only exercised by full-size fields.
+    const char* g = sfm::option("SFM_MFMA_GRID");
+    if (g && std::atoi(g) > 0) grid = std::min(grid, std::atoi(g));
+  }
   sfm::prof_begin(sfm::kProfXcorr, st);
   hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, MODE>), dim3(grid),
                      dim3(kThreads), lds, st, a);

@@ -19,6 +19,20 @@ import numpy as np
 import torch.distributed as dist
 
 
+# True: a process group of ONE rank still goes through its collectives (RCCL
+# accepts a world of one): the nccl-only branches -- `gather_boundaries` on
+# device tensors, the library communicator bootstrapped from a broadcast id --
+# then execute on a single-GPU box (`bench.py --force-multi-gpu-legs`, tests).
+import os as _os
+FORCE_COLLECTIVES = _os.environ.get('SFM_FORCE_COLLECTIVES') == '1'
+
+
+def _alone(ws: int) -> bool:
+  """No collective needed: one rank, unless collectives are forced."""
+  return ws == 1 and not (FORCE_COLLECTIVES and dist.is_available() and
+                          dist.is_initialized())
+
+
 def world(group=None) -> tuple[int, int]:
   if dist.is_available() and dist.is_initialized():
     return dist.get_rank(group), dist.get_world_size(group)
@@ -32,7 +46,7 @@ def shard_units(n_units: int, rank: int, world_size: int) -> list[int]:
 
 def gather_objects(obj, group=None) -> list:
   rank, ws = world(group)
-  if ws == 1:
+  if _alone(ws):
     return [obj]
   out = [None] * ws
   dist.all_gather_object(out, obj, group=group)
@@ -296,7 +310,7 @@ class RcclComm:
       buf = C.create_string_buffer(_abi.COMM_ID_BYTES)
       _abi.check(self.lib.sfm_comm_unique_id(buf))
       ident = [bytes(buf.raw)]
-    if self.world > 1:
+    if not _alone(self.world):
       dist.broadcast_object_list(ident, src=0, group=group)
     handle = C.c_void_p()
     _abi.check(self.lib.sfm_comm_init(C.byref(handle), ident[0], self.rank,
@@ -344,7 +358,12 @@ class HostStagedTransport:
   torch.distributed group that moves HOST tensors (gloo): the library stages
   the packed edge rows and the bands' partial sums through host memory and
   calls back here, so the inter-rank branch of `sfm_mesh_relax_banded` runs
-  where RCCL cannot connect the ranks (two processes sharing one GPU)."""
+  where RCCL cannot connect the ranks (two processes sharing one GPU).
+
+  A callback that raises records the exception in `.error` and makes the C loop
+  return an error on THIS rank only; the neighbours stay in their recv /
+  all-gather until the process group's timeout fires, so create the group with
+  a finite `timeout=` (torch.distributed.new_group / init_process_group)."""
 
   def __init__(self, group=None):
     from . import _abi
@@ -366,8 +385,10 @@ class HostStagedTransport:
       for peer, snd, rcv in ((peer_lo, send_lo, recv_lo), (peer_hi, send_hi, recv_hi)):
         if peer < 0:
           continue
-        ops += [dist.P2POp(dist.isend, self._tensor(snd, count), peer, self.group),
-                dist.P2POp(dist.irecv, self._tensor(rcv, count), peer, self.group)]
+        # the library hands over GROUP ranks; P2POp takes global ranks
+        gpeer = peer if self.group is None else dist.get_global_rank(self.group, peer)
+        ops += [dist.P2POp(dist.isend, self._tensor(snd, count), gpeer, self.group),
+                dist.P2POp(dist.irecv, self._tensor(rcv, count), gpeer, self.group)]
       for req in dist.batch_isend_irecv(ops):
         req.wait()
       self.calls['halo'] += 1
@@ -546,7 +567,7 @@ def relax_mesh_banded(x, prev, config, mesh_force=None, group=None,
       raise ValueError('the host-staged transport takes no RCCL communicator')
     if ws > 1:
       host = HostStagedTransport(group)
-  elif comm is None and (ws > 1 or loopback):
+  elif comm is None and (ws > 1 or loopback or not _alone(ws)):
     comm = own_comm = RcclComm(group)
   n_local = int(bands_per_rank)
   n_bands = ws * n_local
@@ -677,14 +698,18 @@ def solve_section_block(flow, config, stride, relax_fn=None, compose_fn=None,
   return (out, solved[-1]) if with_last else out
 
 
-def gather_boundaries(last_local: list, n_blocks: int, group=None) -> np.ndarray:
+def gather_boundaries(last_local: list, n_blocks: int, group=None,
+                      mesh_shape=None) -> np.ndarray:
   """The mesh-boundary hand-off of the block chain as ONE tensor all-gather.
 
   last_local: the last solved mesh [2, 1, y, x] of each of THIS rank's blocks
   (round-robin deal), DeviceArrays / device tensors on the HIP path.  On an nccl
   (= RCCL) group the meshes travel GPU to GPU over xGMI without touching the
   host; on a gloo group as host tensors.  Returns [2, n_blocks, y, x] (host),
-  identical on every rank.
+  identical on every rank.  A rank without a block (n_blocks < world size)
+  takes part with a zero-filled buffer: it needs `mesh_shape` = the shape
+  [2, 1, y, x] of one boundary mesh; without it EVERY rank raises (decided from
+  (n_blocks, world size) alone, so nobody is left alone in the collective).
   """
   import torch
   rank, ws = world(group)
@@ -694,18 +719,21 @@ def gather_boundaries(last_local: list, n_blocks: int, group=None) -> np.ndarray
     if not isinstance(t, torch.Tensor):
       t = torch.from_numpy(np.ascontiguousarray(np.asarray(t, dtype=np.float32)))
     tensors.append(t.to(torch.float32))
-  if ws == 1:
+  if _alone(ws):
     return np.concatenate([t.cpu().numpy() for t in tensors], axis=1)
-  if not tensors:
-    raise ValueError(f'rank {rank} holds no block: {n_blocks} blocks for {ws} ranks '
-                     '(every rank needs at least one)')
+  if n_blocks < ws and mesh_shape is None:
+    raise ValueError(f'{n_blocks} blocks for {ws} ranks: ranks without a block need '
+                     '`mesh_shape` to take part in the hand-off')
   on_gpu = dist.get_backend(group) == 'nccl'
   per = -(-n_blocks // ws)                      # blocks per rank, padded
-  ref = tensors[0]
-  if on_gpu and not ref.is_cuda:
-    ref = ref.cuda()
-  send = torch.zeros((per,) + tuple(ref.shape), dtype=torch.float32,
-                     device=ref.device if on_gpu else 'cpu')
+  if tensors:
+    shape, device = tuple(tensors[0].shape), tensors[0].device
+  else:
+    shape, device = tuple(int(v) for v in mesh_shape), torch.device('cpu')
+  if on_gpu and device.type != 'cuda':
+    device = torch.device('cuda', torch.cuda.current_device())
+  send = torch.zeros((per,) + shape, dtype=torch.float32,
+                     device=device if on_gpu else 'cpu')
   for k, t in enumerate(tensors):
     send[k].copy_(t)                            # device to device on the HIP path
   parts = [torch.empty_like(send) for _ in range(ws)]
@@ -760,7 +788,8 @@ def align_sections_blocked(flow, config, stride, n_blocks=None, group=None,
     sync()
   t1 = time.perf_counter()
   # mesh-boundary exchange: last solved section of every block, to every rank
-  last = gather_boundaries(last_local, n_blocks, group)
+  last = gather_boundaries(last_local, n_blocks, group,
+                           mesh_shape=(flow.shape[0], 1) + tuple(flow.shape[2:]))
   t2 = time.perf_counter()
   # cross-block mesh: every block is a virtual section (notebook cell 47); it
   # is tiny, so every rank solves it redundantly instead of broadcasting it

@@ -254,9 +254,22 @@ def _run_batches_dev(res: _Resident, desc: _abi.SfmXcorrDesc, starts: torch.Tens
   # (each with its own workspace): the hardware then fills the tail of one
   # call's correlation kernel -- workgroups retiring one by one -- with the
   # prep kernel and the first workgroups of the next call.
-  n_calls = (n_batches + per_call - 1) // per_call
   main = torch.cuda.current_stream(res.dev)
-  lanes = [(main, _dev.workspace(need, res.dev))]
+  while True:
+    try:
+      lanes = [(main, _dev.workspace(need, res.dev))]
+      break
+    except torch.OutOfMemoryError:
+      # a size that passed the budget earlier (_FITTED) no longer fits: memory
+      # pressure grew or the cached block was released.  Forget it and go on
+      # with smaller calls -- the field is the same.
+      _FITTED.pop((torch.device(res.dev).index, WORKSPACE_FRACTION), None)
+      if per_call == 1:
+        raise
+      per_call = max(1, per_call // 2)
+      desc.batch = per_call * batch_size
+      need = lib.sfm_xcorr_workspace_bytes(C.byref(desc))
+  n_calls = (n_batches + per_call - 1) // per_call
   if n_calls > 1 and OVERLAP_CALLS:
     side = _side_stream(res.dev)
     side.wait_stream(main)
@@ -659,10 +672,19 @@ class JAXMaskedXCorrWithStatsCalculator:
         keep = keep and not (np.float64(count) / float(np.prod(psz)) >= max_masked)
       n = 1 if keep else 0
       total = int(batch_size) if keep else 0
+      starts = None
+      if keep:
+        # post start 0; pre start = clip(0 - (patch - post_patch) // 2, 0, inf)
+        # (flow_field.py:601-602, :621-622): +|offset| when the post patch is
+        # the larger one, floor division like NumPy's
+        starts = torch.zeros((2, total, nd), dtype=torch.int32, device=dev)
+        pre0 = [max(0, -((int(p) - int(q)) // 2))
+                for p, q in zip(patch_size, post_patch_size)]
+        if any(pre0):
+          starts[0] = torch.tensor(pre0, dtype=torch.int32, device=dev)
       return dict(out_shape=out_shape, n=n, n_batches=n,
                   positions=torch.zeros((total, nd), dtype=torch.int32, device=dev),
-                  starts=(torch.zeros((2, total, nd), dtype=torch.int32, device=dev)
-                          if keep else None), tg=None, po=None)
+                  starts=starts, tg=None, po=None)
     if selection_mask is None:
       sel = torch.ones(out_shape, dtype=torch.bool, device=dev)
     else:

@@ -229,6 +229,20 @@ def _band_worker(rank, world_size, port, out_dir):
       compose_fn=maps_oracle.compose_maps_fast)
   np.savez(os.path.join(out_dir, f'chain_{rank}.npz'), last=last, xblk=xblk,
            **{f'block{b}': v for b, v in blocks.items()})
+  # fewer blocks than ranks: rank 1 holds no block and must still take part in
+  # the hand-off (a lopsided raise would leave rank 0 in all_gather)
+  blocks1, last1, xblk1 = sdist.align_sections_blocked(
+      flow, cfg, 10.0, n_blocks=1, relax_fn=mesh_oracle.relax_mesh,
+      compose_fn=maps_oracle.compose_maps_fast)
+  np.savez(os.path.join(out_dir, f'chain1_{rank}.npz'), last=last1, xblk=xblk1,
+           n_mine=len(blocks1))
+  # and without a mesh shape EVERY rank raises before the collective
+  try:
+    sdist.gather_boundaries([last1[:, :1]] if rank == 0 else [], 1)
+    raised = False
+  except ValueError:
+    raised = True
+  np.save(os.path.join(out_dir, f'raised_{rank}.npy'), np.array(raised))
   dist.barrier()
   dist.destroy_process_group()
 
@@ -291,6 +305,24 @@ def test_block_chain_matches_single_process(tmp_path):
   for b in range(3):
     np.testing.assert_array_equal(seen[b], blocks[b])
     np.testing.assert_array_equal(seen[b][:, -1], last[:, b])
+
+
+def test_block_chain_with_fewer_blocks_than_ranks(tmp_path):
+  from oracle import maps_oracle, mesh_oracle
+  from sofima_amd import dist as sdist
+  if not (tmp_path / 'chain1_0.npz').exists():
+    port = _free_port()
+    mp.spawn(_band_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  flow, cfg = _chain_case()
+  _, last, xblk = sdist.align_sections_blocked(
+      flow, cfg, 10.0, n_blocks=1, relax_fn=mesh_oracle.relax_mesh,
+      compose_fn=maps_oracle.compose_maps_fast)
+  g = [np.load(tmp_path / f'chain1_{r}.npz') for r in range(2)]
+  assert [int(v['n_mine']) for v in g] == [1, 0]
+  for v in g:
+    np.testing.assert_array_equal(v['last'], last)
+    np.testing.assert_array_equal(v['xblk'], xblk)
+  assert all(bool(np.load(tmp_path / f'raised_{r}.npy')) for r in range(2))
 
 
 def test_band_bounds_and_block_ranges():

@@ -303,6 +303,43 @@ def test_bench_runs_as_two_ranks(gpu):
   assert 'host-staged' in band['transport']
 
 
+def test_bench_multi_gpu_legs_over_rccl_at_world_size_one(gpu):
+  """First contact with RCCL before an 8-GPU box: `bench.py --gpus 1
+  --force-multi-gpu-legs` runs every communicating leg over an nccl process
+  group of ONE rank -- the device all-gather of the boundary meshes
+  (`dist.gather_boundaries` on an nccl group), the library communicator
+  bootstrapped from a broadcast unique id, RCCL send / recv + all-gather inside
+  sfm_mesh_relax_banded (two local bands, loop-back), the all-reduces and the
+  watchdog -- and prints the `multi_gpu` object."""
+  import json
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ)
+  env.pop('SFM_BENCH_BACKEND', None)
+  cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--size', '1024',
+         '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--mesh-iters', '100',
+         '--sustain', '0', '--no-legs', '--force-multi-gpu-legs']
+  out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, out.stdout[-2000:]
+  line = json.loads(lines[0])
+  mg = line['multi_gpu']
+  assert mg['backend'] == 'rccl' and mg['rccl_ranks'] == 1, mg
+  for leg in ('section_chain', 'volumetric_chunks', 'mesh_sharded'):
+    assert 'error' not in mg[leg], (leg, mg[leg])
+  chain = mg['section_chain']
+  assert chain['sections'] == 8 and chain['blocks'] == 1
+  assert 'RCCL' in chain['handoff'] and chain['handoff_only_us'] > 0
+  assert chain['finite_fraction'] > 0.9
+  assert mg['volumetric_chunks']['tile_pairs'] == 4
+  band = mg['mesh_sharded']
+  assert band['bands_per_rank'] == 2 and 'RCCL' in band['transport']
+  assert band['banded_us_per_step'] > 0
+
+
 def _two_rank_band_worker(rank, world_size, port, out_dir):
   import os
   import torch

@@ -289,6 +289,28 @@ def test_flow_field_empty_selection_and_single_patch(gpu):
   np.testing.assert_array_equal(f[:2, 0, 0], [0, 0])
 
 
+@pytest.mark.parametrize('patch,post_patch', [((80, 80), (160, 160)), ((81, 64), (160, 150)),
+                                              ((160, 160), (80, 96))])
+def test_single_cell_grid_with_unequal_patch_sizes_vs_oracle(gpu, patch, post_patch):
+  """ONE grid cell (the call pattern of whole-overlap correlations) with a post
+  patch larger / smaller than the pre patch: the pre start is clip(0 - (patch -
+  post_patch) // 2, 0) (flow_field.py:601-602, :621-622) -- +40 for 80 vs 160 --
+  on the single-patch fast path of device_plan as on the general one."""
+  from sofima_amd import flow_field
+  pre, post = _em_pair(17, 170, 180, shift=(2, -3))
+  post = post[:post_patch[0] + 5, :post_patch[1] + 7].copy()
+  kw = dict(patch_size=patch, step=(400, 400), post_patch_size=post_patch, batch_size=4)
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  got = calc.flow_field(pre, post, **kw)
+  assert got.shape == (4, 1, 1)
+  want = flow_oracle.flow_field(pre, post, **kw)
+  check_flow(got, want)
+  assert np.isfinite(want[:2]).all()
+  # the general plan (a selection mask disables the fast path) gives the same
+  sel = np.ones((1, 1), bool)
+  np.testing.assert_array_equal(calc.flow_field(pre, post, selection_mask=sel, **kw), got)
+
+
 @pytest.mark.parametrize('py,px,qy,qx', [(48, 48, 48, 48), (64, 80, 40, 64),
                                          (160, 160, 160, 160)])
 def test_masked_mfma_matches_direct_kernel(gpu, py, px, qy, qx):

@@ -247,6 +247,65 @@ def test_relax_large_mesh_vs_oracle(gpu):
   np.testing.assert_allclose(ge, we, rtol=1e-3)
 
 
+def test_headline_mesh_leg_followed_through_all_1000_steps(gpu, capsys):
+  """The mesh leg bench.py times -- ONE chunk of 1000 FIRE steps of the
+  [2, 1, 205, 205] mesh pulled to a flow field of the 8192^2 geometry (mesh.py:
+  448-499) -- followed at every 20th step: the HIP state after k steps (a run of
+  k steps of the same persistent kernel from the same start) against the oracle's
+  snapshot at step k.  dt / alpha / cap agree to 1e-6 and n_pos is IDENTICAL at
+  every checkpoint: both take the same FIRE branch at each of the 1000 steps;
+  the positions differ by amplified round-off only (curve asserted)."""
+  import dataclasses
+  import bench
+  from scipy import ndimage
+  from sofima_amd import mesh
+  rng = np.random.default_rng(1002)
+  # a flow field like the warped pair's: content shift + a smooth 6 px
+  # deformation + integer quantisation, NaN border from mesh_inputs
+  n = (8192 - (bench.PATCH - bench.STEP)) // bench.STEP
+  yy, xx = np.mgrid[:n, :n].astype(np.float32) * bench.STEP + bench.PATCH / 2
+  d = bench.WARP[0] * np.sin(2 * np.pi * xx / bench.WARP[1]) * np.cos(2 * np.pi * yy / bench.WARP[1])
+  flow = np.stack([np.rint(-5 - d), np.rint(3 + d)]).astype(np.float32)
+  flow[:, rng.random((n, n)) < 0.003] = np.nan       # a few invalid vectors
+  prev = bench.mesh_inputs(flow, bench.PATCH // 2 // bench.STEP)
+  assert prev.shape == (2, 1, 205, 205)
+  cfg = mesh.IntegrationConfig(
+      dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(bench.STEP, bench.STEP),
+      num_iters=bench.MESH_ITERS, max_iters=bench.MESH_ITERS, stop_v_max=0.005,
+      dt_max=1000, start_cap=0.01, final_cap=10, prefer_orig_order=True)
+  ocfg = cfg_from(dataclasses.asdict(cfg))
+  x0 = np.zeros_like(prev)
+  v0 = np.zeros_like(prev)
+  snaps = []
+  wo = mesh_oracle.velocity_verlet(x0, v0, prev, ocfg, cfg.start_cap,
+                                   snapshots=snaps, snapshot_every=20)
+  snaps.append((cfg.num_iters, wo[0], wo[3], wo[4], wo[5], wo[6]))
+  assert [s[0] for s in snaps] == list(range(20, 1001, 20))
+  scale = float(np.abs(wo[0]).max())
+  curve, uphill = [], 0
+  prev_npos = 0
+  for step, wx, wdt, walpha, wnpos, wcap in snaps:
+    go = mesh.velocity_verlet(x0, v0, prev, dataclasses.replace(cfg, num_iters=step),
+                              cfg.start_cap)
+    np.testing.assert_allclose([go[3], go[4], go[6]], [wdt, walpha, wcap], rtol=1e-6,
+                               err_msg=f'step {step}')
+    assert go[5] == wnpos, (step, go[5], wnpos)
+    uphill += wnpos < prev_npos + 20
+    prev_npos = wnpos
+    curve.append(float(np.abs(np.array(go[0]) - wx).max()) / scale)
+  with capsys.disabled():
+    print('headline mesh |dx| / scale at every 100th step:',
+          ' '.join('%.1e' % c for c in curve[4::5]), '| checkpoints after an uphill step:', uphill)
+  assert uphill >= 1                       # the chunk does contain FIRE resets
+  assert max(curve[:3]) <= 1e-6            # 60 steps: round-off level
+  assert max(curve) <= 2e-3 and curve[-1] <= 1e-3
+  # the end state is what relax_mesh (the bench call) returns
+  gx, _, gt = mesh.relax_mesh(x0, prev, cfg)
+  assert gt == 1000
+  np.testing.assert_array_equal(np.array(gx), np.array(
+      mesh.velocity_verlet(x0, v0, prev, cfg, cfg.start_cap)[0]))
+
+
 def test_error_behaviour(gpu):
   from sofima_amd import mesh
   x = np.zeros((2, 1, 8, 8), np.float32)

@@ -107,3 +107,158 @@ def test_correction_bound_of_the_seed_probe():
   bound = (abs(ma) * np.sqrt(n * (b1 ** 2).sum()) + abs(mb) * np.sqrt(n * (a1 ** 2).sum()) +
            abs(ma * mb) * n)
   assert np.abs(full - raw).max() <= bound + 1e-6
+
+
+# ---------------------------------------------------------------------------
+# Round-4 inequalities ("cold tiles abandoned inside their row
+# loop", "row loops that narrow themselves", "the guard band is counted in
+# rows"): NumPy restatements of what sfm_xcorr_mfma.hip's check_after and the
+# end-of-patch need mask rely on, against directly computed partial surfaces.
+# ---------------------------------------------------------------------------
+def _int_centre(x):
+  """Integer centre of the int8 operands: clamp(round(mean), max - 127, min + 128)."""
+  return float(np.clip(np.round(x.mean()), x.max() - 127, x.min() + 128))
+
+
+def _corr(a, b):
+  """out[dy + Q - 1, dx + Q - 1] = sum_y sum_x a[y + dy, x + dx] b[y, x]."""
+  return fftconvolve(a, b[::-1, ::-1])
+
+
+def _prefix4(e_rows):
+  """Row-energy prefix sums the prep kernel stores at every fourth row
+  (tbound[kRowPre + k] = sum over rows < min(4 k, rows))."""
+  p = len(e_rows)
+  cum = np.concatenate([[0.0], np.cumsum(e_rows)])
+  return np.array([cum[min(4 * k, p)] for k in range(p // 4 + 2)])
+
+
+def _rest_bound(pre_a, pre_b, p, dy0, y, yhi):
+  """check_after's bound of what the patch rows y .. yhi - 1 can still add to ANY
+  shift of the row tile that starts at dy0: operand rows of A that those rows
+  meet under the tile's 16 shifts, prefixes rounded outwards."""
+  a_lo, a_hi = max(0, y + dy0), min(p, yhi + dy0 + 15)
+  ea = pre_a[(a_hi + 3) >> 2] - pre_a[a_lo >> 2]
+  eb = pre_b[(yhi + 3) >> 2] - pre_b[y >> 2]
+  return np.sqrt(max(ea, 0.0) * max(eb, 0.0))
+
+
+def _corr_bound(a, b, a1, b1):
+  n = a.size
+  ma, mb = a.mean() - _int_centre(a), b.mean() - _int_centre(b)
+  return (abs(ma) * np.sqrt(n * (b1 ** 2).sum()) + abs(mb) * np.sqrt(n * (a1 ** 2).sum()) +
+          abs(ma * mb) * n)
+
+
+@pytest.mark.parametrize('kind', ['em', 'noise', 'edges'])
+@pytest.mark.parametrize('p', [48, 80])
+def test_in_loop_rest_bound_dominates_what_the_remaining_rows_add(kind, p):
+  """After the patch rows yb < y the accumulators hold exact partial sums; the
+  rows y .. yhi - 1 add at most sqrt(E_A E_B) of the operand rows that are left
+  to any of the tile's shifts, so max(partial) + rest + |correction|max bounds
+  every FINAL element of the tile (the abandon test), and the same column tile
+  by column tile (the narrowing test)."""
+  rng = np.random.default_rng(7 * p + len(kind))
+  a, b = _patches(kind, rng, p)
+  a1, b1 = a - _int_centre(a), b - _int_centre(b)
+  assert np.abs(a1).max() <= 128 and np.abs(b1).max() <= 128
+  pre_a = _prefix4((a1 ** 2).sum(axis=1))
+  pre_b = _prefix4((b1 ** 2).sum(axis=1))
+  final_s = _corr(a1, b1)                    # exact integer sums S
+  final = _surface(a, b)                     # S + mean correction: what is thresholded
+  corr = _corr_bound(a, b, a1, b1)
+  n_tiles = (2 * p - 1 + 15) // 16
+  nq = n_tiles
+  checked = 0
+  for t in range(n_tiles):
+    dy0 = 16 * t - (p - 1)
+    ylo, yhi = max(0, -dy0 - 15), min(p, p - dy0)
+    r0, r1 = 16 * t, min(16 * t + 16, 2 * p - 1)       # surface rows of the tile
+    for y in range(ylo, yhi, 4):
+      rest_rows = b1.copy()
+      rest_rows[:y] = 0                                # rows the loop has visited
+      remaining = _corr(a1, rest_rows)[r0:r1]
+      partial = final_s[r0:r1] - remaining
+      rest = _rest_bound(pre_a, pre_b, p, dy0, y, yhi)
+      # (rows >= yhi never meet the patch under this tile's shifts)
+      gone = b1.copy()
+      gone[:yhi] = 0
+      assert np.abs(_corr(a1, gone)[r0:r1]).max() < 1e-6
+      assert np.abs(remaining).max() <= rest * (1 + 1e-9) + 1e-6
+      ub = max(partial.max(), 0.0) + rest + corr       # the kernel's `ub` (+ its margins)
+      assert final[r0:r1].max() <= ub * (1 + 1e-9) + 1e-6
+      # narrowing: outer K + 1 column tiles on either side
+      for k in range(0, nq // 2 - 1):
+        cols = np.r_[0:16 * (k + 1), 16 * (nq - 1 - k):2 * p - 1]
+        m_k = max(partial[:, cols].max(), 0.0)
+        assert final[r0:r1][:, cols].max() <= (m_k + rest + corr) * (1 + 1e-9) + 1e-6
+      checked += 1
+    # before the first row group the bound is the tile's own a-priori bound
+    assert _rest_bound(pre_a, pre_b, p, dy0, ylo, yhi) * (1 + 1e-9) + corr + 1e-6 >= \
+        final[r0:r1].max()
+  assert checked > 4 * n_tiles
+
+
+def test_in_loop_bound_is_tight_enough_to_abandon_cold_tiles():
+  """The bound is useful, not only valid: on an EM-like pair with a clear peak
+  most non-central tiles fall below 0.5 x the maximum before their last row."""
+  rng = np.random.default_rng(11)
+  p = 80
+  a, b = _patches('em', rng, p)
+  a1, b1 = a - _int_centre(a), b - _int_centre(b)
+  pre_a = _prefix4((a1 ** 2).sum(axis=1))
+  pre_b = _prefix4((b1 ** 2).sum(axis=1))
+  final_s = _corr(a1, b1)
+  final = _surface(a, b)
+  corr = _corr_bound(a, b, a1, b1)
+  thr = 0.5 * final.max()
+  abandoned = 0
+  n_tiles = (2 * p - 1 + 15) // 16
+  for t in range(n_tiles):
+    dy0 = 16 * t - (p - 1)
+    ylo, yhi = max(0, -dy0 - 15), min(p, p - dy0)
+    r0, r1 = 16 * t, min(16 * t + 16, 2 * p - 1)
+    for y in range(ylo, yhi - 8, 4):
+      rest_rows = b1.copy()
+      rest_rows[:y] = 0
+      partial = final_s[r0:r1] - _corr(a1, rest_rows)[r0:r1]
+      if max(partial.max(), 0.0) + _rest_bound(pre_a, pre_b, p, dy0, y, yhi) + corr < thr:
+        abandoned += 1
+        assert final[r0:r1].max() < thr               # ... and rightly so
+        break
+  assert abandoned >= n_tiles - 4, abandoned
+
+
+@pytest.mark.parametrize('guard', [4, 10, 24, 60])
+def test_row_counted_guard_band_covers_every_window_of_a_hot_element(guard):
+  """A hot tile asks for the tiles its HOT ROWS reach with `guard` rows (lo_t =
+  (16 t + r_lo - guard) >> 4, hi_t = (16 t + r_hi + guard) >> 4 with r_lo / r_hi
+  the first / last hot row of the tile) instead of ceil(guard / 16) whole tiles
+  on either side.  Every row within `guard` of a hot element must lie in a
+  requested tile -- what stays un-stored is then farther than `guard` rows from
+  every element above threshold_rel x the maximum."""
+  rng = np.random.default_rng(guard)
+  p = 80
+  for kind in ('em', 'noise', 'edges'):
+    a, b = _patches(kind, rng, p)
+    s = _surface(a, b)
+    n_tiles = (s.shape[0] + 15) // 16
+    for thr_rel in (0.5, 0.2):
+      hot = s > thr_rel * s.max()
+      need = np.zeros(n_tiles, bool)
+      for t in range(n_tiles):
+        rows = np.nonzero(hot[16 * t:16 * t + 16].any(axis=1))[0]
+        if rows.size == 0:
+          continue
+        lo_t = max(16 * t + rows.min() - guard, 0) >> 4
+        hi_t = min((16 * t + rows.max() + guard) >> 4, n_tiles - 1)
+        need[lo_t:hi_t + 1] = True
+      for r in np.nonzero(hot.any(axis=1))[0]:
+        band = np.arange(max(0, r - guard), min(s.shape[0], r + guard + 1))
+        assert need[band >> 4].all(), (kind, thr_rel, r)
+      # and it is a real saving against whole tiles either side of a hot tile
+      g_tiles = (guard + 15) >> 4
+      whole = np.zeros(n_tiles, bool)
+      for t in np.nonzero([hot[16 * t:16 * t + 16].any() for t in range(n_tiles)])[0]:
+        whole[max(0, t - g_tiles):t + g_tiles + 1] = True
+      assert need.sum() <= whole.sum() and not (need & ~whole).any()
