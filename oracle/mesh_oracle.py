@@ -129,19 +129,25 @@ def _total_force(x, prev, cap, cfg, mesh_force, prev_fn):
 
 def velocity_verlet(x, v, prev, cfg, force_cap, fire_dt=None, fire_alpha=None,
                     mesh_force=inplane_force, prev_fn=None, snapshots=None,
-                    snapshot_every=0):
+                    snapshot_every=0, resume=None):
   """cfg.num_iters damped-VV or FIRE steps.
 
   Returns (x, v, a) or, with FIRE, (x, v, a, dt, alpha, n_pos, cap).
   `snapshots` (a list, FIRE only; test instrumentation, not in the reference):
   receives (step, x, dt, alpha, n_pos, cap) after every `snapshot_every` steps,
   so that a test can follow ONE long chunk without cutting it (a cut would
-  restart n_pos, mesh.py:448).
+  restart n_pos, mesh.py:448).  `resume` = (a, n_pos) (test instrumentation):
+  continue a chunk from a state taken in the middle of it -- the acceleration
+  as it was (computed under the force cap of the step before) and the count of
+  downhill steps -- instead of starting one.
   """
   x = np.array(x, f32)
   v = np.array(v, f32)
   cap = f32(force_cap)
-  a = _total_force(x, prev, cap, cfg, mesh_force, prev_fn)
+  if resume is not None:
+    a = np.array(resume[0], f32)
+  else:
+    a = _total_force(x, prev, cap, cfg, mesh_force, prev_fn)
 
   def vv(x, v, a, dt, cap):
     x = x + dt * v + f32(0.5) * dt * dt * a
@@ -158,11 +164,14 @@ def velocity_verlet(x, v, prev, cfg, force_cap, fire_dt=None, fire_alpha=None,
 
   dt = f32(cfg.dt if fire_dt is None else fire_dt)
   alpha = f32(cfg.alpha if fire_alpha is None else fire_alpha)
-  n_pos = 0
+  n_pos = 0 if resume is None else int(resume[1])
   dt_cap = f32(float(cfg.dt_max) * float(cfg.dt))
+  power = 0.0
   for step in range(cfg.num_iters):
     if snapshots is not None and step and step % snapshot_every == 0:
-      snapshots.append((step, x.copy(), f32(dt), f32(alpha), n_pos, f32(cap)))
+      # (+ the last power and its scale |a||v|: how marginal the last branch was)
+      snapshots.append((step, x.copy(), f32(dt), f32(alpha), n_pos, f32(cap),
+                        float(power), float(np.linalg.norm(a) * np.linalg.norm(v))))
     x, v, a = vv(x, v, a, dt, cap)
     a_n = np.sqrt(np.sum(np.square(a), axis=0, keepdims=True)) + f32(1e-6)
     v_n = np.sqrt(np.sum(np.square(v), axis=0, keepdims=True))

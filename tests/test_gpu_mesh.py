@@ -250,14 +250,31 @@ def test_relax_large_mesh_vs_oracle(gpu):
 def test_headline_mesh_leg_followed_through_all_1000_steps(gpu, capsys):
   """The mesh leg bench.py times -- ONE chunk of 1000 FIRE steps of the
   [2, 1, 205, 205] mesh pulled to a flow field of the 8192^2 geometry (mesh.py:
-  448-499) -- followed at every 20th step: the HIP state after k steps (a run of
-  k steps of the same persistent kernel from the same start) against the oracle's
-  snapshot at step k.  dt / alpha / cap agree to 1e-6 and n_pos is IDENTICAL at
-  every checkpoint: both take the same FIRE branch at each of the 1000 steps;
-  the positions differ by amplified round-off only (curve asserted)."""
+  448-499) -- followed through its whole length.
+
+  FIRE with dt_max = 1000 drives the time step to the stability limit of the
+  mesh, where its fastest modes amplify ANY perturbation by orders of magnitude
+  within a few steps until `power < 0` resets dt; the fixed point is attracting,
+  so the trajectories re-converge.  The oracle shows this against ITSELF: start
+  positions perturbed by 1e-7 of the scale differ by ~3e-3 of the scale around
+  step 220, take other FIRE branches from there on, and end 2e-6 apart.  So
+  "identical FIRE scalars at every checkpoint of the free run" is not a
+  property the reference has against itself, and the test states what IS:
+
+  (a) Window by window: the HIP state after k steps (a run of k steps of the
+  same persistent kernel from the same start; k = 0, 20, ..., 980) is handed to
+  the oracle, which continues the chunk for 20 steps (`resume`: same
+  acceleration, same n_pos).  The HIP state after k + 20 steps has n_pos
+  IDENTICAL and dt / alpha / cap equal to 1e-6 in every one of the 50 windows --
+  the same FIRE branch at each of the 1000 steps when both start from the same
+  state -- and positions within 10 x what the oracle's own continuation moves
+  when its start state is perturbed by 1e-7 of the scale (+ 1e-5).
+  (b) Free running (the oracle alone from the start): FIRE scalars identical
+  while the difference is at round-off level (first 60 steps), the difference
+  curve within 10 x the oracle's own sensitivity curve (+ 1e-5), and the END
+  state -- what relax_mesh returns to the caller -- within SURVEY 8c's 1e-3 px."""
   import dataclasses
   import bench
-  from scipy import ndimage
   from sofima_amd import mesh
   rng = np.random.default_rng(1002)
   # a flow field like the warped pair's: content shift + a smooth 6 px
@@ -269,41 +286,81 @@ def test_headline_mesh_leg_followed_through_all_1000_steps(gpu, capsys):
   flow[:, rng.random((n, n)) < 0.003] = np.nan       # a few invalid vectors
   prev = bench.mesh_inputs(flow, bench.PATCH // 2 // bench.STEP)
   assert prev.shape == (2, 1, 205, 205)
+  total, win = bench.MESH_ITERS, 20
   cfg = mesh.IntegrationConfig(
       dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=(bench.STEP, bench.STEP),
-      num_iters=bench.MESH_ITERS, max_iters=bench.MESH_ITERS, stop_v_max=0.005,
+      num_iters=total, max_iters=total, stop_v_max=0.005,
       dt_max=1000, start_cap=0.01, final_cap=10, prefer_orig_order=True)
   ocfg = cfg_from(dataclasses.asdict(cfg))
+  wcfg = cfg_from(dataclasses.asdict(dataclasses.replace(cfg, num_iters=win)))
   x0 = np.zeros_like(prev)
   v0 = np.zeros_like(prev)
-  snaps = []
-  wo = mesh_oracle.velocity_verlet(x0, v0, prev, ocfg, cfg.start_cap,
-                                   snapshots=snaps, snapshot_every=20)
-  snaps.append((cfg.num_iters, wo[0], wo[3], wo[4], wo[5], wo[6]))
-  assert [s[0] for s in snaps] == list(range(20, 1001, 20))
-  scale = float(np.abs(wo[0]).max())
-  curve, uphill = [], 0
-  prev_npos = 0
-  for step, wx, wdt, walpha, wnpos, wcap in snaps:
-    go = mesh.velocity_verlet(x0, v0, prev, dataclasses.replace(cfg, num_iters=step),
+
+  def hip_state(k):
+    go = mesh.velocity_verlet(x0, v0, prev, dataclasses.replace(cfg, num_iters=k),
                               cfg.start_cap)
-    np.testing.assert_allclose([go[3], go[4], go[6]], [wdt, walpha, wcap], rtol=1e-6,
-                               err_msg=f'step {step}')
-    assert go[5] == wnpos, (step, go[5], wnpos)
-    uphill += wnpos < prev_npos + 20
-    prev_npos = wnpos
-    curve.append(float(np.abs(np.array(go[0]) - wx).max()) / scale)
+    return [np.array(go[0]), np.array(go[1]), np.array(go[2])] + list(go[3:])
+
+  states = {k: hip_state(k) for k in range(win, total + 1, win)}
+  scale = float(np.abs(states[total][0]).max())
+  eps = 1e-7 * scale
+
+  # (a) every 20-step window of the HIP chunk against the oracle's continuation
+  worst = (0.0, 0.0, 0)
+  resets = 0
+  for k in range(0, total, win):
+    if k == 0:
+      start = (x0, v0, cfg.start_cap, None, None, None)
+    else:
+      sx, sv, sa, sdt, salpha, snpos, scap = states[k]
+      start = (sx, sv, scap, sdt, salpha, (sa, snpos))
+    jitter = (rng.standard_normal(x0.shape) * eps).astype(np.float32)
+    wo = mesh_oracle.velocity_verlet(start[0], start[1], prev, wcfg, start[2], start[3],
+                                     start[4], resume=start[5])
+    wp = mesh_oracle.velocity_verlet(start[0] + jitter, start[1], prev, wcfg, start[2],
+                                     start[3], start[4], resume=start[5])
+    gx, _, _, gdt, galpha, gnpos, gcap = states[k + win]
+    assert gnpos == wo[5], (k, gnpos, wo[5])
+    np.testing.assert_allclose([gdt, galpha, gcap], [wo[3], wo[4], wo[6]], rtol=1e-6,
+                               err_msg=f'window {k}')
+    resets += gnpos < (0 if k == 0 else states[k][5]) + win
+    err = float(np.abs(gx - wo[0]).max()) / scale
+    sens = float(np.abs(wp[0] - wo[0]).max()) / scale
+    assert err <= 10 * sens + 1e-5, (k, err, sens)
+    if err > worst[0]:
+      worst = (err, sens, k)
+  assert resets >= 3                         # the chunk does contain FIRE resets
+
+  # (b) the free-running oracle, and the oracle against itself
+  def free_run(start):
+    snaps = []
+    wo = mesh_oracle.velocity_verlet(start, v0, prev, ocfg, cfg.start_cap,
+                                     snapshots=snaps, snapshot_every=win)
+    return snaps + [(total, wo[0], wo[3], wo[4], wo[5], wo[6])]
+
+  ora = free_run(x0)
+  pert = free_run((rng.standard_normal(x0.shape) * eps).astype(np.float32))
+  curve, own = [], []
+  for so, sp in zip(ora, pert):
+    k = so[0]
+    g = states[k]
+    if k <= 60:
+      assert g[5] == so[4] and np.allclose([g[3], g[4], g[6]], [so[2], so[3], so[5]],
+                                           rtol=1e-6), k
+    curve.append(float(np.abs(g[0] - so[1]).max()) / scale)
+    own.append(float(np.abs(sp[1] - so[1]).max()) / scale)
   with capsys.disabled():
-    print('headline mesh |dx| / scale at every 100th step:',
-          ' '.join('%.1e' % c for c in curve[4::5]), '| checkpoints after an uphill step:', uphill)
-  assert uphill >= 1                       # the chunk does contain FIRE resets
-  assert max(curve[:3]) <= 1e-6            # 60 steps: round-off level
-  assert max(curve) <= 2e-3 and curve[-1] <= 1e-3
-  # the end state is what relax_mesh (the bench call) returns
+    print(f'headline mesh: worst window {worst[2]}: {worst[0]:.1e} of the scale (oracle vs '
+          f'its perturbed self there: {worst[1]:.1e}); free run |dx| / scale at every 100th '
+          'step, HIP vs oracle:', ' '.join('%.1e' % c for c in curve[4::5]),
+          '| oracle vs perturbed oracle:', ' '.join('%.1e' % c for c in own[4::5]))
+  assert max(curve[:3]) <= 1e-6              # 60 steps: round-off level
+  assert max(curve) <= 10 * max(own) + 1e-5, (max(curve), max(own))
+  # the end state is what relax_mesh (the bench call) returns: SURVEY 8c, 1e-3 px
   gx, _, gt = mesh.relax_mesh(x0, prev, cfg)
-  assert gt == 1000
-  np.testing.assert_array_equal(np.array(gx), np.array(
-      mesh.velocity_verlet(x0, v0, prev, cfg, cfg.start_cap)[0]))
+  assert gt == total
+  np.testing.assert_array_equal(np.array(gx), states[total][0])
+  np.testing.assert_allclose(np.array(gx), ora[-1][1], atol=1e-3)
 
 
 def test_error_behaviour(gpu):
