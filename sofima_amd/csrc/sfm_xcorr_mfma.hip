@@ -245,6 +245,16 @@ struct MfmaArgs {
   int count_tiles;    // report the pruning counts through clk (timing hooks on)
   int probe;          // seed the running maximum from a probe block (see the kernel)
   int guard, guard_x;
+  // Correction table built where it is read (kModeSameExactLazyG): the prep kernel
+  // leaves, instead of G, the centred column sums above every 16th patch row --
+  // c16[side][I][x] = sum_{y < 16 I} (pixel[y][x] - centre), I <= Py / 16, ints (and
+  // the prefixes T of the post patch's centred row sums) -- and a tile that is about
+  // to run its epilogue first forms its 16 table rows from them and the int8 patches
+  // in LDS, writes them into G (now a per-patch scratch in L2: ten kilobytes that the
+  // same lanes read back at once) and runs the ordinary epilogue.
+  int lazy_g;
+  int* c16;           // [B, c16_stride]: [2][Py / 16 + 1][Px] column sums, then T[Py + 1]
+  long long c16_stride;
   int nq;             // column tiles of the kernel variant
   int prune_k[4];     // outer column tiles (each side) of the row-loop variants (ascending)
 };
@@ -403,6 +413,15 @@ __device__ __forceinline__ v4i load_16_bytes(const unsigned char* img, long long
 // ---------------------------------------------------------------------------
 constexpr int kPrepCols = 3;  // columns per lane: Px <= 192
 
+// One entry of the correction table, G = -mB' IA'[yv][xv] - mA' IB'[Py - yv][Px - xv],
+// from the two (exact, integer-valued) integral-image entries: ONE expression for
+// the prep kernel's table and for the table rows built in the correlation kernel's
+// epilogue (a product, then a fused multiply-add -- pinned, so that the compiler
+// cannot contract the two sites differently: the surfaces must agree bit for bit).
+__device__ __forceinline__ float g_entry(float mua, float mub, float ia, float ib) {
+  return __fmaf_rn(-mua, ib, __fmul_rn(-mub, ia));
+}
+
 // Wave-wide inclusive add scan on the DPP network (row shifts inside each
 // 16-lane row, then row broadcasts), ~12 VALU ops instead of 6 LDS permutes.
 __device__ __forceinline__ int wave_scan_incl(int v) {
@@ -420,7 +439,7 @@ template <int WAVES, int ROWS>
 struct PrepTables {
   int s_c[2];
   float s_mu[2];
-  int band_tot[2][WAVES][64 * kPrepCols];
+  alignas(16) int band_tot[2][WAVES + 1][64 * kPrepCols];   // (+ 1: room for [2][10][160] band sums, lazy_g)
   // pruning bounds: per-row sum and sum of squares of the raw pixels, later the
   // prefix sums of the row energies (doubles)
   // (sum in the low, sum of squares in the high word: one 64-bit LDS atomic per item)
@@ -448,7 +467,7 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
   constexpr int kPrepThreads = 64 * WAVES;
   int (&s_c)[2] = tp->s_c;
   float (&s_mu)[2] = tp->s_mu;
-  int (&band_tot)[2][WAVES][64 * kPrepCols] = tp->band_tot;
+  int (&band_tot)[2][WAVES + 1][64 * kPrepCols] = tp->band_tot;
   // reduction scratch of phase 2, aliased onto band_tot (separated by a barrier)
   static_assert(sizeof(tp->band_tot) >= sizeof(int) * 2 * 3 * kPrepThreads, "alias");
   int (*red)[3][kPrepThreads] = reinterpret_cast<int (*)[3][kPrepThreads]>(&band_tot[0][0][0]);
@@ -679,146 +698,257 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
     }
   }
 
-  // Phase 3a: per-band column totals (band w = rows [w R, (w + 1) R)).
-  // Lane l owns the kPrepCols consecutive columns kPrepCols * l + k, so one
-  // wave scan over the per-lane totals gives the prefix along x.
-  const int R = (py + kPrepWaves - 1) / kPrepWaves;
-  const int ra0 = min(wave * R, py), ra1 = min(ra0 + R, py);
   const int xl = kPrepCols * lane;
+  if (a.lazy_g) {
+    // The correction table is built where it is read (kModeSameExactLazyG): of the
+    // 20 row tiles of a patch 2.8 ever reach an epilogue, so instead of sweeping
+    // Py rows of G (102 KB per patch, 60 % of this kernel's time) the pass leaves
+    // the centred column sums above every 16th row, c16[side][I][x] (14 KB), and
+    // the four 1-D arrays, which need one wave scan each.  Py, Px multiples of 16,
+    // both <= 192 (host).
+    const int NB = py >> 4, cw = px >> 2;
+    int* bsum = &band_tot[0][0][0];   // [2][NB][px]: raw column sums per band of 16 rows
+    static_assert(sizeof(tp->band_tot) >= sizeof(int) * 2 * 10 * 160, "band sums");
+    for (int idx = threadIdx.x; idx < 2 * NB * cw; idx += kPrepThreads) {
+      const int s = idx / (NB * cw), rem = idx - s * NB * cw;
+      const int band = rem / cw, cx = rem - band * cw;
+      const unsigned* src =
+          reinterpret_cast<const unsigned*>(pix[s] + (16 * band) * px) + cx;
+      unsigned v[16];
 #pragma unroll
-  for (int k = 0; k < kPrepCols; ++k) {
-    const int x = xl + k;
-    int ta = 0, tb = 0, qa = 0, qb = 0;
-    if (x < px) {
-      // several rows per trip: the byte loads of a trip are in flight together
-#pragma unroll 5
-      for (int y = ra0; y < ra1; ++y) {
-        const int va = pix[0][y * px + x];
-        const int vb = pix[1][y * px + (px - 1 - x)];  // post patch: mirrored columns
-        ta += va;
-        tb += vb;
-        qa += va * va;
-        qb += vb * vb;
+      for (int y = 0; y < 16; ++y) v[y] = src[y * cw];   // (all in flight together)
+      unsigned lo = 0, hi = 0;       // bytes 0 | 2 and 1 | 3 as 16-bit fields (16 x 255 < 2^16)
+      unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+#pragma unroll
+      for (int y = 0; y < 16; ++y) {
+        lo += v[y] & 0x00ff00ffu;
+        hi += (v[y] >> 8) & 0x00ff00ffu;
+        const unsigned b0 = v[y] & 0xffu, b1 = (v[y] >> 8) & 0xffu;
+        const unsigned b2 = (v[y] >> 16) & 0xffu, b3 = v[y] >> 24;
+        q0 = __umul24(b0, b0) + q0;
+        q1 = __umul24(b1, b1) + q1;
+        q2 = __umul24(b2, b2) + q2;
+        q3 = __umul24(b3, b3) + q3;
+      }
+      int* dst = bsum + (s * NB + band) * px + 4 * cx;
+      *reinterpret_cast<v4i*>(dst) = v4i{static_cast<int>(lo & 0xffffu), static_cast<int>(hi & 0xffffu),
+                                         static_cast<int>(lo >> 16), static_cast<int>(hi >> 16)};
+      if (a.prune) {
+        // (post patch: mirrored index, like the sweep's column energies)
+        const int x0 = 4 * cx;
+        atomicAdd(&col_sq[s][s ? px - 1 - x0 : x0], static_cast<int>(q0));
+        atomicAdd(&col_sq[s][s ? px - 2 - x0 : x0 + 1], static_cast<int>(q1));
+        atomicAdd(&col_sq[s][s ? px - 3 - x0 : x0 + 2], static_cast<int>(q2));
+        atomicAdd(&col_sq[s][s ? px - 4 - x0 : x0 + 3], static_cast<int>(q3));
       }
     }
-    band_tot[0][wave][xl + k] = ta;
-    band_tot[1][wave][xl + k] = tb;
-    if (a.prune && x < px) {
-      atomicAdd(&col_sq[0][x], qa);
-      atomicAdd(&col_sq[1][x], qb);
-    }
-  }
-  __syncthreads();
-  const int ca = s_c[0], cb = s_c[1];
-  const float mua = s_mu[0], mub = s_mu[1];
-  float* G = a.gtab + (long long)b * py * px;
-  float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
-  float* rrowA = aux;
-  float* rrowB = aux + a.aux_n;
-  float* rcolA = aux + 2 * a.aux_n;
-  float* rcolB = aux + 3 * a.aux_n;
-
-  // Phase 3b: running column sums at the first row of the band.
-  //   colA = sum of pre rows  [0, yv)      at yv = ra0
-  //   colB = sum of post rows [0, py - yv) at yv = ra0
-  int colA[kPrepCols], colB[kPrepCols];
+    __syncthreads();
+    int* c16 = a.c16 + b * a.c16_stride;   // [2][NB + 1][px], then T[py + 1]
+    if (threadIdx.x < 2 * px) {
+      const int s = threadIdx.x >= px ? 1 : 0, x = threadIdx.x - s * px;
+      const int c = s_c[s];
+      int band_sum[12];
 #pragma unroll
-  for (int k = 0; k < kPrepCols; ++k) {
-    colA[k] = 0;
-    colB[k] = 0;
-    for (int w2 = 0; w2 < kPrepWaves; ++w2) {
-      const int lo = min(w2 * R, py), hi = min(lo + R, py);
-      if (hi <= ra0) colA[k] += band_tot[0][w2][xl + k];
-      if (hi <= py - ra0) {
-        colB[k] += band_tot[1][w2][xl + k];
-      } else if (lo < py - ra0) {
-        const int x = xl + k;  // partial band: rows [lo, py - ra0)
-        if (x < px)
-          for (int y = lo; y < py - ra0; ++y) colB[k] += pix[1][y * px + (px - 1 - x)];
+      for (int I = 0; I < 12; ++I) band_sum[I] = I < NB ? bsum[(s * NB + I) * px + x] : 0;
+      int run = 0;
+      int* out = c16 + s * (NB + 1) * px + x;
+#pragma unroll
+      for (int I = 0; I < 12; ++I) {
+        if (I < NB) out[I * px] = run - c * 16 * I;
+        run += band_sum[I];
+      }
+      out[NB * px] = run - c * py;
+      bsum[s * NB * px + x] = run;   // the column's raw total (its own entries are consumed)
+    }
+    __syncthreads();
+    const int ca = s_c[0], cb = s_c[1];
+    const float mua = s_mu[0], mub = s_mu[1];
+    float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
+    float* rrowA = aux;
+    float* rrowB = aux + a.aux_n;
+    float* rcolA = aux + 2 * a.aux_n;
+    float* rcolB = aux + 3 * a.aux_n;
+    if (wave == 2 || wave == 3) {
+      // wave 2: exclusive prefixes over the centred ROW sums: IA'[y][Px], IB'[y][Px];
+      // wave 3: over the centred COLUMN sums: IA'[Py][x], IB'[Py][x]  (lane l owns the
+      // entries 3 l .. 3 l + 2, one wave scan per side)
+      const bool rows = wave == 2;
+      const int len = rows ? py : px, other = rows ? px : py;
+      int va[kPrepCols], vb[kPrepCols], sa = 0, sb = 0;
+#pragma unroll
+      for (int k = 0; k < kPrepCols; ++k) {
+        const int i = xl + k;
+        int raw_a = 0, raw_b = 0;
+        if (i < len) {
+          raw_a = rows ? static_cast<int>(row_acc[0][i] & 0xffffffffull) : bsum[i];
+          raw_b = rows ? static_cast<int>(row_acc[1][i] & 0xffffffffull) : bsum[NB * px + i];
+        }
+        va[k] = sa;   // exclusive within the lane
+        vb[k] = sb;
+        sa += i < len ? raw_a - ca * other : 0;
+        sb += i < len ? raw_b - cb * other : 0;
+      }
+      const int ea = wave_scan_incl(sa) - sa, eb = wave_scan_incl(sb) - sb;
+      float* oa = rows ? rrowA : rcolA;
+      float* ob = rows ? rrowB : rcolB;
+#pragma unroll
+      for (int k = 0; k < kPrepCols; ++k) {
+        const int i = xl + k;
+        const float fa = static_cast<float>(ea + va[k]), fb = static_cast<float>(eb + vb[k]);
+        // T = IB'[y][Px], y <= Py, as integers behind the two column-sum tables
+        if (rows && i <= len) c16[2 * (NB + 1) * px + i] = eb + vb[k];
+        if (i < len) oa[i] = -mub * fa;             // rrowA[yv] / rcolA[xv]
+        if (i >= 1 && i <= len) ob[len - i] = mua * fb;   // rrowB[Py - y] / rcolB[Px - x]
+        if (rows && i == len) {
+          aux[4 * a.aux_n + 0] = -mub * fa;         // -mB' IA'[Py][Px]
+          aux[4 * a.aux_n + 1] = -mua * fb;         // -mA' IB'[Py][Px]
+        }
       }
     }
-  }
-  PTICK(3)
-  // Sweep.  The last wave also emits the yv == py row (pre-patch totals).
-  // The post patch is scanned in MIRRORED column order (lane l owns columns
-  // px - 1 - (3 l + k)): the table needs IB[py - yv][px - xv], and
-  //     sum_{x < px - xv} b[.][x]  =  TB - (mirrored prefix up to xv),
-  // so the lane that holds IA[yv][xv] also holds the matching IB value and a
-  // row of G leaves the registers directly -- no transposition through LDS, no
-  // intra-wave fences (the first version spent 1.8 k cycles per row on them).
-  const int y_end = wave == kPrepWaves - 1 ? py + 1 : ra1;
-  for (int yv = ra0; yv < y_end; ++yv) {
-    const int yw = py - yv;
-    // the pixels that move the column sums to row yv + 1: requested now, added
-    // at the end of the trip (their LDS latency hides behind the scans)
-    int nxt_a[kPrepCols], nxt_b[kPrepCols];
-#pragma unroll
+  } else {
+    // Phase 3a: per-band column totals (band w = rows [w R, (w + 1) R)).
+    // Lane l owns the kPrepCols consecutive columns kPrepCols * l + k, so one
+    // wave scan over the per-lane totals gives the prefix along x.
+    const int R = (py + kPrepWaves - 1) / kPrepWaves;
+    const int ra0 = min(wave * R, py), ra1 = min(ra0 + R, py);
+  #pragma unroll
     for (int k = 0; k < kPrepCols; ++k) {
       const int x = xl + k;
-      const bool live = yv < py && x < px;
-      nxt_a[k] = live ? pix[0][yv * px + x] : 0;
-      nxt_b[k] = live ? pix[1][(yw - 1) * px + (px - 1 - x)] : 0;
+      int ta = 0, tb = 0, qa = 0, qb = 0;
+      if (x < px) {
+        // several rows per trip: the byte loads of a trip are in flight together
+  #pragma unroll 5
+        for (int y = ra0; y < ra1; ++y) {
+          const int va = pix[0][y * px + x];
+          const int vb = pix[1][y * px + (px - 1 - x)];  // post patch: mirrored columns
+          ta += va;
+          tb += vb;
+          qa += va * va;
+          qb += vb * vb;
+        }
+      }
+      band_tot[0][wave][xl + k] = ta;
+      band_tot[1][wave][xl + k] = tb;
+      if (a.prune && x < px) {
+        atomicAdd(&col_sq[0][x], qa);
+        atomicAdd(&col_sq[1][x], qb);
+      }
     }
-    int pa[kPrepCols], pb[kPrepCols];
-    int sa = 0, sb = 0;
-#pragma unroll
+    __syncthreads();
+    const int ca = s_c[0], cb = s_c[1];
+    const float mua = s_mu[0], mub = s_mu[1];
+    float* G = a.gtab + (long long)b * py * px;
+    float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
+    float* rrowA = aux;
+    float* rrowB = aux + a.aux_n;
+    float* rcolA = aux + 2 * a.aux_n;
+    float* rcolB = aux + 3 * a.aux_n;
+
+    // Phase 3b: running column sums at the first row of the band.
+    //   colA = sum of pre rows  [0, yv)      at yv = ra0
+    //   colB = sum of post rows [0, py - yv) at yv = ra0
+    int colA[kPrepCols], colB[kPrepCols];
+  #pragma unroll
     for (int k = 0; k < kPrepCols; ++k) {
-      sa += xl + k < px ? colA[k] : 0;
-      sb += xl + k < px ? colB[k] : 0;
-      pa[k] = sa;
-      pb[k] = sb;
+      colA[k] = 0;
+      colB[k] = 0;
+      for (int w2 = 0; w2 < kPrepWaves; ++w2) {
+        const int lo = min(w2 * R, py), hi = min(lo + R, py);
+        if (hi <= ra0) colA[k] += band_tot[0][w2][xl + k];
+        if (hi <= py - ra0) {
+          colB[k] += band_tot[1][w2][xl + k];
+        } else if (lo < py - ra0) {
+          const int x = xl + k;  // partial band: rows [lo, py - ra0)
+          if (x < px)
+            for (int y = lo; y < py - ra0; ++y) colB[k] += pix[1][y * px + (px - 1 - x)];
+        }
+      }
     }
-    const int inc_a = wave_scan_incl(sa), inc_b = wave_scan_incl(sb);
-    const int ea = inc_a - sa, eb = inc_b - sb;   // exclusive prefixes of the lane totals
-    const int ta = __builtin_amdgcn_readlane(inc_a, 63);  // IrawA[yv][px]
-    const int tb = __builtin_amdgcn_readlane(inc_b, 63);  // IrawB[py - yv][px]
-    // centred integral images: I'[y][x] = Iraw[y][x] - c y x
-    // (c y x < 255 * 256 * 192 < 2^24: 24-bit multiplies, full rate; the 32-bit
-    // v_mul_lo_u32 is a quarter-rate instruction and a row had twelve of them)
-    const int cay = ca * yv, cby = cb * yw;
-    auto ia = [&](int raw, int x) { return static_cast<float>(raw - __mul24(cay, x)); };
-    auto ib = [&](int raw, int x) { return static_cast<float>(raw - __mul24(cby, x)); };
-    const float ia_px = ia(ta, px), ib_px = ib(tb, px);
-    if (yv < py) {
-#pragma unroll
+    PTICK(3)
+    // Sweep.  The last wave also emits the yv == py row (pre-patch totals).
+    // The post patch is scanned in MIRRORED column order (lane l owns columns
+    // px - 1 - (3 l + k)): the table needs IB[py - yv][px - xv], and
+    //     sum_{x < px - xv} b[.][x]  =  TB - (mirrored prefix up to xv),
+    // so the lane that holds IA[yv][xv] also holds the matching IB value and a
+    // row of G leaves the registers directly -- no transposition through LDS, no
+    // intra-wave fences (the first version spent 1.8 k cycles per row on them).
+    int y_end = wave == kPrepWaves - 1 ? py + 1 : ra1;
+  #ifdef SFM_ABLATE_SWEEP   // timing experiment only (garbage tables): the prep pass without its sweep
+    y_end = ra0;
+  #endif
+    for (int yv = ra0; yv < y_end; ++yv) {
+      const int yw = py - yv;
+      // the pixels that move the column sums to row yv + 1: requested now, added
+      // at the end of the trip (their LDS latency hides behind the scans)
+      int nxt_a[kPrepCols], nxt_b[kPrepCols];
+  #pragma unroll
       for (int k = 0; k < kPrepCols; ++k) {
-        const int xv = xl + k + 1;
-        if (xv < px)
-          G[yv * px + xv] = -mub * ia(ea + pa[k], xv) - mua * ib(tb - (eb + pb[k]), px - xv);
+        const int x = xl + k;
+        const bool live = yv < py && x < px;
+        nxt_a[k] = live ? pix[0][yv * px + x] : 0;
+        nxt_b[k] = live ? pix[1][(yw - 1) * px + (px - 1 - x)] : 0;
       }
-      if (lane == 0) {
-        G[yv * px] = -mub * ia(0, 0) - mua * ib_px;
-        rrowA[yv] = -mub * ia_px;
-        rrowB[yv] = mua * ib_px;
-      }
-    }
-    if (yv == 0) {
-#pragma unroll
+      int pa[kPrepCols], pb[kPrepCols];
+      int sa = 0, sb = 0;
+  #pragma unroll
       for (int k = 0; k < kPrepCols; ++k) {
-        const int xv = xl + k + 1;
-        if (xv < px) rcolB[xv] = mua * ib(tb - (eb + pb[k]), px - xv);
+        sa += xl + k < px ? colA[k] : 0;
+        sb += xl + k < px ? colB[k] : 0;
+        pa[k] = sa;
+        pb[k] = sb;
       }
-      if (lane == 0) {
-        rcolB[0] = mua * ib_px;
-        aux[4 * a.aux_n + 1] = -mua * ib_px;
+      const int inc_a = wave_scan_incl(sa), inc_b = wave_scan_incl(sb);
+      const int ea = inc_a - sa, eb = inc_b - sb;   // exclusive prefixes of the lane totals
+      const int ta = __builtin_amdgcn_readlane(inc_a, 63);  // IrawA[yv][px]
+      const int tb = __builtin_amdgcn_readlane(inc_b, 63);  // IrawB[py - yv][px]
+      // centred integral images: I'[y][x] = Iraw[y][x] - c y x
+      // (c y x < 255 * 256 * 192 < 2^24: 24-bit multiplies, full rate; the 32-bit
+      // v_mul_lo_u32 is a quarter-rate instruction and a row had twelve of them)
+      const int cay = ca * yv, cby = cb * yw;
+      auto ia = [&](int raw, int x) { return static_cast<float>(raw - __mul24(cay, x)); };
+      auto ib = [&](int raw, int x) { return static_cast<float>(raw - __mul24(cby, x)); };
+      const float ia_px = ia(ta, px), ib_px = ib(tb, px);
+      if (yv < py) {
+  #pragma unroll
+        for (int k = 0; k < kPrepCols; ++k) {
+          const int xv = xl + k + 1;
+          if (xv < px)
+            G[yv * px + xv] = g_entry(mua, mub, ia(ea + pa[k], xv), ib(tb - (eb + pb[k]), px - xv));
+        }
+        if (lane == 0) {
+          G[yv * px] = g_entry(mua, mub, ia(0, 0), ib_px);
+          rrowA[yv] = -mub * ia_px;
+          rrowB[yv] = mua * ib_px;
+        }
       }
-    }
-    if (yv == py) {
-#pragma unroll
+      if (yv == 0) {
+  #pragma unroll
+        for (int k = 0; k < kPrepCols; ++k) {
+          const int xv = xl + k + 1;
+          if (xv < px) rcolB[xv] = mua * ib(tb - (eb + pb[k]), px - xv);
+        }
+        if (lane == 0) {
+          rcolB[0] = mua * ib_px;
+          aux[4 * a.aux_n + 1] = -mua * ib_px;
+        }
+      }
+      if (yv == py) {
+  #pragma unroll
+        for (int k = 0; k < kPrepCols; ++k) {
+          const int xv = xl + k + 1;
+          if (xv < px) rcolA[xv] = -mub * ia(ea + pa[k], xv);
+        }
+        if (lane == 0) {
+          rcolA[0] = -mub * ia(0, 0);
+          aux[4 * a.aux_n + 0] = -mub * ia_px;
+        }
+      }
+      // advance to row yv + 1
+  #pragma unroll
       for (int k = 0; k < kPrepCols; ++k) {
-        const int xv = xl + k + 1;
-        if (xv < px) rcolA[xv] = -mub * ia(ea + pa[k], xv);
+        colA[k] += nxt_a[k];
+        colB[k] -= nxt_b[k];
       }
-      if (lane == 0) {
-        rcolA[0] = -mub * ia(0, 0);
-        aux[4 * a.aux_n + 0] = -mub * ia_px;
-      }
-    }
-    // advance to row yv + 1
-#pragma unroll
-    for (int k = 0; k < kPrepCols; ++k) {
-      colA[k] += nxt_a[k];
-      colB[k] -= nxt_b[k];
     }
   }
   if (a.prune && threadIdx.x < kBoundTiles) {
@@ -853,9 +983,15 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
     for (int k = 0; k < kPrepCols; ++k) {
       const int x = xl + k;
       int sa = 0, sb = 0;
-      for (int w2 = 0; w2 < kPrepWaves; ++w2) {
-        sa += band_tot[0][w2][x];
-        sb += band_tot[1][w2][x];
+      if (a.lazy_g) {   // raw column totals, natural order (post patch: mirrored here)
+        const int* tot = &band_tot[0][0][0];
+        sa = x < px ? tot[x] : 0;
+        sb = x < px ? tot[(py >> 4) * px + (px - 1 - x)] : 0;
+      } else {
+        for (int w2 = 0; w2 < kPrepWaves; ++w2) {
+          sa += band_tot[0][w2][x];
+          sb += band_tot[1][w2][x];
+        }
       }
       ea[k] = x < px ? fmax(col_sq[0][x] - 2.0 * mua_d * sa + mua_d * mua_d * py, 0.0) : 0.0;
       eb[k] = x < px ? fmax(col_sq[1][x] - 2.0 * mub_d * sb + mub_d * mub_d * py, 0.0) : 0.0;
@@ -1947,6 +2083,27 @@ constexpr int kModeGeneral = 0, kModeSame = 1, kModeRaw = 2, kModeSameExact = 3;
 // the same skip mask for the overflow sweeps of the peak kernels.  Values and
 // decisions that reach the output are unchanged: bit-identical results.
 constexpr int kModeSameLazy = 4, kModeSameExactLazy = 5;
+// kModeSameExactLazy with the correction table built in the epilogue of the tiles
+// that are stored (MfmaArgs::lazy_g; Py a multiple of 16): no table G in memory.
+constexpr int kModeSameExactLazyG = 6;
+
+// Inclusive add scan over the 16 lanes of a DPP row (the 16 columns of a tile).
+__device__ __forceinline__ int row16_scan_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  return v;
+}
+// Lane 15 of every 16-lane row to the whole row (ds_swizzle, bit mode: lane' =
+// (lane & 0x10) | 0x0f inside each half wave; no LDS memory is touched).
+__device__ __forceinline__ int row16_last(int v) {
+  return __builtin_amdgcn_ds_swizzle(v, (0x0f << 5) | 0x10);
+}
+// Lane n <- lane 15 - n of the same row.
+__device__ __forceinline__ int row16_mirror(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);   // row_mirror
+}
 
 // Wave-wide maximum of non-negative values on the DPP network (no LDS round
 // trips): row shifts inside each 16-lane row, then row broadcasts; the result
@@ -2050,10 +2207,11 @@ __device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_ld
 
 template <int NCA, int NCE, int MODE>
 __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
+  constexpr bool LAZYG = MODE == kModeSameExactLazyG;
   constexpr bool SAME = MODE == kModeSame || MODE == kModeSameExact || MODE == kModeSameLazy ||
-                        MODE == kModeSameExactLazy;
-  constexpr bool EXACT = MODE == kModeSameExact || MODE == kModeSameExactLazy;
-  constexpr bool LAZY = MODE == kModeSameLazy || MODE == kModeSameExactLazy;
+                        MODE == kModeSameExactLazy || LAZYG;
+  constexpr bool EXACT = MODE == kModeSameExact || MODE == kModeSameExactLazy || LAZYG;
+  constexpr bool LAZY = MODE == kModeSameLazy || MODE == kModeSameExactLazy || LAZYG;
   constexpr bool RAW = MODE == kModeRaw;
   constexpr int NQ = NCA + NCE - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2343,7 +2501,8 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       // asm loads are invisible to the compiler's vmcnt bookkeeping, which is
       // safe because every counted wait that follows is for YOUNGER loads and
       // the counter retires in order.)
-      const char* gt = reinterpret_cast<const char*>(a.gtab + (long long)b * Py * Px);
+      const char* gt = LAZYG ? reinterpret_cast<const char*>(a.c16 + b * a.c16_stride)
+                             : reinterpret_cast<const char*>(a.gtab + (long long)b * Py * Px);
       const unsigned junk_off = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
           (__attribute__((address_space(3))) float*)touch_junk));
       constexpr int kTouches = (32768 / 16 + kThreads - 1) / kThreads;
@@ -2360,7 +2519,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       for (int k = 0; k < kTouches; ++k) {
         const int i = (threadIdx.x + k * kThreads) * 16;
         bool wanted = i < Py * Px;
-        if (LAZY && a.prune && !a.touch_all) {
+        // (the column-sum tables the table rows are built from: all of them)
+        if (LAZYG) wanted = i < 2 * ((Py >> 4) + 1) * Px + Py + 1;
+        if (!LAZYG && LAZY && a.prune && !a.touch_all) {
           const int yv = min(i / Px, Py - 1), yv2 = min((i + 15) / Px, Py - 1);   // (a line may straddle two rows)
           const unsigned t_mask = (1u << ((yv + Py - 1) >> 4)) | (1u << (max(yv - 1, 0) >> 4)) |
                                   (1u << ((yv2 + Py - 1) >> 4)) | (1u << (max(yv2 - 1, 0) >> 4));
@@ -2971,6 +3132,82 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
           }
         }
       }
+      if constexpr (LAZYG) {
+        // The 16 rows of the correction table this tile's epilogue reads, built here
+        // (the prep kernel of this mode leaves no table): rows yv = 16 Ib + j + 1, j < 16,
+        // Ib = p mod (Py / 16), of
+        //   G[yv][xv] = g_entry( IA'[yv][xv], IB'[Py - yv][Px - xv] ),
+        //   IA'[yv][xv]           = sum_{x < xv} colA[x],  colA = c16[0][Ib] + rows 16 Ib .. yv - 1 of a'
+        //   IB'[Py - yv][Px - xv] = T - sum_{x >= Px - xv} colB[x],
+        //                           colB = c16[1][NB - Ib] - rows Py - yv .. 16 (NB - Ib) - 1 of b'
+        // (a', b': the int8 operand copies in LDS; c16: centred column sums above every
+        // 16th row, prep kernel; T = sum of colB over all columns).  This is the prep
+        // kernel's sweep over 16 rows, run by the wave that needs them: lane l owns the
+        // four columns 4 l .. 4 l + 3 of the pre patch and the MIRRORED columns of the post
+        // patch (one aligned LDS dword per row and side), keeps their running column sums,
+        // and a wave scan over the lane totals gives the exclusive prefixes, so the lane
+        // leaves G[yv][4 l .. 4 l + 3] as one 16-byte store.  The same integers as the
+        // table of the other modes, the same expression (g_entry): the same bits.  The rows
+        // go to this patch's G area, now a scratch that stays in L2: every entry the
+        // epilogue below gathers is stored here by this wave first.
+        int oz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oz) : : "memory");
+        const int NB = Py >> 4;
+        const int Ib = p < NB ? p : p - NB;
+        const int* c16 = a.c16 + b * a.c16_stride;
+        const int l4 = 4 * lane + oz;
+        const bool act = l4 < Px;
+        const int xa = act ? l4 : 0;              // (idle lanes read column 0 and store nothing)
+        const int xb = Px - 4 - xa;               // first of the four mirrored columns
+        v4i ca = *reinterpret_cast<const v4i*>(c16 + Ib * Px + xa);
+        const v4i cbn = *reinterpret_cast<const v4i*>(c16 + (NB + 1 + NB - Ib) * Px + xb);
+        // tile NB - 1: its last row is dy = 0, i.e. yv = 0: IA' = 0 and IB' over ALL rows
+        v4i call = v4i{0, 0, 0, 0};
+        if (p == NB - 1) call = *reinterpret_cast<const v4i*>(c16 + (NB + 1 + NB) * Px + xb);
+        int cb[4] = {cbn[3], cbn[2], cbn[1], cbn[0]};     // mirrored order
+        if (!act) {
+          ca = v4i{0, 0, 0, 0};
+          call = v4i{0, 0, 0, 0};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) cb[k] = 0;
+        }
+        const unsigned char* ap = A_lds + (kPadTop + 16 * Ib) * a.pa + xa;
+        const unsigned char* bp = B_lds + (16 * (NB - Ib) - 1) * a.pb + a.ml + xb;
+        float* Gw = a.gtab + (long long)b * Py * Px + xa;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+          const unsigned da = *reinterpret_cast<const unsigned*>(ap + j * a.pa);
+          const unsigned db = *reinterpret_cast<const unsigned*>(bp - j * a.pb);
+          if (act) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              ca[k] += static_cast<int>(static_cast<signed char>(da >> (8 * k)));
+              cb[k] -= static_cast<int>(static_cast<signed char>(db >> (8 * (3 - k))));
+            }
+          }
+          const bool zero_row = p == NB - 1 && j == 15;      // yv = 0 (wave-uniform)
+          int va[4], vb[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            va[k] = zero_row ? 0 : ca[k];
+            vb[k] = zero_row ? call[3 - k] : cb[k];
+          }
+          const int sa = va[0] + va[1] + va[2] + va[3], sb = vb[0] + vb[1] + vb[2] + vb[3];
+          const int inc_a = wave_scan_incl(sa), inc_b = wave_scan_incl(sb);
+          const int tb = __builtin_amdgcn_readlane(inc_b, 63);   // T = IB'[Py - yv][Px]
+          int ia = inc_a - sa, ib = tb - (inc_b - sb);
+          v4i out;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            out[k] = __float_as_int(g_entry(mua, mub, static_cast<float>(ia), static_cast<float>(ib)));
+            ia += va[k];
+            ib -= vb[k];
+          }
+          const int yv = zero_row ? 0 : 16 * Ib + j + 1;
+          // (row 15 of the last tile is padding: there is no row yv = Py)
+          if (act && yv < Py) *reinterpret_cast<v4i*>(Gw + yv * Px) = out;
+        }
+      }
       // The epilogue's table addresses do not depend on the MFMA loop; without
       // this opaque zero the compiler hoists its ~100 gathers above the loop
       // and spills the accumulators.  After the loop there are >140 free VGPRs,
@@ -3523,6 +3760,8 @@ bool same_size(const SfmXcorrDesc* d) {
 }
 
 struct Ws {
+  int* c16;
+  long long c16_stride;
   PatchParams* pp;
   int* integ[2];
   long long stride[2];
@@ -3546,6 +3785,10 @@ Ws carve_ws(const SfmXcorrDesc* d, void* base) {
     w.gtab = c.take<float>(B * d->patch[1] * d->patch[2]);
     w.aux = c.take<float>(B * (4 * w.aux_n + 4));
     w.tbound = c.take<float>(B * kBoundStride);
+    // column sums above every 16th row + row-sum prefixes (kModeSameExactLazyG)
+    w.c16_stride = 2LL * (d->patch[1] / 16 + 1) * d->patch[2] + d->patch[1] + 1;
+    w.c16_stride = (w.c16_stride + 63) / 64 * 64;
+    w.c16 = c.take<int>(B * (size_t)w.c16_stride);
   } else {
     w.stride[0] = (long long)(d->patch[1] + 1) * (d->patch[2] + 1);
     w.stride[1] = (long long)(d->post_patch[1] + 1) * (d->post_patch[2] + 1);
@@ -3612,6 +3855,7 @@ int launch_variant(const MfmaArgs& a, int mode, int grid, size_t lds,
     case kModeSameExact: return launch_one<NCA, NCE, kModeSameExact>(a, grid, lds, st);
     case kModeSameLazy: return launch_one<NCA, NCE, kModeSameLazy>(a, grid, lds, st);
     case kModeSameExactLazy: return launch_one<NCA, NCE, kModeSameExactLazy>(a, grid, lds, st);
+    case kModeSameExactLazyG: return launch_one<NCA, NCE, kModeSameExactLazyG>(a, grid, lds, st);
     case kModeRaw: return launch_one<NCA, NCE, kModeRaw>(a, grid, lds, st);
     default: return launch_one<NCA, NCE, kModeGeneral>(a, grid, lds, st);
   }
@@ -3800,6 +4044,8 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   a.integ_stride[0] = w.stride[0];
   a.integ_stride[1] = w.stride[1];
   a.gtab = w.gtab;
+  a.c16 = w.c16;
+  a.c16_stride = w.c16_stride;
   a.aux = w.aux;
   a.aux_n = w.aux_n;
   a.surface = surface;
@@ -3874,6 +4120,23 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
               a.guard >= 0;
   }
   if (!a.tbound) a.tbound = w.tbound;  // read (not used) by every same-size launch
+  const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
+  // lazy surface stores: the flow path only (fused peak search: nobody else
+  // reads the surface), tile masks of 31 bits, SFM_MFMA_LAZY=0 switches it off
+  bool lazy = same && fp != nullptr && a.n_order <= 31 && a.skipmask != nullptr;
+  {
+    const char* e = sfm::option("SFM_MFMA_LAZY");
+    if (e && e[0] == '0') lazy = false;
+  }
+  // The correction table built in the epilogue of the tiles that are stored instead
+  // of by the prep kernel (kModeSameExactLazyG): pays where few tiles reach an
+  // epilogue, i.e. with the pruning on (the un-pruned launch, every tile finished,
+  // keeps the table).  SFM_MFMA_LAZYG=0: off.
+  {
+    const char* e = sfm::option("SFM_MFMA_LAZYG");
+    a.lazy_g = exact && lazy && a.prune && !(e && e[0] == '0') && a.P[0] % 16 == 0 &&
+               a.P[0] <= 160 && a.P[1] <= 160 && a.P[0] >= 32;
+  }
   // Region behind the patches: the four 1-D correction arrays, reused as the
   // arg-max scratch of the fused peak search, then the running-max word.
   size_t r_bytes = same ? (size_t)4 * w.aux_n * 4 : 0;
@@ -3899,16 +4162,9 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   SFM_LAUNCH_CHECK();
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 48 + 128 + 160 + 128;
   const int grid = d->batch;  // capped to the resident workgroups in launch_one
-  const bool exact = same && d->patch[2] == 16 * kVariants[vi].nca && exact_enabled();
-  // lazy surface stores: the flow path only (fused peak search: nobody else
-  // reads the surface), tile masks of 31 bits, SFM_MFMA_LAZY=0 switches it off
-  bool lazy = same && fp != nullptr && a.n_order <= 31 && a.skipmask != nullptr;
-  {
-    const char* e = sfm::option("SFM_MFMA_LAZY");
-    if (e && e[0] == '0') lazy = false;
-  }
   const int mode = !same ? kModeGeneral
-                   : exact ? (lazy ? kModeSameExactLazy : kModeSameExact)
+                   : exact ? (a.lazy_g ? kModeSameExactLazyG
+                                       : lazy ? kModeSameExactLazy : kModeSameExact)
                            : (lazy ? kModeSameLazy : kModeSame);
   if (int rc = launch_mode(vi, a, mode, grid, lds, st)) return rc;
   if (fp) {
