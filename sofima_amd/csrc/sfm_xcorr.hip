@@ -588,7 +588,7 @@ struct PeakArgs {
   // masked matrix-core path: rows whose largest possible overlap ny * Qx is below
   // 0.3 x the batch maximum of the overlap are zero (flow_field.py:151-155); the
   // large-surface sweeps leave them out
-  const unsigned int* live_ovmax;  // float bits of the batch maximum of the overlap, or NULL
+  const unsigned int* live_ovmax;  // [groups, 2] (+1): float bits of the batch maximum of the overlap, or NULL
   int live_py, live_qy, live_qx;
 };
 
@@ -777,11 +777,12 @@ __device__ __forceinline__ float ord_float(unsigned o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-__device__ __forceinline__ void chunk_rows(const PeakArgs& p, int* r0, int* r1) {
+__device__ __forceinline__ void chunk_rows(const PeakArgs& p, int b, int* r0, int* r1) {
   int lo = 0, hi = p.S[0] * p.S[1];
   if (p.live_ovmax && p.S[0] == 1) {
     // ny(ky) rises to min(Py, Qy) and falls again: the live rows are one range
-    const float thr = 0.3f * __uint_as_float(*p.live_ovmax);
+    // (two maxima per reference batch: denominator, overlap)
+    const float thr = 0.3f * __uint_as_float(p.live_ovmax[2 * (b / p.group)]);
     auto dead = [&](int ky) {
       const int dy = ky - (p.live_qy - 1);
       const int ny = min(p.live_py, p.live_qy + dy) - max(0, dy);
@@ -801,7 +802,7 @@ __global__ void __launch_bounds__(kBlock) peaks_max_kernel(PeakArgs p) {
   __shared__ int li[kBlock];
   const int b = blockIdx.y;
   int r0, r1;
-  chunk_rows(p, &r0, &r1);
+  chunk_rows(p, b, &r0, &r1);
   const float mx = surface_max(p.surf + b * p.bstride, p, lv, li, r0, r1);
   if (threadIdx.x == 0 && r1 > r0) atomicMax(&p.smax[b], ord_bits(mx));
 }
@@ -812,7 +813,7 @@ __global__ void __launch_bounds__(kBlock) peaks_scan_kernel(PeakArgs p) {
   const int b = blockIdx.y;
   const float* s = p.surf + b * p.bstride;
   int r0, r1;
-  chunk_rows(p, &r0, &r1);
+  chunk_rows(p, b, &r0, &r1);
   const float thr = p.threshold_rel * ord_float(p.smax[b]);
   float bv = -INFINITY;
   int bi = 0x7fffffff;
@@ -1107,7 +1108,10 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
   if (use_mfma(d)) {
     const size_t n = sfm::mfma_i8_workspace_bytes(d);
     w.mfma = c.take<char>(n);
-    if (masked) w.maxima = c.take<unsigned int>(2);
+    if (masked) {  // two maxima per reference batch of the call
+      const size_t rows = d->group > 0 && d->group < d->batch ? d->group : d->batch;
+      w.maxima = c.take<unsigned int>(2 * ((B + rows - 1) / rows));
+    }
   } else {
     w.a0 = c.take<float>(B * g.Pn);
     w.b0 = c.take<float>(B * g.Qn);
@@ -1262,16 +1266,36 @@ int group_rows(const SfmXcorrDesc* d) {
 }
 
 // The fused MFMA path keeps the coupled state per group and takes any number
-// of groups in one launch; every other path runs group by group.
+// of groups in one launch; the masked matrix-core path keeps its maxima per group
+// and takes kMaskedGroups groups per round of launches (its product surfaces are
+// 4 GB per 1024 patches of 160^2; SFM_MASKED_GROUPS); every other path runs group
+// by group.
+constexpr int kMaskedGroups = 8;
+
+int masked_groups() {
+  const char* e = sfm::option("SFM_MASKED_GROUPS");
+  const int n = e ? std::atoi(e) : kMaskedGroups;
+  return n < 1 ? 1 : n;
+}
+
 bool one_launch(const SfmXcorrDesc* d) {
   return group_rows(d) == d->batch || (use_mfma(d) && !is_masked(d));
 }
 
-SfmXcorrDesc sub_desc(const SfmXcorrDesc* d, int off) {
+// Rows of one round of launches of sfm_xcorr_peaks (a multiple of the group).
+long long call_rows(const SfmXcorrDesc* d) {
+  if (one_launch(d)) return d->batch;
+  const long long rows = group_rows(d);
+  if (use_mfma(d) && is_masked(d))
+    return std::min<long long>(d->batch, rows * masked_groups());
+  return rows;
+}
+
+SfmXcorrDesc sub_desc(const SfmXcorrDesc* d, int off, long long rows = 0) {
   SfmXcorrDesc sub = *d;
-  const int rows = group_rows(d);
-  sub.batch = d->batch - off < rows ? d->batch - off : rows;
-  sub.group = 0;
+  if (rows <= 0) rows = group_rows(d);
+  sub.batch = static_cast<int>(d->batch - off < rows ? d->batch - off : rows);
+  sub.group = rows > group_rows(d) ? group_rows(d) : 0;
   sub.pre_starts = d->pre_starts + (long long)off * d->ndim;
   sub.post_starts = d->post_starts + (long long)off * d->ndim;
   return sub;
@@ -1361,9 +1385,10 @@ size_t sfm_xcorr_workspace_bytes(const SfmXcorrDesc* d) {
   if (use_fft(d) && sfm::fft_check(d) != SFM_OK) return 0;   // message in sfm_last_error
   SfmXcorrDesc tmp = *d;
   tmp.workspace = nullptr;
-  if (!one_launch(d)) {  // run group by group: scratch for one group
-    tmp.batch = group_rows(d);
-    tmp.group = 0;
+  if (!one_launch(d)) {  // run group by group: scratch for one round of launches
+    const long long rows = call_rows(d);
+    tmp.batch = static_cast<int>(rows);
+    tmp.group = rows > group_rows(d) ? group_rows(d) : 0;
   }
   return carve_xcorr(&tmp, g, true, true).bytes;
 }
@@ -1388,9 +1413,10 @@ int sfm_xcorr_peaks(const SfmXcorrDesc* d, float* peaks) {
   Geo g;
   if (int rc = make_geo(d, &g)) return rc;
   if (one_launch(d)) return peaks_one(d, g, peaks);
-  for (int off = 0; off < d->batch; off += group_rows(d)) {
-    const SfmXcorrDesc sub = sub_desc(d, off);
-    if (int rc = peaks_one(&sub, g, peaks + (long long)off * (d->ndim + 2))) return rc;
+  const long long rows = call_rows(d);
+  for (long long off = 0; off < d->batch; off += rows) {
+    const SfmXcorrDesc sub = sub_desc(d, static_cast<int>(off), rows);
+    if (int rc = peaks_one(&sub, g, peaks + off * (d->ndim + 2))) return rc;
   }
   return SFM_OK;
 }

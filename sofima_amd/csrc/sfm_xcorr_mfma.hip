@@ -215,7 +215,8 @@ struct MfmaArgs {
   const int* n_list;
   // a' * b' pass of the masked path: lower bound of the batch maximum of the overlap
   // (masked_classify_kernel); row tiles below 0.3 x it are zeroed by the overlap rule
-  const int* ov_lb;
+  const int* ov_lb;   // [groups]
+  int ov_group;       // patches per reference batch (maxima are per batch)
   long long s_stride; // padded surface: floats per patch = 16 * NP * sx_pitch
   // dynamic patch queue (NULL: static striding over the workgroups)
   int* work_counter;
@@ -1443,7 +1444,9 @@ struct MaskedFastArgs {
   int all_passes;       // test switch: every patch takes the eight passes (class 3)
   int dead_rows;        // final phase: skip rows below the overlap threshold (SFM_MASKED_DEADROWS=0: off)
   int row_blocks;       // workgroups per surface in the assembly kernels
-  unsigned int* maxima;
+  int group;            // patches per reference batch: maxima / ov_lb are per batch
+  int* ov_lb;           // [groups] lower bound of the batch maximum of the overlap
+  unsigned int* maxima; // [groups, 2]
   float* out;           // [batch, elems] final normalised surface
   unsigned int* smax;   // [batch] or NULL: per-surface maximum (ordered bits)
 };
@@ -1488,19 +1491,12 @@ __global__ void __launch_bounds__(1024) masked_classify_kernel(MaskedFastArgs g)
   // at the zero shift a same-size patch pair overlaps in at least
   // nvalid_A + nvalid_B - Py Px pixels (= Py Px for a clean pair).  The raw pass of
   // a' * b' uses it to leave out row tiles that the overlap rule zeroes anyway.
-  int lb = 0;
+  // One bound per reference batch (`group` patches; zeroed by the host).
   if (g.P[0] == g.Q[0] && g.P[1] == g.Q[1])
-    for (int b = threadIdx.x; b < g.batch; b += 1024)
-      lb = max(lb, g.nvalid[2 * b] + g.nvalid[2 * b + 1] - g.P[0] * g.P[1]);
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) lb = max(lb, __shfl_xor(lb, d, 64));
-  __syncthreads();
-  if (lane == 0) wsum[wave] = lb;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) lb = max(lb, wsum[w]);
-    g.n_items[1] = lb;
-  }
+    for (int b = threadIdx.x; b < g.batch; b += 1024) {
+      const int lb = g.nvalid[2 * b] + g.nvalid[2 * b + 1] - g.P[0] * g.P[1];
+      if (lb > 0) atomicMax(&g.ov_lb[b / g.group], lb);
+    }
 }
 
 // Inclusive integral images T[y][x] = sum over rows <= y, columns <= x of the
@@ -1825,8 +1821,8 @@ __device__ __forceinline__ void phase_finish(const MaskedFastArgs& g, int b,
       float m = red[threadIdx.x][0];
       for (int w = 1; w < kWaves; ++w) m = fmaxf(m, red[threadIdx.x][w]);
       const unsigned bits = __float_as_uint(m);
-      if (bits > __atomic_load_n(&g.maxima[threadIdx.x], __ATOMIC_RELAXED))
-        atomicMax(&g.maxima[threadIdx.x], bits);
+      unsigned int* mx = g.maxima + 2 * (b / g.group) + threadIdx.x;
+      if (bits > __atomic_load_n(mx, __ATOMIC_RELAXED)) atomicMax(mx, bits);
     }
   }
 }
@@ -1847,8 +1843,9 @@ __global__ void __launch_bounds__(kThreads) masked_phase_kernel(MaskedFastArgs g
   const int cls = g.cls[b];
   float tol = 0.f, px_thr = 0.f;
   if (FINAL) {
-    tol = 1e3f * 1.1920928955078125e-07f * __uint_as_float(g.maxima[0]);
-    px_thr = 0.3f * __uint_as_float(g.maxima[1]);
+    const unsigned int* mx = g.maxima + 2 * (b / g.group);
+    tol = 1e3f * 1.1920928955078125e-07f * __uint_as_float(mx[0]);
+    px_thr = 0.3f * __uint_as_float(mx[1]);
   }
   PhaseOut po = {0.f, 0.f, -INFINITY};
   if (cls == 3) return;  // masked_phase3_kernel
@@ -1873,8 +1870,9 @@ __global__ void __launch_bounds__(kThreads) masked_phase3_kernel(MaskedFastArgs 
   const int Sy = g.S[0], Sx = g.S[1];
   float tol = 0.f, px_thr = 0.f;
   if (FINAL) {
-    tol = 1e3f * 1.1920928955078125e-07f * __uint_as_float(g.maxima[0]);
-    px_thr = 0.3f * __uint_as_float(g.maxima[1]);
+    const unsigned int* mx = g.maxima + 2 * (b / g.group);
+    tol = 1e3f * 1.1920928955078125e-07f * __uint_as_float(mx[0]);
+    px_thr = 0.3f * __uint_as_float(mx[1]);
   }
   const long long e0 = (long long)row_block * kWaves * kAsmRowsPerWave * g.pitch;
   const int n4 = static_cast<int>(
@@ -2634,7 +2632,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         const int ky0 = 16 * p, ky1 = min(16 * p + 15, Sy - 1);
         const int dyc = min(max(min(max(0, ky0 - (Qy - 1)), Py - Qy), ky0 - (Qy - 1)), ky1 - (Qy - 1));
         const int ny_max = min(Py, Qy + dyc) - max(0, dyc);
-        const int lb = __builtin_amdgcn_readfirstlane(*a.ov_lb);
+        const int lb = __builtin_amdgcn_readfirstlane(a.ov_lb[b / a.ov_group]);
         const float ov_thr = 0.3f * static_cast<float>(lb);
         if (static_cast<float>(ny_max * Qx) < ov_thr) continue;
         // the same along x: outer column tiles whose widest overlap nx, times
@@ -3963,7 +3961,8 @@ bool masked_all_passes() {
 
 struct MaskedWs {
   PatchParams* pp;
-  int *nvalid, *cls, *first, *items, *n_items, *tab, *raw0, *rawd;
+  int *nvalid, *cls, *first, *items, *n_items, *ov_lb, *tab, *raw0, *rawd;
+  int group, n_groups;
   long long tab_elems, raw_stride;
   size_t bytes;
 };
@@ -3981,6 +3980,10 @@ MaskedWs carve_masked(const SfmXcorrDesc* d, void* base) {
   w.first = c.take<int>(B);
   w.items = c.take<int>(7 * B);
   w.n_items = c.take<int>(16);
+  // reference batches in this call: the tolerances are maxima over a batch
+  w.group = d->group > 0 && d->group < d->batch ? d->group : d->batch;
+  w.n_groups = (d->batch + w.group - 1) / w.group;
+  w.ov_lb = c.take<int>(w.n_groups);
   // + 64 ints: consecutive tables (and product surfaces below) of a patch are read
   // together; strides that are multiples of 4 KB would put them on one memory channel
   w.tab_elems = (long long)d->patch[1] * d->patch[2] + 64;
@@ -4179,8 +4182,9 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
 // batch-global maxima the finalize step needs (flow_field.py:137, 151).
 // Masked (Padfield) correlation on the matrix cores: writes the normalised
 // surface, padded to whole tiles [batch, rows, pitch]; `maxima` = scratch for
-// the batch maxima (flow_field.py:137, 151); `smax` (optional, zeroed by the
-// caller) receives the ordered bits of every surface maximum.
+// the batch maxima (flow_field.py:137, 151), two words per reference batch
+// (`d->group` patches); `smax` (optional, zeroed by the caller) receives the
+// ordered bits of every surface maximum.
 int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
                    unsigned int* maxima, unsigned int* smax) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
@@ -4200,7 +4204,8 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
   hipLaunchKernelGGL(mfma_prep_masked_kernel, dim3(d->batch, 2), dim3(kThreads), 0,
                      st, a);
   SFM_LAUNCH_CHECK();
-  SFM_HIP_CHECK(hipMemsetAsync(maxima, 0, 2 * sizeof(unsigned int), st));
+  SFM_HIP_CHECK(hipMemsetAsync(maxima, 0, 2 * w.n_groups * sizeof(unsigned int), st));
+  SFM_HIP_CHECK(hipMemsetAsync(w.ov_lb, 0, w.n_groups * sizeof(int), st));
   size_t r_bytes = (size_t)kThreads * 8;
   a.r_bytes = static_cast<int>(r_bytes);
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16;
@@ -4242,6 +4247,8 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
     g.xcd_map = !(e && e[0] == '0');
   }
   g.maxima = maxima;
+  g.group = w.group;
+  g.ov_lb = w.ov_lb;
   g.out = surface;
   g.smax = smax;
   const int rows_per_wg = kWaves * kAsmRowsPerWave;
@@ -4253,7 +4260,8 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
   c.plane[0] = kMaskedPasses[0][0];
   c.plane[1] = kMaskedPasses[0][1];
   c.raw_out = w.raw0;
-  c.ov_lb = g.dead_rows ? w.n_items + 1 : nullptr;
+  c.ov_lb = g.dead_rows ? w.ov_lb : nullptr;
+  c.ov_group = w.group;
   if (int rc = launch_mode(vi, c, kModeRaw, d->batch, lds, st)) return rc;
   c.ov_lb = nullptr;  // the other products feed the maxima of every element
   c.raw_out = w.rawd;

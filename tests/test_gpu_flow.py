@@ -943,6 +943,35 @@ def test_masked_flow_mostly_clean_vs_oracle(gpu, monkeypatch):
   check_flow(got, want)
 
 
+def test_masked_groups_per_round_do_not_change_the_field(gpu, monkeypatch):
+  """The masked matrix-core path runs several reference batches per round of
+  launches (maxima, overlap bounds and peak bitmaps are kept per batch):
+  bit-identical to one batch per round, for ragged last batches and for a
+  mean given by the caller."""
+  from sofima_amd import flow_field
+  pre, post = _em_pair(33, 700, 760, warp=2.0)
+  rng = np.random.default_rng(5)
+  pre_mask = np.zeros(pre.shape, bool)
+  pre_mask[200:330, 250:420] = True
+  pre_mask |= rng.random(pre.shape) < 0.002
+  post_mask = np.zeros(post.shape, bool)
+  post_mask[400:520, 100:300] = True
+  calc = flow_field.JAXMaskedXCorrWithStatsCalculator()
+  for bs, mean in ((16, None), (25, 120.0)):
+    kw = dict(pre_mask=pre_mask, post_mask=post_mask, batch_size=bs,
+              mask_only_for_patch_selection=False, max_masked=1.01)
+    if mean is not None:
+      calc = flow_field.JAXMaskedXCorrWithStatsCalculator(mean=mean)
+    monkeypatch.setenv('SFM_MASKED_GROUPS', '1')
+    one = calc.flow_field(pre, post, 160, 40, **kw)
+    for n in ('3', '8'):
+      monkeypatch.setenv('SFM_MASKED_GROUPS', n)
+      np.testing.assert_array_equal(calc.flow_field(pre, post, 160, 40, **kw), one)
+    monkeypatch.delenv('SFM_MASKED_GROUPS')
+    np.testing.assert_array_equal(calc.flow_field(pre, post, 160, 40, **kw), one)
+    assert np.isfinite(one[:2]).mean() > 0.5
+
+
 def _prune_images(kind, seed, h, w):
   """Image pairs that stress the tile pruning in different ways."""
   from scipy import ndimage
