@@ -131,6 +131,10 @@ def main():
                        'communicator from a broadcast id, the watchdog) execute on a '
                        'single-GPU box; the banded mesh runs 2 local bands through '
                        'RCCL self send / recv')
+  ap.add_argument('--aux-leg', default=None, metavar='LEG',
+                  help='run ONE leg of aux_rooflines (1 warm-up + its timed calls) and '
+                       'exit: the process rocprofv3 --pmc counts for that leg\'s '
+                       '`traffic` (tools/measure/pmc_aux.sh)')
   ap.add_argument('--mesh-sharded', type=int, default=0, metavar='BANDS',
                   help='extra leg: one [2,64,204,204] mesh split into BANDS bands '
                        'per rank, stepped by the C-side banded loop (RCCL halo '
@@ -151,6 +155,12 @@ def main():
   import torch
   import torch.distributed as dist
   from sofima_amd import _abi, flow_field, mesh
+
+  if args.aux_leg:
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    print(json.dumps({'aux_leg': aux_legs(dev, args.seed, only=args.aux_leg)}), flush=True)
+    return
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -580,17 +590,31 @@ def main():
       pass
 
 
-def aux_legs(dev, seed):
+AUX_TRAFFIC_FILE = 'r05_pmc_traffic_aux.json'
+
+
+def aux_legs(dev, seed, only=None):
   """HBM roofline lines of the other kernels of the path, wall-clock timed with
   the inputs resident (a few hundred ms each): the FFT form of the correlation
   (float images: flow_field.py:374-441 with method 3; 3-D patches) and the
   volumetric / large in-plane mesh steps (mesh.py:192-279, 383-513).
   `achieved` = ALGORITHMIC bytes / time: each input patch pixel read once and
   the peak statistics written (FFT form); x, v, a read and written and prev
-  read once per node update (mesh: 14 floats in-plane, 21 volumetric)."""
+  read once per node update (mesh: 14 floats in-plane, 21 volumetric).
+  `traffic` = HBM bytes of ONE call of the leg (all its launches) from separate
+  rocprofv3 --pmc passes of `bench.py --aux-leg LEG` (tools/measure/pmc_aux.sh ->
+  profiles/r05_pmc_traffic_aux.json), taken only when that file was measured on
+  the library that is loaded now; `only`: run that one leg (the counted process)."""
   import torch
   from sofima_amd import _abi, flow_field, mesh
   out = []
+  measured = {}
+  try:
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', AUX_TRAFFIC_FILE)))
+    if pmc.get('_meta', {}).get('git_sha') == build_sha():
+      measured = pmc
+  except (OSError, ValueError):
+    pass
 
   def timed(fn, reps):
     fn()
@@ -601,38 +625,48 @@ def aux_legs(dev, seed):
     torch.cuda.synchronize(dev)
     return (time.perf_counter() - t) / reps
 
-  def line(name, kernel, nbytes, sec, **extra):
+  def line(name, kernel, nbytes, sec, calls, **extra):
     gbs = nbytes / sec / 1e9
     o = {'leg': name, 'kernel': kernel, 'bound': 'hbm', 'achieved': round(gbs, 1),
          'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-         'ms': round(sec * 1e3, 3), 'traffic': None}
+         'ms': round(sec * 1e3, 3), 'traffic': None, 'calls_in_counted_process': calls}
+    m = measured.get(name)
+    if m:
+      o['traffic'] = int(m['hbm_bytes_per_call'])
+      o['traffic_over_algorithmic'] = round(m['hbm_bytes_per_call'] / nbytes, 2)
+      o['traffic_gbs'] = round(m['hbm_bytes_per_call'] / sec / 1e9, 1)
+      o['traffic_source'] = 'profiles/' + AUX_TRAFFIC_FILE
     o.update(extra)
     out.append(o)
 
   rng = np.random.default_rng(seed)
-  # FFT form, in-plane: float32 2048^2 pair, patch 160 step 40 -> 48 x 48 patches
-  n2 = 2048
-  a = torch.from_numpy(rng.random((n2, n2), dtype=np.float32)).to(dev)
-  b = torch.roll(a, (2, -3), (0, 1)).contiguous()
-  calc = flow_field.JAXMaskedXCorrWithStatsCalculator(method=_abi.XCORR_FFT)
-  sec = timed(lambda: calc.flow_field(a, b, PATCH, STEP, batch_size=BATCH), 3)
-  np2 = ((n2 - PATCH) // STEP + 1) ** 2
-  line('xcorr_fft_2d', 'fft_pencil / fft_xfwd / fft_xinv (sfm_fft_own.hip)',
-       np2 * (2 * PATCH * PATCH * 4 + 16), sec, patches=np2,
-       workload='float32 2048^2 pair, patch 160 step 40, FFT form')
-  # FFT form, volumetric: 160^3 pair, patch 80 step 40 -> 3^3 patches
-  v = torch.from_numpy(rng.random((160, 160, 160), dtype=np.float32)).to(dev)
-  w = torch.roll(v, (1, -2, 2), (0, 1, 2)).contiguous()
-  calc3 = flow_field.JAXMaskedXCorrWithStatsCalculator()
-  sec = timed(lambda: calc3.flow_field(v, w, (80, 80, 80), (40, 40, 40), batch_size=64), 3)
-  line('xcorr_fft_3d', 'fft3 kernels (sfm_fft_own.hip)', 27 * (2 * 80 ** 3 * 4 + 20), sec,
-       patches=27, workload='float32 160^3 pair, patch 80^3 step 40 (BASELINE configs[4] patch size)')
+  if only in (None, 'xcorr_fft_2d'):
+    # FFT form, in-plane: float32 2048^2 pair, patch 160 step 40 -> 48 x 48 patches
+    n2 = 2048
+    a = torch.from_numpy(rng.random((n2, n2), dtype=np.float32)).to(dev)
+    b = torch.roll(a, (2, -3), (0, 1)).contiguous()
+    calc = flow_field.JAXMaskedXCorrWithStatsCalculator(method=_abi.XCORR_FFT)
+    sec = timed(lambda: calc.flow_field(a, b, PATCH, STEP, batch_size=BATCH), 3)
+    np2 = ((n2 - PATCH) // STEP + 1) ** 2
+    line('xcorr_fft_2d', 'fft_pencil / fft_xfwd / fft_xinv (sfm_fft_own.hip)',
+         np2 * (2 * PATCH * PATCH * 4 + 16), sec, 4, patches=np2,
+         workload='float32 2048^2 pair, patch 160 step 40, FFT form')
+  if only in (None, 'xcorr_fft_3d'):
+    # FFT form, volumetric: 160^3 pair, patch 80 step 40 -> 3^3 patches
+    v = torch.from_numpy(rng.random((160, 160, 160), dtype=np.float32)).to(dev)
+    w = torch.roll(v, (1, -2, 2), (0, 1, 2)).contiguous()
+    calc3 = flow_field.JAXMaskedXCorrWithStatsCalculator()
+    sec = timed(lambda: calc3.flow_field(v, w, (80, 80, 80), (40, 40, 40), batch_size=64), 3)
+    line('xcorr_fft_3d', 'fft3 kernels (sfm_fft_own.hip)', 27 * (2 * 80 ** 3 * 4 + 20), sec, 4,
+         patches=27, workload='float32 160^3 pair, patch 80^3 step 40 (BASELINE configs[4] patch size)')
   # mesh steps: FIRE, 200 iterations of one chunk
   iters = 200
   for name, shape, force, stride, fl in (
       ('mesh_3d', (3, 4, 100, 100, 100), mesh.elastic_mesh_3d, (40, 40, 40), 21),
       ('mesh_2d_large', (2, 4, 2048, 2048), None, (40, 40), 14),
       ('mesh_2d_montage_size', (2, 64, 204, 204), None, (40, 40), 14)):
+    if only not in (None, name):
+      continue
     prev = torch.from_numpy((rng.standard_normal(shape) * 3).astype(np.float32)).to(dev)
     x0 = torch.zeros_like(prev)
     cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=stride,
@@ -642,7 +676,7 @@ def aux_legs(dev, seed):
     sec = timed(lambda: mesh.relax_mesh(x0, prev, cfg, **kw), 2)
     nodes = int(np.prod(shape[1:]))
     line(name, 'integrate_kernel<3>' if force is not None else 'integrate_shared2d_kernel',
-         nodes * iters * fl * 4, sec, nodes=nodes, us_per_step=round(sec / iters * 1e6, 2),
+         nodes * iters * fl * 4, sec, 3, nodes=nodes, us_per_step=round(sec / iters * 1e6, 2),
          node_updates_per_s=round(nodes * iters / sec, 0), state=list(shape),
          bytes_per_node_update=fl * 4)
     del prev, x0
