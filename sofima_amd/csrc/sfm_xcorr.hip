@@ -42,7 +42,9 @@ int fft_correlate(const SfmXcorrDesc* d, const float* a0, const float* b0,
 // (optional, zeroed by the caller) receives the ordered bits of every surface
 // maximum for the peak search.
 int mfma_i8_masked(const SfmXcorrDesc* d, void* ws, float* surface,
-                   unsigned int* maxima, unsigned int* smax);
+                   unsigned int* maxima, unsigned int* smax, float* blkmax);
+// rows per block of `blkmax` (the assembly workgroups take 4 waves x 8 rows)
+constexpr int kMaskedBlkRows = 32;
 }  // namespace sfm
 
 namespace {
@@ -589,6 +591,9 @@ struct PeakArgs {
   // 0.3 x the batch maximum of the overlap are zero (flow_field.py:151-155); the
   // large-surface sweeps leave them out
   const unsigned int* live_ovmax;  // [groups, 2] (+1): float bits of the batch maximum of the overlap, or NULL
+  // masked matrix-core path: maximum of every block of blk_rows surface rows, or NULL
+  const float* blkmax;
+  int blk_rows, blk_n;
   int live_py, live_qy, live_qx;
 };
 
@@ -810,14 +815,16 @@ __global__ void __launch_bounds__(kBlock) peaks_max_kernel(PeakArgs p) {
 __global__ void __launch_bounds__(kBlock) peaks_scan_kernel(PeakArgs p) {
   __shared__ float lv[kBlock];
   __shared__ int li[kBlock];
-  const int b = blockIdx.y;
+  // (with block maxima most surfaces cost a handful of loads: a workgroup walks
+  // several of them, or the launch is bound by the workgroup dispatch rate)
+  for (int b = blockIdx.y; b < p.batch; b += gridDim.y) {
   const float* s = p.surf + b * p.bstride;
   int r0, r1;
   chunk_rows(p, b, &r0, &r1);
   const float thr = p.threshold_rel * ord_float(p.smax[b]);
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for_each_peak(s, p, thr, [&](int i, float v) {
+  auto found = [&](int i, float v) {
     if (better(v, i, bv, bi)) {
       bv = v;
       bi = i;
@@ -828,11 +835,28 @@ __global__ void __launch_bounds__(kBlock) peaks_scan_kernel(PeakArgs p) {
       p.cand_idx[(long long)b * kCandCap + slot] = i;
     }
     if (i == 0) p.zero_is_peak[b] = 1;
-  }, r0, r1);
+  };
+  if (p.blkmax) {
+    // a peak exceeds thr: blocks of rows whose maximum does not are not read
+    // (lane k of every wave looks at block k: one round trip for the whole list)
+    const int lane = threadIdx.x & 63;
+    const int kc = min(lane, p.blk_n - 1);
+    const bool hot = p.blkmax[(long long)b * p.blk_n + kc] > thr && lane < p.blk_n &&
+                     lane * p.blk_rows < r1 && (lane + 1) * p.blk_rows > r0;
+    unsigned long long todo = __ballot(hot);
+    while (todo) {
+      const int k = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      for_each_peak(s, p, thr, found, max(r0, k * p.blk_rows), min(r1, (k + 1) * p.blk_rows));
+    }
+  } else {
+    for_each_peak(s, p, thr, found, r0, r1);
+  }
   block_argmax(&bv, &bi, lv, li);
   if (threadIdx.x == 0 && bv != -INFINITY)
     atomicMax(&p.best[b], (static_cast<unsigned long long>(ord_bits(bv)) << 32) |
                               (0xffffffffu - static_cast<unsigned>(bi)));
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) peaks_first_finish_kernel(PeakArgs p) {
@@ -971,6 +995,7 @@ struct PeakWs {
   unsigned int* bitmap;
   int group, bitmap_words;
   unsigned int* smax;
+  float* blkmax;       // masked MFMA path only: [batch, kBlkMaxN]
   unsigned long long* best;
   int* hot_count;      // fused MFMA path only
   int* skipmask;       // fused MFMA path: pruned row tiles per surface
@@ -980,9 +1005,12 @@ struct PeakWs {
   size_t bytes;
 };
 
+constexpr int kBlkMaxN = 16;   // blocks of sfm::kMaskedBlkRows rows: surfaces up to 512 rows
+
 PeakWs carve_peaks(sfm::Carver& c, int batch, long long sn, bool hot = false,
-                   int group = 0) {
+                   int group = 0, bool blk = false) {
   PeakWs w;
+  w.blkmax = blk ? c.take<float>((size_t)batch * kBlkMaxN) : nullptr;
   w.group = group > 0 && group < batch ? group : batch;
   w.bitmap_words = static_cast<int>((sn + 31) / 32);
   w.idx1 = c.take<int>(batch);
@@ -1012,8 +1040,11 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
               int min_distance, float threshold_rel, const int* radius,
               float* out, hipStream_t st, bool first_pass_done = false,
               bool smax_done = false, const unsigned int* live_ovmax = nullptr,
-              const int* live_geo = nullptr) {
+              const int* live_geo = nullptr, bool use_blkmax = false) {
   PeakArgs p;
+  p.blkmax = use_blkmax ? w.blkmax : nullptr;
+  p.blk_rows = sfm::kMaskedBlkRows;
+  p.blk_n = (S[1] + sfm::kMaskedBlkRows - 1) / sfm::kMaskedBlkRows;
   p.live_ovmax = live_ovmax;
   p.live_py = live_geo ? live_geo[0] : 0;
   p.live_qy = live_geo ? live_geo[1] : 0;
@@ -1056,7 +1087,10 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
           std::min<long long>(rows, 1024), std::max<long long>(1, sn >> 15)));
       if (!smax_done)
         hipLaunchKernelGGL(peaks_max_kernel, dim3(chunks, batch), dim3(kBlock), 0, st, p);
-      hipLaunchKernelGGL(peaks_scan_kernel, dim3(chunks, batch), dim3(kBlock), 0, st, p);
+      if (p.blkmax)   // one workgroup per surface, at most 4096 of them
+        hipLaunchKernelGGL(peaks_scan_kernel, dim3(1, std::min(batch, 4096)), dim3(kBlock), 0, st, p);
+      else
+        hipLaunchKernelGGL(peaks_scan_kernel, dim3(chunks, batch), dim3(kBlock), 0, st, p);
       hipLaunchKernelGGL(peaks_first_finish_kernel, dim3((batch + kBlock - 1) / kBlock),
                          dim3(kBlock), 0, st, p);
     } else {
@@ -1135,7 +1169,8 @@ XcorrWs carve_xcorr(const SfmXcorrDesc* d, const Geo& g, bool with_surface,
   }
   if (with_surface) w.surface = c.take<float>(B * (size_t)w.srows * w.spitch);
   if (with_peaks)
-    w.peaks = carve_peaks(c, d->batch, g.Sn, use_mfma(d) && !masked, d->group);
+    w.peaks = carve_peaks(c, d->batch, g.Sn, use_mfma(d) && !masked, d->group,
+                          use_mfma(d) && masked && (g.S[1] + sfm::kMaskedBlkRows - 1) / sfm::kMaskedBlkRows <= kBlkMaxN);
   w.bytes = c.total();
   return w;
 }
@@ -1163,7 +1198,7 @@ int compute_surface(const SfmXcorrDesc* d, const Geo& g, const XcorrWs& w,
   const bool masked = is_masked(d);
   if (use_mfma(d) && masked) {
     // exact integer correlations on the matrix cores + Padfield assembly
-    return sfm::mfma_i8_masked(d, w.mfma, surface, w.maxima, smax);
+    return sfm::mfma_i8_masked(d, w.mfma, surface, w.maxima, smax, w.peaks.blkmax);
   }
   if (use_mfma(d)) return sfm::mfma_i8_surface(d, w.mfma, surface, fused);
   GatherArgs ga[2];
@@ -1323,6 +1358,12 @@ bool live_rows_enabled() {
   return !(e && e[0] == '0');
 }
 
+// SFM_MASKED_BLKMAX=0: the peak sweep of the masked path reads every live row.
+bool blkmax_enabled() {
+  const char* e = sfm::option("SFM_MASKED_BLKMAX");
+  return !(e && e[0] == '0');
+}
+
 int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
   XcorrWs w = carve_xcorr(d, g, true, true);
   if (!d->workspace || d->workspace_bytes < w.bytes)
@@ -1371,7 +1412,8 @@ int peaks_one(const SfmXcorrDesc* d, const Geo& g, float* peaks) {
                    d->batch, center, d->min_distance,
                    d->threshold_rel, d->peak_radius, peaks,
                    static_cast<hipStream_t>(d->stream), fuse, smax_pre,
-                   masked_mfma && live_rows_enabled() ? w.maxima + 1 : nullptr, live_geo);
+                   masked_mfma && live_rows_enabled() ? w.maxima + 1 : nullptr, live_geo,
+                   masked_mfma && w.peaks.blkmax && blkmax_enabled());
 }
 
 }  // namespace

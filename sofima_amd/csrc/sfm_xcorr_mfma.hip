@@ -1444,11 +1444,14 @@ struct MaskedFastArgs {
   int all_passes;       // test switch: every patch takes the eight passes (class 3)
   int dead_rows;        // final phase: skip rows below the overlap threshold (SFM_MASKED_DEADROWS=0: off)
   int row_blocks;       // workgroups per surface in the assembly kernels
+  int axis_max;         // class 0 maxima come from masked_axis_max_kernel (P == Q)
+  int* sweep0;          // [batch] 1: a class 0 patch whose maxima need the sweep after all
   int group;            // patches per reference batch: maxima / ov_lb are per batch
   int* ov_lb;           // [groups] lower bound of the batch maximum of the overlap
   unsigned int* maxima; // [groups, 2]
   float* out;           // [batch, elems] final normalised surface
   unsigned int* smax;   // [batch] or NULL: per-surface maximum (ordered bits)
+  float* blkmax;        // [batch, row_blocks] or NULL: maximum of every block of 32 surface rows
 };
 
 // One workgroup: classes and the list of extra passes in patch order.
@@ -1493,9 +1496,23 @@ __global__ void __launch_bounds__(1024) masked_classify_kernel(MaskedFastArgs g)
   // a' * b' uses it to leave out row tiles that the overlap rule zeroes anyway.
   // One bound per reference batch (`group` patches; zeroed by the host).
   if (g.P[0] == g.Q[0] && g.P[1] == g.Q[1])
-    for (int b = threadIdx.x; b < g.batch; b += 1024) {
-      const int lb = g.nvalid[2 * b] + g.nvalid[2 * b + 1] - g.P[0] * g.P[1];
-      if (lb > 0) atomicMax(&g.ov_lb[b / g.group], lb);
+    for (int b0 = 0; b0 < g.batch; b0 += 1024) {
+      const int b = b0 + threadIdx.x;
+      int lb = 0, gid = -1;
+      if (b < g.batch) {
+        lb = g.nvalid[2 * b] + g.nvalid[2 * b + 1] - g.P[0] * g.P[1];
+        gid = b / g.group;
+      }
+      // one atomic per wave where its 64 patches share a batch (same-address atomics
+      // serialise in the L2)
+      const int g0 = __builtin_amdgcn_readfirstlane(gid);
+      if (__ballot(gid != g0) == 0) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) lb = max(lb, __shfl_xor(lb, d, 64));
+        if (lane == 0 && g0 >= 0 && lb > 0) atomicMax(&g.ov_lb[g0], lb);
+      } else if (gid >= 0 && lb > 0) {
+        atomicMax(&g.ov_lb[gid], lb);
+      }
     }
 }
 
@@ -1592,6 +1609,115 @@ __global__ void __launch_bounds__(kThreads) masked_tables_kernel(MaskedFastArgs 
           if (row_in && x0 + j < px) T[y * px + x0 + j] = acc[j];
       }
     }
+  }
+}
+
+// Batch maxima of a CLEAN same-size pair (class 0, P == Q) without visiting its
+// 4 P^2 shifts.  den(dy, dx) = sqrt(SSD_A(rect) SSD_B(rect)) in exact arithmetic,
+// SSD = sum of squared deviations from the rectangle's own mean, which only grows
+// with the rectangle; the overlap rectangles of a shift are (rows of dy) x (columns
+// of dx) on both sides, so  den(dy, dx) <= min(den(dy, 0), den(0, dx)).  The float
+// value the assembly computes (padfield_terms: < 2^-20 relative error) can therefore
+// exceed the largest value found on the two axes only where BOTH axis values are
+// within 1e-5 of it -- for textured patches the zero shift alone.  The kernel
+// evaluates the axes (row / column totals of the integral images), then every
+// shift of the candidate cross product with the assembly's own expression, and
+// merges the maximum: the same bits as the sweep over all shifts
+// (masked_phase_rows<0, false>), which these patches then skip.  The overlap
+// maximum of a clean pair is Py Px (zero shift).  One wave per patch.
+constexpr int kAxisMaxLen = 192;   // patch side (matrix path: <= 160 wide, <= 192 tall)
+constexpr int kAxisMaxPairs = 2048;
+
+__device__ __forceinline__ float axis_den(const int (*I)[kAxisMaxLen + 1], int P, int other,
+                                          int d) {
+  // shift d along one axis, zero along the other: side A rows [a0, a1), side B rows
+  // [a0 - d, a1 - d); I[t][i] = total of rows (columns) < i of table t
+  const int a0 = max(0, d), a1 = min(P, P + d);
+  const int s_a = I[0][a1] - I[0][a0];
+  const double sq_a = static_cast<double>(I[1][a1] - I[1][a0]);
+  const int s_b = I[2][a1 - d] - I[2][a0 - d];
+  const double sq_b = static_cast<double>(I[3][a1 - d] - I[3][a0 - d]);
+  return padfield_terms(0, s_a, s_b, (a1 - a0) * other, sq_a, sq_b).den;
+}
+
+__global__ void __launch_bounds__(64) masked_axis_max_kernel(MaskedFastArgs g) {
+  const int b = blockIdx.x;
+  if (g.cls[b] != 0) return;
+  __shared__ int R[4][kAxisMaxLen + 1], Cc[4][kAxisMaxLen + 1];
+  __shared__ short cand[2][2 * kAxisMaxLen];
+  __shared__ int n_cand[2];
+  const int lane = threadIdx.x;
+  const int Py = g.P[0], Px = g.P[1];
+  const int* tab = g.tab + (long long)b * 4 * g.tab_elems;
+  // totals of the rows / columns before index i (inclusive tables: last column / row)
+  for (int i = lane; i < Py; i += 64)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) R[t][i + 1] = tab[t * g.tab_elems + (long long)i * Px + Px - 1];
+  for (int i = lane; i < Px; i += 64)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Cc[t][i + 1] = tab[t * g.tab_elems + (long long)(Py - 1) * Px + i];
+  if (lane < 4) R[lane][0] = Cc[lane][0] = 0;
+  if (lane < 2) n_cand[lane] = 0;
+  __syncthreads();
+  constexpr int kPer = (2 * kAxisMaxLen + 63) / 64;   // shifts per lane and axis
+  float dy_den[kPer], dx_den[kPer];
+  float amax = 0.f;
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int ky = lane + 64 * u, kx = lane + 64 * u;
+    dy_den[u] = ky < 2 * Py - 1 ? axis_den(R, Py, Px, ky - (Py - 1)) : -1.f;
+    dx_den[u] = kx < 2 * Px - 1 ? axis_den(Cc, Px, Py, kx - (Px - 1)) : -1.f;
+    amax = fmaxf(amax, fmaxf(dy_den[u], dx_den[u]));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+  // candidate rows / columns: axis value within 1e-5 of the axis maximum
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    if (dy_den[u] >= 0.f && dy_den[u] * 1.00001f >= amax)
+      cand[0][atomicAdd(&n_cand[0], 1)] = static_cast<short>(lane + 64 * u - (Py - 1));
+    if (dx_den[u] >= 0.f && dx_den[u] * 1.00001f >= amax)
+      cand[1][atomicAdd(&n_cand[1], 1)] = static_cast<short>(lane + 64 * u - (Px - 1));
+  }
+  __syncthreads();
+  float mden = amax;
+  const int ny_c = n_cand[0], nx_c = n_cand[1];
+  // (amax == 0: every denominator is exactly 0.)  A patch with wide flat margins
+  // can have thousands of candidate shifts: it takes the ordinary sweep instead.
+  const bool sweep = amax > 0.f && ny_c * nx_c > kAxisMaxPairs;
+  if (lane == 0) g.sweep0[b] = sweep ? 1 : 0;
+  if (sweep) return;
+  if (amax > 0.f && ny_c * nx_c > 1) {
+    // the shifts off the axes that could reach the maximum: the assembly's expression
+    // on the four box sums (inclusive tables: corner (y1 - 1, x1 - 1) etc.)
+    for (int i = lane; i < ny_c * nx_c; i += 64) {
+      const int dy = cand[0][i / nx_c], dx = cand[1][i % nx_c];
+      const int ya0 = max(0, dy), ya1 = min(Py, Py + dy);
+      const int xa0 = max(0, dx), xa1 = min(Px, Px + dx);
+      int box[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int* T = tab + t * g.tab_elems;
+        const int y0 = t < 2 ? ya0 : ya0 - dy, y1 = t < 2 ? ya1 : ya1 - dy;
+        const int x0 = t < 2 ? xa0 : xa0 - dx, x1 = t < 2 ? xa1 : xa1 - dx;
+        int v = T[(long long)(y1 - 1) * Px + x1 - 1];
+        if (y0 > 0) v -= T[(long long)(y0 - 1) * Px + x1 - 1];
+        if (x0 > 0) v -= T[(long long)(y1 - 1) * Px + x0 - 1];
+        if (y0 > 0 && x0 > 0) v += T[(long long)(y0 - 1) * Px + x0 - 1];
+        box[t] = v;
+      }
+      mden = fmaxf(mden, padfield_terms(0, box[0], box[2], (ya1 - ya0) * (xa1 - xa0),
+                                        static_cast<double>(box[1]), static_cast<double>(box[3])).den);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mden = fmaxf(mden, __shfl_xor(mden, d, 64));
+  }
+  if (lane == 0) {
+    unsigned int* mx = g.maxima + 2 * (b / g.group);
+    const unsigned db = __float_as_uint(mden);
+    const unsigned ob = __float_as_uint(static_cast<float>(Py * Px));
+    if (db > __atomic_load_n(&mx[0], __ATOMIC_RELAXED)) atomicMax(&mx[0], db);
+    if (ob > __atomic_load_n(&mx[1], __ATOMIC_RELAXED)) atomicMax(&mx[1], ob);
   }
 }
 
@@ -1787,7 +1913,7 @@ __device__ __forceinline__ void masked_phase_rows(const MaskedFastArgs& g, int b
 
 // End of an assembly workgroup: surface maximum (FINAL) or batch maxima.
 template <bool FINAL>
-__device__ __forceinline__ void phase_finish(const MaskedFastArgs& g, int b,
+__device__ __forceinline__ void phase_finish(const MaskedFastArgs& g, int b, int row_block,
                                              const PhaseOut& po) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1797,6 +1923,18 @@ __device__ __forceinline__ void phase_finish(const MaskedFastArgs& g, int b,
     if (g.smax) {
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, d, 64));
+      if (g.blkmax) {
+        // and the maximum of this workgroup's 32 rows: the peak sweep skips blocks
+        // that hold nothing above its threshold
+        __shared__ float bred[kWaves];
+        if (lane == 0) bred[wave] = rmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          float m = bred[0];
+          for (int w = 1; w < kWaves; ++w) m = fmaxf(m, bred[w]);
+          g.blkmax[(long long)b * g.row_blocks + row_block] = m;
+        }
+      }
       if (lane == 0 && rmax > -INFINITY) {
         const unsigned u = __float_as_uint(rmax);
         const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -1849,12 +1987,13 @@ __global__ void __launch_bounds__(kThreads) masked_phase_kernel(MaskedFastArgs g
   }
   PhaseOut po = {0.f, 0.f, -INFINITY};
   if (cls == 3) return;  // masked_phase3_kernel
+  if (!FINAL && cls == 0 && g.axis_max && !g.sweep0[b]) return;  // masked_axis_max_kernel
   switch (cls) {
     case 0: masked_phase_rows<0, FINAL>(g, b, row_block, D[wave][0], D[wave][1], tol, px_thr, &po); break;
     case 1: masked_phase_rows<1, FINAL>(g, b, row_block, D[wave][0], D[wave][1], tol, px_thr, &po); break;
     default: masked_phase_rows<2, FINAL>(g, b, row_block, D[wave][0], D[wave][1], tol, px_thr, &po); break;
   }
-  phase_finish<FINAL>(g, b, po);
+  phase_finish<FINAL>(g, b, row_block, po);
 }
 
 // Class 3 (both sides masked): all eight products come from memory and no
@@ -1937,7 +2076,7 @@ __global__ void __launch_bounds__(kThreads) masked_phase3_kernel(MaskedFastArgs 
     }
     if (FINAL) *reinterpret_cast<float4*>(out + 4 * f) = make_float4(v4[0], v4[1], v4[2], v4[3]);
   }
-  phase_finish<FINAL>(g, b, po);
+  phase_finish<FINAL>(g, b, row_block, po);
 }
 
 __device__ __forceinline__ int box_sum(const int* __restrict__ I, int ip, int y0,
@@ -3961,7 +4100,7 @@ bool masked_all_passes() {
 
 struct MaskedWs {
   PatchParams* pp;
-  int *nvalid, *cls, *first, *items, *n_items, *ov_lb, *tab, *raw0, *rawd;
+  int *nvalid, *cls, *first, *items, *n_items, *ov_lb, *sweep0, *tab, *raw0, *rawd;
   int group, n_groups;
   long long tab_elems, raw_stride;
   size_t bytes;
@@ -3984,6 +4123,7 @@ MaskedWs carve_masked(const SfmXcorrDesc* d, void* base) {
   w.group = d->group > 0 && d->group < d->batch ? d->group : d->batch;
   w.n_groups = (d->batch + w.group - 1) / w.group;
   w.ov_lb = c.take<int>(w.n_groups);
+  w.sweep0 = c.take<int>(B);
   // + 64 ints: consecutive tables (and product surfaces below) of a patch are read
   // together; strides that are multiples of 4 KB would put them on one memory channel
   w.tab_elems = (long long)d->patch[1] * d->patch[2] + 64;
@@ -4186,7 +4326,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
 // (`d->group` patches); `smax` (optional, zeroed by the caller) receives the
 // ordered bits of every surface maximum.
 int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
-                   unsigned int* maxima, unsigned int* smax) {
+                   unsigned int* maxima, unsigned int* smax, float* blkmax) {
   hipStream_t st = static_cast<hipStream_t>(d->stream);
   const int vi = pick_variant(d->patch[2], d->post_patch[2]);
   if (vi < 0) return fail(SFM_ERR_INVALID, "patch too wide for the MFMA path");
@@ -4247,11 +4387,20 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
     g.xcd_map = !(e && e[0] == '0');
   }
   g.maxima = maxima;
+  {
+    // class 0 maxima from the axes (SFM_MASKED_AXISMAX=0: the sweep over all shifts)
+    const char* e = sfm::option("SFM_MASKED_AXISMAX");
+    g.axis_max = !(e && e[0] == '0') && a.P[0] == a.Q[0] && a.P[1] == a.Q[1] &&
+                 a.P[0] <= kAxisMaxLen && a.P[1] <= kAxisMaxLen;
+  }
   g.group = w.group;
   g.ov_lb = w.ov_lb;
+  g.sweep0 = w.sweep0;
   g.out = surface;
   g.smax = smax;
+  g.blkmax = smax ? blkmax : nullptr;
   const int rows_per_wg = kWaves * kAsmRowsPerWave;
+  static_assert(kWaves * kAsmRowsPerWave == 32, "blkmax blocks: kMaskedBlkRows in sfm_xcorr.hip");
   g.row_blocks = (a.S[0] + rows_per_wg - 1) / rows_per_wg;
   hipLaunchKernelGGL(masked_classify_kernel, dim3(1), dim3(1024), 0, st, g);
   hipLaunchKernelGGL(masked_tables_kernel, dim3(d->batch), dim3(kThreads), 0, st, g);
@@ -4272,6 +4421,8 @@ int mfma_i8_masked(const SfmXcorrDesc* d, void* ws_base, float* surface,
                            lds, st))
     return rc;
   const dim3 grid(static_cast<unsigned>(((long long)g.row_blocks * d->batch + 7) / 8 * 8));
+  if (g.axis_max)
+    hipLaunchKernelGGL(masked_axis_max_kernel, dim3(d->batch), dim3(64), 0, st, g);
   hipLaunchKernelGGL(masked_phase_kernel<false>, grid, dim3(kThreads), 0, st, g);
   hipLaunchKernelGGL(masked_phase3_kernel<false>, grid, dim3(kThreads), 0, st, g);
   hipLaunchKernelGGL(masked_phase_kernel<true>, grid, dim3(kThreads), 0, st, g);

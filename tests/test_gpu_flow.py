@@ -921,6 +921,49 @@ def test_masked_clean_patch_shortcut_is_bit_identical(gpu, monkeypatch, py, px, 
     np.testing.assert_array_equal(fast, eight)
 
 
+@pytest.mark.parametrize('p', [64, 160, 48])
+def test_masked_clean_pair_maxima_from_the_axes_are_exact(gpu, monkeypatch, p):
+  """The batch maxima of clean same-size pairs come from the two shift axes plus
+  the candidate cross product (masked_axis_max_kernel) instead of a sweep over
+  every shift: same surfaces, bit for bit, as the sweep (SFM_MASKED_AXISMAX=0)
+  and as the eight-pass form -- on textured patches (one candidate), patches
+  with a few flat border rows / columns (several shifts tie with the zero
+  shift), patches that are flat outside a small block (thousands of candidates:
+  they take the sweep) and completely flat patches (every denominator zero)."""
+  from sofima_amd import flow_field
+  prev, curr, pm, cm = _masked_patch_batch(700 + p, 12, p, p, p, p)
+  rng = np.random.default_rng(p)
+  # clean patches are k % 3 == 0: 0, 3, 6, 9
+  for arr in (prev, curr):
+    arr[3, :2] = 90; arr[3, -3:] = 90; arr[3, :, :1] = 90      # flat border rows / columns
+    blk = arr[6, p // 2 - 6:p // 2 + 6, p // 2 - 6:p // 2 + 6].copy()
+    arr[6] = 77; arr[6, p // 2 - 6:p // 2 + 6, p // 2 - 6:p // 2 + 6] = blk   # flat but a block
+    arr[9] = 200                                                 # completely flat
+  # the flat-bordered pair is the batch maximum of the denominator: scale its contrast
+  for arr in (prev, curr):
+    inner = arr[3, 2:-3, 1:].astype(np.float64)
+    arr[3, 2:-3, 1:] = np.clip((inner - inner.mean()) * 3 + 128, 0, 255).astype(np.uint8)
+  runs = {}
+  for name, env in (('axes', {}), ('sweep', {'SFM_MASKED_AXISMAX': '0'}),
+                    ('eight', {'SFM_MASKED_FAST': '0'})):
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    runs[name] = flow_field.masked_xcorr(prev, curr, pm, cm, mean=None)
+    for k in env:
+      monkeypatch.delenv(k)
+  np.testing.assert_array_equal(runs['axes'], runs['sweep'])
+  np.testing.assert_array_equal(runs['axes'], runs['eight'])
+  assert np.abs(runs['axes'][0]).max() > 0.5
+  # clean patches only (every maximum from the axes kernel), incl. an all-flat batch
+  none_a, none_b = np.zeros_like(pm), np.zeros_like(cm)
+  for sl in (slice(None), slice(9, 10)):
+    monkeypatch.setenv('SFM_MASKED_AXISMAX', '0')
+    sweep = flow_field.masked_xcorr(prev[sl], curr[sl], none_a[sl], none_b[sl], mean=None)
+    monkeypatch.delenv('SFM_MASKED_AXISMAX')
+    axes = flow_field.masked_xcorr(prev[sl], curr[sl], none_a[sl], none_b[sl], mean=None)
+    np.testing.assert_array_equal(axes, sweep)
+
+
 def test_masked_flow_mostly_clean_vs_oracle(gpu, monkeypatch):
   """flow_field with mask_only_for_patch_selection=False and a localised mask
   (most patches clean, the ones around the blob dirty) vs the oracle, and vs
@@ -969,6 +1012,10 @@ def test_masked_groups_per_round_do_not_change_the_field(gpu, monkeypatch):
       np.testing.assert_array_equal(calc.flow_field(pre, post, 160, 40, **kw), one)
     monkeypatch.delenv('SFM_MASKED_GROUPS')
     np.testing.assert_array_equal(calc.flow_field(pre, post, 160, 40, **kw), one)
+    # the peak sweep that skips row blocks without anything above its threshold
+    monkeypatch.setenv('SFM_MASKED_BLKMAX', '0')
+    np.testing.assert_array_equal(calc.flow_field(pre, post, 160, 40, **kw), one)
+    monkeypatch.delenv('SFM_MASKED_BLKMAX')
     assert np.isfinite(one[:2]).mean() > 0.5
 
 
