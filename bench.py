@@ -424,12 +424,12 @@ def main():
 
   # HBM traffic of the dominant kernel: PMC counters cannot be read from inside
   # the run, so the figure comes from the separate rocprofv3 --pmc passes of THIS
-  # bench (tools/measure/profile_round4.sh -> profiles/r04_pmc_traffic.json), and
+  # bench (tools/measure/profile_round5.sh -> profiles/r05_pmc_traffic.json), and
   # only when that file was measured on the library that is loaded now
   # (.build_sha); otherwise null.
   if roof and uses_mfma and size == 8192:
     try:
-      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')))
+      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')))
       meta = pmc.get('_meta', {})
       sha = build_sha()
       if sha and meta.get('git_sha') == sha and meta.get('pair', 'exact') == args.pair:
@@ -438,14 +438,22 @@ def main():
             meta_ppl = float(meta.get('patches_per_launch', n_patches))
             ppl = roof['pruned']['patches_per_launch']
             roof['traffic'] = int(v['hbm_bytes_per_launch'] / meta_ppl * ppl)
+          if 'mesh_persist2d' in name and mesh_obj.get('roofline'):
+            # HBM-side bytes of ONE launch of the persistent kernel (all its steps)
+            mesh_obj['roofline']['traffic'] = int(v['hbm_bytes_per_launch'])
+            mesh_obj['roofline']['traffic_note'] = (
+                'per launch of %d FIRE steps (fabric traffic of the inter-workgroup exchange: '
+                'the state itself stays on chip); counters: profiles/r05_pmc_traffic.json'
+                % args.mesh_iters)
+        if roof.get('traffic') is not None:
             roof['traffic_source'] = {
-                'file': 'profiles/r04_pmc_traffic.json', 'measured_on_git_sha': sha,
+                'file': 'profiles/r05_pmc_traffic.json', 'measured_on_git_sha': sha,
                 'launch': 'pruned (production) launch',
                 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of '
                           'this bench; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per '
                           'launch of %d patches' % round(ppl)}
       else:
-        roof['traffic_note'] = ('null: profiles/r04_pmc_traffic.json was measured on %s / '
+        roof['traffic_note'] = ('null: profiles/r05_pmc_traffic.json was measured on %s / '
                                 'pair %s, this library is %s / pair %s'
                                 % (meta.get('git_sha'), meta.get('pair'), sha, args.pair))
     except (OSError, ValueError):
