@@ -787,6 +787,49 @@ def config_legs(dev, canvas, seed):
       'ms_per_strip_pair': round(sec * 1e3, 3), 'patches_per_pair': patches,
       'ms_per_patch': round(sec / patches * 1e3, 4),
       'mvox_s': round(512 * 512 * 120 / sec / 1e6, 1)})
+
+  # -- masked correlation (mask_only_for_patch_selection=False, the reference's
+  # default, flow_field.py:91-156) on the headline geometry: 5 % of both images
+  # masked in discs of radius 130 px.  A patch takes 1 exact int8 product pass
+  # if it holds no masked pixel, 4 if one side does, 8 if both do; the roofline
+  # figure prices those passes (2 P^4 op each) against the dense int8 peak.
+  if canvas.shape[0] >= 8192:
+    from sofima_amd import flow_field as ff
+    side = 8192
+    pre8 = np.ascontiguousarray(canvas[:side, :side])
+    post8 = np.ascontiguousarray(np.roll(pre8, (3, -5), (0, 1)))
+    mrng = np.random.default_rng(seed + 7)
+    yy, xx = np.mgrid[-130:131, -130:131]
+    disc = yy ** 2 + xx ** 2 <= 130 ** 2
+    masks = []
+    for _ in range(2):
+      m = np.zeros((side, side), bool)
+      for _ in range(int(0.05 * side * side / (np.pi * 130 ** 2))):
+        y, x = mrng.integers(130, side - 131, 2)
+        m[y - 130:y + 131, x - 130:x + 131] |= disc
+      masks.append(m)
+    ca = ff._masked_counts(masks[0], (PATCH, PATCH), (STEP, STEP)) > 0
+    cb = ff._masked_counts(masks[1], (PATCH, PATCH), (STEP, STEP)) > 0
+    passes = np.where(ca & cb, 8, np.where(ca | cb, 4, 1))
+    ta, tb = (torch.from_numpy(v).to(dev) for v in (pre8, post8))
+    ma, mb = (torch.from_numpy(v).to(dev) for v in masks)
+    calc2 = flow_field.JAXMaskedXCorrWithStatsCalculator()
+    sec, f = timed(lambda: calc2.flow_field(ta, tb, PATCH, STEP, pre_mask=ma, post_mask=mb,
+                                            batch_size=BATCH, max_masked=1.01,
+                                            mask_only_for_patch_selection=False), 2)
+    top = float(passes.sum()) * 2.0 * PATCH ** 4 / 1e12
+    out.append({
+        'config': 'configs[1] masked flow', 'workload':
+            '8192^2 pair, masks on both images (5 % of the area in discs of radius 130), '
+            'mask_only_for_patch_selection=False, patch 160 step 40 batch 1024',
+        'ms_per_pair': round(sec * 1e3, 2), 'patches_per_pair': int(passes.size),
+        'patches_with_masked_pixels': round(float((ca | cb).mean()), 4),
+        'matrix_passes_per_patch': round(float(passes.mean()), 3),
+        'mpix_s': round(side * side / sec / 1e6, 1),
+        'roofline': {'bound': 'mfma', 'op_dtype': 'int8', 'peak': PEAK_I8_TOPS, 'unit': 'TFLOP/s',
+                     'achieved': round(top / sec, 1), 'frac': round(top / sec / PEAK_I8_TOPS, 4),
+                     'note': 'whole path (prep, tables, product passes, Padfield assembly, peak '
+                             'search) against the matrix passes the patches need'}})
   return out
 
 
