@@ -926,23 +926,29 @@ def test_masked_clean_pair_maxima_from_the_axes_are_exact(gpu, monkeypatch, p):
   """The batch maxima of clean same-size pairs come from the two shift axes plus
   the candidate cross product (masked_axis_max_kernel) instead of a sweep over
   every shift: same surfaces, bit for bit, as the sweep (SFM_MASKED_AXISMAX=0)
-  and as the eight-pass form -- on textured patches (one candidate), patches
-  with a few flat border rows / columns (several shifts tie with the zero
-  shift), patches that are flat outside a small block (thousands of candidates:
-  they take the sweep) and completely flat patches (every denominator zero)."""
+  and as the eight-pass form -- on textured patches (one candidate), a patch
+  whose border rows / columns sit at the mean of the rest (several shifts come
+  within 1e-5 of the zero shift), patches that are flat outside a small block
+  (thousands of candidates: they take the sweep) and completely flat patches
+  (every denominator zero)."""
   from sofima_amd import flow_field
   prev, curr, pm, cm = _masked_patch_batch(700 + p, 12, p, p, p, p)
   rng = np.random.default_rng(p)
   # clean patches are k % 3 == 0: 0, 3, 6, 9
   for arr in (prev, curr):
-    arr[3, :2] = 90; arr[3, -3:] = 90; arr[3, :, :1] = 90      # flat border rows / columns
     blk = arr[6, p // 2 - 6:p // 2 + 6, p // 2 - 6:p // 2 + 6].copy()
     arr[6] = 77; arr[6, p // 2 - 6:p // 2 + 6, p // 2 - 6:p // 2 + 6] = blk   # flat but a block
     arr[9] = 200                                                 # completely flat
-  # the flat-bordered pair is the batch maximum of the denominator: scale its contrast
+  # pair 3: the batch maximum of the denominator (contrast scaled up), with border rows /
+  # columns AT the mean of the rest -- dropping them changes the sum of squared deviations
+  # by less than 1e-5, so several shifts are candidates next to the zero shift
+  # (tests/test_prune_bounds.py shows the same construction on the CPU)
   for arr in (prev, curr):
     inner = arr[3, 2:-3, 1:].astype(np.float64)
-    arr[3, 2:-3, 1:] = np.clip((inner - inner.mean()) * 3 + 128, 0, 255).astype(np.uint8)
+    inner = np.clip(np.round((inner - inner.mean()) * 3 + 128), 0, 255)
+    arr[3, 2:-3, 1:] = inner.astype(np.uint8)
+    m = np.uint8(np.round(inner.mean()))
+    arr[3, :2] = m; arr[3, -3:] = m; arr[3, :, :1] = m
   runs = {}
   for name, env in (('axes', {}), ('sweep', {'SFM_MASKED_AXISMAX': '0'}),
                     ('eight', {'SFM_MASKED_FAST': '0'})):

@@ -262,3 +262,76 @@ def test_row_counted_guard_band_covers_every_window_of_a_hot_element(guard):
       for t in np.nonzero([hot[16 * t:16 * t + 16].any() for t in range(n_tiles)])[0]:
         whole[max(0, t - g_tiles):t + g_tiles + 1] = True
       assert need.sum() <= whole.sum() and not (need & ~whole).any()
+
+
+def _den_all_shifts(a, b):
+  """Padfield denominator sqrt(SSD_A SSD_B) of a CLEAN same-size pair for every
+  shift, exact (float64 on integers): SSD = n sum x^2 - (sum x)^2 over the
+  overlap rectangle of each side, divided by n (flow_field.py:113-131 with all
+  pixels valid; the patch means cancel)."""
+  p = a.shape[0]
+  out = np.zeros((2 * p - 1, 2 * p - 1))
+  ia = np.pad(a.cumsum(0).cumsum(1), ((1, 0), (1, 0)))
+  iqa = np.pad((a * a).cumsum(0).cumsum(1), ((1, 0), (1, 0)))
+  ib = np.pad(b.cumsum(0).cumsum(1), ((1, 0), (1, 0)))
+  iqb = np.pad((b * b).cumsum(0).cumsum(1), ((1, 0), (1, 0)))
+
+  def box(i, ys, xs):
+    return i[ys.stop, xs.stop] - i[ys.start, xs.stop] - i[ys.stop, xs.start] + i[ys.start, xs.start]
+
+  for dy in range(-(p - 1), p):
+    ya, yb = _rows_of_shift(dy, p)
+    for dx in range(-(p - 1), p):
+      xa, xb = _rows_of_shift(dx, p)
+      n = (ya.stop - ya.start) * (xa.stop - xa.start)
+      pd = max(n * box(iqa, ya, xa) - box(ia, ya, xa) ** 2, 0.0)
+      cd = max(n * box(iqb, yb, xb) - box(ib, yb, xb) ** 2, 0.0)
+      out[dy + p - 1, dx + p - 1] = np.sqrt(pd * cd) / n
+  return out
+
+
+@pytest.mark.parametrize('kind', ['smooth', 'noise', 'mean_border', 'flat_but_block', 'flat'])
+def test_denominator_of_a_clean_pair_is_bounded_by_its_axis_values(kind):
+  """masked_axis_max_kernel: the batch maximum of the
+  denominator of a clean same-size pair is found on the two shift axes plus the
+  candidate cross product, because den(dy, dx) <= min(den(dy, 0), den(0, dx))
+  (the sum of squared deviations only grows with the rectangle, and the overlap
+  rectangles are rows(dy) x columns(dx) on both sides).  Checked here on the
+  directly computed surface of denominators, with the kernel's candidate rule
+  (axis value within 1e-5 of the axis maximum) and a float32 evaluation."""
+  p = 24
+  rng = np.random.default_rng(len(kind))
+  a, b = _patches('noise' if kind == 'noise' else 'smooth', rng, p)
+  if kind == 'mean_border':
+    # border rows / columns AT the mean of the rest: dropping them leaves the sum of
+    # squared deviations almost unchanged, so several shifts come within 1e-5 of the
+    # zero shift's denominator
+    for arr in (a, b):
+      arr[:] = np.round((arr - arr.mean()) * 3 + 128).clip(0, 255)
+      inner = arr[2:-3, 1:]
+      arr[:2] = np.round(inner.mean()); arr[-3:] = np.round(inner.mean())
+      arr[:, :1] = np.round(inner.mean())
+  elif kind == 'flat_but_block':
+    for arr in (a, b):
+      blk = arr[8:14, 9:15].copy(); arr[:] = 77; arr[8:14, 9:15] = blk
+  elif kind == 'flat':
+    a[:] = 200; b[:] = 13
+  den = _den_all_shifts(a, b)
+  c = p - 1
+  row_axis, col_axis = den[:, c], den[c, :]
+  # the inequality, exactly (float64 on integers below 2^53: a few ulp of slack)
+  bound = np.minimum(row_axis[:, None], col_axis[None, :])
+  assert (den <= bound * (1 + 1e-12) + 1e-9).all()
+  # the kernel's procedure on float32 values: axis maximum, candidates, cross product
+  den32 = den.astype(np.float32)
+  amax = max(den32[:, c].max(), den32[c, :].max())
+  cy = np.nonzero(den32[:, c] * np.float32(1.00001) >= amax)[0]
+  cx = np.nonzero(den32[c, :] * np.float32(1.00001) >= amax)[0]
+  found = max(amax, den32[np.ix_(cy, cx)].max()) if amax > 0 else np.float32(0)
+  assert found == den32.max()
+  if kind in ('smooth', 'noise'):
+    assert len(cy) == 1 and len(cx) == 1        # the zero shift alone
+  if kind == 'mean_border':
+    assert len(cy) * len(cx) > 1                # several shifts within 1e-5 of it
+  if kind == 'flat':
+    assert den.max() == 0.0
