@@ -92,6 +92,8 @@ int sfm_device_count(int* count);
  *   SFM_MESH_PERSISTENT=0 / SFM_MESH_SPECULATE=0 / SFM_MESH_TILED=0 /
  *   SFM_MESH_SMALL=0 / SFM_MESH_FUSE_TARGET=0
  *                         fall back to the simpler integrator
+ *   SFM_MESH_PACK=0       tiled in-plane step: a workgroup per tile also in a narrow last
+ *                         tile column (default: its tile rows share workgroups)
  *   SFM_MESH_TILE=16|32   tile edge of the persistent integrator
  *   SFM_MESH_XCD=0|1      tiled in-plane step: one contiguous run of tiles per
  *                         XCD never / always (default: from 2048 tiles on)   */

@@ -930,6 +930,13 @@ struct BandArgs {
   const BandDev* multi;  // multi-band launch: the per-band fields above and the
   int n_multi;           // kernel's array / scalar arguments come from here
   int xcd_map;           // blocks of one XCD (block % 8) take a contiguous run of tiles
+  // Packed remainder column (outside band mode).  When X is not a multiple of kSX
+  // the last tile column uses rem = X % kSX of its 62 lanes (204 columns: 18).  With
+  // pack_S >= 2 a workgroup of that column takes pack_S tile rows instead, side by
+  // side in lane segments of pack_segw = rem + 2 lanes (own columns + one halo lane
+  // each side): a lane's row offset is its segment's.  Workgroups per plane:
+  // nty * pack_ntxw full-width tiles, then ceil(nty / pack_S) packed ones.
+  int pack_S, pack_segw, pack_ntxw, pack_recip;   // recip: ceil(2^16 / segw)
 };
 
 // Sum of the bands' partial sums in band order + the FIRE update from them
@@ -976,6 +983,8 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
     bd.ty_mode = 0;
     bd.multi = nullptr;
     bd.n_multi = 0;
+  } else {
+    bd.pack_S = 0;
   }
   constexpr int C = 2;
   constexpr int TW = 64;         // columns -1 .. kSX of the tile
@@ -1067,17 +1076,41 @@ integrate_shared2d_kernel(const float* x_in, const float* v_in, const float* a_i
   const float c2 = 0.5f * (dt * dt);
   const bool fix = p.fire && pending;
 
-  const int tx = tile % ntx;
-  const int ty = (tile / ntx) % nty;
-  const long long plane = tile / (ntx * nty);  // b * Z + z
-  const long long base = plane * p.Y * p.X;
-  const int gx0 = tx * kSX, gy0 = ty * kSY;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gx = gx0 + lane - 1;                 // this lane's column
+  long long plane;   // b * Z + z
+  int gx;            // this lane's column
+  int gy0;           // first row of this lane's tile
+  bool col_own;
+  if (bd.pack_S) {
+    const int n_wide = nty * bd.pack_ntxw;
+    const int per_plane = n_wide + (nty + bd.pack_S - 1) / bd.pack_S;
+    plane = tile / per_plane;
+    const int b = tile - static_cast<int>(plane) * per_plane;
+    if (b < n_wide) {
+      const int ty = b / bd.pack_ntxw, tx = b - ty * bd.pack_ntxw;
+      gx = tx * kSX + lane - 1;
+      gy0 = ty * kSY;
+      col_own = lane >= 1 && lane <= kSX;
+    } else {
+      const int seg = (lane * bd.pack_recip) >> 16;   // lane / segw
+      const int ls = lane - seg * bd.pack_segw;
+      const int ty = (b - n_wide) * bd.pack_S + seg;
+      gx = bd.pack_ntxw * kSX + ls - 1;
+      gy0 = min(ty, nty - 1) * kSY;
+      col_own = seg < bd.pack_S && ty < nty && ls >= 1 && ls <= bd.pack_segw - 2;
+    }
+  } else {
+    const int tx = tile % ntx;
+    const int ty = (tile / ntx) % nty;
+    plane = tile / (ntx * nty);
+    gx = tx * kSX + lane - 1;
+    gy0 = ty * kSY;
+    col_own = lane >= 1 && lane <= kSX;
+  }
+  const long long base = plane * p.Y * p.X;
   const int gxc = min(max(gx, 0), p.X - 1);      // clamped for the loads
-  const bool col_in = gx >= 0 && gx < p.X;
-  const bool col_own = lane >= 1 && lane <= kSX && gx < p.X;
+  col_own = col_own && gx < p.X;
   const int r0 = kRows * wave;                   // first tile row of this thread
 
   // Position of one node after the position update (FUSED) / as stored.
@@ -2694,7 +2727,15 @@ struct MeshWorkspace {
 struct TilePlan {
   int tx = 0, ty = 0, nty = 0, ntx = 0;
   long long tiles = 0;
+  // packed remainder column (BandArgs::pack_*), un-split launches only
+  int pack_S = 0, pack_segw = 0, pack_ntxw = 0;
+  long long packed_tiles = 0;   // workgroups of a packed launch (== tiles without packing)
 };
+
+bool pack_enabled() {
+  const char* e = sfm::option("SFM_MESH_PACK");   // "0": every tile row of the last column its own workgroup
+  return !(e && e[0] == '0');
+}
 
 bool fuse_target_enabled() {
   const char* e = sfm::option("SFM_MESH_FUSE_TARGET");  // "0": advance + target + integrate
@@ -2718,7 +2759,28 @@ TilePlan plan_tiles(int ncomp, long long planes, int Y, int X) {
   best.ntx = (X + kSX - 1) / kSX;
   best.tiles = planes * best.nty * best.ntx;
   if (best.tiles > 0x7fffffffLL / kNP) best = TilePlan();
+  best.packed_tiles = best.tiles;
+  const int rem = X % kSX;
+  if (best.tiles && rem && rem + 2 <= 32 && best.nty >= 2) {
+    best.pack_segw = rem + 2;
+    best.pack_S = std::min(64 / best.pack_segw, best.nty);
+    best.pack_ntxw = best.ntx - 1;
+    best.packed_tiles =
+        planes * ((long long)best.nty * best.pack_ntxw + (best.nty + best.pack_S - 1) / best.pack_S);
+  }
   return best;
+}
+
+// BandArgs of an un-split launch of the tiled step.
+BandArgs plain_band_args(const TilePlan& t, int xcd_map, bool pack) {
+  BandArgs b{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, xcd_map, 0, 0, 0, 0};
+  if (pack && t.pack_S >= 2) {
+    b.pack_S = t.pack_S;
+    b.pack_segw = t.pack_segw;
+    b.pack_ntxw = t.pack_ntxw;
+    b.pack_recip = (65536 + t.pack_segw - 1) / t.pack_segw;
+  }
+  return b;
 }
 
 MeshWorkspace carve(void* ws, size_t prev_floats, size_t alt_floats, long long tiles,
@@ -2980,7 +3042,8 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   const bool fused = tiled && (!dyn_prev || fuse_target);
   if (fuse_target && w.target_list)
     if (int rc = sfm::build_target_list(d->target, w.target_list, st)) return rc;
-  const int tgrid = static_cast<int>(tiles.tiles);
+  const bool pack = tiles.pack_S >= 2 && pack_enabled();
+  const int tgrid = static_cast<int>(pack ? tiles.packed_tiles : tiles.tiles);
   // XCD-contiguous tile order: on once there are several rounds of workgroups
   // (measured after the SGPR spills were gone: [2,4,2048^2] 270 -> 261 us,
   // [2,64,204^2] 62.2 -> 58.6; [2,1,1000^2], one round of 1071 tiles: 31.1 -> 31.5).
@@ -3035,7 +3098,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       hipLaunchKernelGGL(integrate_shared2d_kernel<true>, dim3(tgrid), dim3(kBlock), 0, ls,
                          bi[0], bi[1], bi[2], prev_ptr, bo[0], bo[1], bo[2], p, &w.scal[cur],
                          &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, pending, tiles.nty,
-                         tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, xcd_map});
+                         tiles.ntx, plain_band_args(tiles, xcd_map, pack));
       sfm::prof_end(sfm::kProfMesh, ls);
       SFM_LAUNCH_CHECK();
       in ^= 1;
@@ -3049,7 +3112,7 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       hipLaunchKernelGGL(integrate_shared2d_kernel<false>, dim3(tgrid), dim3(kBlock), 0, ls,
                          d->x, d->v, d->a, prev_ptr, d->x, d->v, d->a, p, &w.scal[cur],
                          &w.scal[cur ^ 1], cap0, w.tile_part, w.ticket, 1, tiles.nty,
-                         tiles.ntx, BandArgs{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, xcd_map});
+                         tiles.ntx, plain_band_args(tiles, xcd_map, pack));
       sfm::prof_end(sfm::kProfMesh, ls);
       SFM_LAUNCH_CHECK();
       if (p.fire) cur ^= 1;

@@ -673,6 +673,52 @@ def test_shared_spring_step_is_bit_identical(gpu, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 2, 75, 70), (2, 3, 204, 204), (2, 1, 50, 92),
+                                   (2, 2, 100, 64), (2, 1, 33, 187), (2, 2, 40, 93)])
+@pytest.mark.parametrize('drift', [False, True])
+def test_packed_last_tile_column(gpu, shape, drift):
+  """Tiled in-plane step with the tile rows of a narrow last tile column packed
+  side by side into one workgroup (X % 62 of 8, 18, 30, 2, 1 columns; 31: not
+  packed) vs a workgroup per tile (SFM_MESH_PACK=0).  Every node takes the same
+  operations; only the grouping of the per-workgroup partial sums changes, so
+  without drift removal (FIRE reads the SIGN of the power only) the chunk is bit
+  for bit the same, with drift removal it agrees to round-off; both follow the
+  oracle."""
+  from oracle import mesh_oracle
+  from scipy import ndimage
+  from sofima_amd import _abi, mesh
+  rng = np.random.default_rng(shape[-1] + shape[-2])
+  prev = ndimage.gaussian_filter(rng.standard_normal(shape), (0, 0, 2, 2)) * (8 if drift else 40)
+  prev = (prev + 0.3 * rng.standard_normal(shape)).astype(np.float32)
+  prev[:, :, :2, -3:] = np.nan     # holes in the packed column
+  prev[:, :, -1, -1] = np.nan
+  x0 = (rng.standard_normal(shape) * 0.3).astype(np.float32)
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.05, k=0.1, stride=(40, 40),
+                               num_iters=40, max_iters=120, stop_v_max=1e-9, dt_max=100,
+                               start_cap=0.05, final_cap=10, prefer_orig_order=True,
+                               remove_drift=drift)
+  with _abi.option('SFM_MESH_PERSISTENT', 0):
+    a = mesh.relax_mesh(x0, prev, cfg)
+    with _abi.option('SFM_MESH_PACK', 0):
+      b = mesh.relax_mesh(x0, prev, cfg)
+  want = mesh_oracle.relax_mesh(x0, prev, cfg)
+  assert a[2] == b[2] == want[2]
+  scale = np.abs(want[0]).max()
+  if not drift:
+    np.testing.assert_array_equal(np.array(a[0]), np.array(b[0]))
+    assert list(a[1]) == list(b[1])
+  else:
+    # (the last-bit difference of the drift means is amplified by the relaxation like
+    # any other change of the summation order -- test_banded_c_loop_fused_kernel; on
+    # the 204^2 case ONE node of 250 k reaches 5e-4 of the scale after 120 steps)
+    diff = np.abs(np.array(a[0]) - np.array(b[0]))
+    assert np.nanmax(diff) <= 1e-3 * scale
+    assert np.mean(diff > 2e-4 * scale) < 1e-4
+  np.testing.assert_allclose(np.array(a[0]), want[0], atol=1e-3 * scale)
+  np.testing.assert_allclose(a[1], want[1], rtol=1e-3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('drift', [False, True])
 def test_xcd_tile_order_is_bit_identical(gpu, drift):
   """SFM_MESH_XCD (every XCD takes one contiguous run of tiles of the fused
