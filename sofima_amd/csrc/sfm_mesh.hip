@@ -2349,15 +2349,25 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     u64* slot = q.comm + (long long)wg * 2 * kSlotS + (long long)((step + 1) & 1) * kSlotS;
     if (active && pidx >= 0) {
       const Scalars sd = first ? sk : next_scalars(sk, true);
-      const Scalars su = next_scalars(sk, false);
       const float dtd = sd.dt, c2d = 0.5f * (dtd * dtd);
-      const float dtu = su.dt, c2u = 0.5f * (dtu * dtu);
-      const float vd0 = v0 * 1.f, vd1 = v1 * 1.f, vu0 = v0 * 0.f, vu1 = v1 * 0.f;
+      const float vd0 = v0 * 1.f, vd1 = v1 * 1.f;
       u64* g = slot + pidx * kGranS;
       put_granule(g + 0, tag, x0 + (dtd * vd0 + c2d * a0));
       put_granule(g + 1, tag, x1 + (dtd * vd1 + c2d * a1));
-      put_granule(g + 2, tag, x0 + (dtu * vu0 + c2u * a0));
-      put_granule(g + 3, tag, x1 + (dtu * vu1 + c2u * a1));
+    }
+  };
+  // The uphill candidates of the state (xs, vs, as) after `step` steps, published
+  // only when the step behind it is redone (everyone redoes it: everyone publishes).
+  auto publish_uphill = [&](int step, unsigned tag, const Scalars& sk, float xs0, float xs1,
+                            float vs0, float vs1, float as0, float as1) {
+    u64* slot = q.comm + (long long)wg * 2 * kSlotS + (long long)((step + 1) & 1) * kSlotS;
+    if (active && pidx >= 0) {
+      const Scalars su = next_scalars(sk, false);
+      const float dtu = su.dt, c2u = 0.5f * (dtu * dtu);
+      const float vu0 = vs0 * 0.f, vu1 = vs1 * 0.f;
+      u64* g = slot + pidx * kGranS;
+      put_granule(g + 2, tag, xs0 + (dtu * vu0 + c2u * as0));
+      put_granule(g + 3, tag, xs1 + (dtu * vu1 + c2u * as1));
     }
   };
   // replica `rep` of workgroup w2's partial of step `step` (eight step places)
@@ -2543,6 +2553,7 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       a0 = ba0;
       a1 = ba1;
       s = next_scalars(s_before, false);
+      publish_uphill(k - 1, want_tag, s_before, x0, x1, v0, v1, a0, a1);
       {
         // the neighbours' uphill candidates of the state after k - 1 steps (same
         // slot and tag as the downhill ones this iteration started with)
