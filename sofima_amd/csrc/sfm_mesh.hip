@@ -1599,6 +1599,64 @@ __device__ __forceinline__ bool poll_granules(const u64* const* g, float* const*
   return true;
 }
 
+// The same for PAIRS of granules that lie side by side in one aligned 16-byte
+// unit, fetched with one 16-byte agent-scope (sc1) buffer load each: half the
+// requests of two 8-byte polls.  Each half carries its own tag and is accepted on
+// its own terms, so nothing here assumes that a 16-byte access is single-copy
+// atomic (8-byte halves are).  off[i]: byte offset of pair i in the exchange area
+// or -1; d[i]: where the two values go.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u load_pair(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);   // aux 16: sc1
+}
+// takes the halves of `x` that carry `epoch`; returns the mask of halves taken
+__device__ __forceinline__ unsigned take_pair(const v4u& x, unsigned epoch, float* d) {
+  unsigned got = 0;
+  if (x.y == epoch) {
+    d[0] = __uint_as_float(x.x);
+    got |= 1u;
+  }
+  if (x.w == epoch) {
+    d[1] = __uint_as_float(x.z);
+    got |= 2u;
+  }
+  return got;
+}
+template <int N>
+__device__ __forceinline__ bool poll_pairs(__amdgpu_buffer_rsrc_t rs, const int* off,
+                                           float* const* d, unsigned* have, unsigned epoch,
+                                           int* abort) {
+  bool need = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) need = need || (off[i] >= 0 && have[i] != 3u);
+  for (int spin = 0; need && spin < kSpinLimit; ++spin) {
+    v4u x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = load_pair(rs, off[i] >= 0 ? off[i] : 0);
+    need = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (off[i] >= 0 && have[i] != 3u) {
+        float t[2];
+        const unsigned got = take_pair(x[i], epoch, t) & ~have[i];
+        if (got & 1u) d[i][0] = t[0];
+        if (got & 2u) d[i][1] = t[1];
+        have[i] |= got;
+        need = need || have[i] != 3u;
+      }
+    if (!need) break;
+    if ((spin & 1023) == 1023 &&
+        __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (need) {
+    __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
+  return true;
+}
+
 // Fixed-order wave sum on the DPP network + row broadcasts (result valid in
 // lane 63).
 #define SFM_DPP_F32(x, ctrl, rmask, bc)                                         \
@@ -2053,7 +2111,7 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
   constexpr int kGranS = 4;   // A0 A1 (downhill) B0 B1 (uphill)
   constexpr int kSlotS = TL::kPerim * kGranS + kPartGran;
   static_assert(kSlotS <= Tile<32>::kSlot, "exchange area is sized for Tile<32>");
-  constexpr int kHaloPollsS = (TL::kHalo * 2 + NT - 1) / NT;
+  constexpr int kHaloPollsS = (TL::kHalo + NT - 1) / NT;   // one 16-byte pair per halo node
   constexpr int kPartPolls1 = (kMaxWg + NT - 1) / NT;  // one value per workgroup
   __shared__ float xt[2][T + 2][T + 3];
   // near-side spring forces of every frame node, by link and component (SH)
@@ -2094,24 +2152,27 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X)
       h_n = slice * plane + (long long)gy * p.X + gx;
   }
-  long long h_off[kHaloPollsS];
+  // byte offset (slot parity 0) of the downhill pair of halo node tid + u NT in the
+  // exchange area, or -1; the uphill pair follows it
+  const __amdgpu_buffer_rsrc_t comm_rs = __builtin_amdgcn_make_buffer_rsrc(
+      q.comm, 0, static_cast<int>((long long)q.n_wg * 2 * kSlotS * sizeof(u64)), 0x00020000);
+  int h_off[kHaloPollsS];
   float* h_dst[kHaloPollsS];
 #pragma unroll
   for (int u = 0; u < kHaloPollsS; ++u) {
     h_off[u] = -1;
     h_dst[u] = nullptr;
-    const int t = tid + u * NT;
-    if (t < TL::kHalo * 2) {
-      const int h = t >> 1, j = t & 1;
+    const int h = tid + u * NT;
+    if (h < TL::kHalo) {
       int qy, qx;
       halo_coord<T>(h, &qy, &qx);
       const int gy = ty_i * T + qy - 1, gx = tx_i * T + qx - 1;
       if (gy >= 0 && gy < p.Y && gx >= 0 && gx < p.X) {
         const int oty = gy / T, otx = gx / T;
         const int owg = (slice * q.nty + oty) * q.ntx + otx;
-        h_off[u] = (long long)owg * 2 * kSlotS +
-                   perim_index<T>(gy - oty * T, gx - otx * T) * kGranS + j;
-        h_dst[u] = &hval[h][j];
+        h_off[u] = (owg * 2 * kSlotS + perim_index<T>(gy - oty * T, gx - otx * T) * kGranS) *
+                   static_cast<int>(sizeof(u64));
+        h_dst[u] = &hval[h][0];
       }
     }
   }
@@ -2180,15 +2241,17 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
   // workgroup's own publication (they publish at about the same time, and a
   // request needs half a round trip to get there): the other half of the round
   // trip hides behind the verification instead of opening the next step.
-  u64 hearly[kHaloPollsS], hearly2[kHaloPollsS];   // two requests, ~1500 cycles apart
+  // (a second request behind the verification's polls bought nothing once a step's
+  // hand-off was two granules per node: 3.13 us per step with either one, 3.38 with
+  // neither)
+  v4u hearly[kHaloPollsS];
 #pragma unroll
-  for (int u = 0; u < kHaloPollsS; ++u) hearly[u] = hearly2[u] = 0;
-  auto request_halo = [&](int step, u64* dst) {
-    const long long next_off = (long long)((step + 1) & 1) * kSlotS;
+  for (int u = 0; u < kHaloPollsS; ++u) hearly[u] = v4u{0, 0, 0, 0};
+  auto request_halo = [&](int step, v4u* dst) {
+    const int next_off = ((step + 1) & 1) * kSlotS * static_cast<int>(sizeof(u64));
 #pragma unroll
     for (int u = 0; u < kHaloPollsS; ++u)
-      dst[u] = __hip_atomic_load(q.comm + (h_off[u] >= 0 ? h_off[u] + next_off : 0),
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dst[u] = load_pair(comm_rs, h_off[u] >= 0 ? h_off[u] + next_off : 0);
   };
   auto issue_early = [&]() {
     if (!early_pending) return;
@@ -2465,25 +2528,24 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     const bool last = k == q.num_iters + 1;
     // the state after k - 1 steps / the partial power of step k - 1 carry this tag
     const unsigned want_tag = static_cast<unsigned>(k) | redo_prev;
-    const long long slot_off = (long long)(k & 1) * kSlotS;
+    const int slot_off = (k & 1) * kSlotS * static_cast<int>(sizeof(u64));
     STICK(0)
     // ---- the halo of the 8 neighbours: the only wait in front of the step --------
     if (!last) {
-      const u64* g[kHaloPollsS];
-      float* d[kHaloPollsS];
+      int off[kHaloPollsS];
+      unsigned have[kHaloPollsS];
 #pragma unroll
       for (int u = 0; u < kHaloPollsS; ++u) {
-        g[u] = h_off[u] >= 0 ? q.comm + h_off[u] + slot_off : nullptr;
-        d[u] = h_dst[u];
-        if (g[u] && static_cast<unsigned>(hearly[u] >> 32) == want_tag) {
-          *d[u] = __uint_as_float(static_cast<unsigned>(hearly[u]));
-          g[u] = nullptr;   // requested at the end of the previous step, arrived since
-        } else if (g[u] && static_cast<unsigned>(hearly2[u] >> 32) == want_tag) {
-          *d[u] = __uint_as_float(static_cast<unsigned>(hearly2[u]));
-          g[u] = nullptr;
+        off[u] = h_off[u] >= 0 ? h_off[u] + slot_off : -1;
+        have[u] = 0;
+        if (off[u] >= 0) {   // requested at the end of the previous step, arrived since?
+          float t[2];
+          have[u] = take_pair(hearly[u], want_tag, t);
+          if (have[u] & 1u) h_dst[u][0] = t[0];
+          if (have[u] & 2u) h_dst[u][1] = t[1];
         }
       }
-      const bool mine_ok = poll_granules<kHaloPollsS>(g, d, want_tag, q.abort);
+      const bool mine_ok = poll_pairs<kHaloPollsS>(comm_rs, off, h_dst, have, want_tag, q.abort);
       if (!wg_and(mine_ok)) {
         ok = false;
         break;
@@ -2520,7 +2582,6 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
     {
       if (tid == 0) part_all[wg] = part_before;  // own: no round trip
       const bool mine_ok = poll_granules<kPartPolls1>(pg, pd, want_tag, q.abort);
-      if (!last && k < q.num_iters) request_halo(k, hearly2);
       if (!wg_and(mine_ok)) {
         ok = false;
         break;
@@ -2557,14 +2618,16 @@ mesh_persist2d_spec_kernel(MeshParams p, const float* __restrict__ xg,
       {
         // the neighbours' uphill candidates of the state after k - 1 steps (same
         // slot and tag as the downhill ones this iteration started with)
-        const u64* g[kHaloPollsS];
+        int off[kHaloPollsS];
+        unsigned have[kHaloPollsS];
         float* d[kHaloPollsS];
 #pragma unroll
         for (int u = 0; u < kHaloPollsS; ++u) {
-          g[u] = h_off[u] >= 0 ? q.comm + h_off[u] + slot_off + 2 : nullptr;
+          off[u] = h_off[u] >= 0 ? h_off[u] + slot_off + 2 * static_cast<int>(sizeof(u64)) : -1;
+          have[u] = 0;
           d[u] = h_dst[u] ? h_dst[u] + 2 : nullptr;
         }
-        const bool mine_ok = poll_granules<kHaloPollsS>(g, d, want_tag, q.abort);
+        const bool mine_ok = poll_pairs<kHaloPollsS>(comm_rs, off, d, have, want_tag, q.abort);
         if (!wg_and(mine_ok)) {
           ok = false;
           break;
