@@ -423,6 +423,27 @@ __device__ __forceinline__ float g_entry(float mua, float mub, float ia, float i
   return __fmaf_rn(-mua, ib, __fmul_rn(-mub, ia));
 }
 
+// v_pk_min_u16 / v_pk_max_u16 on two 16-bit fields of a dword
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
+  us2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  const us2 z = __builtin_elementwise_min(x, y);
+  unsigned r;
+  __builtin_memcpy(&r, &z, 4);
+  return r;
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  us2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  const us2 z = __builtin_elementwise_max(x, y);
+  unsigned r;
+  __builtin_memcpy(&r, &z, 4);
+  return r;
+}
+
 // Wave-wide inclusive add scan on the DPP network (row shifts inside each
 // 16-lane row, then row broadcasts), ~12 VALU ops instead of 6 LDS permutes.
 __device__ __forceinline__ int wave_scan_incl(int v) {
@@ -447,6 +468,7 @@ struct PrepTables {
   unsigned long long row_acc[2][ROWS];
   double row_pre[2][ROWS + 1];
   int col_sq[2][64 * kPrepCols];  // column sums of squares (post: mirrored)
+  int wred[2][3][WAVES];          // min / max / sum per wave (LAZY)
   // sums / sums of squares per 16 x 16 block, later their 2-D prefix sums (in place)
   unsigned long long blk_acc[2][kBlkRows][kBlkCols];  // packed like row_acc
 };
@@ -460,7 +482,9 @@ struct PrepTables {
 // launch went away -- 19.25 vs 18.9 ms per pair.  The two workgroups of a CU do
 // not stay in anti-phase, so the extra VALU / LDS phase of a patch is not hidden
 // behind the other workgroup's matrix loop; it simply adds.  Removed again.
-template <int WAVES, int ROWS>
+// LAZY (MfmaArgs::lazy_g, its own instantiation): the pass never needs a pixel
+// twice, so nothing is staged in LDS -- see the fused loop below.
+template <int WAVES, int ROWS, bool LAZY>
 __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
                                                unsigned char* smem,
                                                PrepTables<WAVES, ROWS>* tp) {
@@ -471,7 +495,10 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
   int (&band_tot)[2][WAVES + 1][64 * kPrepCols] = tp->band_tot;
   // reduction scratch of phase 2, aliased onto band_tot (separated by a barrier)
   static_assert(sizeof(tp->band_tot) >= sizeof(int) * 2 * 3 * kPrepThreads, "alias");
-  int (*red)[3][kPrepThreads] = reinterpret_cast<int (*)[3][kPrepThreads]>(&band_tot[0][0][0]);
+  // (LAZY: band_tot holds the band sums by then; the scratch is its own small array)
+  constexpr int kRedPitch = LAZY ? WAVES : kPrepThreads;
+  int* const redp = LAZY ? &tp->wred[0][0][0] : &band_tot[0][0][0];
+#define SFM_RED(s, i, w) redp[((s) * 3 + (i)) * kRedPitch + (w)]
   unsigned long long (&row_acc)[2][ROWS] = tp->row_acc;
   double (&row_pre)[2][ROWS + 1] = tp->row_pre;
   int (&col_sq)[2][64 * kPrepCols] = tp->col_sq;
@@ -515,6 +542,95 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
 #define SFM_PREP_ITEMS 4
 #endif
   constexpr int kItems = SFM_PREP_ITEMS;  // items per thread and plane whose loads are in flight
+  if constexpr (LAZY) {
+    // LAZY: everything this pass needs of a pixel is a sum -- per row, per column
+    // and band of 16 rows, per 16 x 16 block, minimum / maximum -- so the patches
+    // are never staged in LDS.  A thread takes one half block (8 rows x 16 columns
+    // of one side: eight 16-byte loads in flight, one global round trip per patch)
+    // and leaves its eight row sums and sixteen column sums, each packed with its
+    // sum of squares into one word, in two LDS arrays (plain 16-byte stores: the
+    // first version added them to the shared tables with 41 LDS atomics per thread,
+    // 6- to 10-way address conflicts each, and spent 25 k cycles per patch here);
+    // a second pass (a thread per row / per column) folds them into the tables
+    // the staged form fills.  2 x Py / 8 x Px / 16 items (400 for 160 x 160).  The
+    // same exact integers in the same tables: everything below is shared.  Py, Px
+    // multiples of 16 (host: lazy_g).
+    const int NB = py >> 4, NC = px >> 4;
+    const int per_side = 2 * NB * NC;
+    // rowpart[s][y][chunk] = row sum (12 bits) | sum of squares << 12;
+    // halfcol[s][half band][x] = column sum over 8 rows (11 bits) | sum of squares << 11
+    unsigned* rowpart = reinterpret_cast<unsigned*>(smem);
+    unsigned* halfcol = rowpart + 2 * py * NC;
+    unsigned mnp[2] = {0x00ff00ffu, 0x00ff00ffu}, mxp[2] = {0u, 0u};
+    for (int item = threadIdx.x; item < 2 * per_side; item += kPrepThreads) {
+      const int s = item >= per_side ? 1 : 0;
+      const int rem = item - s * per_side;
+      const int bh = rem / NC, ch = rem - bh * NC;   // half band (8 rows), chunk (16 columns)
+      const int yb = 8 * bh;
+      const int W = s ? a.ishape[1][1] : a.ishape[0][1];
+      const unsigned char* img = s ? a.img[1] : a.img[0];
+      const int yy0 = s ? y0[1] : y0[0], xx0 = s ? x0[1] : x0[0];
+      const long long ib = s ? img_bytes[1] : img_bytes[0];
+      v4i w[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        w[r] = load_16_bytes(img, (long long)(yy0 + yb + r) * W + xx0 + ch * 16, ib);
+      unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};   // bytes 0 | 2, 1 | 3 as 16-bit fields
+      unsigned q[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) q[j] = 0;
+      unsigned mn2 = 0x00ff00ffu, mx2 = 0u;
+      int tsum = 0;
+      unsigned tsq = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int isum = 0, isq = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned v = static_cast<unsigned>(w[r][k]);
+          const unsigned e = v & 0x00ff00ffu, o = (v >> 8) & 0x00ff00ffu;
+          lo[k] += e;
+          hi[k] += o;
+          mn2 = pk_min_u16(pk_min_u16(mn2, e), o);
+          mx2 = pk_max_u16(pk_max_u16(mx2, e), o);
+          isum = static_cast<int>(__builtin_amdgcn_sad_u8(v, 0u, isum));
+          isq = static_cast<int>(__builtin_amdgcn_udot4(v, v, isq, false));
+          const unsigned b0 = v & 0xffu, b1 = (v >> 8) & 0xffu, b2 = (v >> 16) & 0xffu, b3 = v >> 24;
+          q[4 * k + 0] = __umul24(b0, b0) + q[4 * k + 0];
+          q[4 * k + 1] = __umul24(b1, b1) + q[4 * k + 1];
+          q[4 * k + 2] = __umul24(b2, b2) + q[4 * k + 2];
+          q[4 * k + 3] = __umul24(b3, b3) + q[4 * k + 3];
+        }
+        rowpart[(s * py + yb + r) * NC + ch] =
+            static_cast<unsigned>(isum) | (static_cast<unsigned>(isq) << 12);
+        tsum += isum;
+        tsq += static_cast<unsigned>(isq);
+      }
+      atomicAdd(&blk_acc[s][bh >> 1][ch],
+                (static_cast<unsigned long long>(tsq) << 32) | static_cast<unsigned>(tsum));
+      v4i* hd = reinterpret_cast<v4i*>(halfcol + (s * 2 * NB + bh) * px + 16 * ch);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        hd[k] = v4i{static_cast<int>((lo[k] & 0xffffu) | (q[4 * k + 0] << 11)),
+                    static_cast<int>((hi[k] & 0xffffu) | (q[4 * k + 1] << 11)),
+                    static_cast<int>((lo[k] >> 16) | (q[4 * k + 2] << 11)),
+                    static_cast<int>((hi[k] >> 16) | (q[4 * k + 3] << 11))};
+      if (s) {
+        mnp[1] = pk_min_u16(mnp[1], mn2);
+        mxp[1] = pk_max_u16(mxp[1], mx2);
+        sum[1] += tsum;
+      } else {
+        mnp[0] = pk_min_u16(mnp[0], mn2);
+        mxp[0] = pk_max_u16(mxp[0], mx2);
+        sum[0] += tsum;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      mn[s] = static_cast<int>(min(mnp[s] & 0xffffu, mnp[s] >> 16));
+      mx[s] = static_cast<int>(max(mxp[s] & 0xffffu, mxp[s] >> 16));
+    }
+  } else
   for (int item0 = threadIdx.x; item0 < n_items; item0 += kPrepThreads * kItems) {
     v4i w[2][kItems];
 #pragma unroll
@@ -576,28 +692,68 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
       sum[s] += __shfl_xor(sum[s], d, 64);
     }
     if (lane == 0) {
-      red[s][0][wave] = mn[s];
-      red[s][1][wave] = mx[s];
-      red[s][2][wave] = sum[s];
+      SFM_RED(s, 0, wave) = mn[s];
+      SFM_RED(s, 1, wave) = mx[s];
+      SFM_RED(s, 2, wave) = sum[s];
     }
   }
   __syncthreads();
   PTICK(1)
+  if constexpr (LAZY) {
+    // second pass of the fused loop: a thread per column folds the half-band words
+    // into the band sums and the column's sum of squares, a thread per row the
+    // chunk words into the row's sums (the barrier behind the centres orders them)
+    const int NB = py >> 4, NC = px >> 4;
+    const unsigned* rowpart = reinterpret_cast<const unsigned*>(smem);
+    const unsigned* halfcol = rowpart + 2 * py * NC;
+    int* bsum = &band_tot[0][0][0];
+    for (int t = threadIdx.x; t < 2 * px; t += kPrepThreads) {
+      const int s = t >= px ? 1 : 0, x = t - s * px;
+      const unsigned* hc = halfcol + s * 2 * NB * px + x;
+      unsigned wv[24];
+#pragma unroll
+      for (int h = 0; h < 24; ++h) wv[h] = h < 2 * NB ? hc[h * px] : 0u;   // (all in flight together)
+      unsigned sq = 0;
+#pragma unroll
+      for (int I = 0; I < 12; ++I)
+        if (I < NB) {
+          bsum[(s * NB + I) * px + x] = static_cast<int>((wv[2 * I] & 0x7ffu) + (wv[2 * I + 1] & 0x7ffu));
+          sq += (wv[2 * I] >> 11) + (wv[2 * I + 1] >> 11);
+        }
+      // (post patch: mirrored index, like the sweep's column energies)
+      col_sq[s][s ? px - 1 - x : x] = static_cast<int>(sq);
+    }
+    for (int t = threadIdx.x; t < 2 * py; t += kPrepThreads) {
+      const int u = 2 * py - 1 - t;   // (rows from the other end of the workgroup than the columns)
+      const unsigned* rp = rowpart + u * NC;
+      unsigned wv[12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) wv[c] = c < NC ? rp[c] : 0u;
+      unsigned sm = 0, sq = 0;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        sm += wv[c] & 0xfffu;
+        sq += wv[c] >> 12;
+      }
+      (&row_acc[0][0])[(u >= py ? ROWS : 0) + (u >= py ? u - py : u)] =
+          (static_cast<unsigned long long>(sq) << 32) | sm;
+    }
+  }
   if (threadIdx.x < 2) {
     const int s = threadIdx.x;
     int r_mn = 255, r_mx = 0, r_sum = 0;
     for (int w2 = 0; w2 < kPrepWaves; ++w2) {
-      r_mn = min(r_mn, red[s][0][w2]);
-      r_mx = max(r_mx, red[s][1][w2]);
-      r_sum += red[s][2][w2];
+      r_mn = min(r_mn, SFM_RED(s, 0, w2));
+      r_mx = max(r_mx, SFM_RED(s, 1, w2));
+      r_sum += SFM_RED(s, 2, w2);
     }
-    red[s][0][0] = r_mn;
-    red[s][1][0] = r_mx;
-    red[s][2][0] = r_sum;
+    SFM_RED(s, 0, 0) = r_mn;
+    SFM_RED(s, 1, 0) = r_mx;
+    SFM_RED(s, 2, 0) = r_sum;
   }
   if (threadIdx.x < 2) {
     const int s = threadIdx.x;
-    const int mn = red[s][0][0], mx = red[s][1][0], sum = red[s][2][0];
+    const int mn = SFM_RED(s, 0, 0), mx = SFM_RED(s, 1, 0), sum = SFM_RED(s, 2, 0);
     const float mean =
         a.use_mean ? a.mean : static_cast<float>(sum) / static_cast<float>(py * px);
     int c = static_cast<int>(rintf(fminf(fmaxf(mean, 0.f), 255.f)));
@@ -614,6 +770,7 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
     p->c[s] = c;
     p->mu[s] = s_mu[s];
   }
+#undef SFM_RED
   __syncthreads();  // `red` (aliased with band_tot) fully consumed
   PTICK(2)
   if (a.prune && wave < 2) {
@@ -700,50 +857,18 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
   }
 
   const int xl = kPrepCols * lane;
-  if (a.lazy_g) {
+  if (LAZY) {
     // The correction table is built where it is read (kModeSameExactLazyG): of the
     // 20 row tiles of a patch 2.8 ever reach an epilogue, so instead of sweeping
     // Py rows of G (102 KB per patch, 60 % of this kernel's time) the pass leaves
     // the centred column sums above every 16th row, c16[side][I][x] (14 KB), and
     // the four 1-D arrays, which need one wave scan each.  Py, Px multiples of 16,
     // both <= 192 (host).
-    const int NB = py >> 4, cw = px >> 2;
+    const int NB = py >> 4;
     int* bsum = &band_tot[0][0][0];   // [2][NB][px]: raw column sums per band of 16 rows
     static_assert(sizeof(tp->band_tot) >= sizeof(int) * 2 * 10 * 160, "band sums");
-    for (int idx = threadIdx.x; idx < 2 * NB * cw; idx += kPrepThreads) {
-      const int s = idx / (NB * cw), rem = idx - s * NB * cw;
-      const int band = rem / cw, cx = rem - band * cw;
-      const unsigned* src =
-          reinterpret_cast<const unsigned*>(pix[s] + (16 * band) * px) + cx;
-      unsigned v[16];
-#pragma unroll
-      for (int y = 0; y < 16; ++y) v[y] = src[y * cw];   // (all in flight together)
-      unsigned lo = 0, hi = 0;       // bytes 0 | 2 and 1 | 3 as 16-bit fields (16 x 255 < 2^16)
-      unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-#pragma unroll
-      for (int y = 0; y < 16; ++y) {
-        lo += v[y] & 0x00ff00ffu;
-        hi += (v[y] >> 8) & 0x00ff00ffu;
-        const unsigned b0 = v[y] & 0xffu, b1 = (v[y] >> 8) & 0xffu;
-        const unsigned b2 = (v[y] >> 16) & 0xffu, b3 = v[y] >> 24;
-        q0 = __umul24(b0, b0) + q0;
-        q1 = __umul24(b1, b1) + q1;
-        q2 = __umul24(b2, b2) + q2;
-        q3 = __umul24(b3, b3) + q3;
-      }
-      int* dst = bsum + (s * NB + band) * px + 4 * cx;
-      *reinterpret_cast<v4i*>(dst) = v4i{static_cast<int>(lo & 0xffffu), static_cast<int>(hi & 0xffffu),
-                                         static_cast<int>(lo >> 16), static_cast<int>(hi >> 16)};
-      if (a.prune) {
-        // (post patch: mirrored index, like the sweep's column energies)
-        const int x0 = 4 * cx;
-        atomicAdd(&col_sq[s][s ? px - 1 - x0 : x0], static_cast<int>(q0));
-        atomicAdd(&col_sq[s][s ? px - 2 - x0 : x0 + 1], static_cast<int>(q1));
-        atomicAdd(&col_sq[s][s ? px - 3 - x0 : x0 + 2], static_cast<int>(q2));
-        atomicAdd(&col_sq[s][s ? px - 4 - x0 : x0 + 3], static_cast<int>(q3));
-      }
-    }
-    __syncthreads();
+    // (the band sums, the column energies and the block sums were accumulated by
+    // the fused loop above; the barriers since then order them)
     int* c16 = a.c16 + b * a.c16_stride;   // [2][NB + 1][px], then T[py + 1]
     if (threadIdx.x < 2 * px) {
       const int s = threadIdx.x >= px ? 1 : 0, x = threadIdx.x - s * px;
@@ -762,6 +887,7 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
       bsum[s * NB * px + x] = run;   // the column's raw total (its own entries are consumed)
     }
     __syncthreads();
+    PTICK(3)
     const int ca = s_c[0], cb = s_c[1];
     const float mua = s_mu[0], mub = s_mu[1];
     float* aux = a.aux + (long long)b * (4 * a.aux_n + 4);
@@ -984,7 +1110,7 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
     for (int k = 0; k < kPrepCols; ++k) {
       const int x = xl + k;
       int sa = 0, sb = 0;
-      if (a.lazy_g) {   // raw column totals, natural order (post patch: mirrored here)
+      if (LAZY) {   // raw column totals, natural order (post patch: mirrored here)
         const int* tot = &band_tot[0][0][0];
         sa = x < px ? tot[x] : 0;
         sb = x < px ? tot[(py >> 4) * px + (px - 1 - x)] : 0;
@@ -1108,7 +1234,12 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
 
 
 constexpr int kPrepWavesAlone = 8;   // bands of rows swept concurrently (stand-alone kernel)
-__global__ void __launch_bounds__(64 * kPrepWavesAlone) mfma_prep_same_kernel(MfmaArgs a) {
+#ifndef SFM_PREP_LB
+#define SFM_PREP_LB 1
+#endif
+template <bool LAZY>
+__global__ void __launch_bounds__(64 * kPrepWavesAlone, LAZY ? SFM_PREP_LB : 1)
+mfma_prep_same_kernel(MfmaArgs a) {
   if (a.work_counter && blockIdx.x == 0 && threadIdx.x == 0)
     *a.work_counter = 0;  // the correlation kernel's patch queue
   if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[2] = a.clk[3] = a.clk[4] = 0;  // tile counts
@@ -1116,8 +1247,8 @@ __global__ void __launch_bounds__(64 * kPrepWavesAlone) mfma_prep_same_kernel(Mf
     a.xcd_heads[kHeadPitch * threadIdx.x] = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ PrepTables<kPrepWavesAlone, kBoundRows> tables;
-  prep_same_body<kPrepWavesAlone, kBoundRows>(a, xcd_block_item(a, blockIdx.x, a.batch), smem,
-                                              &tables);
+  prep_same_body<kPrepWavesAlone, kBoundRows, LAZY>(a, xcd_block_item(a, blockIdx.x, a.batch),
+                                                    smem, &tables);
 }
 
 // ---------------------------------------------------------------------------
@@ -4289,14 +4420,21 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   if (same) {
     const size_t prep_lds = 2 * (((size_t)a.P[0] * a.P[1] + 15) & ~(size_t)15);
     static size_t prep_attr = 0;
-    if (prep_lds > prep_attr) {
+    if (!a.lazy_g && prep_lds > prep_attr) {
       SFM_HIP_CHECK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&mfma_prep_same_kernel),
+          reinterpret_cast<const void*>(&mfma_prep_same_kernel<false>),
           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(prep_lds)));
       prep_attr = prep_lds;
     }
-    hipLaunchKernelGGL(mfma_prep_same_kernel, dim3(d->batch), dim3(64 * kPrepWavesAlone),
-                       prep_lds, st, a);
+    if (a.lazy_g) {   // no pixels in LDS: the packed row / half-band column words
+      const size_t lazy_lds =
+          sizeof(unsigned) * (2 * (size_t)a.P[0] * (a.P[1] / 16) + 2 * 2 * (size_t)(a.P[0] / 16) * a.P[1]);
+      hipLaunchKernelGGL(mfma_prep_same_kernel<true>, dim3(d->batch),
+                         dim3(64 * kPrepWavesAlone), lazy_lds, st, a);
+    }
+    else
+      hipLaunchKernelGGL(mfma_prep_same_kernel<false>, dim3(d->batch),
+                         dim3(64 * kPrepWavesAlone), prep_lds, st, a);
   } else {
     const size_t prep_lds = (size_t)a.P[0] * a.P[1];
     hipLaunchKernelGGL(mfma_prep_kernel, dim3(d->batch, 2), dim3(kThreads),
