@@ -457,11 +457,12 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 }
 
 // LDS tables of the prep pass (behind the two raw uint8 patches).
-template <int WAVES, int ROWS>
+// (LAZY: the band sums live in the dynamic area, behind the packed words they come from)
+template <int WAVES, int ROWS, bool LAZY>
 struct PrepTables {
   int s_c[2];
   float s_mu[2];
-  alignas(16) int band_tot[2][WAVES + 1][64 * kPrepCols];   // (+ 1: room for [2][10][160] band sums, lazy_g)
+  alignas(16) int band_tot[2][LAZY ? 1 : WAVES + 1][LAZY ? 4 : 64 * kPrepCols];
   // pruning bounds: per-row sum and sum of squares of the raw pixels, later the
   // prefix sums of the row energies (doubles)
   // (sum in the low, sum of squares in the high word: one 64-bit LDS atomic per item)
@@ -487,14 +488,17 @@ struct PrepTables {
 template <int WAVES, int ROWS, bool LAZY>
 __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
                                                unsigned char* smem,
-                                               PrepTables<WAVES, ROWS>* tp) {
+                                               PrepTables<WAVES, ROWS, LAZY>* tp) {
   constexpr int kPrepWaves = WAVES;
   constexpr int kPrepThreads = 64 * WAVES;
   int (&s_c)[2] = tp->s_c;
   float (&s_mu)[2] = tp->s_mu;
-  int (&band_tot)[2][WAVES + 1][64 * kPrepCols] = tp->band_tot;
+  auto& band_tot = tp->band_tot;
   // reduction scratch of phase 2, aliased onto band_tot (separated by a barrier)
-  static_assert(sizeof(tp->band_tot) >= sizeof(int) * 2 * 3 * kPrepThreads, "alias");
+  static_assert(LAZY || sizeof(tp->band_tot) >= sizeof(int) * 2 * 3 * kPrepThreads, "alias");
+  // LAZY: band sums [2][Py / 16][Px] over the row words of the fused loop (same size),
+  // written once those are folded into the row table
+  int* const lazy_bsum = reinterpret_cast<int*>(smem);
   // (LAZY: band_tot holds the band sums by then; the scratch is its own small array)
   constexpr int kRedPitch = LAZY ? WAVES : kPrepThreads;
   int* const redp = LAZY ? &tp->wred[0][0][0] : &band_tot[0][0][0];
@@ -706,7 +710,23 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
     const int NB = py >> 4, NC = px >> 4;
     const unsigned* rowpart = reinterpret_cast<const unsigned*>(smem);
     const unsigned* halfcol = rowpart + 2 * py * NC;
-    int* bsum = &band_tot[0][0][0];
+    int* bsum = lazy_bsum;
+    for (int t = threadIdx.x; t < 2 * py; t += kPrepThreads) {
+      const int u = 2 * py - 1 - t;   // (rows from the other end of the workgroup than the columns)
+      const unsigned* rp = rowpart + u * NC;
+      unsigned wv[12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) wv[c] = c < NC ? rp[c] : 0u;
+      unsigned sm = 0, sq = 0;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        sm += wv[c] & 0xfffu;
+        sq += wv[c] >> 12;
+      }
+      (&row_acc[0][0])[(u >= py ? ROWS : 0) + (u >= py ? u - py : u)] =
+          (static_cast<unsigned long long>(sq) << 32) | sm;
+    }
+    __syncthreads();   // the row words are consumed: the band sums take their place
     for (int t = threadIdx.x; t < 2 * px; t += kPrepThreads) {
       const int s = t >= px ? 1 : 0, x = t - s * px;
       const unsigned* hc = halfcol + s * 2 * NB * px + x;
@@ -722,21 +742,6 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
         }
       // (post patch: mirrored index, like the sweep's column energies)
       col_sq[s][s ? px - 1 - x : x] = static_cast<int>(sq);
-    }
-    for (int t = threadIdx.x; t < 2 * py; t += kPrepThreads) {
-      const int u = 2 * py - 1 - t;   // (rows from the other end of the workgroup than the columns)
-      const unsigned* rp = rowpart + u * NC;
-      unsigned wv[12];
-#pragma unroll
-      for (int c = 0; c < 12; ++c) wv[c] = c < NC ? rp[c] : 0u;
-      unsigned sm = 0, sq = 0;
-#pragma unroll
-      for (int c = 0; c < 12; ++c) {
-        sm += wv[c] & 0xfffu;
-        sq += wv[c] >> 12;
-      }
-      (&row_acc[0][0])[(u >= py ? ROWS : 0) + (u >= py ? u - py : u)] =
-          (static_cast<unsigned long long>(sq) << 32) | sm;
     }
   }
   if (threadIdx.x < 2) {
@@ -865,8 +870,7 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
     // the four 1-D arrays, which need one wave scan each.  Py, Px multiples of 16,
     // both <= 192 (host).
     const int NB = py >> 4;
-    int* bsum = &band_tot[0][0][0];   // [2][NB][px]: raw column sums per band of 16 rows
-    static_assert(sizeof(tp->band_tot) >= sizeof(int) * 2 * 10 * 160, "band sums");
+    int* bsum = lazy_bsum;   // [2][NB][px]: raw column sums per band of 16 rows
     // (the band sums, the column energies and the block sums were accumulated by
     // the fused loop above; the barriers since then order them)
     int* c16 = a.c16 + b * a.c16_stride;   // [2][NB + 1][px], then T[py + 1]
@@ -1111,7 +1115,7 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
       const int x = xl + k;
       int sa = 0, sb = 0;
       if (LAZY) {   // raw column totals, natural order (post patch: mirrored here)
-        const int* tot = &band_tot[0][0][0];
+        const int* tot = lazy_bsum;
         sa = x < px ? tot[x] : 0;
         sb = x < px ? tot[(py >> 4) * px + (px - 1 - x)] : 0;
       } else {
@@ -1234,8 +1238,9 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
 
 
 constexpr int kPrepWavesAlone = 8;   // bands of rows swept concurrently (stand-alone kernel)
+// LAZY: three workgroups per CU (51 KB of LDS each; <= 80 VGPRs at six waves per SIMD)
 #ifndef SFM_PREP_LB
-#define SFM_PREP_LB 1
+#define SFM_PREP_LB 6
 #endif
 template <bool LAZY>
 __global__ void __launch_bounds__(64 * kPrepWavesAlone, LAZY ? SFM_PREP_LB : 1)
@@ -1246,7 +1251,7 @@ mfma_prep_same_kernel(MfmaArgs a) {
   if (a.xcd_heads && blockIdx.x == 0 && threadIdx.x < kXcds)
     a.xcd_heads[kHeadPitch * threadIdx.x] = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ PrepTables<kPrepWavesAlone, kBoundRows> tables;
+  __shared__ PrepTables<kPrepWavesAlone, kBoundRows, LAZY> tables;
   prep_same_body<kPrepWavesAlone, kBoundRows, LAZY>(a, xcd_block_item(a, blockIdx.x, a.batch),
                                                     smem, &tables);
 }
