@@ -744,8 +744,10 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
       col_sq[s][s ? px - 1 - x : x] = static_cast<int>(sq);
     }
   }
-  if (threadIdx.x < 2) {
-    const int s = threadIdx.x;
+  // (LAZY: by two lanes of the last wave, which has no share of the second pass)
+  const int ctr_lane = static_cast<int>(threadIdx.x) - (LAZY ? kPrepThreads - 64 : 0);
+  if (ctr_lane >= 0 && ctr_lane < 2) {
+    const int s = ctr_lane;
     int r_mn = 255, r_mx = 0, r_sum = 0;
     for (int w2 = 0; w2 < kPrepWaves; ++w2) {
       r_mn = min(r_mn, SFM_RED(s, 0, w2));
@@ -756,8 +758,8 @@ __device__ __forceinline__ void prep_same_body(const MfmaArgs& a, const int b,
     SFM_RED(s, 1, 0) = r_mx;
     SFM_RED(s, 2, 0) = r_sum;
   }
-  if (threadIdx.x < 2) {
-    const int s = threadIdx.x;
+  if (ctr_lane >= 0 && ctr_lane < 2) {
+    const int s = ctr_lane;
     const int mn = SFM_RED(s, 0, 0), mx = SFM_RED(s, 1, 0), sum = SFM_RED(s, 2, 0);
     const float mean =
         a.use_mean ? a.mean : static_cast<float>(sum) / static_cast<float>(py * px);
