@@ -81,6 +81,9 @@ int sfm_device_count(int* count);
  *                         the epilogues (default: the rows of the requested tiles only)
  *   SFM_MFMA_WIDEN=1      lazy path: the store requests a patch starts with are widened
  *                         by one row tile (fewer recomputed tiles, more finished ones)
+ *   SFM_MFMA_LAZYG=0      the prep kernel writes the whole correction table (default, pruned
+ *                         flow launches: the finishing tiles build their 16 rows; the prep pass
+ *                         then keeps no patch in LDS)
  *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry
  *   SFM_MFMA_QUEUE=0      static instead of dynamic patch queue
  *   SFM_MFMA_XCD=1        one patch queue per XCD (measured: no gain) instead of a flat one

@@ -109,6 +109,46 @@ def test_many_patches_per_workgroup_on_interleaved_kinds(gpu, py, px, mean):
   check_sharpness(full[ok, 2], want[ok, 2])
 
 
+@pytest.mark.parametrize('py,px', [(160, 160), (128, 128), (112, 112), (96, 96), (64, 64), (48, 48),
+                                   (32, 48), (160, 128), (96, 160), (144, 80), (48, 160)])
+@pytest.mark.parametrize('mean', [None, 100.0])
+def test_prep_without_staging_matches_the_staged_form(gpu, py, px, mean):
+  """The prep pass of the lazy-table mode reduces half blocks of pixels in
+  registers (no patch in LDS, packed row / column words, a second pass) where the
+  staged form sweeps an LDS copy: the same integers in the same tables, so the
+  flow vectors and peak statistics are the same bits (SFM_MFMA_LAZYG=0: staged
+  form + prep-built table; SFM_MFMA_PRUNE=0: every tile).  Patch sizes of every
+  instantiated chunk geometry, non-square patches, starts clamped at the image
+  borders and at every byte alignment; clipped / saturated content (integer
+  centres away from the mean) in two of the seven regions."""
+  from sofima_amd import _abi, flow_field
+  pre, post = _mosaic(47)
+  pre = pre.copy()
+  post = post.copy()
+  pre[:, 500:1000] = np.where(pre[:, 500:1000] > 128, 255, pre[:, 500:1000])   # saturated
+  post[:, 1500:2000] = (post[:, 1500:2000] // 64) * 64                            # few levels
+  rng = np.random.default_rng(3 * py + px)
+  b = 301
+  starts, _ = _interleaved_starts(rng, b, py, px)
+  starts[:7, 1] = np.arange(7)                      # every alignment at the left border
+  starts[7:14, 1] = pre.shape[1] - px - np.arange(7)   # ... and at the right one
+  starts[14, 0] = -40                               # clamped to the top
+  starts[15, 0] = pre.shape[0] + 5                  # ... the bottom
+  kw = dict(min_distance=2, threshold_rel=0.5, peak_radius=5,
+            post_patch_size=(py, px), post_starts=starts)
+  args = (pre, post, None, None, (py, px), starts, mean)
+  got = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+  with _abi.option('SFM_MFMA_LAZYG', 0):
+    staged = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+  with _abi.option('SFM_MFMA_PRUNE', 0):
+    full = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+  np.testing.assert_array_equal(got, staged)
+  np.testing.assert_array_equal(got, full)
+  for grid in (1, 3):
+    with _abi.option('SFM_MFMA_GRID', grid):
+      np.testing.assert_array_equal(flow_field.batched_xcorr_peaks(*args, method=2, **kw), got)
+
+
 def test_every_kernel_switch_returns_the_same_bits(gpu):
   """The run-time switches of the correlation kernel select schedules, never
   results: PROBE, TOUCH_ALL, EXACT, QUEUE, PRIO, MAX_WG_PER_CU (measurement
@@ -125,7 +165,7 @@ def test_every_kernel_switch_returns_the_same_bits(gpu):
     for name, values in (('SFM_MFMA_PROBE', (0,)), ('SFM_MFMA_TOUCH_ALL', (1,)),
                          ('SFM_MFMA_EXACT', (0,)), ('SFM_MFMA_QUEUE', (0,)),
                          ('SFM_MFMA_PRIO', (1, 2, 3)), ('SFM_MFMA_MAX_WG_PER_CU', (1,)),
-                         ('SFM_MFMA_PRUNE', (0,)), ('SFM_MFMA_LAZY', (0,)),
+                         ('SFM_MFMA_PRUNE', (0,)), ('SFM_MFMA_LAZY', (0,)), ('SFM_MFMA_LAZYG', (0,)),
                          ('SFM_MFMA_EARLY', (0, 1, 4)), ('SFM_MFMA_WIDEN', (1,)),
                          ('SFM_MFMA_NARROW', (0, 4)), ('SFM_MFMA_XCD', (1,)),
                          ('SFM_MFMA_GRID', (1, 3))):
