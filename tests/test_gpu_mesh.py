@@ -583,6 +583,69 @@ def test_speculative_fire_is_bit_identical(gpu, shape):
   np.testing.assert_allclose(np.array(c[0]), wx, atol=2e-3 * np.abs(wx).max())
 
 
+@pytest.mark.gpu
+def test_speculative_hand_off_fuzz(gpu):
+  """Time-boxed (25 s) random fuzz of the persistent kernel's hand-off -- candidate
+  positions instead of (x, v, a), uphill candidates only on a redo, 16-byte pair
+  loads -- against the kernel that waits for the power: random shapes (one to four
+  slices, ragged tiles), target fields from smooth to noise, spring constants and
+  time steps that make uphill events from rare to every few steps, several chunks;
+  every third case with another stream keeping the memory system busy (uneven
+  load: the hand-off must not depend on arrival order).  Positions, velocities,
+  FIRE scalars and step counts equal bit for bit."""
+  import time
+  import torch
+  from scipy import ndimage
+  from sofima_amd import mesh
+  rng = np.random.default_rng(5)
+  t0 = time.time()
+  cases = uphill_cases = 0
+  junk = torch.zeros(64 << 20, device='cuda')
+  side = torch.cuda.Stream()
+  while time.time() - t0 < 25.0 or cases < 6:
+    ny, nx = (int(v) for v in rng.integers(17, 211, 2))
+    nz = int(rng.integers(1, 5))
+    if ((ny + 15) // 16) * ((nx + 15) // 16) * nz > 256:
+      nz = 1
+    shape = (2, nz, ny, nx)
+    sig = float(rng.choice([0.0, 1.0, 3.0, 8.0]))
+    prev = rng.standard_normal(shape)
+    if sig:
+      prev = ndimage.gaussian_filter(prev, (0, 0, sig, sig))
+    prev = (prev / np.abs(prev).max() * float(rng.choice([2, 20, 80]))).astype(np.float32)
+    if rng.random() < 0.5:
+      prev[:, :, : int(rng.integers(1, 4))] = np.nan
+    iters = int(rng.integers(20, 200))
+    cfg = mesh.IntegrationConfig(
+        dt=float(rng.choice([0.001, 0.01, 0.1])), gamma=0.0, k0=float(rng.choice([0.01, 0.05, 0.3])),
+        k=float(rng.choice([0.05, 0.1, 0.5])), stride=(40, 40), num_iters=iters,
+        max_iters=iters * int(rng.integers(1, 4)), stop_v_max=1e-9,
+        dt_max=float(rng.choice([10, 1000])), start_cap=float(rng.choice([0.01, 1.0])),
+        final_cap=10, prefer_orig_order=bool(rng.integers(0, 2)))
+    x0 = (rng.standard_normal(shape) * float(rng.choice([0, 0.5]))).astype(np.float32)
+    vv = lambda: mesh.velocity_verlet(x0, np.zeros_like(x0), prev, cfg, cfg.start_cap)
+    busy = cases % 3 == 2
+    if busy:
+      with torch.cuda.stream(side):
+        for _ in range(40):
+          junk.add_(1.0)
+    a = _with_env({'SFM_MESH_SPECULATE': '1'}, vv)
+    a2 = _with_env({'SFM_MESH_SPECULATE': '1'}, lambda: mesh.relax_mesh(x0, prev, cfg))
+    torch.cuda.synchronize()
+    b = _with_env({'SFM_MESH_SPECULATE': '0'}, vv)
+    b2 = _with_env({'SFM_MESH_SPECULATE': '0'}, lambda: mesh.relax_mesh(x0, prev, cfg))
+    msg = f'case {cases}: {shape} {cfg}'
+    for u, w in zip(a[:3], b[:3]):
+      np.testing.assert_array_equal(np.array(u), np.array(w), err_msg=msg)
+    assert a[3:] == b[3:], msg
+    np.testing.assert_array_equal(np.array(a2[0]), np.array(b2[0]), err_msg=msg)
+    np.testing.assert_array_equal(np.array(a2[1]), np.array(b2[1]), err_msg=msg)   # (NaN == NaN: blown-up cases)
+    assert a2[2] == b2[2], msg
+    uphill_cases += a[5] < iters   # n_pos below the step count: the power went negative
+    cases += 1
+  assert uphill_cases >= 3, (cases, uphill_cases)
+
+
 @pytest.mark.parametrize('case', ['tile2d', 'tile3d', 'vol3d', 'plane_vv'])
 def test_small_mesh_single_launch_is_bit_identical(gpu, case):
   """mesh_small_kernel (meshes of at most one workgroup's worth of nodes: all
