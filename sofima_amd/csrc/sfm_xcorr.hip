@@ -602,21 +602,37 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
 }
 
 // (value, index) arg-max with first-index tie break across the block.
+// (`better` is a total order on (value, -index): any reduction tree gives the same
+// winner.  Butterfly over the wave on the shuffle network, then the waves' winners
+// through LDS: two barriers instead of the nine of an LDS tree -- the peak kernels
+// run one workgroup per surface and are priced by their chains of round trips.)
 __device__ void block_argmax(float* v, int* i, float* lv, int* li) {
-  lv[threadIdx.x] = *v;
-  li[threadIdx.x] = *i;
-  __syncthreads();
-  for (int s = kBlock / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s &&
-        better(lv[threadIdx.x + s], li[threadIdx.x + s], lv[threadIdx.x],
-               li[threadIdx.x])) {
-      lv[threadIdx.x] = lv[threadIdx.x + s];
-      li[threadIdx.x] = li[threadIdx.x + s];
+  float bv = *v;
+  int bi = *i;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const float ov = __shfl_xor(bv, d, 64);
+    const int oi = __shfl_xor(bi, d, 64);
+    if (better(ov, oi, bv, bi)) {
+      bv = ov;
+      bi = oi;
     }
-    __syncthreads();
   }
-  *v = lv[0];
-  *i = li[0];
+  if ((threadIdx.x & 63) == 0) {
+    lv[threadIdx.x >> 6] = bv;
+    li[threadIdx.x >> 6] = bi;
+  }
+  __syncthreads();
+  bv = lv[0];
+  bi = li[0];
+#pragma unroll
+  for (int w = 1; w < kBlock / 64; ++w)
+    if (better(lv[w], li[w], bv, bi)) {
+      bv = lv[w];
+      bi = li[w];
+    }
+  *v = bv;
+  *i = bi;
   __syncthreads();
 }
 
@@ -871,26 +887,56 @@ __global__ void __launch_bounds__(kBlock) peaks_first_finish_kernel(PeakArgs p) 
                        1u << (i1 & 31));
 }
 
-__global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
-  __shared__ float lv[kBlock];
-  __shared__ int li[kBlock];
-  const int b = blockIdx.x;
+// Second peak + sharpness of surface b.  WAVE: by one wave (lanes instead of
+// threads, reductions on the shuffle network, no barrier) -- the common case, a
+// candidate list that did not overflow; otherwise by the whole workgroup.
+template <bool WAVE>
+__device__ void second_peak_body(const PeakArgs& p, int b, float* lv, int* li) {
+  constexpr int NT = WAVE ? 64 : kBlock;
+  const int tid = WAVE ? static_cast<int>(threadIdx.x & 63) : static_cast<int>(threadIdx.x);
   const float* s = p.surf + b * p.bstride;
   const float v1 = p.v1[b];
   const int i1 = p.idx1[b];
   const int w = p.nd + 2;
   const unsigned int* bitmap = p.bitmap + (long long)(b / p.group) * p.bitmap_words;
   if (v1 == -INFINITY) {
-    if (threadIdx.x < w) p.out[b * w + threadIdx.x] = NAN;
+    if (tid < w) p.out[b * w + tid] = NAN;
     return;
   }
+  // Sharpness window (flow_field.py:186-192): its position depends on the first
+  // peak only, so its loads go out first and return behind the candidate list's
+  // (one round trip less in this kernel's chain).
+  int pos[3], start[3], size[3];
+  {
+    long long r = i1;
+    pos[2] = static_cast<int>(r % p.S[2]);
+    r /= p.S[2];
+    pos[1] = static_cast<int>(r % p.S[1]);
+    pos[0] = static_cast<int>(r / p.S[1]);
+  }
+  long long wn = 1;
+  for (int a = 0; a < 3; ++a) {
+    size[a] = (a == 0 && p.nd == 2) ? 1 : 2 * p.radius[a] + 1;
+    size[a] = min(size[a], p.S[a]);
+    start[a] = min(max(pos[a] - size[a] / 2, 0), p.S[a] - size[a]);
+    wn *= size[a];
+  }
+  float mn = INFINITY;
+  for (long long k = tid; k < wn; k += NT) {
+    const int x = static_cast<int>(k % size[2]);
+    const long long r = k / size[2];
+    const int y = static_cast<int>(r % size[1]);
+    const int z = static_cast<int>(r / size[1]);
+    mn = fminf(mn, surf_at(s, p, start[0] + z, start[1] + y, start[2] + x));
+  }
+  const float peak_val = surf_at(s, p, pos[0], pos[1], pos[2]);
   // Second peak: best candidate whose flat index is not a first-peak index of
   // ANY surface in the batch (flow_field.py:263-265).
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   const int cnt = p.cand_count[b];
-  if (cnt <= kCandCap) {
-    for (int k = threadIdx.x; k < cnt; k += kBlock) {
+  if (WAVE || cnt <= kCandCap) {
+    for (int k = tid; k < cnt; k += NT) {
       const float v = p.cand_val[(long long)b * kCandCap + k];
       const int i = p.cand_idx[(long long)b * kCandCap + k];
       if ((bitmap[i >> 5] >> (i & 31)) & 1u) continue;
@@ -899,7 +945,7 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
         bi = i;
       }
     }
-  } else {
+  } else if constexpr (!WAVE) {
     // Candidate list overflowed (plateaus): rescan the surface.  Row tiles the
     // correlation kernel pruned were never stored (all their elements are below
     // the threshold): zeros for the sweep.
@@ -923,53 +969,66 @@ __global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
       }
     });
   }
-  block_argmax(&bv, &bi, lv, li);
+  if constexpr (WAVE) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const float ov = __shfl_xor(bv, d, 64);
+      const int oi = __shfl_xor(bi, d, 64);
+      if (better(ov, oi, bv, bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+  } else {
+    block_argmax(&bv, &bi, lv, li);
+  }
   // The value is read from the UN-suppressed array (flow_field.py:266-268):
   // with nothing left the arg-max is index 0, whose value is the surface value
   // there if index 0 is itself a peak.
   float v2 = bv;
   if (bv == -INFINITY && p.zero_is_peak[b]) v2 = s[0];
 
-  // Sharpness: peak / min over a clamped window (flow_field.py:186-192).
-  int pos[3], start[3], size[3];
-  {
-    long long r = i1;
-    pos[2] = static_cast<int>(r % p.S[2]);
-    r /= p.S[2];
-    pos[1] = static_cast<int>(r % p.S[1]);
-    pos[0] = static_cast<int>(r / p.S[1]);
-  }
-  long long wn = 1;
-  for (int a = 0; a < 3; ++a) {
-    size[a] = (a == 0 && p.nd == 2) ? 1 : 2 * p.radius[a] + 1;
-    size[a] = min(size[a], p.S[a]);
-    start[a] = min(max(pos[a] - size[a] / 2, 0), p.S[a] - size[a]);
-    wn *= size[a];
-  }
-  float mn = INFINITY;
-  for (long long k = threadIdx.x; k < wn; k += kBlock) {
-    const int x = static_cast<int>(k % size[2]);
-    const long long r = k / size[2];
-    const int y = static_cast<int>(r % size[1]);
-    const int z = static_cast<int>(r / size[1]);
-    mn = fminf(mn, surf_at(s, p, start[0] + z, start[1] + y, start[2] + x));
-  }
-  lv[threadIdx.x] = mn;
-  __syncthreads();
-  for (int st = kBlock / 2; st > 0; st >>= 1) {
-    if (threadIdx.x < st)
-      lv[threadIdx.x] = fminf(lv[threadIdx.x], lv[threadIdx.x + st]);
+  // Sharpness: peak / min over the clamped window (loaded above).
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mn = fminf(mn, __shfl_xor(mn, d, 64));
+  if constexpr (!WAVE) {
+    if ((threadIdx.x & 63) == 0) lv[threadIdx.x >> 6] = mn;
     __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+      for (int w2 = 0; w2 < kBlock / 64; ++w2) mn = fminf(mn, lv[w2]);
   }
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     float* o = p.out + b * w;
     // x, y[, z] = reversed axis order
     for (int a = 0; a < p.nd; ++a) {
       const int ax = 2 - a;
       o[a] = static_cast<float>(pos[ax]) - p.center[ax];
     }
-    o[p.nd] = surf_at(s, p, pos[0], pos[1], pos[2]) / lv[0];
+    o[p.nd] = peak_val / mn;
     o[p.nd + 1] = v2 == -INFINITY ? 0.f : v1 / v2;
+  }
+}
+
+
+// Four surfaces per workgroup, a wave each (40 401 workgroups of one short chain
+// of round trips were priced by their dispatch); a workgroup in which any
+// candidate list overflowed takes its surfaces one after the other instead.
+__global__ void __launch_bounds__(kBlock) peaks_second_kernel(PeakArgs p) {
+  __shared__ float lv[kBlock];
+  __shared__ int li[kBlock];
+  constexpr int kPer = kBlock / 64;
+  const int b = blockIdx.x * kPer + static_cast<int>(threadIdx.x >> 6);
+  const bool live = b < p.batch;
+  const int cnt = live ? p.cand_count[b] : 0;
+  if (!__syncthreads_or(cnt > kCandCap ? 1 : 0)) {
+    if (live) second_peak_body<true>(p, b, nullptr, nullptr);
+    return;
+  }
+  for (int w2 = 0; w2 < kPer; ++w2) {
+    const int bb = blockIdx.x * kPer + w2;
+    if (bb < p.batch) second_peak_body<false>(p, bb, lv, li);
+    __syncthreads();
   }
 }
 
@@ -1098,7 +1157,7 @@ int run_peaks(const PeakWs& w, char* ws_base, const float* surf, int pitch,
     }
     SFM_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(peaks_second_kernel, dim3(batch), dim3(kBlock), 0, st, p);
+  hipLaunchKernelGGL(peaks_second_kernel, dim3((batch + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, p);
   SFM_LAUNCH_CHECK();
   return SFM_OK;
 }

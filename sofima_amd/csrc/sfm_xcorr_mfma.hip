@@ -2237,12 +2237,22 @@ __device__ __forceinline__ bool peak_better(float v, int i, float bv, int bi) {
   return v > bv || (v == bv && i < bi);
 }
 
-__device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
-                                 int Sy, int Sx, const int* pmax_lds,
-                                 const int* hot_lds, float* scratch) {
-  __syncthreads();  // all tiles stored, running maximum final
-  const float mx = __int_as_float(*pmax_lds);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// First peak of one surface by ONE WAVE (the kernel below runs four surfaces per
+// workgroup, a wave each: 40 401 workgroups of a few hundred hot elements were
+// priced by their dispatch and by a chain of dependent round trips per
+// workgroup).  The first hot-list entry of every lane is requested together with
+// the surface's maximum and fill count, the candidate slots are counted in LDS
+// (a returning global atomic per candidate was a round trip of its own), and the
+// arg-max runs on the shuffle network: no barrier anywhere.
+__device__ void wave_first_peak(const MfmaArgs& a, int b, const float* surf,
+                                int Sy, int Sx, int* cand_lds) {
+  const int lane = threadIdx.x & 63;
+  // (unconditional: entries beyond the fill count are stale and ignored)
+  const float hv0 = a.hot_val[(long long)b * a.hot_cap + min(lane, a.hot_cap - 1)];
+  const int hi0 = a.hot_idx[(long long)b * a.hot_cap + min(lane, a.hot_cap - 1)];
+  const float mx = a.v1[b];          // the surface maximum on entry
+  const int n_hot = a.hot_count[b];
+  if (lane == 0) *cand_lds = 0;      // (LDS operations of one wave are ordered)
   const int pitch = a.sx_pitch;
   const int m = a.min_distance;
   float bv = -INFINITY;
@@ -2278,7 +2288,7 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
       bv = v;
       bi = i;
     }
-    const int slot = atomicAdd(&a.cand_count[b], 1);
+    const int slot = atomicAdd(cand_lds, 1);
     if (slot < a.cand_cap) {
       a.cand_val[(long long)b * a.cand_cap + slot] = v;
       a.cand_idx[(long long)b * a.cand_cap + slot] = i;
@@ -2287,14 +2297,13 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
   };
   if (mx > 0.f) {
     const float thr = a.threshold_rel * mx;
-    const int n_hot = *hot_lds;
     if (n_hot <= a.hot_cap) {
       const float* hv = a.hot_val + (long long)b * a.hot_cap;
       const int* hi = a.hot_idx + (long long)b * a.hot_cap;
-      for (int e = threadIdx.x; e < n_hot; e += kThreads) {
-        const float v = hv[e];
+      for (int e = lane; e < n_hot; e += 64) {
+        const float v = e == lane ? hv0 : hv[e];
         if (!(v > thr)) continue;
-        const int i = hi[e];
+        const int i = e == lane ? hi0 : hi[e];
         const int y = i / Sx;
         consider(y, i - y * Sx, v);
       }
@@ -2302,7 +2311,7 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
       // Hot list overflowed (flat surfaces): sweep the stored surface.
       const int n4 = (Sx + 3) >> 2;
       const int skipped = a.skipmask ? a.skipmask[b] : 0;  // pruned row tiles: not stored
-      for (int y = wave; y < Sy; y += kWaves) {
+      for (int y = 0; y < Sy; ++y) {
         if ((skipped >> (y >> 4)) & 1) continue;
         const float* row = surf + (long long)y * pitch;
         for (int c4 = lane; c4 < n4; c4 += 64) {
@@ -2315,23 +2324,21 @@ __device__ void fused_first_peak(const MfmaArgs& a, int b, const float* surf,
       }
     }
   }
-  // (value, index) arg-max across the block, first index wins ties.
-  float* lv = scratch;
-  int* li = reinterpret_cast<int*>(scratch + kThreads);
-  lv[threadIdx.x] = bv;
-  li[threadIdx.x] = bi;
-  __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s && peak_better(lv[threadIdx.x + s], li[threadIdx.x + s],
-                                       lv[threadIdx.x], li[threadIdx.x])) {
-      lv[threadIdx.x] = lv[threadIdx.x + s];
-      li[threadIdx.x] = li[threadIdx.x + s];
+  // (value, index) arg-max across the wave, first index wins ties (a total
+  // order: any reduction tree finds the same winner).
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const float ov = __shfl_xor(bv, d, 64);
+    const int oi = __shfl_xor(bi, d, 64);
+    if (peak_better(ov, oi, bv, bi)) {
+      bv = ov;
+      bi = oi;
     }
-    __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const float v1 = lv[0];
-    const int i1 = v1 == -INFINITY ? 0 : li[0];  // argmax of an all -inf row is 0
+  if (lane == 0) {
+    a.cand_count[b] = *cand_lds;   // (behind every lane's atomics in this wave's LDS queue)
+    const float v1 = bv;
+    const int i1 = v1 == -INFINITY ? 0 : bi;  // argmax of an all -inf row is 0
     a.idx1[b] = i1;
     a.v1[b] = v1;
     sfm::set_bit_once(&a.bitmap[(long long)(b / a.group) * a.bitmap_words + (i1 >> 5)],
@@ -2430,17 +2437,14 @@ __device__ __forceinline__ float at_byte(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-// One workgroup per surface; v1[b] holds the surface maximum on entry.
+// One WAVE per surface, four surfaces per workgroup; v1[b] holds the surface
+// maximum on entry.
 __global__ void __launch_bounds__(kThreads) mfma_first_peak_kernel(MfmaArgs a) {
-  __shared__ float scratch[2 * kThreads];
-  __shared__ int s_pmax, s_hot;
-  const int b = blockIdx.x;
-  if (threadIdx.x == 0) {
-    s_pmax = __float_as_int(a.v1[b]);
-    s_hot = a.hot_count[b];
-  }
-  fused_first_peak(a, b, a.surface + b * a.s_stride, a.S[0], a.S[1], &s_pmax, &s_hot,
-                   scratch);
+  __shared__ int s_cand[kWaves];
+  const int wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * kWaves + wave;
+  if (b >= a.batch) return;
+  wave_first_peak(a, b, a.surface + b * a.s_stride, a.S[0], a.S[1], &s_cand[wave]);
 }
 
 // XCD-sharded queue: next item of this workgroup (n_items: none left).  Called
@@ -4456,7 +4460,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
                            : (lazy ? kModeSameLazy : kModeSame);
   if (int rc = launch_mode(vi, a, mode, grid, lds, st)) return rc;
   if (fp) {
-    hipLaunchKernelGGL(mfma_first_peak_kernel, dim3(d->batch), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(mfma_first_peak_kernel, dim3((d->batch + kWaves - 1) / kWaves), dim3(kThreads), 0, st, a);
     SFM_LAUNCH_CHECK();
   }
   return SFM_OK;
