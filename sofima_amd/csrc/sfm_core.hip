@@ -65,7 +65,29 @@ Span g_open[2];
 struct ClockSample {
   long long v[5];  // cycles, 10 ns ticks[, row tiles drawn << 32 | skipped, column tiles skipped, MFMAs issued]
 };
-std::deque<ClockSample> g_clock[2];  // stable addresses: targets of async copies
+// Targets of the probes' device-to-host copies: PINNED blocks (a copy into pageable
+// memory holds the host until the stream reaches it -- the launches behind the
+// correlation kernel were not enqueued before it had finished: a 20 us hole in
+// front of the peak kernels of every timed flow).  Blocks are never freed.
+constexpr int kClockBlock = 1024;
+struct ClockPool {
+  std::vector<ClockSample*> blocks;
+  size_t used = 0;
+  ClockSample* next() {
+    if (used == blocks.size() * kClockBlock) {
+      void* p = nullptr;
+      if (hipHostMalloc(&p, sizeof(ClockSample) * kClockBlock, hipHostMallocDefault) != hipSuccess)
+        return nullptr;
+      blocks.push_back(static_cast<ClockSample*>(p));
+    }
+    ClockSample* c = &blocks[used / kClockBlock][used % kClockBlock];
+    ++used;
+    *c = ClockSample{{0, 0, 0, 0, 0}};
+    return c;
+  }
+  ClockSample& at(size_t i) { return blocks[i / kClockBlock][i % kClockBlock]; }
+};
+ClockPool g_clock[2];
 }  // namespace
 
 bool profiling() { return g_prof_on.load(std::memory_order_relaxed); }
@@ -95,8 +117,9 @@ void prof_end(int kind, hipStream_t st) {
 void prof_clock(int kind, const long long* dev_pair, hipStream_t st, int n) {
   if (!profiling() || !dev_pair) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_clock[kind].push_back(ClockSample{{0, 0, 0, 0, 0}});
-  (void)hipMemcpyAsync(g_clock[kind].back().v, dev_pair, sizeof(long long) * (n >= 2 && n <= 5 ? n : 2),
+  ClockSample* c = g_clock[kind].next();
+  if (!c) return;
+  (void)hipMemcpyAsync(c->v, dev_pair, sizeof(long long) * (n >= 2 && n <= 5 ? n : 2),
                        hipMemcpyDeviceToHost, st);
 }
 
@@ -112,7 +135,7 @@ int sfm_profile_enable(int on) {
 int sfm_profile_read(SfmProfile* out) {
   if (!out) return sfm::fail(SFM_ERR_INVALID, "out is NULL");
   std::lock_guard<std::mutex> lk(sfm::g_prof_mu);
-  if (!sfm::g_clock[0].empty() || !sfm::g_clock[1].empty())
+  if (sfm::g_clock[0].used || sfm::g_clock[1].used)
     SFM_HIP_CHECK(hipDeviceSynchronize());  // the probe copies trail the events
   for (int k = 0; k < 2; ++k) {
     double ms = 0.0;
@@ -128,7 +151,8 @@ int sfm_profile_read(SfmProfile* out) {
     sfm::g_spans[k].clear();
     // the events above are later in stream order than the probe copies
     long long cyc = 0, ticks = 0, skipped = 0, drawn = 0, cols = 0, issued = 0, early = 0;
-    for (auto& c : sfm::g_clock[k]) {
+    for (size_t ci = 0; ci < sfm::g_clock[k].used; ++ci) {
+      const sfm::ClockSample& c = sfm::g_clock[k].at(ci);
       cyc += c.v[0];
       ticks += c.v[1];
       skipped += c.v[2] & 0xffffffffLL;
@@ -143,7 +167,7 @@ int sfm_profile_read(SfmProfile* out) {
     out->col_tiles_skipped[k] = cols;
     out->mfma_issued[k] = issued;
     out->tiles_abandoned[k] = early;
-    sfm::g_clock[k].clear();
+    sfm::g_clock[k].used = 0;
   }
   return SFM_OK;
 }
