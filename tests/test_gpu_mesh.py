@@ -597,12 +597,15 @@ def test_speculative_hand_off_fuzz(gpu):
   import torch
   from scipy import ndimage
   from sofima_amd import mesh
-  rng = np.random.default_rng(5)
+  import os
+  # (SFM_FUZZ_SECONDS / SFM_FUZZ_SEED: longer soaks, tools/measure/profile_round5.sh)
+  box = float(os.environ.get('SFM_FUZZ_SECONDS', '25'))
+  rng = np.random.default_rng(int(os.environ.get('SFM_FUZZ_SEED', '5')))
   t0 = time.time()
   cases = uphill_cases = 0
   junk = torch.zeros(64 << 20, device='cuda')
   side = torch.cuda.Stream()
-  while time.time() - t0 < 25.0 or cases < 6:
+  while time.time() - t0 < box or cases < 6:
     ny, nx = (int(v) for v in rng.integers(17, 211, 2))
     nz = int(rng.integers(1, 5))
     if ((ny + 15) // 16) * ((nx + 15) // 16) * nz > 256:
@@ -644,6 +647,7 @@ def test_speculative_hand_off_fuzz(gpu):
     uphill_cases += a[5] < iters   # n_pos below the step count: the power went negative
     cases += 1
   assert uphill_cases >= 3, (cases, uphill_cases)
+  print(f'hand-off fuzz: {cases} cases, {uphill_cases} with uphill events, 0 mismatches')
 
 
 @pytest.mark.parametrize('case', ['tile2d', 'tile3d', 'vol3d', 'plane_vv'])
