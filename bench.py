@@ -144,6 +144,15 @@ def main():
   if args.cpu_baseline_only:
     cpu_baseline_child(args.size, args.seed, args.pair)
     return
+  # wall clock of this process by phase (rank 0's view; `wall_s` in the line): what a
+  # driver that bounds the whole run needs to know, beside the timed region
+  wall = {}
+  w_mark = [time.perf_counter()]
+
+  def lap(name):
+    now = time.perf_counter()
+    wall[name] = round(wall.get(name, 0.0) + now - w_mark[0], 3)
+    w_mark[0] = now
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     # `python bench.py --gpus N` without a launcher: start the N ranks here
     # (one process per GPU, RCCL), exactly as the driver's torchrun line does.
@@ -203,9 +212,11 @@ def main():
   dev = torch.device('cuda', local_rank)
   lib = _abi.load()
 
+  lap('import_init')
   size = args.size
   warp = WARP if args.pair == 'warped' else None
   pre, post = synth_pair(size, args.seed + rank, warp=warp)
+  lap('synth_pair')
   pre_t = torch.from_numpy(pre).to(dev)
   post_t = torch.from_numpy(post).to(dev)
   calc = flow_field.JAXMaskedXCorrWithStatsCalculator(method=args.method)
@@ -238,6 +249,7 @@ def main():
     flow = flow_step()
     prev_t = torch.from_numpy(mesh_inputs(flow, pad)).to(dev)
 
+  lap('warmup')
   prof = _abi.SfmProfile()
   lib.sfm_profile_read(C.byref(prof))  # reset
   lib.sfm_profile_enable(1)
@@ -261,6 +273,7 @@ def main():
   lib.sfm_profile_enable(0)
   _abi.check(lib.sfm_profile_read(C.byref(prof)))
 
+  lap('timed_region')
   times = torch.tensor([elapsed, t_flow, t_mesh], dtype=torch.float64,
                        device=dev if backend == 'nccl' else 'cpu')
   if world > 1:
@@ -461,6 +474,7 @@ def main():
 
   # Steady state: the timed region above is < 1 s on a power-limited kernel, so
   # the same step is repeated back to back for >= --sustain seconds (all ranks).
+  lap('roofline_legs')
   sustained = None
   if args.sustain > 0:
     barrier()
@@ -486,13 +500,16 @@ def main():
                  'mpix_s': round(world * pix * n_sus / s_el / 1e6, 1),
                  'note': 'flow + mesh steps back to back (includes the mesh leg)'}
 
+  lap('sustain')
   aux = None
   if world == 1 and not args.no_legs:
     aux = aux_legs(dev, args.seed)
+    lap('aux_legs')
 
   cfg_legs = None
   if world == 1 and not args.no_legs:
     cfg_legs = config_legs(dev, pre, args.seed)
+    lap('config_legs')
 
   sharded = None
   if args.mesh_sharded > 0:
@@ -522,6 +539,7 @@ def main():
       'patches_per_s': world * n_patches * args.steps / t_flow,
       'mesh': mesh_obj, 'roofline': roof,
       'build_sha': build_sha(),
+      'wall_s': wall,
   }
   if sustained:
     out['sustained'] = sustained
@@ -535,6 +553,7 @@ def main():
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline(size, args.seed + rank, args.pair)
+    lap('cpu_baseline')
 
   # N > 1: the legs that really communicate (the timed default workload above
   # is N independent tile pairs, no data-path collective).  They run LAST and
@@ -563,7 +582,9 @@ def main():
     for name, fn in (
         ('section_chain', lambda: section_chain_leg(dev, rank, world, backend, args.seed,
                                                     args.mesh_iters, pre_t, post_t)),
-        ('volumetric_chunks', lambda: volumetric_leg(dev, rank, world, backend, args.seed)),
+        # (configs[4] is 16 z chunks: two per rank on an 8-GPU node, one per rank below that)
+        ('volumetric_chunks', lambda: volumetric_leg(dev, rank, world, backend, args.seed,
+                                                     chunks_per_rank=2 if world >= 8 else 1)),
         ('mesh_sharded', lambda: mesh_sharded_leg(
             2 if forced else 1, dev, rank, world,
             iters=min(200, max(args.mesh_iters, 20)), loopback=forced))):
@@ -577,6 +598,7 @@ def main():
         multi[name] = {'error': f'{type(e).__name__}: {e}'[:400]}
       finally:
         dog.cancel()
+      lap('multi_gpu.' + name)
       # a rank that failed must not leave the others inside a collective of the
       # NEXT leg: agree on going on (an all-reduce with its own watchdog)
       dog = threading.Timer(args.multi_gpu_timeout, bail)
@@ -589,6 +611,7 @@ def main():
       if flag.item() < 1.0:
         multi[name].setdefault('error', 'failed on another rank')
         break
+  wall['total'] = round(sum(wall.values()), 3)
   if rank == 0:
     print(json.dumps(out), flush=True)
   if world > 1 or forced:
