@@ -87,6 +87,12 @@ int sfm_device_count(int* count);
  *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry
  *   SFM_MFMA_QUEUE=0      static instead of dynamic patch queue
  *   SFM_MFMA_XCD=1        one patch queue per XCD (measured: no gain) instead of a flat one
+ *   SFM_MFMA_PIPE=1       160-wide flow launches as a cross-patch pipeline: one workgroup of
+ *                         eight waves per CU, two patch slots in LDS, the tile queue running
+ *                         across the patch boundary (built in round 6, measured 3-4 % SLOWER
+ *                         than two four-wave workgroups: profiles/r06_xcorr_phase_ticks.txt)
+ *   SFM_MFMA_PIPE_ADMIT=n pipeline: tiles of a patch handed out before its first tile is done
+ *                         (default 2)
  *   SFM_MFMA_PRIO=n       wave priority experiment (0..3)
  *   SFM_MFMA_MAX_WG_PER_CU=n   occupancy cap of the correlation kernel
  *   SFM_MASKED_FAST=0     masked patches always take all eight passes

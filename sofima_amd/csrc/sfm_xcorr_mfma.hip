@@ -257,6 +257,8 @@ struct MfmaArgs {
   int* c16;           // [B, c16_stride]: [2][Py / 16 + 1][Px] column sums, then T[Py + 1]
   long long c16_stride;
   int nq;             // column tiles of the kernel variant
+  int slot_bytes;     // kModePipe: LDS bytes of one patch slot (multiple of 16)
+  int pipe_admit;     // kModePipe: tiles of a patch that may be drawn before its first tile is done
   int prune_k[4];     // outer column tiles (each side) of the row-loop variants (ascending)
 };
 
@@ -1276,11 +1278,15 @@ struct StagePlane {
 
 constexpr int kStageBatch = 7;
 
-__device__ __forceinline__ void stage_patches(const StagePlane& p0, const StagePlane& p1) {
+// (first, limit: the range of work items this call stages -- everything by default)
+template <int NT = kThreads>
+__device__ __forceinline__ void stage_patches(const StagePlane& p0, const StagePlane& p1,
+                                              const int tid, const int first = 0,
+                                              const int limit = 0x7fffffff) {
   const StagePlane* pl[2] = {&p0, &p1};
   const int n_items0 = p0.py * p0.n_chunks, n_items1 = p1.py * p1.n_chunks;
-  const int n_max = max(n_items0, n_items1);
-  for (int item0 = threadIdx.x; item0 < n_max; item0 += kThreads * kStageBatch) {
+  const int n_max = min(max(n_items0, n_items1), limit);
+  for (int item0 = first + tid; item0 < n_max; item0 += NT * kStageBatch) {
     v4i w[2][kStageBatch];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -1288,7 +1294,7 @@ __device__ __forceinline__ void stage_patches(const StagePlane& p0, const StageP
       const int n_items = p.py * p.n_chunks;
 #pragma unroll
       for (int u = 0; u < kStageBatch; ++u) {
-        const int item = min(item0 + u * kThreads, n_items - 1);  // extra items: ignored
+        const int item = min(item0 + u * NT, n_items - 1);  // extra items: ignored
         const int y = item / p.n_chunks, ch = item - y * p.n_chunks;
         const long long off = (long long)(p.y0 + y) * p.W + p.x0 + ch * 16;
         w[s][u] = load_16_bytes(p.img, off, p.img_bytes);
@@ -1301,7 +1307,7 @@ __device__ __forceinline__ void stage_patches(const StagePlane& p0, const StageP
       const int n_items = p.py * p.n_chunks;
 #pragma unroll
       for (int u = 0; u < kStageBatch; ++u) {
-        const int item = item0 + u * kThreads;
+        const int item = item0 + u * NT;
         if (item >= n_items) break;
         const int y = item / p.n_chunks, ch = item - y * p.n_chunks;
         v4i out;
@@ -2368,6 +2374,11 @@ constexpr int kModeSameLazy = 4, kModeSameExactLazy = 5;
 // kModeSameExactLazy with the correction table built in the epilogue of the tiles
 // that are stored (MfmaArgs::lazy_g; Py a multiple of 16): no table G in memory.
 constexpr int kModeSameExactLazyG = 6;
+// kModeSameExactLazyG as a cross-patch pipeline: ONE workgroup of eight waves per CU, TWO
+// patch slots in LDS, the tile queue running across the patch boundary (see the kernel).
+constexpr int kModePipe = 7;
+constexpr int kPipeCtl = 32;  // ints of a slot's control header (behind its lazy-store state;
+                              // 256 ints of seed-probe sums follow)
 
 // Inclusive add scan over the 16 lanes of a DPP row (the 16 columns of a tile).
 __device__ __forceinline__ int row16_scan_incl(int v) {
@@ -2485,8 +2496,27 @@ __device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_ld
 }
 
 template <int NCA, int NCE, int MODE>
-__global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
-  constexpr bool LAZYG = MODE == kModeSameExactLazyG;
+__global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
+                                  MODE == kModePipe ? 1 : 2) xcorr_mfma_kernel(MfmaArgs a) {
+  // Cross-patch pipeline (kModePipe; everything else is kModeSameExactLazyG).  The other
+  // modes run two workgroups of four waves per CU, each on its own patch, and every patch
+  // has phases in which its four waves wait for each other: the staging round trip, the
+  // seed probe's barrier, the waves that find the tile queue empty while the long tiles of
+  // the patch drain, the publication barrier.  Here ONE workgroup of EIGHT waves owns the
+  // CU and LDS holds TWO patch slots (pixels, 1-D arrays, bounds, lazy-store state, a
+  // control header each: 2 x 72 KB at 160^2).  A wave is not bound to a slot: it draws a
+  // row tile from whichever slot has one (control word = generation << 8 | next tile, so
+  // the draw is atomic with the patch's identity), and there is no workgroup barrier after
+  // start-up.  The wave whose tile completes a patch (per-slot completion counter) is its
+  // CLOSER: alone it runs the end-of-patch pass (recomputation of band tiles that finished
+  // un-stored, against the final maximum), publishes the patch, claims the next patch from
+  // the global queue, stages it into the slot it just freed (pixels, tables, seed probe,
+  // table touches -- one wave's loads, while the other seven work on the other slot) and
+  // re-arms the slot's control word.  The state a slot carries from patch to patch (seed
+  // block, previous need mask, hot columns) stays with the slot, i.e. every slot behaves
+  // like a workgroup of the other modes; results do not depend on any of it.
+  constexpr bool PIPE = MODE == kModePipe;
+  constexpr bool LAZYG = MODE == kModeSameExactLazyG || PIPE;
   constexpr bool SAME = MODE == kModeSame || MODE == kModeSameExact || MODE == kModeSameLazy ||
                         MODE == kModeSameExactLazy || LAZYG;
   constexpr bool EXACT = MODE == kModeSameExact || MODE == kModeSameExactLazy || LAZYG;
@@ -2496,6 +2526,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float touch_junk[kThreads];  // sink of the LDS-direct G touches
   __shared__ int probe_lds[kThreads];     // K-split sums of the seed probe (a.prune)
+  // (kModePipe: everything below exists once per slot, `bind_slot` re-points the names)
   unsigned char* A_lds = smem;
   unsigned char* B_lds = smem + a.a_bytes;
   float* R_lds = reinterpret_cast<float*>(smem + a.a_bytes + a.b_bytes);
@@ -2523,6 +2554,32 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   int* lz_ks = lz_cq + 4;
   // lz_rows[p]: first | last << 8 row (0 .. 15) of tile p with a possibly hot element
   int* lz_rows = lz_ks + 32;
+  // kModePipe, control header of a slot:
+  //   [0] generation << 8 | next tile of the tile order (>= n_order: nothing to draw; written
+  //       by the opener LAST, so a successful draw implies a completely staged patch)
+  //   [1] tiles of the patch that are done (pruned, abandoned, cold or finished)
+  //   [2] patch index   [3] slot retired (no patch left for it)
+  //   [4..7] float bits of mean_A - c_A, mean_B - c_B, const_a, const_b of the patch
+  int* ctl = lz_rows + 32;
+  int* pr_lds = probe_lds;   // seed-probe sums (kModePipe: the slot's own 256 words)
+  auto bind_slot = [&](int s) {
+    unsigned char* base = smem + s * a.slot_bytes;
+    A_lds = base;
+    B_lds = base + a.a_bytes;
+    R_lds = reinterpret_cast<float*>(base + a.a_bytes + a.b_bytes);
+    pmax_lds = reinterpret_cast<int*>(base + a.a_bytes + a.b_bytes + a.r_bytes);
+    hot_lds = pmax_lds + 1;
+    tb_lds = reinterpret_cast<float*>(pmax_lds + 4);
+    best_lds = reinterpret_cast<int*>(tb_lds + kBoundStride);
+    lz = best_lds + 8;
+    lz_tmax = reinterpret_cast<float*>(lz + 4);
+    lz_prev = reinterpret_cast<int*>(lz_tmax + 31);
+    lz_cq = lz_prev + 1;
+    lz_ks = lz_cq + 4;
+    lz_rows = lz_ks + 32;
+    ctl = lz_rows + 32;
+    pr_lds = ctl + kPipeCtl;
+  };
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -2531,10 +2588,26 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 
   const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
   // Zero the whole LDS image once: pad rows / margins stay zero afterwards.
-  for (int i = threadIdx.x * 16; i < a.a_bytes + a.b_bytes; i += kThreads * 16)
+  for (int i = threadIdx.x * 16; i < (PIPE ? 2 * a.slot_bytes : a.a_bytes + a.b_bytes);
+       i += (PIPE ? 2 : 1) * kThreads * 16)
     *reinterpret_cast<v4i*>(smem + i) = v4i{0, 0, 0, 0};
+  if constexpr (PIPE) {
+    __syncthreads();
+    if (lane == 0 && wave < 2) {
+      bind_slot(wave);
+      *best_lds = (((a.Q[0] - 1) / 16) << 8) | ((a.Q[1] - 1) / 16);  // the zero shift
+      best_lds[2] = 1;
+      lz_cq[0] = NQ;
+      lz_cq[1] = -1;
+      lz_cq[2] = lz_cq[3] = (a.Q[1] - 1) / 16;
+      ctl[0] = 255;    // generation 0, nothing to draw
+      ctl[2] = -1;
+    }
+    bind_slot(0);
+    __syncthreads();
+  }
 
-  if (SAME && (a.prune || LAZY) && threadIdx.x == 0) {
+  if (!PIPE && SAME && (a.prune || LAZY) && threadIdx.x == 0) {
     *best_lds = (((a.Q[0] - 1) / 16) << 8) | ((a.Q[1] - 1) / 16);  // the zero shift
     best_lds[2] = 1;  // pruning events of the previous patch (optimistic start)
     best_lds[3] = 0;  // patches of this workgroup so far
@@ -2555,7 +2628,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
 #ifdef SFM_MFMA_TIMING
   const long long wstart = wall_clock64();
   const long long cstart = clock64();
-  long long tph[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0}; long long tc = clock64(); int npat = 0;
+  long long tph[18] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; long long tc = clock64(); int npat = 0;
 #define TICK(i) { long long tn = clock64(); tph[i] += tn - tc; tc = tn; }
 #else
 #define TICK(i)
@@ -2579,10 +2652,270 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
   const int n_items = (RAW && a.list) ? *a.n_list : a.batch;
   // HW_REG_XCC_ID (20), bits [3:0]: the XCD this workgroup runs on
   int q_state = a.xcd_heads ? static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;
-  for (int item = a.xcd_heads ? pull_item(a, n_items, &q_state, next_lds) : blockIdx.x;
-       item < n_items;
-       item = a.xcd_heads ? pull_item(a, n_items, &q_state, next_lds)
-                          : next_patch(a, item, next_lds)) {
+  // (g0, gs: first row group and stride of the calling wave; alone: no other wave takes part)
+  // (kind 0: the four waves of a workgroup, sums through LDS atomics, barrier, seed;
+  // kind 2, kModePipe: this wave's share of the row groups into the slot's sums only --
+  // seed_finish() follows when every share is in)
+  auto seed_finish = [&]() {
+    int sm = max(max(pr_lds[lane], pr_lds[64 + lane]), max(pr_lds[128 + lane], pr_lds[192 + lane]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sm = max(sm, __shfl_xor(sm, d, 64));
+    const float m_lo = __int2float_rd(sm) - tb_lds[kBoundCorr];
+    if (lane == 0 && m_lo > 0.f) atomicMax(pmax_lds, __float_as_int(m_lo));
+  };
+  auto seed_probe = [&](const int g0, const int gs, const int kind) {
+      // Seed of the running maximum.  The first tiles are drawn before any tile
+      // has finished, i.e. with nothing to prune against.  So the 16 x 16 block of
+      // shifts that held the previous patch's maximum is evaluated first, its
+      // patch rows split over the four waves (exact integer sums S, the same
+      // fragments the row loop would use), summed through LDS atomics, and
+      //   max(surface) >= max(S over the block) - |correction|max =: m_lo
+      // (tbound[kBoundCorr], prep kernel) goes into the running maximum.  m_lo is
+      // strictly below a real element, so the final maximum is unaffected.
+      const int pq = __builtin_amdgcn_readfirstlane(*best_lds);
+      const int ps = pq >> 8, qs = pq & 255;
+      const int pdy0 = 16 * ps - (Qy - 1);
+      const int pylo = max(0, -pdy0 - 15), pyhi = min(Qy, Py - pdy0);
+      const unsigned char* pap = A_lds + (kPadTop + pylo + g + pdy0 + n) * a.pa;
+      const unsigned char* pbp = B_lds + (pylo + g) * a.pb + (pos0 & ~3);
+      // two row groups per trip: their loads are in flight together and they
+      // accumulate into separate registers (no dependent MFMA chain of 2 NCA)
+      v4i pacc = v4i{0, 0, 0, 0}, pacc2 = v4i{0, 0, 0, 0};
+      const int n_grp = (pyhi - pylo + 3) >> 2;
+      // The pairs (ca, c) on the diagonal of column tile qs are ca = ca_lo + i,
+      // c = c_lo + i, i < n_on: contiguous A chunks against a contiguous run of B
+      // dwords (4 n_on + 1, shared between neighbouring fragments like in the row
+      // loop).  Pairs past n_on, and groups past the tile, read A from a zero
+      // padding row instead (branch-free).
+      const int ca_lo = max(0, qs - cq0), c_lo = ca_lo - qs + cq0;
+      const int n_on = min(NCA - ca_lo, NCE - c_lo);
+      const unsigned char* zero_row = A_lds + n * a.pa;  // inside the top padding
+      constexpr int kPD = 4 * NCA + 1;
+      auto load_group = [&](int grp, v4i* paf, unsigned* pd) {
+        const bool live = grp < n_grp;
+        const int gc = min(grp, n_grp - 1);
+        const unsigned char* ag = pap + 4 * gc * a.pa + 16 * ca_lo;
+        const unsigned char* bg = pbp + 4 * gc * a.pb + 16 * c_lo;
+#pragma unroll
+        for (int i = 0; i < NCA; ++i)
+          paf[i] = *reinterpret_cast<const v4i*>((live && i < n_on) ? ag + 16 * i : zero_row);
+#pragma unroll
+        for (int j = 0; j < kPD; ++j) pd[j] = *reinterpret_cast<const unsigned*>(bg + 4 * j);
+      };
+      auto mma_group = [&](const v4i* paf, const unsigned* pd, v4i& acc_out) {
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) {
+          v4i bf;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            bf[k] = static_cast<int>(
+                __builtin_amdgcn_alignbyte(pd[4 * i + k + 1], pd[4 * i + k], sh));
+          acc_out = __builtin_amdgcn_mfma_i32_16x16x64_i8(paf[i], bf, acc_out, 0, 0, 0);
+        }
+      };
+      for (int grp = g0; grp < n_grp; grp += 2 * gs) {
+        v4i paf[NCA], paf2[NCA];
+        unsigned pd[kPD], pd2[kPD];
+        load_group(grp, paf, pd);
+        load_group(grp + gs, paf2, pd2);
+        mma_group(paf, pd, pacc);
+        mma_group(paf2, pd2, pacc2);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pacc[r] += pacc2[r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&pr_lds[r * 64 + lane], pacc[r]);
+      if (kind == 2) return;
+      __syncthreads();
+      seed_finish();
+  };
+  // kModePipe: opening a slot, i.e. everything the other modes do per patch with 256
+  // threads and three barriers (staging, tables, state reset, seed probe, table touches),
+  // cut into UNITS that any wave without a tile can take:
+  //   unit 0            (the closer itself) the 1-D arrays, the pruning bounds, the zeroed
+  //                     probe sums, the table touches
+  //   units 1 .. NA     staging: 7 x 64 sixteen-byte items of either patch each
+  //   units NA+1 .. +NB the seed probe: every NB-th row group of the probe block (only
+  //                     after units 0 .. NA: they read the staged pixels)
+  // Claims are one LDS atomic (ctl[8]); the wave whose unit is the last one done (ctl[9])
+  // seeds the running maximum from the probe sums and arms the slot.  The patch that goes
+  // into a slot was claimed from the global queue -- and its PatchParams fetched -- while
+  // the previous patch of the slot was still running (ctl[18 ..]), so nothing of an
+  // opening waits for a global round trip except unit 0's own table loads.
+  constexpr int kProbeUnits = 4;
+  auto n_stage_units = [&]() {
+    const int n_max = max(Py * NCA, Qy * ((Qx + 15) / 16));
+    return (n_max + 64 * kStageBatch - 1) / (64 * kStageBatch);
+  };
+  // (lane 0) claims the patch after next for the bound slot and parks its parameters
+  auto prefetch_next = [&](const int first) {
+    int nb = first;
+    if (nb < 0) {
+      if (lane == 0) nb = 2 * static_cast<int>(gridDim.x) + atomicAdd(a.work_counter, 1);
+      nb = __builtin_amdgcn_readfirstlane(nb);
+    }
+    if (nb < n_items) {
+      const PatchParams pp = a.pp[nb];
+      if (lane == 0) {
+        ctl[19] = pp.y0[0]; ctl[20] = pp.x0[0]; ctl[21] = pp.c[0];
+        ctl[22] = pp.y0[1]; ctl[23] = pp.x0[1]; ctl[24] = pp.c[1];
+        ctl[25] = __float_as_int(pp.mu[0]); ctl[26] = __float_as_int(pp.mu[1]);
+      }
+    }
+    if (lane == 0) ctl[18] = nb;
+  };
+  auto open_unit_done = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    int dn = 0;
+    if (lane == 0) dn = atomicAdd(&ctl[9], 1) + 1;
+    dn = __builtin_amdgcn_readfirstlane(dn);
+    if (dn == __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[10]))) {
+      // the last unit: seed, then arm (generation + 1, tile 0; every LDS write of the
+      // opening is older than this one)
+      if (__builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[11]))) seed_finish();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const int gen = (*const_cast<volatile int*>(&ctl[0]) >> 8) + 1;
+        *const_cast<volatile int*>(&ctl[0]) = gen << 8;
+      }
+    }
+  };
+  // unit c >= 1 of the bound slot's opening (claimed by the caller)
+  auto open_unit = [&](const int c) {
+    const int na = n_stage_units();
+    if (c <= na) {
+      const int y0a = __builtin_amdgcn_readfirstlane(ctl[12]), x0a = __builtin_amdgcn_readfirstlane(ctl[13]);
+      const int cca = __builtin_amdgcn_readfirstlane(ctl[14]);
+      const int y0b = __builtin_amdgcn_readfirstlane(ctl[15]), x0b = __builtin_amdgcn_readfirstlane(ctl[16]);
+      const int ccb = __builtin_amdgcn_readfirstlane(ctl[17]);
+      const StagePlane sa = {a.img[0], bytes0, a.ishape[0][1], y0a, x0a, Py, Px,
+                             cca, A_lds, a.pa, kPadTop, 0, NCA};
+      const StagePlane sb = {a.img[1], bytes1, a.ishape[1][1], y0b, x0b, Qy, Qx,
+                             ccb, B_lds, a.pb, 0, a.ml, (Qx + 15) / 16};
+      stage_patches<64>(sa, sb, lane, (c - 1) * 64 * kStageBatch, c * 64 * kStageBatch);
+      TICK(15)
+    } else {
+      // (the pixels and the zeroed sums first)
+      while (__builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[9])) < na + 1)
+        __builtin_amdgcn_s_sleep(2);
+      seed_probe(c - na - 1, kProbeUnits, 2);
+      TICK(16)
+    }
+    open_unit_done();
+  };
+  // the closer (or, at start-up, the wave that owns the slot): next patch into the bound slot
+  auto open_begin = [&]() {
+    const int nb = __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[18]));
+    if (nb >= n_items) {
+      if (lane == 0) ctl[3] = 1;   // retired: the control word stays at "nothing to draw"
+      return false;
+    }
+#ifdef SFM_MFMA_TIMING
+    ++npat;
+#endif
+    const int na = n_stage_units();
+    if (lane == 0) {
+      ctl[2] = nb;
+      ctl[12] = ctl[19]; ctl[13] = ctl[20]; ctl[14] = ctl[21];
+      ctl[15] = ctl[22]; ctl[16] = ctl[23]; ctl[17] = ctl[24];
+      ctl[4] = ctl[25]; ctl[5] = ctl[26];
+      *pmax_lds = 0;
+      *hot_lds = 0;
+      // initial store requests: as in the other lazy modes (see there)
+      const int pt = *best_lds >> 8, gt = (a.guard + 15) >> 4;
+      const int lo_t = max(pt - gt, 0), hi_t = min(pt + gt, a.n_order - 1);
+      const int pv = *lz_prev;
+      lz[0] = (pv && !a.widen ? 0 : static_cast<int>(((2u << hi_t) - 1u) & ~((1u << lo_t) - 1u))) |
+              pv | (a.widen ? (pv << 1) | (pv >> 1) : 0);
+      lz[1] = lz[2] = lz[3] = 0;
+      if (lz_cq[1] >= lz_cq[0]) {
+        lz_cq[2] = lz_cq[0];
+        lz_cq[3] = lz_cq[1];
+      }
+      lz_cq[0] = NQ;
+      lz_cq[1] = -1;
+      int probe_on = 0;
+      if (a.prune) {
+        best_lds[1] = 0;
+        const int n_done = best_lds[3];
+        best_lds[3] = n_done + 1;
+        probe_on = (a.probe && (best_lds[2] > 0 || (n_done & 7) == 0)) ? 1 : 0;
+        best_lds[4] = probe_on;
+        best_lds[2] = 0;
+      }
+      ctl[1] = 0;
+      ctl[9] = 0;
+      ctl[10] = 1 + na + (probe_on ? kProbeUnits : 0);
+      ctl[11] = probe_on;
+      // (in order behind everything above: the staging units may start)
+      *const_cast<volatile int*>(&ctl[8]) = 1;
+    }
+    // unit 0
+    const float* aux = a.aux + (long long)nb * (4 * a.aux_n + 4);
+    constexpr int kAuxP = (4 * (16 * NCA + 1) + 63) / 64;   // (Py <= Px = 16 NCA)
+    float auxv[kAuxP], tbv[kBoundStride / 64];
+#pragma unroll
+    for (int k = 0; k < kAuxP; ++k) {
+      const int i = lane + 64 * k;
+      auxv[k] = i < 4 * a.aux_n ? aux[i] : 0.f;
+    }
+    const float ca_new = aux[4 * a.aux_n + 0], cb_new = aux[4 * a.aux_n + 1];
+#pragma unroll
+    for (int k = 0; k < kBoundStride / 64; ++k)
+      tbv[k] = a.tbound[(long long)nb * kBoundStride + lane + 64 * k];
+#ifndef SFM_NO_TOUCH
+    {
+      // the column-sum tables this patch's finishing tiles build their table rows from
+      const char* gt = reinterpret_cast<const char*>(a.c16 + nb * a.c16_stride);
+      const unsigned junk_off = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+          (__attribute__((address_space(3))) float*)touch_junk));
+      const int n_lines = (2 * ((Py >> 4) + 1) * Px + Py + 1 + 15) >> 4;
+      for (int k = lane; k < n_lines; k += 64) {
+        const char* src = gt + (size_t)k * 64;
+        unsigned saved_m0;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+            "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(saved_m0)
+            : "v"(src), "s"(junk_off)
+            : "memory");
+      }
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pr_lds[lane + 64 * k] = 0;
+    if (lane < 32) lz_ks[lane] = 0;
+#pragma unroll
+    for (int k = 0; k < kAuxP; ++k) {
+      const int i = lane + 64 * k;
+      if (i < 4 * a.aux_n) R_lds[i] = auxv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kBoundStride / 64; ++k) tb_lds[lane + 64 * k] = tbv[k];
+    if (lane == 0) {
+      ctl[6] = __float_as_int(ca_new);
+      ctl[7] = __float_as_int(cb_new);
+    }
+    TICK(17)
+    open_unit_done();
+    return true;
+  };
+  int cur = 0;   // kModePipe: the slot this wave is bound to
+  if constexpr (PIPE) {
+    // start-up: waves 0 and 1 own the first opening of slot 0 / 1, everybody helps
+    cur = wave & 1;
+    bind_slot(cur);
+    if (wave < 2) {
+      prefetch_next(2 * static_cast<int>(blockIdx.x) + wave);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (open_begin()) prefetch_next(-1);
+    }
+  }
+  // (kModePipe: ONE trip -- its tile loop runs across all patches of the workgroup)
+  for (int item = PIPE ? 0 : a.xcd_heads ? pull_item(a, n_items, &q_state, next_lds) : blockIdx.x;
+       PIPE ? item == 0 : item < n_items;
+       item = PIPE ? 1 : a.xcd_heads ? pull_item(a, n_items, &q_state, next_lds)
+                                      : next_patch(a, item, next_lds)) {
     int b = item;
     int plane0 = a.plane[0], plane1 = a.plane[1];
     if (RAW && a.list) {
@@ -2597,6 +2930,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     ++npat;
 #endif
     TICK(7)
+    float const_a = 0.f, const_b = 0.f;
+    float mua = 0.f, mub = 0.f, muab = 0.f;
+    if constexpr (!PIPE) {
     __syncthreads();  // previous patch fully consumed / zero fill done
     TICK(0)
     const PatchParams pp = a.pp[b];
@@ -2604,7 +2940,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     // take the remainder loops below
     constexpr int kAuxRegs = 3;
     float auxv[kAuxRegs];
-    float const_a = 0.f, const_b = 0.f, tbv = 0.f;
+    float tbv = 0.f;
     if (RAW) {
       stage_plane(a.img[0], bytes0, a.ishape[0][1], pp.y0[0], pp.x0[0], a.mask[0],
                   (long long)a.mshape[0][0] * a.mshape[0][1], a.mshape[0][1],
@@ -2634,7 +2970,7 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
                              pp.c[0], A_lds, a.pa, kPadTop, 0, NCA};
       const StagePlane sb = {a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
                              pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16};
-      stage_patches(sa, sb);
+      stage_patches(sa, sb, threadIdx.x);
       TICK(8)
     }
     if (threadIdx.x == 0) {
@@ -2691,80 +3027,13 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     TICK(9)
     __syncthreads();
 
-    if (SAME && a.prune && a.probe && __builtin_amdgcn_readfirstlane(best_lds[4])) {
-      // Seed of the running maximum.  The first tiles are drawn before any tile
-      // has finished, i.e. with nothing to prune against.  So the 16 x 16 block of
-      // shifts that held the previous patch's maximum is evaluated first, its
-      // patch rows split over the four waves (exact integer sums S, the same
-      // fragments the row loop would use), summed through LDS atomics, and
-      //   max(surface) >= max(S over the block) - |correction|max =: m_lo
-      // (tbound[kBoundCorr], prep kernel) goes into the running maximum.  m_lo is
-      // strictly below a real element, so the final maximum is unaffected.
-      const int pq = __builtin_amdgcn_readfirstlane(*best_lds);
-      const int ps = pq >> 8, qs = pq & 255;
-      const int pdy0 = 16 * ps - (Qy - 1);
-      const int pylo = max(0, -pdy0 - 15), pyhi = min(Qy, Py - pdy0);
-      const unsigned char* pap = A_lds + (kPadTop + pylo + g + pdy0 + n) * a.pa;
-      const unsigned char* pbp = B_lds + (pylo + g) * a.pb + (pos0 & ~3);
-      // two row groups per trip: their loads are in flight together and they
-      // accumulate into separate registers (no dependent MFMA chain of 2 NCA)
-      v4i pacc = v4i{0, 0, 0, 0}, pacc2 = v4i{0, 0, 0, 0};
-      const int n_grp = (pyhi - pylo + 3) >> 2;
-      // The pairs (ca, c) on the diagonal of column tile qs are ca = ca_lo + i,
-      // c = c_lo + i, i < n_on: contiguous A chunks against a contiguous run of B
-      // dwords (4 n_on + 1, shared between neighbouring fragments like in the row
-      // loop).  Pairs past n_on, and groups past the tile, read A from a zero
-      // padding row instead (branch-free).
-      const int ca_lo = max(0, qs - cq0), c_lo = ca_lo - qs + cq0;
-      const int n_on = min(NCA - ca_lo, NCE - c_lo);
-      const unsigned char* zero_row = A_lds + n * a.pa;  // inside the top padding
-      constexpr int kPD = 4 * NCA + 1;
-      auto load_group = [&](int grp, v4i* paf, unsigned* pd) {
-        const bool live = grp < n_grp;
-        const int gc = min(grp, n_grp - 1);
-        const unsigned char* ag = pap + 4 * gc * a.pa + 16 * ca_lo;
-        const unsigned char* bg = pbp + 4 * gc * a.pb + 16 * c_lo;
-#pragma unroll
-        for (int i = 0; i < NCA; ++i)
-          paf[i] = *reinterpret_cast<const v4i*>((live && i < n_on) ? ag + 16 * i : zero_row);
-#pragma unroll
-        for (int j = 0; j < kPD; ++j) pd[j] = *reinterpret_cast<const unsigned*>(bg + 4 * j);
-      };
-      auto mma_group = [&](const v4i* paf, const unsigned* pd, v4i& acc_out) {
-#pragma unroll
-        for (int i = 0; i < NCA; ++i) {
-          v4i bf;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            bf[k] = static_cast<int>(
-                __builtin_amdgcn_alignbyte(pd[4 * i + k + 1], pd[4 * i + k], sh));
-          acc_out = __builtin_amdgcn_mfma_i32_16x16x64_i8(paf[i], bf, acc_out, 0, 0, 0);
-        }
-      };
-      for (int grp = wave; grp < n_grp; grp += 2 * kWaves) {
-        v4i paf[NCA], paf2[NCA];
-        unsigned pd[kPD], pd2[kPD];
-        load_group(grp, paf, pd);
-        load_group(grp + kWaves, paf2, pd2);
-        mma_group(paf, pd, pacc);
-        mma_group(paf2, pd2, pacc2);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pacc[r] += pacc2[r];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&probe_lds[r * 64 + lane], pacc[r]);
-      __syncthreads();
-      int sm = max(max(probe_lds[lane], probe_lds[64 + lane]),
-                   max(probe_lds[128 + lane], probe_lds[192 + lane]));
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) sm = max(sm, __shfl_xor(sm, d, 64));
-      const float m_lo = __int2float_rd(sm) - tb_lds[kBoundCorr];
-      if (lane == 0 && m_lo > 0.f) atomicMax(pmax_lds, __float_as_int(m_lo));
-    }
+    if (SAME && a.prune && a.probe && __builtin_amdgcn_readfirstlane(best_lds[4]))
+      seed_probe(wave, kWaves, 0);
 
     TICK(1)
-    const float mua = pp.mu[0], mub = pp.mu[1];
-    float muab = mua * mub;
+    mua = pp.mu[0];
+    mub = pp.mu[1];
+    muab = mua * mub;
     asm volatile("" : "+v"(muab));  // every global load so far has been consumed
 #ifndef SFM_NO_TOUCH
     if (SAME) {
@@ -2819,9 +3088,10 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       }
     }
 #endif
+    }  // !PIPE: the patch's staging
     const int* IA = (SAME || RAW) ? nullptr : a.integ[0] + b * a.integ_stride[0];
     const int* IB = (SAME || RAW) ? nullptr : a.integ[1] + b * a.integ_stride[1];
-    const float* G = SAME ? a.gtab + (long long)b * Py * Px : nullptr;
+    const float* G = SAME ? a.gtab + (long long)b * Py * Px : nullptr;   // (kModePipe: per draw)
     float* surf = a.surface + b * a.s_stride;
 
 #if SFM_DYNAMIC_TILES
@@ -2829,7 +3099,68 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
     for (;;) {
       int ti = 0, p = 0;
       bool forced = false;
-      if (!redo_phase) {
+      if (PIPE && !redo_phase) {
+        // A tile of either slot.  The control word is tested with a plain read and drawn
+        // from with ONE atomic; the patch header is read in the same round (it cannot
+        // change while this wave holds a tile of the patch).
+        bool got = false;
+        for (int spin = 0;; ++spin) {
+          const int v = __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[0]));
+          const int dead_here = __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[3]));
+          // (the first tiles of a patch run against the seed of the running maximum alone:
+          // only pipe_admit of them are handed out before one is done)
+          const int done_here = __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[1]));
+          if ((v & 255) < a.n_order && ((v & 255) < a.pipe_admit || done_here > 0)) {
+            int v2 = 0, hb = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0;
+            if (lane == 0) v2 = atomicAdd(&ctl[0], 1);
+            hb = *const_cast<volatile int*>(&ctl[2]);
+            h4 = *const_cast<volatile int*>(&ctl[4]);
+            h5 = *const_cast<volatile int*>(&ctl[5]);
+            h6 = *const_cast<volatile int*>(&ctl[6]);
+            h7 = *const_cast<volatile int*>(&ctl[7]);
+            v2 = __builtin_amdgcn_readfirstlane(v2);
+            if ((v2 & 255) < a.n_order) {
+              ti = v2 & 255;
+              b = __builtin_amdgcn_readfirstlane(hb);
+              mua = __int_as_float(__builtin_amdgcn_readfirstlane(h4));
+              mub = __int_as_float(__builtin_amdgcn_readfirstlane(h5));
+              const_a = __int_as_float(__builtin_amdgcn_readfirstlane(h6));
+              const_b = __int_as_float(__builtin_amdgcn_readfirstlane(h7));
+              muab = mua * mub;
+              G = a.gtab + (long long)b * Py * Px;
+              surf = a.surface + b * a.s_stride;
+              got = true;
+              break;
+            }
+          }
+          // no tile here: a unit of this slot's opening, if it is being opened
+          {
+            const int u = __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[8]));
+            const int nu = __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[10]));
+            if (u >= 1 && u < nu) {
+              int c = 0;
+              if (lane == 0) c = atomicAdd(&ctl[8], 1);
+              c = __builtin_amdgcn_readfirstlane(c);
+              if (c < nu) {
+                TICK(13)
+                open_unit(c);
+                spin = 0;
+                continue;   // (same slot: more units, or its first tiles)
+              }
+            }
+          }
+          cur ^= 1;
+          bind_slot(cur);
+          if (dead_here &&
+              __builtin_amdgcn_readfirstlane(*const_cast<volatile int*>(&ctl[3])))
+            break;   // both slots retired: this wave is done
+          if (spin & 1) __builtin_amdgcn_s_sleep(4);
+        }
+        TICK(13)   // (timing build) looking for a tile
+        if (!got) break;
+        p = __builtin_amdgcn_readfirstlane(a.order[ti]);
+      }
+      if (!PIPE && !redo_phase) {
         if (lane == 0) ti = atomicAdd(pmax_lds + 3, 1);
         ti = __builtin_amdgcn_readfirstlane(ti);
         if (ti >= a.n_order) {
@@ -2875,6 +3206,21 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         int todo = need & done & (~*const_cast<volatile int*>(&lz[2]) | bad) &
                    ~*const_cast<volatile int*>(&lz[3]);
         todo = __builtin_amdgcn_readfirstlane(todo);
+        if (PIPE && todo == 0) {
+          // the patch is complete: publish it (what the peak kernels read), then put the
+          // next patch into this slot
+          if (lane == 0) {
+            a.v1[b] = __int_as_float(*const_cast<volatile int*>(pmax_lds));
+            a.hot_count[b] = *const_cast<volatile int*>(hot_lds);
+            a.skipmask[b] = ~*const_cast<volatile int*>(&lz[2]) &
+                            static_cast<int>((2u << (a.n_order - 1)) - 1u);
+          }
+          TICK(14)   // (timing build) end-of-patch pass of the closer
+          if (open_begin()) prefetch_next(-1);
+          TICK(17)
+          redo_phase = false;
+          continue;
+        }
         if (todo == 0) break;
         p = __builtin_ctz(todo);
         int old = 0;
@@ -2890,6 +3236,9 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
       constexpr bool forced = false;
       static_assert(!LAZY, "lazy stores need the dynamic tile queue");
 #endif
+      // (the tile's body is a block of its own: a `continue` inside it ends the tile and
+      // falls through to the completion count of kModePipe behind it)
+      do {
       // The two workgroups of a CU share each SIMD's MFMA pipe, and the issue
       // arbiter always favours the older wave: the younger workgroup would
       // run ~25 % slower and finish long after its partner.  Alternating the
@@ -3921,9 +4270,21 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
         }
       }
       TICK(4)
+      } while (0);
+      if constexpr (PIPE) {
+        TICK(9)   // (timing build) tiles that end without an epilogue
+        if (!forced) {
+          // done with this tile, whatever became of it; the wave that completes the
+          // patch closes it (every LDS write of this wave is older than the count)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          int dn = 0;
+          if (lane == 0) dn = atomicAdd(&ctl[1], 1) + 1;
+          if (__builtin_amdgcn_readfirstlane(dn) == a.n_order) redo_phase = true;
+        }
+      }
     }
     TICK(5)
-    if (a.do_peaks) {
+    if (!PIPE && a.do_peaks) {
       // Publish the running maximum and the hot-list fill; the first-peak
       // search over them is mfma_first_peak_kernel (every patch in parallel,
       // off the matrix pipeline's critical path).
@@ -3966,7 +4327,14 @@ __global__ void __launch_bounds__(kThreads, 2) xcorr_mfma_kernel(MfmaArgs a) {
            wall ? cyc * 100 / wall : 0, tph[2] / (npat ? npat : 1),
            tph[3] / (npat ? npat : 1));
   }
-  if (blockIdx.x == 7 && lane == 0)
+  if (PIPE && blockIdx.x == 7 && lane == 0) {
+    // totals of this wave over the launch (cycles): divide by the workgroup's patches
+    printf("pipewave %d opened %d tiles %d: total %lld seek %lld setup %lld tests %lld groups %lld loop-tail %lld "
+           "epi %lld hot %lld exit %lld close %lld stage %lld probe %lld arm %lld\n",
+           wave, npat, tiles_drawn, clock64() - cstart, tph[13], tph[10], tph[11], tph[12], tph[2], tph[3],
+           tph[4], tph[9], tph[14], tph[15], tph[16], tph[17]);
+  }
+  if (!PIPE && blockIdx.x == 7 && lane == 0)
     printf("wave %d patches %d: next %lld sync %lld pix %lld aux+touch %lld stagesync %lld mfma %lld (+ setup %lld tests %lld groups %lld) epi %lld hot %lld tail %lld peaks %lld\n",
            wave, npat, tph[7] / npat, tph[0] / npat, tph[8] / npat, tph[9] / npat, tph[1] / npat, tph[2] / npat,
            tph[10] / npat, tph[11] / npat, tph[12] / npat, tph[3] / npat,
@@ -4080,6 +4448,31 @@ Ws carve_ws(const SfmXcorrDesc* d, void* base) {
 
 int device_cus();
 
+// kModePipe: one workgroup of eight waves per CU, two patch slots in LDS.
+template <int NCA, int NCE>
+int launch_pipe(const MfmaArgs& a, int grid, hipStream_t st) {
+  const size_t lds = 2 * static_cast<size_t>(a.slot_bytes);
+  static size_t attr_set = 0;
+  if (lds > attr_set) {
+    SFM_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE, kModePipe>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    attr_set = lds;
+  }
+  grid = std::min((grid + 1) / 2, device_cus());
+  {
+    const char* g = sfm::option("SFM_MFMA_GRID");   // (tests: many patches per workgroup)
+    if (g && std::atoi(g) > 0) grid = std::min(grid, std::max(1, std::atoi(g) / 2));
+  }
+  sfm::prof_begin(sfm::kProfXcorr, st);
+  hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, kModePipe>), dim3(grid),
+                     dim3(2 * kThreads), lds, st, a);
+  sfm::prof_end(sfm::kProfXcorr, st);
+  sfm::prof_clock(sfm::kProfXcorr, a.clk, st, 5);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
 template <int NCA, int NCE, int MODE>
 int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   static size_t attr_set = 0;
@@ -4135,6 +4528,13 @@ int launch_variant(const MfmaArgs& a, int mode, int grid, size_t lds,
     case kModeSameLazy: return launch_one<NCA, NCE, kModeSameLazy>(a, grid, lds, st);
     case kModeSameExactLazy: return launch_one<NCA, NCE, kModeSameExactLazy>(a, grid, lds, st);
     case kModeSameExactLazyG: return launch_one<NCA, NCE, kModeSameExactLazyG>(a, grid, lds, st);
+    case kModePipe:
+      // (instantiated for the 160-wide variant; the narrower ones keep three or four
+      // workgroups per CU and are not priced by the per-patch phases)
+      if constexpr (NCA == 10)
+        return launch_pipe<NCA, NCE>(a, grid, st);
+      else
+        return launch_one<NCA, NCE, kModeSameExactLazyG>(a, grid, lds, st);
     case kModeRaw: return launch_one<NCA, NCE, kModeRaw>(a, grid, lds, st);
     default: return launch_one<NCA, NCE, kModeGeneral>(a, grid, lds, st);
   }
@@ -4453,9 +4853,23 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   }
   SFM_LAUNCH_CHECK();
   const size_t lds = (size_t)l.a_bytes + l.b_bytes + r_bytes + 16 + 4 * kBoundStride + 48 + 128 + 160 + 128;
+  a.slot_bytes = static_cast<int>((lds + 4 * kPipeCtl + 4 * 256 + 15) / 16 * 16);
   const int grid = d->batch;  // capped to the resident workgroups in launch_one
+  // cross-patch pipeline (kModePipe): SFM_MFMA_PIPE=1
+  bool pipe = false;
+  {
+    const char* e = sfm::option("SFM_MFMA_PIPE");
+    pipe = e && e[0] == '1' && a.lazy_g && kVariants[vi].nca == 10 && a.work_counter &&
+           !a.xcd_heads && a.P[0] <= a.P[1] && a.n_order < 128 &&
+           2 * (size_t)a.slot_bytes + 2048 <= 160 * 1024;
+  }
+  {
+    const char* e = sfm::option("SFM_MFMA_PIPE_ADMIT");
+    a.pipe_admit = e && std::atoi(e) > 0 ? std::atoi(e) : 2;
+  }
   const int mode = !same ? kModeGeneral
-                   : exact ? (a.lazy_g ? kModeSameExactLazyG
+                   : exact ? (pipe ? kModePipe
+                              : a.lazy_g ? kModeSameExactLazyG
                                        : lazy ? kModeSameExactLazy : kModeSameExact)
                            : (lazy ? kModeSameLazy : kModeSame);
   if (int rc = launch_mode(vi, a, mode, grid, lds, st)) return rc;

@@ -149,6 +149,69 @@ def test_prep_without_staging_matches_the_staged_form(gpu, py, px, mean):
       np.testing.assert_array_equal(flow_field.batched_xcorr_peaks(*args, method=2, **kw), got)
 
 
+@pytest.mark.parametrize('mean', [None, 100.0])
+def test_cross_patch_pipeline_is_bit_identical(gpu, mean):
+  """SFM_MFMA_PIPE=1 (kModePipe: one workgroup of eight waves per CU, two patch
+  slots in LDS, the tile queue running across the patch boundary, the closing wave
+  recomputing / publishing / re-opening alone, openings cut into units any idle wave
+  takes) against the two-workgroup kernel and the un-pruned run: the same bits on the
+  batch that interleaves all seven adversarial image kinds, through 1, 3 and all
+  workgroups (1 workgroup = both slots of ONE CU carry the whole batch: every slot
+  hand-over, retirement with tiles still in flight in the other slot, batches of 1
+  and 2 patches = a slot that never opens), with every admission limit and with the
+  kernel's other switches on top."""
+  from sofima_amd import _abi, flow_field
+  pre, post = _mosaic(53)
+  rng = np.random.default_rng(17)
+  py = px = 160
+  for b in (1, 2, 3, 98, 301):
+    starts, _ = _interleaved_starts(rng, b, py, px)
+    kw = dict(min_distance=2, threshold_rel=0.5, peak_radius=5,
+              post_patch_size=(py, px), post_starts=starts)
+    args = (pre, post, None, None, (py, px), starts, mean)
+    ref = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+    if b == 98:
+      with _abi.option('SFM_MFMA_PRUNE', 0):
+        np.testing.assert_array_equal(flow_field.batched_xcorr_peaks(*args, method=2, **kw), ref)
+    with _abi.option('SFM_MFMA_PIPE', 1):
+      for grid in (0, 2, 6):
+        with _abi.option('SFM_MFMA_GRID', grid):
+          for admit in ((255, 2, 1) if b == 98 else (0,)):
+            with _abi.option('SFM_MFMA_PIPE_ADMIT', admit):
+              np.testing.assert_array_equal(
+                  flow_field.batched_xcorr_peaks(*args, method=2, **kw), ref,
+                  err_msg=f'batch {b} grid {grid} admit {admit}')
+      if b == 98:
+        for name, val in (('SFM_MFMA_EARLY', 0), ('SFM_MFMA_NARROW', 0), ('SFM_MFMA_PROBE', 0),
+                          ('SFM_MFMA_WIDEN', 1)):
+          with _abi.option(name, val), _abi.option('SFM_MFMA_GRID', 2):
+            np.testing.assert_array_equal(
+                flow_field.batched_xcorr_peaks(*args, method=2, **kw), ref,
+                err_msg=f'{name}={val}')
+  # other peak geometries (guard bands of 60 rows: the closer recomputes band tiles)
+  starts, _ = _interleaved_starts(rng, 70, py, px)
+  for radius, md, thr in ((30, 2, 0.9), (5, 2, 0.2), (12, 6, 0.5)):
+    kw = dict(min_distance=md, threshold_rel=thr, peak_radius=radius,
+              post_patch_size=(py, px), post_starts=starts)
+    args = (pre, post, None, None, (py, px), starts, mean)
+    ref = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
+    with _abi.option('SFM_MFMA_PIPE', 1), _abi.option('SFM_MFMA_GRID', 4):
+      np.testing.assert_array_equal(flow_field.batched_xcorr_peaks(*args, method=2, **kw), ref)
+
+
+def test_cross_patch_pipeline_whole_bench_field(gpu):
+  """The literal bench pair through the pipeline kernel: the whole [4, 201, 201]
+  field equals the production kernel's (which the oracle test above pins)."""
+  import bench
+  from sofima_amd import _abi, flow_field as ff
+  pre, post = bench.synth_pair(8192, 1002, warp=bench.WARP)
+  calc = ff.JAXMaskedXCorrWithStatsCalculator()
+  ref = calc.flow_field(pre, post, bench.PATCH, bench.STEP, batch_size=bench.BATCH)
+  with _abi.option('SFM_MFMA_PIPE', 1):
+    got = calc.flow_field(pre, post, bench.PATCH, bench.STEP, batch_size=bench.BATCH)
+  np.testing.assert_array_equal(got, ref)
+
+
 def test_every_kernel_switch_returns_the_same_bits(gpu):
   """The run-time switches of the correlation kernel select schedules, never
   results: PROBE, TOUCH_ALL, EXACT, QUEUE, PRIO, MAX_WG_PER_CU (measurement
