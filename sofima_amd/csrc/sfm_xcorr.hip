@@ -1246,7 +1246,7 @@ int check_desc(const SfmXcorrDesc* d) {
     return sfm::fail(SFM_ERR_INVALID, "unknown method %d", d->method);
   if (d->method == SFM_XCORR_MFMA_I8 && !sfm::mfma_i8_eligible(d))
     return sfm::fail(SFM_ERR_INVALID,
-                     "MFMA_I8 needs uint8 2-D images and patches up to 160 wide");
+                     "MFMA_I8 needs uint8 2-D images, post patches up to 160 wide and (un-masked) pre patches up to 320 wide");
   return SFM_OK;
 }
 

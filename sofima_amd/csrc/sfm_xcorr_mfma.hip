@@ -2497,7 +2497,14 @@ __device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_ld
 
 template <int NCA, int NCE, int MODE>
 __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
-                                  MODE == kModePipe ? 1 : 2) xcorr_mfma_kernel(MfmaArgs a) {
+                                  (MODE == kModePipe || NCA > 10) ? 1 : 2) xcorr_mfma_kernel(MfmaArgs a) {
+  // Search-window geometry (NCA > 10: pre patches 161 .. 320 wide against a post patch of up
+  // to 160, processor/flow.py:577,792-803).  The pre patch alone is up to 119 KB of LDS, so a
+  // CU holds ONE workgroup = one wave per SIMD -- which then owns the SIMD's whole register
+  // file: 512 registers per lane, the 25 .. 30 accumulator tiles of a row tile in the upper
+  // half (the compiler places them in AGPRs), the 15 .. 20 A fragments double-buffered in the
+  // lower one (the fragments of the next row group are in flight while the 165 .. 220 matrix
+  // instructions of this one issue).  kModeGeneral semantics; no pruning.
   // Cross-patch pipeline (kModePipe; everything else is kModeSameExactLazyG).  The other
   // modes run two workgroups of four waves per CU, each on its own patch, and every patch
   // has phases in which its four waves wait for each other: the staging round trip, the
@@ -3695,9 +3702,7 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
           rows(std::integral_constant<int, kKs4>{});
         if (kKs5 > kKs4 && col_skip == kKs5 && !abandoned && yb0 < yhi)
           rows(std::integral_constant<int, kKs5>{});
-      } else
-#if SFM_AF_PREFETCH
-      {
+      } else if constexpr (SFM_AF_PREFETCH || NCA > 10) {
         v4i afA[NCA], afB[NCA];
 #pragma unroll
         for (int ca = 0; ca < NCA; ++ca)
@@ -3710,9 +3715,8 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
           bp += 8 * a.pb;
         }
         if (yb0 < yhi) row_group(afA, nullptr, nullptr, bp);
-      }
-#else
-      {
+        mfma_issued += (long long)((yhi - ylo + 3) / 4) * (NCA * NCE);
+      } else {
         for (int yb0 = ylo; yb0 < yhi; yb0 += 4) {
           v4i af[NCA];
 #pragma unroll
@@ -3724,7 +3728,6 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
         }
         mfma_issued += (long long)((yhi - ylo + 3) / 4) * (NCA * NCE);
       }
-#endif
 
       TICK(2)
       if (LAZY && abandoned) {
@@ -3866,6 +3869,176 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
         continue;
       }
 #endif
+      // One column tile's share of the hot list (see the tile's peak pass below).
+      int hq_lo = NQ, hq_hi = -1;   // column tiles with elements that may be hot
+      auto hot_insert = [&](const int q, const float v0, const float v1, const float v2,
+                            const float v3, const float thr_t) {
+        float* hv = a.hot_val + (long long)b * a.hot_cap;
+        int* hi = a.hot_idx + (long long)b * a.hot_cap;
+        const float vv[4] = {v0, v1, v2, v3};
+        const float vm = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+        if (__any(vm > thr_t)) {  // wave-uniform, rarely taken
+          hq_lo = min(hq_lo, q);
+          hq_hi = q;
+          // one list reservation per column tile (ballots + one LDS atomic): an
+          // atomic per lane and row was four dependent LDS round trips here
+          unsigned long long bal[4];
+          int total = 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bal[r] = __ballot(vv[r] > thr_t);
+            total += __builtin_popcountll(bal[r]);
+          }
+          int base = 0;
+          if (lane == 0) base = atomicAdd(hot_lds, total);
+          base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = vv[r];
+            if (v > thr_t) {
+              const int slot = base + static_cast<int>(__builtin_amdgcn_mbcnt_hi(
+                                          static_cast<unsigned>(bal[r] >> 32),
+                                          __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(bal[r]), 0u)));
+              if (slot < a.hot_cap) {
+                hv[slot] = v;
+                hi[slot] = (16 * p + 4 * g + r) * Sx + 16 * q + n;
+              }
+            }
+            base += __builtin_popcountll(bal[r]);
+          }
+        }
+      };
+      // kModeGeneral, search-window variants (NCA > 10): the epilogue (pass 0) and the
+      // hot-list pass (pass 1) over the column tiles of this row tile.
+      // Search-window variants: a lone wave per SIMD pays every round trip of its table
+      // look-ups in full, and eight of them per output (two box sums from two integral
+      // images) made the epilogue as long as the matrix loop.  With Px >= Qx a shift dx
+      // is in one of three regimes, and in each of them half of the eight corner terms
+      // are a row constant or zero:
+      //   L  dx <= 0:            xa0 = 0 (IA[.][0] = 0),  xb1 = Qx (row total of B)
+      //   M  0 < dx < Px - Qx:   xb0 = 0,  xb1 = Qx: the post patch lies inside -- SB is
+      //                          the row total, SA the only box with four corners
+      //   R  dx >= Px - Qx:      xa1 = Px (row total of A),  xb0 = 0
+      // so FOUR gathers per output are enough, selected per lane without a branch:
+      //   v0, v1 = IA[oa1 | oa0][L, M: xa1;  R: xa0]
+      //   v2, v3 = L: IB[ob1 | ob0][xb0]   M: IA[oa1 | oa0][xa0]   R: IB[ob1 | ob0][xb1]
+      //   SA = L: v0 - v1   M: (v0 - v1) - (v2 - v3)   R: total_A - (v0 - v1)
+      //   SB = L: total_B - (v2 - v3)   M: total_B   R: v2 - v3
+      // -- the same integers as the eight-corner form, so the same bits.  The gathers of
+      // a group of column tiles are all in flight before the previous group is consumed.
+      auto wide_general = [&](const int pass, const float thr) {
+        if constexpr (NCA > 10 && MODE == kModeGeneral) {
+          const int ipa = Px + 1, ipb = Qx + 1;
+          int oa0[4], oa1[4], ob0[4], ob1[4], ny[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ky = min(16 * p + 4 * g + r, Sy - 1);
+            const int dy = ky - (Qy - 1);
+            const int ya0 = max(0, dy), ya1 = min(Py, Qy + dy);
+            oa0[r] = ya0 * ipa + opaque_zero;
+            oa1[r] = ya1 * ipa;
+            ob0[r] = (ya0 - dy) * ipb + opaque_zero;
+            ob1[r] = (ya1 - dy) * ipb;
+            ny[r] = ya1 - ya0;
+          }
+          int ta[4], tb[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ta[r] = IA[oa1[r] + Px] - IA[oa0[r] + Px];
+            tb[r] = IB[ob1[r] + Qx] - IB[ob0[r] + Qx];
+          }
+          // (regimes as all-ones / zero lane masks: nested selects came out as divergent
+          // branches, one basic block per output)
+          const long long ib_delta = IB - IA;   // IB's entries addressed from IA
+          // The column tiles are walked by a RUN-TIME loop, two tiles per trip: unrolled over
+          // 25 .. 30 tiles the scheduler hoisted every gather of a tile's 100 .. 120 outputs
+          // per lane to the front and spilled a thousand registers.  The accumulator tile of
+          // a run-time q is reached through a switch over its compile-time names (a compare
+          // tree on a scalar: the accumulators must never be indexed dynamically) and is
+          // only ever READ here -- a loop that also wrote the finished values back through
+          // such a switch left every register array of the kernel in scratch memory.  The
+          // hot-list pass (pass 1, only for a tile that may hold a hot element: a few per
+          // patch) therefore recomputes its values from the integer sums instead.
+          auto acc_get = [&](int q, int* dst) {
+            switch (q) {
+#define SFM_ACC_CASE(k)                                                   \
+  case k:                                                                 \
+    if constexpr (k < NQ) {                                               \
+      dst[0] = acc[k][0]; dst[1] = acc[k][1]; dst[2] = acc[k][2]; dst[3] = acc[k][3]; \
+    }                                                                     \
+    break;
+              SFM_ACC_CASE(0) SFM_ACC_CASE(1) SFM_ACC_CASE(2) SFM_ACC_CASE(3) SFM_ACC_CASE(4)
+              SFM_ACC_CASE(5) SFM_ACC_CASE(6) SFM_ACC_CASE(7) SFM_ACC_CASE(8) SFM_ACC_CASE(9)
+              SFM_ACC_CASE(10) SFM_ACC_CASE(11) SFM_ACC_CASE(12) SFM_ACC_CASE(13) SFM_ACC_CASE(14)
+              SFM_ACC_CASE(15) SFM_ACC_CASE(16) SFM_ACC_CASE(17) SFM_ACC_CASE(18) SFM_ACC_CASE(19)
+              SFM_ACC_CASE(20) SFM_ACC_CASE(21) SFM_ACC_CASE(22) SFM_ACC_CASE(23) SFM_ACC_CASE(24)
+              SFM_ACC_CASE(25) SFM_ACC_CASE(26) SFM_ACC_CASE(27) SFM_ACC_CASE(28) SFM_ACC_CASE(29)
+#undef SFM_ACC_CASE
+              default: break;
+            }
+          };
+          static_assert(NQ <= 30, "extend the accumulator switch");
+          constexpr int kQW = 2;   // column tiles per trip (32 gathers in flight)
+#pragma unroll 1
+          for (int q0 = 0; q0 < NQ; q0 += kQW) {
+            int sv[kQW][4], gv[kQW][4][4], mLs[kQW], mRs[kQW], xw[kQW];
+#pragma unroll
+            for (int u = 0; u < kQW; ++u) {
+              const int q = min(q0 + u, NQ - 1);   // (an odd tile count: the last trip repeats a tile)
+              acc_get(q, sv[u]);
+              const int kx = 16 * q + n;
+              const int dx = min(kx, Sx - 1) - (Qx - 1);
+              const int xa0 = max(0, dx), xa1 = min(Px, Qx + dx);
+              const int mL = -static_cast<int>(dx <= 0);
+              const int mR = ~mL & -static_cast<int>(dx >= Px - Qx);
+              const int mM = ~(mL | mR);
+              const int xb0 = xa0 - dx, xb1 = xa1 - dx;
+              const int c01 = (xa0 & mR) | (xa1 & ~mR);
+              const int c23 = (xb0 & mL) | (xa0 & mM) | (xb1 & mR);
+              const long long d23 = ib_delta & ~static_cast<long long>(mM);
+              mLs[u] = mL;
+              mRs[u] = mR;
+              xw[u] = xa1 - xa0;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                gv[u][r][0] = IA[oa1[r] + c01];
+                gv[u][r][1] = IA[oa0[r] + c01];
+                gv[u][r][2] = IA[d23 + (((oa1[r] & mM) | (ob1[r] & ~mM)) + c23)];
+                gv[u][r][3] = IA[d23 + (((oa0[r] & mM) | (ob0[r] & ~mM)) + c23)];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < kQW; ++u) {
+              const int q = min(q0 + u, NQ - 1);
+              const int kx = 16 * q + n;
+              const int mL = mLs[u], mR = mRs[u], mM = ~(mL | mR);
+              const float fnx = static_cast<float>(xw[u]);
+              float outv[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int d01 = gv[u][r][0] - gv[u][r][1], d23 = gv[u][r][2] - gv[u][r][3];
+                const int sa = (d01 & ~mR) + ((ta[r] - d01) & mR) - (d23 & mM);
+                const int sb = ((tb[r] - d23) & mL) + (tb[r] & mM) + (d23 & mR);
+                // (explicit fused operations: the two passes are two copies of this code, and
+                // the hot list must hold the very bits pass 0 stored -- the first-peak kernel
+                // compares a hot value with the stored surface around it)
+                float v = static_cast<float>(sv[u][r]);
+                v = __builtin_fmaf(-mua, static_cast<float>(sb), v);
+                v = __builtin_fmaf(-mub, static_cast<float>(sa), v);
+                v = __builtin_fmaf(muab, __fmul_rn(static_cast<float>(ny[r]), fnx), v);
+                const bool ok = rowok[r] && (q < NQ - 1 || kx < Sx);
+                if (pass == 0) {
+                  __builtin_nontemporal_store(v, &surf[srow[r] + 16 * q]);
+                  tmax = fmaxf(tmax, ok ? v : 0.f);
+                }
+                outv[r] = ok ? v : -INFINITY;
+              }
+              // (an odd tile count: the repeated tile of the last trip is listed once)
+              if (pass == 1 && q0 + u < NQ) hot_insert(q, outv[0], outv[1], outv[2], outv[3], thr);
+            }
+          }
+        }
+      };
       if (RAW) {
         // exact integer products; the Padfield assembly happens afterwards
         int* raw = a.raw_out + (a.list ? item : b) * a.raw_stride;
@@ -4104,6 +4277,9 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
           ob1[r] = (ya1 - dy) * ipb;
           ny[r] = ya1 - ya0;
         }
+        if constexpr (NCA > 10) {
+          wide_general(0, 0.f);
+        } else {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int kx = 16 * q + n;
@@ -4126,6 +4302,7 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
             tmax = fmaxf(tmax, ok ? v : 0.f);
             acc[q][r] = __float_as_int(ok ? v : -INFINITY);
           }
+        }
         }
       }
       TICK(3)
@@ -4221,47 +4398,15 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
             atomicOr(&lz[1], 1 << p);
           }
         }
-        float* hv = a.hot_val + (long long)b * a.hot_cap;
-        int* hi = a.hot_idx + (long long)b * a.hot_cap;
         // tmax is the wave-wide tile maximum: nothing to do unless it clears
         // the running threshold (the common case away from the peak).
         if (tmax > thr_t) {
-        int hq_lo = NQ, hq_hi = -1;   // column tiles with elements that may be hot
+        if constexpr (NCA > 10) wide_general(1, thr_t);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+        for (int q = 0; q < (NCA > 10 ? 0 : NQ); ++q) {
           const float v0 = __int_as_float(acc[q][0]), v1 = __int_as_float(acc[q][1]);
           const float v2 = __int_as_float(acc[q][2]), v3 = __int_as_float(acc[q][3]);
-          const float vm = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-          if (__any(vm > thr_t)) {  // wave-uniform, rarely taken
-            hq_lo = min(hq_lo, q);
-            hq_hi = q;
-            // one list reservation per column tile (ballots + one LDS atomic): an
-            // atomic per lane and row was four dependent LDS round trips here
-            unsigned long long bal[4];
-            int total = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              bal[r] = __ballot(__int_as_float(acc[q][r]) > thr_t);
-              total += __builtin_popcountll(bal[r]);
-            }
-            int base = 0;
-            if (lane == 0) base = atomicAdd(hot_lds, total);
-            base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float v = __int_as_float(acc[q][r]);
-              if (v > thr_t) {
-                const int slot = base + static_cast<int>(__builtin_amdgcn_mbcnt_hi(
-                                            static_cast<unsigned>(bal[r] >> 32),
-                                            __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(bal[r]), 0u)));
-                if (slot < a.hot_cap) {
-                  hv[slot] = v;
-                  hi[slot] = (16 * p + 4 * g + r) * Sx + 16 * q + n;
-                }
-              }
-              base += __builtin_popcountll(bal[r]);
-            }
-          }
+          hot_insert(q, v0, v1, v2, v3, thr_t);
         }
         if (LAZY && lane == 0 && hq_hi >= 0) {
           atomicMin(&lz_cq[0], hq_lo);
@@ -4346,7 +4491,9 @@ struct Variant {
   int nca, nce;
 };
 // Instantiated chunk geometries: NCA >= ceil(Px / 16), NCE >= floor((Qx + 14) / 16) + 1.
-constexpr Variant kVariants[] = {{3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {10, 11}};
+// ({15, 11}, {20, 11}: search-window geometry, pre patches up to 240 / 320 wide)
+constexpr Variant kVariants[] = {{3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {10, 11},
+                                 {15, 11}, {20, 11}};
 
 bool exact_enabled() {
   const char* e = sfm::option("SFM_MFMA_EXACT");
@@ -4522,6 +4669,10 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
 template <int NCA, int NCE>
 int launch_variant(const MfmaArgs& a, int mode, int grid, size_t lds,
                    hipStream_t st) {
+  if constexpr (NCA > 10) {   // search-window variants: un-masked general mode only
+    if (mode != kModeGeneral) return sfm::fail(SFM_ERR_INVALID, "wide MFMA variant: general mode only");
+    return launch_one<NCA, NCE, kModeGeneral>(a, grid, lds, st);
+  } else
   switch (mode) {
     case kModeSame: return launch_one<NCA, NCE, kModeSame>(a, grid, lds, st);
     case kModeSameExact: return launch_one<NCA, NCE, kModeSameExact>(a, grid, lds, st);
@@ -4543,6 +4694,7 @@ int launch_variant(const MfmaArgs& a, int mode, int grid, size_t lds,
 int launch_mode(int vi, const MfmaArgs& a, int mode, int grid, size_t lds,
                 hipStream_t st) {
   switch (vi) {
+#ifndef SFM_DEV_ONLY_WIDE   // (development: compile the search-window variants alone)
     case 0: return launch_variant<3, 4>(a, mode, grid, lds, st);
     case 1: return launch_variant<4, 5>(a, mode, grid, lds, st);
     case 2: return launch_variant<5, 6>(a, mode, grid, lds, st);
@@ -4550,6 +4702,9 @@ int launch_mode(int vi, const MfmaArgs& a, int mode, int grid, size_t lds,
     case 4: return launch_variant<7, 8>(a, mode, grid, lds, st);
     case 5: return launch_variant<8, 9>(a, mode, grid, lds, st);
     case 6: return launch_variant<10, 11>(a, mode, grid, lds, st);
+#endif
+    case 7: return launch_variant<15, 11>(a, mode, grid, lds, st);
+    case 8: return launch_variant<20, 11>(a, mode, grid, lds, st);
   }
   return sfm::fail(SFM_ERR_INVALID, "no MFMA variant");
 }
@@ -4686,9 +4841,19 @@ bool mfma_i8_eligible(const SfmXcorrDesc* d) {
   if (d->patch[0] != 1 || d->post_patch[0] != 1) return false;
   const int py = d->patch[1], px = d->patch[2];
   const int qy = d->post_patch[1], qx = d->post_patch[2];
-  if (pick_variant(px, qx) < 0) return false;
+  const int vi = pick_variant(px, qx);
+  if (vi < 0) return false;
   if (py < 1 || qy < 1 || qy > py || qx > px) return false;
-  if ((long long)py * px > 32768) return false;        // prep kernel LDS copy
+  if (kVariants[vi].nca <= 10) {
+    if ((long long)py * px > 32768) return false;      // prep kernel LDS copy
+  } else {
+    // search-window variants: un-masked, the prep kernel's LDS copy of a patch and the
+    // correlation kernel's two patches + scratch within one CU's LDS
+    if (d->pre_mask || d->post_mask) return false;
+    if ((long long)py * px > 140 * 1024) return false;
+    const Layout l = make_layout(d, kVariants[vi]);
+    if ((size_t)l.a_bytes + l.b_bytes + 8 * 1024 > 160 * 1024) return false;
+  }
   if ((long long)qy * qx * 16384 > 0x7fffffffLL) return false;  // int32 sums
   if ((py + qy - 1 + 15) / 16 > kWaves * kMaxTilesPerWave) return false;
   // (the staging loads are 16 bytes wide and clamped into the image)
@@ -4848,6 +5013,13 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
                          dim3(64 * kPrepWavesAlone), prep_lds, st, a);
   } else {
     const size_t prep_lds = (size_t)a.P[0] * a.P[1];
+    static size_t prep_gen_attr = 0;
+    if (prep_lds > 48 * 1024 && prep_lds > prep_gen_attr) {
+      SFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_prep_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(prep_lds)));
+      prep_gen_attr = prep_lds;
+    }
     hipLaunchKernelGGL(mfma_prep_kernel, dim3(d->batch, 2), dim3(kThreads),
                        prep_lds, st, a);
   }

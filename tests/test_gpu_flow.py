@@ -295,6 +295,83 @@ def test_flow_field_empty_selection_and_single_patch(gpu):
   np.testing.assert_array_equal(f[:2, 0, 0], [0, 0])
 
 
+# -- search-window geometry on the matrix cores (pre patch 161 .. 320 wide against a post
+# patch of up to 160: processor/flow.py:577,792-803 calls flow_field(patch_size = 160 +
+# 2 search_radius, post_patch_size = 160)) -------------------------------------------------
+@pytest.mark.parametrize('py,px,qy,qx', [
+    (240, 240, 160, 160), (320, 320, 160, 160), (192, 176, 160, 144), (320, 200, 120, 160),
+    (200, 320, 160, 96), (161, 161, 160, 160),
+])
+def test_search_window_mfma_matches_direct_kernel(gpu, py, px, qy, qx):
+  """The wide variants of the int8 kernel (one wave per SIMD, accumulators in the upper
+  register file) against the float direct kernel: identical peaks, statistics within the
+  float kernel's tolerance; starts that overshoot the image on every side (clamped like
+  lax.dynamic_slice, flow_field.py:320-325), per-patch and fixed means."""
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(py * 1000 + px)
+  from scipy import ndimage
+  h, w = 520, 560
+  base = ndimage.gaussian_filter(rng.standard_normal((h + 8, w + 8)), 1.5)
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  pre = base[4:4 + h, 4:4 + w].copy()
+  post = base[6:6 + h, 1:1 + w].copy()
+  post[::7, ::5] += 3
+  b = 21
+  starts = np.stack([rng.integers(-20, h - py + 30, b),
+                     rng.integers(-20, w - px + 30, b)], axis=1)
+  post_starts = starts + np.array([(py - qy) // 2, (px - qx) // 2]) + rng.integers(-9, 10, (b, 2))
+  kw = dict(min_distance=2, threshold_rel=0.5, peak_radius=5,
+            post_patch_size=(qy, qx), post_starts=post_starts)
+  for mean in (None, 117.5):
+    ref = flow_field.batched_xcorr_peaks(pre, post, None, None, (py, px), starts,
+                                         mean, method=1, **kw)
+    got = flow_field.batched_xcorr_peaks(pre, post, None, None, (py, px), starts,
+                                         mean, method=2, **kw)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(got[:, :2], ref[:, :2])
+    ok = np.isfinite(ref[:, 2])
+    # (the float kernel sums up to 102 400 products per output here, 4 x the 160^2 case the
+    # VS_F32_KERNEL criterion was sized on: window minimum to 8e-5 x |peak|.  The oracle
+    # comparison of the same kernel is test_search_window_flow_vs_oracle.)
+    check_sharpness(got[ok, 2], ref[ok, 2], inv_atol=8e-5, inv_from=0.0)
+    np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('patch', [240, 320])
+def test_search_window_flow_vs_oracle(gpu, patch):
+  """flow_field(patch_size = 160 + 2 search_radius, post_patch_size = 160) -- the call of
+  EstimateMissingFlow -- on whole reference batches (5 of 64 + a ragged one) against the
+  oracle, matrix-core form (the automatic choice) and FFT form; and two batches with
+  clamped starts through batched_xcorr_peaks."""
+  from sofima_amd import flow_field
+  pre, post = _em_pair(29, 900, 980, shift=(7, -11), warp=2.0)
+  kw = dict(patch_size=patch, step=40, post_patch_size=160, batch_size=64)
+  want = flow_oracle.flow_field(pre, post, workers=8, **kw)
+  assert np.isfinite(want[:2]).mean() > 0.9 and want.shape[1] * want.shape[2] > 2 * 64
+  for method in (0, 2, 3):
+    got = flow_field.JAXMaskedXCorrWithStatsCalculator(method=method).flow_field(pre, post, **kw)
+    check_flow(got, want)
+  # clamped starts, two whole batches (batch coupling as in the reference)
+  rng = np.random.default_rng(patch)
+  b = 128
+  starts = np.stack([rng.integers(-40, 900 - patch + 40, b),
+                     rng.integers(-40, 980 - patch + 40, b)], axis=1)
+  post_starts = starts + (patch - 160) // 2
+  for lo in (0, 64):
+    sl = slice(lo, lo + 64)
+    w_pk = flow_oracle.batched_xcorr_peaks(pre, post, None, None, (patch, patch), starts[sl], None,
+                                           2, 0.5, 5, (160, 160), post_starts[sl], workers=8)
+    g_pk = flow_field.batched_xcorr_peaks(pre, post, None, None, (patch, patch), starts[sl], None,
+                                          min_distance=2, threshold_rel=0.5, peak_radius=5,
+                                          post_patch_size=(160, 160), post_starts=post_starts[sl],
+                                          method=2)
+    np.testing.assert_array_equal(np.isnan(g_pk), np.isnan(w_pk))
+    np.testing.assert_array_equal(g_pk[:, :2], w_pk[:, :2])
+    np.testing.assert_allclose(g_pk[:, 3], w_pk[:, 3], rtol=1e-4, atol=1e-6)
+    ok = np.isfinite(w_pk[:, 2])
+    check_sharpness(g_pk[ok, 2], w_pk[ok, 2])
+
+
 @pytest.mark.parametrize('patch,post_patch', [((80, 80), (160, 160)), ((81, 64), (160, 150)),
                                               ((160, 160), (80, 96))])
 def test_single_cell_grid_with_unequal_patch_sizes_vs_oracle(gpu, patch, post_patch):
