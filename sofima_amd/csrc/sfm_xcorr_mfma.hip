@@ -404,6 +404,170 @@ __device__ __forceinline__ v4i load_16_bytes(const unsigned char* img, long long
 }
 
 // ---------------------------------------------------------------------------
+// prep of the search-window variants (pre patches up to 320 x 320): the same outputs as
+// mfma_prep_kernel -- clamped origin, integer centre, mean - centre, the integral image
+// I[y + 1][x + 1] = sum_{y' <= y, x' <= x} (pixel - centre) of one patch side -- for patches
+// where that kernel's thread-per-column sweep (a byte load per pixel, Py dependent LDS round
+// trips per column, a second pass over the table in global memory) took a third of the
+// correlation launch's time.  One workgroup of eight waves per (patch, side):
+//   1. the patch goes to LDS with 16-byte loads (minimum, maximum and sum on the way);
+//   2. wave w owns the rows [w R, (w + 1) R); lane l the columns 8 l .. 8 l + 7 (one aligned
+//      8-byte LDS read per row).  A first sweep leaves the column sums of every stripe, so
+//      that each wave knows the column sums ABOVE its stripe;
+//   3. a second sweep carries the running column sums down the stripe; per row the lane's
+//      eight prefix sums plus a wave scan of the lane totals are the integral-image row,
+//      stored as two 16-byte pieces per lane (contiguous across the wave).
+// ---------------------------------------------------------------------------
+constexpr int kWidePrepWaves = 8;
+__device__ __forceinline__ int wave_scan_incl(int v);   // (defined with the same-size prep pass)
+typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ void __launch_bounds__(64 * kWidePrepWaves) mfma_prep_wide_kernel(MfmaArgs a) {
+  if (a.work_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    *a.work_counter = 0;  // the correlation kernel's patch queue
+  if (a.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    a.clk[2] = a.clk[3] = a.clk[4] = 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int red[3][kWidePrepWaves];
+  constexpr int kColsPerLane = 8, kMaxCols = 64 * kColsPerLane;
+  __shared__ int stripe[kWidePrepWaves][kMaxCols];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int py = s == 0 ? a.P[0] : a.Q[0];
+  const int px = s == 0 ? a.P[1] : a.Q[1];
+  const int H = a.ishape[s][0], W = a.ishape[s][1];
+  // lax.dynamic_slice start clamping (flow_field.py:320-325).
+  const int y0 = min(max(a.starts[s][b * 2 + 0], 0), H - py);
+  const int x0 = min(max(a.starts[s][b * 2 + 1], 0), W - px);
+  const unsigned char* img = a.img[s];
+  const long long img_bytes = (long long)H * W;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_chunks = (px + 15) >> 4, pitch = 16 * n_chunks + 16;   // (+16: rows on different banks)
+  int mn = 255, mx = 0, sum = 0;
+  for (int item = threadIdx.x; item < py * n_chunks; item += 64 * kWidePrepWaves) {
+    const int y = item / n_chunks, ch = item - y * n_chunks;
+    v4i w = load_16_bytes(img, (long long)(y0 + y) * W + x0 + ch * 16, img_bytes);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned v = static_cast<unsigned>(w[k]);
+      const int keep = min(px - (ch * 16 + 4 * k), 4);   // bytes of this dword inside the patch
+      if (keep < 4) v = keep <= 0 ? 0u : (v & (0xffffffffu >> (8 * (4 - keep))));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pv = static_cast<int>((v >> (8 * j)) & 255u);
+        if (j < keep) {
+          mn = min(mn, pv);
+          mx = max(mx, pv);
+        }
+        sum += pv;   // (bytes outside the patch are zero)
+      }
+      w[k] = static_cast<int>(v);
+    }
+    *reinterpret_cast<v4i*>(smem + y * pitch + ch * 16) = w;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    mn = min(mn, __shfl_xor(mn, d, 64));
+    mx = max(mx, __shfl_xor(mx, d, 64));
+    sum += __shfl_xor(sum, d, 64);
+  }
+  if (lane == 0) {
+    red[0][wave] = mn;
+    red[1][wave] = mx;
+    red[2][wave] = sum;
+  }
+  __syncthreads();
+  mn = red[0][0];
+  mx = red[1][0];
+  sum = red[2][0];
+#pragma unroll
+  for (int w = 1; w < kWidePrepWaves; ++w) {
+    mn = min(mn, red[0][w]);
+    mx = max(mx, red[1][w]);
+    sum += red[2][w];
+  }
+  const float n_f = static_cast<float>(py * px);
+  const float mean = a.use_mean ? a.mean : static_cast<float>(sum) / n_f;
+  // Centre: nearest integer to the mean that keeps every pixel in int8.
+  int c = static_cast<int>(rintf(fminf(fmaxf(mean, 0.f), 255.f)));
+  c = min(max(c, mx - 127), mn + 128);
+  if (threadIdx.x == 0) {
+    PatchParams* p = &a.pp[b];
+    p->y0[s] = y0;
+    p->x0[s] = x0;
+    p->c[s] = c;
+    p->mu[s] = a.use_mean
+                   ? a.mean - static_cast<float>(c)
+                   : static_cast<float>(
+                         (static_cast<double>(sum) - static_cast<double>(c) * py * px) /
+                         (static_cast<double>(py) * px));
+  }
+  int* I = a.integ[s] + b * a.integ_stride[s];
+  const int ip = px + 1;
+  const int R = (py + kWidePrepWaves - 1) / kWidePrepWaves;
+  const int r0 = wave * R, r1 = min(py, r0 + R);
+  const int xl = kColsPerLane * lane;
+  const bool act = xl < px;
+  // (columns past the patch hold zero bytes: they must not pick up -c)
+  int cm[kColsPerLane];
+#pragma unroll
+  for (int k = 0; k < kColsPerLane; ++k) cm[k] = xl + k < px ? c : 0;
+  auto row_pixels = [&](int y, int* pv) {
+    const uint2 d = *reinterpret_cast<const uint2*>(smem + y * pitch + (act ? xl : 0));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pv[k] = static_cast<int>((d.x >> (8 * k)) & 255u) - cm[k];
+      pv[4 + k] = static_cast<int>((d.y >> (8 * k)) & 255u) - cm[4 + k];
+    }
+  };
+  int col[kColsPerLane];
+#pragma unroll
+  for (int k = 0; k < kColsPerLane; ++k) col[k] = 0;
+  for (int y = r0; y < r1; ++y) {
+    int pv[kColsPerLane];
+    row_pixels(y, pv);
+#pragma unroll
+    for (int k = 0; k < kColsPerLane; ++k) col[k] += pv[k];
+  }
+#pragma unroll
+  for (int k = 0; k < kColsPerLane; ++k) stripe[wave][xl + k] = act ? col[k] : 0;
+  // zero first row / column of the table
+  for (int x = threadIdx.x; x <= px; x += 64 * kWidePrepWaves) I[x] = 0;
+  for (int y = threadIdx.x; y <= py; y += 64 * kWidePrepWaves) I[y * ip] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kColsPerLane; ++k) col[k] = 0;
+  for (int w = 0; w < wave; ++w)
+#pragma unroll
+    for (int k = 0; k < kColsPerLane; ++k) col[k] += stripe[w][xl + k];
+  for (int y = r0; y < r1; ++y) {
+    int pv[kColsPerLane];
+    row_pixels(y, pv);
+    int run = 0, pre[kColsPerLane];
+#pragma unroll
+    for (int k = 0; k < kColsPerLane; ++k) {
+      col[k] += pv[k];
+      run += act ? col[k] : 0;
+      pre[k] = run;
+    }
+    const int before = wave_scan_incl(run) - run;   // columns left of this lane
+    if (act) {
+      int* dst = I + (y + 1) * ip + xl + 1;
+      const v4i_a4 lo = {pre[0] + before, pre[1] + before, pre[2] + before, pre[3] + before};
+      const v4i_a4 hi = {pre[4] + before, pre[5] + before, pre[6] + before, pre[7] + before};
+      if (xl + 8 <= px) {
+        *reinterpret_cast<v4i_a4*>(dst) = lo;
+        *reinterpret_cast<v4i_a4*>(dst + 4) = hi;
+      } else {
+#pragma unroll
+        for (int k = 0; k < kColsPerLane; ++k)
+          if (xl + k < px) dst[k] = (k < 4 ? lo[k] : hi[k - 4]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // prep for P == Q: centres, means, combined correction table G and the 1-D
 // row / column arrays.  One 256-thread block per patch; LDS holds the two raw
 // uint8 patches (2 Py Px bytes), so several blocks share a CU.
@@ -5020,6 +5184,19 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
                                         static_cast<int>(prep_lds)));
       prep_gen_attr = prep_lds;
     }
+    if (kVariants[vi].nca > 10 && a.P[1] <= 512 && !a.xcd_heads) {
+      // search-window variants: the wide prep pass (see mfma_prep_wide_kernel)
+      const size_t wide_lds = (size_t)a.P[0] * (16 * ((a.P[1] + 15) / 16) + 16);
+      static size_t wide_attr = 0;
+      if (wide_lds > wide_attr) {
+        SFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_prep_wide_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          static_cast<int>(wide_lds)));
+        wide_attr = wide_lds;
+      }
+      hipLaunchKernelGGL(mfma_prep_wide_kernel, dim3(d->batch, 2), dim3(64 * kWidePrepWaves),
+                         wide_lds, st, a);
+    } else
     hipLaunchKernelGGL(mfma_prep_kernel, dim3(d->batch, 2), dim3(kThreads),
                        prep_lds, st, a);
   }
