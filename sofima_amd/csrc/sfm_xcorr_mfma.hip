@@ -76,6 +76,9 @@
 // Ping-pong prefetch of the A fragments across row groups: measured 6 % SLOWER
 // on the <10,11> variant (200 bytes of spills at the 256-VGPR limit), neutral on
 // the smaller ones; kept as an experiment switch.
+#ifndef SFM_WIDE_TRIP
+#define SFM_WIDE_TRIP 2
+#endif
 #ifndef SFM_AF_PREFETCH
 #define SFM_AF_PREFETCH 0
 #endif
@@ -3513,6 +3516,41 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
       const int dy0 = 16 * p - (Qy - 1);
       const int ylo = max(0, -dy0 - 15);
       const int yhi = min(Qy, Py - dy0);
+      if constexpr (NCA > 10 && MODE == kModeGeneral) {
+        // Search-window variants: the rows of the two integral images this tile's epilogue
+        // will gather from (written by the prep launch: in HBM by now) are pulled towards
+        // this XCD's L2 while the matrix loop runs -- LDS-direct loads into a junk area,
+        // no register result, nothing waits for them.  For the 16 shifts dy of the tile
+        // the epilogue reads the rows ya0 = max(0, dy) and ya1 = min(Py, Qy + dy) of IA and
+        // the rows ya0 - dy, ya1 - dy of IB: four runs of at most 16 consecutive rows.
+        const int dlo = dy0, dhi = min(dy0 + 15, Sy - 1 - (Qy - 1));
+        const unsigned junk_off = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+            (__attribute__((address_space(3))) float*)touch_junk));
+        auto touch_rows = [&](const int* tab, int ipitch, int row_lo, int row_hi) {
+          const char* base = reinterpret_cast<const char*>(tab + (long long)row_lo * ipitch);
+          const int n_lines = ((row_hi - row_lo + 1) * ipitch * 4 + 63) >> 6;
+          for (int k = lane; k < n_lines; k += 64) {
+            const char* src = base + (size_t)k * 64;
+            unsigned saved_m0;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(saved_m0)
+                : "v"(src), "s"(junk_off)
+                : "memory");
+          }
+        };
+        const int* IAt = a.integ[0] + b * a.integ_stride[0];
+        const int* IBt = a.integ[1] + b * a.integ_stride[1];
+        const int a0lo = max(0, dlo), a0hi = max(0, dhi);
+        const int a1lo = min(Py, Qy + dlo), a1hi = min(Py, Qy + dhi);
+        if (a0hi > 0) touch_rows(IAt, Px + 1, a0lo, a0hi);        // (row 0 is all zero: one line)
+        touch_rows(IAt, Px + 1, a1lo, a1hi);
+        const int b0lo = min(a0lo - dlo, a0hi - dhi), b0hi = max(a0lo - dlo, a0hi - dhi);
+        const int b1lo = min(a1lo - dlo, a1hi - dhi), b1hi = max(a1lo - dlo, a1hi - dhi);
+        if (b0hi > 0) touch_rows(IBt, Qx + 1, b0lo, b0hi);
+        touch_rows(IBt, Qx + 1, b1lo, b1hi);
+      }
       v4i acc[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) acc[q] = v4i{0, 0, 0, 0};
@@ -3546,6 +3584,11 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
           for (int ca = 0; ca < NCA; ++ca)
             af_next[ca] = *reinterpret_cast<const v4i*>(ap_next + 16 * ca);
         }
+        // (one read of the caller's array per chunk: with NCA x NCE uses per call site the
+        // double-buffered fragment arrays of the wide variants were left in scratch memory)
+        v4i afl[NCA];
+#pragma unroll
+        for (int ca = 0; ca < NCA; ++ca) afl[ca] = af[ca];
 #pragma unroll
         for (int c = 0; c < NCE; ++c) {
           v4i bf;
@@ -3556,7 +3599,7 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
 #pragma unroll
           for (int ca = 0; ca < NCA; ++ca) {
             const int q = ca - c + cq0;
-            acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ca], bf, acc[q], 0,
+            acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afl[ca], bf, acc[q], 0,
                                                            0, 0);
           }
         }
@@ -4142,65 +4185,137 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
             }
           };
           static_assert(NQ <= 30, "extend the accumulator switch");
-          constexpr int kQW = 2;   // column tiles per trip (32 gathers in flight)
-#pragma unroll 1
-          for (int q0 = 0; q0 < NQ; q0 += kQW) {
-            int sv[kQW][4], gv[kQW][4][4], mLs[kQW], mRs[kQW], xw[kQW];
+          // One trip: the column tiles q0 .. q0 + kT - 1 of the run that ends at hi.  REG:
+          // the regime every lane of both tiles is in (0 L, 1 M, 2 R: scalar table bases,
+          // 32-bit byte offsets, no selects) or 3 (the one or two tiles a regime boundary
+          // runs through: per-lane masks).
+          constexpr int kT = SFM_WIDE_TRIP;   // column tiles per trip (16 kT gathers in flight)
+          // (REG 0 .. 2: consecutive tiles are 16 columns = 64 bytes apart in every table row
+          // and in the surface, so a trip forms its addresses once, for its first tile, and
+          // reaches the others through the instructions' immediate offsets)
+          auto trip = [&](auto reg_const, auto t_const, const int q0) {
+            constexpr int REG = decltype(reg_const)::value;
+            constexpr int T = decltype(t_const)::value;
+            int sv[T][4], gv[T][4][4], mLs[T], mRs[T], xw[T];
 #pragma unroll
-            for (int u = 0; u < kQW; ++u) {
-              const int q = min(q0 + u, NQ - 1);   // (an odd tile count: the last trip repeats a tile)
-              acc_get(q, sv[u]);
-              const int kx = 16 * q + n;
-              const int dx = min(kx, Sx - 1) - (Qx - 1);
-              const int xa0 = max(0, dx), xa1 = min(Px, Qx + dx);
-              const int mL = -static_cast<int>(dx <= 0);
-              const int mR = ~mL & -static_cast<int>(dx >= Px - Qx);
-              const int mM = ~(mL | mR);
-              const int xb0 = xa0 - dx, xb1 = xa1 - dx;
-              const int c01 = (xa0 & mR) | (xa1 & ~mR);
-              const int c23 = (xb0 & mL) | (xa0 & mM) | (xb1 & mR);
-              const long long d23 = ib_delta & ~static_cast<long long>(mM);
-              mLs[u] = mL;
-              mRs[u] = mR;
-              xw[u] = xa1 - xa0;
+            for (int u = 0; u < T; ++u) acc_get(q0 + u, sv[u]);
+            if constexpr (REG == 3) {
+#pragma unroll
+              for (int u = 0; u < T; ++u) {
+                const int q = q0 + u;
+                const int kx = 16 * q + n;
+                const int dx = min(kx, Sx - 1) - (Qx - 1);
+                const int xa0 = max(0, dx), xa1 = min(Px, Qx + dx);
+                xw[u] = xa1 - xa0;
+                const int mL = -static_cast<int>(dx <= 0);
+                const int mR = ~mL & -static_cast<int>(dx >= Px - Qx);
+                const int mM = ~(mL | mR);
+                const int xb0 = xa0 - dx, xb1 = xa1 - dx;
+                const int c01 = (xa0 & mR) | (xa1 & ~mR);
+                const int c23 = (xb0 & mL) | (xa0 & mM) | (xb1 & mR);
+                const long long d23 = ib_delta & ~static_cast<long long>(mM);
+                mLs[u] = mL;
+                mRs[u] = mR;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  gv[u][r][0] = IA[oa1[r] + c01];
+                  gv[u][r][1] = IA[oa0[r] + c01];
+                  gv[u][r][2] = IA[d23 + (((oa1[r] & mM) | (ob1[r] & ~mM)) + c23)];
+                  gv[u][r][3] = IA[d23 + (((oa0[r] & mM) | (ob0[r] & ~mM)) + c23)];
+                }
+              }
+            } else {
+              const int dx0 = 16 * q0 + n - (Qx - 1);     // (no clamped column in these runs)
+              // L: IA[.][xa1 = Qx + dx], IB[.][xb0 = -dx]   M: IA[.][Qx + dx], IA[.][xa0 = dx]
+              // R: IA[.][xa0 = dx], IB[.][xb1 = Px - dx]   -- step per tile: +16, except the
+              // two IB columns, which step -16
+              const int c01 = REG == 2 ? dx0 : Qx + dx0;
+              const int c23 = REG == 0 ? -dx0 : (REG == 1 ? dx0 : Px - dx0);
+              constexpr int kStep23 = REG == 1 ? 16 : -16;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                gv[u][r][0] = IA[oa1[r] + c01];
-                gv[u][r][1] = IA[oa0[r] + c01];
-                gv[u][r][2] = IA[d23 + (((oa1[r] & mM) | (ob1[r] & ~mM)) + c23)];
-                gv[u][r][3] = IA[d23 + (((oa0[r] & mM) | (ob0[r] & ~mM)) + c23)];
+                const int* p0 = IA + (oa1[r] + c01);
+                const int* p1 = IA + (oa0[r] + c01);
+                const int* p2 = REG == 1 ? IA + (oa1[r] + c23) : IB + (ob1[r] + c23);
+                const int* p3 = REG == 1 ? IA + (oa0[r] + c23) : IB + (ob0[r] + c23);
+#pragma unroll
+                for (int u = 0; u < T; ++u) {
+                  gv[u][r][0] = p0[16 * u];
+                  gv[u][r][1] = p1[16 * u];
+                  gv[u][r][2] = p2[kStep23 * u];
+                  gv[u][r][3] = p3[kStep23 * u];
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < T; ++u) {
+                const int dx = dx0 + 16 * u;
+                xw[u] = REG == 0 ? Qx + dx : (REG == 1 ? Qx : Px - dx);
               }
             }
+            float* srow_p[4];
 #pragma unroll
-            for (int u = 0; u < kQW; ++u) {
-              const int q = min(q0 + u, NQ - 1);
+            for (int r = 0; r < 4; ++r) srow_p[r] = surf + (srow[r] + 16 * q0);
+#pragma unroll
+            for (int u = 0; u < T; ++u) {
+              const int q = q0 + u;
               const int kx = 16 * q + n;
-              const int mL = mLs[u], mR = mRs[u], mM = ~(mL | mR);
               const float fnx = static_cast<float>(xw[u]);
               float outv[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int d01 = gv[u][r][0] - gv[u][r][1], d23 = gv[u][r][2] - gv[u][r][3];
-                const int sa = (d01 & ~mR) + ((ta[r] - d01) & mR) - (d23 & mM);
-                const int sb = ((tb[r] - d23) & mL) + (tb[r] & mM) + (d23 & mR);
-                // (explicit fused operations: the two passes are two copies of this code, and
-                // the hot list must hold the very bits pass 0 stored -- the first-peak kernel
-                // compares a hot value with the stored surface around it)
+                int sa, sb;
+                if constexpr (REG == 3) {
+                  const int mL = mLs[u], mR = mRs[u], mM = ~(mL | mR);
+                  sa = (d01 & ~mR) + ((ta[r] - d01) & mR) - (d23 & mM);
+                  sb = ((tb[r] - d23) & mL) + (tb[r] & mM) + (d23 & mR);
+                } else {
+                  sa = REG == 0 ? d01 : (REG == 1 ? d01 - d23 : ta[r] - d01);
+                  sb = REG == 0 ? tb[r] - d23 : (REG == 1 ? tb[r] : d23);
+                }
+                // (explicit fused operations: the passes and regimes are copies of this code,
+                // and the hot list must hold the very bits pass 0 stored -- the first-peak
+                // kernel compares a hot value with the stored surface around it)
                 float v = static_cast<float>(sv[u][r]);
                 v = __builtin_fmaf(-mua, static_cast<float>(sb), v);
                 v = __builtin_fmaf(-mub, static_cast<float>(sa), v);
                 v = __builtin_fmaf(muab, __fmul_rn(static_cast<float>(ny[r]), fnx), v);
-                const bool ok = rowok[r] && (q < NQ - 1 || kx < Sx);
+                // (only the last column tile has columns past the surface)
+                const bool ok = REG == 3 ? rowok[r] && (q < NQ - 1 || kx < Sx) : rowok[r];
                 if (pass == 0) {
-                  __builtin_nontemporal_store(v, &surf[srow[r] + 16 * q]);
+                  __builtin_nontemporal_store(v, srow_p[r] + 16 * u);
                   tmax = fmaxf(tmax, ok ? v : 0.f);
                 }
                 outv[r] = ok ? v : -INFINITY;
               }
-              // (an odd tile count: the repeated tile of the last trip is listed once)
-              if (pass == 1 && q0 + u < NQ) hot_insert(q, outv[0], outv[1], outv[2], outv[3], thr);
+              if (pass == 1) hot_insert(q, outv[0], outv[1], outv[2], outv[3], thr);
             }
-          }
+          };
+          auto run = [&](auto reg_const, int lo, int hi) {   // tiles [lo, hi)
+            int q0 = lo;
+#pragma unroll 1
+            for (; q0 + kT <= hi; q0 += kT) trip(reg_const, std::integral_constant<int, kT>{}, q0);
+#pragma unroll 1
+            for (; q0 < hi; ++q0) trip(reg_const, std::integral_constant<int, 1>{}, q0);
+          };
+          // Column tiles by regime (dx = 16 q + n - (Qx - 1), n = 0 .. 15; the clamped
+          // columns past the surface count as R):
+          //   L  every lane dx <= 0:            q < qL
+          //   M  every lane 0 < dx < Px - Qx:   qM0 <= q < qM1
+          //   R  every lane dx >= Px - Qx:      q >= qR
+          const int qL = Qx >= 16 ? min((Qx - 16) / 16 + 1, NQ) : 0;
+          const int qM0 = min((Qx + 15) / 16, NQ);
+          const int qM1 = min(max(Px >= 17 ? (Px - 17) / 16 + 1 : 0, qM0), NQ);
+          // (tiles with columns past the surface -- from column Sx on; several tiles when the
+          // variant is wider than the patch -- take the per-lane code: their shifts are clamped)
+          const int qc = min(Sx / 16, NQ);
+          const int qR = min(max((Px + 14) / 16, qM1), qc);
+          run(std::integral_constant<int, 0>{}, 0, min(qL, qc));
+          run(std::integral_constant<int, 3>{}, min(qL, qc), min(qM0, qc));
+          run(std::integral_constant<int, 1>{}, min(qM0, qc), min(qM1, qc));
+          run(std::integral_constant<int, 3>{}, min(qM1, qc), qR);
+          run(std::integral_constant<int, 2>{}, qR, qc);
+          run(std::integral_constant<int, 3>{}, qc, NQ);
         }
       };
       if (RAW) {
