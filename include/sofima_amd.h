@@ -68,7 +68,6 @@ int sfm_device_count(int* count);
  * default; value NULL removes the explicit setting again.
  * sfm_get_option copies the value in effect (returns 1 and "" when unset).
  *   SFM_MFMA_PRUNE=0      correlation kernel computes every surface tile
- *   SFM_MFMA_PROBE=0      no seed probe in front of the pruning
  *   SFM_MFMA_LAZY=0       flow path stores every computed surface tile (default:
  *                         only the tiles the peak kernels can read)
  *   SFM_MFMA_EARLY=n      lazy path: least number of row groups between two tests that
@@ -77,15 +76,11 @@ int sfm_device_count(int* count);
  *   SFM_MFMA_NARROW=n     lazy path: widest in-flight narrowing of a row loop (outer column
  *                         tiles dropped once proved cold; default: down to the four
  *                         central tiles; 0: never)
- *   SFM_MFMA_TOUCH_ALL=1  lazy path: pull a patch's whole correction table into L2 ahead of
- *                         the epilogues (default: the rows of the requested tiles only)
  *   SFM_MFMA_WIDEN=1      lazy path: the store requests a patch starts with are widened
  *                         by one row tile (fewer recomputed tiles, more finished ones)
  *   SFM_MFMA_LAZYG=0      the prep kernel writes the whole correction table (default, pruned
  *                         flow launches: the finishing tiles build their 16 rows; the prep pass
  *                         then keeps no patch in LDS)
- *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry
- *   SFM_MFMA_QUEUE=0      static instead of dynamic patch queue
  *   SFM_MFMA_XCD=1        one patch queue per XCD (measured: no gain) instead of a flat one
  *   SFM_MFMA_PIPE=1       160-wide flow launches as a cross-patch pipeline: one workgroup of
  *                         eight waves per CU, two patch slots in LDS, the tile queue running
@@ -93,10 +88,21 @@ int sfm_device_count(int* count);
  *                         than two four-wave workgroups: profiles/r06_xcorr_phase_ticks.txt)
  *   SFM_MFMA_PIPE_ADMIT=n pipeline: tiles of a patch handed out before its first tile is done
  *                         (default 2)
+ *   (measurement-only, honoured by a library built with -DSFM_MEASUREMENT_SWITCHES only --
+ *   sfm_get_option("SFM_BUILD_MEASUREMENT_SWITCHES") = "1"; the production build ignores them:)
+ *   SFM_MFMA_PROBE=0      no seed probe in front of the pruning
+ *   SFM_MFMA_TOUCH_ALL=1  lazy path: pull a patch's whole correction table into L2
+ *   SFM_MFMA_EXACT=0      run-time instead of compile-time column geometry
+ *   SFM_MFMA_QUEUE=0      static instead of dynamic patch queue
  *   SFM_MFMA_PRIO=n       wave priority experiment (0..3)
  *   SFM_MFMA_MAX_WG_PER_CU=n   occupancy cap of the correlation kernel
  *   SFM_MASKED_FAST=0     masked patches always take all eight passes
  *   SFM_MASKED_DEADROWS=0 no overlap-rule skips in the masked assembly
+ *   SFM_MASKED_GROUPS=n   masked matrix-core path: reference batches (`group` patches each)
+ *                         processed per round of a call (default 8).  The workspace of a masked
+ *                         call -- sfm_xcorr_workspace_bytes -- is sized for n groups (about 4 GB
+ *                         per 1024 patches of 160^2): a caller with a tight memory budget and a
+ *                         small `group` sets a smaller n BEFORE asking for the size
  *   SFM_PHASE_XCD=0       masked assembly without the XCD-aware tile order
  *   SFM_MESH_PERSISTENT=0 / SFM_MESH_SPECULATE=0 / SFM_MESH_TILED=0 /
  *   SFM_MESH_SMALL=0 / SFM_MESH_FUSE_TARGET=0
@@ -672,6 +678,13 @@ int sfm_comm_allgather(SfmComm* comm, const float* send, float* recv, size_t cou
 /* In-place all-reduce of a few scalars (chunk statistics). */
 int sfm_comm_allreduce_scalars(SfmComm* comm, float* inout, size_t count, int op,
                                void* stream);
+
+/* Test hook (no reference counterpart; tests/test_gpu_fft_own.py): batched 1-D complex FFT of
+ * `n_pencils` strided pencils through the FFT form's pencil kernel -- pencil p at in + p,
+ * its n_in samples at stride n_pencils (float2 each), zero-extended to length n; out
+ * [n, n_pencils].  n: any length the hand-written transforms take (radices 2, 3, 5). */
+int sfm_debug_fft1d(const void* in, void* out, int n, int n_in, int n_pencils,
+                    int inverse, void* stream);
 
 #ifdef __cplusplus
 }

@@ -394,6 +394,8 @@ SIGNATURES.update({
     'sfm_comm_unique_id': (C.c_int, [C.c_void_p]),
     'sfm_comm_init': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     'sfm_comm_destroy': (C.c_int, [C.c_void_p]),
+    'sfm_debug_fft1d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p]),
     'sfm_comm_halo_exchange': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.c_void_p]),

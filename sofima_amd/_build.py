@@ -28,8 +28,10 @@ SOURCES = {
     'sfm_comm.hip': [],
     'sfm_warp.hip': ['-ffp-contract=off'],
 }
+# SFM_BUILD_FLAGS: extra flags for every unit (-DSFM_MEASUREMENT_SWITCHES: the library
+# honours the measurement-only switches, see csrc/sfm_common.h)
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-          '-Wno-unused-result']
+          '-Wno-unused-result'] + os.environ.get('SFM_BUILD_FLAGS', '').split()
 
 
 def _hipcc() -> str:

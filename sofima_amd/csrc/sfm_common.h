@@ -32,6 +32,19 @@ int fail(int code, const char* fmt, ...);
 // valid for the life of the process (values are interned, never freed).  Entry
 // points resolve their switches once, outside their launch loops.
 const char* option(const char* name);
+// Measurement-only switches (SFM_MFMA_PROBE / TOUCH_ALL / EXACT / QUEUE / PRIO /
+// MAX_WG_PER_CU: they select schedules nobody ships, for A/B runs under tools/measure/):
+// read only by a library built with -DSFM_MEASUREMENT_SWITCHES (SFM_BUILD_FLAGS of
+// sofima_amd/_build.py; tools/measure/build_timing_lib.sh builds one); the production
+// library ignores them.  sfm_get_option("SFM_BUILD_MEASUREMENT_SWITCHES") says which it is.
+inline const char* measure_option(const char* name) {
+#ifdef SFM_MEASUREMENT_SWITCHES
+  return option(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 std::string option_str(const char* name);   // copy; empty when unset
 
 // FIRE scalars as the mesh kernels keep them on the device (sfm_mesh.hip) and

@@ -186,6 +186,13 @@ int sfm_set_option(const char* name, const char* value) {
 int sfm_get_option(const char* name, char* value, size_t capacity) {
   if (!name || !value || capacity == 0) return sfm::fail(SFM_ERR_INVALID, "option: NULL argument");
   const char* v = sfm::option(name);
+  if (std::strcmp(name, "SFM_BUILD_MEASUREMENT_SWITCHES") == 0) {
+#ifdef SFM_MEASUREMENT_SWITCHES
+    v = "1";
+#else
+    v = "0";
+#endif
+  }
   if (!v) {
     value[0] = 0;
     return 1;

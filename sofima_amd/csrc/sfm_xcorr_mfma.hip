@@ -2425,7 +2425,12 @@ __device__ void wave_first_peak(const MfmaArgs& a, int b, const float* surf,
   const int hi0 = a.hot_idx[(long long)b * a.hot_cap + min(lane, a.hot_cap - 1)];
   const float mx = a.v1[b];          // the surface maximum on entry
   const int n_hot = a.hot_count[b];
-  if (lane == 0) *cand_lds = 0;      // (LDS operations of one wave are ordered)
+  if (lane == 0) *cand_lds = 0;
+  // (the reset, the other lanes' atomics and the read-back below are LDS operations of ONE
+  // wave, which the hardware runs in program order; the fences keep the compiler from
+  // reordering them around the divergent loops in between)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   const int pitch = a.sx_pitch;
   const int m = a.min_distance;
   float bv = -INFINITY;
@@ -2508,6 +2513,8 @@ __device__ void wave_first_peak(const MfmaArgs& a, int b, const float* surf,
       bi = oi;
     }
   }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (lane == 0) {
     a.cand_count[b] = *cand_lds;   // (behind every lane's atomics in this wave's LDS queue)
     const float v1 = bv;
@@ -4045,6 +4052,13 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
           // (row 15 of the last tile is padding: there is no row yv = Py)
           if (act && yv < Py) *reinterpret_cast<v4i*>(Gw + yv * Px) = out;
         }
+        // The epilogue below gathers these rows back (other lanes' stores included) through
+        // loads the compiler cannot relate to the stores above: every store of this wave has
+        // to have reached the L2 (vector memory is write-through) before the first gather
+        // is issued.  (Tiles p and p + NB of a patch write the SAME values into the same
+        // rows, possibly from two waves at once: duplicate writers of identical bits.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       // The epilogue's table addresses do not depend on the MFMA loop; without
       // this opaque zero the compiler hoists its ~100 gathers above the loop
@@ -4775,7 +4789,7 @@ constexpr Variant kVariants[] = {{3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9},
                                  {15, 11}, {20, 11}};
 
 bool exact_enabled() {
-  const char* e = sfm::option("SFM_MFMA_EXACT");
+  const char* e = sfm::measure_option("SFM_MFMA_EXACT");
   return !(e && e[0] == '0');
 }
 
@@ -4924,7 +4938,7 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   int wg_per_cu = per_cu;
   {
     // (a measurement switch; read per call so that a test can flip it)
-    const char* cap = sfm::option("SFM_MFMA_MAX_WG_PER_CU");
+    const char* cap = sfm::measure_option("SFM_MFMA_MAX_WG_PER_CU");
     if (cap && std::atoi(cap) > 0) wg_per_cu = std::min(wg_per_cu, std::atoi(cap));
   }
   grid = std::min(grid, device_cus() * wg_per_cu);
@@ -5179,7 +5193,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
   a.aux_n = w.aux_n;
   a.surface = surface;
   {
-    const char* e = sfm::option("SFM_MFMA_QUEUE");
+    const char* e = sfm::measure_option("SFM_MFMA_QUEUE");
     a.work_counter = (e && e[0] == '0') ? nullptr : w.counter;
     // Measured on MI355X (8192^2 warped pair, A/B on one box, pruned and not):
     // 15.48-15.53 / 20.0-20.06 ms either way -- the staging round trip is hidden
@@ -5188,7 +5202,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     const char* x = sfm::option("SFM_MFMA_XCD");
     a.xcd_heads = (a.work_counter && x && x[0] == '1') ? w.counter + 64 : nullptr;
     a.clk = reinterpret_cast<long long*>(w.counter + 16);
-    const char* p = sfm::option("SFM_MFMA_PRIO");
+    const char* p = sfm::measure_option("SFM_MFMA_PRIO");
     a.prio_mode = p ? std::atoi(p) : 0;
   }
   if (fp) {
@@ -5220,7 +5234,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
     a.prune_k[2] = col_skip_2(a.nq);
     a.prune_k[3] = col_skip_3(a.nq);
     {
-      const char* e = sfm::option("SFM_MFMA_PROBE");  // "0": no seed probe
+      const char* e = sfm::measure_option("SFM_MFMA_PROBE");  // "0": no seed probe
       a.probe = !(e && e[0] == '0');
     }
     a.count_tiles = sfm::profiling() ? 1 : 0;
@@ -5237,7 +5251,7 @@ int mfma_i8_surface(const SfmXcorrDesc* d, void* ws_base, float* surface,
       // warped pair: 12.29 ms per launch without, 12.54 ms with the widening.)
       const char* wd = sfm::option("SFM_MFMA_WIDEN");
       a.widen = wd ? std::atoi(wd) : 0;
-      const char* ta = sfm::option("SFM_MFMA_TOUCH_ALL");
+      const char* ta = sfm::measure_option("SFM_MFMA_TOUCH_ALL");
       a.touch_all = ta && ta[0] == '1';
       const char* nw = sfm::option("SFM_MFMA_NARROW");
       a.narrow = nw ? std::atoi(nw) : 64;   // widest narrowing allowed (0: off)

@@ -24,12 +24,20 @@ import torch.distributed as dist
 # device tensors, the library communicator bootstrapped from a broadcast id --
 # then execute on a single-GPU box (`bench.py --force-multi-gpu-legs`, tests).
 import os as _os
-FORCE_COLLECTIVES = _os.environ.get('SFM_FORCE_COLLECTIVES') == '1'
+FORCE_COLLECTIVES = None   # None: the environment decides; True / False: set by the caller
+
+
+def force_collectives() -> bool:
+  """The switch, read where it is used: `FORCE_COLLECTIVES` if a caller assigned it
+  (bench.py --force-multi-gpu-legs), else SFM_FORCE_COLLECTIVES=1 in the environment."""
+  if FORCE_COLLECTIVES is not None:
+    return bool(FORCE_COLLECTIVES)
+  return _os.environ.get('SFM_FORCE_COLLECTIVES') == '1'
 
 
 def _alone(ws: int) -> bool:
   """No collective needed: one rank, unless collectives are forced."""
-  return ws == 1 and not (FORCE_COLLECTIVES and dist.is_available() and
+  return ws == 1 and not (force_collectives() and dist.is_available() and
                           dist.is_initialized())
 
 
@@ -567,7 +575,9 @@ def relax_mesh_banded(x, prev, config, mesh_force=None, group=None,
       raise ValueError('the host-staged transport takes no RCCL communicator')
     if ws > 1:
       host = HostStagedTransport(group)
-  elif comm is None and (ws > 1 or loopback or not _alone(ws)):
+  elif comm is None and (ws > 1 or loopback):
+    # (a forced world of one gathers through collectives, but only `loopback` asks for
+    # RCCL self send / recv between its local bands: no communicator otherwise)
     comm = own_comm = RcclComm(group)
   n_local = int(bands_per_rank)
   n_bands = ws * n_local

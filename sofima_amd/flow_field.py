@@ -269,11 +269,20 @@ def _run_batches_dev(res: _Resident, desc: _abi.SfmXcorrDesc, starts: torch.Tens
       per_call = max(1, per_call // 2)
       desc.batch = per_call * batch_size
       need = lib.sfm_xcorr_workspace_bytes(C.byref(desc))
+      if need == 0:
+        _abi.check(-1)
   n_calls = (n_batches + per_call - 1) // per_call
   if n_calls > 1 and OVERLAP_CALLS:
-    side = _side_stream(res.dev)
-    side.wait_stream(main)
-    lanes.append((side, _dev.workspace(need, res.dev)))
+    # the second lane is an optimisation: under memory pressure the calls simply stay on
+    # one stream
+    try:
+      side_ws = _dev.workspace(need, res.dev)
+    except torch.OutOfMemoryError:
+      side_ws = None
+    if side_ws is not None:
+      side = _side_stream(res.dev)
+      side.wait_stream(main)
+      lanes.append((side, side_ws))
   for ci, bi in enumerate(range(0, n_batches, per_call)):
     stream, ws = lanes[ci % len(lanes)]
     nb = min(per_call, n_batches - bi)

@@ -30,6 +30,14 @@ def test_header_and_binding_agree(lib):
   assert sorted(_abi.SIGNATURES) == declared
   for name in declared:
     assert hasattr(lib, name), f'{name} is declared but not exported'
+  # ... and the other way round: every C symbol the library exports is in the header
+  # (C++ internals are mangled and not part of the boundary)
+  import subprocess
+  out = subprocess.run(['nm', '-D', '--defined-only', _abi.lib_path()], capture_output=True,
+                       text=True, check=True).stdout
+  exported = sorted({line.split()[-1] for line in out.splitlines()
+                     if ' T ' in line and line.split()[-1].startswith('sfm_')})
+  assert exported == declared, (set(exported) ^ set(declared))
 
 
 def test_version_and_error_channel(lib):

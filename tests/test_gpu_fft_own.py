@@ -19,9 +19,6 @@ def _fft1d(x, n, inverse):
   n_in, pencils = x.shape
   xin = torch.from_numpy(np.ascontiguousarray(x.astype(np.complex64))).cuda()
   out = torch.zeros((n, pencils), dtype=torch.complex64, device='cuda')
-  lib.sfm_debug_fft1d.restype = C.c_int
-  lib.sfm_debug_fft1d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                  C.c_void_p]
   rc = lib.sfm_debug_fft1d(xin.data_ptr(), out.data_ptr(), n, n_in, pencils, int(inverse),
                            torch.cuda.current_stream().cuda_stream)
   assert rc == 0

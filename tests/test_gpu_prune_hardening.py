@@ -225,13 +225,19 @@ def test_every_kernel_switch_returns_the_same_bits(gpu):
               post_patch_size=(py, px), post_starts=starts)
     args = (pre, post, None, None, (py, px), starts, None)
     want = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
-    for name, values in (('SFM_MFMA_PROBE', (0,)), ('SFM_MFMA_TOUCH_ALL', (1,)),
-                         ('SFM_MFMA_EXACT', (0,)), ('SFM_MFMA_QUEUE', (0,)),
-                         ('SFM_MFMA_PRIO', (1, 2, 3)), ('SFM_MFMA_MAX_WG_PER_CU', (1,)),
+    # (the first six are measurement-only: a production library ignores them -- run this
+    # test with SOFIMA_AMD_LIB=.../libsofima_amd_measure.so, NOTIMING=1
+    # tools/measure/build_timing_lib.sh, to exercise them)
+    measure = (('SFM_MFMA_PROBE', (0,)), ('SFM_MFMA_TOUCH_ALL', (1,)),
+               ('SFM_MFMA_EXACT', (0,)), ('SFM_MFMA_QUEUE', (0,)),
+               ('SFM_MFMA_PRIO', (1, 2, 3)), ('SFM_MFMA_MAX_WG_PER_CU', (1,)))
+    if _abi.get_option('SFM_BUILD_MEASUREMENT_SWITCHES') != '1':
+      measure = ()
+    for name, values in measure + (
                          ('SFM_MFMA_PRUNE', (0,)), ('SFM_MFMA_LAZY', (0,)), ('SFM_MFMA_LAZYG', (0,)),
                          ('SFM_MFMA_EARLY', (0, 1, 4)), ('SFM_MFMA_WIDEN', (1,)),
                          ('SFM_MFMA_NARROW', (0, 4)), ('SFM_MFMA_XCD', (1,)),
-                         ('SFM_MFMA_GRID', (1, 3))):
+                         ('SFM_MFMA_GRID', (1, 3)), ('SFM_MFMA_PIPE', (1,))):
       for v in values:
         with _abi.option(name, v):
           got = flow_field.batched_xcorr_peaks(*args, method=2, **kw)
