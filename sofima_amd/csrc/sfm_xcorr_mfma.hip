@@ -76,6 +76,9 @@
 // Ping-pong prefetch of the A fragments across row groups: measured 6 % SLOWER
 // on the <10,11> variant (200 bytes of spills at the 256-VGPR limit), neutral on
 // the smaller ones; kept as an experiment switch.
+#ifndef SFM_WIDE_BPREFETCH_MAX
+#define SFM_WIDE_BPREFETCH_MAX 20   // widest variant whose B dwords are double-buffered too
+#endif
 #ifndef SFM_WIDE_TRIP
 #define SFM_WIDE_TRIP 2
 #endif
@@ -3611,6 +3614,42 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
           }
         }
       };
+      // Search-window variants: the B dwords of the NEXT row group are requested with its A
+      // fragments, behind this group's own loads -- a lone wave per SIMD has no partner to
+      // cover the round trip at the head of a row group (measured 20.6 cycles per matrix
+      // instruction with the dwords loaded where they are used).
+      constexpr int kNDW = 4 * NCE + 1;
+      auto row_group_w = [&](const v4i* af, v4i* af_next, const unsigned char* ap_next,
+                             const unsigned* dc, unsigned* dn, const unsigned char* bp_next) {
+        if (af_next) {
+#pragma unroll
+          for (int j = 0; j < kNDW; ++j)
+            dn[j] = *reinterpret_cast<const unsigned*>(bp_next + 4 * j);
+#pragma unroll
+          for (int ca = 0; ca < NCA; ++ca)
+            af_next[ca] = *reinterpret_cast<const v4i*>(ap_next + 16 * ca);
+        }
+        v4i afl[NCA];
+        unsigned dl[kNDW];
+#pragma unroll
+        for (int ca = 0; ca < NCA; ++ca) afl[ca] = af[ca];
+#pragma unroll
+        for (int j = 0; j < kNDW; ++j) dl[j] = dc[j];
+#pragma unroll
+        for (int c = 0; c < NCE; ++c) {
+          v4i bf;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            bf[k] = static_cast<int>(
+                __builtin_amdgcn_alignbyte(dl[4 * c + k + 1], dl[4 * c + k], sh));
+#pragma unroll
+          for (int ca = 0; ca < NCA; ++ca) {
+            const int q = ca - c + cq0;
+            acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afl[ca], bf, acc[q], 0,
+                                                           0, 0);
+          }
+        }
+      };
       // (the general P != Q epilogue needs the registers: old order there)
       if constexpr (SFM_LOOP_CA_OUTER && MODE != kModeGeneral) {
         // Software-pipelined order: A chunk outer, B fragment inner.  All NCE B
@@ -3916,6 +3955,23 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
           rows(std::integral_constant<int, kKs4>{});
         if (kKs5 > kKs4 && col_skip == kKs5 && !abandoned && yb0 < yhi)
           rows(std::integral_constant<int, kKs5>{});
+      } else if constexpr (NCA > 10 && NCA <= SFM_WIDE_BPREFETCH_MAX) {
+        v4i afA[NCA], afB[NCA];
+        unsigned dA[kNDW], dB[kNDW];
+#pragma unroll
+        for (int ca = 0; ca < NCA; ++ca)
+          afA[ca] = *reinterpret_cast<const v4i*>(ap + 16 * ca);
+#pragma unroll
+        for (int j = 0; j < kNDW; ++j) dA[j] = *reinterpret_cast<const unsigned*>(bp + 4 * j);
+        int yb0 = ylo;
+        for (; yb0 + 4 < yhi; yb0 += 8) {
+          row_group_w(afA, afB, ap + 4 * a.pa, dA, dB, bp + 4 * a.pb);
+          row_group_w(afB, afA, ap + 8 * a.pa, dB, dA, bp + 8 * a.pb);
+          ap += 8 * a.pa;
+          bp += 8 * a.pb;
+        }
+        if (yb0 < yhi) row_group_w(afA, nullptr, nullptr, dA, nullptr, nullptr);
+        mfma_issued += (long long)((yhi - ylo + 3) / 4) * (NCA * NCE);
       } else if constexpr (SFM_AF_PREFETCH || NCA > 10) {
         v4i afA[NCA], afB[NCA];
 #pragma unroll

@@ -247,8 +247,13 @@ def test_relax_large_mesh_vs_oracle(gpu):
   np.testing.assert_allclose(ge, we, rtol=1e-3)
 
 
-def test_headline_mesh_leg_followed_through_all_1000_steps(gpu, capsys):
-  """The mesh leg bench.py times -- ONE chunk of 1000 FIRE steps of the
+@pytest.mark.parametrize('source', ['analytic', 'bench'])
+def test_headline_mesh_leg_followed_through_all_1000_steps(gpu, capsys, source):
+  """(source 'bench': the LITERAL input of the bench's mesh leg -- the flow field
+  flow_field() returns for bench.synth_pair(8192, 1002, warp), through bench.mesh_inputs;
+  'analytic': a field of the same geometry written down directly.)
+
+  The mesh leg bench.py times -- ONE chunk of 1000 FIRE steps of the
   [2, 1, 205, 205] mesh pulled to a flow field of the 8192^2 geometry (mesh.py:
   448-499) -- followed through its whole length.
 
@@ -284,6 +289,12 @@ def test_headline_mesh_leg_followed_through_all_1000_steps(gpu, capsys):
   d = bench.WARP[0] * np.sin(2 * np.pi * xx / bench.WARP[1]) * np.cos(2 * np.pi * yy / bench.WARP[1])
   flow = np.stack([np.rint(-5 - d), np.rint(3 + d)]).astype(np.float32)
   flow[:, rng.random((n, n)) < 0.003] = np.nan       # a few invalid vectors
+  if source == 'bench':
+    from sofima_amd import flow_field
+    pre, post = bench.synth_pair(8192, 1002, warp=bench.WARP)
+    flow = flow_field.JAXMaskedXCorrWithStatsCalculator().flow_field(
+        pre, post, bench.PATCH, bench.STEP, batch_size=bench.BATCH)
+    assert flow.shape == (4, n, n)
   prev = bench.mesh_inputs(flow, bench.PATCH // 2 // bench.STEP)
   assert prev.shape == (2, 1, 205, 205)
   total, win = bench.MESH_ITERS, 20
