@@ -107,6 +107,9 @@ int sfm_device_count(int* count);
  *   SFM_MESH_PERSISTENT=0 / SFM_MESH_SPECULATE=0 / SFM_MESH_TILED=0 /
  *   SFM_MESH_SMALL=0 / SFM_MESH_FUSE_TARGET=0
  *                         fall back to the simpler integrator
+ *   SFM_MESH_PERSIST3D=1  volumetric montage (native target mesh): every step of a chunk in ONE
+ *                         launch with grid barriers (built in round 6: bit-identical, 2 x SLOWER
+ *                         than the four launches per step it replaces, which stay the default)
  *   SFM_MESH_PACK=0       tiled in-plane step: a workgroup per tile also in a narrow last
  *                         tile column (default: its tile rows share workgroups)
  *   SFM_MESH_TILE=16|32   tile edge of the persistent integrator

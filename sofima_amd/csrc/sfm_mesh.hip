@@ -25,6 +25,7 @@
 //   finish:       the pending gate / drift / scalar update of the last step,
 //                 then e_kin and v_max.
 #include "sfm_common.h"
+#include "sfm_target.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -1393,6 +1394,341 @@ drift_cols_kernel(const float* __restrict__ x, const float* __restrict__ v,
     colsum[(3 + c) * p.X + xi] = s1 / p.n_col;
   }
   if (threadIdx.x == 0) col_ticket[c] = 0;   // ready for the next step's launch
+}
+
+// ---------------------------------------------------------------------------
+// Volumetric montage (BASELINE configs[4]: [3, n_tiles, 12, 12, 12] with the native
+// target mesh as prev_fn, elastic_mesh_3d, FIRE, per-column drift means): the whole
+// chunk of steps in ONE launch.
+//
+// The multi-launch step of such a mesh is advance_kernel + target_mesh_kernel +
+// integrate_kernel<3> + drift_cols_kernel: four launches of 7-16 us each for 110 k nodes,
+// every one of them a launch ramp, two or three dependent round trips and a tail.  Here
+// the SAME blocks run the SAME code -- a workgroup of this launch is block b of every one
+// of those kernels: 256 consecutive nodes, one node per thread (x, v, a of the node stay
+// in registers from step to step), its row of partial sums, the chunk sums of
+// drift_cols_kernel in that kernel's decomposition -- and what separated the launches
+// becomes a grid barrier (one atomic per workgroup and phase; the launch is as wide as
+// the chip holds at once, checked by the caller):
+//   A  FIRE scalars from the partial rows of the previous step (every workgroup reduces
+//      them, like advance_kernel), per-column drift means from the chunk sums, position
+//      update of the own node                                               -- barrier 1
+//   B  target of the own node, sampled from the neighbour tiles' positions (a wave lies
+//      inside ONE tile: 64 divides the tile's node count), kept in registers
+//   C  spring force from the neighbours' positions, pull towards the target, velocity
+//      update, FIRE mixing; the block's row of partial sums                 -- barrier 2
+//   D  (per-column drift) chunk sums of x and v, drift_cols_kernel's code    -- barrier 3
+// Same float operations in the same order as the four kernels: x, v, a, the FIRE
+// scalars and the statistics are bit-identical to the multi-launch path, which is the
+// default; this form is opt-in (SFM_MESH_PERSIST3D=1) because it is SLOWER (r6, [3,64,12,12,12],
+// per step): 247 us with agent-scope release / acquire fences around the barriers (a release
+// writes back the XCD's whole L2, an acquire per wave invalidates it: 1728 invalidates per
+// barrier), 129 us with written-through agent-scope stores instead of the release, 95 us with
+// one invalidate per workgroup -- against 47 us for the four launches.  Phase ticks
+// (SFM_P3_TIMING): A 10, B + C 20-25, D 6 us of work, and 14-30 us in EACH barrier: 432
+// device-scope atomics on one address are served one after the other at the memory side,
+// and after every invalidate the neighbours' positions, the partial rows and the chunk sums
+// come from memory instead of the L2 the four kernels find them in.  Eight XCDs with
+// private L2s make a grid barrier a cache flush; what a single launch needs is a tile per
+// workgroup (a 12^3 tile's springs never leave the workgroup) with only the overlap strips
+// and the sums crossing -- the layout of the in-plane persistent kernel, not this one.
+// A barrier that times out leaves the caller's state untouched (persist_commit_kernel).
+// ---------------------------------------------------------------------------
+struct Persist3dArgs {
+  float* x;               // working copies of the caller's state
+  float* v;
+  float* a;
+  Scalars* scal;          // [2]; scal[0] holds the chunk's start values
+  float* partials;        // [grid, kNP]
+  float* colsum;          // [6][X]
+  float* col_part;        // [3][col_chunks][2][X]
+  unsigned* bar;          // grid barrier counter (zero at launch)
+  int* abort;
+  int num_iters;
+  float cap0;
+  int col_chunks, col_rows_per;
+  SfmTargetMeshDesc t;
+};
+
+constexpr int kP3MaxX = 256;
+
+template <typename T>
+__device__ __forceinline__ void st_agent(T* ptr, T v) {
+  __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, int* abort, unsigned target,
+                                             int* ok_lds) {
+  // What other workgroups read was stored with agent-scope stores (written through: a
+  // release fence at agent scope would write back this XCD's whole L2, 432 times per phase --
+  // measured 80 us per barrier); they only have to have left the wave.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    long long spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(16);   // (~0.5 us: 432 pollers of one address are a hot spot)
+      if (++spins > (1LL << 21) ||
+          __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    *ok_lds = ok;
+  }
+  // drop what this CU / XCD cached of the others' data: ONE wave's invalidate serves the
+  // workgroup (the vector L1 is the CU's, the L2 the XCD's; every wave doing it was 1728
+  // invalidates per barrier)
+  if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  asm volatile("" ::: "memory");
+  return *ok_lds != 0;
+}
+
+template <bool COLS>
+__global__ void __launch_bounds__(kBlock, 2)
+mesh_persist3d_kernel(MeshParams p, Persist3dArgs q) {
+  using namespace sfm_target;
+  __shared__ float lds[kNP * kBlock];
+  __shared__ float cs_lds[6 * kP3MaxX];
+  __shared__ NbEntry s_e[kBlock / 64][4];
+  __shared__ int ok_lds;
+  __shared__ float col_lds[2][kBlock];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long n = blockIdx.x * (long long)kBlock + tid;
+  const bool live = n < p.N;
+  const long long nn = live ? n : p.N - 1;
+  const SfmTargetMeshDesc& d = q.t;
+  const int mz = d.mesh_shape[0], my = d.mesh_shape[1], mx = d.mesh_shape[2];
+  const long long mn = (long long)mz * my * mx;
+  // the tile of this wave (64 divides mn) and the node's place in it
+  const long long wn = __builtin_amdgcn_readfirstlane(
+      static_cast<int>(min(blockIdx.x * (long long)kBlock + 64LL * wave, p.N - 1) / mn));
+  const int tile = static_cast<int>(wn);
+  const int in_tile = static_cast<int>(nn - (long long)tile * mn);
+  const int tx = in_tile % mx, ty = (in_tile / mx) % my, tz = in_tile / (mx * my);
+  if (lane < 4) s_e[wave][lane] = make_entry(d, tile, lane);
+  __syncthreads();
+  const int xi = static_cast<int>(nn % p.X);
+  unsigned phase = 0;
+  int cur = 0;
+#ifdef SFM_P3_TIMING
+  long long tk[6] = {0, 0, 0, 0, 0, 0}, tc = wall_clock64();
+#define P3TICK(i) { const long long tn = wall_clock64(); tk[i] += tn - tc; tc = tn; }
+#else
+#define P3TICK(i)
+#endif
+  for (int it = 0; it < q.num_iters; ++it) {
+    const int pending = it > 0;
+    // ---- A: scalars, drift means, position update (advance_kernel) ----------------------
+    Scalars s, s_in;
+    {
+      // (written by workgroup 0 one step ago: read from the L2, not through a scalar load)
+      const int* src = reinterpret_cast<const int*>(&q.scal[cur]);
+      int* dst = reinterpret_cast<int*>(&s_in);
+      for (int i = 0; i < static_cast<int>(sizeof(Scalars) / 4); ++i)
+        dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (pending) {
+      update_scalars(s_in, q.partials, static_cast<int>(gridDim.x), p, lds, &s);
+    } else {
+      s = s_in;
+      s.gate = 1.f;
+      for (int c = 0; c < 3; ++c) s.mx[c] = s.mv[c] = 0.f;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+      const int* src = reinterpret_cast<const int*>(&s);
+      int* dst = reinterpret_cast<int*>(&q.scal[cur ^ 1]);
+      for (int i = 0; i < static_cast<int>(sizeof(Scalars) / 4); ++i) st_agent(dst + i, src[i]);
+    }
+    cur ^= 1;
+    if (COLS && pending) {
+      // the chunk sums in chunk order, then the mean (drift_cols_kernel's last workgroup)
+      for (int t = tid; t < 3 * p.X; t += kBlock) {
+        const int c = t / p.X, xc = t - c * p.X;
+        float s0 = 0.f, s1 = 0.f;
+        for (int kb = 0; kb < q.col_chunks; kb += kColBatch) {
+          float b0[kColBatch], b1[kColBatch];
+#pragma unroll
+          for (int k = 0; k < kColBatch; ++k) {
+            const float* src = q.col_part +
+                (((long long)c * q.col_chunks + min(kb + k, q.col_chunks - 1)) * 2) * p.X + xc;
+            b0[k] = src[0];
+            b1[k] = src[p.X];
+          }
+#pragma unroll
+          for (int k = 0; k < kColBatch; ++k)
+            if (kb + k < q.col_chunks) {
+              s0 = s0 + b0[k];
+              s1 = s1 + b1[k];
+            }
+        }
+        cs_lds[c * p.X + xc] = s0 / p.n_col;
+        cs_lds[(3 + c) * p.X + xc] = s1 / p.n_col;
+        if (blockIdx.x == 0) {
+          q.colsum[c * p.X + xc] = s0 / p.n_col;
+          q.colsum[(3 + c) * p.X + xc] = s1 / p.n_col;
+        }
+      }
+      __syncthreads();
+    }
+    {
+      const float dt = s.dt;
+      const float c2 = 0.5f * (dt * dt);
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float xv = q.x[c * p.N + n];
+          float vv = q.v[c * p.N + n];
+          if (pending) {
+            vv = vv * s.gate;
+            if (COLS) {
+              xv = xv - cs_lds[c * p.X + xi];
+              vv = vv - cs_lds[(3 + c) * p.X + xi] * s.gate;
+            } else if (p.remove_drift) {
+              xv = xv - s.mx[c];
+              vv = vv - s.mv[c];
+            }
+            st_agent(&q.v[c * p.N + n], vv);
+          }
+          st_agent(&q.x[c * p.N + n], xv + (dt * vv + c2 * q.a[c * p.N + n]));
+        }
+      }
+    }
+    P3TICK(0)
+    if (!grid_barrier(q.bar, q.abort, ++phase * gridDim.x, &ok_lds)) return;
+    P3TICK(1)
+    // ---- B: the target of the own node (target_mesh_kernel<0>) --------------------------
+    float prev[3] = {NAN, NAN, NAN};
+    {
+      auto plane_of = [&](int c, int nb_i) {
+        return plain(q.x + ((long long)c * d.n_tiles + nb_i) * mn);
+      };
+      target_node<0>(d, s_e[wave], tz, ty, tx, plane_of, &prev[0], &prev[1], &prev[2]);
+    }
+    // ---- C: force, velocity, partial sums (integrate_kernel<3>) -------------------------
+    {
+      const float dt = s.dt, alpha = s.alpha, cap = s.cap;
+      const float hdtg = (0.5f * dt) * p.gamma;
+      const float fact0 = 1.0f / (1.0f + hdtg);
+      const float fact1 = 1.0f - hdtg;
+      const float hdt = 0.5f * dt;
+      float part[kNP];
+      for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+      if (live) {
+        float f[3], vn[3];
+        node_force<3>(q.x, p, n, f);
+        float a2 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float xv = q.x[c * p.N + n];
+          f[c] = f[c] + prev_pull(xv, prev[c], p.neg_k0, cap);
+          const float a_old = q.a[c * p.N + n];
+          vn[c] = fact0 * (q.v[c * p.N + n] * fact1 + hdt * (a_old + f[c]));
+          q.a[c * p.N + n] = f[c];
+          a2 = a2 + f[c] * f[c];
+          v2 = v2 + vn[c] * vn[c];
+          part[0] = part[0] + f[c] * vn[c];
+          part[1 + c] = part[1 + c] + xv;
+        }
+        const float a_norm = sqrtf(a2) + 1e-6f;
+        const float v_norm = sqrtf(v2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          vn[c] = vn[c] + alpha * (f[c] / a_norm * v_norm - vn[c]);
+          part[4 + c] = part[4 + c] + vn[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st_agent(&q.v[c * p.N + n], vn[c]);
+      }
+      block_sum(part, 7, lds);
+      if (tid == 0)
+        for (int i = 0; i < kNP; ++i) st_agent(&q.partials[blockIdx.x * kNP + i], part[i]);
+    }
+    P3TICK(2)
+    if (!grid_barrier(q.bar, q.abort, ++phase * gridDim.x, &ok_lds)) return;
+    P3TICK(3)
+    // ---- D: chunk sums of the columns (drift_cols_kernel, blocks (chunk, c)) ------------
+    if (COLS) {
+      const long long rows = p.N / p.X;
+      const int G = kBlock / p.X;
+      for (int vb = blockIdx.x; vb < 3 * q.col_chunks; vb += gridDim.x) {
+        const int c = vb / q.col_chunks, chunk = vb - c * q.col_chunks;
+        const long long r0 = (long long)chunk * q.col_rows_per;
+        const long long r1 = min(rows, r0 + q.col_rows_per);
+        const int g = tid / p.X, xc = tid % p.X;
+        float acc[2] = {0.f, 0.f};
+        if (g < G)
+          for (long long rb = r0 + g; rb < r1; rb += (long long)G * kColBatch) {
+            float bx[kColBatch], bv[kColBatch];
+#pragma unroll
+            for (int k = 0; k < kColBatch; ++k) {
+              const long long r = min(rb + (long long)k * G, rows - 1);
+              bx[k] = q.x[c * p.N + r * p.X + xc];
+              bv[k] = q.v[c * p.N + r * p.X + xc];
+            }
+#pragma unroll
+            for (int k = 0; k < kColBatch; ++k)
+              if (rb + (long long)k * G < r1) {
+                acc[0] = acc[0] + bx[k];
+                acc[1] = acc[1] + bv[k];
+              }
+          }
+        col_lds[0][tid] = acc[0];
+        col_lds[1][tid] = acc[1];
+        __syncthreads();
+        if (tid < p.X) {
+          float s0 = col_lds[0][tid], s1 = col_lds[1][tid];
+          for (int k = 1; k < G; ++k) {
+            s0 = s0 + col_lds[0][tid + k * p.X];
+            s1 = s1 + col_lds[1][tid + k * p.X];
+          }
+          float* dst = q.col_part + (((long long)c * q.col_chunks + chunk) * 2) * p.X + tid;
+          st_agent(dst, s0);
+          st_agent(dst + p.X, s1);
+        }
+        __syncthreads();
+      }
+      P3TICK(4)
+      if (!grid_barrier(q.bar, q.abort, ++phase * gridDim.x, &ok_lds)) return;
+      P3TICK(5)
+    }
+  }
+#ifdef SFM_P3_TIMING
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 200 || blockIdx.x == 431))
+    printf("P3 block %d: per step (10 ns ticks) A %lld bar1 %lld BC %lld bar2 %lld D %lld bar3 %lld\n",
+           blockIdx.x, tk[0] / q.num_iters, tk[1] / q.num_iters, tk[2] / q.num_iters,
+           tk[3] / q.num_iters, tk[4] / q.num_iters, tk[5] / q.num_iters);
+#endif
+  // the drift means the last step leaves pending (read by finish_kernel)
+  if (COLS && blockIdx.x == 0 && q.num_iters > 0) {
+    for (int t = tid; t < 3 * p.X; t += kBlock) {
+      const int c = t / p.X, xc = t - c * p.X;
+      float s0 = 0.f, s1 = 0.f;
+      for (int kb = 0; kb < q.col_chunks; kb += kColBatch) {
+        float b0[kColBatch], b1[kColBatch];
+#pragma unroll
+        for (int k = 0; k < kColBatch; ++k) {
+          const float* src = q.col_part +
+              (((long long)c * q.col_chunks + min(kb + k, q.col_chunks - 1)) * 2) * p.X + xc;
+          b0[k] = src[0];
+          b1[k] = src[p.X];
+        }
+#pragma unroll
+        for (int k = 0; k < kColBatch; ++k)
+          if (kb + k < q.col_chunks) {
+            s0 = s0 + b0[k];
+            s1 = s1 + b1[k];
+          }
+      }
+      q.colsum[c * p.X + xc] = s0 / p.n_col;
+      q.colsum[(3 + c) * p.X + xc] = s1 / p.n_col;
+    }
+  }
 }
 
 // Applies the pending gate / drift of the last step and emits the per-block
@@ -2802,6 +3138,13 @@ bool small_enabled() {
   return !(e && e[0] == '0');
 }
 
+bool persist3d_enabled() {
+  // opt-in ("1"): built in round 6, bit-identical, and measured SLOWER than the four-launch
+  // step it replaces (95-130 us per step against 47 on [3,64,12,12,12]: see the kernel)
+  const char* e = sfm::option("SFM_MESH_PERSIST3D");
+  return e && e[0] == '1';
+}
+
 bool persistent_enabled() {
   const char* e = sfm::option("SFM_MESH_PERSISTENT");
   return !(e && e[0] == '0');
@@ -2930,7 +3273,9 @@ MeshWorkspace carve_for(const SfmMeshDesc* d, void* ws, TilePlan* plan) {
   // second (x, v, a) set: ping-pong of the fused tiled step, staging of the
   // persistent kernel's result
   return carve(ws, d->target ? cn : 0,
-               (d->ncomp == 2 && !d->prev_cb && d->force_kind == SFM_FORCE_SPRINGS) ? cn : 0,
+               ((d->ncomp == 2 && !d->prev_cb && d->force_kind == SFM_FORCE_SPRINGS) ||
+                (d->ncomp == 3 && d->target))   // (volumetric montage: mesh_persist3d_kernel)
+                   ? cn : 0,
                t.tiles,
                d->shape[3], d->target ? sfm::target_list_ints(d->target) : 0);
 }
@@ -3194,6 +3539,69 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     hipLaunchKernelGGL(drift_cols_kernel<3>, dim3(col_chunks, 3), dim3(kBlock), 0, ls, xs, vs, p,
                        w.colsum, w.col_part, w.col_ticket, col_rows_per);
   };
+  bool persist3d_done = false;
+
+  // Volumetric montage: every step of the chunk in one launch (mesh_persist3d_kernel).
+  if (persist3d_enabled() && p.ncomp == 3 && d->target && !d->prev_cb && p.fire &&
+      d->num_iters >= 1 && p.force_kind == SFM_FORCE_SPRINGS && p.has_prev && w.alt[0] &&
+      p.own_y0 <= 0 && p.own_y1 >= p.Y && p.X <= kP3MaxX && d->target->ncomp == 3 &&
+      d->target->n_eval == 0 && (long long)grid * kBlock >= p.N) {
+    const SfmTargetMeshDesc& t = *d->target;
+    const long long mn = (long long)t.mesh_shape[0] * t.mesh_shape[1] * t.mesh_shape[2];
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    const void* kfn = p.drift_cols ? reinterpret_cast<const void*>(&mesh_persist3d_kernel<true>)
+                                   : reinterpret_cast<const void*>(&mesh_persist3d_kernel<false>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kBlock, 0) != hipSuccess)
+      per_cu = 0;
+    // every workgroup has to be resident at once (grid barriers); a wave inside one tile
+    if (mn % 64 == 0 && mn * t.n_tiles == p.N && (long long)per_cu * cus >= grid) {
+      const size_t bytes = (size_t)3 * p.N * sizeof(float);
+      SFM_HIP_CHECK(hipMemcpyAsync(w.alt[0], d->x, bytes, hipMemcpyDeviceToDevice, st));
+      SFM_HIP_CHECK(hipMemcpyAsync(w.alt[1], d->v, bytes, hipMemcpyDeviceToDevice, st));
+      SFM_HIP_CHECK(hipMemcpyAsync(w.alt[2], d->a, bytes, hipMemcpyDeviceToDevice, st));
+      SFM_HIP_CHECK(hipMemsetAsync(w.comm, 0, 64, st));
+      SFM_HIP_CHECK(hipMemsetAsync(w.abort, 0, sizeof(int), st));
+      Persist3dArgs q;
+      q.x = w.alt[0];
+      q.v = w.alt[1];
+      q.a = w.alt[2];
+      q.scal = w.scal;
+      q.partials = w.partials;
+      q.colsum = w.colsum;
+      q.col_part = w.col_part;
+      q.bar = reinterpret_cast<unsigned*>(w.comm);
+      q.abort = w.abort;
+      q.num_iters = d->num_iters;
+      q.cap0 = cap0;
+      q.col_chunks = col_chunks;
+      q.col_rows_per = col_rows_per;
+      q.t = t;
+      sfm::prof_begin(sfm::kProfMesh, st);
+      if (p.drift_cols)
+        hipLaunchKernelGGL(mesh_persist3d_kernel<true>, dim3(grid), dim3(kBlock), 0, st, p, q);
+      else
+        hipLaunchKernelGGL(mesh_persist3d_kernel<false>, dim3(grid), dim3(kBlock), 0, st, p, q);
+      sfm::prof_end(sfm::kProfMesh, st);
+      SFM_LAUNCH_CHECK();
+      hipLaunchKernelGGL(persist_commit_kernel, dim3(grid_for(3 * p.N)), dim3(kBlock), 0, st,
+                         w.abort, w.alt[0], w.alt[1], w.alt[2], d->x, d->v, d->a, 3 * p.N);
+      SFM_LAUNCH_CHECK();
+      int aborted = 0;
+      SFM_HIP_CHECK(hipMemcpyAsync(&aborted, w.abort, sizeof(int), hipMemcpyDeviceToHost, st));
+      SFM_HIP_CHECK(hipStreamSynchronize(st));
+      if (!aborted) {
+        persist3d_done = true;
+        cur = d->num_iters & 1;
+      } else {
+        // a barrier timed out (workgroups not co-resident): x, v, a are untouched; start over
+        SFM_HIP_CHECK(hipMemcpyAsync(&w.scal[0], &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+      }
+    }
+  }
   auto step = [&](int pending) -> int {
     if (fused) {
       float** bi = bufs[in];
@@ -3246,8 +3654,8 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
   };
 #undef SFM_STEP_DISPATCH
 
-  int it = small ? d->num_iters : 0;
-  if (!small && d->num_iters > 0) {
+  int it = (small || persist3d_done) ? d->num_iters : 0;
+  if (!small && !persist3d_done && d->num_iters > 0) {
     if (int rc = step(0)) return rc;
     it = 1;
   }

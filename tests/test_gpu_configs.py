@@ -238,6 +238,48 @@ def test_cfg4_3d_montage_mesh_vs_oracle(gpu):
   np.testing.assert_allclose(np.array(got[0]), want[0], atol=1e-3 * scale)
 
 
+@pytest.mark.parametrize('grid,mesh_shape,drift', [((8, 8), (12, 12, 12), True),
+                                                  ((8, 8), (12, 12, 12), False),
+                                                  ((2, 2), (12, 12, 12), True),
+                                                  ((3, 2), (8, 16, 12), True),
+                                                  ((2, 3), (4, 8, 10), True)])
+def test_cfg4_montage_mesh_single_launch_is_bit_identical(gpu, grid, mesh_shape, drift):
+  """mesh_persist3d_kernel (every step of a chunk of the volumetric montage in ONE launch:
+  the blocks of advance / target mesh / integrate / column means with grid barriers in
+  between; opt-in, SFM_MESH_PERSIST3D=1) against the four-launch step: positions, velocities,
+  accelerations, FIRE scalars, e_kin and step counts are the same bits -- per-column drift
+  means and none, 64 and 4 tiles, a tile size 64 does not divide (the last case: the
+  single launch declines it, both runs take the four-launch step), chunks of 1, 2 and 37
+  steps, two chunks in a row through relax_mesh."""
+  import dataclasses
+  from sofima_amd import _abi, mesh, stitch_elastic
+  rng = np.random.default_rng(sum(mesh_shape) + grid[0])
+  nb, fx, fy, x0 = synth_montage(rng, grid[0], grid[1], mesh_shape, 3, amp=5.0)
+  stride = (40.0, 40.0, 40.0)
+  base = mesh.IntegrationConfig(
+      dt=0.001, gamma=0.0, k0=0.01, k=0.1, stride=stride, num_iters=37,
+      max_iters=74, stop_v_max=1e-9, dt_max=100, prefer_orig_order=False,
+      start_cap=0.1, final_cap=10.0, remove_drift=drift)
+  fn = stitch_elastic.TargetMeshFn(nb, fx, fy, stride)
+  for iters in (1, 2, 37):
+    cfg = dataclasses.replace(base, num_iters=iters, max_iters=iters)
+    runs = []
+    for single in (1, 0):
+      with _abi.option('SFM_MESH_PERSIST3D', single):
+        runs.append(mesh.velocity_verlet(x0, np.zeros_like(x0), None, cfg, cfg.start_cap,
+                                         mesh_force=mesh.elastic_mesh_3d, prev_fn=fn))
+    a, b = runs
+    for i in range(3):
+      np.testing.assert_array_equal(np.array(a[i]), np.array(b[i]), err_msg=f'{iters} steps, array {i}')
+    assert tuple(a[3:]) == tuple(b[3:]), (iters, a[3:], b[3:])
+  res = []
+  for single in (1, 0):
+    with _abi.option('SFM_MESH_PERSIST3D', single):
+      res.append(mesh.relax_mesh(x0, None, base, mesh_force=mesh.elastic_mesh_3d, prev_fn=fn))
+  np.testing.assert_array_equal(np.array(res[0][0]), np.array(res[1][0]))
+  assert res[0][1] == res[1][1] and res[0][2] == res[1][2] == 74
+
+
 def test_cfg4_flow_map3d_vs_reference_output(gpu, golden):
   """stitch_elastic.compute_flow_map3d (stitch_elastic.py:85-194) on a 2 x 2 grid
   of 3-d tiles == the flow arrays and offsets the reference's function produced
