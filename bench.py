@@ -437,12 +437,12 @@ def main():
 
   # HBM traffic of the dominant kernel: PMC counters cannot be read from inside
   # the run, so the figure comes from the separate rocprofv3 --pmc passes of THIS
-  # bench (tools/measure/profile_round5.sh -> profiles/r05_pmc_traffic.json), and
+  # bench (tools/measure/profile_round6.sh -> profiles/r06_pmc_traffic.json), and
   # only when that file was measured on the library that is loaded now
   # (.build_sha); otherwise null.
   if roof and uses_mfma and size == 8192:
     try:
-      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')))
+      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r06_pmc_traffic.json')))
       meta = pmc.get('_meta', {})
       sha = build_sha()
       if sha and meta.get('git_sha') == sha and meta.get('pair', 'exact') == args.pair:
@@ -456,17 +456,17 @@ def main():
             mesh_obj['roofline']['traffic'] = int(v['hbm_bytes_per_launch'])
             mesh_obj['roofline']['traffic_note'] = (
                 'per launch of %d FIRE steps (fabric traffic of the inter-workgroup exchange: '
-                'the state itself stays on chip); counters: profiles/r05_pmc_traffic.json'
+                'the state itself stays on chip); counters: profiles/r06_pmc_traffic.json'
                 % args.mesh_iters)
         if roof.get('traffic') is not None:
             roof['traffic_source'] = {
-                'file': 'profiles/r05_pmc_traffic.json', 'measured_on_git_sha': sha,
+                'file': 'profiles/r06_pmc_traffic.json', 'measured_on_git_sha': sha,
                 'launch': 'pruned (production) launch',
                 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of '
                           'this bench; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per '
                           'launch of %d patches' % round(ppl)}
       else:
-        roof['traffic_note'] = ('null: profiles/r05_pmc_traffic.json was measured on %s / '
+        roof['traffic_note'] = ('null: profiles/r06_pmc_traffic.json was measured on %s / '
                                 'pair %s, this library is %s / pair %s'
                                 % (meta.get('git_sha'), meta.get('pair'), sha, args.pair))
     except (OSError, ValueError):
@@ -621,7 +621,7 @@ def main():
       pass
 
 
-AUX_TRAFFIC_FILE = 'r05_pmc_traffic_aux.json'
+AUX_TRAFFIC_FILE = 'r06_pmc_traffic_aux.json'
 
 
 def aux_legs(dev, seed, only=None):
@@ -634,7 +634,7 @@ def aux_legs(dev, seed, only=None):
   read once per node update (mesh: 14 floats in-plane, 21 volumetric).
   `traffic` = HBM bytes of ONE call of the leg (all its launches) from separate
   rocprofv3 --pmc passes of `bench.py --aux-leg LEG` (tools/measure/pmc_aux.sh ->
-  profiles/r05_pmc_traffic_aux.json), taken only when that file was measured on
+  profiles/r06_pmc_traffic_aux.json), taken only when that file was measured on
   the library that is loaded now; `only`: run that one leg (the counted process)."""
   import torch
   from sofima_amd import _abi, flow_field, mesh

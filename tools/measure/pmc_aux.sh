@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the aux_rooflines legs of bench.py: one counted process per leg,
 # FETCH_SIZE and WRITE_SIZE in separate passes -> gpurun_out/pmc_aux/traffic_aux.json
-# (copy to profiles/r05_pmc_traffic_aux.json).   gpurun -- bash tools/measure/pmc_aux.sh
+# (copy to profiles/r06_pmc_traffic_aux.json).   gpurun -- bash tools/measure/pmc_aux.sh
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_aux; rm -rf $O; mkdir -p $O
 SHA=$(cd $R && python -c "from sofima_amd import _build; print(_build.source_hash())")
 cd /tmp && export TMPDIR=/tmp
