@@ -79,6 +79,9 @@
 #ifndef SFM_WIDE_BPREFETCH_MAX
 #define SFM_WIDE_BPREFETCH_MAX 20   // widest variant whose B dwords are double-buffered too
 #endif
+#ifndef SFM_WIDE_HALVES
+#define SFM_WIDE_HALVES 1   // search-window variants: 8 waves per CU, a row tile as two column halves
+#endif
 #ifndef SFM_WIDE_TRIP
 #define SFM_WIDE_TRIP 2
 #endif
@@ -2673,7 +2676,8 @@ __device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_ld
 }
 
 template <int NCA, int NCE, int MODE>
-__global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
+__global__ void __launch_bounds__((MODE == kModePipe || (NCA > 10 && SFM_WIDE_HALVES)) ? 2 * kThreads
+                                                                                       : kThreads,
                                   (MODE == kModePipe || NCA > 10) ? 1 : 2) xcorr_mfma_kernel(MfmaArgs a) {
   // Search-window geometry (NCA > 10: pre patches 161 .. 320 wide against a post patch of up
   // to 160, processor/flow.py:577,792-803).  The pre patch alone is up to 119 KB of LDS, so a
@@ -2707,6 +2711,13 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
   constexpr bool LAZY = MODE == kModeSameLazy || MODE == kModeSameExactLazy || LAZYG;
   constexpr bool RAW = MODE == kModeRaw;
   constexpr int NQ = NCA + NCE - 1;
+  // Search-window variants, second form (SFM_WIDE_HALVES, the default): the CU's one workgroup
+  // has EIGHT waves (two per SIMD: a partner covers a wave's fragment round trips and runs
+  // its matrix loop under the other's epilogue) and a tile job is one column HALF of a row
+  // tile -- NQH accumulator tiles in plain VGPRs, the 12 .. 15 A chunks that reach them.
+  constexpr bool WIDE8 = NCA > 10 && MODE == kModeGeneral && SFM_WIDE_HALVES;
+  constexpr int NQH = (NQ + 1) / 2;
+  constexpr int kCq0 = NCE - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float touch_junk[kThreads];  // sink of the LDS-direct G touches
   __shared__ int probe_lds[kThreads];     // K-split sums of the seed probe (a.prune)
@@ -2773,7 +2784,7 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
   const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
   // Zero the whole LDS image once: pad rows / margins stay zero afterwards.
   for (int i = threadIdx.x * 16; i < (PIPE ? 2 * a.slot_bytes : a.a_bytes + a.b_bytes);
-       i += (PIPE ? 2 : 1) * kThreads * 16)
+       i += ((PIPE || WIDE8) ? 2 : 1) * kThreads * 16)
     *reinterpret_cast<v4i*>(smem + i) = v4i{0, 0, 0, 0};
   if constexpr (PIPE) {
     __syncthreads();
@@ -3154,7 +3165,7 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
                              pp.c[0], A_lds, a.pa, kPadTop, 0, NCA};
       const StagePlane sb = {a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
                              pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16};
-      stage_patches(sa, sb, threadIdx.x);
+      stage_patches<WIDE8 ? 2 * kThreads : kThreads>(sa, sb, threadIdx.x);
       TICK(8)
     }
     if (threadIdx.x == 0) {
@@ -3354,6 +3365,11 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
         } else {
           p = __builtin_amdgcn_readfirstlane(a.order[ti]);
         }
+      }
+      int half = 0;   // WIDE8: which column half of row tile p this job is
+      if constexpr (WIDE8) {
+        half = p >> 8;
+        p &= 255;
       }
       if (LAZY && redo_phase) {
         // What has to be in memory, now that the maximum is final: the tiles that
@@ -3955,6 +3971,52 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
           rows(std::integral_constant<int, kKs4>{});
         if (kKs5 > kKs4 && col_skip == kKs5 && !abandoned && yb0 < yhi)
           rows(std::integral_constant<int, kKs5>{});
+      } else if constexpr (WIDE8) {
+        auto half_rows = [&](auto h_const) {
+          constexpr int H = decltype(h_const)::value;
+          constexpr int Q0 = H ? NQH : 0, Q1 = H ? NQ : NQH;
+          // A chunks with a pair (ca, c) whose column tile ca - c + kCq0 lies in [Q0, Q1)
+          constexpr int CA0 = Q0 - kCq0 > 0 ? Q0 - kCq0 : 0;
+          constexpr int CA1 = Q1 - 1 < NCA - 1 ? Q1 - 1 : NCA - 1;
+          constexpr int NC = CA1 - CA0 + 1;
+          int n_pairs = 0;
+          for (int yy = ylo; yy < yhi; yy += 4) {
+            unsigned d[kNDW];
+            v4i af[NC];
+#pragma unroll
+            for (int j = 0; j < kNDW; ++j) d[j] = *reinterpret_cast<const unsigned*>(bp + 4 * j);
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+              af[i] = *reinterpret_cast<const v4i*>(ap + 16 * (CA0 + i));
+#pragma unroll
+            for (int c = 0; c < NCE; ++c) {
+              v4i bf;
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                bf[k] = static_cast<int>(
+                    __builtin_amdgcn_alignbyte(d[4 * c + k + 1], d[4 * c + k], sh));
+#pragma unroll
+              for (int i = 0; i < NC; ++i) {
+                const int q = CA0 + i - c + kCq0;
+                if (q >= Q0 && q < Q1)
+                  acc[q - Q0] =
+                      __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf, acc[q - Q0], 0, 0, 0);
+              }
+            }
+            ap += 4 * a.pa;
+            bp += 4 * a.pb;
+          }
+#pragma unroll
+          for (int c = 0; c < NCE; ++c)
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+              n_pairs += (CA0 + i - c + kCq0 >= Q0 && CA0 + i - c + kCq0 < Q1) ? 1 : 0;
+          mfma_issued += (long long)((yhi - ylo + 3) / 4) * n_pairs;
+        };
+        if (half)
+          half_rows(std::integral_constant<int, 1>{});
+        else
+          half_rows(std::integral_constant<int, 0>{});
       } else if constexpr (NCA > 10 && NCA <= SFM_WIDE_BPREFETCH_MAX) {
         v4i afA[NCA], afB[NCA];
         unsigned dA[kNDW], dB[kNDW];
@@ -4255,6 +4317,8 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
             }
           };
           static_assert(NQ <= 30, "extend the accumulator switch");
+          const int qb_half = WIDE8 ? half * NQH : 0;
+          const int qe_half = WIDE8 ? min(NQ, qb_half + NQH) : NQ;
           // One trip: the column tiles q0 .. q0 + kT - 1 of the run that ends at hi.  REG:
           // the regime every lane of both tiles is in (0 L, 1 M, 2 R: scalar table bases,
           // 32-bit byte offsets, no selects) or 3 (the one or two tiles a regime boundary
@@ -4268,7 +4332,7 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
             constexpr int T = decltype(t_const)::value;
             int sv[T][4], gv[T][4][4], mLs[T], mRs[T], xw[T];
 #pragma unroll
-            for (int u = 0; u < T; ++u) acc_get(q0 + u, sv[u]);
+            for (int u = 0; u < T; ++u) acc_get(q0 + u - qb_half, sv[u]);
             if constexpr (REG == 3) {
 #pragma unroll
               for (int u = 0; u < T; ++u) {
@@ -4380,12 +4444,16 @@ __global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads : kThreads,
           // variant is wider than the patch -- take the per-lane code: their shifts are clamped)
           const int qc = min(Sx / 16, NQ);
           const int qR = min(max((Px + 14) / 16, qM1), qc);
-          run(std::integral_constant<int, 0>{}, 0, min(qL, qc));
-          run(std::integral_constant<int, 3>{}, min(qL, qc), min(qM0, qc));
-          run(std::integral_constant<int, 1>{}, min(qM0, qc), min(qM1, qc));
-          run(std::integral_constant<int, 3>{}, min(qM1, qc), qR);
-          run(std::integral_constant<int, 2>{}, qR, qc);
-          run(std::integral_constant<int, 3>{}, qc, NQ);
+          // (WIDE8: this job's column half only)
+          auto run_c = [&](auto reg_const, int lo, int hi) {
+            run(reg_const, max(lo, qb_half), min(hi, qe_half));
+          };
+          run_c(std::integral_constant<int, 0>{}, 0, min(qL, qc));
+          run_c(std::integral_constant<int, 3>{}, min(qL, qc), min(qM0, qc));
+          run_c(std::integral_constant<int, 1>{}, min(qM0, qc), min(qM1, qc));
+          run_c(std::integral_constant<int, 3>{}, min(qM1, qc), qR);
+          run_c(std::integral_constant<int, 2>{}, qR, qc);
+          run_c(std::integral_constant<int, 3>{}, qc, NQ);
         }
       };
       if (RAW) {
@@ -4971,6 +5039,8 @@ int launch_pipe(const MfmaArgs& a, int grid, hipStream_t st) {
 
 template <int NCA, int NCE, int MODE>
 int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
+  // (search-window variants: eight waves per workgroup, see WIDE8 in the kernel)
+  constexpr int kThreadsV = (NCA > 10 && SFM_WIDE_HALVES) ? 2 * kThreads : kThreads;
   static size_t attr_set = 0;
   if (lds > attr_set) {
     SFM_HIP_CHECK(hipFuncSetAttribute(
@@ -4985,7 +5055,7 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   if (per_cu == 0 || per_cu_lds != lds) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &n, reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE, MODE>), kThreads,
+            &n, reinterpret_cast<const void*>(&xcorr_mfma_kernel<NCA, NCE, MODE>), kThreadsV,
             lds) != hipSuccess || n < 1)
       n = lds * 2 <= 160 * 1024 ? 2 : 1;
     per_cu = n;
@@ -5008,7 +5078,7 @@ int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   }
   sfm::prof_begin(sfm::kProfXcorr, st);
   hipLaunchKernelGGL((xcorr_mfma_kernel<NCA, NCE, MODE>), dim3(grid),
-                     dim3(kThreads), lds, st, a);
+                     dim3(kThreadsV), lds, st, a);
   sfm::prof_end(sfm::kProfXcorr, st);
   sfm::prof_clock(sfm::kProfXcorr, a.clk, st, 5);
   SFM_LAUNCH_CHECK();
@@ -5118,6 +5188,16 @@ int fill_common(const SfmXcorrDesc* d, const Layout& l, MfmaArgs* ap) {
     return sfm::fail(SFM_ERR_INVALID, "too many dy tiles");
   a.n_order = static_cast<int>(work.size());
   for (size_t i = 0; i < work.size(); ++i) a.order[i] = work[i].second;
+  if (l.nca > 10 && SFM_WIDE_HALVES) {
+    // search-window variants: a tile job is one column half of a row tile (p | half << 8)
+    if (2 * work.size() > sizeof(a.order) / sizeof(a.order[0]))
+      return sfm::fail(SFM_ERR_INVALID, "too many dy tiles");
+    a.n_order = static_cast<int>(2 * work.size());
+    for (size_t i = 0; i < work.size(); ++i) {
+      a.order[2 * i] = work[i].second;
+      a.order[2 * i + 1] = work[i].second | (1 << 8);
+    }
+  }
   int load[kWaves] = {0, 0, 0, 0};
   for (auto& t : work) {
     int best = 0;
