@@ -3980,14 +3980,20 @@ __global__ void __launch_bounds__((MODE == kModePipe || (NCA > 10 && SFM_WIDE_HA
           constexpr int CA1 = Q1 - 1 < NCA - 1 ? Q1 - 1 : NCA - 1;
           constexpr int NC = CA1 - CA0 + 1;
           int n_pairs = 0;
-          for (int yy = ylo; yy < yhi; yy += 4) {
+          // (the A chunks of the next row group are requested behind this group's B dwords:
+          // two register sets, swapped by unrolling two groups per trip)
+          auto group = [&](const v4i* af, v4i* af_next) {
             unsigned d[kNDW];
-            v4i af[NC];
 #pragma unroll
             for (int j = 0; j < kNDW; ++j) d[j] = *reinterpret_cast<const unsigned*>(bp + 4 * j);
+            if (af_next) {
 #pragma unroll
-            for (int i = 0; i < NC; ++i)
-              af[i] = *reinterpret_cast<const v4i*>(ap + 16 * (CA0 + i));
+              for (int i = 0; i < NC; ++i)
+                af_next[i] = *reinterpret_cast<const v4i*>(ap + 4 * a.pa + 16 * (CA0 + i));
+            }
+            v4i afl[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) afl[i] = af[i];
 #pragma unroll
             for (int c = 0; c < NCE; ++c) {
               v4i bf;
@@ -4000,12 +4006,22 @@ __global__ void __launch_bounds__((MODE == kModePipe || (NCA > 10 && SFM_WIDE_HA
                 const int q = CA0 + i - c + kCq0;
                 if (q >= Q0 && q < Q1)
                   acc[q - Q0] =
-                      __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf, acc[q - Q0], 0, 0, 0);
+                      __builtin_amdgcn_mfma_i32_16x16x64_i8(afl[i], bf, acc[q - Q0], 0, 0, 0);
               }
             }
             ap += 4 * a.pa;
             bp += 4 * a.pb;
+          };
+          v4i afA[NC], afB[NC];
+#pragma unroll
+          for (int i = 0; i < NC; ++i)
+            afA[i] = *reinterpret_cast<const v4i*>(ap + 16 * (CA0 + i));
+          int yy = ylo;
+          for (; yy + 4 < yhi; yy += 8) {
+            group(afA, afB);
+            group(afB, afA);
           }
+          if (yy < yhi) group(afA, nullptr);
 #pragma unroll
           for (int c = 0; c < NCE; ++c)
 #pragma unroll
