@@ -82,6 +82,9 @@
 #ifndef SFM_WIDE_HALVES
 #define SFM_WIDE_HALVES 1   // search-window variants: 8 waves per CU, a row tile as two column halves
 #endif
+#ifndef SFM_WIDE_WAVES
+#define SFM_WIDE_WAVES 8    // waves of the search-window variants' one workgroup per CU (8 or 12)
+#endif
 #ifndef SFM_WIDE_TRIP
 #define SFM_WIDE_TRIP 2
 #endif
@@ -2676,8 +2679,8 @@ __device__ __forceinline__ int next_patch(const MfmaArgs& a, int b, int* next_ld
 }
 
 template <int NCA, int NCE, int MODE>
-__global__ void __launch_bounds__((MODE == kModePipe || (NCA > 10 && SFM_WIDE_HALVES)) ? 2 * kThreads
-                                                                                       : kThreads,
+__global__ void __launch_bounds__(MODE == kModePipe ? 2 * kThreads
+                                  : (NCA > 10 && SFM_WIDE_HALVES) ? 64 * SFM_WIDE_WAVES : kThreads,
                                   (MODE == kModePipe || NCA > 10) ? 1 : 2) xcorr_mfma_kernel(MfmaArgs a) {
   // Search-window geometry (NCA > 10: pre patches 161 .. 320 wide against a post patch of up
   // to 160, processor/flow.py:577,792-803).  The pre patch alone is up to 119 KB of LDS, so a
@@ -2685,7 +2688,8 @@ __global__ void __launch_bounds__((MODE == kModePipe || (NCA > 10 && SFM_WIDE_HA
   // file: 512 registers per lane, the 25 .. 30 accumulator tiles of a row tile in the upper
   // half (the compiler places them in AGPRs), the 15 .. 20 A fragments double-buffered in the
   // lower one (the fragments of the next row group are in flight while the 165 .. 220 matrix
-  // instructions of this one issue).  kModeGeneral semantics; no pruning.
+  // instructions of this one issue).  kModeGeneral semantics; no pruning.  (That is the FIRST
+  // form, SFM_WIDE_HALVES=0; the default is the second one, WIDE8 below.)
   // Cross-patch pipeline (kModePipe; everything else is kModeSameExactLazyG).  The other
   // modes run two workgroups of four waves per CU, each on its own patch, and every patch
   // has phases in which its four waves wait for each other: the staging round trip, the
@@ -2784,7 +2788,7 @@ __global__ void __launch_bounds__((MODE == kModePipe || (NCA > 10 && SFM_WIDE_HA
   const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
   // Zero the whole LDS image once: pad rows / margins stay zero afterwards.
   for (int i = threadIdx.x * 16; i < (PIPE ? 2 * a.slot_bytes : a.a_bytes + a.b_bytes);
-       i += ((PIPE || WIDE8) ? 2 : 1) * kThreads * 16)
+       i += (PIPE ? 2 * kThreads : WIDE8 ? 64 * SFM_WIDE_WAVES : kThreads) * 16)
     *reinterpret_cast<v4i*>(smem + i) = v4i{0, 0, 0, 0};
   if constexpr (PIPE) {
     __syncthreads();
@@ -3165,7 +3169,7 @@ __global__ void __launch_bounds__((MODE == kModePipe || (NCA > 10 && SFM_WIDE_HA
                              pp.c[0], A_lds, a.pa, kPadTop, 0, NCA};
       const StagePlane sb = {a.img[1], bytes1, a.ishape[1][1], pp.y0[1], pp.x0[1], Qy, Qx,
                              pp.c[1], B_lds, a.pb, 0, a.ml, (Qx + 15) / 16};
-      stage_patches<WIDE8 ? 2 * kThreads : kThreads>(sa, sb, threadIdx.x);
+      stage_patches<WIDE8 ? 64 * SFM_WIDE_WAVES : kThreads>(sa, sb, threadIdx.x);
       TICK(8)
     }
     if (threadIdx.x == 0) {
@@ -4012,16 +4016,26 @@ __global__ void __launch_bounds__((MODE == kModePipe || (NCA > 10 && SFM_WIDE_HA
             ap += 4 * a.pa;
             bp += 4 * a.pb;
           };
-          v4i afA[NC], afB[NC];
+          if constexpr (SFM_WIDE_WAVES <= 8) {
+            v4i afA[NC], afB[NC];
 #pragma unroll
-          for (int i = 0; i < NC; ++i)
-            afA[i] = *reinterpret_cast<const v4i*>(ap + 16 * (CA0 + i));
-          int yy = ylo;
-          for (; yy + 4 < yhi; yy += 8) {
-            group(afA, afB);
-            group(afB, afA);
+            for (int i = 0; i < NC; ++i)
+              afA[i] = *reinterpret_cast<const v4i*>(ap + 16 * (CA0 + i));
+            int yy = ylo;
+            for (; yy + 4 < yhi; yy += 8) {
+              group(afA, afB);
+              group(afB, afA);
+            }
+            if (yy < yhi) group(afA, nullptr);
+          } else {   // three waves per SIMD (170 registers each): no second fragment set
+            for (int yy = ylo; yy < yhi; yy += 4) {
+              v4i af1[NC];
+#pragma unroll
+              for (int i = 0; i < NC; ++i)
+                af1[i] = *reinterpret_cast<const v4i*>(ap + 16 * (CA0 + i));
+              group(af1, nullptr);
+            }
           }
-          if (yy < yhi) group(afA, nullptr);
 #pragma unroll
           for (int c = 0; c < NCE; ++c)
 #pragma unroll
@@ -5056,7 +5070,7 @@ int launch_pipe(const MfmaArgs& a, int grid, hipStream_t st) {
 template <int NCA, int NCE, int MODE>
 int launch_one(const MfmaArgs& a, int grid, size_t lds, hipStream_t st) {
   // (search-window variants: eight waves per workgroup, see WIDE8 in the kernel)
-  constexpr int kThreadsV = (NCA > 10 && SFM_WIDE_HALVES) ? 2 * kThreads : kThreads;
+  constexpr int kThreadsV = (NCA > 10 && SFM_WIDE_HALVES) ? 64 * SFM_WIDE_WAVES : kThreads;
   static size_t attr_set = 0;
   if (lds > attr_set) {
     SFM_HIP_CHECK(hipFuncSetAttribute(
