@@ -690,6 +690,33 @@ def aux_legs(dev, seed, only=None):
     sec = timed(lambda: calc3.flow_field(v, w, (80, 80, 80), (40, 40, 40), batch_size=64), 3)
     line('xcorr_fft_3d', 'fft3 kernels (sfm_fft_own.hip)', 27 * (2 * 80 ** 3 * 4 + 20), sec, 4,
          patches=27, workload='float32 160^3 pair, patch 80^3 step 40 (BASELINE configs[4] patch size)')
+  if only in (None, 'xcorr_search_window'):
+    # search-window call of EstimateMissingFlow (processor/flow.py:577,792-803): pre patches
+    # of 160 + 2 x 40 against 160 post patches on the matrix cores (kModeGeneral, wide
+    # variant) -- an MFMA-bound line; the FFT form of the same call is timed beside it
+    n2 = 4096
+    from tests.util import em_texture
+    base = em_texture(rng, (n2 + 16, n2 + 16))
+    a8 = torch.from_numpy(np.ascontiguousarray(base[8:8 + n2, 8:8 + n2])).to(dev)
+    b8 = torch.from_numpy(np.ascontiguousarray(base[10:10 + n2, 5:5 + n2])).to(dev)
+    pw = PATCH + 2 * 40
+    calc_m = flow_field.JAXMaskedXCorrWithStatsCalculator()
+    calc_f = flow_field.JAXMaskedXCorrWithStatsCalculator(method=_abi.XCORR_FFT)
+    sec = timed(lambda: calc_m.flow_field(a8, b8, pw, STEP, batch_size=BATCH,
+                                          post_patch_size=PATCH), 3)
+    sec_f = timed(lambda: calc_f.flow_field(a8, b8, pw, STEP, batch_size=BATCH,
+                                            post_patch_size=PATCH), 2)
+    npw = ((n2 - PATCH) // STEP + 1) ** 2
+    ops = 2.0 * pw * pw * PATCH * PATCH * npw
+    out.append({'leg': 'xcorr_search_window', 'kernel': 'xcorr_mfma_kernel<15,11,general> (+ mfma_prep_wide_kernel)',
+                'bound': 'mfma', 'achieved': round(ops / sec / 1e12, 1), 'peak': PEAK_I8_TOPS,
+                'unit': 'TFLOP/s', 'frac': round(ops / sec / 1e12 / PEAK_I8_TOPS, 4),
+                'ms': round(sec * 1e3, 3), 'traffic': None, 'calls_in_counted_process': 4,
+                'patches': npw, 'us_per_patch': round(sec / npw * 1e6, 3),
+                'fft_form_us_per_patch': round(sec_f / npw * 1e6, 3),
+                'speedup_over_fft_form': round(sec_f / sec, 2),
+                'workload': 'uint8 4096^2 pair, pre patch %d post patch %d step 40 (whole flow_field() '
+                            'call: prep + correlation + peaks; no pruning in this mode)' % (pw, PATCH)})
   # mesh steps: FIRE, 200 iterations of one chunk
   iters = 200
   for name, shape, force, stride, fl in (
