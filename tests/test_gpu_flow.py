@@ -745,6 +745,54 @@ def test_mfma_random_geometry_fuzz(gpu, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(10))
+def test_search_window_random_geometry_fuzz(gpu, seed):
+  """Random search-window geometries on the wide variants of the int8 kernel -- pre patch
+  161 .. 320 wide and 32 .. 320 tall (any parity, non multiples of 16), post patch up to 160
+  wide and no larger than the pre patch, images barely larger than the patch, starts on and
+  beyond every border (clamped), per-patch and fixed means, batches of 1 .. 40 -- against the
+  oracle (float64 surfaces: the exact arbiter of near-equal candidates): vectors and NaN
+  pattern identical, ratio to 1e-4, sharpness by SURVEY 8c's criterion; and the FFT form of
+  the same call agrees with the matrix-core form on the vectors."""
+  from scipy import ndimage
+  from sofima_amd import flow_field
+  rng = np.random.default_rng(7000 + seed)
+  px = int(rng.integers(161, 321))
+  py = int(rng.integers(32, 321))
+  if py * px > 140 * 1024:
+    py = (140 * 1024) // px
+  qx = int(rng.integers(16, 161))
+  qy = int(rng.integers(16, min(py, 160) + 1))
+  h, w = py + int(rng.integers(0, 120)), px + int(rng.integers(0, 120))
+  base = ndimage.gaussian_filter(rng.standard_normal((h + 12, w + 12)), float(rng.uniform(1.2, 2.5)))
+  base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+  dy, dx = int(rng.integers(-5, 6)), int(rng.integers(-5, 6))
+  pre = np.ascontiguousarray(base[6:6 + h, 6:6 + w])
+  post = np.ascontiguousarray(base[6 + dy:6 + dy + h, 6 + dx:6 + dx + w])
+  b = int(rng.integers(1, 41))
+  starts = np.stack([rng.integers(-8, h - py + 9, b), rng.integers(-8, w - px + 9, b)], axis=1)
+  starts[0] = (0, 0)
+  starts[-1] = (h - py, w - px)
+  post_starts = starts + np.array([(py - qy) // 2, (px - qx) // 2])
+  mean = None if seed % 2 == 0 else 120.0
+  geo = str((py, px, qy, qx, h, w, b, mean))
+  want = flow_oracle.batched_xcorr_peaks(pre, post, None, None, (py, px), starts, mean, 2, 0.5, 5,
+                                         (qy, qx), post_starts, workers=8)
+  kw = dict(min_distance=2, threshold_rel=0.5, peak_radius=5, post_patch_size=(qy, qx),
+            post_starts=post_starts)
+  got = flow_field.batched_xcorr_peaks(pre, post, None, None, (py, px), starts, mean,
+                                       method=2, **kw)
+  fft = flow_field.batched_xcorr_peaks(pre, post, None, None, (py, px), starts, mean,
+                                       method=3, **kw)
+  np.testing.assert_array_equal(np.isnan(got), np.isnan(want), err_msg=geo)
+  np.testing.assert_array_equal(got[:, :2], want[:, :2], err_msg=geo)
+  np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-4, atol=1e-6, err_msg=geo)
+  ok = np.isfinite(want[:, 2])
+  check_sharpness(got[ok, 2], want[ok, 2])
+  np.testing.assert_array_equal(fft[:, :2], got[:, :2], err_msg=geo)
+
+
+@pytest.mark.gpu
 def test_concurrent_python_threads(gpu):
   """The boundary is re-entrant: flow on the matrix cores, the FFT
   form and a mesh relaxation called from four threads at once give the results
