@@ -733,7 +733,8 @@ def aux_legs(dev, seed, only=None):
     kw = {'mesh_force': force} if force is not None else {}
     sec = timed(lambda: mesh.relax_mesh(x0, prev, cfg, **kw), 2)
     nodes = int(np.prod(shape[1:]))
-    line(name, 'integrate_kernel<3>' if force is not None else 'integrate_shared2d_kernel',
+    line(name, 'integrate_march3d_kernel<512> + advance_kernel<3>' if force is not None
+         else 'integrate_shared2d_kernel',
          nodes * iters * fl * 4, sec, 3, nodes=nodes, us_per_step=round(sec / iters * 1e6, 2),
          node_updates_per_s=round(nodes * iters / sec, 0), state=list(shape),
          bytes_per_node_update=fl * 4)

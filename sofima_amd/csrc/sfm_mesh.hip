@@ -37,6 +37,11 @@ namespace {
 typedef unsigned long long u64;
 constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 1024;
+// Volumes below this many nodes keep integrate_kernel<3>: a column of planes is a
+// serial chain of barriers, and a small volume has too few columns to fill the CUs
+// (measured: [3,1,64^3] 30 us per step against 48-60, [3,8,48^3] 85 against 79-85,
+// [3,4,100^3] 310 against 218, [3,1,160^3] 322 against 209).
+constexpr long long kMarch3dMinNodes = 1000000;
 // Minimum waves per SIMD the register allocator must leave room for
 // (__launch_bounds__ second argument).  Measured on [3,4,100^3] / [2,64,204^2]:
 // the volumetric stencil takes 180 VGPRs unconstrained (2 waves per SIMD, 369 us
@@ -687,6 +692,302 @@ integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
   }
   if (p.fire) {
     block_sum(part, 7, lds);
+    if (threadIdx.x == 0)
+      for (int i = 0; i < kNP; ++i) partials[blockIdx.x * kNP + i] = part[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// integrate_kernel<3> for the 13 default links, every spring evaluated ONCE.
+//
+// integrate_kernel<3> evaluates the 26 springs of a node from the node's own side
+// (2 500 VALU instructions per node: the kernel runs at 0.14 of the HBM roofline).
+// A spring seen from its two ends is the same float expression: with o = n - off,
+//   far side of n  : d = x[n] - x[o] + rest        (df at node n)
+//   near side of o : d = x[o + off] - x[o] + rest  (dn at node o)
+// so the owner of a spring can publish the force and the other end can read it.
+// Here a workgroup owns a column of the volume -- a tile of the (y, x) plane, T
+// threads = tile positions INCLUDING one halo ring where a neighbour tile exists --
+// and marches along z.  A node (thread) owns the 13 springs that stay in its plane
+// or go UP:
+//   links 0, 1, 3, 4            (dz = 0)   near form, partner in the same plane
+//   links 2, 5-9, 11, 12        (dz = +1)  near form, partner in plane z + 1
+//   link 10 = (1, 1, -1)                   FAR form at the lower end: the node at
+//                                          (x, y, z) owns the spring to (x-1, y-1, z+1)
+// so every owned spring needs the positions of planes z and z + 1 only.  The four
+// in-plane forces go to LDS (`P`, read by the partners after one barrier), the nine
+// upward ones to LDS (`U`, read by the nodes of the NEXT plane), and a node adds its 26
+// terms in the reference's link order (mesh.py:271-277: += far side, -= near side,
+// link by link) from its own registers, P and U: the same floats in the same order as
+// node_force_default3d -- `a` and (without FIRE) every later state are bit-identical.
+// The FIRE sums are added in a different order (a thread's column, then the
+// workgroup tree) like those of the tiled in-plane integrator.
+// Halo threads evaluate their springs (a value any tile computes is the same float)
+// and take no part in the sums; a chunk of planes starts with one extra plane that
+// only produces U.  LDS: 39 floats per thread.
+// ---------------------------------------------------------------------------
+struct March3dArgs {
+  int txh, tyh;   // thread tile, the halo ring included (core = txh - 2 by tyh - 2)
+  int ntx, nty;   // tiles per plane
+  int cols;       // columns = B * nty * ntx
+  int run;        // planes per workgroup: workgroup w owns planes [w * run, (w + 1) * run)
+                  // of the sequence (column 0: z = 0 .. Z-1, column 1: ...)
+};
+
+// Owned spring of link (DX, DY, DZ) at node n.  FAR = false: the near form, partner
+// n + off; FAR = true: the far form, partner n - off.  A missing partner is replaced
+// by the node itself (d = rest; the result is masked where it is used).
+// float at byte offset `b` (32 bits: an SGPR base + VGPR offset load)
+__device__ __forceinline__ float ld_b(const float* __restrict__ base, unsigned b) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + b);
+}
+
+template <int DX, int DY, int DZ, bool FAR, bool PREFER>
+__device__ __forceinline__ void march_spring(const float* __restrict__ x0,
+                                             const float* __restrict__ x1,
+                                             const float* __restrict__ x2, int syb, int szb,
+                                             const DefLinks3& dl, unsigned nb, bool ok,
+                                             const float* self, float* f) {
+  constexpr int kc = SFM_CLASS3(DX, DY, DZ);
+  const int offb = (DX) * 4 + (DY) * syb + (DZ) * szb;  // bytes
+  const unsigned mb = nb + static_cast<unsigned>(ok ? (FAR ? -offb : offb) : 0);
+  const float rest[3] = {dl.rest(DX, 0), dl.rest(DY, 1), dl.rest(DZ, 2)};
+  const float o[3] = {ld_b(x0, mb), ld_b(x1, mb), ld_b(x2, mb)};
+  float d[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d[c] = FAR ? self[c] - o[c] + rest[c] : o[c] - self[c] + rest[c];
+  spring_xyz<DX, DY, DZ>(d, dl.l0c[kc], dl.nkc[kc], PREFER ? 1 : 0, f);
+}
+
+template <int T>
+__device__ void block_sum_t(float* vals, int nv, float* lds) {
+  for (int i = 0; i < nv; ++i) lds[i * T + threadIdx.x] = vals[i];
+  __syncthreads();
+  for (int s = T / 2; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s)
+      for (int i = 0; i < nv; ++i)
+        lds[i * T + threadIdx.x] = lds[i * T + threadIdx.x] + lds[i * T + threadIdx.x + s];
+    __syncthreads();
+  }
+  for (int i = 0; i < nv; ++i) vals[i] = lds[i * T];
+  __syncthreads();
+}
+
+// v where the lane's mask is all ones, +0.0f where it is zero
+__device__ __forceinline__ float keep_if(float v, unsigned mask) {
+  return __uint_as_float(__float_as_uint(v) & mask);
+}
+
+#ifndef SFM_MARCH_LB
+#define SFM_MARCH_LB(T) 4  // waves per SIMD: 1, 2, 4 workgroups of 1024, 512, 256 per CU
+#endif
+template <int T, bool PREFER>
+__global__ void __launch_bounds__(T, SFM_MARCH_LB(T))
+integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
+                         float* __restrict__ a, const float* __restrict__ prev,
+                         MeshParams p, const Scalars* __restrict__ scal,
+                         float fixed_cap, float* __restrict__ partials, March3dArgs g) {
+  extern __shared__ float march_lds[];
+  float* P = march_lds;           // [4 links][3][T]  in-plane forces of this plane
+  float* U = march_lds + 12 * T;  // [9 links][3][T]  upward forces of the plane below
+  const int tid = threadIdx.x;
+  float dt, alpha, cap;
+  if (p.fire) {
+    dt = scal->dt;
+    alpha = scal->alpha;
+    cap = scal->cap;
+  } else {
+    dt = p.vv_dt;
+    alpha = 0.f;
+    cap = fixed_cap;
+  }
+  const float hdtg = (0.5f * dt) * p.gamma;
+  const float fact0 = 1.0f / (1.0f + hdtg);
+  const float fact1 = 1.0f - hdtg;
+  const float hdt = 0.5f * dt;
+  const DefLinks3 dl(p);
+  const int W = g.txh;
+  const int tx = tid % W, ty = tid / W;
+  const int cxw = g.txh - 2, cyw = g.tyh - 2;
+  const int sy = p.X, sz = p.X * p.Y;
+  const int syb = sy * 4, szb = sz * 4;  // bytes
+  const unsigned N = static_cast<unsigned>(p.N);
+  const float* __restrict__ x0 = x;
+  const float* __restrict__ x1 = x + N;
+  const float* __restrict__ x2 = x + 2 * (size_t)N;
+  float part[kNP];
+  for (int i = 0; i < kNP; ++i) part[i] = 0.f;
+  const long long all_planes = (long long)g.cols * p.Z;
+  const long long pos1 = min(all_planes, (long long)(blockIdx.x + 1) * g.run);
+  for (long long pos = (long long)blockIdx.x * g.run; pos < pos1;) {
+    int r = static_cast<int>(pos / p.Z);
+    const int z0 = static_cast<int>(pos - (long long)r * p.Z);
+    const int z1 = static_cast<int>(min<long long>(p.Z, z0 + (pos1 - pos)));
+    pos += z1 - z0;
+    const int tix = r % g.ntx;
+    r /= g.ntx;
+    const int tiy = r % g.nty;
+    const int b = r / g.nty;
+    const int xi = tix * cxw - 1 + tx, yi = tiy * cyw - 1 + ty;
+    const bool act = ty < g.tyh && xi >= 0 && xi < p.X && yi >= 0 && yi < p.Y;
+    const bool core = act && tx >= 1 && tx < g.txh - 1 && ty >= 1 && ty < g.tyh - 1;
+    const bool own = yi >= p.own_y0 && yi < p.own_y1;
+    const bool xm = xi > 0, xp = xi + 1 < p.X, ym = yi > 0, yp = yi + 1 < p.Y;
+    // the near side of a link counts where its partner exists
+    const unsigned kxp = xp ? ~0u : 0u, kxm = xm ? ~0u : 0u, kyp = yp ? ~0u : 0u,
+                   kym = ym ? ~0u : 0u;
+    int z = z0 > 0 ? z0 - 1 : 0;
+    unsigned n = act ? static_cast<unsigned>(xi + sy * yi) + static_cast<unsigned>(sz) *
+                           static_cast<unsigned>(b * p.Z + z)
+                     : 0u;
+    float self[3] = {0.f, 0.f, 0.f};
+    unsigned nb = n * 4u;
+    if (act) {
+      self[0] = ld_b(x0, nb);
+      self[1] = ld_b(x1, nb);
+      self[2] = ld_b(x2, nb);
+    }
+    // A slot nobody owns (outside the mesh) and, at the bottom of the volume, the
+    // plane below read as +0: the far side of a link whose owner does not exist.
+#pragma unroll
+    for (int k = 0; k < 39; ++k) march_lds[k * T + tid] = 0.f;
+    for (; z < z1; ++z, n += sz, nb += szb) {
+      const bool zp = z + 1 < p.Z;
+      const unsigned kzp = zp ? ~0u : 0u;
+      const bool sum = z >= z0;
+      float up[9][3];   // links 2, 5, 6, 7, 8, 9, 10 (far form), 11, 12
+      float next[3] = {self[0], self[1], self[2]};
+      if (act && sum) {
+        float fin[4][3];  // links 0, 1, 3, 4
+        march_spring<1, 0, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp, self, fin[0]);
+        march_spring<0, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, yp, self, fin[1]);
+        march_spring<1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp && yp, self, fin[2]);
+        march_spring<-1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xm && yp, self, fin[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) P[(k * 3 + c) * T + tid] = fin[k][c];
+      }
+      __syncthreads();  // P of this plane; U of the plane below
+      if (act) {
+        if (zp) {
+          next[0] = ld_b(x0, nb + szb);
+          next[1] = ld_b(x1, nb + szb);
+          next[2] = ld_b(x2, nb + szb);
+        }
+        {
+          // link 2: the partner is this column's next node
+          constexpr int kc = SFM_CLASS3(0, 0, 1);
+          const float rest[3] = {dl.rest(0, 0), dl.rest(0, 1), dl.rest(1, 2)};
+          float d[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) d[c] = next[c] - self[c] + rest[c];
+          spring_xyz<0, 0, 1>(d, dl.l0c[kc], dl.nkc[kc], PREFER ? 1 : 0, up[0]);
+        }
+        march_spring<1, 0, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp && zp, self, up[1]);
+        march_spring<-1, 0, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xm && zp, self, up[2]);
+        march_spring<0, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, yp && zp, self, up[3]);
+        march_spring<0, -1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, ym && zp, self, up[4]);
+        march_spring<1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp && yp && zp, self, up[5]);
+        march_spring<1, 1, -1, true, PREFER>(x0, x1, x2, syb, szb, dl, nb, xm && ym && zp, self, up[6]);
+        march_spring<1, -1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp && ym && zp, self, up[7]);
+        march_spring<-1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xm && yp && zp, self, up[8]);
+        // a spring without partner counts as +0 on both sides
+        {
+          const unsigned k1 = kxp & kzp, k2 = kxm & kzp, k3 = kyp & kzp, k4 = kym & kzp;
+          const unsigned k5 = k1 & kyp, k6 = k2 & kym, k7 = k1 & kym, k8 = k2 & kyp;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            up[0][c] = keep_if(up[0][c], kzp);
+            up[1][c] = keep_if(up[1][c], k1);
+            up[2][c] = keep_if(up[2][c], k2);
+            up[3][c] = keep_if(up[3][c], k3);
+            up[4][c] = keep_if(up[4][c], k4);
+            up[5][c] = keep_if(up[5][c], k5);
+            up[6][c] = keep_if(up[6][c], k6);
+            up[7][c] = keep_if(up[7][c], k7);
+            up[8][c] = keep_if(up[8][c], k8);
+          }
+        }
+        if (core && sum) {
+          float acc[3] = {0.f, 0.f, 0.f};
+          // link by link: += the far side (owned by the node at n - off), -= the near side
+#define SFM_TERM(FAR_PTR, FAR_IDX, NEAR_EXPR)                                            \
+  _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                       \
+    acc[c] = acc[c] + (FAR_PTR)[c * T + (FAR_IDX)];                                      \
+    acc[c] = acc[c] - (NEAR_EXPR);                                                      \
+  }
+          const unsigned kxpyp = kxp & kyp, kxmyp = kxm & kyp;
+          // clang-format off
+          SFM_TERM(P + 0 * 3 * T, tid - 1,     keep_if(P[(0 * 3 + c) * T + tid], kxp))    // 0  ( 1, 0, 0)
+          SFM_TERM(P + 1 * 3 * T, tid - W,     keep_if(P[(1 * 3 + c) * T + tid], kyp))    // 1  ( 0, 1, 0)
+          SFM_TERM(U + 0 * 3 * T, tid,         up[0][c])                   // 2  ( 0, 0, 1)
+          SFM_TERM(P + 2 * 3 * T, tid - 1 - W, keep_if(P[(2 * 3 + c) * T + tid], kxpyp))  // 3  ( 1, 1, 0)
+          SFM_TERM(P + 3 * 3 * T, tid + 1 - W, keep_if(P[(3 * 3 + c) * T + tid], kxmyp))  // 4  (-1, 1, 0)
+          SFM_TERM(U + 1 * 3 * T, tid - 1,     up[1][c])                   // 5  ( 1, 0, 1)
+          SFM_TERM(U + 2 * 3 * T, tid + 1,     up[2][c])                   // 6  (-1, 0, 1)
+          SFM_TERM(U + 3 * 3 * T, tid - W,     up[3][c])                   // 7  ( 0, 1, 1)
+          SFM_TERM(U + 4 * 3 * T, tid + W,     up[4][c])                   // 8  ( 0,-1, 1)
+          SFM_TERM(U + 5 * 3 * T, tid - 1 - W, up[5][c])                   // 9  ( 1, 1, 1)
+          // 10 ( 1, 1,-1): the far side is this node's own far-form spring, the near
+          // side is owned by the node at (x+1, y+1) of the plane below
+          _Pragma("unroll") for (int c = 0; c < 3; ++c) {
+            acc[c] = acc[c] + up[6][c];
+            acc[c] = acc[c] - U[(6 * 3 + c) * T + tid + 1 + W];
+          }
+          SFM_TERM(U + 7 * 3 * T, tid - 1 + W, up[7][c])                   // 11 ( 1,-1, 1)
+          SFM_TERM(U + 8 * 3 * T, tid + 1 - W, up[8][c])                   // 12 (-1, 1, 1)
+          // clang-format on
+#undef SFM_TERM
+          // ---- integrate_kernel's node update ----
+          float vn[3];
+          float a2 = 0.f, v2 = 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float xv = self[c];
+            float f = acc[c];
+            if (p.has_prev) f = f + prev_pull(xv, ld_b(prev + c * (size_t)N, nb), p.neg_k0, cap);
+            float* ac = a + c * (size_t)N;
+            float* vc = v + c * (size_t)N;
+            const float a_old = ld_b(ac, nb);
+            vn[c] = fact0 * (ld_b(vc, nb) * fact1 + hdt * (a_old + f));
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(ac) + nb) = f;
+            acc[c] = f;
+            a2 = a2 + f * f;
+            v2 = v2 + vn[c] * vn[c];
+            if (p.fire && own) {
+              part[0] = part[0] + f * vn[c];
+              part[1 + c] = part[1 + c] + xv;
+            }
+          }
+          if (p.fire) {
+            const float a_norm = sqrtf(a2) + 1e-6f;
+            const float v_norm = sqrtf(v2);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              vn[c] = vn[c] + alpha * (acc[c] / a_norm * v_norm - vn[c]);
+              if (own) part[4 + c] = part[4 + c] + vn[c];
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(v + c * (size_t)N) + nb) = vn[c];
+        }
+      }
+      __syncthreads();  // every read of P and U is done
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) U[(k * 3 + c) * T + tid] = up[k][c];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) self[c] = next[c];
+    }
+  }
+  if (p.fire) {
+    __syncthreads();
+    block_sum_t<T>(part, 7, march_lds);
     if (threadIdx.x == 0)
       for (int i = 0; i < kNP; ++i) partials[blockIdx.x * kNP + i] = part[i];
   }
@@ -3145,6 +3446,116 @@ bool persist3d_enabled() {
   return e && e[0] == '1';
 }
 
+// Plan of integrate_march3d_kernel for a mesh: the thread tile (halo included) that
+// wastes the fewest thread slots, and enough chunks of planes to fill the CUs.
+struct March3dPlan {
+  March3dArgs g;
+  int T = 0;        // threads per workgroup (0: not applicable)
+  int grid = 0;
+  size_t lds = 0;
+};
+
+int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+March3dPlan plan_march3d(const MeshParams& p) {
+  March3dPlan best;
+  // SFM_MESH_MARCH3D: "0" off, "1" on for every default-link volume, else by size
+  const char* e = sfm::option("SFM_MESH_MARCH3D");
+  if (e && e[0] == '0') return best;
+  if (p.ncomp != 3 || !p.default_links || p.force_kind != SFM_FORCE_SPRINGS) return best;
+  const bool forced = e && e[0] == '1';
+  if (!forced && p.N < kMarch3dMinNodes) return best;
+  const char* te = sfm::option("SFM_MESH_MARCH3D_T");
+  const int t_only = te ? atoi(te) : 0;
+  if ((unsigned long long)p.N * 12ull >= (1ull << 32)) return best;  // 32-bit byte offsets
+  long long best_cost = 0;
+  for (int T : {1024, 512, 256}) {
+    if (t_only && T != t_only) continue;
+    for (int ntx = 1; ntx <= p.X; ++ntx) {
+      const int cxw = (p.X + ntx - 1) / ntx;
+      const int txh = cxw + 2;
+      if (txh * 3 > T) continue;
+      const int rows = T / txh;  // >= 3
+      const int nty = (p.Y + rows - 3) / (rows - 2);
+      const int tyh = (p.Y + nty - 1) / nty + 2;
+      // thread slots per plane; 16 waves in step at every barrier cost ~15 % against
+      // two workgroups of 8 (measured on [3,4,100^3]: 180 us with 12 288 slots per plane
+      // against 176 with 13 824)
+      const long long cost = (long long)ntx * nty * T * (T == 1024 ? 115 : 100);
+      if (best.T == 0 || cost < best_cost) {
+        best_cost = cost;
+        best.T = T;
+        best.g.txh = txh;
+        best.g.tyh = tyh;
+        best.g.ntx = ntx;
+        best.g.nty = nty;
+      }
+      if (cxw <= 8) break;  // narrower tiles only add halo
+    }
+  }
+  if (best.T == 0) return best;
+  best.lds = (size_t)39 * best.T * sizeof(float);
+  const int per_cu = std::max<int>(1, static_cast<int>(160 * 1024 / best.lds));
+  const long long cols = (long long)p.B * best.g.ntx * best.g.nty;
+  if (cols > 0x7fffffffLL / std::max(p.Z, 1)) {
+    best.T = 0;
+    return best;
+  }
+  const long long slots = std::min<long long>((long long)device_cus() * per_cu, kMaxBlocks);
+  const long long planes = cols * p.Z;
+  // every workgroup the same number of planes (a run that crosses into the next column
+  // pays one more start-up plane); not below 8 planes per workgroup
+  long long run = std::max<long long>((planes + slots - 1) / slots, std::min<long long>(8, p.Z));
+  const char* ze = sfm::option("SFM_MESH_MARCH3D_ZC");
+  if (ze && atoi(ze) > 0) run = atoi(ze);
+  if ((planes + run - 1) / run > kMaxBlocks) run = (planes + kMaxBlocks - 1) / kMaxBlocks;
+  best.g.cols = static_cast<int>(cols);
+  best.g.run = static_cast<int>(run);
+  best.grid = static_cast<int>((planes + run - 1) / run);
+  return best;
+}
+
+template <int T, bool PREFER>
+int launch_march3d_t(const March3dPlan& m, hipStream_t st, const float* x, float* v, float* a,
+                     const float* prev, const MeshParams& p, const Scalars* scal, float cap,
+                     float* partials) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SFM_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&integrate_march3d_kernel<T, PREFER>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 39 * T * static_cast<int>(sizeof(float))));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((integrate_march3d_kernel<T, PREFER>), dim3(m.grid), dim3(T), m.lds, st, x,
+                     v, a, prev, p, scal, cap, partials, m.g);
+  SFM_LAUNCH_CHECK();
+  return SFM_OK;
+}
+
+int launch_march3d(const March3dPlan& m, hipStream_t st, const float* x, float* v, float* a,
+                   const float* prev, const MeshParams& p, const Scalars* scal, float cap,
+                   float* partials) {
+#define SFM_MARCH(T)                                                                      \
+  return p.prefer ? launch_march3d_t<T, true>(m, st, x, v, a, prev, p, scal, cap, partials) \
+                  : launch_march3d_t<T, false>(m, st, x, v, a, prev, p, scal, cap, partials)
+  switch (m.T) {
+    case 1024: SFM_MARCH(1024);
+    case 512: SFM_MARCH(512);
+    default: SFM_MARCH(256);
+  }
+#undef SFM_MARCH
+}
+
 bool persistent_enabled() {
   const char* e = sfm::option("SFM_MESH_PERSISTENT");
   return !(e && e[0] == '0');
@@ -3515,7 +3926,9 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
     SFM_HIP_CHECK(hipMemsetAsync(w.tile_part, 0, (size_t)tiles.tiles * kNP * sizeof(u64), st));
     finish_mode = 2;
   }
-  const int part_rows = grid;
+  // default-link volumes: every spring once (integrate_march3d_kernel)
+  const March3dPlan march = (!tiled && !small) ? plan_march3d(p) : March3dPlan();
+  const int part_rows = march.T ? march.grid : grid;
   // One integration step, enqueued on `ls`.
   hipStream_t ls = st;
 #define SFM_STEP_DISPATCH(KERNEL, ...)                                       \
@@ -3642,8 +4055,14 @@ int sfm_mesh_relax_chunk(const SfmMeshDesc* d, SfmFireState* fire,
       if (int rc = eval_prev(ls)) return rc;
       if (int rc = external_force()) return rc;
       sfm::prof_begin(sfm::kProfMesh, ls);
-      SFM_STEP_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
-                        &w.scal[cur], cap0, w.partials);
+      if (march.T) {
+        if (int rc = launch_march3d(march, ls, d->x, d->v, d->a, prev_ptr, p, &w.scal[cur], cap0,
+                                    w.partials))
+          return rc;
+      } else {
+        SFM_STEP_DISPATCH(integrate_kernel, d->x, d->v, d->a, prev_ptr, p,
+                          &w.scal[cur], cap0, w.partials);
+      }
       sfm::prof_end(sfm::kProfMesh, ls);
       if (p.fire && p.drift_cols) {
         column_means(d->x, d->v);

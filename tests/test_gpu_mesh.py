@@ -818,3 +818,97 @@ def test_xcd_tile_order_is_bit_identical(gpu, drift):
     out.append((np.array(x), list(e), t))
   np.testing.assert_array_equal(out[0][0], out[1][0])
   assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+
+
+_MARCH_SHAPES = [(3, 1, 5, 7, 9), (3, 2, 40, 33, 70), (3, 17, 23, 100), (3, 1, 1, 30, 300),
+                 (3, 3, 30, 1, 40), (3, 2, 64, 64, 1), (3, 1, 9, 130, 61)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', _MARCH_SHAPES)
+@pytest.mark.parametrize('prefer', [False, True])
+def test_march3d_every_spring_once_is_bit_identical(gpu, shape, prefer):
+  """integrate_march3d_kernel (a workgroup marches a column of the volume along z;
+  every spring of the 13 default links is evaluated by ONE of its ends and read from
+  LDS by the other) against integrate_kernel<3> (every node evaluates its 26 springs).
+  A spring seen from its two ends is the same float expression and the terms are
+  added in the reference's link order (mesh.py:271-277), so the damped-Verlet chunk --
+  positions, velocities AND forces after 7 steps -- is bit-identical for every
+  workgroup size and plane run, with NaN targets, with and without the prev pull, on
+  meshes with an axis of length 1 and meshes wider than a tile."""
+  from sofima_amd import _abi, mesh
+  rng = np.random.default_rng(3)
+  x0 = (rng.standard_normal(shape) * 2).astype(np.float32)
+  v0 = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+  for has_prev in (True, False):
+    prev = None
+    if has_prev:
+      prev = (rng.standard_normal(shape) * 4).astype(np.float32)
+      prev[..., :1] = np.nan
+    cfg = mesh.IntegrationConfig(dt=0.05, gamma=0.5, k0=0.05, k=0.1, stride=(10, 10, 10),
+                                 num_iters=7, max_iters=7, stop_v_max=1e-9, dt_max=100,
+                                 start_cap=10.0, final_cap=10.0, fire=False,
+                                 prefer_orig_order=prefer)
+    run = lambda: [np.array(t) for t in mesh.velocity_verlet(
+        x0, v0, prev, cfg, cfg.start_cap, mesh_force=mesh.elastic_mesh_3d)]
+    with _abi.option('SFM_MESH_MARCH3D', 0):
+      want = run()
+    for t, zc in ((None, None), (256, 2), (512, 3), (1024, None)):
+      with _abi.option('SFM_MESH_MARCH3D', 1), _abi.option('SFM_MESH_MARCH3D_T', t), \
+          _abi.option('SFM_MESH_MARCH3D_ZC', zc):
+        got = run()
+      for name, w, g in zip('xva', want, got):
+        np.testing.assert_array_equal(w, g, err_msg=f'{name} T={t} run={zc} prev={has_prev}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 2, 40, 33, 70), (3, 1, 9, 130, 61), (3, 17, 23, 100)])
+def test_march3d_fire_vs_oracle(gpu, shape):
+  """With FIRE the z-march kernel adds the power / drift sums in another order (a
+  thread's column, then the workgroup tree): the relaxation agrees with the per-node
+  kernel to round-off and with the oracle at the tolerance of the other 3-D tests
+  (mesh.py:192-279, 371-521)."""
+  from sofima_amd import _abi, mesh
+  rng = np.random.default_rng(11)
+  x0 = (rng.standard_normal(shape) * 2).astype(np.float32)
+  prev = (rng.standard_normal(shape) * 4).astype(np.float32)
+  prev[..., :2] = np.nan
+  cfg = mesh.IntegrationConfig(dt=0.001, gamma=0.0, k0=0.05, k=0.1, stride=(10, 10, 10),
+                               num_iters=30, max_iters=30, stop_v_max=1e-9, dt_max=100,
+                               start_cap=1.0, final_cap=10.0, remove_drift=True)
+  run = lambda: mesh.relax_mesh(x0.copy(), prev.copy(), cfg, mesh_force=mesh.elastic_mesh_3d)
+  with _abi.option('SFM_MESH_MARCH3D', 0):
+    a = run()
+  with _abi.option('SFM_MESH_MARCH3D', 1):
+    b = run()
+  wx, we, wt = mesh_oracle.relax_mesh(x0.copy(), prev.copy(), cfg,
+                                      mesh_force=mesh_oracle.elastic_mesh_3d)
+  scale = np.abs(wx).max()
+  assert a[2] == b[2] == wt
+  np.testing.assert_allclose(np.array(b[0]), np.array(a[0]), atol=2e-4 * scale)
+  np.testing.assert_allclose(np.array(b[0]), wx, atol=1e-3 * scale)
+  np.testing.assert_allclose(b[1], we, rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_march3d_is_the_default_for_large_volumes(gpu):
+  """From 10^6 nodes on a default-link volume takes the z-march kernel without any
+  switch (the kernel trace under profiles/ names it): same damped-Verlet chunk as
+  with SFM_MESH_MARCH3D=0."""
+  import torch
+  from sofima_amd import _abi, mesh
+  shape = (3, 2, 80, 80, 80)
+  rng = np.random.default_rng(2)
+  dev = torch.device('cuda:0')
+  x0 = torch.from_numpy((rng.standard_normal(shape) * 2).astype(np.float32)).to(dev)
+  prev = torch.from_numpy((rng.standard_normal(shape) * 4).astype(np.float32)).to(dev)
+  cfg = mesh.IntegrationConfig(dt=0.05, gamma=0.5, k0=0.05, k=0.1, stride=(10, 10, 10),
+                               num_iters=5, max_iters=5, stop_v_max=1e-9, dt_max=100,
+                               start_cap=10.0, final_cap=10.0, fire=False)
+  run = lambda: [np.array(t) for t in mesh.velocity_verlet(
+      x0, torch.zeros_like(x0), prev, cfg, cfg.start_cap, mesh_force=mesh.elastic_mesh_3d)]
+  got = run()
+  with _abi.option('SFM_MESH_MARCH3D', 0):
+    want = run()
+  for w, g in zip(want, got):
+    np.testing.assert_array_equal(w, g)
