@@ -746,11 +746,15 @@ template <int DX, int DY, int DZ, bool FAR, bool PREFER>
 __device__ __forceinline__ void march_spring(const float* __restrict__ x0,
                                              const float* __restrict__ x1,
                                              const float* __restrict__ x2, int syb, int szb,
-                                             const DefLinks3& dl, unsigned nb, bool ok,
+                                             const DefLinks3& dl, unsigned nb, unsigned ok,
                                              const float* self, float* f) {
   constexpr int kc = SFM_CLASS3(DX, DY, DZ);
+  // (formed here from the two strides: thirteen hoisted offsets were spilled SGPRs)
+  asm volatile("" : "+s"(syb), "+s"(szb));
   const int offb = (DX) * 4 + (DY) * syb + (DZ) * szb;  // bytes
-  const unsigned mb = nb + static_cast<unsigned>(ok ? (FAR ? -offb : offb) : 0);
+  // ok: all ones where the partner exists, else 0 (lane masks as SGPR pairs, one per
+  // link, were a third of the kernel's spilled SGPRs)
+  const unsigned mb = nb + (static_cast<unsigned>(FAR ? -offb : offb) & ok);
   const float rest[3] = {dl.rest(DX, 0), dl.rest(DY, 1), dl.rest(DZ, 2)};
   const float o[3] = {ld_b(x0, mb), ld_b(x1, mb), ld_b(x2, mb)};
   float d[3];
@@ -812,6 +816,7 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
   const int sy = p.X, sz = p.X * p.Y;
   const int syb = sy * 4, szb = sz * 4;  // bytes
   const unsigned N = static_cast<unsigned>(p.N);
+  const unsigned Nb = N * 4u;  // bytes per component plane (3 N floats < 4 GB: plan_march3d)
   const float* __restrict__ x0 = x;
   const float* __restrict__ x1 = x + N;
   const float* __restrict__ x2 = x + 2 * (size_t)N;
@@ -859,10 +864,10 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
       float next[3] = {self[0], self[1], self[2]};
       if (act && sum) {
         float fin[4][3];  // links 0, 1, 3, 4
-        march_spring<1, 0, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp, self, fin[0]);
-        march_spring<0, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, yp, self, fin[1]);
-        march_spring<1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp && yp, self, fin[2]);
-        march_spring<-1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xm && yp, self, fin[3]);
+        march_spring<1, 0, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp, self, fin[0]);
+        march_spring<0, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kyp, self, fin[1]);
+        march_spring<1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kyp, self, fin[2]);
+        march_spring<-1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kyp, self, fin[3]);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -884,31 +889,18 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
           for (int c = 0; c < 3; ++c) d[c] = next[c] - self[c] + rest[c];
           spring_xyz<0, 0, 1>(d, dl.l0c[kc], dl.nkc[kc], PREFER ? 1 : 0, up[0]);
         }
-        march_spring<1, 0, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp && zp, self, up[1]);
-        march_spring<-1, 0, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xm && zp, self, up[2]);
-        march_spring<0, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, yp && zp, self, up[3]);
-        march_spring<0, -1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, ym && zp, self, up[4]);
-        march_spring<1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp && yp && zp, self, up[5]);
-        march_spring<1, 1, -1, true, PREFER>(x0, x1, x2, syb, szb, dl, nb, xm && ym && zp, self, up[6]);
-        march_spring<1, -1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xp && ym && zp, self, up[7]);
-        march_spring<-1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, xm && yp && zp, self, up[8]);
-        // a spring without partner counts as +0 on both sides
-        {
-          const unsigned k1 = kxp & kzp, k2 = kxm & kzp, k3 = kyp & kzp, k4 = kym & kzp;
-          const unsigned k5 = k1 & kyp, k6 = k2 & kym, k7 = k1 & kym, k8 = k2 & kyp;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            up[0][c] = keep_if(up[0][c], kzp);
-            up[1][c] = keep_if(up[1][c], k1);
-            up[2][c] = keep_if(up[2][c], k2);
-            up[3][c] = keep_if(up[3][c], k3);
-            up[4][c] = keep_if(up[4][c], k4);
-            up[5][c] = keep_if(up[5][c], k5);
-            up[6][c] = keep_if(up[6][c], k6);
-            up[7][c] = keep_if(up[7][c], k7);
-            up[8][c] = keep_if(up[8][c], k8);
-          }
-        }
+        march_spring<1, 0, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kzp, self, up[1]);
+        march_spring<-1, 0, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kzp, self, up[2]);
+        march_spring<0, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kyp & kzp, self, up[3]);
+        march_spring<0, -1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kym & kzp, self, up[4]);
+        march_spring<1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kyp & kzp, self, up[5]);
+        march_spring<1, 1, -1, true, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kym & kzp, self, up[6]);
+        march_spring<1, -1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kym & kzp, self, up[7]);
+        march_spring<-1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kyp & kzp, self, up[8]);
+        // A spring without partner was evaluated against the node itself: d = rest, l = l0,
+        // l0 / l = 1 exactly, force = k * 0 * d = +-0 (a NaN position gives NaN, which
+        // spring_xyz turns into 0) -- and subtracting +-0 from a sum that started at +0
+        // gives what subtracting the reference's +0 gives.  No mask on the near sides.
         if (core && sum) {
           float acc[3] = {0.f, 0.f, 0.f};
           // link by link: += the far side (owned by the node at n - off), -= the near side
@@ -917,13 +909,12 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
     acc[c] = acc[c] + (FAR_PTR)[c * T + (FAR_IDX)];                                      \
     acc[c] = acc[c] - (NEAR_EXPR);                                                      \
   }
-          const unsigned kxpyp = kxp & kyp, kxmyp = kxm & kyp;
           // clang-format off
-          SFM_TERM(P + 0 * 3 * T, tid - 1,     keep_if(P[(0 * 3 + c) * T + tid], kxp))    // 0  ( 1, 0, 0)
-          SFM_TERM(P + 1 * 3 * T, tid - W,     keep_if(P[(1 * 3 + c) * T + tid], kyp))    // 1  ( 0, 1, 0)
+          SFM_TERM(P + 0 * 3 * T, tid - 1,     P[(0 * 3 + c) * T + tid])    // 0  ( 1, 0, 0)
+          SFM_TERM(P + 1 * 3 * T, tid - W,     P[(1 * 3 + c) * T + tid])    // 1  ( 0, 1, 0)
           SFM_TERM(U + 0 * 3 * T, tid,         up[0][c])                   // 2  ( 0, 0, 1)
-          SFM_TERM(P + 2 * 3 * T, tid - 1 - W, keep_if(P[(2 * 3 + c) * T + tid], kxpyp))  // 3  ( 1, 1, 0)
-          SFM_TERM(P + 3 * 3 * T, tid + 1 - W, keep_if(P[(3 * 3 + c) * T + tid], kxmyp))  // 4  (-1, 1, 0)
+          SFM_TERM(P + 2 * 3 * T, tid - 1 - W, P[(2 * 3 + c) * T + tid])  // 3  ( 1, 1, 0)
+          SFM_TERM(P + 3 * 3 * T, tid + 1 - W, P[(3 * 3 + c) * T + tid])  // 4  (-1, 1, 0)
           SFM_TERM(U + 1 * 3 * T, tid - 1,     up[1][c])                   // 5  ( 1, 0, 1)
           SFM_TERM(U + 2 * 3 * T, tid + 1,     up[2][c])                   // 6  (-1, 0, 1)
           SFM_TERM(U + 3 * 3 * T, tid - W,     up[3][c])                   // 7  ( 0, 1, 1)
@@ -946,12 +937,12 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
           for (int c = 0; c < 3; ++c) {
             const float xv = self[c];
             float f = acc[c];
-            if (p.has_prev) f = f + prev_pull(xv, ld_b(prev + c * (size_t)N, nb), p.neg_k0, cap);
-            float* ac = a + c * (size_t)N;
-            float* vc = v + c * (size_t)N;
-            const float a_old = ld_b(ac, nb);
-            vn[c] = fact0 * (ld_b(vc, nb) * fact1 + hdt * (a_old + f));
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(ac) + nb) = f;
+            // one base pointer per array, the component in the 32-bit offset
+            const unsigned nbc = nb + c * Nb;
+            if (p.has_prev) f = f + prev_pull(xv, ld_b(prev, nbc), p.neg_k0, cap);
+            const float a_old = ld_b(a, nbc);
+            vn[c] = fact0 * (ld_b(v, nbc) * fact1 + hdt * (a_old + f));
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(a) + nbc) = f;
             acc[c] = f;
             a2 = a2 + f * f;
             v2 = v2 + vn[c] * vn[c];
@@ -971,7 +962,7 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
           }
 #pragma unroll
           for (int c = 0; c < 3; ++c)
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(v + c * (size_t)N) + nb) = vn[c];
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(v) + (nb + c * Nb)) = vn[c];
         }
       }
       __syncthreads();  // every read of P and U is done
