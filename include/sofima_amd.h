@@ -112,7 +112,7 @@ int sfm_device_count(int* count);
  *                         than the four launches per step it replaces, which stay the default)
  *   SFM_MESH_MARCH3D=0|1  default-link volumes (elastic_mesh_3d): the z-march integrator that
  *                         evaluates every spring once -- never / for every volume (default:
- *                         from 10^6 nodes on).  Forces bit-identical to the per-node kernel.
+ *                         from 1.5 * 10^6 nodes on).  Forces bit-identical to the per-node kernel.
  *   SFM_MESH_MARCH3D_T=256|512|1024 / SFM_MESH_MARCH3D_ZC=n
  *                         its workgroup size / planes per workgroup (default: planned per mesh)
  *   SFM_MESH_PACK=0       tiled in-plane step: a workgroup per tile also in a narrow last

@@ -39,9 +39,10 @@ constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 1024;
 // Volumes below this many nodes keep integrate_kernel<3>: a column of planes is a
 // serial chain of barriers, and a small volume has too few columns to fill the CUs
-// (measured: [3,1,64^3] 30 us per step against 48-60, [3,8,48^3] 85 against 79-85,
-// [3,4,100^3] 310 against 218, [3,1,160^3] 322 against 209).
-constexpr long long kMarch3dMinNodes = 1000000;
+// (per step, per-node kernel against z-march: [3,1,64^3] 28 us / 58, [3,8,48^3] 67 / 83,
+// [3,1,100^3] 76 / 88, [3,2,100^3] 131 / 115, [3,1,128^3] 138 / 111, [3,4,100^3] 252 / 212,
+// [3,1,160^3] 257 / 201: tools/measure/march3d_sizes.py).
+constexpr long long kMarch3dMinNodes = 1500000;
 // Minimum waves per SIMD the register allocator must leave room for
 // (__launch_bounds__ second argument).  Measured on [3,4,100^3] / [2,64,204^2]:
 // the volumetric stencil takes 180 VGPRs unconstrained (2 waves per SIMD, 369 us
@@ -373,50 +374,65 @@ struct DefLinks3 {
   }
 };
 
-// elastic_mesh_3d with the 13 default links (MESH_LINK_DIRECTIONS), unrolled
-// with compile-time directions and branch free: a spring whose other end lies
-// outside the mesh is evaluated against the node itself, which gives d = rest,
-// l = l0 and a force of exactly (+-)0.  Same per-link order as node_force_at:
-// += far end, -= near end (mesh.py:271-277).  26 independent chains instead of
-// 26 exec-masked blocks: the small 3-D meshes of a volumetric montage are
-// bound by this kernel's latency.
+// elastic_mesh_3d with the 13 default links (MESH_LINK_DIRECTIONS), unrolled with
+// compile-time directions and branch free.  Same per-link order as node_force_at:
+// += far end, -= near end (mesh.py:271-277).  26 independent chains instead of 26
+// exec-masked blocks: the small 3-D meshes of a volumetric montage are bound by this
+// kernel's latency.  (r4: class constants instead of 52 wave-uniform rest / k values:
+// spills 233 -> 119, [3,4,100^3] 334 -> 309 us per step.)
+// A spring whose other end lies outside the mesh is evaluated against the node
+// itself: d = rest, l = l0, l0 / l = 1 exactly, force = k * 0 * d = +-0 (a NaN position
+// gives NaN, which spring_xyz turns into 0); adding / subtracting that +-0 to a sum that
+// started at +0 gives what the reference's masked +0 gives -- no select.  The 26 "other
+// end exists" conditions are six VGPR words combined with v_and and AND-ed into the
+// partner offset (as booleans they were SGPR pairs, most of the spilled SGPRs).
+// Offsets are 32-bit bytes: build_params routes a mesh whose three component planes
+// exceed 4 GB to the generic link loop (node_force_at).
 __device__ __forceinline__ void node_force_default3d(const float* __restrict__ x,
-                                                     const MeshParams& p, long long n,
-                                                     int xi, int yi, int zi,
-                                                     const float* self, float* out) {
+                                                        const MeshParams& p, unsigned n,
+                                                        int xi, int yi, int zi,
+                                                        const float* self, float* out) {
   float acc[3] = {0.f, 0.f, 0.f};
-  const long long sy = p.X, sz = (long long)p.X * p.Y;
-  // (spills 233 -> 119, [3,4,100^3] 334 -> 309 us per step.  A further
-  // instantiation without the other force kinds got the spills to 75 but 108
-  // bytes of scratch: 390 us.)
+  const int syb = p.X * 4, szb = p.X * p.Y * 4;
+  const unsigned Nb = static_cast<unsigned>(p.N) * 4u;
+  const unsigned nb = n * 4u;
+  const unsigned kxm = xi > 0 ? ~0u : 0u, kxp = xi + 1 < p.X ? ~0u : 0u;
+  const unsigned kym = yi > 0 ? ~0u : 0u, kyp = yi + 1 < p.Y ? ~0u : 0u;
+  const unsigned kzm = zi > 0 ? ~0u : 0u, kzp = zi + 1 < p.Z ? ~0u : 0u;
   const DefLinks3 dl(p);
-#define SFM_LINK(L, DX, DY, DZ)                                                      \
+  auto ld = [&](unsigned b) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + b);
+  };
+#define SFM_LINK(DX, DY, DZ)                                                        \
   {                                                                                  \
     constexpr int kc = SFM_CLASS3(DX, DY, DZ);                                       \
     const float l0 = dl.l0c[kc];                                                     \
     const float rest[3] = {dl.rest(DX, 0), dl.rest(DY, 1), dl.rest(DZ, 2)};          \
-    const bool okf = xi - (DX) >= 0 && xi - (DX) < p.X && yi - (DY) >= 0 &&          \
-                     yi - (DY) < p.Y && zi - (DZ) >= 0 && zi - (DZ) < p.Z;            \
-    const bool okn = xi + (DX) >= 0 && xi + (DX) < p.X && yi + (DY) >= 0 &&          \
-                     yi + (DY) < p.Y && zi + (DZ) >= 0 && zi + (DZ) < p.Z;            \
-    const long long off = (DX) + (DY) * sy + (DZ) * sz;                              \
-    const long long mf = okf ? n - off : n, mn = okn ? n + off : n;                  \
+    /* the far end exists where the node has a neighbour at -dir, the near end at +dir */ \
+    const unsigned kn = ((DX) > 0 ? kxp : (DX) < 0 ? kxm : ~0u) &                    \
+                        ((DY) > 0 ? kyp : (DY) < 0 ? kym : ~0u) &                    \
+                        ((DZ) > 0 ? kzp : (DZ) < 0 ? kzm : ~0u);                     \
+    const unsigned kf = ((DX) > 0 ? kxm : (DX) < 0 ? kxp : ~0u) &                    \
+                        ((DY) > 0 ? kym : (DY) < 0 ? kyp : ~0u) &                    \
+                        ((DZ) > 0 ? kzm : (DZ) < 0 ? kzp : ~0u);                     \
+    const unsigned off = static_cast<unsigned>((DX) * 4 + (DY) * syb + (DZ) * szb);  \
+    const unsigned mf = nb - (off & kf), mn = nb + (off & kn);                       \
     float df[3], dn[3], ff[3], fn[3];                                                \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                  \
-      df[c] = self[c] - x[c * p.N + mf] + rest[c];                                   \
-      dn[c] = x[c * p.N + mn] - self[c] + rest[c];                                   \
+      df[c] = self[c] - ld(mf + c * Nb) + rest[c];                                   \
+      dn[c] = ld(mn + c * Nb) - self[c] + rest[c];                                   \
     }                                                                                \
     spring_xyz<DX, DY, DZ>(df, l0, dl.nkc[kc], p.prefer, ff);                        \
     spring_xyz<DX, DY, DZ>(dn, l0, dl.nkc[kc], p.prefer, fn);                        \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                  \
-      acc[c] = acc[c] + (okf ? ff[c] : 0.f);                                         \
-      acc[c] = acc[c] - (okn ? fn[c] : 0.f);                                         \
+      acc[c] = acc[c] + ff[c];                                                       \
+      acc[c] = acc[c] - fn[c];                                                       \
     }                                                                                \
   }
-  SFM_LINK(0, 1, 0, 0) SFM_LINK(1, 0, 1, 0) SFM_LINK(2, 0, 0, 1) SFM_LINK(3, 1, 1, 0)
-  SFM_LINK(4, -1, 1, 0) SFM_LINK(5, 1, 0, 1) SFM_LINK(6, -1, 0, 1) SFM_LINK(7, 0, 1, 1)
-  SFM_LINK(8, 0, -1, 1) SFM_LINK(9, 1, 1, 1) SFM_LINK(10, 1, 1, -1) SFM_LINK(11, 1, -1, 1)
-  SFM_LINK(12, -1, 1, 1)
+  SFM_LINK(1, 0, 0) SFM_LINK(0, 1, 0) SFM_LINK(0, 0, 1) SFM_LINK(1, 1, 0)
+  SFM_LINK(-1, 1, 0) SFM_LINK(1, 0, 1) SFM_LINK(-1, 0, 1) SFM_LINK(0, 1, 1)
+  SFM_LINK(0, -1, 1) SFM_LINK(1, 1, 1) SFM_LINK(1, 1, -1) SFM_LINK(1, -1, 1)
+  SFM_LINK(-1, 1, 1)
 #undef SFM_LINK
   out[0] = acc[0];
   out[1] = acc[1];
@@ -487,7 +503,7 @@ __device__ void node_force(const float* __restrict__ x, const MeshParams& p,
 #pragma unroll
   for (int c = 0; c < C; ++c) self[c] = x[c * p.N + n];
   if (C == 3 && p.default_links) {
-    node_force_default3d(x, p, n, xi, yi, zi, self, out);
+    node_force_default3d(x, p, static_cast<unsigned>(n), xi, yi, zi, self, out);
     return;
   }
   node_force_at<C>(
@@ -3384,7 +3400,9 @@ int build_params(const SfmMeshDesc* d, MeshParams* p) {
     }
   } else {
     p->n_links = d->n_links > 0 ? d->n_links : 13;
-    p->default_links = d->n_links == 0;
+    // (the unrolled default-link stencil and the z-march kernel use 32-bit byte offsets
+    // over the three component planes; a mesh beyond 4 GB takes the generic link loop)
+    p->default_links = d->n_links == 0 && (unsigned long long)p->N * 12ull < (1ull << 32);
     if (p->n_links > SFM_MESH_MAX_LINKS)
       return sfm::fail(SFM_ERR_INVALID, "too many links: %d", p->n_links);
     for (int L = 0; L < p->n_links; ++L) {

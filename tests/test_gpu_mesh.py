@@ -892,12 +892,12 @@ def test_march3d_fire_vs_oracle(gpu, shape):
 
 @pytest.mark.gpu
 def test_march3d_is_the_default_for_large_volumes(gpu):
-  """From 10^6 nodes on a default-link volume takes the z-march kernel without any
+  """From 1.5 * 10^6 nodes on a default-link volume takes the z-march kernel without any
   switch (the kernel trace under profiles/ names it): same damped-Verlet chunk as
   with SFM_MESH_MARCH3D=0."""
   import torch
   from sofima_amd import _abi, mesh
-  shape = (3, 2, 80, 80, 80)
+  shape = (3, 2, 100, 100, 100)
   rng = np.random.default_rng(2)
   dev = torch.device('cuda:0')
   x0 = torch.from_numpy((rng.standard_normal(shape) * 2).astype(np.float32)).to(dev)
