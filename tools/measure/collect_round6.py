@@ -29,6 +29,7 @@ parts = [('mesh_time', 'mesh_time.log'), ('montage_time', 'montage_time.log'),
          ('search_window_rates', 'search_window_rates.txt'),
          ('march3d (integrate_kernel<3> against integrate_march3d_kernel, auto plan)',
           'march3d_trace_summary.txt'),
+         ('march3d_sizes (per-node kernel against z-march over volume sizes)', 'march3d_sizes.txt'),
          ('pytest -m gpu', 'pytest.log')]
 with open(os.path.join(P, 'r06_other_times.txt'), 'w') as f:
   f.write('# r06 other timings, build %s\n' % sha)
