@@ -912,3 +912,45 @@ def test_march3d_is_the_default_for_large_volumes(gpu):
     want = run()
   for w, g in zip(want, got):
     np.testing.assert_array_equal(w, g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 2, 9, 33, 17), (3, 1, 1, 12, 40), (3, 1, 6, 1, 7)])
+def test_forces_3d_with_nan_and_inf_positions_vs_oracle(gpu, shape):
+  """elastic_mesh_3d on positions holding NaN and +-inf, also on the faces, edges and
+  corners of the volume (mesh.py:192-279: every spring component passes through
+  nan_to_num(posinf=0, neginf=0)).  The HIP stencil evaluates a missing neighbour
+  against the node itself and adds the resulting +-0 without a select: a non-finite
+  position there must still give what the reference's masked 0 gives.  Both kernels
+  (per node / z-march through one damped-Verlet step) against the oracle."""
+  from sofima_amd import _abi, mesh
+  rng = np.random.default_rng(13)
+  x = (rng.standard_normal(shape) * 3).astype(np.float32)
+  flat = x.reshape(3, -1)
+  n = flat.shape[1]
+  for k, bad in enumerate((np.nan, np.inf, -np.inf)):
+    idx = rng.integers(0, n, max(2, n // 40))
+    flat[rng.integers(0, 3, idx.size), idx] = bad
+  # corners and face centres of the first volume
+  vol = x.reshape((3, -1) + shape[-3:])
+  vol[0, 0, 0, 0, 0] = np.nan
+  vol[1, 0, -1, -1, -1] = np.inf
+  vol[2, 0, 0, -1, 0] = -np.inf
+  for poo in (False, True):
+    got = np.array(mesh.elastic_mesh_3d(x, 0.1, (40.0, 40.0, 30.0), poo))
+    want = mesh_oracle.elastic_mesh_3d(x, 0.1, (40.0, 40.0, 30.0), poo)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got == 0, want == 0)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
+  # the z-march kernel adds the same floats: one Verlet step from these positions
+  cfg = mesh.IntegrationConfig(dt=0.05, gamma=0.5, k0=0.05, k=0.1, stride=(40.0, 40.0, 30.0),
+                               num_iters=1, max_iters=1, stop_v_max=1e-9, dt_max=100,
+                               start_cap=10.0, final_cap=10.0, fire=False)
+  run = lambda: [np.array(t) for t in mesh.velocity_verlet(
+      x, np.zeros_like(x), None, cfg, cfg.start_cap, mesh_force=mesh.elastic_mesh_3d)]
+  with _abi.option('SFM_MESH_MARCH3D', 0):
+    a = run()
+  with _abi.option('SFM_MESH_MARCH3D', 1):
+    b = run()
+  for u, w in zip(a, b):
+    np.testing.assert_array_equal(u, w)

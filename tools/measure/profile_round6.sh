@@ -54,7 +54,7 @@ timeout 300 python $R/tools/measure/pipe_ab.py time 10 2>&1 | grep -v amdgpu > $
 MARCH_SHAPES=0,1 MARCH_T=0 bash $R/tools/measure/march3d_trace.sh > /dev/null 2>&1; cp $R/gpurun_out/march3d_trace_summary.txt $O/march3d_trace_summary.txt
 python $R/tools/measure/march3d_sizes.py 2>&1 | grep -v amdgpu > $O/march3d_sizes.txt
 cd /tmp
-(timeout 400 python $R/tools/measure/soak.py 200; timeout 200 python $R/tools/measure/prune_fuzz.py 120) 2>&1 | grep -v amdgpu > $O/soak_fuzz.log
+(timeout 400 python $R/tools/measure/soak.py 200; timeout 200 python $R/tools/measure/prune_fuzz.py 120; timeout 200 python $R/tools/measure/march3d_fuzz.py 60) 2>&1 | grep -v amdgpu > $O/soak_fuzz.log
 cd /tmp; MASK_CASE="blobs r=130" timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_masked -o t -- python $R/tools/measure/masked_time.py > $O/trace_masked.log 2>&1
 python $R/tools/rocpd_summary.py $(find $O/trace_masked -name '*.db' | head -1) > $O/trace_masked_summary.md 2>&1
 find $O -name '*.db' -delete; find $O -name '*.csv' -size +5M -delete; rm -rf $O/trace_masked $R/gpurun_out/pmc_aux
