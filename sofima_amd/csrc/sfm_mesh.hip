@@ -39,9 +39,9 @@ constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 1024;
 // Volumes below this many nodes keep integrate_kernel<3>: a column of planes is a
 // serial chain of barriers, and a small volume has too few columns to fill the CUs
-// (per step, per-node kernel against z-march: [3,1,64^3] 28 us / 58, [3,8,48^3] 67 / 83,
-// [3,1,100^3] 76 / 88, [3,2,100^3] 131 / 115, [3,1,128^3] 138 / 111, [3,4,100^3] 252 / 212,
-// [3,1,160^3] 257 / 201: tools/measure/march3d_sizes.py).
+// (per step, per-node kernel against z-march: [3,1,64^3] 28 us / 55, [3,8,48^3] 66 / 78,
+// [3,1,100^3] 75 / 80, [3,2,100^3] 132 / 106, [3,1,128^3] 137 / 110, [3,4,100^3] 251 / 185,
+// [3,1,160^3] 257 / 183: tools/measure/march3d_sizes.py).
 constexpr long long kMarch3dMinNodes = 1500000;
 // Minimum waves per SIMD the register allocator must leave room for
 // (__launch_bounds__ second argument).  Measured on [3,4,100^3] / [2,64,204^2]:
@@ -723,27 +723,32 @@ integrate_kernel(const float* __restrict__ x, float* __restrict__ v,
 //   near side of o : d = x[o + off] - x[o] + rest  (dn at node o)
 // so the owner of a spring can publish the force and the other end can read it.
 // Here a workgroup owns a column of the volume -- a tile of the (y, x) plane, T
-// threads = tile positions INCLUDING one halo ring where a neighbour tile exists --
-// and marches along z.  A node (thread) owns the 13 springs that stay in its plane
-// or go UP:
-//   links 0, 1, 3, 4            (dz = 0)   near form, partner in the same plane
-//   links 2, 5-9, 11, 12        (dz = +1)  near form, partner in plane z + 1
-//   link 10 = (1, 1, -1)                   FAR form at the lower end: the node at
-//                                          (x, y, z) owns the spring to (x-1, y-1, z+1)
-// so every owned spring needs the positions of planes z and z + 1 only.  The four
-// in-plane forces go to LDS (`P`, read by the partners after one barrier), the nine
-// upward ones to LDS (`U`, read by the nodes of the NEXT plane), and a node adds its 26
-// terms in the reference's link order (mesh.py:271-277: += far side, -= near side,
-// link by link) from its own registers, P and U: the same floats in the same order as
+// threads = tile positions INCLUDING a halo (one column on each side, one row on top)
+// -- and marches along z.  In iteration z a thread holds its node of plane z (`self`)
+// and of plane z + 1 (`next`) and owns 13 springs, every one between planes z / z + 1
+// or inside plane z, chosen so that a reader finds its owner in its own tile row or the
+// row above (offsets (-1,0), (+1,0), (0,-1), (-1,-1), (+1,-1): no halo row below):
+//   links 0, 1, 3, 4       (dz = 0)   near form at `self`, partner in plane z
+//                                     -> LDS `P`, read by the partner in this iteration
+//   links 2, 5, 6, 7, 9, 12 (dz = +1) near form at `self`, partner in plane z + 1
+//                                     -> LDS `U` (link 2: a register), read by the partner
+//                                     in the NEXT iteration
+//   links 8 = (0,-1,1), 11 = (1,-1,1): FAR form at `next` (the upper end), partner
+//   link 10 = (1,1,-1):                near form at `next`,  in plane z at (., y+1)
+//                                     -> LDS `P` for the partner (this iteration) and a
+//                                     register for this thread's own node of plane z + 1
+// so every owned spring needs the positions of planes z and z + 1 only, and a node adds
+// its 26 terms in the reference's link order (mesh.py:271-277: += far side, -= near
+// side, link by link) from registers, P and U: the same floats in the same order as
 // node_force_default3d -- `a` and (without FIRE) every later state are bit-identical.
 // The FIRE sums are added in a different order (a thread's column, then the
 // workgroup tree) like those of the tiled in-plane integrator.
 // Halo threads evaluate their springs (a value any tile computes is the same float)
-// and take no part in the sums; a chunk of planes starts with one extra plane that
-// only produces U.  LDS: 39 floats per thread.
+// and take no part in the sums; a run of planes starts with one extra plane that only
+// produces U and the registers.  LDS: 36 floats per thread.
 // ---------------------------------------------------------------------------
 struct March3dArgs {
-  int txh, tyh;   // thread tile, the halo ring included (core = txh - 2 by tyh - 2)
+  int txh, tyh;   // thread tile, the halo included (core = txh - 2 by tyh - 1)
   int ntx, nty;   // tiles per plane
   int cols;       // columns = B * nty * ntx
   int run;        // planes per workgroup: workgroup w owns planes [w * run, (w + 1) * run)
@@ -801,6 +806,27 @@ __device__ __forceinline__ float keep_if(float v, unsigned mask) {
 #ifndef SFM_MARCH_LB
 #define SFM_MARCH_LB(T) 4  // waves per SIMD: 1, 2, 4 workgroups of 1024, 512, 256 per CU
 #endif
+// A spring owned through the node of the NEXT plane (links 8, 10, 11, see the kernel):
+// `next` is that node's position, the partner lies in plane z at byte offset offb from
+// this column's plane-z node; a missing partner is replaced by the next-plane node itself
+// (d = rest).  FAR: d = next - o + rest, else d = o - next + rest.
+template <int DX, int DY, int DZ, bool FAR, bool PREFER>
+__device__ __forceinline__ void march_spring_up(const float* __restrict__ x0,
+                                                const float* __restrict__ x1,
+                                                const float* __restrict__ x2, int offb, int szb,
+                                                const DefLinks3& dl, unsigned nb, unsigned ok,
+                                                const float* next, float* f) {
+  constexpr int kc = SFM_CLASS3(DX, DY, DZ);
+  asm volatile("" : "+s"(offb), "+s"(szb));  // (formed at its use, see march_spring)
+  const unsigned mb = nb + static_cast<unsigned>(szb) + (static_cast<unsigned>(offb - szb) & ok);
+  const float rest[3] = {dl.rest(DX, 0), dl.rest(DY, 1), dl.rest(DZ, 2)};
+  const float o[3] = {ld_b(x0, mb), ld_b(x1, mb), ld_b(x2, mb)};
+  float d[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d[c] = FAR ? next[c] - o[c] + rest[c] : o[c] - next[c] + rest[c];
+  spring_xyz<DX, DY, DZ>(d, dl.l0c[kc], dl.nkc[kc], PREFER ? 1 : 0, f);
+}
+
 template <int T, bool PREFER>
 __global__ void __launch_bounds__(T, SFM_MARCH_LB(T))
 integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
@@ -808,8 +834,11 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
                          MeshParams p, const Scalars* __restrict__ scal,
                          float fixed_cap, float* __restrict__ partials, March3dArgs g) {
   extern __shared__ float march_lds[];
-  float* P = march_lds;           // [4 links][3][T]  in-plane forces of this plane
-  float* U = march_lds + 12 * T;  // [9 links][3][T]  upward forces of the plane below
+  // P: forces exchanged inside an iteration -- links 0, 1, 3, 4 of plane z and links 8,
+  // 10, 11 between planes z and z + 1 (slots 4, 5, 6); U: links 5, 6, 7, 9, 12 of the
+  // plane below, for the next iteration.
+  float* P = march_lds;           // [7][3][T]
+  float* U = march_lds + 21 * T;  // [5][3][T]
   const int tid = threadIdx.x;
   float dt, alpha, cap;
   if (p.fire) {
@@ -828,7 +857,7 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
   const DefLinks3 dl(p);
   const int W = g.txh;
   const int tx = tid % W, ty = tid / W;
-  const int cxw = g.txh - 2, cyw = g.tyh - 2;
+  const int cxw = g.txh - 2, cyw = g.tyh - 1;  // halo: one column each side, one row on top
   const int sy = p.X, sz = p.X * p.Y;
   const int syb = sy * 4, szb = sz * 4;  // bytes
   const unsigned N = static_cast<unsigned>(p.N);
@@ -851,12 +880,11 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
     const int b = r / g.nty;
     const int xi = tix * cxw - 1 + tx, yi = tiy * cyw - 1 + ty;
     const bool act = ty < g.tyh && xi >= 0 && xi < p.X && yi >= 0 && yi < p.Y;
-    const bool core = act && tx >= 1 && tx < g.txh - 1 && ty >= 1 && ty < g.tyh - 1;
+    const bool core = act && tx >= 1 && tx < g.txh - 1 && ty >= 1;
     const bool own = yi >= p.own_y0 && yi < p.own_y1;
-    const bool xm = xi > 0, xp = xi + 1 < p.X, ym = yi > 0, yp = yi + 1 < p.Y;
-    // the near side of a link counts where its partner exists
-    const unsigned kxp = xp ? ~0u : 0u, kxm = xm ? ~0u : 0u, kyp = yp ? ~0u : 0u,
-                   kym = ym ? ~0u : 0u;
+    // all ones where the neighbour in that direction exists
+    const unsigned kxp = xi + 1 < p.X ? ~0u : 0u, kxm = xi > 0 ? ~0u : 0u;
+    const unsigned kyp = yi + 1 < p.Y ? ~0u : 0u, kym = yi > 0 ? ~0u : 0u;
     int z = z0 > 0 ? z0 - 1 : 0;
     unsigned n = act ? static_cast<unsigned>(xi + sy * yi) + static_cast<unsigned>(sz) *
                            static_cast<unsigned>(b * p.Z + z)
@@ -868,34 +896,56 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
       self[1] = ld_b(x1, nb);
       self[2] = ld_b(x2, nb);
     }
-    // A slot nobody owns (outside the mesh) and, at the bottom of the volume, the
-    // plane below read as +0: the far side of a link whose owner does not exist.
+    // forces this thread computed one iteration ago for what is now its node: the far
+    // sides of links 2, 8, 11 and the near side of link 10 (+0 at the bottom of the volume)
+    float c2[3] = {0.f, 0.f, 0.f}, c8[3] = {0.f, 0.f, 0.f}, c10[3] = {0.f, 0.f, 0.f},
+          c11[3] = {0.f, 0.f, 0.f};
+    // A slot nobody owns (outside the mesh) reads as +0: the side of a link whose owner
+    // does not exist; so does the plane below the volume.
 #pragma unroll
-    for (int k = 0; k < 39; ++k) march_lds[k * T + tid] = 0.f;
+    for (int k = 0; k < 36; ++k) march_lds[k * T + tid] = 0.f;
     for (; z < z1; ++z, n += sz, nb += szb) {
       const bool zp = z + 1 < p.Z;
       const unsigned kzp = zp ? ~0u : 0u;
       const bool sum = z >= z0;
-      float up[9][3];   // links 2, 5, 6, 7, 8, 9, 10 (far form), 11, 12
       float next[3] = {self[0], self[1], self[2]};
-      if (act && sum) {
-        float fin[4][3];  // links 0, 1, 3, 4
-        march_spring<1, 0, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp, self, fin[0]);
-        march_spring<0, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kyp, self, fin[1]);
-        march_spring<1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kyp, self, fin[2]);
-        march_spring<-1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kyp, self, fin[3]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) P[(k * 3 + c) * T + tid] = fin[k][c];
-      }
-      __syncthreads();  // P of this plane; U of the plane below
+      float q8[3] = {0.f, 0.f, 0.f}, q10[3] = {0.f, 0.f, 0.f}, q11[3] = {0.f, 0.f, 0.f};
       if (act) {
         if (zp) {
           next[0] = ld_b(x0, nb + szb);
           next[1] = ld_b(x1, nb + szb);
           next[2] = ld_b(x2, nb + szb);
+          // links that reach DOWN in y are owned through their upper end, this column's
+          // node of plane z + 1, so that every reader finds its owner in its own row or the
+          // row above (no halo row below the tile):
+          //   8  ( 0,-1, 1): far form at `next`, partner (x, y+1) of plane z
+          //   10 ( 1, 1,-1): near form at `next`, partner (x+1, y+1) of plane z
+          //   11 ( 1,-1, 1): far form at `next`, partner (x-1, y+1) of plane z
+          march_spring_up<0, -1, 1, true, PREFER>(x0, x1, x2, syb, szb, dl, nb, kyp, next, q8);
+          march_spring_up<1, 1, -1, false, PREFER>(x0, x1, x2, 4 + syb, szb, dl, nb, kxp & kyp, next, q10);
+          march_spring_up<1, -1, 1, true, PREFER>(x0, x1, x2, syb - 4, szb, dl, nb, kxm & kyp, next, q11);
         }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          P[(4 * 3 + c) * T + tid] = q8[c];
+          P[(5 * 3 + c) * T + tid] = q10[c];
+          P[(6 * 3 + c) * T + tid] = q11[c];
+        }
+        if (sum) {
+          float fin[4][3];  // links 0, 1, 3, 4
+          march_spring<1, 0, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp, self, fin[0]);
+          march_spring<0, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kyp, self, fin[1]);
+          march_spring<1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kyp, self, fin[2]);
+          march_spring<-1, 1, 0, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kyp, self, fin[3]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) P[(k * 3 + c) * T + tid] = fin[k][c];
+        }
+      }
+      __syncthreads();  // P of this iteration; U of the plane below
+      float up[6][3];   // links 2, 5, 6, 7, 9, 12 (near form)
+      if (act) {
         {
           // link 2: the partner is this column's next node
           constexpr int kc = SFM_CLASS3(0, 0, 1);
@@ -908,44 +958,40 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
         march_spring<1, 0, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kzp, self, up[1]);
         march_spring<-1, 0, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kzp, self, up[2]);
         march_spring<0, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kyp & kzp, self, up[3]);
-        march_spring<0, -1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kym & kzp, self, up[4]);
-        march_spring<1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kyp & kzp, self, up[5]);
-        march_spring<1, 1, -1, true, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kym & kzp, self, up[6]);
-        march_spring<1, -1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kym & kzp, self, up[7]);
-        march_spring<-1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kyp & kzp, self, up[8]);
+        march_spring<1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxp & kyp & kzp, self, up[4]);
+        march_spring<-1, 1, 1, false, PREFER>(x0, x1, x2, syb, szb, dl, nb, kxm & kyp & kzp, self, up[5]);
         // A spring without partner was evaluated against the node itself: d = rest, l = l0,
         // l0 / l = 1 exactly, force = k * 0 * d = +-0 (a NaN position gives NaN, which
         // spring_xyz turns into 0) -- and subtracting +-0 from a sum that started at +0
         // gives what subtracting the reference's +0 gives.  No mask on the near sides.
         if (core && sum) {
           float acc[3] = {0.f, 0.f, 0.f};
-          // link by link: += the far side (owned by the node at n - off), -= the near side
-#define SFM_TERM(FAR_PTR, FAR_IDX, NEAR_EXPR)                                            \
+          // link by link: += the far side, -= the near side (mesh.py:271-277)
+#define SFM_TERM(FAR_EXPR, NEAR_EXPR)                                                     \
   _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                       \
-    acc[c] = acc[c] + (FAR_PTR)[c * T + (FAR_IDX)];                                      \
+    acc[c] = acc[c] + (FAR_EXPR);                                                       \
     acc[c] = acc[c] - (NEAR_EXPR);                                                      \
   }
+#define SFM_P(K, IDX) P[((K) * 3 + c) * T + (IDX)]
+#define SFM_U(K, IDX) U[((K) * 3 + c) * T + (IDX)]
           // clang-format off
-          SFM_TERM(P + 0 * 3 * T, tid - 1,     P[(0 * 3 + c) * T + tid])    // 0  ( 1, 0, 0)
-          SFM_TERM(P + 1 * 3 * T, tid - W,     P[(1 * 3 + c) * T + tid])    // 1  ( 0, 1, 0)
-          SFM_TERM(U + 0 * 3 * T, tid,         up[0][c])                   // 2  ( 0, 0, 1)
-          SFM_TERM(P + 2 * 3 * T, tid - 1 - W, P[(2 * 3 + c) * T + tid])  // 3  ( 1, 1, 0)
-          SFM_TERM(P + 3 * 3 * T, tid + 1 - W, P[(3 * 3 + c) * T + tid])  // 4  (-1, 1, 0)
-          SFM_TERM(U + 1 * 3 * T, tid - 1,     up[1][c])                   // 5  ( 1, 0, 1)
-          SFM_TERM(U + 2 * 3 * T, tid + 1,     up[2][c])                   // 6  (-1, 0, 1)
-          SFM_TERM(U + 3 * 3 * T, tid - W,     up[3][c])                   // 7  ( 0, 1, 1)
-          SFM_TERM(U + 4 * 3 * T, tid + W,     up[4][c])                   // 8  ( 0,-1, 1)
-          SFM_TERM(U + 5 * 3 * T, tid - 1 - W, up[5][c])                   // 9  ( 1, 1, 1)
-          // 10 ( 1, 1,-1): the far side is this node's own far-form spring, the near
-          // side is owned by the node at (x+1, y+1) of the plane below
-          _Pragma("unroll") for (int c = 0; c < 3; ++c) {
-            acc[c] = acc[c] + up[6][c];
-            acc[c] = acc[c] - U[(6 * 3 + c) * T + tid + 1 + W];
-          }
-          SFM_TERM(U + 7 * 3 * T, tid - 1 + W, up[7][c])                   // 11 ( 1,-1, 1)
-          SFM_TERM(U + 8 * 3 * T, tid + 1 - W, up[8][c])                   // 12 (-1, 1, 1)
+          SFM_TERM(SFM_P(0, tid - 1),     SFM_P(0, tid))      // 0  ( 1, 0, 0)
+          SFM_TERM(SFM_P(1, tid - W),     SFM_P(1, tid))      // 1  ( 0, 1, 0)
+          SFM_TERM(c2[c],                 up[0][c])           // 2  ( 0, 0, 1)
+          SFM_TERM(SFM_P(2, tid - 1 - W), SFM_P(2, tid))      // 3  ( 1, 1, 0)
+          SFM_TERM(SFM_P(3, tid + 1 - W), SFM_P(3, tid))      // 4  (-1, 1, 0)
+          SFM_TERM(SFM_U(0, tid - 1),     up[1][c])           // 5  ( 1, 0, 1)
+          SFM_TERM(SFM_U(1, tid + 1),     up[2][c])           // 6  (-1, 0, 1)
+          SFM_TERM(SFM_U(2, tid - W),     up[3][c])           // 7  ( 0, 1, 1)
+          SFM_TERM(c8[c],                 SFM_P(4, tid - W))  // 8  ( 0,-1, 1)
+          SFM_TERM(SFM_U(3, tid - 1 - W), up[4][c])           // 9  ( 1, 1, 1)
+          SFM_TERM(SFM_P(5, tid - 1 - W), c10[c])             // 10 ( 1, 1,-1)
+          SFM_TERM(c11[c],                SFM_P(6, tid + 1 - W))  // 11 ( 1,-1, 1)
+          SFM_TERM(SFM_U(4, tid + 1 - W), up[5][c])           // 12 (-1, 1, 1)
           // clang-format on
 #undef SFM_TERM
+#undef SFM_P
+#undef SFM_U
           // ---- integrate_kernel's node update ----
           float vn[3];
           float a2 = 0.f, v2 = 0.f;
@@ -984,9 +1030,16 @@ integrate_march3d_kernel(const float* __restrict__ x, float* __restrict__ v,
       __syncthreads();  // every read of P and U is done
       if (act) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
+        for (int k = 0; k < 5; ++k)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) U[(k * 3 + c) * T + tid] = up[k][c];
+          for (int c = 0; c < 3; ++c) U[(k * 3 + c) * T + tid] = up[k + 1][c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          c2[c] = up[0][c];
+          c8[c] = q8[c];
+          c10[c] = q10[c];
+          c11[c] = q11[c];
+        }
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) self[c] = next[c];
@@ -3494,9 +3547,9 @@ March3dPlan plan_march3d(const MeshParams& p) {
       const int cxw = (p.X + ntx - 1) / ntx;
       const int txh = cxw + 2;
       if (txh * 3 > T) continue;
-      const int rows = T / txh;  // >= 3
-      const int nty = (p.Y + rows - 3) / (rows - 2);
-      const int tyh = (p.Y + nty - 1) / nty + 2;
+      const int rows = T / txh;  // >= 3; one halo row (on top) per tile
+      const int nty = (p.Y + rows - 2) / (rows - 1);
+      const int tyh = (p.Y + nty - 1) / nty + 1;
       // thread slots per plane; 16 waves in step at every barrier cost ~15 % against
       // two workgroups of 8 (measured on [3,4,100^3]: 180 us with 12 288 slots per plane
       // against 176 with 13 824)
@@ -3513,7 +3566,7 @@ March3dPlan plan_march3d(const MeshParams& p) {
     }
   }
   if (best.T == 0) return best;
-  best.lds = (size_t)39 * best.T * sizeof(float);
+  best.lds = (size_t)36 * best.T * sizeof(float);
   const int per_cu = std::max<int>(1, static_cast<int>(160 * 1024 / best.lds));
   const long long cols = (long long)p.B * best.g.ntx * best.g.nty;
   if (cols > 0x7fffffffLL / std::max(p.Z, 1)) {
@@ -3542,7 +3595,7 @@ int launch_march3d_t(const March3dPlan& m, hipStream_t st, const float* x, float
   if (!attr_set) {
     SFM_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&integrate_march3d_kernel<T, PREFER>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 39 * T * static_cast<int>(sizeof(float))));
+        hipFuncAttributeMaxDynamicSharedMemorySize, 36 * T * static_cast<int>(sizeof(float))));
     attr_set = true;
   }
   hipLaunchKernelGGL((integrate_march3d_kernel<T, PREFER>), dim3(m.grid), dim3(T), m.lds, st, x,
