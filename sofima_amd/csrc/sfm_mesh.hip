@@ -625,6 +625,7 @@ advance_kernel(float* __restrict__ x, float* __restrict__ v,
   }
   const float dt = s.dt;
   const float c2 = 0.5f * (dt * dt);
+  const bool store_v = s.gate != 1.f || p.drift_cols || p.remove_drift;
   for (long long n = blockIdx.x * (long long)kBlock + threadIdx.x; n < p.N;
        n += (long long)gridDim.x * kBlock) {
 #pragma unroll
@@ -641,7 +642,9 @@ advance_kernel(float* __restrict__ x, float* __restrict__ v,
           xv = xv - s.mx[c];
           vv = vv - s.mv[c];
         }
-        v[c * p.N + n] = vv;
+        // a downhill step without drift removal leaves v as it is (v * 1 = v): no store
+        // (12 of the kernel's 60 bytes per node)
+        if (store_v) v[c * p.N + n] = vv;
       }
       x[c * p.N + n] = xv + (dt * vv + c2 * a[c * p.N + n]);
     }
